@@ -1,0 +1,1118 @@
+// ba.hip — Levenberg–Marquardt Schur-complement bundle adjustment on MI355X (gfx950), f64.
+//
+// Replaces what Optimizer::{BundleAdjustmentClient, LocalBundleAdjustmentClient, MapFusionGBA}
+// (cslam/src/Optimizer.cpp:40-212, 349-644, 646-859) hand to g2o: BlockSolver_6_3 +
+// OptimizationAlgorithmLevenberg over EdgeSE3ProjectXYZ edges with a Huber kernel
+// (g2o/core/block_solver.hpp:354-604, optimization_algorithm_levenberg.cpp:61-189,
+//  types/types_six_dof_expmap.cpp:103-147, core/robust_kernel_impl.cpp:78-90).
+//
+// MI355X design (not a translation of g2o's pointer graph):
+//  * problem flattened to SoA buffers resident in HBM; edges sorted by landmark so that the
+//    landmark-side work (Hll, b_l, D^-1, back-substitution, chi2) is one thread per landmark over
+//    a contiguous edge range, and a per-camera edge list drives the camera-side work (Hpp, b_p,
+//    diagonal Schur blocks, b_schur) with one wave per camera and a wave reduction — no atomics,
+//    so every sum has a fixed order and the solver is bit-reproducible run to run;
+//  * off-diagonal Schur blocks are *gathered*: the host builds, once per problem, the list of
+//    (edge_a, edge_c) pair instances per block; one wave owns one 6x6 block (lane = matrix
+//    element) and streams its instances (W blocks are 144-byte contiguous rows);
+//  * reduced camera system solved by block-Jacobi preconditioned CG on the block-CSR matrix
+//    (two kernels per iteration, scalars stay on the device, deterministic two-stage reductions);
+//  * sharding: landmarks (with all their edges) are partitioned across ranks, the
+//    camera state is replicated, and ONE RCCL all-reduce per LM trial sums
+//    [S blocks | b_schur] over xGMI; every rank then solves the identical reduced system.
+//  * LM control (lambda schedule, rho test, stop rules) runs on the host exactly as
+//    optimization_algorithm_levenberg.cpp:61-164 does; one 32-byte D2H read per trial.
+#include "common.h"
+#include "ba_math.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n);   // comm.hip
+int ccm_allreduce_max_f64(ccm_ctx* ctx, double* d_buf, size_t n);
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTPB = 256;
+constexpr uint32_t kTransposeBit = 0x80000000u;
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// deterministic block sum (fixed tree), result valid in thread 0; blockDim.x == kTPB
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= kTPB/kWave */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x / kWave;
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kTPB / kWave; i++) s += lds[i];
+  return s;
+}
+
+// sum of an array of partials, identical result in every lane of every wave (fixed order)
+__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n) {
+  const int lane = threadIdx.x & (kWave - 1);
+  double s = 0;
+  for (int i = lane; i < n; i += kWave) s += p[i];
+  return wave_sum(s);
+}
+
+struct BaDev {
+  // sizes
+  int n_cam, Cp, Lloc, Eloc, nOff;
+  double huber;
+  // camera state (all cameras replicated), [2][n_cam*7]
+  double* cam[2];
+  const double* K;           // [n_cam*4]
+  const int* slot_cam;       // [Cp] pose slot -> camera index
+  // landmark state (own landmarks), [2][Lloc*3]
+  double* pt[2];
+  // edges of own landmarks, sorted by landmark
+  const int* pt_off;         // [Lloc+1]
+  const int* ed_cam;         // [Eloc] camera index
+  const int* ed_cslot;       // [Eloc] pose slot or -1 (fixed camera)
+  const int* ed_pt;          // [Eloc] local landmark
+  const double* obs;         // [Eloc*2]
+  const double* info;        // [Eloc]
+  // per camera slot: list of local edges
+  const int* cam_off;        // [Cp+1]
+  const int* cam_edge;       // [..]
+  // linear system pieces
+  double* W;                 // [Eloc*18]  Hpl block of each edge (pose rows x landmark cols)
+  double* Hll;               // [Lloc*6]   symmetric 3x3
+  double* bl;                // [Lloc*3]
+  double* Dinv;              // [Lloc*6]
+  double* dl;                // [Lloc*3]   D^-1 b_l
+  double* Hpp;               // [Cp*36]    partial (own edges)
+  double* bp;                // [Cp*6]     partial
+  // reduced system (contiguous: all-reduced in one call)
+  double* S;                 // [(Cp+nOff)*36] diagonal blocks first
+  double* bs;                // [Cp*6]
+  const int* inst_off;       // [nOff+1]
+  const int* inst_a;         // edge with the block-row camera
+  const int* inst_c;         // edge with the block-col camera
+  // block CSR for SpMV (full rows, diag included)
+  const int* row_off;        // [Cp+1]
+  const int* row_col;        // [..]
+  const uint32_t* row_blk;   // [..] block id | transpose bit
+  // PCG
+  double *x, *r, *z, *q, *p[2], *Minv;
+  double *ppq, *prz[2];      // partials
+  double* pcg_scal;          // [0]=rz0 [1]=thresh^2  [2]=lambda
+  int* pcg_flag;             // [0]=done [1]=iters [2]=fail
+  int n_wg_spmv, n_wg_upd;
+  // trial outputs
+  double* edge_chi2;         // [Eloc]
+  uint8_t* edge_depth;       // [Eloc]
+  double* part_pt;           // [n_wg_pt*2]  (robust chi2, scale) partials
+  double* part_cam;          // [n_wg_cam]   scale partials (pose part)
+  double* scal;              // [4]  chi2, scale, maxdiag, -
+  int n_wg_pt, n_wg_cam;
+};
+
+// ---------------------------------------------------------------------------------------------
+// linearisation: landmark side (one thread per own landmark)          [CCM_K_BA_LINEARIZE]
+// buildSystem (block_solver.hpp:502-560) for Hll, b_l and the Hpl blocks
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTPB) void ba_linearize_pts(BaDev d, int cur) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= d.Lloc) return;
+  const double X[3] = {d.pt[cur][3 * l], d.pt[cur][3 * l + 1], d.pt[cur][3 * l + 2]};
+  double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  const int e0 = d.pt_off[l], e1 = d.pt_off[l + 1];
+  for (int e = e0; e < e1; e++) {
+    const int c = d.ed_cam[e];
+    const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+    const double* Kc = d.K + 4 * (size_t)c;
+    const double K4[4] = {Kc[0], Kc[1], Kc[2], Kc[3]};
+    double r0, r1;
+    ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+    double Ji[6], Jj[12];
+    ba_jacobians(T, K4, X, Ji, Jj);
+    const double om = d.info[e];
+    double rho0, w;
+    ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
+    const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    b[0] += Ji[0] * o0 + Ji[3] * o1; b[1] += Ji[1] * o0 + Ji[4] * o1; b[2] += Ji[2] * o0 + Ji[5] * o1;
+    H[0] += (Ji[0] * Ji[0] + Ji[3] * Ji[3]) * wom; H[1] += (Ji[0] * Ji[1] + Ji[3] * Ji[4]) * wom;
+    H[2] += (Ji[0] * Ji[2] + Ji[3] * Ji[5]) * wom; H[3] += (Ji[1] * Ji[1] + Ji[4] * Ji[4]) * wom;
+    H[4] += (Ji[1] * Ji[2] + Ji[4] * Ji[5]) * wom; H[5] += (Ji[2] * Ji[2] + Ji[5] * Ji[5]) * wom;
+    if (d.ed_cslot[e] >= 0) {
+      double* W = d.W + 18 * (size_t)e;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[i * 3 + j] = (Jj[i] * Ji[j] + Jj[6 + i] * Ji[3 + j]) * wom;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) d.Hll[6 * (size_t)l + i] = H[i];
+  d.bl[3 * (size_t)l] = b[0]; d.bl[3 * (size_t)l + 1] = b[1]; d.bl[3 * (size_t)l + 2] = b[2];
+}
+
+// linearisation: camera side (one wave per free camera)                [CCM_K_BA_CAM]
+__global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
+  if (i >= d.Cp) return;
+  const int c = d.slot_cam[i];
+  const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+  const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int s = d.cam_off[i] + lane; s < d.cam_off[i + 1]; s += kWave) {
+    const int e = d.cam_edge[s];
+    const int l = d.ed_pt[e];
+    const double X[3] = {d.pt[cur][3 * l], d.pt[cur][3 * l + 1], d.pt[cur][3 * l + 2]};
+    double r0, r1;
+    ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+    double Xc[3];
+    ba_map(T, X, Xc);
+    double Jj[12];
+    {
+      const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z, fx = K4[0], fy = K4[1];
+      Jj[0] = x * y / z_2 * fx; Jj[1] = -(1 + (x * x / z_2)) * fx; Jj[2] = y / z * fx; Jj[3] = -1. / z * fx; Jj[4] = 0; Jj[5] = x / z_2 * fx;
+      Jj[6] = (1 + y * y / z_2) * fy; Jj[7] = -x * y / z_2 * fy; Jj[8] = -x / z * fy; Jj[9] = 0; Jj[10] = -1. / z * fy; Jj[11] = y / z_2 * fy;
+    }
+    const double om = d.info[e];
+    double rho0, w;
+    ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
+    const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[k++] += (Jj[a] * Jj[b] + Jj[6 + a] * Jj[6 + b]) * wom;
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * o0 + Jj[6 + a] * o1;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+    double* H = d.Hpp + 36 * (size_t)i;
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+      for (int b = a; b < 6; b++) { H[a * 6 + b] = acc[k]; H[b * 6 + a] = acc[k]; k++; }
+    for (int a = 0; a < 6; a++) d.bp[6 * (size_t)i + a] = acc[21 + a];
+  }
+}
+
+// max |diag| of Hpp (after it has been summed over ranks) and of the own Hll  -> scal[2]
+__global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_full) {
+  __shared__ double lds[kTPB];
+  double m = 0;
+  for (int i = threadIdx.x; i < d.Cp * 6; i += kTPB) m = fmax(m, fabs(hpp_full[36 * (size_t)(i / 6) + (i % 6) * 7]));
+  for (int i = threadIdx.x; i < d.Lloc * 3; i += kTPB) {
+    const int l = i / 3, k = i % 3;
+    m = fmax(m, fabs(d.Hll[6 * (size_t)l + (k == 0 ? 0 : (k == 1 ? 3 : 5))]));
+  }
+  lds[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = kTPB / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.scal[2] = lds[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// per LM trial
+// ---------------------------------------------------------------------------------------------
+// D = Hll + lambda I ; Dinv ; dl = Dinv b_l           (block_solver.hpp:385-396)   [CCM_K_BA_DINV]
+__global__ __launch_bounds__(kTPB) void ba_dinv(BaDev d, double lambda) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= d.Lloc) return;
+  double a[6], r[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) a[i] = d.Hll[6 * (size_t)l + i];
+  a[0] += lambda; a[3] += lambda; a[5] += lambda;
+  ba_sym3_inv(a, r);
+#pragma unroll
+  for (int i = 0; i < 6; i++) d.Dinv[6 * (size_t)l + i] = r[i];
+  const double b0 = d.bl[3 * (size_t)l], b1 = d.bl[3 * (size_t)l + 1], b2 = d.bl[3 * (size_t)l + 2];
+  d.dl[3 * (size_t)l] = r[0] * b0 + r[1] * b1 + r[2] * b2;
+  d.dl[3 * (size_t)l + 1] = r[1] * b0 + r[3] * b1 + r[4] * b2;
+  d.dl[3 * (size_t)l + 2] = r[2] * b0 + r[4] * b1 + r[5] * b2;
+}
+
+// diagonal Schur blocks and b_schur (one wave per free camera)          [CCM_K_BA_SCHUR_DIAG]
+//   S_ii = Hpp_i - sum_e W_e Dinv W_e^T ;  bs_i = bp_i - sum_e W_e dl      (block_solver.hpp:398-439)
+__global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
+  if (i >= d.Cp) return;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int s = d.cam_off[i] + lane; s < d.cam_off[i + 1]; s += kWave) {
+    const int e = d.cam_edge[s];
+    const int l = d.ed_pt[e];
+    double W[18], Di[6], dl[3];
+    const double* Wp = d.W + 18 * (size_t)e;
+#pragma unroll
+    for (int k = 0; k < 18; k++) W[k] = Wp[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Di[k] = d.Dinv[6 * (size_t)l + k];
+    dl[0] = d.dl[3 * (size_t)l]; dl[1] = d.dl[3 * (size_t)l + 1]; dl[2] = d.dl[3 * (size_t)l + 2];
+    double Y[18];   // W * Dinv
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      Y[r * 3 + 0] = W[r * 3] * Di[0] + W[r * 3 + 1] * Di[1] + W[r * 3 + 2] * Di[2];
+      Y[r * 3 + 1] = W[r * 3] * Di[1] + W[r * 3 + 1] * Di[3] + W[r * 3 + 2] * Di[4];
+      Y[r * 3 + 2] = W[r * 3] * Di[2] + W[r * 3 + 1] * Di[4] + W[r * 3 + 2] * Di[5];
+    }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) { acc[k] += Y[a * 3] * W[b * 3] + Y[a * 3 + 1] * W[b * 3 + 1] + Y[a * 3 + 2] * W[b * 3 + 2]; k++; }
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += W[a * 3] * dl[0] + W[a * 3 + 1] * dl[1] + W[a * 3 + 2] * dl[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 27; k++) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+    const double* H = d.Hpp + 36 * (size_t)i;
+    double* S = d.S + 36 * (size_t)i;
+    int k = 0;
+    for (int a = 0; a < 6; a++)
+      for (int b = a; b < 6; b++) { const double v = H[a * 6 + b] - acc[k]; S[a * 6 + b] = v; S[b * 6 + a] = v; k++; }
+    for (int a = 0; a < 6; a++) d.bs[6 * (size_t)i + a] = d.bp[6 * (size_t)i + a] - acc[21 + a];
+  }
+}
+
+// off-diagonal Schur blocks: one wave per block, lane = element (r,c)   [CCM_K_BA_SCHUR_OFF]
+//   S_ij = - sum_inst W_a Dinv W_c^T
+__global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave);
+  if (b >= d.nOff) return;
+  const int r = lane / 6, c = lane % 6;
+  double acc = 0;
+  if (lane < 36) {
+    const int s0 = d.inst_off[b], s1 = d.inst_off[b + 1];
+    for (int s = s0; s < s1; s++) {
+      const int ea = d.inst_a[s], ec = d.inst_c[s];
+      const int l = d.ed_pt[ea];
+      const double* Wa = d.W + 18 * (size_t)ea + 3 * r;
+      const double* Wc = d.W + 18 * (size_t)ec + 3 * c;
+      const double* Di = d.Dinv + 6 * (size_t)l;
+      const double a0 = Wa[0], a1 = Wa[1], a2 = Wa[2];
+      const double y0 = a0 * Di[0] + a1 * Di[1] + a2 * Di[2];
+      const double y1 = a0 * Di[1] + a1 * Di[3] + a2 * Di[4];
+      const double y2 = a0 * Di[2] + a1 * Di[4] + a2 * Di[5];
+      acc += y0 * Wc[0] + y1 * Wc[1] + y2 * Wc[2];
+    }
+    d.S[36 * (size_t)(d.Cp + b) + lane] = -acc;
+  }
+}
+
+// ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
+// preconditioner: inverse of the damped diagonal blocks
+__global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, double rel_tol) {
+  __shared__ double lds[kTPB / kWave];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double rz = 0;
+  if (i < d.Cp) {
+    double A[36], Inv[36];
+    const double* S = d.S + 36 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 36; k++) A[k] = S[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) A[k * 7] += lambda;
+    if (!ba_spd6_inv(A, Inv)) { d.pcg_flag[2] = 1; for (int k = 0; k < 36; k++) Inv[k] = (k % 7 == 0) ? 1.0 : 0.0; }
+    double* M = d.Minv + 36 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 36; k++) M[k] = Inv[k];
+    double rr[6], zz[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) rr[k] = d.bs[6 * (size_t)i + k];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += Inv[a * 6 + k] * rr[k];
+      zz[a] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      d.x[6 * (size_t)i + k] = 0; d.r[6 * (size_t)i + k] = rr[k]; d.z[6 * (size_t)i + k] = zz[k];
+      d.p[0][6 * (size_t)i + k] = 0;   // p_{-1} = 0, beta_0 = 0 -> p_0 = z_0
+      rz += rr[k] * zz[k];
+    }
+  }
+  const double s = block_sum(rz, lds);
+  if (threadIdx.x == 0) {
+    d.prz[0][blockIdx.x] = s;
+    d.prz[1][blockIdx.x] = 0;
+    if (blockIdx.x == 0) { d.pcg_scal[1] = rel_tol * rel_tol; d.pcg_scal[2] = lambda; }
+  }
+}
+
+// iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
+__global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
+  __shared__ double lds[kTPB / kWave];
+  if (d.pcg_flag[0]) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x / kWave;
+  const int i = blockIdx.x * (kTPB / kWave) + wv;
+  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  double beta = 0;
+  if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
+  else {
+    const double rz_prev = sum_partials(d.prz[(k + 1) & 1], d.n_wg_upd);
+    beta = rz_k / rz_prev;
+  }
+  const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
+  // convergence test (identical in every workgroup): sqrt(rz_k / rz_0) <= rel_tol, or exact zero residual
+  if (rz_k <= d.pcg_scal[1] * rz0 || !(rz_k > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; if (rz_k != rz_k) d.pcg_flag[2] = 1; }
+    return;
+  }
+  const double lambda = d.pcg_scal[2];
+  const double* pold = d.p[k & 1];
+  double* pnew = d.p[(k + 1) & 1];
+  double pq = 0;
+  if (i < d.Cp) {
+    const int r = lane / 6, c = lane % 6;
+    double acc = 0;
+    if (lane < 36) {
+      const int s0 = d.row_off[i], s1 = d.row_off[i + 1];
+      for (int s = s0; s < s1; s++) {
+        const int j = d.row_col[s];
+        const uint32_t bt = d.row_blk[s];
+        const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+        const double v = (bt & kTransposeBit) ? B[c * 6 + r] : B[r * 6 + c];
+        const double pj = d.z[6 * (size_t)j + c] + beta * pold[6 * (size_t)j + c];
+        acc += v * pj;
+      }
+    }
+    // reduce over c (6 consecutive lanes r*6 .. r*6+5): fixed order
+    double row = 0;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) row += __shfl(acc, r * 6 + cc, kWave);
+    // lanes 0..5 take element r = lane
+    const double qr = __shfl(row, (lane % 6) * 6, kWave);   // lane L<6 reads the sum of row L
+    if (lane < 6) {
+      const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
+      const double qv = qr + lambda * pi;
+      d.q[6 * (size_t)i + lane] = qv;
+      pnew[6 * (size_t)i + lane] = pi;
+      pq = pi * qv;
+    }
+    pq = wave_sum(lane < 6 ? pq : 0.0);
+  }
+  __syncthreads();
+  if (lane == 0) lds[wv] = (i < d.Cp) ? pq : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int w = 0; w < kTPB / kWave; w++) s += lds[w];
+    d.ppq[blockIdx.x] = s;
+  }
+}
+
+// alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial rz_{k+1}        [CCM_K_BA_PCG_UPDATE]
+__global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
+  __shared__ double lds[kTPB / kWave];
+  if (d.pcg_flag[0]) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  const double pq = sum_partials(d.ppq, d.n_wg_spmv);
+  if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = 1; }
+    return;
+  }
+  const double alpha = rz_k / pq;
+  const double* p = d.p[(k + 1) & 1];
+  double rz = 0;
+  if (i < d.Cp) {
+    double rr[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      d.x[6 * (size_t)i + a] += alpha * p[6 * (size_t)i + a];
+      rr[a] = d.r[6 * (size_t)i + a] - alpha * d.q[6 * (size_t)i + a];
+      d.r[6 * (size_t)i + a] = rr[a];
+    }
+    const double* M = d.Minv + 36 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      double s = 0;
+#pragma unroll
+      for (int b = 0; b < 6; b++) s += M[a * 6 + b] * rr[b];
+      d.z[6 * (size_t)i + a] = s;
+      rz += rr[a] * s;
+    }
+  }
+  const double s = block_sum(rz, lds);
+  if (threadIdx.x == 0) {
+    d.prz[(k + 1) & 1][blockIdx.x] = s;
+    if (blockIdx.x == 0) d.pcg_flag[1] = k + 1;
+  }
+}
+
+// ---- apply the step to a trial state, chi2 of the trial ---------------------------------------
+// cameras: T_trial = exp(dx) * T ; partial of sum x (lambda x + b_p)                   [CCM_K_BA_UPDATE]
+__global__ __launch_bounds__(kTPB) void ba_update_cams(BaDev d, int cur, double lambda, int add_lambda_term) {
+  __shared__ double lds[kTPB / kWave];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0;
+  if (i < d.Cp) {
+    const int c = d.slot_cam[i];
+    double u[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) u[a] = d.x[6 * (size_t)i + a];
+    const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+    const BaPose Tn = ba_oplus(u, T);
+    ba_store_pose(d.cam[cur ^ 1] + 7 * (size_t)c, Tn);
+#pragma unroll
+    for (int a = 0; a < 6; a++) sc += u[a] * ((add_lambda_term ? lambda * u[a] : 0.0) + d.bp[6 * (size_t)i + a]);
+  }
+  const double s = block_sum(sc, lds);
+  if (threadIdx.x == 0) d.part_cam[blockIdx.x] = s;
+}
+
+// landmarks: dX = Dinv (b_l - sum_e W_e^T dx_cam) ; X_trial = X + dX ; robust chi2 of the own
+// edges at the trial state (block_solver.hpp:461-481, sparse_optimizer.cpp:61-114,422-435) [CCM_K_BA_BACKSUB]
+__global__ __launch_bounds__(kTPB) void ba_backsub_chi2(BaDev d, int cur, double lambda, int chi2_only) {
+  __shared__ double lds[kTPB / kWave];
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  double chi = 0, sc = 0;
+  if (l < d.Lloc) {
+    const int e0 = d.pt_off[l], e1 = d.pt_off[l + 1];
+    double X[3] = {d.pt[cur][3 * (size_t)l], d.pt[cur][3 * (size_t)l + 1], d.pt[cur][3 * (size_t)l + 2]};
+    const int trial = chi2_only ? cur : (cur ^ 1);
+    if (!chi2_only) {
+      double cl[3] = {d.bl[3 * (size_t)l], d.bl[3 * (size_t)l + 1], d.bl[3 * (size_t)l + 2]};
+      const double bl0 = cl[0], bl1 = cl[1], bl2 = cl[2];
+      for (int e = e0; e < e1; e++) {
+        const int cs = d.ed_cslot[e];
+        if (cs < 0) continue;
+        const double* W = d.W + 18 * (size_t)e;
+        const double* xp = d.x + 6 * (size_t)cs;
+#pragma unroll
+        for (int r = 0; r < 6; r++) { cl[0] -= W[r * 3] * xp[r]; cl[1] -= W[r * 3 + 1] * xp[r]; cl[2] -= W[r * 3 + 2] * xp[r]; }
+      }
+      const double* Di = d.Dinv + 6 * (size_t)l;
+      const double dx0 = Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2];
+      const double dx1 = Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2];
+      const double dx2 = Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
+      sc = dx0 * (lambda * dx0 + bl0) + dx1 * (lambda * dx1 + bl1) + dx2 * (lambda * dx2 + bl2);
+      X[0] += dx0; X[1] += dx1; X[2] += dx2;
+      d.pt[trial][3 * (size_t)l] = X[0]; d.pt[trial][3 * (size_t)l + 1] = X[1]; d.pt[trial][3 * (size_t)l + 2] = X[2];
+    }
+    for (int e = e0; e < e1; e++) {
+      const int c = d.ed_cam[e];
+      const BaPose T = ba_load_pose(d.cam[trial] + 7 * (size_t)c);
+      const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
+      double r0, r1;
+      const double zc = ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+      const double c2 = (r0 * r0 + r1 * r1) * d.info[e];
+      double rho0, w;
+      ba_huber(c2, d.huber, rho0, w);
+      chi += rho0;
+      d.edge_chi2[e] = c2;
+      d.edge_depth[e] = zc > 0.0;
+    }
+  }
+  const double s0 = block_sum(chi, lds);
+  const double s1 = block_sum(sc, lds);
+  if (threadIdx.x == 0) { d.part_pt[2 * blockIdx.x] = s0; d.part_pt[2 * blockIdx.x + 1] = s1; }
+}
+
+// final reduction of the trial scalars (single workgroup, fixed order)
+__global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d) {
+  __shared__ double lds[kTPB / kWave];
+  double chi = 0, sc = 0;
+  for (int i = threadIdx.x; i < d.n_wg_pt; i += kTPB) { chi += d.part_pt[2 * i]; sc += d.part_pt[2 * i + 1]; }
+  for (int i = threadIdx.x; i < d.n_wg_cam; i += kTPB) sc += d.part_cam[i];
+  const double a = block_sum(chi, lds);
+  const double b = block_sum(sc, lds);
+  if (threadIdx.x == 0) { d.scal[0] = a; d.scal[1] = b; }
+}
+
+__global__ void ba_copy_cams(double* dst, const double* src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+__global__ void ba_scatter_points(double* full, const double* own, const int* own_slot /*local -> global landmark slot*/, int Lloc) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= Lloc) return;
+  const int g = own_slot[l];
+  full[3 * (size_t)g] = own[3 * (size_t)l]; full[3 * (size_t)g + 1] = own[3 * (size_t)l + 1]; full[3 * (size_t)g + 2] = own[3 * (size_t)l + 2];
+}
+
+}  // namespace
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct ccm_ba {
+  ccm_ctx* ctx = nullptr;
+  int rank = 0, nranks = 1;
+  int n_cam = 0, n_pt = 0, n_edge = 0;
+  int Cp = 0, Lp = 0, Lloc = 0, Eloc = 0, nOff = 0;
+  int64_t n_inst = 0, n_act_edges = 0, n_row_entries = 0;
+  int lp_begin = 0, lp_end = 0;
+  std::vector<int> slot_cam, cam_slot, slot_pt, pt_slot;
+  std::vector<int> loc_edge_orig;       // local edge -> original edge index
+  std::vector<void*> allocs;
+  BaDev d{};
+  int cur = 0;
+  double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
+  double* d_pt_full = nullptr; int* d_own_slot = nullptr;
+  double* d_hpp_full = nullptr;
+  double ms_setup = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_upload(ccm_ba* ba, const std::vector<T>& v, T** out) {
+  ccm_ctx* ctx = ba->ctx;
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  CCM_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+  ba->allocs.push_back(p);
+  if (!v.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *out = (T*)p;
+  return CCM_OK;
+}
+template <typename T>
+int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
+  ccm_ctx* ctx = ba->ctx;
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  CCM_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+  ba->allocs.push_back(p);
+  if (zero) CCM_HIP_CHECK(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+  *out = (T*)p;
+  return CCM_OK;
+}
+
+#define RC(x) do { int _rc = (x); if (_rc != CCM_OK) return _rc; } while (0)
+
+}  // namespace
+
+// Host-only partition of landmark slots into nranks contiguous ranges balanced by weight
+// (pair instances + edges).  Exported for the CPU tests of the sharding logic.
+extern "C" int ccm_ba_partition(const int64_t* weight, int n, int nranks, int32_t* begin_out /* nranks+1 */) {
+  if (!begin_out || nranks < 1 || n < 0 || (n && !weight)) return CCM_E_ARG;
+  int64_t total = 0;
+  for (int i = 0; i < n; i++) total += weight[i];
+  begin_out[0] = 0;
+  int64_t acc = 0;
+  int r = 1;
+  for (int i = 0; i < n && r < nranks; i++) {
+    acc += weight[i];
+    // close shard r-1 once it has reached r/nranks of the total weight
+    while (r < nranks && acc * nranks >= total * r) { begin_out[r] = i + 1; r++; }
+  }
+  for (; r < nranks; r++) begin_out[r] = n;
+  begin_out[nranks] = n;
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, int nranks, ccm_ba** out) {
+  if (!ctx || !P || !out || nranks < 1 || rank < 0 || rank >= nranks) return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: bad args");
+  if (P->n_cam <= 0 || P->n_pt < 0 || P->n_edge < 0 || !P->cam_qt || !P->cam_fixed || !P->cam_K ||
+      (P->n_pt && !P->pt_xyz) || (P->n_edge && (!P->e_cam || !P->e_pt || !P->e_obs || !P->e_info)))
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: incomplete problem");
+  for (int e = 0; e < P->n_edge; e++)
+    if (P->e_cam[e] < 0 || P->e_cam[e] >= P->n_cam || P->e_pt[e] < 0 || P->e_pt[e] >= P->n_pt)
+      return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: edge index out of range");
+  const double t0 = now_ms();
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ccm_ba* ba = new ccm_ba();
+  ba->ctx = ctx; ba->rank = rank; ba->nranks = nranks;
+  ba->n_cam = P->n_cam; ba->n_pt = P->n_pt; ba->n_edge = P->n_edge;
+  auto fail = [&](int rc) { ccm_ba_destroy(ba); return rc; };
+
+  // ---- active set (initializeOptimization(0), sparse_optimizer.cpp:199-267) ----
+  std::vector<int> act;
+  act.reserve(P->n_edge);
+  std::vector<char> cam_has(P->n_cam, 0), pt_has(P->n_pt, 0);
+  for (int e = 0; e < P->n_edge; e++) {
+    if (P->e_level && P->e_level[e] != 0) continue;
+    act.push_back(e);
+    cam_has[P->e_cam[e]] = 1; pt_has[P->e_pt[e]] = 1;
+  }
+  ba->n_act_edges = (int64_t)act.size();
+  ba->cam_slot.assign(P->n_cam, -1); ba->pt_slot.assign(P->n_pt, -1);
+  for (int c = 0; c < P->n_cam; c++) if (cam_has[c] && !P->cam_fixed[c]) { ba->cam_slot[c] = (int)ba->slot_cam.size(); ba->slot_cam.push_back(c); }
+  for (int p = 0; p < P->n_pt; p++) if (pt_has[p]) { ba->pt_slot[p] = (int)ba->slot_pt.size(); ba->slot_pt.push_back(p); }
+  const int Cp = ba->Cp = (int)ba->slot_cam.size();
+  const int Lp = ba->Lp = (int)ba->slot_pt.size();
+
+  // ---- edges sorted by (landmark slot, pose slot) — fixed cameras (slot -1) first ----
+  std::vector<int> order(act.size());
+  {
+    std::vector<int> cnt(Lp + 1, 0);
+    for (int e : act) cnt[ba->pt_slot[P->e_pt[e]] + 1]++;
+    for (int l = 0; l < Lp; l++) cnt[l + 1] += cnt[l];
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int e : act) order[pos[ba->pt_slot[P->e_pt[e]]]++] = e;
+    for (int l = 0; l < Lp; l++)
+      std::stable_sort(order.begin() + cnt[l], order.begin() + cnt[l + 1],
+                       [&](int a, int b) { return ba->cam_slot[P->e_cam[a]] < ba->cam_slot[P->e_cam[b]]; });
+  }
+  std::vector<int> g_pt_off(Lp + 1, 0);
+  for (size_t k = 0; k < order.size(); k++) g_pt_off[ba->pt_slot[P->e_pt[order[k]]] + 1]++;
+  for (int l = 0; l < Lp; l++) g_pt_off[l + 1] += g_pt_off[l];
+
+  // ---- shard the landmarks: weight = pair instances + edges ----
+  std::vector<int64_t> weight(Lp);
+  for (int l = 0; l < Lp; l++) {
+    int kf = 0;
+    for (int k = g_pt_off[l]; k < g_pt_off[l + 1]; k++) kf += ba->cam_slot[P->e_cam[order[k]]] >= 0;
+    weight[l] = (int64_t)kf * (kf + 1) / 2 + (g_pt_off[l + 1] - g_pt_off[l]);
+  }
+  std::vector<int32_t> shard(nranks + 1);
+  ccm_ba_partition(weight.data(), Lp, nranks, shard.data());
+  const int lb = ba->lp_begin = shard[rank], le = ba->lp_end = shard[rank + 1];
+  const int Lloc = ba->Lloc = le - lb;
+  const int eb = g_pt_off[lb], ee = g_pt_off[le];
+  const int Eloc = ba->Eloc = ee - eb;
+
+  // ---- global off-diagonal block structure + own pair instances ----
+  struct Inst { uint64_t key; int ea, ec; };
+  std::vector<uint64_t> all_keys;
+  std::vector<Inst> own;
+  for (int l = 0; l < Lp; l++) {
+    const int k0 = g_pt_off[l], k1 = g_pt_off[l + 1];
+    const bool mine = l >= lb && l < le;
+    for (int a = k0; a < k1; a++) {
+      const int ia = ba->cam_slot[P->e_cam[order[a]]];
+      if (ia < 0) continue;
+      for (int c = a + 1; c < k1; c++) {
+        const int ic = ba->cam_slot[P->e_cam[order[c]]];
+        if (ic == ia) continue;   // two observations of one landmark in one camera: contributes to the diagonal only
+        const uint64_t key = ((uint64_t)(uint32_t)ia << 32) | (uint32_t)ic;   // ia < ic by the sort
+        all_keys.push_back(key);
+        if (mine) own.push_back(Inst{key, a - eb, c - eb});
+      }
+    }
+  }
+  std::sort(all_keys.begin(), all_keys.end());
+  all_keys.erase(std::unique(all_keys.begin(), all_keys.end()), all_keys.end());
+  const int nOff = ba->nOff = (int)all_keys.size();
+  std::stable_sort(own.begin(), own.end(), [](const Inst& x, const Inst& y) { return x.key < y.key; });
+  ba->n_inst = (int64_t)own.size();
+  std::vector<int> inst_off(nOff + 1, 0), inst_a(own.size()), inst_c(own.size());
+  {
+    size_t s = 0;
+    for (int b = 0; b < nOff; b++) {
+      inst_off[b] = (int)s;
+      while (s < own.size() && own[s].key == all_keys[b]) { inst_a[s] = own[s].ea; inst_c[s] = own[s].ec; s++; }
+    }
+    inst_off[nOff] = (int)s;
+  }
+  // ---- block CSR rows (full symmetric pattern) ----
+  std::vector<int> row_cnt(Cp + 1, 0);
+  for (int i = 0; i < Cp; i++) row_cnt[i + 1] = 1;
+  for (int b = 0; b < nOff; b++) { row_cnt[(int)(all_keys[b] >> 32) + 1]++; row_cnt[(int)(uint32_t)all_keys[b] + 1]++; }
+  for (int i = 0; i < Cp; i++) row_cnt[i + 1] += row_cnt[i];
+  std::vector<int> row_col(row_cnt[Cp]); std::vector<uint32_t> row_blk(row_cnt[Cp]);
+  {
+    // column-ascending per row: lower part (transposed blocks, ascending j because keys are sorted by (i,j)
+    // and we visit b in order -> for row j the i's arrive ascending), then diagonal, then upper part.
+    std::vector<int> lower_cnt(Cp, 0);
+    for (int b = 0; b < nOff; b++) lower_cnt[(int)(uint32_t)all_keys[b]]++;
+    std::vector<int> pos_low(Cp), pos_up(Cp);
+    for (int i = 0; i < Cp; i++) {
+      pos_low[i] = row_cnt[i];
+      const int dpos = row_cnt[i] + lower_cnt[i];
+      row_col[dpos] = i; row_blk[dpos] = (uint32_t)i;
+      pos_up[i] = dpos + 1;
+    }
+    for (int b = 0; b < nOff; b++) {
+      const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
+      row_col[pos_up[i]] = j; row_blk[pos_up[i]++] = (uint32_t)(Cp + b);
+      row_col[pos_low[j]] = i; row_blk[pos_low[j]++] = (uint32_t)(Cp + b) | kTransposeBit;
+    }
+  }
+  ba->n_row_entries = row_cnt[Cp];
+
+  // ---- local edge arrays ----
+  std::vector<int> pt_off(Lloc + 1), ed_cam(Eloc), ed_cslot(Eloc), ed_pt(Eloc);
+  std::vector<double> obs(2 * (size_t)Eloc), info(Eloc);
+  ba->loc_edge_orig.resize(Eloc);
+  for (int l = 0; l <= Lloc; l++) pt_off[l] = g_pt_off[lb + l] - eb;
+  for (int k = 0; k < Eloc; k++) {
+    const int e = order[eb + k];
+    ba->loc_edge_orig[k] = e;
+    ed_cam[k] = P->e_cam[e]; ed_cslot[k] = ba->cam_slot[P->e_cam[e]]; ed_pt[k] = ba->pt_slot[P->e_pt[e]] - lb;
+    obs[2 * (size_t)k] = P->e_obs[2 * (size_t)e]; obs[2 * (size_t)k + 1] = P->e_obs[2 * (size_t)e + 1];
+    info[k] = P->e_info[e];
+  }
+  std::vector<int> cam_off(Cp + 1, 0), cam_edge;
+  for (int k = 0; k < Eloc; k++) if (ed_cslot[k] >= 0) cam_off[ed_cslot[k] + 1]++;
+  for (int i = 0; i < Cp; i++) cam_off[i + 1] += cam_off[i];
+  cam_edge.resize(cam_off[Cp]);
+  {
+    std::vector<int> pos(cam_off.begin(), cam_off.end() - 1);
+    for (int k = 0; k < Eloc; k++) if (ed_cslot[k] >= 0) cam_edge[pos[ed_cslot[k]]++] = k;
+  }
+  std::vector<int> own_slot(Lloc);
+  for (int l = 0; l < Lloc; l++) own_slot[l] = lb + l;
+
+  // ---- upload ----
+  BaDev& d = ba->d;
+  d.n_cam = P->n_cam; d.Cp = Cp; d.Lloc = Lloc; d.Eloc = Eloc; d.nOff = nOff; d.huber = P->huber_delta;
+  {
+    std::vector<double> K(P->cam_K, P->cam_K + 4 * (size_t)P->n_cam);
+    double* dk = nullptr; if (int rc = dev_upload(ba, K, &dk)) return fail(rc); d.K = dk;
+  }
+#define UP(vec, field, T) { T* _p = nullptr; if (int rc = dev_upload(ba, vec, &_p)) return fail(rc); d.field = _p; }
+  UP(ba->slot_cam, slot_cam, int) UP(pt_off, pt_off, int) UP(ed_cam, ed_cam, int) UP(ed_cslot, ed_cslot, int)
+  UP(ed_pt, ed_pt, int) UP(obs, obs, double) UP(info, info, double) UP(cam_off, cam_off, int) UP(cam_edge, cam_edge, int)
+  UP(inst_off, inst_off, int) UP(inst_a, inst_a, int) UP(inst_c, inst_c, int)
+  UP(row_cnt, row_off, int) UP(row_col, row_col, int) UP(row_blk, row_blk, uint32_t)
+#undef UP
+  if (int rc = dev_upload(ba, own_slot, &ba->d_own_slot)) return fail(rc);
+#define AL(field, n, T) { T* _p = nullptr; if (int rc = dev_alloc<T>(ba, (n), &_p)) return fail(rc); d.field = _p; }
+  AL(cam[0], 7 * (size_t)P->n_cam, double) AL(cam[1], 7 * (size_t)P->n_cam, double)
+  AL(pt[0], 3 * (size_t)Lloc, double) AL(pt[1], 3 * (size_t)Lloc, double)
+  AL(W, 18 * (size_t)Eloc, double) AL(Hll, 6 * (size_t)Lloc, double) AL(bl, 3 * (size_t)Lloc, double)
+  AL(Dinv, 6 * (size_t)Lloc, double) AL(dl, 3 * (size_t)Lloc, double) AL(Hpp, 36 * (size_t)Cp, double) AL(bp, 6 * (size_t)Cp, double)
+  AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
+  AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double) AL(Minv, 36 * (size_t)Cp, double)
+  d.n_wg_spmv = ccm_div_up(std::max(Cp, 1), kTPB / kWave); d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kTPB);
+  d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
+  AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
+  AL(pcg_scal, 4, double) AL(pcg_flag, 4, int)
+  AL(edge_chi2, Eloc, double) AL(edge_depth, Eloc, uint8_t)
+  AL(part_pt, 2 * (size_t)d.n_wg_pt, double) AL(part_cam, d.n_wg_cam, double) AL(scal, 4, double)
+#undef AL
+  ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
+  if (int rc = dev_alloc<double>(ba, ba->red_count, &ba->d_red)) return fail(rc);
+  d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
+  if (int rc = dev_alloc<double>(ba, 3 * (size_t)std::max(Lp, 1), &ba->d_pt_full)) return fail(rc);
+  if (int rc = dev_alloc<double>(ba, 36 * (size_t)std::max(Cp, 1), &ba->d_hpp_full)) return fail(rc);
+  int rc = ccm_ba_reset_state(ba, P->cam_qt, P->pt_xyz);
+  if (rc) return fail(rc);
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ba->ms_setup = now_ms() - t0;
+  *out = ba;
+  return CCM_OK;
+}
+
+extern "C" void ccm_ba_destroy(ccm_ba* ba) {
+  if (!ba) return;
+  if (ba->ctx) { hipSetDevice(ba->ctx->device); hipStreamSynchronize(ba->ctx->stream); }
+  for (void* p : ba->allocs) hipFree(p);
+  delete ba;
+}
+
+extern "C" int ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double* pt_xyz) {
+  if (!ba || !cam_qt || (ba->n_pt && !pt_xyz)) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<double> cam(7 * (size_t)ba->n_cam);
+  for (int c = 0; c < ba->n_cam; c++) {
+    BaPose T = ba_load_pose(cam_qt + 7 * (size_t)c);
+    ba_normalize_rotation(T);   // SE3Quat(q,t) ctor normalises (se3quat.h:61-63)
+    ba_store_pose(&cam[7 * (size_t)c], T);
+  }
+  std::vector<double> pts(3 * (size_t)std::max(ba->Lloc, 1), 0.0);
+  for (int l = 0; l < ba->Lloc; l++) {
+    const int p = ba->slot_pt[ba->lp_begin + l];
+    pts[3 * (size_t)l] = pt_xyz[3 * (size_t)p]; pts[3 * (size_t)l + 1] = pt_xyz[3 * (size_t)p + 1]; pts[3 * (size_t)l + 2] = pt_xyz[3 * (size_t)p + 2];
+  }
+  ba->cur = 0;
+  for (int k = 0; k < 2; k++) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.cam[k], cam.data(), cam.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (ba->Lloc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.pt[k], pts.data(), 3 * (size_t)ba->Lloc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts, int64_t* n_free_cams,
+                             int64_t* n_blocks, int64_t* n_pairs) {
+  if (!ba) return CCM_E_ARG;
+  if (n_active_edges) *n_active_edges = ba->Eloc;
+  if (n_active_pts) *n_active_pts = ba->Lloc;
+  if (n_free_cams) *n_free_cams = ba->Cp;
+  if (n_blocks) *n_blocks = ba->Cp + ba->nOff;
+  if (n_pairs) *n_pairs = ba->n_inst;
+  return CCM_OK;
+}
+
+namespace {
+
+int read_scalars(ccm_ba* ba, double out[4]) {
+  ccm_ctx* ctx = ba->ctx;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, ba->d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+// chi2 of the current state (computeActiveErrors + activeRobustChi2)
+int eval_chi2(ccm_ba* ba, double* chi) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BA_CHI2);
+    hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
+  }
+  hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
+  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
+  RC(ccm_allreduce_f64(ctx, d.scal, 2));
+  double s[4];
+  RC(read_scalars(ba, s));
+  *chi = s[0];
+  return CCM_OK;
+}
+
+int build_system(ccm_ba* ba) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  if (d.Lloc) {
+    ccm_prof_scope ps(ctx, CCM_K_BA_LINEARIZE);
+    hipLaunchKernelGGL(ba_linearize_pts, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+  }
+  if (d.Cp) {
+    ccm_prof_scope ps(ctx, CCM_K_BA_CAM);
+    hipLaunchKernelGGL(ba_linearize_cams, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+// lambda_init = tau * max diag  (computeLambdaInit)
+int max_diag(ccm_ba* ba, double* out) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  const double* hpp = d.Hpp;
+  if (ba->nranks > 1 && d.Cp) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_hpp_full, d.Hpp, 36 * (size_t)d.Cp * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    RC(ccm_allreduce_f64(ctx, ba->d_hpp_full, 36 * (size_t)d.Cp));
+    hpp = ba->d_hpp_full;
+  }
+  hipLaunchKernelGGL(ba_maxdiag, dim3(1), dim3(kTPB), 0, ctx->stream, d, hpp);
+  RC(ccm_allreduce_max_f64(ctx, d.scal + 2, 1));
+  double s[4];
+  RC(read_scalars(ba, s));
+  *out = s[2];
+  return CCM_OK;
+}
+
+// one LM trial: solve with lambda, write trial state, return tempChi, scale, ok
+int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_chi, double* scale, bool* ok, int* pcg_iters) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  const int cur = ba->cur;
+  if (d.Lloc) {
+    ccm_prof_scope ps(ctx, CCM_K_BA_DINV);
+    hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
+  }
+  *ok = true;
+  *pcg_iters = 0;
+  if (d.Cp) {
+    {
+      ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
+      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d);
+    }
+    if (d.nOff) {
+      ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
+      hipLaunchKernelGGL(ba_schur_off, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+    }
+    RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
+    // ---- PCG ----
+    const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-10;
+    const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(ba_pcg_init, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, lambda, tol);
+    int flags[4] = {0, 0, 0, 0};
+    const int chunk = 24;
+    int k = 0;
+    while (k < max_it) {
+      const int kend = std::min(max_it, k + chunk);
+      for (; k < kend; k++) {
+        {
+          ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
+          hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, k);
+        }
+        {
+          ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
+          hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+        }
+      }
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      if (flags[0]) break;
+    }
+    *pcg_iters = flags[0] ? flags[1] : k;
+    if (flags[2]) *ok = false;   // not SPD / NaN: linear solver failure (levenberg.cpp:126-127)
+  }
+  if (d.Cp) {
+    ccm_prof_scope ps(ctx, CCM_K_BA_UPDATE);
+    hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0);
+  } else hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BA_BACKSUB);
+    hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
+  }
+  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
+  RC(ccm_allreduce_f64(ctx, d.scal, 2));
+  double s[4];
+  RC(read_scalars(ba, s));
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  *temp_chi = s[0];
+  *scale = s[1];
+  return CCM_OK;
+}
+
+}  // namespace
+
+extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volatile unsigned char* stop_flag, ccm_ba_stats* stats) {
+  if (!ba) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  if (ba->nranks > 1 && (!ctx->comm || ctx->comm_nranks != ba->nranks || ctx->comm_rank != ba->rank))
+    return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba_run: sharded problem needs a matching communicator (ccm_comm_init)");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ccm_ba_options opt{};
+  if (opt_in) opt = *opt_in;
+  const double t_start = now_ms();
+  ccm_ba_stats st{};
+  st.ms_setup = ba->ms_setup;
+  st.n_schur_blocks = ba->Cp + ba->nOff;
+  st.n_pair_instances = ba->n_inst;
+  double lambda = 0, ni = 2;
+  int nBad = 0;
+  double currentChi = 0;
+  int reason = 0;
+  bool have_chi = false;
+  int rc = CCM_OK;
+  const bool empty = (ba->n_act_edges == 0);
+  for (int it = 0; it < opt.max_iters && !empty; it++) {
+    if (stop_flag && *stop_flag) { reason = 1; break; }
+    // computeActiveErrors + activeRobustChi2 — equal to the chi2 of the last accepted state, which the
+    // previous iteration already evaluated (same state => same value); only iteration 0 needs a pass.
+    if (!have_chi) { if ((rc = eval_chi2(ba, &currentChi))) return rc; have_chi = true; st.chi2_initial = currentChi; }
+    const double iniChi = currentChi;
+    if ((rc = build_system(ba))) return rc;
+    if (it == 0) {
+      if (opt.lambda_init > 0) lambda = opt.lambda_init;
+      else { double md = 0; if ((rc = max_diag(ba, &md))) return rc; lambda = 1e-5 * md; }
+      ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      double tempChi = 0, scale = 0; bool ok2 = true; int pit = 0;
+      if ((rc = lm_trial(ba, lambda, opt, &tempChi, &scale, &ok2, &pit))) return rc;
+      st.pcg_iters += pit;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      scale += 1e-3;
+      rho /= scale;
+      if (opt.verbose && ba->rank == 0)
+        fprintf(stderr, "[ccm_ba] it %d trial %d lambda %.6g chi %.9g -> %.9g rho %.4g pcg %d%s\n", it, qmax, lambda, currentChi, tempChi, rho, pit, ok2 ? "" : " (solver failed)");
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        ba->cur ^= 1;                        // discardTop(): the trial state becomes the estimate
+      } else {
+        lambda *= ni; ni *= 2;               // pop(): the estimate stays
+      }
+      qmax++; st.lm_trials++;
+    } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+    st.iters_done++;
+    if (qmax == 10 || rho == 0) { reason = 2; break; }
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) { reason = 3; break; }
+  }
+  st.stop_reason = reason;
+  st.chi2_final = currentChi;
+  st.lambda_final = lambda;
+  st.ms_iters = now_ms() - t_start;
+  st.ms_total = st.ms_iters + st.ms_setup;
+  if (stats) *stats = st;
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge, uint8_t* depth_pos) {
+  if (!ba) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (cam_qt) {
+    std::vector<double> cam(7 * (size_t)ba->n_cam);
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(cam.data(), d.cam[ba->cur], cam.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ba->Cp; i++) std::memcpy(cam_qt + 7 * (size_t)ba->slot_cam[i], &cam[7 * (size_t)ba->slot_cam[i]], 7 * sizeof(double));
+  }
+  if (pt_xyz && ba->Lp) {
+    std::vector<double> pts(3 * (size_t)ba->Lp);
+    if (ba->nranks > 1) {
+      CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pt_full, 0, pts.size() * sizeof(double), ctx->stream));
+      if (ba->Lloc) hipLaunchKernelGGL(ba_scatter_points, dim3(ccm_div_up(ba->Lloc, kTPB)), dim3(kTPB), 0, ctx->stream, ba->d_pt_full, d.pt[ba->cur], ba->d_own_slot, ba->Lloc);
+      RC(ccm_allreduce_f64(ctx, ba->d_pt_full, pts.size()));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), ba->d_pt_full, pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), d.pt[ba->cur], pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < ba->Lp; l++) std::memcpy(pt_xyz + 3 * (size_t)ba->slot_pt[l], &pts[3 * (size_t)l], 3 * sizeof(double));
+  }
+  if ((chi2_per_edge || depth_pos) && ba->Eloc) {
+    // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors);
+    // isDepthPositive(): recomputed at the final estimate.  Only the own (shard-local) active edges are written.
+    std::vector<double> c2(ba->Eloc);
+    std::vector<uint8_t> dp(ba->Eloc);
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(c2.data(), d.edge_chi2, c2.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (depth_pos) {
+      // depth at the final estimate: run the chi2-only pass into scratch copies
+      double* save = nullptr;
+      CCM_HIP_CHECK(ctx, hipMalloc(&save, sizeof(double) * ba->Eloc));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(save, d.edge_chi2, sizeof(double) * ba->Eloc, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(dp.data(), d.edge_depth, dp.size(), hipMemcpyDeviceToHost, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d.edge_chi2, save, sizeof(double) * ba->Eloc, hipMemcpyDeviceToDevice, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      hipFree(save);
+    }
+    for (int k = 0; k < ba->Eloc; k++) {
+      if (chi2_per_edge) chi2_per_edge[ba->loc_edge_orig[k]] = c2[k];
+      if (depth_pos) depth_pos[ba->loc_edge_orig[k]] = dp[k];
+    }
+  }
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_options* opt,
+                               const volatile unsigned char* stop_flag, double* chi2_per_edge, uint8_t* depth_pos,
+                               ccm_ba_stats* stats) {
+  ccm_ba* ba = nullptr;
+  int rc = ccm_ba_create(ctx, prob, ctx ? ctx->comm_rank : 0, ctx ? ctx->comm_nranks : 1, &ba);
+  if (rc) return rc;
+  rc = ccm_ba_run(ba, opt, stop_flag, stats);
+  if (rc == CCM_OK) rc = ccm_ba_download(ba, prob->cam_qt, prob->pt_xyz, chi2_per_edge, depth_pos);
+  ccm_ba_destroy(ba);
+  return rc;
+}

@@ -1,0 +1,53 @@
+// common.h — internal helpers shared by the HIP translation units of libccm_hip.so.
+// gfx950 only: wave = 64 lanes, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/ccm_hip.h"
+
+struct ccm_prof_slot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  int64_t launches = 0;
+  double total_ms = 0.0;
+};
+
+struct ccm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // event pool for per-kernel timing
+  int prof_class = -2;  // -2 none, -1 all
+  ccm_prof_slot prof[CCM_K_COUNT];
+  std::vector<hipEvent_t> ev_pool;
+  // RCCL communicator (opaque; ncclComm_t) for the sharded global BA
+  void* comm = nullptr;
+  int comm_rank = 0, comm_nranks = 1;
+  // reusable staging buffers
+  void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
+};
+
+int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
+
+#define CCM_HIP_CHECK(ctx, expr)                                                        \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return ccm_set_error((ctx), CCM_E_HIP,                                            \
+                           std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +   \
+                               __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
+  } while (0)
+
+// RAII-ish bracket used around a kernel launch when profiling of its class is enabled.
+struct ccm_prof_scope {
+  ccm_ctx* ctx; int cls; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
+  ccm_prof_scope(ccm_ctx* c, int k);
+  ~ccm_prof_scope();
+};
+
+// device scratch that grows on demand (never shrinks); contents undefined
+int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out);
+
+static inline int ccm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,162 @@
+// ctx.hip — context, error reporting, device memory wrappers, event-based kernel timing.
+#include "common.h"
+#include <cstring>
+
+static std::mutex g_err_mu;
+static std::string g_last_err;
+
+int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_last_err = msg;
+  return code;
+}
+
+extern "C" const char* ccm_version(void) { return "ccm_hip 0.1 gfx950"; }
+
+extern "C" int ccm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char* ccm_last_error(const ccm_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  return g_last_err.c_str();
+}
+
+extern "C" int ccm_ctx_create(int device_id, ccm_ctx** out) {
+  if (!out) return ccm_set_error(nullptr, CCM_E_ARG, "ccm_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return ccm_set_error(nullptr, CCM_E_NOGPU,
+                         "ccm_ctx_create: no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= n)
+    return ccm_set_error(nullptr, CCM_E_ARG, "ccm_ctx_create: device_id out of range");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+    return ccm_set_error(nullptr, CCM_E_HIP, "ccm_ctx_create: hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return ccm_set_error(nullptr, CCM_E_NOGPU,
+                         std::string("ccm_ctx_create: device is ") + prop.gcnArchName +
+                             ", kernels are built for gfx950 only");
+  ccm_ctx* c = new ccm_ctx();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return ccm_set_error(nullptr, CCM_E_HIP, "ccm_ctx_create: stream creation failed");
+  }
+  *out = c;
+  return CCM_OK;
+}
+
+extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  ccm_comm_destroy(ctx);
+  for (auto& s : ctx->prof)
+    for (auto& p : s.pending) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int ccm_ctx_sync(ccm_ctx* ctx) {
+  if (!ctx) return CCM_E_ARG;
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+extern "C" int ccm_dev_alloc(ccm_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return CCM_E_ARG;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  CCM_HIP_CHECK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+  return CCM_OK;
+}
+extern "C" int ccm_dev_free(ccm_ctx* ctx, void* dptr) {
+  if (!ctx) return CCM_E_ARG;
+  if (dptr) CCM_HIP_CHECK(ctx, hipFree(dptr));
+  return CCM_OK;
+}
+extern "C" int ccm_memcpy_h2d(ccm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return CCM_E_ARG;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+extern "C" int ccm_memcpy_d2h(ccm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return CCM_E_ARG;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->d_scratch_bytes) {
+    if (ctx->d_scratch) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_scratch); ctx->d_scratch = nullptr; }
+    size_t nb = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ctx->d_scratch, nb);
+    if (e != hipSuccess) { ctx->d_scratch_bytes = 0; return ccm_set_error(ctx, CCM_E_HIP, "scratch hipMalloc failed"); }
+    ctx->d_scratch_bytes = nb;
+  }
+  *out = ctx->d_scratch;
+  return CCM_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------
+static hipEvent_t take_event(ccm_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+ccm_prof_scope::ccm_prof_scope(ccm_ctx* c, int k) : ctx(c), cls(k) {
+  on = c && (c->prof_class == -1 || c->prof_class == k);
+  if (!on) return;
+  e0 = take_event(ctx); e1 = take_event(ctx);
+  hipEventRecord(e0, ctx->stream);
+}
+ccm_prof_scope::~ccm_prof_scope() {
+  if (!on) return;
+  hipEventRecord(e1, ctx->stream);
+  ctx->prof[cls].pending.emplace_back(e0, e1);
+}
+
+extern "C" int ccm_prof_enable(ccm_ctx* ctx, int kernel_class) {
+  if (!ctx || kernel_class < -2 || kernel_class >= CCM_K_COUNT) return CCM_E_ARG;
+  ctx->prof_class = kernel_class;
+  return CCM_OK;
+}
+
+static void drain(ccm_ctx* ctx, ccm_prof_slot& s) {
+  for (auto& p : s.pending) {
+    hipEventSynchronize(p.second);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { s.total_ms += ms; s.launches++; }
+    ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second);
+  }
+  s.pending.clear();
+}
+
+extern "C" int ccm_prof_reset(ccm_ctx* ctx) {
+  if (!ctx) return CCM_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  for (auto& s : ctx->prof) { drain(ctx, s); s.launches = 0; s.total_ms = 0.0; }
+  return CCM_OK;
+}
+
+extern "C" int ccm_prof_read(ccm_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms) {
+  if (!ctx || kernel_class < 0 || kernel_class >= CCM_K_COUNT) return CCM_E_ARG;
+  hipStreamSynchronize(ctx->stream);
+  drain(ctx, ctx->prof[kernel_class]);
+  if (launches) *launches = ctx->prof[kernel_class].launches;
+  if (total_ms) *total_ms = ctx->prof[kernel_class].total_ms;
+  return CCM_OK;
+}

@@ -1,0 +1,251 @@
+// hamming.hip — 256-bit Hamming distance kernels (gfx950, wave64).
+//
+// Reference: ORBmatcher::DescriptorDistance (cslam/src/ORBmatcher.cpp:1653-1669) evaluated
+// inside the best / second-best scans of the Search* methods (e.g. :102-134, :220-245,
+// :1408-1433).  Integer work, bit-exact.
+//
+// Design notes (MI355X):
+//  * dense Q x T: one lane owns one query (8 dwords in VGPRs).  The target row index is
+//    wave-uniform, so target words arrive through the scalar cache (s_load_dwordx8) and the
+//    inner step is 8 x (v_xor_b32 with an SGPR operand + v_bcnt_u32_b32 accumulate) — no LDS
+//    traffic at all.  T is split across blockIdx.y so that small problems still put >= 1
+//    wave on every SIMD; partial (best,second) pairs are merged in split order, which keeps
+//    the reference's "first minimum wins" tie rule (lowest target index).
+//  * CSR (windowed) search: one wave per query, lanes over that query's candidate list; the
+//    query words are wave-uniform (scalar loads), each lane gathers one 32-byte target row
+//    (2 x global_load_dwordx4).  Per-slot distances are written for the host-side ordered
+//    resolution pass; best/second come from two wave min-reductions over (dist,slot) keys.
+#include "common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int ham256(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
+  int d = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]);
+  return d;
+}
+
+// partial results layout: [split][Q]
+__global__ __launch_bounds__(256) void hamming_dense_partial(
+    const uint32_t* __restrict__ q, int Q, const uint32_t* __restrict__ t, int T, int t_per_split,
+    int32_t* __restrict__ p_best_idx, int32_t* __restrict__ p_best, int32_t* __restrict__ p_second) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  const int split = blockIdx.y;
+  const int t0 = split * t_per_split;
+  const int t1 = min(T, t0 + t_per_split);
+  uint32_t qa[8];
+  if (qi < Q) {
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+    uint4 lo = qp[0], hi = qp[1];
+    qa[0] = lo.x; qa[1] = lo.y; qa[2] = lo.z; qa[3] = lo.w;
+    qa[4] = hi.x; qa[5] = hi.y; qa[6] = hi.z; qa[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qa[k] = 0;
+  }
+  int best = 256, second = 256, best_idx = -1;
+  for (int ti = t0; ti < t1; ++ti) {       // ti is wave-uniform -> scalar loads of the target row
+    const uint32_t* tp = t + (size_t)ti * 8;
+    const int d = ham256(qa, tp);
+    if (d < best) { second = best; best = d; best_idx = ti; }
+    else if (d < second) { second = d; }
+  }
+  if (qi < Q) {
+    const size_t o = (size_t)split * Q + qi;
+    p_best_idx[o] = best_idx; p_best[o] = best; p_second[o] = second;
+  }
+}
+
+__global__ __launch_bounds__(256) void hamming_dense_merge(
+    int Q, int n_split, const int32_t* __restrict__ p_best_idx, const int32_t* __restrict__ p_best,
+    const int32_t* __restrict__ p_second, int32_t* __restrict__ best_idx, int32_t* __restrict__ best,
+    int32_t* __restrict__ second) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= Q) return;
+  int b = 256, s = 256, bi = -1;
+  for (int sp = 0; sp < n_split; ++sp) {   // ascending target ranges: strict '<' keeps the first minimum
+    const size_t o = (size_t)sp * Q + qi;
+    const int pb = p_best[o], ps = p_second[o];
+    if (pb < b) { s = min(b, ps); b = pb; bi = p_best_idx[o]; }
+    else        { s = min(s, pb); }
+  }
+  best_idx[qi] = bi; best[qi] = b; second[qi] = s;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, kWave));
+  return v;
+}
+
+// one wave per query; blockDim = 256 -> 4 queries per workgroup
+__global__ __launch_bounds__(256) void hamming_csr_kernel(
+    const uint32_t* __restrict__ q, int Q, const uint32_t* __restrict__ t,
+    const int32_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx,
+    uint16_t* __restrict__ cand_dist, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+    int32_t* __restrict__ second_dist) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
+  if (qi >= Q) return;
+  const int c0 = cand_off[qi], c1 = cand_off[qi + 1];
+  uint32_t qa[8];
+  {
+    const uint32_t* qp = q + (size_t)qi * 8;   // wave-uniform address
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qa[k] = qp[k];
+  }
+  // running (best, second) as keys (dist << 20 | slot-in-list); slot < 2^20 is checked on the host
+  uint32_t kbest = 0xFFFFFFFFu, ksecond = 0xFFFFFFFFu;
+  for (int base = c0; base < c1; base += kWave) {
+    const int s = base + lane;
+    uint32_t key = 0xFFFFFFFFu;
+    if (s < c1) {
+      const int ti = cand_idx[s];
+      const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)ti * 8);
+      const uint4 lo = tp[0], hi = tp[1];
+      int d = __builtin_popcount(qa[0] ^ lo.x) + __builtin_popcount(qa[1] ^ lo.y) +
+              __builtin_popcount(qa[2] ^ lo.z) + __builtin_popcount(qa[3] ^ lo.w) +
+              __builtin_popcount(qa[4] ^ hi.x) + __builtin_popcount(qa[5] ^ hi.y) +
+              __builtin_popcount(qa[6] ^ hi.z) + __builtin_popcount(qa[7] ^ hi.w);
+      if (cand_dist) cand_dist[s] = (uint16_t)d;
+      key = ((uint32_t)d << 20) | (uint32_t)(s - c0);
+    }
+    if (best_idx) {
+      const uint32_t m1 = wave_min_u32(key);
+      const uint32_t key2 = (key == m1) ? 0xFFFFFFFFu : key;   // keys are unique (slot bits)
+      const uint32_t m2 = wave_min_u32(key2);
+      // merge chunk (m1,m2) after running (kbest,ksecond): smaller key = smaller dist, then earlier slot
+      if (m1 < kbest) { ksecond = min(kbest, m2); kbest = m1; }
+      else            { ksecond = min(ksecond, m1); }
+    }
+  }
+  if (best_idx && lane == 0) {
+    if (kbest == 0xFFFFFFFFu) { best_idx[qi] = -1; best_dist[qi] = 256; second_dist[qi] = 256; }
+    else {
+      best_idx[qi] = cand_idx[c0 + (int)(kbest & 0xFFFFFu)];
+      best_dist[qi] = (int)(kbest >> 20);
+      second_dist[qi] = (ksecond == 0xFFFFFFFFu) ? 256 : (int)(ksecond >> 20);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ccm_hamming_dense_best2_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
+                                           int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist) {
+  if (!ctx || Q < 0 || T < 0) return ccm_set_error(ctx, CCM_E_ARG, "hamming_dense: bad args");
+  if (Q == 0) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int qblocks = ccm_div_up(Q, 256);
+  // choose the T split so that the grid has >= ~2048 waves when the problem allows it
+  int n_split = 1;
+  if (T > 0) {
+    const int waves_q = ccm_div_up(Q, 64);
+    n_split = std::max(1, std::min(ccm_div_up(T, 64), ccm_div_up(2048, waves_q)));
+  }
+  const int t_per_split = T > 0 ? ccm_div_up(T, n_split) : 0;
+  if (T > 0) n_split = ccm_div_up(T, t_per_split);
+  void* scratch = nullptr;
+  const size_t part = (size_t)n_split * Q * sizeof(int32_t);
+  int rc = ccm_scratch(ctx, 3 * part, &scratch);
+  if (rc) return rc;
+  int32_t* p_idx = (int32_t*)scratch;
+  int32_t* p_best = p_idx + (size_t)n_split * Q;
+  int32_t* p_second = p_best + (size_t)n_split * Q;
+  {
+    ccm_prof_scope ps(ctx, CCM_K_HAMMING_DENSE);
+    hipLaunchKernelGGL(hamming_dense_partial, dim3(qblocks, n_split), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)d_q, Q, (const uint32_t*)d_t, T, t_per_split, p_idx, p_best, p_second);
+    hipLaunchKernelGGL(hamming_dense_merge, dim3(qblocks), dim3(256), 0, ctx->stream, Q, n_split, p_idx, p_best,
+                       p_second, d_best_idx, d_best_dist, d_second_dist);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+extern "C" int ccm_hamming_dense_best2(ccm_ctx* ctx, const uint8_t* q, int Q, const uint8_t* t, int T,
+                                       int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  if (!ctx || Q < 0 || T < 0 || (Q && (!q || !best_idx || !best_dist || !second_dist)) || (T && !t))
+    return ccm_set_error(ctx, CCM_E_ARG, "hamming_dense: bad args");
+  if (Q == 0) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint8_t *d_q = nullptr, *d_t = nullptr; int32_t* d_out = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_q, (size_t)Q * 32));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)std::max(T, 1) * 32));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)Q * 3 * sizeof(int32_t)));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (T) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
+  int rc = ccm_hamming_dense_best2_dev(ctx, d_q, Q, d_t, T, d_out, d_out + Q, d_out + 2 * (size_t)Q);
+  if (rc == CCM_OK) {
+    hipMemcpyAsync(best_idx, d_out, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(best_dist, d_out + Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(second_dist, d_out + 2 * (size_t)Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_dense: ") + hipGetErrorString(e));
+  }
+  hipFree(d_q); hipFree(d_t); hipFree(d_out);
+  return rc;
+}
+
+extern "C" int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
+                                   const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
+                                   uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist,
+                                   int32_t* d_second_dist) {
+  (void)T; (void)n_cand;
+  if (!ctx || Q < 0) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: bad args");
+  if (d_best_idx && (!d_best_dist || !d_second_dist)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: best2 outputs must be all set or all NULL");
+  if (Q == 0) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  {
+    ccm_prof_scope ps(ctx, CCM_K_HAMMING_CSR);
+    hipLaunchKernelGGL(hamming_csr_kernel, dim3(ccm_div_up(Q, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q,
+                       (const uint32_t*)d_t, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+extern "C" int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint8_t* t, int T,
+                               const int32_t* cand_off, const int32_t* cand_idx, uint16_t* cand_dist,
+                               int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  if (!ctx || Q < 0 || T < 0 || (Q && (!q || !cand_off)))
+    return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: bad args");
+  if (Q == 0) return CCM_OK;
+  const int64_t n_cand = cand_off[Q];
+  if (n_cand < 0 || (n_cand && (!cand_idx || !t))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: bad candidate list");
+  for (int i = 0; i < Q; ++i) {
+    const int64_t len = (int64_t)cand_off[i + 1] - cand_off[i];
+    if (len < 0 || len >= (1 << 20)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: candidate list length out of range");
+  }
+  for (int64_t s = 0; s < n_cand; ++s)
+    if (cand_idx[s] < 0 || cand_idx[s] >= T) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: candidate index out of range");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint8_t *d_q = nullptr, *d_t = nullptr; int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr; uint16_t* d_dist = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_q, (size_t)Q * 32));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)std::max(T, 1) * 32));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_off, (size_t)(Q + 1) * 4));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_idx, (size_t)std::max<int64_t>(n_cand, 1) * 4));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_dist, (size_t)std::max<int64_t>(n_cand, 1) * 2));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)Q * 3 * 4));
+  hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (T) hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (n_cand) hipMemcpyAsync(d_idx, cand_idx, (size_t)n_cand * 4, hipMemcpyHostToDevice, ctx->stream);
+  int rc = ccm_hamming_csr_dev(ctx, d_q, Q, d_t, T, d_off, d_idx, n_cand, d_dist, best_idx ? d_out : nullptr,
+                               best_idx ? d_out + Q : nullptr, best_idx ? d_out + 2 * (size_t)Q : nullptr);
+  if (rc == CCM_OK) {
+    if (cand_dist && n_cand) hipMemcpyAsync(cand_dist, d_dist, (size_t)n_cand * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (best_idx) {
+      hipMemcpyAsync(best_idx, d_out, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(best_dist, d_out + Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(second_dist, d_out + 2 * (size_t)Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_csr: ") + hipGetErrorString(e));
+  }
+  hipFree(d_q); hipFree(d_t); hipFree(d_off); hipFree(d_idx); hipFree(d_dist); hipFree(d_out);
+  return rc;
+}

@@ -1,0 +1,71 @@
+"""Hamming / window-search entry points of the C ABI (ORBmatcher path).
+
+Mirrors the pieces of cslam::ORBmatcher that are data-parallel (cslam/src/ORBmatcher.cpp):
+DescriptorDistance (:1653-1669) and the best / second-best scans of the Search* methods.  The
+ordered resolution pass that reproduces the reference's sequential "claimed feature" semantics
+(ORBmatcher.cpp:113-115, 1417-1419) lives in the C++ host shim (ccm_slam_amd/host/); the Python
+functions here are the harness used by tests and bench.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import Context, check, lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def hamming_dense_best2(ctx: Context, q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    Q, T = q.shape[0], t.shape[0]
+    bi, bd, sd = (np.empty(Q, np.int32) for _ in range(3))
+    check(lib().ccm_hamming_dense_best2(ctx.handle, _p(q), Q, _p(t), T, _p(bi), _p(bd), _p(sd)), ctx.handle)
+    return bi, bd, sd
+
+
+def hamming_csr(ctx: Context, q, t, cand_off, cand_idx, want_best2: bool = True):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    cand_off = np.ascontiguousarray(cand_off, np.int32)
+    cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+    Q, T = q.shape[0], t.shape[0]
+    dist = np.empty(max(cand_idx.size, 1), np.uint16)
+    if want_best2:
+        bi, bd, sd = (np.empty(Q, np.int32) for _ in range(3))
+    else:
+        bi = bd = sd = None
+    check(lib().ccm_hamming_csr(ctx.handle, _p(q), Q, _p(t), T, _p(cand_off), _p(cand_idx), _p(dist), _p(bi), _p(bd),
+                                _p(sd)), ctx.handle)
+    return dist[:cand_idx.size], bi, bd, sd
+
+
+class DenseMatcherDev:
+    """Device-resident dense best/second search for bench.py (inputs uploaded once)."""
+
+    def __init__(self, ctx: Context, q: np.ndarray, t: np.ndarray):
+        self.ctx = ctx
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        self.Q, self.T = q.shape[0], t.shape[0]
+        self.d_q, self.d_t = ctx.upload(q), ctx.upload(t)
+        self.d_out = ctx.alloc(max(self.Q, 1) * 12)
+
+    def run(self):
+        Q = self.Q
+        check(lib().ccm_hamming_dense_best2_dev(self.ctx.handle, C.c_void_p(self.d_q), Q, C.c_void_p(self.d_t), self.T,
+                                                C.c_void_p(self.d_out), C.c_void_p(self.d_out + 4 * Q),
+                                                C.c_void_p(self.d_out + 8 * Q)), self.ctx.handle)
+
+    def result(self):
+        out = np.empty(3 * self.Q, np.int32)
+        self.ctx.d2h(out, self.d_out)
+        return out[:self.Q], out[self.Q:2 * self.Q], out[2 * self.Q:]
+
+    def close(self):
+        for p in (self.d_q, self.d_t, self.d_out):
+            self.ctx.free(p)

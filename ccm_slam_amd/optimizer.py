@@ -1,0 +1,135 @@
+"""Bundle-adjustment / pose-optimisation entry points of the C ABI (Optimizer path).
+
+Python harness over ccm_ba_* / ccm_pose_optimize (include/ccm_hip.h), mirroring the static methods
+of cslam::Optimizer on flat problems:
+  local_bundle_adjustment  <- Optimizer::LocalBundleAdjustmentClient (cslam/src/Optimizer.cpp:349-644)
+  global_bundle_adjustment <- Optimizer::MapFusionGBA                (cslam/src/Optimizer.cpp:646-859)
+  pose_optimization        <- Optimizer::PoseOptimizationClient      (cslam/src/Optimizer.cpp:215-347)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import BAOptions, BAProblem, BAStats, Context, check, lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p).value if a is not None else None
+
+
+class BAHandle:
+    """Staged BA (ccm_ba_create / run / download).  Keeps the flattened arrays alive."""
+
+    def __init__(self, ctx: Context, prob: dict, rank: int = 0, nranks: int = 1):
+        self.ctx = ctx
+        self.prob = prob
+        self._keep = {
+            "cam_qt": np.ascontiguousarray(prob["cam_qt"], np.float64).copy(),
+            "cam_fixed": np.ascontiguousarray(prob["cam_fixed"], np.uint8),
+            "cam_K": np.ascontiguousarray(prob["cam_K"], np.float64),
+            "pt_xyz": np.ascontiguousarray(prob["pt_xyz"], np.float64).copy(),
+            "e_cam": np.ascontiguousarray(prob["e_cam"], np.int32),
+            "e_pt": np.ascontiguousarray(prob["e_pt"], np.int32),
+            "e_obs": np.ascontiguousarray(prob["e_obs"], np.float64),
+            "e_info": np.ascontiguousarray(prob["e_info"], np.float64),
+        }
+        lvl = prob.get("e_level")
+        self._keep["e_level"] = np.ascontiguousarray(lvl, np.uint8) if lvl is not None else None
+        k = self._keep
+        self.cprob = BAProblem(int(prob["n_cam"]), int(prob["n_pt"]), int(prob["n_edge"]), _vp(k["cam_qt"]),
+                               _vp(k["cam_fixed"]), _vp(k["cam_K"]), _vp(k["pt_xyz"]), _vp(k["e_cam"]), _vp(k["e_pt"]),
+                               _vp(k["e_obs"]), _vp(k["e_info"]), _vp(k["e_level"]), float(prob["huber_delta"]))
+        self._h = C.c_void_p()
+        check(lib().ccm_ba_create(ctx.handle, C.byref(self.cprob), int(rank), int(nranks), C.byref(self._h)), ctx.handle)
+
+    def reset(self):
+        check(lib().ccm_ba_reset_state(self._h, C.c_void_p(_vp(self._keep["cam_qt"])), C.c_void_p(_vp(self._keep["pt_xyz"]))),
+              self.ctx.handle)
+
+    def run(self, max_iters: int, pcg_max_iters: int = 0, pcg_rel_tol: float = 0.0, lambda_init: float = 0.0,
+            verbose: int = 0) -> BAStats:
+        opt = BAOptions(int(max_iters), int(pcg_max_iters), float(pcg_rel_tol), float(lambda_init), int(verbose))
+        st = BAStats()
+        check(lib().ccm_ba_run(self._h, C.byref(opt), None, C.byref(st)), self.ctx.handle)
+        return st
+
+    def download(self, chi2_in=None):
+        cam = self._keep["cam_qt"].copy()
+        pts = self._keep["pt_xyz"].copy()
+        ne = int(self.prob["n_edge"])
+        chi2 = np.zeros(ne, np.float64) if chi2_in is None else np.ascontiguousarray(chi2_in, np.float64).copy()
+        dpos = np.zeros(ne, np.uint8)
+        check(lib().ccm_ba_download(self._h, C.c_void_p(_vp(cam)), C.c_void_p(_vp(pts)), C.c_void_p(_vp(chi2)),
+                                    C.c_void_p(_vp(dpos))), self.ctx.handle)
+        return cam, pts, chi2, dpos
+
+    def counts(self):
+        v = [C.c_int64() for _ in range(5)]
+        check(lib().ccm_ba_counts(self._h, *[C.byref(x) for x in v]), self.ctx.handle)
+        return dict(zip(("edges", "points", "free_cams", "blocks", "pairs"), (x.value for x in v)))
+
+    def close(self):
+        if self._h:
+            lib().ccm_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bundle_adjustment(ctx: Context, prob: dict, max_iters: int, chi2_in=None, **kw):
+    """optimizer.initializeOptimization(0); optimizer.optimize(max_iters) on the flat problem.
+    Returns (cam_qt, pt_xyz, chi2_per_edge, depth_pos, stats)."""
+    h = BAHandle(ctx, prob)
+    try:
+        st = h.run(max_iters, **kw)
+        cam, pts, chi2, dpos = h.download(chi2_in)
+    finally:
+        h.close()
+    return cam, pts, chi2, dpos, st
+
+
+def global_bundle_adjustment(ctx: Context, prob: dict, n_iterations: int = 20, **kw):
+    """Optimizer::MapFusionGBA numerics (Optimizer.cpp:786-797): one optimize(nIterations) pass,
+    Huber sqrt(5.99) on every edge."""
+    return bundle_adjustment(ctx, prob, n_iterations, **kw)
+
+
+def local_bundle_adjustment(ctx: Context, prob: dict, **kw):
+    """Optimizer::LocalBundleAdjustmentClient numerics (Optimizer.cpp:536-602): optimize(5) with Huber
+    sqrt(5.991); edges with chi2 > 5.991 or non-positive depth go to level 1 and the kernel is
+    dropped; optimize(10); finally every edge with chi2 > 5.991 or non-positive depth is reported
+    for erasure (level-1 edges keep the chi2 of the first pass, as g2o leaves their _error alone).
+    Returns (cam_qt, pt_xyz, to_erase mask, stats1, stats2)."""
+    p1 = dict(prob)
+    p1["huber_delta"] = float(np.float32(np.sqrt(np.float32(5.991))))
+    cam, pts, chi2, dpos, st1 = bundle_adjustment(ctx, p1, 5, **kw)
+    level = np.ascontiguousarray(prob.get("e_level", np.zeros(prob["n_edge"], np.uint8)), np.uint8).copy()
+    active = level == 0
+    out = active & ((chi2 > 5.991) | (dpos == 0))
+    level[out] = 1
+    p2 = dict(prob)
+    p2.update(cam_qt=cam, pt_xyz=pts, e_level=level, huber_delta=0.0)
+    cam2, pts2, chi2b, dpos2, st2 = bundle_adjustment(ctx, p2, 10, chi2_in=chi2, **kw)
+    erase = active & ((chi2b > 5.991) | (dpos2 == 0))
+    return cam2, pts2, erase, st1, st2
+
+
+def pose_optimization(ctx: Context, cam_qt, Xw, obs, info, K):
+    cam = np.ascontiguousarray(cam_qt, np.float64).copy()
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    info = np.ascontiguousarray(info, np.float64)
+    K = np.ascontiguousarray(K, np.float64)
+    n = Xw.shape[0]
+    outl = np.zeros(max(n, 1), np.uint8)
+    ninl = C.c_int(0)
+    check(lib().ccm_pose_optimize(ctx.handle, C.c_void_p(_vp(cam)), n, C.c_void_p(_vp(Xw)), C.c_void_p(_vp(obs)),
+                                  C.c_void_p(_vp(info)), C.c_void_p(_vp(K)), C.c_void_p(_vp(outl)), C.byref(ninl)),
+          ctx.handle)
+    return cam, outl[:n], ninl.value

@@ -1,0 +1,211 @@
+/*
+ * ccm_hip.h — C ABI of libccm_hip.so, the MI355X (gfx950) back end for CCM-SLAM's
+ * ORB-extract / Hamming-match / bundle-adjustment hot path.
+ *
+ * The reference has no FFI for this path: cslam::ORBextractor, cslam::ORBmatcher and
+ * cslam::Optimizer are concrete C++ classes (cslam/include/cslam/ORBextractor.h:103-138,
+ * ORBmatcher.h:100-139, Optimizer.h:84-112).  The drop-in replaces their three translation
+ * units with shims (ccm_slam_amd/host/) that flatten the shared_ptr graph into the POD
+ * buffers below and call this ABI.  Every entry point cites the reference code it stands for.
+ *
+ * Conventions
+ *   - plain C, POD only, caller-owned memory, no exceptions across the boundary;
+ *   - return value: 0 = ok, <0 = error (CCM_E_*); ccm_last_error() gives a message;
+ *   - handle based and re-entrant: one ccm_ctx per calling thread (own HIP stream);
+ *     a ctx must not be used from two threads at once (reference threading: SURVEY §8b);
+ *   - "host" entry points take host pointers and do their own H2D/D2H; "_dev" entry points
+ *     take device pointers obtained from ccm_dev_alloc (used by bench.py so that inputs are
+ *     resident in HBM when the timed region starts).
+ */
+#ifndef CCM_HIP_H
+#define CCM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCM_OK            0
+#define CCM_E_ARG        -1   /* bad argument                                   */
+#define CCM_E_HIP        -2   /* HIP runtime error (message in ccm_last_error)   */
+#define CCM_E_NOGPU      -3   /* no gfx950 device visible: the product never falls back to CPU */
+#define CCM_E_NUMERIC    -4   /* reduced system not positive definite / NaN      */
+#define CCM_E_COMM       -5   /* RCCL error                                      */
+#define CCM_E_STATE      -6   /* call sequence error                             */
+
+typedef struct ccm_ctx ccm_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int         ccm_ctx_create(int device_id, ccm_ctx** out);
+void        ccm_ctx_destroy(ccm_ctx* ctx);
+const char* ccm_last_error(const ccm_ctx* ctx);   /* ctx may be NULL: last global error */
+int         ccm_ctx_sync(ccm_ctx* ctx);           /* hipStreamSynchronize on the ctx stream */
+int         ccm_device_count(void);
+/* library/build identification, e.g. "ccm_hip 0.1 gfx950" */
+const char* ccm_version(void);
+
+/* device memory owned by the ctx' device (thin wrappers so callers need no HIP headers) */
+int ccm_dev_alloc(ccm_ctx* ctx, size_t bytes, void** dptr);
+int ccm_dev_free(ccm_ctx* ctx, void* dptr);
+int ccm_memcpy_h2d(ccm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int ccm_memcpy_d2h(ccm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- per-kernel timing with HIP events on the ctx stream ------------------------------
+ * bench.py's roofline leg: when enabled, every launch of the selected kernel class is
+ * bracketed by hipEventRecord on the launching stream; ccm_prof_read drains the events and
+ * returns launches and summed milliseconds since the last ccm_prof_reset.               */
+enum {
+  CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
+  CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
+  CCM_K_BA_SCHUR_DIAG, CCM_K_BA_SCHUR_OFF, CCM_K_BA_PCG_SPMV, CCM_K_BA_PCG_UPDATE,
+  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_COUNT
+};
+int ccm_prof_enable(ccm_ctx* ctx, int kernel_class /* -1: all, -2: none */);
+int ccm_prof_reset(ccm_ctx* ctx);
+int ccm_prof_read(ccm_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms);
+
+/* ---- 256-bit Hamming ------------------------------------------------------------------
+ * Replaces ORBmatcher::DescriptorDistance (cslam/src/ORBmatcher.cpp:1653-1669) and the
+ * best / second-best scans inside the Search* methods (ORBmatcher.cpp:102-134, 220-245,
+ * 1408-1433 ...).  Descriptors are rows of 32 bytes (cv::Mat N x 32 CV_8U, Frame.h:138).
+ * Tie rule everywhere: strict '<' in candidate order, i.e. the FIRST minimum wins
+ * (ORBmatcher.cpp:121,129).                                                              */
+
+/* dense brute force: for every query row the best and second-best target over ALL T rows,
+ * scanned in ascending target index.  best_idx = -1 / dists = 256 when T == 0.           */
+int ccm_hamming_dense_best2(ccm_ctx* ctx, const uint8_t* q, int Q, const uint8_t* t, int T,
+                            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+int ccm_hamming_dense_best2_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
+                                int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
+
+/* windowed / bucketed search (reference semantics): query i is compared with the ordered
+ * candidate list cand_idx[cand_off[i] .. cand_off[i+1]) (the order GetFeaturesInArea
+ * produced, Frame.cpp:228-250).  cand_dist receives one distance per candidate slot — the
+ * host-side ordered resolution pass (claimed-feature skipping, ORBmatcher.cpp:113-115)
+ * consumes it.  best2 outputs are computed ignoring claims and may be NULL.             */
+int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint8_t* t, int T,
+                    const int32_t* cand_off, const int32_t* cand_idx,
+                    uint16_t* cand_dist,
+                    int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
+                        const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
+                        uint16_t* d_cand_dist,
+                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
+
+/* ---- ORB extraction -------------------------------------------------------------------
+ * Replaces ORBextractor::ORBextractor / operator() (cslam/src/ORBextractor.cpp:579-639,
+ * 1216-1278).  ccm_keypoint == cv::KeyPoint without class_id.                            */
+typedef struct { float x, y, size, angle, response; int32_t octave; } ccm_keypoint;
+typedef struct ccm_orb ccm_orb;
+
+int  ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, int nlevels,
+                    int ini_th_fast, int min_th_fast, ccm_orb** out);
+void ccm_orb_destroy(ccm_orb* orb);
+/* accessor mirrors of ORBextractor::GetScaleFactors() etc. (ORBextractor.h:114-136): fills
+ * up to nlevels floats; which: 0 scale, 1 inv scale, 2 sigma2, 3 inv sigma2.             */
+int  ccm_orb_get_table(const ccm_orb* orb, int which, float* out, int cap);
+int  ccm_orb_features_per_level(const ccm_orb* orb, int32_t* out, int cap);
+/* one frame, host buffers in and out.  kps/desc capacity must be >= nfeatures rows.
+ * pyramid_out (nullable): nlevels caller buffers receiving the un-bordered level images
+ * (mvImagePyramid, ORBextractor.h:138), each at least level_w*level_h bytes, row stride = level_w. */
+int  ccm_orb_extract(ccm_orb* orb, const uint8_t* img, int w, int h, int stride,
+                     ccm_keypoint* kps, uint8_t* desc, int cap, int* n_out,
+                     uint8_t* const* pyramid_out);
+int  ccm_orb_level_size(const ccm_orb* orb, int w, int h, int level, int* lw, int* lh);
+/* batch of frames already resident in HBM (d_imgs: n_frames images, tightly packed w*h each);
+ * outputs stay on the device: d_kps [n_frames][cap], d_desc [n_frames][cap][32],
+ * d_counts [n_frames].  Host octree selection (DistributeOctTree) runs between the two device
+ * phases exactly as in ccm_orb_extract.                                                   */
+int  ccm_orb_extract_batch_dev(ccm_orb* orb, const uint8_t* d_imgs, int n_frames, int w, int h,
+                               ccm_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
+/* intermediate products for parity tests (host copies; any pointer may be NULL):
+ * FAST score map and blurred image of one level of the LAST extracted frame.              */
+int  ccm_orb_debug_level(ccm_orb* orb, int level, uint8_t* score_out, uint8_t* blur_out);
+/* pre-octree FAST candidates of the last frame: returns count for the level, fills up to cap */
+int  ccm_orb_debug_candidates(ccm_orb* orb, int level, ccm_keypoint* out, int cap, int* n_out);
+
+/* ---- bundle adjustment ----------------------------------------------------------------
+ * Replaces the g2o machinery driven by Optimizer::BundleAdjustmentClient /
+ * LocalBundleAdjustmentClient / MapFusionGBA (cslam/src/Optimizer.cpp:40-212, 349-644,
+ * 646-859): BlockSolver_6_3 + OptimizationAlgorithmLevenberg + EdgeSE3ProjectXYZ + Huber
+ * (thirdparty/g2o/g2o/core/block_solver.hpp, optimization_algorithm_levenberg.cpp,
+ * types/types_six_dof_expmap.{h,cpp}, core/robust_kernel_impl.cpp).
+ * All state is f64.  cam_qt rows: qx qy qz qw tx ty tz (world -> camera, as g2o::SE3Quat). */
+typedef struct {
+  int32_t n_cam, n_pt, n_edge;
+  double*        cam_qt;     /* [n_cam*7]  in/out                                        */
+  const uint8_t* cam_fixed;  /* [n_cam]    1 = vertex->setFixed(true)                    */
+  const double*  cam_K;      /* [n_cam*4]  fx fy cx cy (e->fx.. come from the KF)        */
+  double*        pt_xyz;     /* [n_pt*3]   in/out                                        */
+  const int32_t* e_cam;      /* [n_edge]                                                 */
+  const int32_t* e_pt;       /* [n_edge]                                                 */
+  const double*  e_obs;      /* [n_edge*2] keypoint (undistorted) pixel                  */
+  const double*  e_info;     /* [n_edge]   invSigma2 (information = I2 * invSigma2)      */
+  const uint8_t* e_level;    /* [n_edge]   nullable; g2o edge level, only level 0 is optimised */
+  double         huber_delta;/* <= 0: no robust kernel                                   */
+} ccm_ba_problem;
+
+typedef struct {
+  int32_t max_iters;         /* optimizer.optimize(n)                                    */
+  int32_t pcg_max_iters;     /* <=0: default 1000                                        */
+  double  pcg_rel_tol;       /* <=0: default 1e-10 (on sqrt(r.z / r0.z0))                */
+  double  lambda_init;       /* <=0: tau * max diag(H), tau = 1e-5 (levenberg.cpp:166-180) */
+  int32_t verbose;
+} ccm_ba_options;
+
+typedef struct {
+  int32_t iters_done;        /* value optimize() would return                            */
+  int32_t lm_trials;         /* total inner trials                                       */
+  int32_t pcg_iters;         /* total PCG iterations                                     */
+  int32_t stop_reason;       /* 0 iters exhausted, 1 stop flag, 2 trials exhausted/rho==0, 3 chi2 stagnation, 4 solver failure */
+  double  chi2_initial, chi2_final, lambda_final;
+  double  ms_setup, ms_total, ms_iters;   /* host wall clock */
+  int32_t n_schur_blocks;    /* upper-triangular blocks incl. diagonal                   */
+  int64_t n_pair_instances;
+} ccm_ba_stats;
+
+typedef struct ccm_ba ccm_ba;
+
+/* one-shot: build structure, upload, optimise, write cam_qt/pt_xyz back.
+ * stop_flag (nullable) is the reference's bool* pbStopFlag, polled between LM trials.
+ * chi2_per_edge (nullable, [n_edge]) = e->chi2() at the final estimate; depth_pos (nullable,
+ * [n_edge]) = e->isDepthPositive().                                                      */
+int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_options* opt,
+                    const volatile unsigned char* stop_flag,
+                    double* chi2_per_edge, uint8_t* depth_pos, ccm_ba_stats* stats);
+
+/* staged API (bench / multi-GPU): create uploads the problem and builds the Schur structure;
+ * rank/nranks shard the landmarks (each rank owns a contiguous landmark range balanced by
+ * pair count; camera state is replicated).  With nranks > 1 a communicator must be attached
+ * before ccm_ba_run.                                                                      */
+int  ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* prob, int rank, int nranks, ccm_ba** out);
+void ccm_ba_destroy(ccm_ba* ba);
+int  ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double* pt_xyz); /* re-upload initial state */
+int  ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt, const volatile unsigned char* stop_flag,
+                ccm_ba_stats* stats);
+int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge, uint8_t* depth_pos);
+/* algorithmic byte count of one LM trial for the roofline */
+int  ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts,
+                   int64_t* n_free_cams, int64_t* n_blocks, int64_t* n_pairs);
+
+/* RCCL communicator for the sharded GBA.  id_bytes is an ncclUniqueId (128 bytes) produced by
+ * ccm_comm_unique_id on rank 0 and broadcast by the launcher (bench.py uses torch.distributed). */
+int ccm_comm_unique_id(uint8_t id_bytes[128]);
+int ccm_comm_init(ccm_ctx* ctx, int nranks, int rank, const uint8_t id_bytes[128]);
+int ccm_comm_destroy(ccm_ctx* ctx);
+
+/* motion-only pose optimisation: Optimizer::PoseOptimizationClient (Optimizer.cpp:215-347):
+ * 4 rounds x 10 LM iterations on one SE3 vertex with unary EdgeSE3ProjectXYZOnlyPose edges,
+ * Huber sqrt(5.991) (dropped for the last round), chi2 threshold 5.991, dense 6x6 solve.
+ * cam_qt in: Frame.mTcw as SE3Quat, out: optimised pose.  outlier[n] = Frame.mvbOutlier.
+ * Returns via n_inlier the reference's return value (nInitialCorrespondences - nBad).     */
+int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const double* Xw /*n*3*/,
+                      const double* obs /*n*2*/, const double* info /*n*/, const double K[4],
+                      uint8_t* outlier, int* n_inlier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCM_HIP_H */

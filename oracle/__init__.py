@@ -1,0 +1,205 @@
+"""ctypes bindings of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Allowed importers: tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (ccm_slam_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+class BAStats(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("lm_trials", C.c_int32), ("stop_reason", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("ms_residuals", C.c_double), ("ms_quadratic", C.c_double), ("ms_schur", C.c_double),
+                ("ms_linear", C.c_double), ("ms_update", C.c_double), ("ms_structure", C.c_double),
+                ("ms_total", C.c_double),
+                ("n_free_cams", C.c_int32), ("n_active_pts", C.c_int32), ("n_active_edges", C.c_int32),
+                ("n_schur_blocks", C.c_int32),
+                ("chi2_hist", C.c_double * 64), ("lambda_hist", C.c_double * 64), ("trials_hist", C.c_int32 * 64)]
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(path):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return path
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.ora_ba_chi2.restype = C.c_double
+        _LIB.ora_grid_candidates.restype = C.c_int64
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+# ---- Hamming / matcher -------------------------------------------------------------------------
+def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
+    return int(lib().ora_descriptor_distance(_p(np.ascontiguousarray(a, np.uint8), C.c_uint8),
+                                             _p(np.ascontiguousarray(b, np.uint8), C.c_uint8)))
+
+
+def hamming_dense_best2(q: np.ndarray, t: np.ndarray):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    Q, T = q.shape[0], t.shape[0]
+    bi, bd, sd = (np.empty(Q, np.int32) for _ in range(3))
+    lib().ora_hamming_dense_best2(_p(q, C.c_uint8), Q, _p(t, C.c_uint8), T, _p(bi, C.c_int32), _p(bd, C.c_int32),
+                                  _p(sd, C.c_int32))
+    return bi, bd, sd
+
+
+def hamming_csr(q, t, cand_off, cand_idx):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    cand_off = np.ascontiguousarray(cand_off, np.int32)
+    cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+    Q = q.shape[0]
+    dist = np.empty(max(cand_idx.size, 1), np.uint16)
+    bi, bd, sd = (np.empty(Q, np.int32) for _ in range(3))
+    lib().ora_hamming_csr(_p(q, C.c_uint8), Q, _p(t, C.c_uint8), _p(cand_off, C.c_int32), _p(cand_idx, C.c_int32),
+                          _p(dist, C.c_uint16), _p(bi, C.c_int32), _p(bd, C.c_int32), _p(sd, C.c_int32))
+    return dist[:cand_idx.size], bi, bd, sd
+
+
+def grid_candidates(kx, ky, octave, bounds, qx, qy, qr, qminl, qmaxl):
+    kx, ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+    octave = np.ascontiguousarray(octave, np.int32)
+    qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+    qminl, qmaxl = np.ascontiguousarray(qminl, np.int32), np.ascontiguousarray(qmaxl, np.int32)
+    Q = qx.size
+    off = np.empty(Q + 1, np.int32)
+    args = [_p(kx, C.c_float), _p(ky, C.c_float), _p(octave, C.c_int32), kx.size] + [C.c_float(b) for b in bounds] + \
+           [_p(qx, C.c_float), _p(qy, C.c_float), _p(qr, C.c_float), _p(qminl, C.c_int32), _p(qmaxl, C.c_int32), Q]
+    n = lib().ora_grid_candidates(*args, _p(off, C.c_int32), None, C.c_int64(0))
+    idx = np.empty(max(n, 1), np.int32)
+    lib().ora_grid_candidates(*args, _p(off, C.c_int32), _p(idx, C.c_int32), C.c_int64(n))
+    return off, idx[:n]
+
+
+def search_by_projection_mp(kx, ky, octave, fdesc, bounds, scale_factors, mp_in_view, mp_proj_x, mp_proj_y, mp_level,
+                            mp_view_cos, mp_desc, th, nnratio, frame_mp):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    kx, ky, sf = f32(kx), f32(ky), f32(scale_factors)
+    octave = np.ascontiguousarray(octave, np.int32)
+    fdesc = np.ascontiguousarray(fdesc, np.uint8)
+    mp_in_view = np.ascontiguousarray(mp_in_view, np.uint8)
+    px, py, vc = f32(mp_proj_x), f32(mp_proj_y), f32(mp_view_cos)
+    lvl = np.ascontiguousarray(mp_level, np.int32)
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    frame_mp = np.ascontiguousarray(frame_mp, np.int32).copy()
+    n = lib().ora_search_by_projection_mp(
+        _p(kx, C.c_float), _p(ky, C.c_float), _p(octave, C.c_int32), _p(fdesc, C.c_uint8), kx.size,
+        *[C.c_float(b) for b in bounds], _p(sf, C.c_float), mp_in_view.size, _p(mp_in_view, C.c_uint8),
+        _p(px, C.c_float), _p(py, C.c_float), _p(lvl, C.c_int32), _p(vc, C.c_float), _p(mp_desc, C.c_uint8),
+        C.c_float(th), C.c_float(nnratio), _p(frame_mp, C.c_int32))
+    return int(n), frame_mp
+
+
+def search_by_projection_last(kx, ky, octave, kangle, fdesc, bounds, scale_factors, l_valid, l_u, l_v, l_octave,
+                              l_angle, l_mp_desc, th, check_orientation, cur_mp):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    kx, ky, ka, sf = f32(kx), f32(ky), f32(kangle), f32(scale_factors)
+    octave = np.ascontiguousarray(octave, np.int32)
+    fdesc = np.ascontiguousarray(fdesc, np.uint8)
+    l_valid = np.ascontiguousarray(l_valid, np.uint8)
+    lu, lv, la = f32(l_u), f32(l_v), f32(l_angle)
+    lo = np.ascontiguousarray(l_octave, np.int32)
+    l_mp_desc = np.ascontiguousarray(l_mp_desc, np.uint8)
+    cur_mp = np.ascontiguousarray(cur_mp, np.int32).copy()
+    n = lib().ora_search_by_projection_last(
+        _p(kx, C.c_float), _p(ky, C.c_float), _p(octave, C.c_int32), _p(ka, C.c_float), _p(fdesc, C.c_uint8), kx.size,
+        *[C.c_float(b) for b in bounds], _p(sf, C.c_float), l_valid.size, _p(l_valid, C.c_uint8), _p(lu, C.c_float),
+        _p(lv, C.c_float), _p(lo, C.c_int32), _p(la, C.c_float), _p(l_mp_desc, C.c_uint8), C.c_float(th),
+        int(check_orientation), _p(cur_mp, C.c_int32))
+    return int(n), cur_mp
+
+
+# ---- bundle adjustment -------------------------------------------------------------------------
+def ba_optimize(prob: dict, max_iters: int, linear_solver: int = 0, lambda_init: float = 0.0, chi2_in=None):
+    """Runs the oracle LM on a copy of the problem state.  Returns (cam_qt, pt_xyz, chi2_per_edge,
+    depth_pos, stats)."""
+    cam = np.ascontiguousarray(prob["cam_qt"], np.float64).copy()
+    pts = np.ascontiguousarray(prob["pt_xyz"], np.float64).copy()
+    ne = int(prob["n_edge"])
+    chi2 = np.zeros(ne, np.float64) if chi2_in is None else np.ascontiguousarray(chi2_in, np.float64).copy()
+    dpos = np.zeros(ne, np.uint8)
+    st = BAStats()
+    lvl = prob.get("e_level")
+    lib().ora_ba_optimize(
+        int(prob["n_cam"]), int(prob["n_pt"]), ne, _p(cam, C.c_double), _p(np.ascontiguousarray(prob["cam_fixed"], np.uint8), C.c_uint8),
+        _p(np.ascontiguousarray(prob["cam_K"], np.float64), C.c_double), _p(pts, C.c_double),
+        _p(np.ascontiguousarray(prob["e_cam"], np.int32), C.c_int32), _p(np.ascontiguousarray(prob["e_pt"], np.int32), C.c_int32),
+        _p(np.ascontiguousarray(prob["e_obs"], np.float64), C.c_double), _p(np.ascontiguousarray(prob["e_info"], np.float64), C.c_double),
+        _p(np.ascontiguousarray(lvl, np.uint8), C.c_uint8) if lvl is not None else None,
+        C.c_double(prob["huber_delta"]), int(max_iters), int(linear_solver), C.c_double(lambda_init), None,
+        _p(chi2, C.c_double), _p(dpos, C.c_uint8), C.byref(st))
+    return cam, pts, chi2, dpos, st
+
+
+def ba_chi2(prob: dict, cam=None, pts=None) -> float:
+    cam = np.ascontiguousarray(prob["cam_qt"] if cam is None else cam, np.float64)
+    pts = np.ascontiguousarray(prob["pt_xyz"] if pts is None else pts, np.float64)
+    lvl = prob.get("e_level")
+    return float(lib().ora_ba_chi2(
+        int(prob["n_cam"]), int(prob["n_pt"]), int(prob["n_edge"]), _p(cam, C.c_double),
+        _p(np.ascontiguousarray(prob["cam_K"], np.float64), C.c_double), _p(pts, C.c_double),
+        _p(np.ascontiguousarray(prob["e_cam"], np.int32), C.c_int32), _p(np.ascontiguousarray(prob["e_pt"], np.int32), C.c_int32),
+        _p(np.ascontiguousarray(prob["e_obs"], np.float64), C.c_double), _p(np.ascontiguousarray(prob["e_info"], np.float64), C.c_double),
+        _p(np.ascontiguousarray(lvl, np.uint8), C.c_uint8) if lvl is not None else None, C.c_double(prob["huber_delta"])))
+
+
+def ba_partial_system(prob: dict, lam: float, pt_lo: int, pt_hi: int, add_lambda: bool):
+    """(Hschur dense (n,n), bschur (n,), partial robust chi2) of the landmark shard [pt_lo, pt_hi)."""
+    args = [int(prob["n_cam"]), int(prob["n_pt"]), int(prob["n_edge"]),
+            _p(np.ascontiguousarray(prob["cam_qt"], np.float64), C.c_double),
+            _p(np.ascontiguousarray(prob["cam_fixed"], np.uint8), C.c_uint8),
+            _p(np.ascontiguousarray(prob["cam_K"], np.float64), C.c_double),
+            _p(np.ascontiguousarray(prob["pt_xyz"], np.float64), C.c_double),
+            _p(np.ascontiguousarray(prob["e_cam"], np.int32), C.c_int32), _p(np.ascontiguousarray(prob["e_pt"], np.int32), C.c_int32),
+            _p(np.ascontiguousarray(prob["e_obs"], np.float64), C.c_double), _p(np.ascontiguousarray(prob["e_info"], np.float64), C.c_double),
+            _p(np.ascontiguousarray(prob["e_level"], np.uint8), C.c_uint8), C.c_double(prob["huber_delta"]),
+            C.c_double(lam), int(pt_lo), int(pt_hi), int(add_lambda)]
+    ncp = C.c_int(0)
+    lib().ora_ba_partial_system(*args, None, None, None, C.byref(ncp))
+    n = ncp.value * 6
+    H = np.zeros((n, n), np.float64)
+    b = np.zeros(n, np.float64)
+    chi = C.c_double(0)
+    lib().ora_ba_partial_system(*args, _p(H, C.c_double), _p(b, C.c_double), C.byref(chi), C.byref(ncp))
+    return H, b, chi.value
+
+
+def pose_optimize(cam_qt, Xw, obs, info, K):
+    cam = np.ascontiguousarray(cam_qt, np.float64).copy()
+    Xw = np.ascontiguousarray(Xw, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    info = np.ascontiguousarray(info, np.float64)
+    K = np.ascontiguousarray(K, np.float64)
+    n = Xw.shape[0]
+    outl = np.zeros(max(n, 1), np.uint8)
+    ninl = lib().ora_pose_optimize(_p(cam, C.c_double), n, _p(Xw, C.c_double), _p(obs, C.c_double), _p(info, C.c_double),
+                                   _p(K, C.c_double), _p(outl, C.c_uint8))
+    return cam, outl[:n], int(ninl)

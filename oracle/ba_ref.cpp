@@ -1,0 +1,923 @@
+// ba_ref.cpp — CPU ORACLE (test infrastructure, NOT product code) for the Optimizer / g2o path.
+//
+// Restates on flat arrays what cslam::Optimizer builds and vendored g2o executes:
+//   Optimizer::BundleAdjustmentClient / LocalBundleAdjustmentClient / MapFusionGBA
+//       cslam/src/Optimizer.cpp:40-212, 349-644, 646-859
+//   Optimizer::PoseOptimizationClient            cslam/src/Optimizer.cpp:215-347
+//   g2o (paths under cslam/thirdparty/g2o/g2o/):
+//     types/types_six_dof_expmap.{h,cpp}  EdgeSE3ProjectXYZ(+OnlyPose), VertexSE3Expmap
+//     types/types_sba.h                    VertexSBAPointXYZ
+//     types/se3quat.h, types/se3_ops.hpp   SE3Quat::exp, operator*, normalizeRotation
+//     core/base_binary_edge.hpp:55-120, base_unary_edge.hpp:43-72   constructQuadraticForm
+//     core/base_edge.h:58-61,96-102        chi2, robustInformation
+//     core/robust_kernel_impl.cpp:78-90    RobustKernelHuber::robustify
+//     core/block_solver.hpp:143-295,354-486,502-604   structure / Schur / setLambda
+//     core/optimization_algorithm_levenberg.cpp:61-189  LM control
+//     core/sparse_optimizer.cpp:61-114,199-267,354-435   active set, optimize loop, update
+//     solvers/linear_solver_dense.h:65-113, linear_solver_eigen.h:106-136
+// Eigen is not available here; its fixed-size primitives (Quaterniond(R), q*v, toRotationMatrix,
+// 3x3 inverse, LDLT) are restated from their documented algorithms.
+//
+// PARITY PIN: the reference has no tests / golden vectors for this path and cannot be compiled in
+// this container (Eigen absent) — "parity unpinned" against a running g2o.  The oracle is pinned
+// instead by (i) an independent numpy/scipy derivation of one LM step (tests/test_oracle_ba.py),
+// (ii) convergence to ground truth on noise-free scenes, (iii) dense-vs-sparse solver agreement.
+//
+// Stand-in: LinearSolverEigen = Eigen::SimplicialLDLT + AMD ordering.  Here: block (6x6) sparse
+// Cholesky with a greedy minimum-degree ordering on the camera graph.  Same solution up to f64
+// rounding; different elimination order, so last-bit differences vs Eigen are expected.
+#include <cstdint>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <map>
+#include <set>
+#include <algorithm>
+#include <limits>
+#include <chrono>
+#include <cstdio>
+
+namespace {
+
+using std::vector;
+typedef double M3[9];    // row-major 3x3
+typedef double M6[36];   // row-major 6x6
+
+struct Quat { double x, y, z, w; };
+struct Pose { Quat q; double t[3]; };
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Eigen::Quaternion::normalize + g2o SE3Quat::normalizeRotation (se3quat.h:280-285)
+inline void normalize_rotation(Quat& q) {
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+// Eigen quaternion product
+inline Quat qmul(const Quat& a, const Quat& b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+// Eigen QuaternionBase::_transformVector: v + w*uv + u x uv, uv = 2 (u x v)
+inline void qrot(const Quat& q, const double v[3], double out[3]) {
+  double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  out[0] = v[0] + q.w * uv[0] + (q.y * uv[2] - q.z * uv[1]);
+  out[1] = v[1] + q.w * uv[1] + (q.z * uv[0] - q.x * uv[2]);
+  out[2] = v[2] + q.w * uv[2] + (q.x * uv[1] - q.y * uv[0]);
+}
+// Eigen QuaternionBase::toRotationMatrix
+inline void qtoR(const Quat& q, M3 R) {
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// Eigen Quaternion(Matrix3) (quaternionbase_assign_impl<Other,3,3>)
+inline Quat RtoQ(const M3 m) {
+  Quat q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    t = std::sqrt(t + 1.0);
+    q.w = 0.5 * t;
+    t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+    double c[3];
+    c[i] = 0.5 * t;
+    t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    c[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    c[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+inline void pose_map(const Pose& T, const double X[3], double out[3]) {   // SE3Quat::map (se3quat.h:217-220)
+  qrot(T.q, X, out);
+  out[0] += T.t[0]; out[1] += T.t[1]; out[2] += T.t[2];
+}
+// SE3Quat::exp (se3quat.h:223-257); update = [omega(3), upsilon(3)]
+inline Pose se3_exp(const double u[6]) {
+  const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+  const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const M3 Om = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  M3 Om2;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double s = 0; for (int k = 0; k < 3; k++) s += Om[i * 3 + k] * Om[k * 3 + j];
+    Om2[i * 3 + j] = s;
+  }
+  M3 R, V;
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+  } else {
+    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta);
+    const double c = (theta - std::sin(theta)) / std::pow(theta, 3);
+    for (int i = 0; i < 9; i++) {
+      const double I = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = I + a * Om[i] + b * Om2[i];
+      V[i] = I + b * Om[i] + c * Om2[i];
+    }
+  }
+  Pose P;
+  P.q = RtoQ(R);
+  for (int i = 0; i < 3; i++) P.t[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
+  normalize_rotation(P.q);   // SE3Quat(const Quaterniond&, const Vector3d&) ctor (:61-63)
+  return P;
+}
+// SE3Quat::operator* (se3quat.h:104-110)
+inline Pose pose_mul(const Pose& a, const Pose& b) {
+  Pose r = a;
+  double rt[3];
+  qrot(a.q, b.t, rt);
+  r.t[0] += rt[0]; r.t[1] += rt[1]; r.t[2] += rt[2];
+  r.q = qmul(a.q, b.q);
+  normalize_rotation(r.q);
+  return r;
+}
+
+// RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-90)
+inline void huber(double e2, double delta, double rho[3]) {
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+  else {
+    const double sqrte = std::sqrt(e2);
+    rho[0] = 2 * sqrte * delta - dsqr;
+    rho[1] = delta / sqrte;
+    rho[2] = -0.5 * rho[1] / e2;
+  }
+}
+
+// 3x3 inverse by cofactors (Eigen fixed-size inverse, compute_inverse_size3_helper)
+inline void inv3(const M3 m, M3 r) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c10 = m[5] * m[6] - m[3] * m[8], c20 = m[3] * m[7] - m[4] * m[6];
+  const double det = c00 * m[0] + c10 * m[1] + c20 * m[2];
+  const double id = 1.0 / det;
+  r[0] = c00 * id; r[3] = c10 * id; r[6] = c20 * id;
+  r[1] = (m[2] * m[7] - m[1] * m[8]) * id; r[4] = (m[0] * m[8] - m[2] * m[6]) * id; r[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  r[2] = (m[1] * m[5] - m[2] * m[4]) * id; r[5] = (m[2] * m[3] - m[0] * m[5]) * id; r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// ----- dense Cholesky (stand-in for Eigen::LDLT in LinearSolverDense) ---------------------------
+bool dense_chol_solve(vector<double>& A, int n, const double* b, double* x) {
+  // A row-major full symmetric; factor lower in place
+  for (int j = 0; j < n; j++) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0.0) || !std::isfinite(d)) return false;
+    d = std::sqrt(d);
+    A[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[(size_t)i * n + j];
+      const double* ri = &A[(size_t)i * n];
+      const double* rj = &A[(size_t)j * n];
+      for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
+      A[(size_t)i * n + j] = s / d;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    double s = b[i];
+    for (int k = 0; k < i; k++) s -= A[(size_t)i * n + k] * x[k];
+    x[i] = s / A[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= A[(size_t)k * n + i] * x[k];
+    x[i] = s / A[(size_t)i * n + i];
+  }
+  return true;
+}
+
+// ----- block sparse Cholesky with greedy minimum-degree ordering -------------------------------
+struct BlockChol {
+  int nb = 0;
+  vector<int> perm, iperm;            // perm[k] = original block eliminated k-th
+  vector<vector<int>> cstruct;        // per eliminated column k: sorted rows (positions > k)
+  vector<vector<double>> Lcol;        // per column: (1 + |cstruct|) blocks of 36 (diag first)
+  bool analysed = false;
+
+  void analyse(int n, const vector<std::pair<int, int>>& upper_blocks) {
+    nb = n;
+    vector<std::set<int>> adj(n);
+    for (auto& p : upper_blocks) if (p.first != p.second) { adj[p.first].insert(p.second); adj[p.second].insert(p.first); }
+    perm.assign(n, -1); iperm.assign(n, -1);
+    vector<char> done(n, 0);
+    std::set<std::pair<int, int>> heap;   // (degree, node)
+    for (int i = 0; i < n; i++) heap.insert({(int)adj[i].size(), i});
+    vector<vector<int>> nbrs(n);
+    for (int k = 0; k < n; k++) {
+      auto it = heap.begin();
+      const int v = it->second;
+      heap.erase(it);
+      perm[k] = v; iperm[v] = k; done[v] = 1;
+      vector<int> nb_v(adj[v].begin(), adj[v].end());
+      nbrs[k] = nb_v;
+      for (int a : nb_v) { heap.erase({(int)adj[a].size(), a}); adj[a].erase(v); }
+      for (size_t i = 0; i < nb_v.size(); i++)
+        for (size_t j = i + 1; j < nb_v.size(); j++) { adj[nb_v[i]].insert(nb_v[j]); adj[nb_v[j]].insert(nb_v[i]); }
+      for (int a : nb_v) heap.insert({(int)adj[a].size(), a});
+      adj[v].clear();
+    }
+    cstruct.assign(n, {});
+    for (int k = 0; k < n; k++) {
+      for (int a : nbrs[k]) cstruct[k].push_back(iperm[a]);
+      std::sort(cstruct[k].begin(), cstruct[k].end());
+    }
+    Lcol.assign(n, {});
+    for (int k = 0; k < n; k++) Lcol[k].assign((cstruct[k].size() + 1) * 36, 0.0);
+    analysed = true;
+  }
+
+  static void chol6(double* A, bool& ok) {   // lower Cholesky in place (row-major), upper part ignored
+    for (int j = 0; j < 6; j++) {
+      double d = A[j * 6 + j];
+      for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+      if (!(d > 0.0) || !std::isfinite(d)) { ok = false; return; }
+      d = std::sqrt(d);
+      A[j * 6 + j] = d;
+      for (int i = j + 1; i < 6; i++) {
+        double s = A[i * 6 + j];
+        for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
+        A[i * 6 + j] = s / d;
+      }
+    }
+    for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) A[i * 6 + j] = 0.0;
+  }
+
+  // blocks: map (i<=j) -> 6x6 row-major (block (i,j) of the symmetric matrix, upper part)
+  bool factor_solve(const vector<std::pair<int, int>>& keys, const vector<double>& vals, const double* b, double* x) {
+    const int n = nb;
+    for (int k = 0; k < n; k++) std::fill(Lcol[k].begin(), Lcol[k].end(), 0.0);
+    // scatter A (lower form in permuted order): column = min(pos), row = max(pos)
+    for (size_t kb = 0; kb < keys.size(); kb++) {
+      const int i = keys[kb].first, j = keys[kb].second;
+      const int pi = iperm[i], pj = iperm[j];
+      const double* B = &vals[kb * 36];   // block (i,j)
+      if (pi == pj) { std::memcpy(&Lcol[pi][0], B, 36 * sizeof(double)); continue; }
+      const int col = std::min(pi, pj), row = std::max(pi, pj);
+      const auto& cs = cstruct[col];
+      const int pos = (int)(std::lower_bound(cs.begin(), cs.end(), row) - cs.begin());
+      double* dst = &Lcol[col][(size_t)(pos + 1) * 36];
+      // need block (row_node, col_node) of A: if row corresponds to j (pj>pi) it is B^T, else B
+      if (pj > pi) { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) dst[r * 6 + c] = B[c * 6 + r]; }
+      else std::memcpy(dst, B, 36 * sizeof(double));
+    }
+    bool ok = true;
+    for (int k = 0; k < n && ok; k++) {
+      double* D = &Lcol[k][0];
+      chol6(D, ok);
+      if (!ok) break;
+      const auto& cs = cstruct[k];
+      const int m = (int)cs.size();
+      // L_rk = A_rk * L_kk^{-T}
+      for (int r = 0; r < m; r++) {
+        double* A = &Lcol[k][(size_t)(r + 1) * 36];
+        for (int row = 0; row < 6; row++)
+          for (int j = 0; j < 6; j++) {
+            double s = A[row * 6 + j];
+            for (int p = 0; p < j; p++) s -= A[row * 6 + p] * D[j * 6 + p];
+            A[row * 6 + j] = s / D[j * 6 + j];
+          }
+      }
+      // trailing update
+      for (int c = 0; c < m; c++) {
+        const int colc = cs[c];
+        const double* Lc = &Lcol[k][(size_t)(c + 1) * 36];
+        const auto& cs2 = cstruct[colc];
+        {  // diagonal block of column colc
+          double* T = &Lcol[colc][0];
+          for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) {
+            double s = 0; for (int p = 0; p < 6; p++) s += Lc[i * 6 + p] * Lc[j * 6 + p];
+            T[i * 6 + j] -= s;
+          }
+        }
+        size_t pos = 0;
+        for (int r = c + 1; r < m; r++) {
+          const int rowr = cs[r];
+          while (cs2[pos] < rowr) pos++;
+          double* T = &Lcol[colc][(pos + 1) * 36];
+          const double* Lr = &Lcol[k][(size_t)(r + 1) * 36];
+          for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+            double s = 0; for (int p = 0; p < 6; p++) s += Lr[i * 6 + p] * Lc[j * 6 + p];
+            T[i * 6 + j] -= s;
+          }
+        }
+      }
+    }
+    if (!ok) return false;
+    // solve L y = Pb ; L^T z = y
+    vector<double> y((size_t)n * 6);
+    for (int k = 0; k < n; k++) for (int i = 0; i < 6; i++) y[(size_t)k * 6 + i] = b[(size_t)perm[k] * 6 + i];
+    for (int k = 0; k < n; k++) {
+      const double* D = &Lcol[k][0];
+      double* yk = &y[(size_t)k * 6];
+      for (int i = 0; i < 6; i++) { double s = yk[i]; for (int p = 0; p < i; p++) s -= D[i * 6 + p] * yk[p]; yk[i] = s / D[i * 6 + i]; }
+      const auto& cs = cstruct[k];
+      for (size_t r = 0; r < cs.size(); r++) {
+        const double* L = &Lcol[k][(r + 1) * 36];
+        double* yr = &y[(size_t)cs[r] * 6];
+        for (int i = 0; i < 6; i++) { double s = 0; for (int p = 0; p < 6; p++) s += L[i * 6 + p] * yk[p]; yr[i] -= s; }
+      }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+      const double* D = &Lcol[k][0];
+      double* yk = &y[(size_t)k * 6];
+      const auto& cs = cstruct[k];
+      for (size_t r = 0; r < cs.size(); r++) {
+        const double* L = &Lcol[k][(r + 1) * 36];
+        const double* yr = &y[(size_t)cs[r] * 6];
+        for (int p = 0; p < 6; p++) { double s = 0; for (int i = 0; i < 6; i++) s += L[i * 6 + p] * yr[i]; yk[p] -= s; }
+      }
+      for (int i = 5; i >= 0; i--) { double s = yk[i]; for (int p = i + 1; p < 6; p++) s -= D[p * 6 + i] * yk[p]; yk[i] = s / D[i * 6 + i]; }
+    }
+    for (int k = 0; k < n; k++) for (int i = 0; i < 6; i++) x[(size_t)perm[k] * 6 + i] = y[(size_t)k * 6 + i];
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct Timers { double residuals = 0, quadratic = 0, schur = 0, linear = 0, update = 0, structure = 0; };
+
+struct BA {
+  int n_cam, n_pt, n_edge;
+  vector<Pose> cam; vector<uint8_t> cam_fixed; const double* K;
+  vector<double> pt;
+  const int32_t *e_cam, *e_pt; const double *e_obs, *e_info; vector<uint8_t> e_level;
+  double huber_delta;
+  // active structure (g2o initializeOptimization + buildStructure)
+  vector<int> act_edges;           // indices of active edges in insertion order
+  vector<int> cam_slot;            // cam -> pose index (free cams with >=1 active edge), else -1
+  vector<int> pt_slot;             // pt -> landmark index, else -1
+  vector<int> slot_cam, slot_pt;
+  int Cp = 0, Lp = 0;
+  // system
+  vector<double> Hpp;              // Cp*36 diagonal blocks (BA has no pose-pose edges)
+  vector<double> Hll;              // Lp*9
+  vector<double> Hpl;              // per active edge 6x3 (zero if cam fixed)
+  vector<double> b;                // 6*Cp + 3*Lp
+  vector<double> x;                // solution
+  vector<vector<int>> pt_edges;    // per landmark slot: active-edge positions, ordered by pose slot (HplCCS column order)
+  vector<double> err;              // per active edge 2
+  // Schur pattern: upper-triangular 6x6 blocks (i<=j); blocks 0..Cp-1 are the diagonal ones
+  vector<std::pair<int, int>> hs_keys; vector<double> hs_vals;
+  vector<vector<int>> pt_pair_block;   // per landmark: block index for each (a, c2>=a) pair in elimination order
+  BlockChol chol;
+  int linear_solver = 0;           // 0 auto, 1 dense, 2 sparse
+  Timers tm;
+  int pt_begin = 0, pt_end = 0;    // landmark-slot shard [begin,end) used by the partial-system entry
+
+  void project(const Pose& T, const double* Kc, const double X[3], double out[2], double* zc = nullptr) const {
+    double Xc[3]; pose_map(T, X, Xc);
+    out[0] = Xc[0] / Xc[2] * Kc[0] + Kc[2];   // cam_project (types_six_dof_expmap.cpp:141-147) + project2d
+    out[1] = Xc[1] / Xc[2] * Kc[1] + Kc[3];
+    if (zc) *zc = Xc[2];
+  }
+
+  void init_active(int level) {
+    act_edges.clear();
+    cam_slot.assign(n_cam, -1); pt_slot.assign(n_pt, -1);
+    vector<char> cam_has(n_cam, 0), pt_has(n_pt, 0);
+    for (int e = 0; e < n_edge; e++) {
+      if (e_level[e] != level) continue;
+      // allVerticesFixed never holds: points are never fixed in these graphs
+      act_edges.push_back(e);
+      cam_has[e_cam[e]] = 1; pt_has[e_pt[e]] = 1;
+    }
+    slot_cam.clear(); slot_pt.clear();
+    for (int c = 0; c < n_cam; c++) if (cam_has[c] && !cam_fixed[c]) { cam_slot[c] = (int)slot_cam.size(); slot_cam.push_back(c); }
+    for (int p = 0; p < n_pt; p++) if (pt_has[p]) { pt_slot[p] = (int)slot_pt.size(); slot_pt.push_back(p); }
+    Cp = (int)slot_cam.size(); Lp = (int)slot_pt.size();
+    pt_begin = 0; pt_end = Lp;
+  }
+
+  void build_structure() {
+    const double t0 = now_ms();
+    Hpp.assign((size_t)Cp * 36, 0.0); Hll.assign((size_t)Lp * 9, 0.0);
+    Hpl.assign(act_edges.size() * 18, 0.0);
+    b.assign((size_t)Cp * 6 + (size_t)Lp * 3, 0.0); x.assign(b.size(), 0.0);
+    err.assign(act_edges.size() * 2, 0.0);
+    pt_edges.assign(Lp, {});
+    for (size_t k = 0; k < act_edges.size(); k++) {
+      const int e = act_edges[k];
+      if (cam_slot[e_cam[e]] >= 0) pt_edges[pt_slot[e_pt[e]]].push_back((int)k);
+    }
+    for (auto& v : pt_edges)
+      std::stable_sort(v.begin(), v.end(), [&](int a, int c) { return cam_slot[e_cam[act_edges[a]]] < cam_slot[e_cam[act_edges[c]]]; });
+    std::map<std::pair<int, int>, int> index;
+    hs_keys.clear();
+    for (int i = 0; i < Cp; i++) { index[{i, i}] = i; hs_keys.push_back({i, i}); }
+    pt_pair_block.assign(Lp, {});
+    for (int l = 0; l < Lp; l++) {
+      const auto& v = pt_edges[l];
+      for (size_t a = 0; a < v.size(); a++)
+        for (size_t c = a; c < v.size(); c++) {
+          const int i = cam_slot[e_cam[act_edges[v[a]]]], j = cam_slot[e_cam[act_edges[v[c]]]];
+          auto key = std::make_pair(i, j);
+          auto it = index.find(key);
+          int id;
+          if (it == index.end()) { id = (int)hs_keys.size(); index[key] = id; hs_keys.push_back(key); } else id = it->second;
+          pt_pair_block[l].push_back(id);
+        }
+    }
+    hs_vals.assign(hs_keys.size() * 36, 0.0);
+    const bool sparse = (linear_solver == 2) || (linear_solver == 0 && Cp > 150);
+    if (sparse) chol.analyse(Cp, hs_keys); else chol.analysed = false;
+    tm.structure += now_ms() - t0;
+  }
+
+  // computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114)
+  double compute_errors_chi2() {
+    const double t0 = now_ms();
+    double chi = 0;
+    for (size_t k = 0; k < act_edges.size(); k++) {
+      const int e = act_edges[k];
+      double pr[2];
+      project(cam[e_cam[e]], K + 4 * (size_t)e_cam[e], &pt[3 * (size_t)e_pt[e]], pr);
+      const double e0 = e_obs[2 * (size_t)e] - pr[0], e1 = e_obs[2 * (size_t)e + 1] - pr[1];   // computeError (types_six_dof_expmap.h:90-95)
+      err[2 * k] = e0; err[2 * k + 1] = e1;
+      const double c2 = (e0 * e0 + e1 * e1) * e_info[e];   // chi2 = e^T Omega e, Omega = I*invSigma2
+      if (huber_delta > 0) { double rho[3]; huber(c2, huber_delta, rho); chi += rho[0]; }
+      else chi += c2;
+    }
+    tm.residuals += now_ms() - t0;
+    return chi;
+  }
+
+  // BlockSolver::buildSystem (block_solver.hpp:502-560): linearizeOplus + constructQuadraticForm
+  void build_system() {
+    const double t0 = now_ms();
+    std::fill(Hpp.begin(), Hpp.end(), 0.0); std::fill(Hll.begin(), Hll.end(), 0.0);
+    std::fill(Hpl.begin(), Hpl.end(), 0.0); std::fill(b.begin(), b.end(), 0.0);
+    for (size_t k = 0; k < act_edges.size(); k++) {
+      const int e = act_edges[k];
+      const int c = e_cam[e], p = e_pt[e];
+      const double* Kc = K + 4 * (size_t)c;
+      const double fx = Kc[0], fy = Kc[1];
+      double Xc[3]; pose_map(cam[c], &pt[3 * (size_t)p], Xc);
+      const double xx = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+      M3 R; qtoR(cam[c].q, R);
+      // linearizeOplus (types_six_dof_expmap.cpp:103-139)
+      const double tmp[6] = {fx, 0, -xx / z * fx, 0, fy, -y / z * fy};
+      double Ji[6];   // 2x3  d e / d point
+      for (int r = 0; r < 2; r++) for (int cc = 0; cc < 3; cc++) {
+        double s = 0; for (int q = 0; q < 3; q++) s += tmp[r * 3 + q] * R[q * 3 + cc];
+        Ji[r * 3 + cc] = -1. / z * s;
+      }
+      double Jj[12];  // 2x6  d e / d pose
+      Jj[0] = xx * y / z_2 * fx; Jj[1] = -(1 + (xx * xx / z_2)) * fx; Jj[2] = y / z * fx; Jj[3] = -1. / z * fx; Jj[4] = 0; Jj[5] = xx / z_2 * fx;
+      Jj[6] = (1 + y * y / z_2) * fy; Jj[7] = -xx * y / z_2 * fy; Jj[8] = -xx / z * fy; Jj[9] = 0; Jj[10] = -1. / z * fy; Jj[11] = y / z_2 * fy;
+      // constructQuadraticForm (base_binary_edge.hpp:55-120)
+      const double om = e_info[e];
+      const double e0 = err[2 * k], e1 = err[2 * k + 1];
+      double w = 1.0;
+      if (huber_delta > 0) { double rho[3]; huber((e0 * e0 + e1 * e1) * om, huber_delta, rho); w = rho[1]; }
+      const double omr0 = -om * e0 * w, omr1 = -om * e1 * w;   // omega_r = -Omega*e, scaled by rho[1]
+      const double wom = w * om;                                 // robustInformation = rho[1]*Omega
+      const int ls = pt_slot[p], cs = cam_slot[c];
+      // from = vertex 0 = point (A = Ji), to = vertex 1 = pose (B = Jj)
+      double* bl = &b[(size_t)Cp * 6 + (size_t)ls * 3];
+      double* Hl = &Hll[(size_t)ls * 9];
+      for (int i = 0; i < 3; i++) {
+        bl[i] += Ji[i] * omr0 + Ji[3 + i] * omr1;
+        for (int j = 0; j < 3; j++) Hl[i * 3 + j] += (Ji[i] * Ji[j] + Ji[3 + i] * Ji[3 + j]) * wom;
+      }
+      if (cs >= 0) {
+        double* bp = &b[(size_t)cs * 6];
+        double* Hp = &Hpp[(size_t)cs * 36];
+        double* W = &Hpl[k * 18];
+        for (int i = 0; i < 6; i++) {
+          bp[i] += Jj[i] * omr0 + Jj[6 + i] * omr1;
+          for (int j = 0; j < 6; j++) Hp[i * 6 + j] += (Jj[i] * Jj[j] + Jj[6 + i] * Jj[6 + j]) * wom;
+          for (int j = 0; j < 3; j++) W[i * 3 + j] += (Jj[i] * Ji[j] + Jj[6 + i] * Ji[3 + j]) * wom;   // Hpl block (pose row, landmark col)
+        }
+      }
+    }
+    tm.quadratic += now_ms() - t0;
+  }
+
+  double max_diag() const {   // computeLambdaInit (optimization_algorithm_levenberg.cpp:166-180)
+    double m = 0;
+    for (int i = 0; i < Cp; i++) for (int j = 0; j < 6; j++) m = std::max(std::fabs(Hpp[(size_t)i * 36 + j * 7]), m);
+    for (int i = 0; i < Lp; i++) for (int j = 0; j < 3; j++) m = std::max(std::fabs(Hll[(size_t)i * 9 + j * 4]), m);
+    return m;
+  }
+
+  // Schur complement for landmark slots [lb,le) into Hschur / coeff; lambda added to both diagonals.
+  // block_solver.hpp:367-439.  When add_hpp is false the Hpp (+lambda) term is left out (partial systems).
+  void schur(double lambda, int lb, int le, bool add_hpp, bool skip_empty, vector<double>& coeff, vector<double>& Dinv_all, vector<double>& db_all) {
+    std::fill(hs_vals.begin(), hs_vals.end(), 0.0);
+    if (add_hpp)
+      for (int i = 0; i < Cp; i++) {
+        double* blk = &hs_vals[(size_t)i * 36];
+        for (int q = 0; q < 36; q++) blk[q] = Hpp[(size_t)i * 36 + q];
+        for (int q = 0; q < 6; q++) blk[q * 7] += lambda;
+      }
+    coeff.assign((size_t)Cp * 6, 0.0);
+    Dinv_all.assign((size_t)Lp * 9, 0.0); db_all.assign((size_t)Lp * 3, 0.0);
+    for (int l = lb; l < le; l++) {
+      if (skip_empty && pt_edges[l].empty()) continue;
+      size_t pair_pos = 0;
+      M3 D, Dinv;
+      for (int q = 0; q < 9; q++) D[q] = Hll[(size_t)l * 9 + q];
+      D[0] += lambda; D[4] += lambda; D[8] += lambda;
+      inv3(D, Dinv);
+      std::memcpy(&Dinv_all[(size_t)l * 9], Dinv, sizeof(M3));
+      const double* bl = &b[(size_t)Cp * 6 + (size_t)l * 3];
+      double db[3];
+      for (int i = 0; i < 3; i++) db[i] = Dinv[i * 3] * bl[0] + Dinv[i * 3 + 1] * bl[1] + Dinv[i * 3 + 2] * bl[2];
+      std::memcpy(&db_all[(size_t)l * 3], db, sizeof(db));
+      const auto& col = pt_edges[l];
+      for (size_t a = 0; a < col.size(); a++) {
+        const double* Bi = &Hpl[(size_t)col[a] * 18];
+        const int i1 = cam_slot[e_cam[act_edges[col[a]]]];
+        double BDinv[18];
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 3; c++)
+          BDinv[r * 3 + c] = Bi[r * 3] * Dinv[c] + Bi[r * 3 + 1] * Dinv[3 + c] + Bi[r * 3 + 2] * Dinv[6 + c];
+        for (int r = 0; r < 6; r++) coeff[(size_t)i1 * 6 + r] += Bi[r * 3] * db[0] + Bi[r * 3 + 1] * db[1] + Bi[r * 3 + 2] * db[2];
+        for (size_t c2 = a; c2 < col.size(); c2++) {
+          const double* Bj = &Hpl[(size_t)col[c2] * 18];
+          const int i2 = cam_slot[e_cam[act_edges[col[c2]]]];
+          (void)i2;
+          double* H = &hs_vals[(size_t)pt_pair_block[l][pair_pos++] * 36];
+          for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++)
+            H[r * 6 + c] -= BDinv[r * 3] * Bj[c * 3] + BDinv[r * 3 + 1] * Bj[c * 3 + 1] + BDinv[r * 3 + 2] * Bj[c * 3 + 2];
+        }
+      }
+    }
+  }
+
+  // BlockSolver::solve, Schur branch (block_solver.hpp:354-486)
+  bool solve(double lambda) {
+    double t0 = now_ms();
+    vector<double> coeff, Dinv, db;
+    schur(lambda, 0, Lp, true, false, coeff, Dinv, db);
+    vector<double> bschur((size_t)Cp * 6);
+    for (size_t i = 0; i < bschur.size(); i++) bschur[i] = b[i] - coeff[i];
+    tm.schur += now_ms() - t0;
+    t0 = now_ms();
+    bool ok = true;
+    if (Cp > 0) {
+      if (chol.analysed) ok = chol.factor_solve(hs_keys, hs_vals, bschur.data(), x.data());
+      else {
+        const int n = Cp * 6;
+        vector<double> A((size_t)n * n, 0.0);
+        for (size_t kb = 0; kb < hs_keys.size(); kb++) {
+          const int i = hs_keys[kb].first, j = hs_keys[kb].second;
+          for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+            A[(size_t)(i * 6 + r) * n + j * 6 + c] = hs_vals[kb * 36 + r * 6 + c];
+            A[(size_t)(j * 6 + c) * n + i * 6 + r] = hs_vals[kb * 36 + r * 6 + c];
+          }
+        }
+        ok = dense_chol_solve(A, n, bschur.data(), x.data());
+      }
+    }
+    tm.linear += now_ms() - t0;
+    if (!ok) return false;
+    // landmark back-substitution: xl = Dinv (bl - Hpl^T xp)   (:461-481)
+    for (int l = 0; l < Lp; l++) {
+      double cl[3] = {b[(size_t)Cp * 6 + (size_t)l * 3], b[(size_t)Cp * 6 + (size_t)l * 3 + 1], b[(size_t)Cp * 6 + (size_t)l * 3 + 2]};
+      for (int k : pt_edges[l]) {
+        const double* W = &Hpl[(size_t)k * 18];
+        const double* xp = &x[(size_t)cam_slot[e_cam[act_edges[k]]] * 6];
+        for (int c = 0; c < 3; c++) for (int r = 0; r < 6; r++) cl[c] -= W[r * 3 + c] * xp[r];
+      }
+      const double* Di = &Dinv[(size_t)l * 9];
+      for (int i = 0; i < 3; i++) x[(size_t)Cp * 6 + (size_t)l * 3 + i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
+    }
+    return true;
+  }
+
+  // SparseOptimizer::update (sparse_optimizer.cpp:422-435) + oplusImpl
+  void apply_update() {
+    const double t0 = now_ms();
+    for (int i = 0; i < Cp; i++) {
+      Pose& T = cam[slot_cam[i]];
+      T = pose_mul(se3_exp(&x[(size_t)i * 6]), T);   // VertexSE3Expmap::oplusImpl (types_six_dof_expmap.h:73-76)
+    }
+    for (int l = 0; l < Lp; l++) {
+      double* X = &pt[3 * (size_t)slot_pt[l]];
+      for (int i = 0; i < 3; i++) X[i] += x[(size_t)Cp * 6 + (size_t)l * 3 + i];   // VertexSBAPointXYZ::oplusImpl (types_sba.h:52-56)
+    }
+    tm.update += now_ms() - t0;
+  }
+};
+
+struct LMState { double lambda = 0, ni = 2; int nBad = 0; };
+
+// OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164); returns 0 OK, 1 Terminate
+int lm_iteration(BA& ba, int iteration, LMState& st, const volatile unsigned char* stop, int* trials_out,
+                 double* chi_out, double lambda_init_user, double* ini_chi_out = nullptr) {
+  if (iteration == 0) ba.build_structure();
+  double currentChi = ba.compute_errors_chi2();
+  double tempChi = currentChi;
+  const double iniChi = currentChi;
+  if (ini_chi_out) *ini_chi_out = iniChi;
+  ba.build_system();
+  if (iteration == 0) {
+    st.lambda = lambda_init_user > 0 ? lambda_init_user : 1e-5 * ba.max_diag();
+    st.ni = 2; st.nBad = 0;
+  }
+  double rho = 0;
+  int qmax = 0;
+  do {
+    const vector<Pose> cam_backup = ba.cam;       // push()
+    const vector<double> pt_backup = ba.pt;
+    const bool ok2 = ba.solve(st.lambda);
+    ba.apply_update();
+    tempChi = ba.compute_errors_chi2();
+    if (!ok2) tempChi = std::numeric_limits<double>::max();
+    rho = currentChi - tempChi;
+    double scale = 0;                              // computeScale (:182-189)
+    for (size_t j = 0; j < ba.x.size(); j++) scale += ba.x[j] * (st.lambda * ba.x[j] + ba.b[j]);
+    scale += 1e-3;
+    rho /= scale;
+    if (rho > 0 && std::isfinite(tempChi)) {
+      double alpha = 1. - std::pow((2 * rho - 1), 3);
+      alpha = std::min(alpha, 2. / 3.);
+      const double scaleFactor = std::max(1. / 3., alpha);
+      st.lambda *= scaleFactor;
+      st.ni = 2;
+      currentChi = tempChi;
+    } else {
+      st.lambda *= st.ni;
+      st.ni *= 2;
+      ba.cam = cam_backup; ba.pt = pt_backup;      // pop()
+    }
+    qmax++;
+  } while (rho < 0 && qmax < 10 && !(stop && *stop));
+  if (trials_out) *trials_out = qmax;
+  if (chi_out) *chi_out = currentChi;
+  if (qmax == 10 || rho == 0) return 1;
+  if ((iniChi - currentChi) * 1e3 < iniChi) st.nBad++; else st.nBad = 0;
+  if (st.nBad >= 3) return 1;
+  return 0;
+}
+
+void load_problem(BA& ba, int n_cam, int n_pt, int n_edge, const double* cam_qt, const uint8_t* cam_fixed,
+                  const double* cam_K, const double* pt_xyz, const int32_t* e_cam, const int32_t* e_pt,
+                  const double* e_obs, const double* e_info, const uint8_t* e_level, double huber_delta) {
+  ba.n_cam = n_cam; ba.n_pt = n_pt; ba.n_edge = n_edge;
+  ba.cam.resize(n_cam);
+  for (int c = 0; c < n_cam; c++) {
+    const double* v = cam_qt + 7 * (size_t)c;
+    ba.cam[c].q = {v[0], v[1], v[2], v[3]};
+    ba.cam[c].t[0] = v[4]; ba.cam[c].t[1] = v[5]; ba.cam[c].t[2] = v[6];
+    normalize_rotation(ba.cam[c].q);   // SE3Quat(q,t) ctor normalises (Converter::toSE3Quat, Converter.cc:40-50)
+  }
+  ba.cam_fixed.assign(cam_fixed, cam_fixed + n_cam);
+  ba.K = cam_K;
+  ba.pt.assign(pt_xyz, pt_xyz + 3 * (size_t)n_pt);
+  ba.e_cam = e_cam; ba.e_pt = e_pt; ba.e_obs = e_obs; ba.e_info = e_info;
+  ba.e_level.assign(n_edge, 0);
+  if (e_level) ba.e_level.assign(e_level, e_level + n_edge);
+  ba.huber_delta = huber_delta;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct ora_ba_stats {
+  int32_t iters_done, lm_trials, stop_reason;
+  double chi2_initial, chi2_final, lambda_final;
+  double ms_residuals, ms_quadratic, ms_schur, ms_linear, ms_update, ms_structure, ms_total;
+  int32_t n_free_cams, n_active_pts, n_active_edges, n_schur_blocks;
+  double chi2_hist[64]; double lambda_hist[64]; int32_t trials_hist[64];
+};
+
+// SparseOptimizer::optimize(n) (sparse_optimizer.cpp:354-419) on level-0 edges.
+int ora_ba_optimize(int n_cam, int n_pt, int n_edge, double* cam_qt, const uint8_t* cam_fixed, const double* cam_K,
+                    double* pt_xyz, const int32_t* e_cam, const int32_t* e_pt, const double* e_obs,
+                    const double* e_info, const uint8_t* e_level, double huber_delta, int max_iters,
+                    int linear_solver, double lambda_init, const volatile unsigned char* stop_flag,
+                    double* chi2_per_edge, uint8_t* depth_pos, ora_ba_stats* stats) {
+  const double t0 = now_ms();
+  BA ba;
+  load_problem(ba, n_cam, n_pt, n_edge, cam_qt, cam_fixed, cam_K, pt_xyz, e_cam, e_pt, e_obs, e_info, e_level, huber_delta);
+  ba.linear_solver = linear_solver;
+  ba.init_active(0);
+  LMState st;
+  int iters = 0, trials_total = 0, reason = 0;
+  double chi_first = 0, chi_last = 0;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (!ba.act_edges.empty()) {
+    for (int i = 0; i < max_iters; i++) {
+      if (stop_flag && *stop_flag) { reason = 1; break; }
+      int trials = 0; double chi = 0, ini = 0;
+      const int r = lm_iteration(ba, i, st, stop_flag, &trials, &chi, lambda_init, &ini);
+      if (i == 0) chi_first = ini;
+      trials_total += trials; iters++;
+      chi_last = chi;
+      if (stats && i < 64) { stats->chi2_hist[i] = chi; stats->lambda_hist[i] = st.lambda; stats->trials_hist[i] = trials; }
+      if (r != 0) { reason = (st.nBad >= 3) ? 3 : 2; break; }
+    }
+  }
+  // write back
+  for (int c = 0; c < n_cam; c++) {
+    double* v = cam_qt + 7 * (size_t)c;
+    v[0] = ba.cam[c].q.x; v[1] = ba.cam[c].q.y; v[2] = ba.cam[c].q.z; v[3] = ba.cam[c].q.w;
+    v[4] = ba.cam[c].t[0]; v[5] = ba.cam[c].t[1]; v[6] = ba.cam[c].t[2];
+  }
+  std::memcpy(pt_xyz, ba.pt.data(), sizeof(double) * 3 * (size_t)n_pt);
+  // e->chi2() as the caller of optimize() sees it: _error holds the value of the LAST
+  // computeActiveErrors (the last LM trial, even if that trial was rejected and popped); edges that
+  // were not active keep whatever they had (entries left untouched).
+  if (chi2_per_edge)
+    for (size_t k = 0; k < ba.act_edges.size() && ba.err.size() == 2 * ba.act_edges.size(); k++) {
+      const int e = ba.act_edges[k];
+      chi2_per_edge[e] = (ba.err[2 * k] * ba.err[2 * k] + ba.err[2 * k + 1] * ba.err[2 * k + 1]) * e_info[e];
+    }
+  if (depth_pos)
+    for (int e = 0; e < n_edge; e++) {
+      double pr[2], zc;
+      ba.project(ba.cam[e_cam[e]], cam_K + 4 * (size_t)e_cam[e], &ba.pt[3 * (size_t)e_pt[e]], pr, &zc);
+      depth_pos[e] = zc > 0.0;   // isDepthPositive (types_six_dof_expmap.h:97-101), evaluated at the final estimate
+    }
+  if (stats) {
+    stats->iters_done = iters; stats->lm_trials = trials_total; stats->stop_reason = reason;
+    stats->chi2_initial = chi_first; stats->chi2_final = chi_last; stats->lambda_final = st.lambda;
+    stats->ms_residuals = ba.tm.residuals; stats->ms_quadratic = ba.tm.quadratic; stats->ms_schur = ba.tm.schur;
+    stats->ms_linear = ba.tm.linear; stats->ms_update = ba.tm.update; stats->ms_structure = ba.tm.structure;
+    stats->ms_total = now_ms() - t0;
+    stats->n_free_cams = ba.Cp; stats->n_active_pts = ba.Lp; stats->n_active_edges = (int)ba.act_edges.size();
+    stats->n_schur_blocks = (int)ba.hs_keys.size();
+  }
+  return iters;
+}
+
+// robust chi2 of the active (level-0) edges at the given state
+double ora_ba_chi2(int n_cam, int n_pt, int n_edge, const double* cam_qt, const double* cam_K, const double* pt_xyz,
+                   const int32_t* e_cam, const int32_t* e_pt, const double* e_obs, const double* e_info,
+                   const uint8_t* e_level, double huber_delta) {
+  BA ba;
+  vector<uint8_t> fixed(n_cam, 0);
+  load_problem(ba, n_cam, n_pt, n_edge, cam_qt, fixed.data(), cam_K, pt_xyz, e_cam, e_pt, e_obs, e_info, e_level, huber_delta);
+  ba.init_active(0);
+  ba.err.assign(ba.act_edges.size() * 2, 0.0);
+  return ba.compute_errors_chi2();
+}
+
+// Reduced camera system at the given state for the landmark-slot shard [shard, nshards):
+// dense row-major Hschur (upper+lower filled) of size (6*Cp)^2, bschur, and the partial robust chi2.
+// Hpp/b_p contributions come only from edges whose landmark is in the shard, so that the SUM over
+// shards equals the full system (lambda is added on shard 0 only).  Used by the gloo tests that
+// exercise the all-reduce algebra of the sharded global BA.
+int ora_ba_partial_system(int n_cam, int n_pt, int n_edge, const double* cam_qt, const uint8_t* cam_fixed,
+                          const double* cam_K, const double* pt_xyz, const int32_t* e_cam, const int32_t* e_pt,
+                          const double* e_obs, const double* e_info, const uint8_t* e_level, double huber_delta,
+                          double lambda, int pt_lo, int pt_hi /* original point index range */, int add_lambda,
+                          double* Hs_dense, double* bs, double* chi2_partial, int* n_free_cams) {
+  BA full;
+  load_problem(full, n_cam, n_pt, n_edge, cam_qt, cam_fixed, cam_K, pt_xyz, e_cam, e_pt, e_obs, e_info, e_level, huber_delta);
+  full.linear_solver = 1;
+  full.init_active(0);
+  const int Cp = full.Cp;
+  if (n_free_cams) *n_free_cams = Cp;
+  if (!Hs_dense) return 0;
+  // restrict to the shard by deactivating edges whose point is outside [pt_lo, pt_hi) but keep slots of the full problem
+  BA ba = full;
+  vector<int> keep;
+  for (int e : full.act_edges) if (e_pt[e] >= pt_lo && e_pt[e] < pt_hi) keep.push_back(e);
+  ba.act_edges = keep;
+  ba.build_structure();
+  const double chi = ba.compute_errors_chi2();
+  ba.build_system();
+  vector<double> coeff_acc, Dinv, db;
+  ba.schur(lambda, 0, ba.Lp, true, true, coeff_acc, Dinv, db);
+  if (!add_lambda) for (int i = 0; i < Cp; i++) for (int q = 0; q < 6; q++) ba.hs_vals[(size_t)i * 36 + q * 7] -= lambda;
+  const int n = Cp * 6;
+  std::fill(Hs_dense, Hs_dense + (size_t)n * n, 0.0);
+  for (size_t kb = 0; kb < ba.hs_keys.size(); kb++) {
+    const int i = ba.hs_keys[kb].first, j = ba.hs_keys[kb].second;
+    for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+      Hs_dense[(size_t)(i * 6 + r) * n + j * 6 + c] = ba.hs_vals[kb * 36 + r * 6 + c];
+      Hs_dense[(size_t)(j * 6 + c) * n + i * 6 + r] = ba.hs_vals[kb * 36 + r * 6 + c];
+    }
+  }
+  for (int i = 0; i < n; i++) bs[i] = ba.b[i] - coeff_acc[i];
+  if (chi2_partial) *chi2_partial = chi;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer::PoseOptimizationClient — cslam/src/Optimizer.cpp:215-347, flat restatement.
+// One SE3 vertex, unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.h:143-171,
+// .cpp:266-288), Huber delta = (float)sqrt(5.991), 4 rounds x optimize(10) restarted from the input
+// pose each round (:299), chi2 threshold 5.991f with chi2 cast to float (:318-320), kernel removed
+// after the third round (:332-333), dense 6x6 solve (LinearSolverDense).  Returns
+// nInitialCorrespondences - nBad (or 0 if fewer than 3 correspondences, :290-291).
+int ora_pose_optimize(double* cam_qt, int n, const double* Xw, const double* obs, const double* info, const double* Kc,
+                      uint8_t* outlier) {
+  if (n < 3) return 0;
+  Pose T0;
+  T0.q = {cam_qt[0], cam_qt[1], cam_qt[2], cam_qt[3]};
+  T0.t[0] = cam_qt[4]; T0.t[1] = cam_qt[5]; T0.t[2] = cam_qt[6];
+  normalize_rotation(T0.q);
+  Pose T = T0;
+  const double delta = (double)(float)std::sqrt(5.991);   // const float deltaMono = sqrt(5.991) (:247)
+  vector<uint8_t> level(n, 0), robust(n, 1);
+  vector<double> err(2 * (size_t)n, 0.0);
+  for (int i = 0; i < n; i++) outlier[i] = 0;
+  const float chi2Mono[4] = {5.991f, 5.991f, 5.991f, 5.991f};
+  int nBad = 0;
+  auto compute_error = [&](int i) {
+    double Xc[3]; pose_map(T, Xw + 3 * (size_t)i, Xc);
+    err[2 * i] = obs[2 * i] - (Xc[0] / Xc[2] * Kc[0] + Kc[2]);
+    err[2 * i + 1] = obs[2 * i + 1] - (Xc[1] / Xc[2] * Kc[1] + Kc[3]);
+  };
+  for (int it = 0; it < 4; it++) {
+    T = T0;                                       // vSE3->setEstimate(Converter::toSE3Quat(Frame.mTcw)) (:299)
+    vector<int> act;
+    for (int i = 0; i < n; i++) if (level[i] == 0) act.push_back(i);
+    if (!act.empty()) {                            // initializeOptimization(0) fails on an empty active set
+      double lambda = 0, ni = 2; int nBadLM = 0;
+      for (int iter = 0; iter < 10; iter++) {
+        auto chi2_active = [&]() {
+          double chi = 0;
+          for (int i : act) {
+            compute_error(i);
+            const double c2 = (err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]) * info[i];
+            if (robust[i]) { double rho[3]; huber(c2, delta, rho); chi += rho[0]; } else chi += c2;
+          }
+          return chi;
+        };
+        double currentChi = chi2_active();
+        const double iniChi = currentChi;
+        double H[36] = {0}, b[6] = {0};
+        for (int i : act) {
+          double Xc[3]; pose_map(T, Xw + 3 * (size_t)i, Xc);
+          const double x = Xc[0], y = Xc[1], invz = 1.0 / Xc[2], invz_2 = invz * invz;
+          const double fx = Kc[0], fy = Kc[1];
+          double J[12];   // EdgeSE3ProjectXYZOnlyPose::linearizeOplus (types_six_dof_expmap.cpp:266-288)
+          J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+          J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+          const double om = info[i];
+          double w = 1.0;
+          if (robust[i]) { double rho[3]; huber((err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]) * om, delta, rho); w = rho[1]; }
+          const double o0 = -om * err[2 * i] * w, o1 = -om * err[2 * i + 1] * w, wom = w * om;   // base_unary_edge.hpp:43-72
+          for (int r = 0; r < 6; r++) {
+            b[r] += J[r] * o0 + J[6 + r] * o1;
+            for (int c = 0; c < 6; c++) H[r * 6 + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * wom;
+          }
+        }
+        if (iter == 0) { double m = 0; for (int j = 0; j < 6; j++) m = std::max(std::fabs(H[j * 7]), m); lambda = 1e-5 * m; ni = 2; nBadLM = 0; }
+        double rho = 0, tempChi; int qmax = 0; double xs[6];
+        do {
+          const Pose backup = T;
+          vector<double> A(36);
+          for (int q = 0; q < 36; q++) A[q] = H[q];
+          for (int q = 0; q < 6; q++) A[q * 7] += lambda;
+          const bool ok2 = dense_chol_solve(A, 6, b, xs);
+          T = pose_mul(se3_exp(xs), T);
+          tempChi = chi2_active();
+          if (!ok2) tempChi = std::numeric_limits<double>::max();
+          rho = currentChi - tempChi;
+          double scale = 0;
+          for (int j = 0; j < 6; j++) scale += xs[j] * (lambda * xs[j] + b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && std::isfinite(tempChi)) {
+            double alpha = 1. - std::pow((2 * rho - 1), 3);
+            alpha = std::min(alpha, 2. / 3.);
+            lambda *= std::max(1. / 3., alpha);
+            ni = 2; currentChi = tempChi;
+          } else { lambda *= ni; ni *= 2; T = backup; }
+          qmax++;
+        } while (rho < 0 && qmax < 10);
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+        if (nBadLM >= 3) break;
+      }
+    }
+    nBad = 0;
+    for (int i = 0; i < n; i++) {
+      if (outlier[i]) compute_error(i);             // (:313-316); active edges keep the _error of the LAST evaluated
+                                                    // trial (g2o does not recompute after a rejected step)
+      const float chi2 = (float)((err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]) * info[i]);
+      if (chi2 > chi2Mono[it]) { outlier[i] = 1; level[i] = 1; nBad++; }
+      else { outlier[i] = 0; level[i] = 0; }
+      if (it == 2) robust[i] = 0;
+    }
+    if (n < 10) break;                              // optimizer.edges().size() < 10 (:336-337)
+  }
+  cam_qt[0] = T.q.x; cam_qt[1] = T.q.y; cam_qt[2] = T.q.z; cam_qt[3] = T.q.w;
+  cam_qt[4] = T.t[0]; cam_qt[5] = T.t[1]; cam_qt[6] = T.t[2];
+  return n - nBad;
+}
+
+}  // extern "C"
