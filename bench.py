@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — headline measurement of the CCM-SLAM hot path on MI355X.
+
+Metric (BASELINE.json): "tracked fps/agent + global-BA ms/iter, EuRoC MH 4-agent merge @1/2/4/8 GPU".
+The JSON line's `value` is the global-BA rate (LM iterations / s, whole job) on the synthetic
+4-agent merged map `gba_c4` (2000 KFs, 150k landmarks, ~0.95M observations);
+`ms_per_step` is the global-BA ms/iter the metric names; the tracked-fps half of the metric is
+reported in `extra.orb_fps_per_agent` once the ORB path is built in.
+
+A "step" is one Levenberg–Marquardt iteration of Optimizer::MapFusionGBA's optimize() call
+(cslam/src/Optimizer.cpp:796-801): linearise all edges, then per LM trial Schur-eliminate the
+landmarks, solve the reduced camera system, back-substitute, update, evaluate chi2.
+With N > 1 GPUs the landmarks are sharded across ranks (one RCCL all-reduce of the reduced camera
+system per LM trial); the total problem is fixed => "scaling": "strong".
+
+Inputs are uploaded (and the Schur structure built) before the timed region; the timed region is
+exactly K LM iterations bracketed by barrier + device synchronise, MAX over ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)   # Opt.GBAIterations = 20 (cslam/conf/config.yaml:129)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="gba_c4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--pcg-max-iters", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # device sync + torch.distributed plumbing only
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from ccm_slam_amd import optimizer, synth
+    from ccm_slam_amd._lib import Context, K, comm_unique_id
+
+    ctx = Context(local_rank)
+    if world > 1:
+        ids = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(world, rank, ids[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    prob = synth.make_ba_config(args.workload)
+    t0 = time.perf_counter()
+    h = optimizer.BAHandle(ctx, prob, rank=rank, nranks=world)
+    setup_s = time.perf_counter() - t0
+    counts = h.counts()
+
+    def run_iters(n):
+        """exactly n LM iterations (re-entering optimize() if g2o's stop rule ends a call early)"""
+        done, trials, pcg = 0, 0, 0
+        while done < n:
+            st = h.run(n - done, pcg_max_iters=args.pcg_max_iters)
+            done += st.iters_done
+            trials += st.lm_trials
+            pcg += st.pcg_iters
+            if st.iters_done == 0:
+                break
+        return done, trials, pcg, st
+
+    # ---- warmup: also finds the dominant kernel class (events on every class here, not in the timed run)
+    ctx.prof_enable(-1)
+    ctx.prof_reset()
+    if args.warmup > 0:
+        run_iters(args.warmup)
+    prof = {name: ctx.prof_read(k) for name, k in K.items() if name.startswith("BA_")}
+    dominant = max(prof, key=lambda n: prof[n][1]) if any(v[0] for v in prof.values()) else "BA_SCHUR_OFF"
+    h.reset()
+    ctx.prof_enable(K[dominant])
+    ctx.prof_reset()
+
+    # ---- timed region
+    barrier()
+    t0 = time.perf_counter()
+    done, trials, pcg, st = run_iters(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    launches, kernel_ms = ctx.prof_read(K[dominant])
+    ctx.prof_enable(-2)
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch)
+    E, L, C, B, P = counts["edges"], counts["points"], counts["free_cams"], counts["blocks"], counts["pairs"]
+    n_off = B - C
+    alg_bytes = {
+        # q = S p over the symmetric block matrix read once + z,p in, q,p out
+        "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,
+        "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,
+        # per pair instance two 6x3 W blocks + symmetric Dinv, per block one 6x6 store
+        "BA_SCHUR_OFF": (144.0 * 2 + 48.0 + 8.0) * P + 288.0 * n_off,
+        "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
+        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + 144.0) * E + (24.0 + 72.0) * L,
+        "BA_CAM": (24.0 + 24.0 + 8.0) * E + (56.0 + 288.0 + 48.0) * C,
+        "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
+        "BA_BACKSUB": (144.0 + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L,
+        "BA_UPDATE": (56.0 * 2 + 48.0 * 2) * C,
+        "BA_CHI2": (56.0 + 24.0 + 9.0 + 8.0) * E + 24.0 * L,
+    }[dominant]
+    avg_ms = kernel_ms / launches if launches else float("nan")
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    roofline = {"kernel": dominant.lower(), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "launches": launches, "avg_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes}
+
+    # ---- CPU baseline: the oracle (g2o restatement, 1 thread) on a bounded sample of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        _, _, _, _, ost = oracle.ba_optimize(prob, args.cpu_iters)
+        it_ms = (ost.ms_total - ost.ms_structure) / max(ost.iters_done, 1)
+        cpu = {"value": round(1e3 / it_ms, 5), "unit": "LM iter/s", "cores": 1, "kind": "port",
+               "ms_per_iter": round(it_ms, 2), "structure_ms": round(ost.ms_structure, 1),
+               "sample": f"{ost.iters_done} LM iterations ({ost.lm_trials} trials) of {args.workload}: "
+                         f"{prob['n_cam']} KFs, {prob['n_pt']} landmarks, {prob['n_edge']} observations; "
+                         "oracle/ba_ref.cpp -O2 -g single thread (g2o build flags), block-sparse Cholesky stand-in for Eigen SimplicialLDLT",
+               "phases_ms": {"residuals": round(ost.ms_residuals, 1), "quadratic_form": round(ost.ms_quadratic, 1),
+                             "schur": round(ost.ms_schur, 1), "linear_solve": round(ost.ms_linear, 1)}}
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / max(done, 1)
+        out = {
+            "metric": "global-BA LM iterations/s (4-agent merged map); ms_per_step = global-BA ms/iter",
+            "value": round(done / elapsed, 4), "unit": "LM iter/s", "n_gpus": world, "steps": done, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: global BA (MapFusionGBA numerics), {prob['n_cam']} KFs / "
+                                   f"{prob['n_pt']} landmarks / {prob['n_edge']} observations, Huber sqrt(5.99), "
+                                   f"landmark-sharded x{world}",
+                       "lm_trials": trials, "pcg_iters": pcg, "schur_blocks": B, "pair_instances_rank0": P,
+                       "chi2_initial": st.chi2_initial if done == st.iters_done else None, "chi2_final": st.chi2_final,
+                       "setup_ms_excluded": round(setup_s * 1e3, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_port"] = round((done / elapsed) / cpu["value"], 1)
+        print(json.dumps(out))
+    h.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,14 +103,16 @@ def rodrigues(w: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------------------------
 # bundle-adjustment scenes
 # --------------------------------------------------------------------------------------------
-def _agent_loop(n_kf: int, agent: int):
+def _agent_loop(n_kf: int, agent: int, loop_len: int | None = None):
     """world->camera poses (R (n,3,3), t (n,3)) of one agent on a closed elliptical loop, looking
-    along the tangent; ~0.15 m between consecutive keyframes."""
-    per = 0.15 * n_kf
+    along the tangent; ~0.15 m between consecutive keyframes.  With loop_len > n_kf only the first
+    n_kf keyframes of a loop_len-keyframe loop are produced (an open trajectory segment)."""
+    n_all = n_kf if loop_len is None else max(loop_len, n_kf)
+    per = 0.15 * n_all
     A = per / (2 * np.pi) * 1.22 + 0.35 * agent
     B = A * 0.62
     h = 1.4 + 0.25 * agent
-    th = 2 * np.pi * (np.arange(n_kf) / n_kf) + 0.37 * agent
+    th = 2 * np.pi * (np.arange(n_kf) / n_all) + 0.37 * agent
     c = np.stack([A * np.cos(th) + 0.8 * agent, B * np.sin(th) - 0.5 * agent, np.full(n_kf, h)], 1)
     f = np.stack([-A * np.sin(th), B * np.cos(th), np.zeros(n_kf)], 1)
     f /= np.linalg.norm(f, axis=1, keepdims=True)
@@ -126,7 +128,7 @@ def make_ba_problem(n_agents: int = 1, kfs_per_agent: int = 70, n_points: int = 
                     mean_track: float = 6.0, max_track: int = 30, cross_frac: float = 0.1,
                     outlier_frac: float = 0.02, noise: bool = True, n_fixed: int = 1,
                     fixed_mode: str = "first", pose_sigma_t: float = 0.02, pose_sigma_r_deg: float = 0.5,
-                    point_sigma: float = 0.03, huber_delta: float | None = None):
+                    point_sigma: float = 0.03, huber_delta: float | None = None, loop_len: int | None = None):
     """Build a BA problem in the flat layout of ccm_ba_problem (include/ccm_hip.h).
 
     Returns a dict of contiguous numpy arrays (cam_qt, cam_fixed, cam_K, pt_xyz, e_cam, e_pt,
@@ -144,7 +146,7 @@ def make_ba_problem(n_agents: int = 1, kfs_per_agent: int = 70, n_points: int = 
     fx, fy, cx, cy = EUROC_K
     Rs, ts, cs = [], [], []
     for a in range(n_agents):
-        R, t, c = _agent_loop(kfs_per_agent, a)
+        R, t, c = _agent_loop(kfs_per_agent, a, loop_len)
         Rs.append(R), ts.append(t), cs.append(c)
     R_all = np.concatenate(Rs)
     t_all = np.concatenate(ts)

@@ -32,7 +32,7 @@ def _check(prob, iters, ctx, oracle_lib, **kw):
 
 def test_tiny_two_view(ctx, oracle_lib):
     # Optimizer::BundleAdjustmentClient on the 2-KF initial map (Tracking.cpp:414): 20 iterations
-    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=2, n_points=150, seed=11, mean_track=2, n_fixed=1)
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=2, n_points=150, seed=11, mean_track=2, n_fixed=1, loop_len=60)
     _check(prob, 20, ctx, oracle_lib)
 
 
