@@ -1055,7 +1055,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   return CCM_OK;
 }
 
-extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge, uint8_t* depth_pos) {
+extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge) {
   if (!ba) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
@@ -1079,29 +1079,32 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int l = 0; l < ba->Lp; l++) std::memcpy(pt_xyz + 3 * (size_t)ba->slot_pt[l], &pts[3 * (size_t)l], 3 * sizeof(double));
   }
-  if ((chi2_per_edge || depth_pos) && ba->Eloc) {
-    // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors);
-    // isDepthPositive(): recomputed at the final estimate.  Only the own (shard-local) active edges are written.
+  if (chi2_per_edge && ba->Eloc) {
+    // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors,
+    // even when that trial was rejected).  Only the own (shard-local) active edges are written; inactive
+    // (level != 0) edges keep whatever the caller passed in, as g2o leaves their _error untouched.
     std::vector<double> c2(ba->Eloc);
-    std::vector<uint8_t> dp(ba->Eloc);
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(c2.data(), d.edge_chi2, c2.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (depth_pos) {
-      // depth at the final estimate: run the chi2-only pass into scratch copies
-      double* save = nullptr;
-      CCM_HIP_CHECK(ctx, hipMalloc(&save, sizeof(double) * ba->Eloc));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(save, d.edge_chi2, sizeof(double) * ba->Eloc, hipMemcpyDeviceToDevice, ctx->stream));
-      hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(dp.data(), d.edge_depth, dp.size(), hipMemcpyDeviceToHost, ctx->stream));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d.edge_chi2, save, sizeof(double) * ba->Eloc, hipMemcpyDeviceToDevice, ctx->stream));
-      CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      hipFree(save);
-    }
-    for (int k = 0; k < ba->Eloc; k++) {
-      if (chi2_per_edge) chi2_per_edge[ba->loc_edge_orig[k]] = c2[k];
-      if (depth_pos) depth_pos[ba->loc_edge_orig[k]] = dp[k];
-    }
+    for (int k = 0; k < ba->Eloc; k++) chi2_per_edge[ba->loc_edge_orig[k]] = c2[k];
   }
+  return CCM_OK;
+}
+
+// e->isDepthPositive() (types_six_dof_expmap.h:97-101) for EVERY edge (active or not) at the given state.
+// Host arithmetic on the downloaded state: O(n_edge), off the hot path (called once after optimize()).
+static void depth_positive_all(const ccm_ba_problem* P, const double* cam_qt, const double* pt_xyz, uint8_t* depth_pos) {
+  for (int e = 0; e < P->n_edge; e++) {
+    BaPose T = ba_load_pose(cam_qt + 7 * (size_t)P->e_cam[e]);
+    double Xc[3];
+    ba_map(T, pt_xyz + 3 * (size_t)P->e_pt[e], Xc);
+    depth_pos[e] = Xc[2] > 0.0;
+  }
+}
+
+extern "C" int ccm_ba_depth_positive(const ccm_ba_problem* P, const double* cam_qt, const double* pt_xyz, uint8_t* depth_pos) {
+  if (!P || !cam_qt || !pt_xyz || !depth_pos) return CCM_E_ARG;
+  depth_positive_all(P, cam_qt, pt_xyz, depth_pos);
   return CCM_OK;
 }
 
@@ -1112,7 +1115,8 @@ extern "C" int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_
   int rc = ccm_ba_create(ctx, prob, ctx ? ctx->comm_rank : 0, ctx ? ctx->comm_nranks : 1, &ba);
   if (rc) return rc;
   rc = ccm_ba_run(ba, opt, stop_flag, stats);
-  if (rc == CCM_OK) rc = ccm_ba_download(ba, prob->cam_qt, prob->pt_xyz, chi2_per_edge, depth_pos);
+  if (rc == CCM_OK) rc = ccm_ba_download(ba, prob->cam_qt, prob->pt_xyz, chi2_per_edge);
+  if (rc == CCM_OK && depth_pos) depth_positive_all(prob, prob->cam_qt, prob->pt_xyz, depth_pos);
   ccm_ba_destroy(ba);
   return rc;
 }

@@ -61,8 +61,10 @@ class BAHandle:
         ne = int(self.prob["n_edge"])
         chi2 = np.zeros(ne, np.float64) if chi2_in is None else np.ascontiguousarray(chi2_in, np.float64).copy()
         dpos = np.zeros(ne, np.uint8)
-        check(lib().ccm_ba_download(self._h, C.c_void_p(_vp(cam)), C.c_void_p(_vp(pts)), C.c_void_p(_vp(chi2)),
-                                    C.c_void_p(_vp(dpos))), self.ctx.handle)
+        check(lib().ccm_ba_download(self._h, C.c_void_p(_vp(cam)), C.c_void_p(_vp(pts)), C.c_void_p(_vp(chi2))),
+              self.ctx.handle)
+        check(lib().ccm_ba_depth_positive(C.byref(self.cprob), C.c_void_p(_vp(cam)), C.c_void_p(_vp(pts)),
+                                          C.c_void_p(_vp(dpos))), self.ctx.handle)
         return cam, pts, chi2, dpos
 
     def counts(self):

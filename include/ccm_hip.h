@@ -170,8 +170,9 @@ typedef struct ccm_ba ccm_ba;
 
 /* one-shot: build structure, upload, optimise, write cam_qt/pt_xyz back.
  * stop_flag (nullable) is the reference's bool* pbStopFlag, polled between LM trials.
- * chi2_per_edge (nullable, [n_edge]) = e->chi2() at the final estimate; depth_pos (nullable,
- * [n_edge]) = e->isDepthPositive().                                                      */
+ * chi2_per_edge (nullable, in/out [n_edge]) = e->chi2() as the caller of optimize() sees it: for
+ * active (level-0) edges the value of the last evaluated LM trial, inactive edges are left
+ * untouched; depth_pos (nullable, [n_edge]) = e->isDepthPositive() at the final estimate.    */
 int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_options* opt,
                     const volatile unsigned char* stop_flag,
                     double* chi2_per_edge, uint8_t* depth_pos, ccm_ba_stats* stats);
@@ -185,7 +186,11 @@ void ccm_ba_destroy(ccm_ba* ba);
 int  ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double* pt_xyz); /* re-upload initial state */
 int  ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt, const volatile unsigned char* stop_flag,
                 ccm_ba_stats* stats);
-int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge, uint8_t* depth_pos);
+int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge);
+/* e->isDepthPositive() for every edge of the problem at the given state (host arithmetic, O(n_edge)) */
+int  ccm_ba_depth_positive(const ccm_ba_problem* prob, const double* cam_qt, const double* pt_xyz, uint8_t* depth_pos);
+/* host-only: split n landmark weights into nranks contiguous ranges (begin_out has nranks+1 entries) */
+int  ccm_ba_partition(const int64_t* weight, int n, int nranks, int32_t* begin_out);
 /* algorithmic byte count of one LM trial for the roofline */
 int  ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts,
                    int64_t* n_free_cams, int64_t* n_blocks, int64_t* n_pairs);
