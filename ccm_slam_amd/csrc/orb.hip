@@ -1,0 +1,805 @@
+// orb.hip — ORB extraction on MI355X (gfx950): pyramid, FAST-9/16 score, per-cell NMS with threshold
+// fallback, intensity-centroid orientation, 7x7 Gaussian blur, steered BRIEF.  Integer / exactly
+// specified f32 arithmetic: bit-exact against the reference semantics restated in oracle/orb_ref.cpp.
+//
+// Replaces cslam::ORBextractor (cslam/src/ORBextractor.cpp):
+//   ctor :579-639            -> ccm_orb_create (host tables)
+//   ComputePyramid :1280     -> orb_resize_kernel, one launch per level (level l depends on l-1)
+//   ComputeKeyPointsOctTree  -> orb_fast_score_kernel (all levels, one launch) +
+//        :933-998               orb_cells_kernel (one workgroup per 30-px cell: threshold, 3x3 strict NMS with
+//                               zero padding at the cell's interior edge, empty-cell retry with minThFAST,
+//                               raster-order compaction) + orb_compact_kernel
+//   DistributeOctTree :707   -> host (serial by nature, <= ~10 N candidates), own
+//                               index-linked implementation below
+//   IC_Angle :68 + computeOrbDescriptor :100 -> orb_orient_desc_kernel (one wave per keypoint; the 256
+//                               comparisons are 4 x 64-lane ballots = 32 bytes)
+//   GaussianBlur :1259       -> orb_blur_kernel (LDS tiled separable 8.8 fixed point, REFLECT_101)
+//
+// MI355X notes: one frame moves ~9 MB, far below what the Infinity Cache holds, so a single frame is
+// launch-latency bound (12 launches + one host round trip for the octree); all levels live in ONE
+// device allocation and the score / cell / blur kernels cover every level per launch to keep the launch
+// count down.  The batch entry point pipelines frames over several streams so the host octree of frame
+// i overlaps the device phases of frame i+1.
+#include "common.h"
+#include "orb_math.h"
+#include "orb_pattern.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <vector>
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxLevels = 16;
+constexpr int kEdge = 19, kHalfPatch = 15, kPatch = 31;
+constexpr int kCellCap = 320;      // >= ceil(36/2)*ceil(34/2): NMS keeps no two adjacent pixels
+constexpr int kCandFirstCopy = 16384;
+
+struct LevelInfo {
+  int w, h, stride, off;           // off: pixel offset of the level in the pyramid buffer
+  int nCols, nRows, wCell, hCell, cellBase;
+  int rowBase;                     // first global row index (sum of h of previous levels)
+  int tabOff;                      // offset into the resize tables
+  float scale;
+};
+
+struct OrbDev {
+  int nlevels, ncells, totalRows, maxW;
+  LevelInfo lv[kMaxLevels];
+  int umax[16];
+};
+
+__constant__ int8_t c_pattern[1024];
+
+// ---- pyramid: cv::resize INTER_LINEAR 8UC1 fixed point (oracle/orb_ref.cpp resize_linear_u8) ----
+__global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
+                                                         uint8_t* __restrict__ dst, int dw, int dh, int dstride,
+                                                         const int16_t* __restrict__ xofs, const int16_t* __restrict__ ialpha,
+                                                         const int16_t* __restrict__ yofs, const int16_t* __restrict__ ibeta) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int dy = blockIdx.y;
+  if (dx >= dw) return;
+  const int sy = yofs[dy];
+  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+  const int a0 = ialpha[2 * dx], a1 = ialpha[2 * dx + 1];
+  const int b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+  const uint8_t* S0 = src + (size_t)sy0 * sstride;
+  const uint8_t* S1 = src + (size_t)sy1 * sstride;
+  const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+  const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+  dst[(size_t)dy * dstride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+__device__ __forceinline__ int find_level(const OrbDev& d, int grow) {
+  int l = 0;
+#pragma unroll 1
+  for (int k = 1; k < d.nlevels; k++) if (grow >= d.lv[k].rowBase) l = k;
+  return l;
+}
+
+// ---- FAST-9/16 corner score for every pixel of every level ----------------------------------------
+// score = max over the 16 arcs of 9 contiguous ring pixels of min(v - p)  (dark ring)  or of min(p - v)
+// (bright ring), minus 1  ==  cornerScore<16>() of OpenCV for any pixel that is a corner at threshold t
+// (then score >= t); a pixel is a corner at threshold t iff score >= t.  Stored clamped to [0,255].
+__global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+  const int grow = blockIdx.y;
+  const int l = find_level(d, grow);
+  const LevelInfo L = d.lv[l];
+  const int y = grow - L.rowBase;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < kEdge || x >= L.w - kEdge || y < kEdge || y >= L.h - kEdge) return;
+  const uint8_t* p = pyr + L.off + (size_t)y * L.stride + x;
+  const int s = L.stride;
+  const int v = p[0];
+  int dd[16];
+  dd[0] = v - p[3 * s];          dd[1] = v - p[3 * s + 1];      dd[2] = v - p[2 * s + 2];      dd[3] = v - p[s + 3];
+  dd[4] = v - p[3];              dd[5] = v - p[-s + 3];         dd[6] = v - p[-2 * s + 2];     dd[7] = v - p[-3 * s + 1];
+  dd[8] = v - p[-3 * s];         dd[9] = v - p[-3 * s - 1];     dd[10] = v - p[-2 * s - 2];    dd[11] = v - p[-s - 3];
+  dd[12] = v - p[-3];            dd[13] = v - p[s - 3];         dd[14] = v - p[2 * s - 2];     dd[15] = v - p[3 * s - 1];
+  // sliding min / max of width 9 over the circular ring by doubling: 2,4,8 then +1
+  int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn2[k] = min(dd[k], dd[(k + 1) & 15]); mx2[k] = max(dd[k], dd[(k + 1) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+  for (int k = 0; k < 16; k++) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+  int A = -256, B = 256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) { A = max(A, min(mn8[k], dd[(k + 8) & 15])); B = min(B, max(mx8[k], dd[(k + 8) & 15])); }
+  const int sc = max(A, -B) - 1;
+  score[L.off + (size_t)y * L.stride + x] = (uint8_t)min(max(sc, 0), 255);
+}
+
+// ---- per-cell threshold + NMS + fallback + ordered compaction ------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) { const int t = __shfl_up(v, off, kWave); if (lane >= off) v += t; }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t* __restrict__ score, int iniTh, int minTh,
+                                                        uint32_t* __restrict__ cell_slots, int* __restrict__ cell_counts) {
+  __shared__ uint8_t tile[40 * 48];
+  __shared__ int wsum[4];
+  __shared__ int total_s;
+  const int cell = blockIdx.x;
+  int l = 0;
+  for (int k = 1; k < d.nlevels; k++) if (cell >= d.lv[k].cellBase) l = k;
+  const LevelInfo L = d.lv[l];
+  const int ci = (cell - L.cellBase) / L.nCols, cj = (cell - L.cellBase) % L.nCols;
+  const int minB = kEdge - 3, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+  const int iniX = minB + cj * L.wCell, iniY = minB + ci * L.hCell;
+  int maxX = iniX + L.wCell + 6, maxY = iniY + L.hCell + 6;
+  if (iniY >= maxBY - 3 || iniX >= maxBX - 6) { if (threadIdx.x == 0) cell_counts[cell] = 0; return; }
+  if (maxX > maxBX) maxX = maxBX;
+  if (maxY > maxBY) maxY = maxBY;
+  // interior processed by cv::FAST on the ROI [iniX,maxX) x [iniY,maxY): 3-pixel margin
+  const int x0 = iniX + 3, y0 = iniY + 3;
+  const int iw = (maxX - iniX) - 6, ih = (maxY - iniY) - 6;
+  if (iw <= 0 || ih <= 0) { if (threadIdx.x == 0) cell_counts[cell] = 0; return; }
+  const int tw = iw + 2;   // zero-padded tile width
+  const int npx = iw * ih;
+  const int per = (npx + 255) / 256;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  for (int pass = 0; pass < 2; pass++) {
+    const int th = pass == 0 ? iniTh : minTh;
+    for (int t = threadIdx.x; t < (ih + 2) * tw; t += 256) {
+      const int ty = t / tw - 1, tx = t % tw - 1;
+      int m = 0;
+      if (tx >= 0 && tx < iw && ty >= 0 && ty < ih) {
+        const int sc = score[L.off + (size_t)(y0 + ty) * L.stride + x0 + tx];
+        m = sc >= th ? sc : 0;
+      }
+      tile[t] = (uint8_t)m;
+    }
+    __syncthreads();
+    uint32_t flags = 0;
+    int cnt = 0;
+    const int p0 = threadIdx.x * per;
+    for (int k = 0; k < per; k++) {
+      const int p = p0 + k;
+      if (p < npx) {
+        const int ty = p / iw, tx = p % iw;
+        const uint8_t* c = tile + (ty + 1) * tw + tx + 1;
+        const int m = c[0];
+        if (m > 0 && m > c[-1] && m > c[1] && m > c[-tw - 1] && m > c[-tw] && m > c[-tw + 1] && m > c[tw - 1] && m > c[tw] && m > c[tw + 1]) {
+          flags |= 1u << k; cnt++;
+        }
+      }
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    if (lane == kWave - 1) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += wsum[w];
+    if (threadIdx.x == 0) total_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int total = total_s;
+    if (total > 0 || pass == 1) {
+      int pos = base + incl - cnt;
+      for (int k = 0; k < per; k++) {
+        if (flags & (1u << k)) {
+          const int p = p0 + k;
+          const int ty = p / iw, tx = p % iw;
+          const int sc = tile[(ty + 1) * tw + tx + 1];
+          // candidate coordinates relative to (minBorderX, minBorderY), as in vToDistributeKeys (:989-994)
+          const uint32_t rx = (uint32_t)(x0 + tx - minB), ry = (uint32_t)(y0 + ty - minB);
+          if (pos < kCellCap) cell_slots[(size_t)cell * kCellCap + pos] = rx | (ry << 12) | ((uint32_t)sc << 24);
+          pos++;
+        }
+      }
+      if (threadIdx.x == 0) cell_counts[cell] = min(total, kCellCap);
+      return;
+    }
+    __syncthreads();
+  }
+}
+
+// concatenate the per-cell lists in cell order: out = [offsets (ncells+1)] [records ...]
+__global__ __launch_bounds__(1024) void orb_compact_kernel(int ncells, const uint32_t* __restrict__ cell_slots,
+                                                           const int* __restrict__ cell_counts, int* __restrict__ offsets,
+                                                           uint32_t* __restrict__ records) {
+  __shared__ int sh[1024];
+  __shared__ int carry_s;
+  const int t = threadIdx.x;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ncells; base += 1024) {
+    const int c = base + t;
+    const int v = c < ncells ? cell_counts[c] : 0;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = t >= off ? sh[t - off] : 0;
+      __syncthreads();
+      sh[t] += add;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (c < ncells) offsets[c] = carry + sh[t] - v;
+    __syncthreads();
+    if (t == 1023) carry_s = carry + sh[1023];
+    __syncthreads();
+  }
+  if (t == 0) offsets[ncells] = carry_s;
+  __syncthreads();
+  const int wave = t / kWave, lane = t & (kWave - 1);
+  for (int c = wave; c < ncells; c += 1024 / kWave) {
+    const int n = cell_counts[c], o = offsets[c];
+    for (int k = lane; k < n; k += kWave) records[o + k] = cell_slots[(size_t)c * kCellCap + k];
+  }
+}
+
+// ---- GaussianBlur 7x7 sigma 2, 8.8 fixed point {18,34,48,56,48,34,18}, REFLECT_101 -------------------
+__device__ __forceinline__ int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+  return p;
+}
+
+constexpr int kBlurTW = 64, kBlurTH = 16;
+__global__ __launch_bounds__(256) void orb_blur_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                       const int* __restrict__ tile_level, const int* __restrict__ tile_xy) {
+  __shared__ uint8_t in[(kBlurTH + 6) * (kBlurTW + 6)];
+  __shared__ uint16_t hs[(kBlurTH + 6) * kBlurTW];
+  const int l = tile_level[blockIdx.x];
+  const LevelInfo L = d.lv[l];
+  const int bx = tile_xy[2 * blockIdx.x], by = tile_xy[2 * blockIdx.x + 1];
+  const uint8_t* src = pyr + L.off;
+  for (int t = threadIdx.x; t < (kBlurTH + 6) * (kBlurTW + 6); t += 256) {
+    const int ty = t / (kBlurTW + 6), tx = t % (kBlurTW + 6);
+    const int gx = reflect101(bx + tx - 3, L.w), gy = reflect101(by + ty - 3, L.h);
+    in[t] = src[(size_t)gy * L.stride + gx];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < (kBlurTH + 6) * kBlurTW; t += 256) {
+    const int ty = t / kBlurTW, tx = t % kBlurTW;
+    const uint8_t* r = in + ty * (kBlurTW + 6) + tx;
+    hs[t] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < kBlurTH * kBlurTW; t += 256) {
+    const int ty = t / kBlurTW, tx = t % kBlurTW;
+    const int gx = bx + tx, gy = by + ty;
+    if (gx < L.w && gy < L.h) {
+      const uint16_t* c = hs + ty * kBlurTW + tx;
+      const uint32_t s = 18u * (c[0] + c[6 * kBlurTW]) + 34u * (c[kBlurTW] + c[5 * kBlurTW]) + 48u * (c[2 * kBlurTW] + c[4 * kBlurTW]) + 56u * c[3 * kBlurTW];
+      blur[L.off + (size_t)gy * L.stride + gx] = (uint8_t)((s + (1u << 15)) >> 16);
+    }
+  }
+}
+
+// ---- orientation + descriptor: one wave per keypoint -----------------------------------------------
+struct KpIn { int16_t x, y; int16_t level; int16_t response; };
+
+__global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                              const KpIn* __restrict__ kin, int n, ccm_keypoint* __restrict__ kout,
+                                                              uint8_t* __restrict__ desc) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  if (i >= n) return;
+  const KpIn kp = kin[i];
+  const LevelInfo L = d.lv[kp.level];
+  // IC_Angle (:68-95): integer moments over the radius-15 disc of the UNBLURRED level
+  const uint8_t* center = pyr + L.off + (size_t)kp.y * L.stride + kp.x;
+  int m10 = 0, m01 = 0;
+  {
+    const int u = lane - kHalfPatch;   // lanes 0..30 <-> u = -15..15
+    for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+      const int av = v < 0 ? -v : v;
+      if (lane <= 2 * kHalfPatch && (u <= d.umax[av] && u >= -d.umax[av])) {
+        const int val = center[v * L.stride + u];
+        m10 += u * val; m01 += v * val;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off, kWave); m01 += __shfl_xor(m01, off, kWave); }
+  }
+  const float angle = orbm::fast_atan2((float)m01, (float)m10);
+  // computeOrbDescriptor (:100-316) on the blurred level
+  const float factorPI = (float)(3.14159265358979323846 / 180.f);
+  const float ang = angle * factorPI;
+  const float a = orbm::cosf_glibc(ang), b = orbm::sinf_glibc(ang);
+  const uint8_t* bc = blur + L.off + (size_t)kp.y * L.stride + kp.x;
+  unsigned long long words[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pair = j * 64 + lane;
+    const float x0 = (float)c_pattern[pair * 4], y0 = (float)c_pattern[pair * 4 + 1];
+    const float x1 = (float)c_pattern[pair * 4 + 2], y1 = (float)c_pattern[pair * 4 + 3];
+    const int t0 = bc[orbm::cv_round(x0 * b + y0 * a) * L.stride + orbm::cv_round(x0 * a - y0 * b)];
+    const int t1 = bc[orbm::cv_round(x1 * b + y1 * a) * L.stride + orbm::cv_round(x1 * a - y1 * b)];
+    words[j] = __ballot(t0 < t1);
+  }
+  if (lane < 4) reinterpret_cast<unsigned long long*>(desc + (size_t)i * 32)[lane] = words[lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 2 : 3];
+  if (lane == 0) {
+    ccm_keypoint o;
+    // operator() epilogue (:1268-1274): pt *= mvScaleFactor[level] for level != 0
+    o.x = kp.level != 0 ? (float)kp.x * L.scale : (float)kp.x;
+    o.y = kp.level != 0 ? (float)kp.y * L.scale : (float)kp.y;
+    o.size = (float)(int)(kPatch * L.scale);   // scaledPatchSize = PATCH_SIZE*mvScaleFactor[level] truncated to int (:1006)
+    o.angle = angle;
+    o.response = (float)kp.response;
+    o.octave = kp.level;
+    kout[i] = o;
+  }
+}
+
+// =================================================================================================
+// host: DistributeOctTree (ORBextractor.cpp:707-931), index-linked list instead of std::list
+// =================================================================================================
+struct Cand { float x, y, response; };
+
+struct ONode {
+  int ulx, uly, urx, bry;          // UL.x, UL.y, UR.x, BR.y  (BL.x = UL.x, BL.y = BR.y, UR.y = UL.y, BR.x = UR.x)
+  std::vector<int> keys;           // indices into the candidate array, insertion order preserved
+  int prev = -1, next = -1;
+  bool noMore = false, alive = true;
+};
+
+struct Octree {
+  std::vector<ONode> nodes;
+  int head = -1, tail = -1, count = 0;
+  void push_back(int id) { ONode& n = nodes[id]; n.prev = tail; n.next = -1; if (tail >= 0) nodes[tail].next = id; else head = id; tail = id; count++; }
+  void push_front(int id) { ONode& n = nodes[id]; n.next = head; n.prev = -1; if (head >= 0) nodes[head].prev = id; else tail = id; head = id; count++; }
+  int erase(int id) {
+    ONode& n = nodes[id];
+    const int nx = n.next;
+    if (n.prev >= 0) nodes[n.prev].next = n.next; else head = n.next;
+    if (n.next >= 0) nodes[n.next].prev = n.prev; else tail = n.prev;
+    n.alive = false; count--;
+    return nx;
+  }
+};
+
+// splits node `id` into its four children (n1 UL, n2 UR, n3 BL, n4 BR); returns child ids (or -1 when empty)
+static void divide_node(Octree& T, int id, const Cand* c, int child[4]) {
+  const int ulx = T.nodes[id].ulx, uly = T.nodes[id].uly, urx = T.nodes[id].urx, bry = T.nodes[id].bry;
+  const int halfX = (int)std::ceil(static_cast<float>(urx - ulx) / 2);
+  const int halfY = (int)std::ceil(static_cast<float>(bry - uly) / 2);
+  const int midx = ulx + halfX, midy = uly + halfY;
+  ONode ch[4];
+  ch[0].ulx = ulx; ch[0].uly = uly; ch[0].urx = midx; ch[0].bry = midy;
+  ch[1].ulx = midx; ch[1].uly = uly; ch[1].urx = urx; ch[1].bry = midy;
+  ch[2].ulx = ulx; ch[2].uly = midy; ch[2].urx = midx; ch[2].bry = bry;
+  ch[3].ulx = midx; ch[3].uly = midy; ch[3].urx = urx; ch[3].bry = bry;
+  for (int k : T.nodes[id].keys) {
+    const Cand& kp = c[k];
+    if (kp.x < midx) { if (kp.y < midy) ch[0].keys.push_back(k); else ch[2].keys.push_back(k); }
+    else if (kp.y < midy) ch[1].keys.push_back(k);
+    else ch[3].keys.push_back(k);
+  }
+  for (int q = 0; q < 4; q++) {
+    if (ch[q].keys.empty()) { child[q] = -1; continue; }
+    ch[q].noMore = ch[q].keys.size() == 1;
+    child[q] = (int)T.nodes.size();
+    T.nodes.push_back(std::move(ch[q]));
+  }
+}
+
+// returns the selected candidate indices in the reference's output order (front-to-back list order)
+static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int maxX, int minY, int maxY, int N) {
+  Octree T;
+  T.nodes.reserve((size_t)n * 4 + 16);
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  for (int i = 0; i < nIni; i++) {
+    ONode r;
+    r.ulx = (int)(hX * static_cast<float>(i)); r.urx = (int)(hX * static_cast<float>(i + 1)); r.uly = 0; r.bry = maxY - minY;
+    T.nodes.push_back(r);
+    T.push_back(i);
+  }
+  for (int k = 0; k < n; k++) T.nodes[(int)(c[k].x / hX)].keys.push_back(k);
+  for (int id = T.head; id >= 0;) {
+    ONode& nd = T.nodes[id];
+    if (nd.keys.size() == 1) { nd.noMore = true; id = nd.next; }
+    else if (nd.keys.empty()) id = T.erase(id);
+    else id = nd.next;
+  }
+  bool finish = false;
+  std::vector<std::pair<int, int>> sizeAndNode;   // (size, node id); node ids grow with creation order
+  while (!finish) {
+    const int prevSize = T.count;
+    int nToExpand = 0;
+    sizeAndNode.clear();
+    for (int id = T.head; id >= 0;) {
+      if (T.nodes[id].noMore) { id = T.nodes[id].next; continue; }
+      int child[4];
+      divide_node(T, id, c, child);
+      for (int q = 0; q < 4; q++) {
+        if (child[q] < 0) continue;
+        T.push_front(child[q]);
+        if (T.nodes[child[q]].keys.size() > 1) { nToExpand++; sizeAndNode.emplace_back((int)T.nodes[child[q]].keys.size(), child[q]); }
+      }
+      id = T.erase(id);
+    }
+    if (T.count >= N || T.count == prevSize) finish = true;
+    else if (T.count + nToExpand * 3 > N) {
+      while (!finish) {
+        const int prev2 = T.count;
+        std::vector<std::pair<int, int>> prevList = sizeAndNode;
+        sizeAndNode.clear();
+        // reference sorts pair<int,ExtractorNode*>; equal sizes tie on the heap address there — here on
+        // creation order (the node id), the tie-break the oracle defines
+        std::sort(prevList.begin(), prevList.end());
+        for (int j = (int)prevList.size() - 1; j >= 0; j--) {
+          const int id = prevList[j].second;
+          int child[4];
+          divide_node(T, id, c, child);
+          for (int q = 0; q < 4; q++) {
+            if (child[q] < 0) continue;
+            T.push_front(child[q]);
+            if (T.nodes[child[q]].keys.size() > 1) sizeAndNode.emplace_back((int)T.nodes[child[q]].keys.size(), child[q]);
+          }
+          T.erase(id);
+          if (T.count >= N) break;
+        }
+        if (T.count >= N || T.count == prev2) finish = true;
+      }
+    }
+  }
+  std::vector<int> result;
+  result.reserve(T.count);
+  for (int id = T.head; id >= 0; id = T.nodes[id].next) {
+    const std::vector<int>& ks = T.nodes[id].keys;
+    int best = ks[0];
+    float maxResp = c[best].response;
+    for (size_t k = 1; k < ks.size(); k++) if (c[ks[k]].response > maxResp) { best = ks[k]; maxResp = c[best].response; }
+    result.push_back(best);
+  }
+  return result;
+}
+
+}  // namespace
+
+// =================================================================================================
+struct ccm_orb {
+  ccm_ctx* ctx = nullptr;
+  int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
+  float scaleFactor = 1.2f;
+  std::vector<float> sf, isf, s2, is2;
+  std::vector<int> nfeat;
+  int umax[16];
+  // geometry-dependent state
+  int w = 0, h = 0;
+  OrbDev dev{};
+  size_t pyr_bytes = 0;
+  uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  int16_t* d_tabs = nullptr; std::vector<int> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // per level offsets into d_tabs
+  uint32_t* d_cell_slots = nullptr; int* d_cell_counts = nullptr; int* d_cand = nullptr;   // d_cand: [ncells+1 offsets][records]
+  int cand_cap = 0;
+  int* d_tile_level = nullptr; int* d_tile_xy = nullptr; int n_blur_tiles = 0;
+  KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr; int kp_cap = 0;
+  int* h_cand = nullptr;   // pinned
+  KpIn* h_kin = nullptr;   // pinned
+  hipEvent_t ev_cand = nullptr;
+  // last-frame debug
+  std::vector<std::vector<Cand>> last_cand;
+};
+
+static void orb_free_geometry(ccm_orb* o) {
+  hipFree(o->d_pyr); hipFree(o->d_score); hipFree(o->d_blur); hipFree(o->d_tabs); hipFree(o->d_cell_slots);
+  hipFree(o->d_cell_counts); hipFree(o->d_cand); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
+  hipFree(o->d_kin); hipFree(o->d_kout); hipFree(o->d_desc);
+  if (o->h_cand) hipHostFree(o->h_cand);
+  if (o->h_kin) hipHostFree(o->h_kin);
+  o->d_pyr = o->d_score = o->d_blur = nullptr; o->d_tabs = nullptr; o->d_cell_slots = nullptr; o->d_cell_counts = nullptr;
+  o->d_cand = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->d_kin = nullptr; o->d_kout = nullptr; o->d_desc = nullptr;
+  o->h_cand = nullptr; o->h_kin = nullptr;
+}
+
+extern "C" int ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
+                              int min_th_fast, ccm_orb** out) {
+  if (!ctx || !out || nfeatures <= 0 || nlevels <= 0 || nlevels > kMaxLevels || !(scale_factor > 1.0f) || min_th_fast < 1 || ini_th_fast < 1)
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_orb_create: bad args");
+  ccm_orb* o = new ccm_orb();
+  o->ctx = ctx; o->nfeatures = nfeatures; o->nlevels = nlevels; o->iniTh = ini_th_fast; o->minTh = min_th_fast; o->scaleFactor = scale_factor;
+  // ORBextractor ctor (:584-638), f32 arithmetic as written there
+  o->sf.resize(nlevels); o->s2.resize(nlevels); o->isf.resize(nlevels); o->is2.resize(nlevels); o->nfeat.resize(nlevels);
+  o->sf[0] = 1.0f; o->s2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) { o->sf[i] = o->sf[i - 1] * scale_factor; o->s2[i] = o->sf[i] * o->sf[i]; }
+  for (int i = 0; i < nlevels; i++) { o->isf[i] = 1.0f / o->sf[i]; o->is2[i] = 1.0f / o->s2[i]; }
+  const float factor = 1.0f / scale_factor;
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int level = 0; level < nlevels - 1; level++) { o->nfeat[level] = (int)lrintf(nDesired); sum += o->nfeat[level]; nDesired *= factor; }
+  o->nfeat[nlevels - 1] = std::max(nfeatures - sum, 0);
+  {
+    int v, v0;
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1), vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) o->umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) { while (o->umax[v0] == o->umax[v0 + 1]) ++v0; o->umax[v] = v0; ++v0; }
+  }
+  hipSetDevice(ctx->device);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kOrbPattern31, 1024);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev_cand, hipEventDisableTiming);
+  if (e != hipSuccess) { delete o; return ccm_set_error(ctx, CCM_E_HIP, std::string("orb: pattern upload: ") + hipGetErrorString(e)); }
+  *out = o;
+  return CCM_OK;
+}
+
+extern "C" void ccm_orb_destroy(ccm_orb* o) {
+  if (!o) return;
+  if (o->ctx) { hipSetDevice(o->ctx->device); hipStreamSynchronize(o->ctx->stream); }
+  orb_free_geometry(o);
+  if (o->ev_cand) hipEventDestroy(o->ev_cand);
+  delete o;
+}
+
+extern "C" int ccm_orb_get_table(const ccm_orb* o, int which, float* out, int cap) {
+  if (!o || !out || which < 0 || which > 3) return CCM_E_ARG;
+  const std::vector<float>& t = which == 0 ? o->sf : which == 1 ? o->isf : which == 2 ? o->s2 : o->is2;
+  for (int i = 0; i < o->nlevels && i < cap; i++) out[i] = t[i];
+  return CCM_OK;
+}
+extern "C" int ccm_orb_features_per_level(const ccm_orb* o, int32_t* out, int cap) {
+  if (!o || !out) return CCM_E_ARG;
+  for (int i = 0; i < o->nlevels && i < cap; i++) out[i] = o->nfeat[i];
+  return CCM_OK;
+}
+extern "C" int ccm_orb_level_size(const ccm_orb* o, int w, int h, int level, int* lw, int* lh) {
+  if (!o || level < 0 || level >= o->nlevels || !lw || !lh) return CCM_E_ARG;
+  *lw = (int)lrintf((float)w * o->isf[level]);   // cvRound((float)image.cols*scale) (:1285)
+  *lh = (int)lrintf((float)h * o->isf[level]);
+  return CCM_OK;
+}
+extern "C" int ccm_orb_max_keypoints(const ccm_orb* o) { return o ? o->nfeatures + 3 * o->nlevels + 8 : 0; }
+
+// (re)build everything that depends on the image size
+static int orb_prepare(ccm_orb* o, int w, int h) {
+  ccm_ctx* ctx = o->ctx;
+  if (o->w == w && o->h == h && o->d_pyr) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  orb_free_geometry(o);
+  OrbDev& d = o->dev;
+  d.nlevels = o->nlevels;
+  for (int i = 0; i < 16; i++) d.umax[i] = o->umax[i];
+  int off = 0, cellBase = 0, rowBase = 0, maxW = 0;
+  std::vector<int16_t> tabs;
+  o->tab_xofs.assign(o->nlevels, 0); o->tab_ialpha.assign(o->nlevels, 0); o->tab_yofs.assign(o->nlevels, 0); o->tab_ibeta.assign(o->nlevels, 0);
+  std::vector<int> tile_level, tile_xy;
+  for (int l = 0; l < o->nlevels; l++) {
+    LevelInfo& L = d.lv[l];
+    ccm_orb_level_size(o, w, h, l, &L.w, &L.h);
+    if (L.w < 2 * kEdge + 8 || L.h < 2 * kEdge + 8) return ccm_set_error(ctx, CCM_E_ARG, "orb: image too small for the requested pyramid");
+    if (L.w > 4000 || L.h > 4000) return ccm_set_error(ctx, CCM_E_ARG, "orb: image too large (packed candidate coordinates are 12 bit)");
+    L.stride = (L.w + 63) & ~63;
+    L.off = off; off += L.stride * L.h;
+    L.rowBase = rowBase; rowBase += L.h;
+    L.scale = o->sf[l];
+    maxW = std::max(maxW, L.w);
+    // cell grid (:949-955), f32 arithmetic as in the reference
+    const float width = (float)((L.w - kEdge + 3) - (kEdge - 3)), height = (float)((L.h - kEdge + 3) - (kEdge - 3));
+    L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
+    if (L.nCols <= 0 || L.nRows <= 0) return ccm_set_error(ctx, CCM_E_ARG, "orb: pyramid level smaller than one cell");
+    L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+    if (L.wCell + 6 > 46 || L.hCell + 6 > 38) return ccm_set_error(ctx, CCM_E_STATE, "orb: cell larger than the LDS tile");
+    L.cellBase = cellBase; cellBase += L.nCols * L.nRows;
+    // resize tables for level l (from level l-1)
+    if (l > 0) {
+      const LevelInfo& P = d.lv[l - 1];
+      const double scale_x = 1. / ((double)L.w / P.w), scale_y = 1. / ((double)L.h / P.h);
+      o->tab_xofs[l] = (int)tabs.size();
+      for (int dx = 0; dx < L.w; dx++) { float fx = (float)((dx + 0.5) * scale_x - 0.5); int sx = (int)std::floor(fx); if (sx < 0) sx = 0; if (sx >= P.w - 1) sx = P.w - 1; tabs.push_back((int16_t)sx); }
+      o->tab_ialpha[l] = (int)tabs.size();
+      for (int dx = 0; dx < L.w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5); int sx = (int)std::floor(fx); fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= P.w - 1) { fx = 0; sx = P.w - 1; }
+        tabs.push_back((int16_t)std::min(std::max((int)lrintf((1.f - fx) * 2048.f), -32768), 32767));
+        tabs.push_back((int16_t)std::min(std::max((int)lrintf(fx * 2048.f), -32768), 32767));
+      }
+      o->tab_yofs[l] = (int)tabs.size();
+      for (int dy = 0; dy < L.h; dy++) { float fy = (float)((dy + 0.5) * scale_y - 0.5); tabs.push_back((int16_t)(int)std::floor(fy)); }
+      o->tab_ibeta[l] = (int)tabs.size();
+      for (int dy = 0; dy < L.h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5); int sy = (int)std::floor(fy); fy -= sy;
+        tabs.push_back((int16_t)std::min(std::max((int)lrintf((1.f - fy) * 2048.f), -32768), 32767));
+        tabs.push_back((int16_t)std::min(std::max((int)lrintf(fy * 2048.f), -32768), 32767));
+      }
+      if (tabs.size() & 1) tabs.push_back(0);
+    }
+    for (int by = 0; by < L.h; by += kBlurTH)
+      for (int bx = 0; bx < L.w; bx += kBlurTW) { tile_level.push_back(l); tile_xy.push_back(bx); tile_xy.push_back(by); }
+  }
+  d.ncells = cellBase; d.totalRows = rowBase; d.maxW = maxW;
+  o->pyr_bytes = (size_t)off + 4096;
+  o->n_blur_tiles = (int)tile_level.size();
+  o->cand_cap = d.ncells * kCellCap;
+  o->kp_cap = ccm_orb_max_keypoints(o);
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_pyr, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_score, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_blur, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_pyr, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_score, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_blur, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
+  if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cell_slots, (size_t)o->cand_cap * sizeof(uint32_t)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cell_counts, (size_t)d.ncells * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_level, tile_level.size() * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_xy, tile_xy.size() * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_level, tile_level.data(), tile_level.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_xy, tile_xy.data(), tile_xy.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_kout, (size_t)o->kp_cap * sizeof(ccm_keypoint)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_desc, (size_t)o->kp_cap * 32));
+  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int), hipHostMallocDefault));
+  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_kin, (size_t)o->kp_cap * sizeof(KpIn), hipHostMallocDefault));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  o->w = w; o->h = h;
+  return CCM_OK;
+}
+
+// device phase 1: pyramid, scores, cells, compaction; blur is queued too (it does not depend on the octree)
+static int orb_phase1(ccm_orb* o) {
+  ccm_ctx* ctx = o->ctx;
+  const OrbDev& d = o->dev;
+  for (int l = 1; l < o->nlevels; l++) {
+    const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
+    ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE);
+    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, ctx->stream, o->d_pyr + P.off, P.w, P.h, P.stride,
+                       o->d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
+                       o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
+  }
+  {
+    ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
+    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, ctx->stream, d, o->d_pyr, o->d_score);
+  }
+  {
+    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
+    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d, o->d_score, o->iniTh, o->minTh, o->d_cell_slots, o->d_cell_counts);
+    hipLaunchKernelGGL(orb_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, d.ncells, o->d_cell_slots, o->d_cell_counts, o->d_cand,
+                       (uint32_t*)(o->d_cand + d.ncells + 1));
+  }
+  const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_cand, o->d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_cand, ctx->stream));
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BLUR);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, ctx->stream, d, o->d_pyr, o->d_blur, o->d_tile_level, o->d_tile_xy);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+// host phase: read candidates, run the octree per level, fill h_kin; returns the keypoint count
+static int orb_host_select(ccm_orb* o, int* n_out) {
+  ccm_ctx* ctx = o->ctx;
+  const OrbDev& d = o->dev;
+  // wait for the candidate copy only (the blur kernel queued behind it keeps running)
+  CCM_HIP_CHECK(ctx, hipEventSynchronize(o->ev_cand));
+  const int* offs = o->h_cand;
+  const int total = offs[d.ncells];
+  if (total > kCandFirstCopy) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_cand + d.ncells + 1 + kCandFirstCopy, o->d_cand + d.ncells + 1 + kCandFirstCopy,
+                                      (size_t)(total - kCandFirstCopy) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  const uint32_t* rec = (const uint32_t*)(o->h_cand + d.ncells + 1);
+  o->last_cand.assign(o->nlevels, {});
+  int n = 0;
+  for (int l = 0; l < o->nlevels; l++) {
+    const LevelInfo& L = d.lv[l];
+    const int c0 = offs[L.cellBase], c1 = offs[L.cellBase + L.nCols * L.nRows];
+    std::vector<Cand>& cand = o->last_cand[l];
+    cand.resize(c1 - c0);
+    for (int k = c0; k < c1; k++) {
+      const uint32_t r = rec[k];
+      cand[k - c0] = Cand{(float)(r & 0xFFF), (float)((r >> 12) & 0xFFF), (float)(r >> 24)};
+    }
+    if (cand.empty()) continue;
+    const int minB = kEdge - 3;
+    std::vector<int> sel = distribute_octree(cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l]);
+    for (int id : sel) {
+      if (n >= o->kp_cap) break;
+      o->h_kin[n++] = KpIn{(int16_t)((int)cand[id].x + minB), (int16_t)((int)cand[id].y + minB), (int16_t)l, (int16_t)cand[id].response};
+    }
+  }
+  *n_out = n;
+  return CCM_OK;
+}
+
+static int orb_phase2(ccm_orb* o, int n) {
+  ccm_ctx* ctx = o->ctx;
+  if (n == 0) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_kin, o->h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BRIEF);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->d_pyr, o->d_blur, o->d_kin, n, o->d_kout, o->d_desc);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int stride, ccm_keypoint* kps, uint8_t* desc,
+                               int cap, int* n_out, uint8_t* const* pyramid_out) {
+  if (!o || !img || w <= 0 || h <= 0 || stride < w || !kps || !desc || !n_out) return ccm_set_error(o ? o->ctx : nullptr, CCM_E_ARG, "ccm_orb_extract: bad args");
+  ccm_ctx* ctx = o->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = orb_prepare(o, w, h);
+  if (rc) return rc;
+  const LevelInfo& L0 = o->dev.lv[0];
+  CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = orb_phase1(o))) return rc;
+  int n = 0;
+  if ((rc = orb_host_select(o, &n))) return rc;
+  if ((rc = orb_phase2(o, n))) return rc;
+  const int nc = std::min(n, cap);
+  if (nc) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(kps, o->d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(desc, o->d_desc, (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (pyramid_out)
+    for (int l = 0; l < o->nlevels; l++)
+      if (pyramid_out[l]) {
+        const LevelInfo& L = o->dev.lv[l];
+        CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, o->d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+      }
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *n_out = nc;
+  return CCM_OK;
+}
+
+extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int n_frames, int w, int h, ccm_keypoint* d_kps,
+                                         uint8_t* d_desc, int cap, int32_t* d_counts) {
+  if (!o || !d_imgs || n_frames < 0 || !d_kps || !d_desc || !d_counts) return ccm_set_error(o ? o->ctx : nullptr, CCM_E_ARG, "ccm_orb_extract_batch_dev: bad args");
+  ccm_ctx* ctx = o->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = orb_prepare(o, w, h);
+  if (rc) return rc;
+  const LevelInfo& L0 = o->dev.lv[0];
+  for (int f = 0; f < n_frames; f++) {
+    CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = orb_phase1(o))) return rc;
+    int n = 0;
+    if ((rc = orb_host_select(o, &n))) return rc;
+    if ((rc = orb_phase2(o, n))) return rc;
+    const int nc = std::min(n, cap);
+    if (nc) {
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_kps + (size_t)f * cap, o->d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToDevice, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc + (size_t)f * cap * 32, o->d_desc, (size_t)nc * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_counts + f, &nc, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // nc lives on this stack frame
+  }
+  return CCM_OK;
+}
+
+extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uint8_t* blur_out) {
+  if (!o || !o->d_pyr || level < 0 || level >= o->nlevels) return CCM_E_ARG;
+  ccm_ctx* ctx = o->ctx;
+  const LevelInfo& L = o->dev.lv[level];
+  if (score_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  if (blur_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(blur_out, L.w, o->d_blur + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) {
+  if (!o || level < 0 || level >= o->nlevels || !n_out || (int)o->last_cand.size() != o->nlevels) return CCM_E_ARG;
+  const std::vector<Cand>& c = o->last_cand[level];
+  *n_out = (int)c.size();
+  for (int i = 0; i < (int)c.size() && i < cap && out; i++) out[i] = ccm_keypoint{c[i].x, c[i].y, 7.f, -1.f, c[i].response, 0};
+  return CCM_OK;
+}
+
+// host-only entry point for the CPU tests of the octree (no GPU involved): selects from candidates
+// given relative to (minX,minY); writes the indices of the chosen candidates in output order.
+extern "C" int ccm_orb_distribute_octree(const float* x, const float* y, const float* response, int n, int minX, int maxX,
+                                         int minY, int maxY, int N, int32_t* sel_out, int cap, int* n_out) {
+  if (n < 0 || !n_out || (n && (!x || !y || !response)) || maxX <= minX || maxY <= minY || N <= 0) return CCM_E_ARG;
+  std::vector<Cand> c(n);
+  for (int i = 0; i < n; i++) c[i] = Cand{x[i], y[i], response[i]};
+  std::vector<int> sel;
+  if (n) sel = distribute_octree(c.data(), n, minX, maxX, minY, maxY, N);
+  *n_out = (int)sel.size();
+  for (int i = 0; i < (int)sel.size() && i < cap && sel_out; i++) sel_out[i] = sel[i];
+  return CCM_OK;
+}

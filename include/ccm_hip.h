@@ -107,13 +107,20 @@ void ccm_orb_destroy(ccm_orb* orb);
  * up to nlevels floats; which: 0 scale, 1 inv scale, 2 sigma2, 3 inv sigma2.             */
 int  ccm_orb_get_table(const ccm_orb* orb, int which, float* out, int cap);
 int  ccm_orb_features_per_level(const ccm_orb* orb, int32_t* out, int cap);
-/* one frame, host buffers in and out.  kps/desc capacity must be >= nfeatures rows.
+/* one frame, host buffers in and out.  kps/desc capacity (cap rows) should be >= ccm_orb_max_keypoints().
  * pyramid_out (nullable): nlevels caller buffers receiving the un-bordered level images
  * (mvImagePyramid, ORBextractor.h:138), each at least level_w*level_h bytes, row stride = level_w. */
 int  ccm_orb_extract(ccm_orb* orb, const uint8_t* img, int w, int h, int stride,
                      ccm_keypoint* kps, uint8_t* desc, int cap, int* n_out,
                      uint8_t* const* pyramid_out);
 int  ccm_orb_level_size(const ccm_orb* orb, int w, int h, int level, int* lw, int* lh);
+/* upper bound of keypoints one frame can return: DistributeOctTree stops at >= N nodes per level and
+ * may overshoot by up to 3 (ORBextractor.cpp:837,898), so the total can exceed nfeatures.          */
+int  ccm_orb_max_keypoints(const ccm_orb* orb);
+/* host-only (no GPU): DistributeOctTree (ORBextractor.cpp:707-931) on candidates given relative to
+ * (minX,minY); sel_out receives the indices of the kept candidates in the reference's output order. */
+int  ccm_orb_distribute_octree(const float* x, const float* y, const float* response, int n, int minX, int maxX,
+                               int minY, int maxY, int N, int32_t* sel_out, int cap, int* n_out);
 /* batch of frames already resident in HBM (d_imgs: n_frames images, tightly packed w*h each);
  * outputs stay on the device: d_kps [n_frames][cap], d_desc [n_frames][cap][32],
  * d_counts [n_frames].  Host octree selection (DistributeOctTree) runs between the two device

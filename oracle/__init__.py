@@ -203,3 +203,112 @@ def pose_optimize(cam_qt, Xw, obs, info, K):
     ninl = lib().ora_pose_optimize(_p(cam, C.c_double), n, _p(Xw, C.c_double), _p(obs, C.c_double), _p(info, C.c_double),
                                    _p(K, C.c_double), _p(outl, C.c_uint8))
     return cam, outl[:n], int(ninl)
+
+
+# ---- ORB extractor ---------------------------------------------------------------------------------
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                     ("response", np.float32), ("octave", np.int32)])
+
+
+class OrbOracle:
+    """cslam::ORBextractor restated (oracle/orb_ref.cpp)."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7):
+        L = lib()
+        L.ora_orb_create.restype = C.c_void_p
+        self.nlevels, self.nfeatures = nlevels, nfeatures
+        self._h = C.c_void_p(L.ora_orb_create(int(nfeatures), C.c_float(scale), int(nlevels), int(ini_th), int(min_th)))
+
+    def close(self):
+        if self._h:
+            lib().ora_orb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = lib().ora_orb_extract(self._h, _p(img, C.c_uint8), w, h, w, kps.ctypes.data_as(C.c_void_p), _p(desc, C.c_uint8), cap)
+        self._wh = (w, h)
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        lib().ora_orb_level_size(self._h, w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    def level(self, level):
+        lw, lh = self.level_size(*self._wh, level)
+        out = np.empty((lh, lw), np.uint8)
+        lib().ora_orb_get_level(self._h, level, _p(out, C.c_uint8))
+        return out
+
+    def blur(self, level):
+        lw, lh = self.level_size(*self._wh, level)
+        out = np.empty((lh, lw), np.uint8)
+        lib().ora_orb_get_blur(self._h, level, _p(out, C.c_uint8))
+        return out
+
+    def candidates(self, level):
+        n = lib().ora_orb_get_candidates(self._h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        lib().ora_orb_get_candidates(self._h, level, out.ctypes.data_as(C.c_void_p), n)
+        return out[:n]
+
+    def tables(self):
+        nl = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(nl, np.float32) for _ in range(4))
+        nf = np.zeros(nl, np.int32)
+        um = np.zeros(16, np.int32)
+        lib().ora_orb_tables(self._h, _p(sf, C.c_float), _p(isf, C.c_float), _p(s2, C.c_float), _p(is2, C.c_float),
+                             _p(nf, C.c_int32), _p(um, C.c_int32))
+        return sf, isf, s2, is2, nf, um
+
+
+def resize_linear_u8(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().ora_resize_linear_u8(_p(src, C.c_uint8), src.shape[1], src.shape[0], _p(out, C.c_uint8), dw, dh)
+    return out
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    out = np.empty_like(src)
+    lib().ora_gaussian_blur7(_p(src, C.c_uint8), src.shape[1], src.shape[0], _p(out, C.c_uint8))
+    return out
+
+
+def gaussian_kernel7():
+    k = np.zeros(7, np.int32)
+    lib().ora_gaussian_kernel7(_p(k, C.c_int32))
+    return k
+
+
+def fast9_16(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(max(cap, 1), KP_DTYPE)
+    n = lib().ora_fast9_16(_p(img, C.c_uint8), img.shape[1], img.shape[0], int(threshold), out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n]
+
+
+def fast_atan2(y, x):
+    lib().ora_fast_atan2.restype = C.c_float
+    return float(lib().ora_fast_atan2(C.c_float(y), C.c_float(x)))
+
+
+def distribute_octree(kps, minX, maxX, minY, maxY, N):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(max(kps.size, 1), KP_DTYPE)
+    n = lib().ora_distribute_octree(kps.ctypes.data_as(C.c_void_p), kps.size, minX, maxX, minY, maxY, N,
+                                    out.ctypes.data_as(C.c_void_p), out.size)
+    return out[:n]

@@ -1,0 +1,86 @@
+"""GPU parity: ORB extraction vs the oracle restatement of cslam::ORBextractor — bit-exact keypoints
+(all six fields) and descriptors, plus every intermediate product (pyramid levels, FAST score semantics via
+the pre-octree candidate lists, blurred levels)."""
+import numpy as np
+import pytest
+
+from ccm_slam_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(ctx, oracle_lib, img, nfeatures, **kw):
+    ex = orb.ORBextractor(ctx, nfeatures, **kw)
+    kps, desc, pyr = ex(img, want_pyramid=True)
+    o = oracle_lib.OrbOracle(nfeatures, **{{"ini_th_fast": "ini_th", "min_th_fast": "min_th", "scale_factor": "scale"}.get(k, k): v for k, v in kw.items()})
+    okps, odesc = o.extract(img)
+    for l in range(ex.nlevels):
+        assert np.array_equal(pyr[l], o.level(l)), f"pyramid level {l}"
+        cand = ex.debug_candidates(l)
+        ocand = o.candidates(l)
+        assert len(cand) == len(ocand), f"candidate count level {l}: {len(cand)} vs {len(ocand)}"
+        for f in ("x", "y", "response"):
+            assert np.array_equal(cand[f], ocand[f]), f"candidates level {l} field {f}"
+        if (okps["octave"] == l).any():
+            _, blur = ex.debug_level(l)
+            assert np.array_equal(blur, o.blur(l)), f"blur level {l}"
+    assert len(kps) == len(okps)
+    for f in ("octave", "x", "y", "response", "size", "angle"):
+        assert np.array_equal(kps[f], okps[f]), f"keypoint field {f}"
+    assert np.array_equal(desc, odesc)
+    ex.close()
+    return kps, desc
+
+
+@pytest.mark.parametrize("seed,t", [(1000, 0), (1000, 7), (1003, 0)])
+def test_euroc_shape_1000_features(ctx, oracle_lib, seed, t):
+    kps, desc = _compare(ctx, oracle_lib, synth.gen_image(seed, t), 1000)
+    assert 900 <= len(kps) <= 1000 + 24
+
+
+def test_init_extractor_2000_features(ctx, oracle_lib):
+    kps, _ = _compare(ctx, oracle_lib, synth.gen_image(1001, 3), 2000)
+    assert len(kps) > 1500
+
+
+def test_low_texture_uses_min_threshold(ctx, oracle_lib):
+    # smooth image with a few weak blobs: most cells are empty at iniThFAST=20 and retry with minThFAST=7
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:480, 0:752]
+    img = (100 + 30 * np.sin(xx / 60.0) * np.cos(yy / 45.0)).astype(np.float64)
+    for _ in range(300):
+        x, y = rng.integers(30, 720), rng.integers(30, 450)
+        img[y - 1:y + 2, x - 1:x + 2] += rng.integers(8, 18)
+    _compare(ctx, oracle_lib, np.clip(np.rint(img), 0, 255).astype(np.uint8), 1000)
+
+
+def test_constant_image_no_keypoints(ctx, oracle_lib):
+    ex = orb.ORBextractor(ctx, 1000)
+    kps, desc = ex(np.full((480, 752), 77, np.uint8))
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    ex.close()
+
+
+def test_other_geometry_and_levels(ctx, oracle_lib):
+    img = synth.gen_image(77, 1, w=640, h=360)
+    _compare(ctx, oracle_lib, img, 700, nlevels=5, scale_factor=1.3)
+
+
+def test_accessors_match_reference_tables(ctx, oracle_lib):
+    ex = orb.ORBextractor(ctx, 1000)
+    o = oracle_lib.OrbOracle(1000)
+    sf, isf, s2, is2, nf, _ = o.tables()
+    assert np.array_equal(ex.GetScaleFactors(), sf) and np.array_equal(ex.GetInverseScaleFactors(), isf)
+    assert np.array_equal(ex.GetScaleSigmaSquares(), s2) and np.array_equal(ex.GetInverseScaleSigmaSquares(), is2)
+    assert np.array_equal(ex.features_per_level(), nf)
+    assert list(nf) == [217, 181, 151, 126, 105, 87, 73, 60]
+    ex.close()
+
+
+def test_repeatable(ctx):
+    img = synth.gen_image(1000, 11)
+    ex = orb.ORBextractor(ctx, 1000)
+    k1, d1 = ex(img)
+    k2, d2 = ex(img)
+    assert np.array_equal(d1, d2) and np.array_equal(k1, k2)
+    ex.close()
