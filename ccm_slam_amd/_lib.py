@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libccm_hip.so")
@@ -88,6 +89,10 @@ class Context:
         self._h = C.c_void_p()
         check(lib().ccm_ctx_create(int(device), C.byref(self._h)))
         self.device = device
+        self._children = weakref.WeakSet()   # handles (ORB, BA) that must be destroyed before the ctx
+
+    def adopt(self, child):
+        self._children.add(child)
 
     @property
     def handle(self):
@@ -98,6 +103,11 @@ class Context:
 
     def close(self):
         if self._h:
+            for ch in list(self._children):
+                try:
+                    ch.close()
+                except Exception:
+                    pass
             lib().ccm_ctx_destroy(self._h)
             self._h = C.c_void_p()
 

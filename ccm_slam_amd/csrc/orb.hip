@@ -34,7 +34,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxLevels = 16;
 constexpr int kEdge = 19, kHalfPatch = 15, kPatch = 31;
-constexpr int kCellCap = 320;      // >= ceil(36/2)*ceil(34/2): NMS keeps no two adjacent pixels
+constexpr int kCellMax = 50;       // largest cell edge supported by the LDS tile
+constexpr int kCellCap = 640;      // >= ceil(50/2)^2: strict 3x3 NMS keeps no two adjacent pixels
 constexpr int kCandFirstCopy = 16384;
 
 struct LevelInfo {
@@ -123,7 +124,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 
 __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t* __restrict__ score, int iniTh, int minTh,
                                                         uint32_t* __restrict__ cell_slots, int* __restrict__ cell_counts) {
-  __shared__ uint8_t tile[40 * 48];
+  __shared__ uint8_t tile[(kCellMax + 2) * (kCellMax + 2)];
   __shared__ int wsum[4];
   __shared__ int total_s;
   const int cell = blockIdx.x;
@@ -578,7 +579,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
     if (L.nCols <= 0 || L.nRows <= 0) return ccm_set_error(ctx, CCM_E_ARG, "orb: pyramid level smaller than one cell");
     L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
-    if (L.wCell + 6 > 46 || L.hCell + 6 > 38) return ccm_set_error(ctx, CCM_E_STATE, "orb: cell larger than the LDS tile");
+    if (L.wCell > kCellMax || L.hCell > kCellMax) return ccm_set_error(ctx, CCM_E_STATE, "orb: cell larger than the LDS tile");
     L.cellBase = cellBase; cellBase += L.nCols * L.nRows;
     // resize tables for level l (from level l-1)
     if (l > 0) {

@@ -43,6 +43,7 @@ class BAHandle:
                                _vp(k["e_obs"]), _vp(k["e_info"]), _vp(k["e_level"]), float(prob["huber_delta"]))
         self._h = C.c_void_p()
         check(lib().ccm_ba_create(ctx.handle, C.byref(self.cprob), int(rank), int(nranks), C.byref(self._h)), ctx.handle)
+        ctx.adopt(self)
 
     def reset(self):
         check(lib().ccm_ba_reset_state(self._h, C.c_void_p(_vp(self._keep["cam_qt"])), C.c_void_p(_vp(self._keep["pt_xyz"]))),

@@ -22,6 +22,7 @@ class ORBextractor:
         check(lib().ccm_orb_create(ctx.handle, int(nfeatures), C.c_float(scale_factor), int(nlevels), int(ini_th_fast),
                                    int(min_th_fast), C.byref(self._h)), ctx.handle)
         self.cap = int(lib().ccm_orb_max_keypoints(self._h))
+        ctx.adopt(self)
 
     def close(self):
         if self._h:
