@@ -340,3 +340,35 @@ def gen_image(seed: int, t: int = 0, w: int = IMG_W, h: int = IMG_H) -> np.ndarr
     nrng = np.random.default_rng(seed * 7919 + t)
     img = img + nrng.integers(-4, 5, img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_pose_problem(n: int = 300, seed: int = 0, outlier_frac: float = 0.1, pose_sigma_t: float = 0.05,
+                      pose_sigma_r_deg: float = 1.0):
+    """One tracked frame for Optimizer::PoseOptimizationClient (Optimizer.cpp:215-347): n map points seen by
+    a camera, f32-rounded world positions (MapPoint::GetWorldPos is CV_32F), f32 keypoints with octave-
+    dependent noise, a fraction of gross outliers, and a perturbed initial pose (the motion-model prediction)."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = EUROC_K
+    R, t, _ = _agent_loop(40, 0)
+    R, t = R[3], t[3]
+    depth = rng.uniform(1.5, 9.0, n)
+    u = rng.uniform(30, IMG_W - 30, n)
+    v = rng.uniform(30, IMG_H - 30, n)
+    Xc = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], 1)
+    Xw = (Xc - t) @ R          # R^T (Xc - t)
+    Xw = Xw.astype(np.float32).astype(np.float64)
+    _, _, _, inv_s2 = scale_tables()
+    octave = np.clip(np.ceil(np.log(10.0 / depth) / np.log(SCALE)), 0, N_LEVELS - 1).astype(np.int64)
+    Xc2 = Xw @ R.T + t
+    obs = np.stack([fx * Xc2[:, 0] / Xc2[:, 2] + cx, fy * Xc2[:, 1] / Xc2[:, 2] + cy], 1)
+    obs += rng.normal(size=obs.shape) * (SCALE ** octave)[:, None]
+    out = rng.random(n) < outlier_frac
+    obs += out[:, None] * rng.uniform(8, 60, (n, 2)) * rng.choice([-1.0, 1.0], (n, 2))
+    obs = obs.astype(np.float32).astype(np.float64)
+    dR = rodrigues(rng.normal(size=(1, 3)) * np.deg2rad(pose_sigma_r_deg))[0]
+    R0 = (dR @ R).astype(np.float32).astype(np.float64)
+    t0 = (t + rng.normal(size=3) * pose_sigma_t).astype(np.float32).astype(np.float64)
+    cam0 = np.concatenate([quat_from_R(R0[None])[0], t0])
+    gt = np.concatenate([quat_from_R(R[None])[0], t])
+    return dict(cam_qt=cam0, Xw=Xw, obs=obs, info=inv_s2[octave].astype(np.float64), K=np.array(EUROC_K), gt_cam_qt=gt,
+                is_outlier=out)

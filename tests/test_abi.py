@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/ccm_hip.h declares;
+host-only entry points work; creating a context without a GPU fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "ccm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ccm_slam_amd import _lib
+    lib = _lib.lib()
+    names = _declared()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_version_and_error_strings():
+    from ccm_slam_amd import _lib
+    lib = _lib.lib()
+    assert lib.ccm_version().decode().endswith("gfx950")
+    assert lib.ccm_ctx_create(0, None) == -1   # CCM_E_ARG
+
+
+def test_no_gpu_means_no_context():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from ccm_slam_amd._lib import CcmError, Context
+    with pytest.raises(CcmError, match="no HIP device|no CPU fallback|device"):
+        Context(0)
+
+
+def test_partition_balances_weights():
+    from ccm_slam_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    w = rng.integers(1, 50, 1000).astype(np.int64)
+    for nr in (1, 2, 3, 8):
+        out = np.zeros(nr + 1, np.int32)
+        assert lib.ccm_ba_partition(w.ctypes.data_as(C.c_void_p), w.size, nr, out.ctypes.data_as(C.c_void_p)) == 0
+        assert out[0] == 0 and out[-1] == w.size and (np.diff(out) >= 0).all()
+        sums = np.array([w[out[i]:out[i + 1]].sum() for i in range(nr)])
+        assert sums.sum() == w.sum()
+        assert sums.max() <= w.sum() / nr + 50
+    out = np.zeros(5, np.int32)
+    assert lib.ccm_ba_partition(None, 0, 4, out.ctypes.data_as(C.c_void_p)) == 0 and (out == 0).all()
+
+
+def test_depth_positive_host():
+    from ccm_slam_amd import _lib, synth
+    from ccm_slam_amd.optimizer import _vp
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=10, n_points=100, seed=1)
+    cam = np.ascontiguousarray(prob["cam_qt"]); pts = np.ascontiguousarray(prob["pt_xyz"])
+    k = {n: np.ascontiguousarray(prob[n]) for n in ("cam_fixed", "cam_K", "e_cam", "e_pt", "e_obs", "e_info")}
+    cp = _lib.BAProblem(prob["n_cam"], prob["n_pt"], prob["n_edge"], _vp(cam), _vp(k["cam_fixed"]), _vp(k["cam_K"]), _vp(pts),
+                        _vp(k["e_cam"]), _vp(k["e_pt"]), _vp(k["e_obs"]), _vp(k["e_info"]), None, 0.0)
+    out = np.zeros(prob["n_edge"], np.uint8)
+    assert _lib.lib().ccm_ba_depth_positive(C.byref(cp), C.c_void_p(_vp(cam)), C.c_void_p(_vp(pts)), C.c_void_p(_vp(out))) == 0
+    assert out.all()   # every synthetic observation is in front of its camera

@@ -1,0 +1,118 @@
+"""CPU: pins the BA oracle (oracle/ba_ref.cpp) with derivations that share no code with it:
+ (i) one Levenberg-Marquardt step re-derived in numpy/scipy: numerical Jacobian of the reprojection residual
+     under the exp-map / additive parameterisation, Huber-weighted dense normal equations, dense solve;
+ (ii) noise-free scenes converge to ground truth; (iii) dense vs block-sparse Cholesky agree; (iv) the LM
+     acceptance rule keeps chi2 monotone; (v) the sharded partial systems sum to the full system."""
+import numpy as np
+from scipy.linalg import expm
+
+import oracle
+from ccm_slam_amd import synth
+
+
+def _T_from_qt(qt):
+    T = np.eye(4)
+    T[:3, :3] = synth.R_from_quat(qt[None, :4])[0]
+    T[:3, 3] = qt[4:]
+    return T
+
+
+def _residuals(prob, Ts, pts):
+    K = prob["cam_K"]
+    e = np.zeros((prob["n_edge"], 2))
+    for k in range(prob["n_edge"]):
+        c, p = prob["e_cam"][k], prob["e_pt"][k]
+        Xc = Ts[c][:3, :3] @ pts[p] + Ts[c][:3, 3]
+        e[k, 0] = prob["e_obs"][k, 0] - (K[c, 0] * Xc[0] / Xc[2] + K[c, 2])
+        e[k, 1] = prob["e_obs"][k, 1] - (K[c, 1] * Xc[1] / Xc[2] + K[c, 3])
+    return e
+
+
+def _twist(u):
+    M = np.zeros((4, 4))
+    w = u[:3]
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u[3:]
+    return M
+
+
+def test_one_lm_step_matches_numpy_derivation():
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=5, n_points=40, seed=7, mean_track=4, n_fixed=1, loop_len=50,
+                                 outlier_frac=0.1)
+    free = np.nonzero(prob["cam_fixed"] == 0)[0]
+    Ts0 = [_T_from_qt(q) for q in prob["cam_qt"]]
+    pts0 = prob["pt_xyz"].copy()
+    npar = 6 * len(free) + 3 * prob["n_pt"]
+
+    def apply(x):
+        Ts = [T.copy() for T in Ts0]
+        for i, c in enumerate(free):
+            Ts[c] = expm(_twist(x[6 * i:6 * i + 6])) @ Ts0[c]
+        return Ts, pts0 + x[6 * len(free):].reshape(-1, 3)
+
+    r0 = _residuals(prob, Ts0, pts0)
+    J = np.zeros((2 * prob["n_edge"], npar))
+    h = 1e-6
+    for j in range(npar):
+        d = np.zeros(npar)
+        d[j] = h
+        J[:, j] = ((_residuals(prob, *apply(d)) - _residuals(prob, *apply(-d))) / (2 * h)).ravel()
+    om = prob["e_info"]
+    chi2 = (r0 ** 2).sum(1) * om
+    delta = prob["huber_delta"]
+    w = np.where(chi2 <= delta * delta, 1.0, delta / np.sqrt(np.maximum(chi2, 1e-300)))
+    W = np.repeat(w * om, 2)
+    H = J.T @ (W[:, None] * J)
+    b = -J.T @ (W * r0.ravel())
+    lam = 1e-5 * np.abs(np.diag(H)).max()
+    dx = np.linalg.solve(H + lam * np.eye(npar), b)
+    Ts1, pts1 = apply(dx)
+    # oracle: one iteration, same lambda
+    ocam, opts, _, _, st = oracle.ba_optimize(prob, 1, linear_solver=1)
+    assert st.iters_done == 1 and st.lm_trials == 1 and st.chi2_final < st.chi2_initial
+    rob0 = np.where(chi2 <= delta * delta, chi2, 2 * np.sqrt(chi2) * delta - delta * delta).sum()
+    assert abs(st.chi2_initial - rob0) < 1e-9 * rob0
+    assert np.abs(opts - pts1).max() < 2e-6
+    for c in range(prob["n_cam"]):
+        assert np.abs(_T_from_qt(ocam[c]) - Ts1[c]).max() < 2e-6
+
+
+def test_noise_free_scene_converges_to_truth():
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=12, n_points=400, seed=3, noise=False, n_fixed=2, loop_len=80)
+    rng = np.random.default_rng(0)
+    prob["pt_xyz"] = prob["pt_xyz"] + rng.normal(size=prob["pt_xyz"].shape) * 0.02
+    cam, pts, _, _, st = oracle.ba_optimize(prob, 25)
+    assert st.chi2_final < 1e-4 * st.chi2_initial
+    assert np.abs(pts - prob["gt_pt_xyz"]).max() < 2e-3
+
+
+def test_dense_and_sparse_solvers_agree_and_chi2_is_monotone():
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=40, n_points=2500, seed=5)
+    c1, p1, _, _, s1 = oracle.ba_optimize(prob, 8, linear_solver=1)
+    c2, p2, _, _, s2 = oracle.ba_optimize(prob, 8, linear_solver=2)
+    assert s1.iters_done == s2.iters_done and abs(s1.chi2_final - s2.chi2_final) < 1e-8 * s1.chi2_final
+    assert np.abs(c1 - c2).max() < 1e-9 and np.abs(p1 - p2).max() < 1e-8
+    hist = [s1.chi2_initial] + [s1.chi2_hist[i] for i in range(s1.iters_done)]
+    assert all(b <= a for a, b in zip(hist, hist[1:]))
+
+
+def test_partial_systems_sum_to_full_system():
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=15, n_points=600, seed=9)
+    lam = 37.5
+    Hf, bf, cf = oracle.ba_partial_system(prob, lam, 0, prob["n_pt"], True)
+    mid = prob["n_pt"] // 3
+    H1, b1, c1 = oracle.ba_partial_system(prob, lam, 0, mid, True)
+    H2, b2, c2 = oracle.ba_partial_system(prob, lam, mid, prob["n_pt"], False)
+    assert np.abs(H1 + H2 - Hf).max() < 1e-9 * np.abs(Hf).max()
+    assert np.abs(b1 + b2 - bf).max() < 1e-9 * np.abs(bf).max()
+    assert abs(c1 + c2 - cf) < 1e-9 * cf
+    assert np.allclose(Hf, Hf.T) and np.linalg.eigvalsh(Hf).min() > 0
+
+
+def test_pose_optimization_recovers_pose_and_flags_outliers():
+    p = synth.make_pose_problem(400, 1, 0.15)
+    cam, outl, ninl = oracle.pose_optimize(p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
+    dt, dr = synth.pose_errors(cam[None], p["gt_cam_qt"][None])
+    assert dt[0] < 0.01 and dr[0] < 0.05
+    assert outl[p["is_outlier"]].mean() > 0.95 and ninl == 400 - outl.sum()
+    assert oracle.pose_optimize(p["cam_qt"], p["Xw"][:2], p["obs"][:2], p["info"][:2], p["K"])[2] == 0

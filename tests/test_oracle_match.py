@@ -1,0 +1,97 @@
+"""CPU: the matcher oracle against self-evident known answers (the reference ships no golden vectors)."""
+import numpy as np
+
+import oracle
+
+
+def _popcount_dist(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+def test_descriptor_distance_is_popcount():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+        assert oracle.descriptor_distance(a, b) == _popcount_dist(a, b)
+    z = np.zeros(32, np.uint8)
+    assert oracle.descriptor_distance(z, z) == 0
+    assert oracle.descriptor_distance(z, np.full(32, 255, np.uint8)) == 256
+
+
+def test_dense_best2_brute_force():
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (20, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    t[7] = q[3]; t[9] = q[3]   # exact duplicates: first index must win, second-best distance is 0 too
+    bi, bd, sd = oracle.hamming_dense_best2(q, t)
+    for i in range(20):
+        d = np.array([_popcount_dist(q[i], t[j]) for j in range(50)])
+        assert bd[i] == d.min() and bi[i] == int(np.argmin(d))
+        assert sd[i] == np.sort(d)[1]
+    assert bi[3] == 7 and bd[3] == 0 and sd[3] == 0
+
+
+def test_grid_candidates_window_and_levels():
+    # 4 keypoints, Frame grid 75x48 over a 752x480 image (Frame.cpp:87-88, 200-253)
+    kx = np.array([100.0, 103.0, 140.0, 100.0], np.float32)
+    ky = np.array([100.0, 101.0, 100.0, 100.0], np.float32)
+    octv = np.array([0, 1, 0, 3], np.int32)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    off, idx = oracle.grid_candidates(kx, ky, octv, bounds, [100.0, 100.0, 100.0], [100.0, 100.0, 100.0], [5.0, 5.0, 50.0],
+                                      [-1, 1, 0], [-1, 3, 0])
+    assert sorted(idx[off[0]:off[1]]) == [0, 1, 3]        # no level check
+    assert sorted(idx[off[1]:off[2]]) == [1, 3]           # levels 1..3
+    assert sorted(idx[off[2]:off[3]]) == [0, 2]           # maxLevel = 0 keeps octave 0 only
+    # strict inequality: a point exactly r away is excluded (|dx| < r)
+    off, idx = oracle.grid_candidates(kx, ky, octv, bounds, [95.0], [100.0], [5.0], [-1], [-1])
+    assert 0 not in idx[off[0]:off[1]]
+
+
+def test_search_by_projection_claims_are_sequential():
+    # two map points project onto the same spot; one feature.  The first map point claims it, the second
+    # one must then skip it (ORBmatcher.cpp:113-115) even though its descriptor matches better.
+    d = np.zeros((1, 32), np.uint8)
+    mp_desc = np.zeros((2, 32), np.uint8)
+    mp_desc[0, 0] = 0b111          # distance 3
+    n, fm = oracle.search_by_projection_mp([100.0], [100.0], [0], d, (0, 0, 752, 480), np.ones(8, np.float32),
+                                           [1, 1], [100.0, 100.0], [100.0, 100.0], [0, 0], [1.0, 1.0], mp_desc, 1.0, 0.6,
+                                           [-1])
+    assert n == 1 and fm[0] == 0
+    # not in view -> skipped
+    n, fm = oracle.search_by_projection_mp([100.0], [100.0], [0], d, (0, 0, 752, 480), np.ones(8, np.float32),
+                                           [0, 1], [100.0, 100.0], [100.0, 100.0], [0, 0], [1.0, 1.0], mp_desc, 1.0, 0.6,
+                                           [-1])
+    assert n == 1 and fm[0] == 1
+
+
+def test_search_by_projection_ratio_test_same_level_only():
+    # two features at the same level with distances 40 and 50: 40 > 0.6*50 -> rejected;
+    # when the second-best sits on another level the ratio test is skipped (ORBmatcher.cpp:137-141)
+    f = np.zeros((2, 32), np.uint8)
+    f[0, :5] = 0xFF   # 40 bits
+    f[1, :6] = 0xFF; f[1, 6] = 0x03  # 50 bits
+    mp = np.zeros((1, 32), np.uint8)
+    args = ([100.0, 101.0], [100.0, 100.0])
+    n, fm = oracle.search_by_projection_mp(*args, [1, 1], f, (0, 0, 752, 480), np.ones(8, np.float32), [1], [100.0], [100.0],
+                                           [1], [1.0], mp, 1.0, 0.6, [-1, -1])
+    assert n == 0
+    n, fm = oracle.search_by_projection_mp(*args, [1, 0], f, (0, 0, 752, 480), np.ones(8, np.float32), [1], [100.0], [100.0],
+                                           [1], [1.0], mp, 1.0, 0.6, [-1, -1])
+    assert n == 1 and fm[0] == 0
+
+
+def test_search_by_projection_last_rotation_histogram():
+    # 12 consistent matches (rotation 0) and one with a 90 degree rotation: the odd one is removed
+    # (HISTO_LENGTH bins of 30 degrees, ORBmatcher.cpp:1358,1437-1445)
+    n_f = 13
+    kx = np.arange(n_f, dtype=np.float32) * 40 + 50
+    ky = np.full(n_f, 200, np.float32)
+    desc = np.zeros((n_f, 32), np.uint8)
+    for i in range(n_f):
+        desc[i, i] = 0xFF
+    kangle = np.zeros(n_f, np.float32)
+    l_angle = np.zeros(n_f, np.float32); l_angle[5] = 90.0
+    n, cur = oracle.search_by_projection_last(kx, ky, np.zeros(n_f, np.int32), kangle, desc, (0, 0, 752, 480),
+                                              np.ones(8, np.float32), np.ones(n_f, np.uint8), kx, ky, np.zeros(n_f, np.int32),
+                                              l_angle, desc, 7.0, 1, -np.ones(n_f, np.int32))
+    assert n == 12 and cur[5] == -1 and (np.delete(cur, 5) == np.delete(np.arange(n_f), 5)).all()

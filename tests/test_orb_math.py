@@ -1,0 +1,60 @@
+"""CPU: the product's scalar ORB math header (ccm_slam_amd/csrc/orb_math.h) against this machine's libm
+(cosf/sinf — bit-for-bit) and the oracle's fastAtan2."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = r'''
+#include "%s/ccm_slam_amd/csrc/orb_math.h"
+#include <string.h>
+extern "C" long check_trig(unsigned lo, unsigned hi, unsigned step) {
+  long bad = 0;
+  for (unsigned long u = lo; u <= hi; u += step) { unsigned v = (unsigned)u; float a; memcpy(&a, &v, 4);
+    float c1 = cosf(a), c2 = orbm::cosf_glibc(a), s1 = sinf(a), s2 = orbm::sinf_glibc(a);
+    bad += (memcmp(&c1, &c2, 4) != 0) + (memcmp(&s1, &s2, 4) != 0); }
+  return bad;
+}
+extern "C" float my_atan2(float y, float x) { return orbm::fast_atan2(y, x); }
+extern "C" int my_round(float v) { return orbm::cv_round(v); }
+''' % ROOT
+
+
+def _helper():
+    d = tempfile.mkdtemp()
+    src = os.path.join(d, "h.cpp")
+    open(src, "w").write(SRC)
+    so = os.path.join(d, "h.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", so, "-lm"])
+    lib = C.CDLL(so)
+    lib.check_trig.restype = C.c_long
+    lib.my_atan2.restype = C.c_float
+    return lib
+
+
+def test_sincos_bit_exact_vs_libm_over_the_angle_range():
+    lib = _helper()
+    hi = int(np.float32(6.4).view(np.uint32))
+    # every 7th float in [0, 6.4] (155 M values would take ~1 s each pass; stride keeps the suite quick);
+    # the exhaustive run (1 087 163 598 floats, 0 mismatches) is recorded in DESIGN.md
+    assert lib.check_trig(0, hi, 7) == 0
+
+
+def test_fast_atan2_equals_oracle_restatement():
+    lib = _helper()
+    rng = np.random.default_rng(0)
+    for _ in range(20000):
+        y, x = (float(v) for v in rng.integers(-3_000_000, 3_000_000, 2))
+        assert lib.my_atan2(C.c_float(y), C.c_float(x)) == np.float32(oracle.fast_atan2(y, x))
+    assert lib.my_atan2(C.c_float(0), C.c_float(0)) == 0.0
+
+
+def test_cv_round_half_to_even():
+    lib = _helper()
+    for v, e in [(0.5, 0), (1.5, 2), (2.5, 2), (-0.5, 0), (-1.5, -2), (2.4999, 2), (-7.5, -8), (13.0, 13)]:
+        assert lib.my_round(C.c_float(v)) == e

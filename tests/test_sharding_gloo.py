@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the algebra of the landmark-sharded global BA.
+
+The HIP kernels cannot run here, so each rank builds ITS shard's partial reduced camera system with the
+oracle, the shards are summed with torch.distributed.all_reduce (the collective the product issues through
+RCCL once per LM trial, ccm_slam_amd/csrc/ba.hip lm_trial), and the sum must equal the unsharded system; the
+shard boundaries come from the product's own host-side partitioner (ccm_ba_partition)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from ccm_slam_amd import _lib, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=12, n_points=500, seed=13)
+    # weights as ccm_ba_create computes them: pair instances + edges per landmark
+    free = prob["cam_fixed"][prob["e_cam"]] == 0
+    k_all = np.bincount(prob["e_pt"], minlength=prob["n_pt"])
+    k_free = np.bincount(prob["e_pt"], weights=free, minlength=prob["n_pt"]).astype(np.int64)
+    w = (k_free * (k_free + 1) // 2 + k_all).astype(np.int64)
+    bounds = np.zeros(world + 1, np.int32)
+    assert _lib.lib().ccm_ba_partition(w.ctypes.data_as(C.c_void_p), w.size, world, bounds.ctypes.data_as(C.c_void_p)) == 0
+    lam = 12.0
+    H, b, chi = oracle.ba_partial_system(prob, lam, int(bounds[rank]), int(bounds[rank + 1]), rank == 0)
+    buf = torch.from_numpy(np.concatenate([H.ravel(), b, [chi]]))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    Hf, bf, cf = oracle.ba_partial_system(prob, lam, 0, prob["n_pt"], True)
+    full = np.concatenate([Hf.ravel(), bf, [cf]])
+    err = float(np.abs(buf.numpy() - full).max() / np.abs(full).max())
+    # every rank solves the identical reduced system -> identical camera step
+    n = bf.size
+    dx = np.linalg.solve(buf.numpy()[:n * n].reshape(n, n), buf.numpy()[n * n:n * n + n])
+    gathered = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(dx))
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    q.put((rank, err, same, [int(x) for x in bounds]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_partial_systems_allreduce_to_full_system():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, same, bounds in res:
+        assert err < 1e-10, (rank, err)
+        assert same
+        assert bounds[0] == 0 and bounds[-1] == 500 and 100 < bounds[1] < 400
