@@ -31,6 +31,65 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def tracking_leg(ctx, with_cpu, n_frames=32):
+    """Per-frame cost of the agent-side hot path on one GPU, synthetic EuRoC-shaped stream (752x480,
+    1000 ORB features): ORB extraction through the host API (image in, keypoints+descriptors out, PCIe
+    included), one windowed Hamming search (SearchByProjection shape: 1000 queries x ~30 candidates) and
+    three PoseOptimizationClient calls (Tracking.cpp:532,595,631 call it 2-3 times per frame)."""
+    import numpy as np
+    from ccm_slam_amd import matcher, optimizer, orb, synth
+    ex = orb.ORBextractor(ctx, 1000)
+    imgs = [synth.gen_image(1000, t) for t in range(n_frames)]
+    for i in range(3):
+        ex(imgs[i])
+    t0 = time.perf_counter()
+    for im in imgs:
+        kps, desc = ex(im)
+    t_orb = (time.perf_counter() - t0) / n_frames
+    rng = np.random.default_rng(0)
+    Q, T = 1000, len(kps)
+    lens = rng.poisson(30, Q)
+    off = np.zeros(Q + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    idx = rng.integers(0, T, off[-1]).astype(np.int32)
+    q = desc[rng.integers(0, T, Q)]
+    matcher.hamming_csr(ctx, q, desc, off, idx)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        matcher.hamming_csr(ctx, q, desc, off, idx)
+    t_match = (time.perf_counter() - t0) / 20
+    p = synth.make_pose_problem(300, 0, 0.1)
+    optimizer.pose_optimization(ctx, p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        optimizer.pose_optimization(ctx, p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
+    t_pose = (time.perf_counter() - t0) / 20
+    frame = t_orb + t_match + 3 * t_pose
+    out = {"tracked_fps_per_agent": round(1.0 / frame, 1), "orb_extract_ms": round(t_orb * 1e3, 4),
+           "orb_fps_per_agent": round(1.0 / t_orb, 1), "window_match_ms": round(t_match * 1e3, 4),
+           "pose_opt_ms": round(t_pose * 1e3, 4), "features": int(T),
+           "note": "host-API timings (H2D/D2H included); ORB keypoints/descriptors bit-exact vs oracle (tests/test_orb_gpu.py)"}
+    if with_cpu:
+        import oracle
+        o = oracle.OrbOracle(1000)
+        t0 = time.perf_counter()
+        for im in imgs[:8]:
+            o.extract(im)
+        c_orb = (time.perf_counter() - t0) / 8
+        t0 = time.perf_counter()
+        for _ in range(10):
+            oracle.pose_optimize(p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
+        c_pose = (time.perf_counter() - t0) / 10
+        t0 = time.perf_counter()
+        for _ in range(5):
+            oracle.hamming_csr(q, desc, off, idx)
+        c_match = (time.perf_counter() - t0) / 5
+        out["cpu_port"] = {"tracked_fps_per_agent": round(1.0 / (c_orb + c_match + 3 * c_pose), 1), "orb_extract_ms": round(c_orb * 1e3, 3),
+                           "window_match_ms": round(c_match * 1e3, 4), "pose_opt_ms": round(c_pose * 1e3, 4), "cores": 1}
+    ex.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +215,11 @@ def main():
                "phases_ms": {"residuals": round(ost.ms_residuals, 1), "quadratic_form": round(ost.ms_quadratic, 1),
                              "schur": round(ost.ms_schur, 1), "linear_solve": round(ost.ms_linear, 1)}}
 
+    # ---- the other half of the metric: tracked fps / agent (rank 0 only; one agent = one GPU)
+    extra = None
+    if rank == 0:
+        extra = tracking_leg(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(done, 1)
         out = {
@@ -171,6 +235,7 @@ def main():
                        "setup_ms_excluded": round(setup_s * 1e3, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "extra": extra,
         }
         if cpu:
             out["speedup_vs_cpu_port"] = round((done / elapsed) / cpu["value"], 1)
