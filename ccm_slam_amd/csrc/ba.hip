@@ -392,28 +392,38 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
   double* pnew = d.p[(k + 1) & 1];
   double pq = 0;
   if (i < d.Cp) {
-    const int r = lane / 6, c = lane % 6;
+    // lane = g*8 + r: group g (0..7) takes every 8th block of the row, r (0..5) is the block row; each lane does
+    // one 1x6 . 6x1 product per block (48 contiguous bytes of the block), so 8 blocks are in flight per wave step
+    // and the dependent index -> block -> vector load chain is paid row_len/8 times instead of row_len times.
+    const int g = lane >> 3, r = lane & 7;
     double acc = 0;
-    if (lane < 36) {
+    if (r < 6) {
       const int s0 = d.row_off[i], s1 = d.row_off[i + 1];
-      for (int s = s0; s < s1; s++) {
+      for (int s = s0 + g; s < s1; s += 8) {
         const int j = d.row_col[s];
         const uint32_t bt = d.row_blk[s];
         const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
-        const double v = (bt & kTransposeBit) ? B[c * 6 + r] : B[r * 6 + c];
-        const double pj = d.z[6 * (size_t)j + c] + beta * pold[6 * (size_t)j + c];
-        acc += v * pj;
+        const double* zj = d.z + 6 * (size_t)j;
+        const double* pj = pold + 6 * (size_t)j;
+        double v[6];
+        if (bt & kTransposeBit) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
       }
     }
-    // reduce over c (6 consecutive lanes r*6 .. r*6+5): fixed order
-    double row = 0;
-#pragma unroll
-    for (int cc = 0; cc < 6; cc++) row += __shfl(acc, r * 6 + cc, kWave);
-    // lanes 0..5 take element r = lane
-    const double qr = __shfl(row, (lane % 6) * 6, kWave);   // lane L<6 reads the sum of row L
+    // sum over the 8 groups (lanes with equal r): fixed xor tree
+    acc += __shfl_xor(acc, 8, kWave);
+    acc += __shfl_xor(acc, 16, kWave);
+    acc += __shfl_xor(acc, 32, kWave);
     if (lane < 6) {
       const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
-      const double qv = qr + lambda * pi;
+      const double qv = acc + lambda * pi;
       d.q[6 * (size_t)i + lane] = qv;
       pnew[6 * (size_t)i + lane] = pi;
       pq = pi * qv;
