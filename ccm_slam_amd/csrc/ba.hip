@@ -216,13 +216,19 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
 }
 
 // max |diag| of Hpp (after it has been summed over ranks) and of the own Hll  -> scal[2]
-__global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_full) {
+// stage 1: grid-stride partial maxima (one per workgroup) ; stage 2 (final != 0): max of the partials
+__global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_full, double* partial, int n_partial, int final) {
   __shared__ double lds[kTPB];
   double m = 0;
-  for (int i = threadIdx.x; i < d.Cp * 6; i += kTPB) m = fmax(m, fabs(hpp_full[36 * (size_t)(i / 6) + (i % 6) * 7]));
-  for (int i = threadIdx.x; i < d.Lloc * 3; i += kTPB) {
-    const int l = i / 3, k = i % 3;
-    m = fmax(m, fabs(d.Hll[6 * (size_t)l + (k == 0 ? 0 : (k == 1 ? 3 : 5))]));
+  if (!final) {
+    const int stride = gridDim.x * kTPB;
+    for (int i = blockIdx.x * kTPB + threadIdx.x; i < d.Cp * 6; i += stride) m = fmax(m, fabs(hpp_full[36 * (size_t)(i / 6) + (i % 6) * 7]));
+    for (int i = blockIdx.x * kTPB + threadIdx.x; i < d.Lloc * 3; i += stride) {
+      const int l = i / 3, k = i % 3;
+      m = fmax(m, fabs(d.Hll[6 * (size_t)l + (k == 0 ? 0 : (k == 1 ? 3 : 5))]));
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_partial; i += kTPB) m = fmax(m, partial[i]);
   }
   lds[threadIdx.x] = m;
   __syncthreads();
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_fu
     if (threadIdx.x < s) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) d.scal[2] = lds[0];
+  if (threadIdx.x == 0) { if (final) d.scal[2] = lds[0]; else partial[blockIdx.x] = lds[0]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -339,9 +345,8 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, doub
 #pragma unroll
     for (int k = 0; k < 6; k++) A[k * 7] += lambda;
     if (!ba_spd6_inv(A, Inv)) { d.pcg_flag[2] = 1; for (int k = 0; k < 36; k++) Inv[k] = (k % 7 == 0) ? 1.0 : 0.0; }
-    double* M = d.Minv + 36 * (size_t)i;
 #pragma unroll
-    for (int k = 0; k < 36; k++) M[k] = Inv[k];
+    for (int k = 0; k < 36; k++) d.Minv[(size_t)k * d.Cp + i] = Inv[k];   // SoA: coalesced across rows
     double rr[6], zz[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) rr[k] = d.bs[6 * (size_t)i + k];
@@ -462,12 +467,11 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
       rr[a] = d.r[6 * (size_t)i + a] - alpha * d.q[6 * (size_t)i + a];
       d.r[6 * (size_t)i + a] = rr[a];
     }
-    const double* M = d.Minv + 36 * (size_t)i;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       double s = 0;
 #pragma unroll
-      for (int b = 0; b < 6; b++) s += M[a * 6 + b] * rr[b];
+      for (int b = 0; b < 6; b++) s += d.Minv[(size_t)(a * 6 + b) * d.Cp + i] * rr[b];
       d.z[6 * (size_t)i + a] = s;
       rz += rr[a] * s;
     }
@@ -919,7 +923,9 @@ int max_diag(ccm_ba* ba, double* out) {
     RC(ccm_allreduce_f64(ctx, ba->d_hpp_full, 36 * (size_t)d.Cp));
     hpp = ba->d_hpp_full;
   }
-  hipLaunchKernelGGL(ba_maxdiag, dim3(1), dim3(kTPB), 0, ctx->stream, d, hpp);
+  const int nb = std::max(1, std::min(d.n_wg_pt, 512));   // partials live in part_pt (>= 2*n_wg_pt doubles)
+  hipLaunchKernelGGL(ba_maxdiag, dim3(nb), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 0);
+  hipLaunchKernelGGL(ba_maxdiag, dim3(1), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 1);
   RC(ccm_allreduce_max_f64(ctx, d.scal + 2, 1));
   double s[4];
   RC(read_scalars(ba, s));

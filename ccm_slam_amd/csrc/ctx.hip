@@ -63,6 +63,7 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
     for (auto& p : s.pending) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->d_io) hipFree(ctx->d_io);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -106,6 +107,18 @@ int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
     ctx->d_scratch_bytes = nb;
   }
   *out = ctx->d_scratch;
+  return CCM_OK;
+}
+
+int ccm_io_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->d_io_bytes) {
+    if (ctx->d_io) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_io); ctx->d_io = nullptr; }
+    size_t nb = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&ctx->d_io, nb);
+    if (e != hipSuccess) { ctx->d_io_bytes = 0; return ccm_set_error(ctx, CCM_E_HIP, "io scratch hipMalloc failed"); }
+    ctx->d_io_bytes = nb;
+  }
+  *out = ctx->d_io;
   return CCM_OK;
 }
 

@@ -172,10 +172,10 @@ extern "C" int ccm_hamming_dense_best2(ccm_ctx* ctx, const uint8_t* q, int Q, co
     return ccm_set_error(ctx, CCM_E_ARG, "hamming_dense: bad args");
   if (Q == 0) return CCM_OK;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  uint8_t *d_q = nullptr, *d_t = nullptr; int32_t* d_out = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_q, (size_t)Q * 32));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)std::max(T, 1) * 32));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)Q * 3 * sizeof(int32_t)));
+  const size_t bq = ccm_align256((size_t)Q * 32), bt = ccm_align256((size_t)std::max(T, 1) * 32);
+  void* io = nullptr;
+  { int rc0 = ccm_io_scratch(ctx, bq + bt + (size_t)Q * 3 * sizeof(int32_t), &io); if (rc0) return rc0; }
+  uint8_t* d_q = (uint8_t*)io; uint8_t* d_t = d_q + bq; int32_t* d_out = (int32_t*)(d_t + bt);
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream));
   if (T) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
   int rc = ccm_hamming_dense_best2_dev(ctx, d_q, Q, d_t, T, d_out, d_out + Q, d_out + 2 * (size_t)Q);
@@ -186,7 +186,6 @@ extern "C" int ccm_hamming_dense_best2(ccm_ctx* ctx, const uint8_t* q, int Q, co
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_dense: ") + hipGetErrorString(e));
   }
-  hipFree(d_q); hipFree(d_t); hipFree(d_out);
   return rc;
 }
 
@@ -223,13 +222,12 @@ extern "C" int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint
   for (int64_t s = 0; s < n_cand; ++s)
     if (cand_idx[s] < 0 || cand_idx[s] >= T) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: candidate index out of range");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  uint8_t *d_q = nullptr, *d_t = nullptr; int32_t *d_off = nullptr, *d_idx = nullptr, *d_out = nullptr; uint16_t* d_dist = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_q, (size_t)Q * 32));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_t, (size_t)std::max(T, 1) * 32));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_off, (size_t)(Q + 1) * 4));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_idx, (size_t)std::max<int64_t>(n_cand, 1) * 4));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_dist, (size_t)std::max<int64_t>(n_cand, 1) * 2));
-  CCM_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)Q * 3 * 4));
+  const size_t bq = ccm_align256((size_t)Q * 32), bt = ccm_align256((size_t)std::max(T, 1) * 32), bo = ccm_align256((size_t)(Q + 1) * 4);
+  const size_t bi = ccm_align256((size_t)std::max<int64_t>(n_cand, 1) * 4), bd = ccm_align256((size_t)std::max<int64_t>(n_cand, 1) * 2);
+  void* io = nullptr;
+  { int rc0 = ccm_io_scratch(ctx, bq + bt + bo + bi + bd + (size_t)Q * 12, &io); if (rc0) return rc0; }
+  uint8_t* d_q = (uint8_t*)io; uint8_t* d_t = d_q + bq; int32_t* d_off = (int32_t*)(d_t + bt); int32_t* d_idx = (int32_t*)((uint8_t*)d_off + bo);
+  uint16_t* d_dist = (uint16_t*)((uint8_t*)d_idx + bi); int32_t* d_out = (int32_t*)((uint8_t*)d_dist + bd);
   hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream);
   if (T) hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream);
   hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -246,6 +244,5 @@ extern "C" int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_csr: ") + hipGetErrorString(e));
   }
-  hipFree(d_q); hipFree(d_t); hipFree(d_off); hipFree(d_idx); hipFree(d_dist); hipFree(d_out);
   return rc;
 }

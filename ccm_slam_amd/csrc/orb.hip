@@ -200,39 +200,24 @@ __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t*
   }
 }
 
-// concatenate the per-cell lists in cell order: out = [offsets (ncells+1)] [records ...]
-__global__ __launch_bounds__(1024) void orb_compact_kernel(int ncells, const uint32_t* __restrict__ cell_slots,
+// concatenate the per-cell lists in cell order: out = [offsets (ncells+1)] [records ...].
+// One workgroup per cell: its offset is the sum of the counts of all earlier cells (<= ~1000 ints, cheaper
+// than a separate scan launch), then it copies its own records.
+__global__ __launch_bounds__(256) void orb_compact_kernel(int ncells, const uint32_t* __restrict__ cell_slots,
                                                            const int* __restrict__ cell_counts, int* __restrict__ offsets,
                                                            uint32_t* __restrict__ records) {
-  __shared__ int sh[1024];
-  __shared__ int carry_s;
-  const int t = threadIdx.x;
-  if (t == 0) carry_s = 0;
+  __shared__ int wsum[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  int s = 0;
+  for (int k = t; k < c; k += 256) s += cell_counts[k];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, kWave);
+  if ((t & (kWave - 1)) == 0) wsum[t / kWave] = s;
   __syncthreads();
-  for (int base = 0; base < ncells; base += 1024) {
-    const int c = base + t;
-    const int v = c < ncells ? cell_counts[c] : 0;
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const int add = t >= off ? sh[t - off] : 0;
-      __syncthreads();
-      sh[t] += add;
-      __syncthreads();
-    }
-    const int carry = carry_s;
-    if (c < ncells) offsets[c] = carry + sh[t] - v;
-    __syncthreads();
-    if (t == 1023) carry_s = carry + sh[1023];
-    __syncthreads();
-  }
-  if (t == 0) offsets[ncells] = carry_s;
-  __syncthreads();
-  const int wave = t / kWave, lane = t & (kWave - 1);
-  for (int c = wave; c < ncells; c += 1024 / kWave) {
-    const int n = cell_counts[c], o = offsets[c];
-    for (int k = lane; k < n; k += kWave) records[o + k] = cell_slots[(size_t)c * kCellCap + k];
-  }
+  const int o = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const int n = cell_counts[c];
+  if (t == 0) { offsets[c] = o; if (c == ncells - 1) offsets[ncells] = o + n; }
+  for (int k = t; k < n; k += 256) records[o + k] = cell_slots[(size_t)c * kCellCap + k];
 }
 
 // ---- GaussianBlur 7x7 sigma 2, 8.8 fixed point {18,34,48,56,48,34,18}, REFLECT_101 -------------------
@@ -656,7 +641,7 @@ static int orb_phase1(ccm_orb* o) {
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
     hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d, o->d_score, o->iniTh, o->minTh, o->d_cell_slots, o->d_cell_counts);
-    hipLaunchKernelGGL(orb_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, d.ncells, o->d_cell_slots, o->d_cell_counts, o->d_cand,
+    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d.ncells, o->d_cell_slots, o->d_cell_counts, o->d_cand,
                        (uint32_t*)(o->d_cand + d.ncells + 1));
   }
   const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
