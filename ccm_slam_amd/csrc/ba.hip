@@ -448,32 +448,40 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial rz_{k+1}        [CCM_K_BA_PCG_UPDATE]
 __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   __shared__ double lds[kTPB / kWave];
-  if (d.pcg_flag[0]) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // issue every independent load first: the kernel is a chain of dependent round trips otherwise
+  const int done = d.pcg_flag[0];
+  const double* p = d.p[(k + 1) & 1];
+  double xv[6], rv[6], qv[6], pv[6], M[36];
+  if (i < d.Cp) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) { xv[a] = d.x[6 * (size_t)i + a]; rv[a] = d.r[6 * (size_t)i + a]; qv[a] = d.q[6 * (size_t)i + a]; pv[a] = p[6 * (size_t)i + a]; }
+#pragma unroll
+    for (int a = 0; a < 36; a++) M[a] = d.Minv[(size_t)a * d.Cp + i];
+  }
   const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
   const double pq = sum_partials(d.ppq, d.n_wg_spmv);
+  if (done) return;
   if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = 1; }
     return;
   }
   const double alpha = rz_k / pq;
-  const double* p = d.p[(k + 1) & 1];
   double rz = 0;
   if (i < d.Cp) {
-    double rr[6];
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-      d.x[6 * (size_t)i + a] += alpha * p[6 * (size_t)i + a];
-      rr[a] = d.r[6 * (size_t)i + a] - alpha * d.q[6 * (size_t)i + a];
-      d.r[6 * (size_t)i + a] = rr[a];
+      d.x[6 * (size_t)i + a] = xv[a] + alpha * pv[a];
+      rv[a] -= alpha * qv[a];
+      d.r[6 * (size_t)i + a] = rv[a];
     }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
       double s = 0;
 #pragma unroll
-      for (int b = 0; b < 6; b++) s += d.Minv[(size_t)(a * 6 + b) * d.Cp + i] * rr[b];
+      for (int c = 0; c < 6; c++) s += M[a * 6 + c] * rv[c];
       d.z[6 * (size_t)i + a] = s;
-      rz += rr[a] * s;
+      rz += rv[a] * s;
     }
   }
   const double s = block_sum(rz, lds);
