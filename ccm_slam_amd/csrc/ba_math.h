@@ -84,7 +84,8 @@ BA_HD BaPose ba_oplus(const double u[6], const BaPose& T) {
   if (theta < 0.00001) {
     for (int i = 0; i < 9; i++) { R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
   } else {
-    const double st = sin(theta), ct = cos(theta);
+    double st, ct;
+    sincos(theta, &st, &ct);
     const double a = st / theta, b = (1 - ct) / (theta * theta), c = (theta - st) / (theta * theta * theta);
     for (int i = 0; i < 9; i++) {
       const double I = (i % 4 == 0) ? 1.0 : 0.0;

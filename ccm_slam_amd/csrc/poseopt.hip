@@ -79,12 +79,25 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
 // ONE wave: no barriers at all.  Every lane carries the pose, H, b and the LM scalars in registers (the serial
 // 6x6 solve / exp map is executed once for the wave by SIMT anyway); edges are strided over the 64 lanes and
 // every reduction is a butterfly, so all lanes always agree and the control flow stays wave-uniform.
-__global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a) {
+__global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lane = threadIdx.x;
   const double delta = (double)(float)sqrt(5.991);
   const double K4[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
   BaPose T0 = ba_load_pose(a.cam);
   ba_normalize_rotation(T0);
+  uint8_t* g_outlier = a.outlier;
+  if (use_lds) {
+    // one wave has no other wave to hide global latency behind: stage the whole problem (64 B + 3 flags per
+    // edge) in LDS once; every later pass over the edges runs at LDS latency
+    double* lx = sm; double* lo = sm + 3 * (size_t)a.n; double* li = sm + 5 * (size_t)a.n; double* le = sm + 6 * (size_t)a.n;
+    uint8_t* lb = reinterpret_cast<uint8_t*>(sm + 8 * (size_t)a.n);
+    for (int i = lane; i < 3 * a.n; i += kWave) lx[i] = a.Xw[i];
+    for (int i = lane; i < 2 * a.n; i += kWave) lo[i] = a.obs[i];
+    for (int i = lane; i < a.n; i += kWave) li[i] = a.info[i];
+    a.Xw = lx; a.obs = lo; a.info = li; a.err = le;
+    a.level = lb; a.robust = lb + a.n; a.outlier = lb + 2 * (size_t)a.n;
+  }
   for (int i = lane; i < a.n; i += kWave) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
   BaPose T = T0;
   int nBad = 0;
@@ -171,7 +184,8 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a) {
           scale += 1e-3;
           rho = (currentChi - tempChi) / scale;
           if (rho > 0 && isfinite(tempChi)) {
-            double alpha = 1. - pow((2 * rho - 1), 3);
+            const double t2 = 2 * rho - 1;
+            double alpha = 1. - t2 * t2 * t2;   // pow(x,3): same value to 1 ulp, ~300 fewer f64 instructions
             alpha = fmin(alpha, 2. / 3.);
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
@@ -205,6 +219,7 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a) {
     nBad = (int)wsum(bad);
     if (a.n < 10) break;
   }
+  if (use_lds) for (int i = lane; i < a.n; i += kWave) g_outlier[i] = a.outlier[i];
   if (lane == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
 }
 
@@ -236,7 +251,14 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   CCM_HIP_CHECK(ctx, hipMemcpyAsync((void*)a.info, info, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
-    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kWave), 0, ctx->stream, a);
+    // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
+    const size_t lds_bytes = 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+    const int use_lds = lds_bytes <= 150 * 1024;
+    if (use_lds && lds_bytes > 64 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)poseopt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    }
+    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kWave), use_lds ? lds_bytes : 0, ctx->stream, a, use_lds);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   int n_bad = 0;
