@@ -1,0 +1,345 @@
+// ccm_host.cpp — implementation of the host-side mirror (see ccm_host.h).  Plain C++17, no HIP headers:
+// everything device-side goes through the C ABI.
+#include "ccm_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace cslam {
+
+static void check(int rc, ccm_ctx* ctx, const char* what) {
+  if (rc != CCM_OK) throw infrastructure_ex(std::string(what) + ": " + ccm_last_error(ctx));
+}
+
+HipContext::HipContext(int device) { check(ccm_ctx_create(device, &ctx_), nullptr, "ccm_ctx_create"); }
+HipContext::~HipContext() { ccm_ctx_destroy(ctx_); }
+
+// ---- ORBextractor ----------------------------------------------------------------------------------
+ORBextractor::ORBextractor(HipContext& ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+    : nlevels_(nlevels), scaleFactor_(scaleFactor) {
+  check(ccm_orb_create(ctx.get(), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, &orb_), ctx.get(), "ccm_orb_create");
+}
+ORBextractor::~ORBextractor() { ccm_orb_destroy(orb_); }
+
+std::vector<float> ORBextractor::table(int which) const {
+  std::vector<float> t(nlevels_);
+  ccm_orb_get_table(orb_, which, t.data(), nlevels_);
+  return t;
+}
+
+void ORBextractor::operator()(const uint8_t* image, int cols, int rows, int step, std::vector<KeyPoint>& keypoints,
+                              std::vector<uint8_t>& descriptors) {
+  if (!image || cols <= 0 || rows <= 0) { keypoints.clear(); descriptors.clear(); return; }   // if(_image.empty()) return; (:1219)
+  const int cap = ccm_orb_max_keypoints(orb_);
+  static_assert(sizeof(KeyPoint) == sizeof(ccm_keypoint), "KeyPoint must match ccm_keypoint");
+  keypoints.resize(cap);
+  descriptors.resize((size_t)cap * 32);
+  std::vector<uint8_t*> pyr;
+  if (keepPyramid) {
+    mvImagePyramid.resize(nlevels_);
+    pyr.resize(nlevels_);
+    for (int l = 0; l < nlevels_; l++) {
+      Level& L = mvImagePyramid[l];
+      ccm_orb_level_size(orb_, cols, rows, l, &L.cols, &L.rows);
+      L.data.resize((size_t)L.cols * L.rows);
+      pyr[l] = L.data.data();
+    }
+  }
+  int n = 0;
+  const int rc = ccm_orb_extract(orb_, image, cols, rows, step, reinterpret_cast<ccm_keypoint*>(keypoints.data()), descriptors.data(),
+                                 cap, &n, keepPyramid ? pyr.data() : nullptr);
+  if (rc != CCM_OK) throw infrastructure_ex(std::string("ccm_orb_extract: ") + ccm_last_error(nullptr));
+  keypoints.resize(n);
+  descriptors.resize((size_t)n * 32);
+}
+
+// ---- Frame grid (Frame.cpp:87-88, 103-118, 200-265), FRAME_GRID_COLS 75 x ROWS 48 -------------------
+namespace {
+constexpr int kGridCols = 75, kGridRows = 48;
+
+struct FrameGrid {
+  const FrameView& F;
+  float wInv, hInv;
+  std::vector<int> start;   // CSR over cells (column-major: cell = ix * rows + iy), insertion order kept
+  std::vector<int> items;
+  explicit FrameGrid(const FrameView& f) : F(f) {
+    wInv = static_cast<float>(kGridCols) / static_cast<float>(F.mnMaxX - F.mnMinX);
+    hInv = static_cast<float>(kGridRows) / static_cast<float>(F.mnMaxY - F.mnMinY);
+    std::vector<int> cellOf(F.N, -1);
+    start.assign(kGridCols * kGridRows + 1, 0);
+    for (int i = 0; i < F.N; i++) {
+      const int px = (int)std::round((F.mvKeysUn[i].x - F.mnMinX) * wInv);   // PosInGrid uses round()
+      const int py = (int)std::round((F.mvKeysUn[i].y - F.mnMinY) * hInv);
+      if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+      cellOf[i] = px * kGridRows + py;
+      start[cellOf[i] + 1]++;
+    }
+    for (size_t c = 1; c < start.size(); c++) start[c] += start[c - 1];
+    items.resize(start.back());
+    std::vector<int> pos(start.begin(), start.end() - 1);
+    for (int i = 0; i < F.N; i++) if (cellOf[i] >= 0) items[pos[cellOf[i]]++] = i;
+  }
+  // appends the candidate indices in the reference's order (ix-major, iy, insertion)
+  void featuresInArea(float x, float y, float r, int minLevel, int maxLevel, std::vector<int32_t>& out) const {
+    const int nMinCellX = std::max(0, (int)std::floor((x - F.mnMinX - r) * wInv));
+    if (nMinCellX >= kGridCols) return;
+    const int nMaxCellX = std::min(kGridCols - 1, (int)std::ceil((x - F.mnMinX + r) * wInv));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - F.mnMinY - r) * hInv));
+    if (nMinCellY >= kGridRows) return;
+    const int nMaxCellY = std::min(kGridRows - 1, (int)std::ceil((y - F.mnMinY + r) * hInv));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const int c = ix * kGridRows + iy;
+        for (int s = start[c]; s < start[c + 1]; s++) {
+          const int k = items[s];
+          const KeyPoint& kp = F.mvKeysUn[k];
+          if (bCheckLevels) {
+            if (kp.octave < minLevel) continue;
+            if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+          }
+          if (std::fabs(kp.x - x) < r && std::fabs(kp.y - y) < r) out.push_back(k);
+        }
+      }
+  }
+};
+
+void threeMaxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {   // ORBmatcher.cpp:1607-1648
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+}  // namespace
+
+int ORBmatcher::DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t x, y;
+    std::memcpy(&x, a + 4 * i, 4); std::memcpy(&y, b + 4 * i, 4);
+    dist += __builtin_popcount(x ^ y);
+  }
+  return dist;
+}
+
+// Device does every Hamming distance of every (map point, window candidate) pair in one launch; the host then
+// replays the reference's loop over the map points IN ORDER on the precomputed distances, so that features
+// claimed by an earlier map point are skipped by later ones exactly as ORBmatcher.cpp:113-115 does.
+int ORBmatcher::SearchByProjection(FrameView& F, const TrackedMapPoints& mps, float th) {
+  FrameGrid grid(F);
+  const bool bFactor = th != 1.0;
+  std::vector<int32_t> q_of;        // compact query -> map point index
+  std::vector<int32_t> off(1, 0), idx;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < mps.n; i++) {
+    if (!mps.mbTrackInView[i]) continue;
+    const int lvl = mps.mnTrackScaleLevel[i];
+    float r = (mps.mTrackViewCos[i] > 0.998) ? 2.5f : 4.0f;   // RadiusByViewingCos (:150-156)
+    if (bFactor) r *= th;
+    const size_t before = idx.size();
+    grid.featuresInArea(mps.mTrackProjX[i], mps.mTrackProjY[i], r * F.mvScaleFactors[lvl], lvl - 1, lvl, idx);
+    if (idx.size() == before) continue;   // vIndices.empty()
+    q_of.push_back(i);
+    off.push_back((int32_t)idx.size());
+    qdesc.insert(qdesc.end(), mps.mDescriptor + (size_t)i * 32, mps.mDescriptor + (size_t)i * 32 + 32);
+  }
+  const int Q = (int)q_of.size();
+  if (Q == 0) return 0;
+  std::vector<uint16_t> dist(idx.size());
+  check(ccm_hamming_csr(ctx_.get(), qdesc.data(), Q, F.mDescriptors, F.N, off.data(), idx.data(), dist.data(), nullptr, nullptr, nullptr),
+        ctx_.get(), "ccm_hamming_csr");
+  int nmatches = 0;
+  for (int q = 0; q < Q; q++) {
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int k = idx[s];
+      if (F.mvpMapPoints[k] >= 0) continue;   // F.mvpMapPoints[idx] && Observations() > 0
+      const int d = dist[s];
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F.mvKeysUn[k].octave; bestIdx = k; }
+      else if (d < bestDist2) { bestLevel2 = F.mvKeysUn[k].octave; bestDist2 = d; }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      F.mvpMapPoints[bestIdx] = q_of[q];
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(FrameView& C, const LastFrameProjections& last, float th) {
+  FrameGrid grid(C);
+  std::vector<int32_t> q_of, off(1, 0), idx;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < last.n; i++) {
+    if (!last.valid[i]) continue;
+    const int oct = last.octave[i];
+    const size_t before = idx.size();
+    grid.featuresInArea(last.u[i], last.v[i], th * C.mvScaleFactors[oct], oct - 1, oct + 1, idx);
+    if (idx.size() == before) continue;
+    q_of.push_back(i);
+    off.push_back((int32_t)idx.size());
+    qdesc.insert(qdesc.end(), last.mpDescriptor + (size_t)i * 32, last.mpDescriptor + (size_t)i * 32 + 32);
+  }
+  const int Q = (int)q_of.size();
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;   // upstream quirk: 30-degree bins (:1358)
+  if (Q > 0) {
+    std::vector<uint16_t> dist(idx.size());
+    check(ccm_hamming_csr(ctx_.get(), qdesc.data(), Q, C.mDescriptors, C.N, off.data(), idx.data(), dist.data(), nullptr, nullptr, nullptr),
+          ctx_.get(), "ccm_hamming_csr");
+    for (int q = 0; q < Q; q++) {
+      int bestDist = 256, bestIdx2 = -1;
+      for (int s = off[q]; s < off[q + 1]; s++) {
+        const int k = idx[s];
+        if (C.mvpMapPoints[k] >= 0) continue;
+        if (dist[s] < bestDist) { bestDist = dist[s]; bestIdx2 = k; }
+      }
+      if (bestDist <= TH_HIGH) {
+        C.mvpMapPoints[bestIdx2] = q_of[q];
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = last.angle[q_of[q]] - C.mvKeysUn[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(bestIdx2);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int k : rotHist[i]) { C.mvpMapPoints[k] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// ---- Optimizer ---------------------------------------------------------------------------------------
+int Optimizer::PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, const double* Xw, const double* obs,
+                                      const double* invSigma2, const double K[4], std::vector<uint8_t>& outlier) {
+  outlier.assign(std::max(n, 1), 0);
+  int ninl = 0;
+  check(ccm_pose_optimize(ctx.get(), cam_qt, n, Xw, obs, invSigma2, K, outlier.data(), &ninl), ctx.get(), "ccm_pose_optimize");
+  outlier.resize(n);
+  return ninl;
+}
+
+static ccm_ba_problem make_problem(BAProblem& p, const uint8_t* level, double huber) {
+  ccm_ba_problem c{};
+  c.n_cam = p.n_cam(); c.n_pt = p.n_pt(); c.n_edge = p.n_edge();
+  c.cam_qt = p.cam_qt.data(); c.cam_fixed = p.cam_fixed.data(); c.cam_K = p.cam_K.data(); c.pt_xyz = p.pt_xyz.data();
+  c.e_cam = p.e_cam.data(); c.e_pt = p.e_pt.data(); c.e_obs = p.e_obs.data(); c.e_info = p.e_info.data();
+  c.e_level = level; c.huber_delta = huber;
+  return c;
+}
+
+void Optimizer::LocalBundleAdjustmentClient(HipContext& ctx, BAProblem& p, bool* pbStopFlag, std::vector<uint8_t>& to_erase) {
+  const int ne = p.n_edge();
+  to_erase.assign(ne, 0);
+  if (pbStopFlag && *pbStopFlag) return;   // :532-534
+  const double thHuberMono = (double)(float)std::sqrt(5.991);   // const float thHuberMono = sqrt(5.991) (:468)
+  std::vector<uint8_t> level(ne, 0), dpos(ne, 1);
+  std::vector<double> chi2(ne, 0.0);
+  ccm_ba_options opt{}; opt.max_iters = 5;
+  ccm_ba_problem c = make_problem(p, level.data(), thHuberMono);
+  const volatile unsigned char* stop = reinterpret_cast<const volatile unsigned char*>(pbStopFlag);
+  check(ccm_ba_optimize(ctx.get(), &c, &opt, stop, chi2.data(), dpos.data(), nullptr), ctx.get(), "ccm_ba_optimize");
+  bool bDoMore = !(pbStopFlag && *pbStopFlag);
+  if (bDoMore) {
+    for (int e = 0; e < ne; e++) if (chi2[e] > 5.991 || !dpos[e]) level[e] = 1;   // setLevel(1); kernel dropped for all (:548-560)
+    opt.max_iters = 10;
+    c = make_problem(p, level.data(), 0.0);
+    check(ccm_ba_optimize(ctx.get(), &c, &opt, stop, chi2.data(), dpos.data(), nullptr), ctx.get(), "ccm_ba_optimize");
+  }
+  for (int e = 0; e < ne; e++) to_erase[e] = (chi2[e] > 5.991 || !dpos[e]) ? 1 : 0;   // :574-586
+}
+
+void Optimizer::GlobalBundleAdjustment(HipContext& ctx, BAProblem& p, int nIterations, bool* pbStopFlag, bool bRobust, ccm_ba_stats* stats) {
+  const double thHuber2D = (double)(float)std::sqrt(5.99);   // :759
+  ccm_ba_options opt{}; opt.max_iters = nIterations;
+  ccm_ba_problem c = make_problem(p, nullptr, bRobust ? thHuber2D : 0.0);
+  check(ccm_ba_optimize(ctx.get(), &c, &opt, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr, nullptr, stats),
+        ctx.get(), "ccm_ba_optimize");
+}
+
+}  // namespace cslam
+
+// ---- C wrappers so the Python test-suite can drive the C++ mirror ---------------------------------------
+extern "C" {
+int ccmh_search_by_projection_mp(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* fdesc, int N,
+                                 float minX, float minY, float maxX, float maxY, const float* scale_factors, int n_mp,
+                                 const uint8_t* in_view, const float* px, const float* py, const int32_t* lvl, const float* vcos,
+                                 const uint8_t* mp_desc, float th, float nnratio, int32_t* frame_mp) {
+  try {
+    cslam::HipContext ctx(device);
+    std::vector<cslam::KeyPoint> kps(N);
+    for (int i = 0; i < N; i++) kps[i] = cslam::KeyPoint{kx[i], ky[i], 31.f, 0.f, 0.f, oct[i]};
+    cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = fdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
+    F.mvScaleFactors = scale_factors; F.mvpMapPoints = frame_mp;
+    cslam::TrackedMapPoints M; M.n = n_mp; M.mbTrackInView = in_view; M.mTrackProjX = px; M.mTrackProjY = py; M.mnTrackScaleLevel = lvl;
+    M.mTrackViewCos = vcos; M.mDescriptor = mp_desc;
+    cslam::ORBmatcher m(ctx, nnratio, true);
+    return m.SearchByProjection(F, M, th);
+  } catch (const std::exception&) { return -1000; }
+}
+
+int ccmh_search_by_projection_last(int device, const float* kx, const float* ky, const int32_t* oct, const float* kangle,
+                                   const uint8_t* fdesc, int N, float minX, float minY, float maxX, float maxY,
+                                   const float* scale_factors, int n_last, const uint8_t* valid, const float* u, const float* v,
+                                   const int32_t* l_oct, const float* l_angle, const uint8_t* l_desc, float th, int check_ori,
+                                   int32_t* cur_mp) {
+  try {
+    cslam::HipContext ctx(device);
+    std::vector<cslam::KeyPoint> kps(N);
+    for (int i = 0; i < N; i++) kps[i] = cslam::KeyPoint{kx[i], ky[i], 31.f, kangle[i], 0.f, oct[i]};
+    cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = fdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
+    F.mvScaleFactors = scale_factors; F.mvpMapPoints = cur_mp;
+    cslam::LastFrameProjections L; L.n = n_last; L.valid = valid; L.u = u; L.v = v; L.octave = l_oct; L.angle = l_angle; L.mpDescriptor = l_desc;
+    cslam::ORBmatcher m(ctx, 0.9f, check_ori != 0);
+    return m.SearchByProjection(F, L, th);
+  } catch (const std::exception&) { return -1000; }
+}
+
+int ccmh_local_ba(int device, int n_cam, int n_pt, int n_edge, double* cam_qt, const uint8_t* cam_fixed, const double* cam_K,
+                  double* pt_xyz, const int32_t* e_cam, const int32_t* e_pt, const double* e_obs, const double* e_info, uint8_t* to_erase) {
+  try {
+    cslam::HipContext ctx(device);
+    cslam::BAProblem p;
+    p.cam_qt.assign(cam_qt, cam_qt + 7 * (size_t)n_cam); p.cam_fixed.assign(cam_fixed, cam_fixed + n_cam);
+    p.cam_K.assign(cam_K, cam_K + 4 * (size_t)n_cam); p.pt_xyz.assign(pt_xyz, pt_xyz + 3 * (size_t)n_pt);
+    p.e_cam.assign(e_cam, e_cam + n_edge); p.e_pt.assign(e_pt, e_pt + n_edge);
+    p.e_obs.assign(e_obs, e_obs + 2 * (size_t)n_edge); p.e_info.assign(e_info, e_info + n_edge);
+    std::vector<uint8_t> er;
+    cslam::Optimizer::LocalBundleAdjustmentClient(ctx, p, nullptr, er);
+    std::memcpy(cam_qt, p.cam_qt.data(), sizeof(double) * p.cam_qt.size());
+    std::memcpy(pt_xyz, p.pt_xyz.data(), sizeof(double) * p.pt_xyz.size());
+    std::memcpy(to_erase, er.data(), er.size());
+    return 0;
+  } catch (const std::exception&) { return -1000; }
+}
+
+int ccmh_orb_extract(int device, int nfeatures, const uint8_t* img, int w, int h, void* kps_out, uint8_t* desc_out, int cap) {
+  try {
+    cslam::HipContext ctx(device);
+    cslam::ORBextractor ex(ctx, nfeatures, 1.2f, 8, 20, 7);
+    std::vector<cslam::KeyPoint> k; std::vector<uint8_t> d;
+    ex(img, w, h, w, k, d);
+    const int n = std::min<int>((int)k.size(), cap);
+    std::memcpy(kps_out, k.data(), sizeof(cslam::KeyPoint) * n);
+    std::memcpy(desc_out, d.data(), (size_t)n * 32);
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+}

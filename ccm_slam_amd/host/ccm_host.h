@@ -1,0 +1,135 @@
+// ccm_host.h — host-side C++ mirror of the reference's class API for the hot path, on top of the C ABI
+// (include/ccm_hip.h).  This is what replaces the three reference translation units
+//   cslam/src/ORBextractor.cpp, cslam/src/ORBmatcher.cpp, cslam/src/Optimizer.cpp
+// in a drop-in build (INTEGRATION.md shows the glue that walks the reference's shared_ptr graph).
+//
+// The reference's data model (Frame / KeyFrame / MapPoint / Map, OpenCV types) is OUT OF SCOPE and not
+// available in this image, so the classes below take *views*: plain structs of pointers into the caller's
+// arrays, holding exactly the fields the reference methods read.  With CCM_HAVE_OPENCV defined the
+// ORBextractor additionally offers the cv::InputArray / cv::OutputArray operator() of the reference.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/ccm_hip.h"
+
+namespace cslam {
+
+// thrown where the reference throws estd::infrastructure_ex (cslam/include/cslam/estd.h:74-81)
+struct infrastructure_ex : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// one device context per calling thread (SURVEY §8b threading)
+class HipContext {
+ public:
+  explicit HipContext(int device = 0);
+  ~HipContext();
+  ccm_ctx* get() const { return ctx_; }
+ private:
+  ccm_ctx* ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// ORBextractor — cslam/include/cslam/ORBextractor.h:103-138
+// ---------------------------------------------------------------------------------------------------
+struct KeyPoint { float x, y, size, angle, response; int octave; };   // cv::KeyPoint minus class_id
+
+class ORBextractor {
+ public:
+  ORBextractor(HipContext& ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+  ~ORBextractor();
+  // operator()(image, mask /*ignored, as in the reference*/, keypoints, descriptors): 8-bit single-channel image
+  void operator()(const uint8_t* image, int cols, int rows, int step, std::vector<KeyPoint>& keypoints,
+                  std::vector<uint8_t>& descriptors /* N x 32, row-major like cv::Mat CV_8U */);
+  int GetLevels() const { return nlevels_; }
+  float GetScaleFactor() const { return scaleFactor_; }
+  std::vector<float> GetScaleFactors() const { return table(0); }
+  std::vector<float> GetInverseScaleFactors() const { return table(1); }
+  std::vector<float> GetScaleSigmaSquares() const { return table(2); }
+  std::vector<float> GetInverseScaleSigmaSquares() const { return table(3); }
+  // mvImagePyramid (public member of the reference): un-bordered levels of the last frame
+  struct Level { int cols, rows; std::vector<uint8_t> data; };
+  std::vector<Level> mvImagePyramid;
+  bool keepPyramid = false;   // fill mvImagePyramid on every call (costs a D2H of ~1.1 MB)
+ private:
+  std::vector<float> table(int which) const;
+  ccm_orb* orb_ = nullptr;
+  int nlevels_; float scaleFactor_;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// ORBmatcher — cslam/include/cslam/ORBmatcher.h:100-139
+// ---------------------------------------------------------------------------------------------------
+// What SearchByProjection reads from a Frame (cslam/include/cslam/Frame.h:131-152)
+struct FrameView {
+  int N = 0;
+  const KeyPoint* mvKeysUn = nullptr;       // undistorted keypoints (x, y, octave, angle)
+  const uint8_t* mDescriptors = nullptr;    // N x 32
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+  const float* mvScaleFactors = nullptr;    // nlevels
+  // mvpMapPoints as indices: -1 = no map point; >= 0 = a map point with Observations() > 0 ("claimed")
+  int32_t* mvpMapPoints = nullptr;          // in/out, length N
+};
+// What the loop reads from each candidate map point (MapPoint.h:224-228,289)
+struct TrackedMapPoints {
+  int n = 0;
+  const uint8_t* mbTrackInView = nullptr;   // && !isBad()
+  const float* mTrackProjX = nullptr; const float* mTrackProjY = nullptr;
+  const int32_t* mnTrackScaleLevel = nullptr;
+  const float* mTrackViewCos = nullptr;
+  const uint8_t* mDescriptor = nullptr;     // n x 32
+};
+// Last-frame side of SearchByProjection(Frame&, const Frame&, th): projections are computed by the caller
+// (f32, ORBmatcher.cpp:1381-1397) — valid[i] = has map point && !outlier && in front && inside the image
+struct LastFrameProjections {
+  int n = 0;
+  const uint8_t* valid = nullptr; const float* u = nullptr; const float* v = nullptr;
+  const int32_t* octave = nullptr;          // LastFrame.mvKeys[i].octave
+  const float* angle = nullptr;             // LastFrame.mvKeysUn[i].angle
+  const uint8_t* mpDescriptor = nullptr;    // n x 32, pMP->GetDescriptor()
+};
+
+class ORBmatcher {
+ public:
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+  ORBmatcher(HipContext& ctx, float nnratio = 0.6f, bool checkOri = true) : ctx_(ctx), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  // ORBmatcher.cpp:1653-1669 (host popcount; the batched form is ccm_hamming_*)
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b);
+  // ORBmatcher.cpp:71-148.  Returns nmatches; F.mvpMapPoints[idx] = index of the matched map point.
+  int SearchByProjection(FrameView& F, const TrackedMapPoints& mps, float th);
+  // ORBmatcher.cpp:1350-1476.
+  int SearchByProjection(FrameView& CurrentFrame, const LastFrameProjections& last, float th);
+ private:
+  HipContext& ctx_;
+  float mfNNratio; bool mbCheckOrientation;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Optimizer — cslam/include/cslam/Optimizer.h:84-112 (numerics; graph walking is the integrator's glue)
+// ---------------------------------------------------------------------------------------------------
+struct BAProblem {   // owning, f64 like g2o; filled from KeyFrames / MapPoints via Converter (Converter.cc:40-119)
+  std::vector<double> cam_qt;   // n_cam*7
+  std::vector<uint8_t> cam_fixed;
+  std::vector<double> cam_K;    // n_cam*4
+  std::vector<double> pt_xyz;   // n_pt*3
+  std::vector<int32_t> e_cam, e_pt;
+  std::vector<double> e_obs, e_info;
+  int n_cam() const { return (int)cam_fixed.size(); }
+  int n_pt() const { return (int)pt_xyz.size() / 3; }
+  int n_edge() const { return (int)e_cam.size(); }
+};
+
+class Optimizer {
+ public:
+  // PoseOptimizationClient (Optimizer.cpp:215-347): returns nInitialCorrespondences - nBad; outlier[] = mvbOutlier
+  static int PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, const double* Xw, const double* obs,
+                                    const double* invSigma2, const double K[4], std::vector<uint8_t>& outlier);
+  // LocalBundleAdjustmentClient numerics (Optimizer.cpp:532-602): optimize(5) Huber sqrt(5.991) -> outliers to level 1,
+  // kernel off -> optimize(10).  pbStopFlag as in the reference.  to_erase[e] = 1 for observations the reference erases.
+  static void LocalBundleAdjustmentClient(HipContext& ctx, BAProblem& p, bool* pbStopFlag, std::vector<uint8_t>& to_erase);
+  // BundleAdjustmentClient / MapFusionGBA numerics (Optimizer.cpp:163-167, 786-797): optimize(nIterations), Huber sqrt(5.99)
+  static void GlobalBundleAdjustment(HipContext& ctx, BAProblem& p, int nIterations, bool* pbStopFlag, bool bRobust,
+                                     ccm_ba_stats* stats = nullptr);
+};
+
+}  // namespace cslam

@@ -1,0 +1,107 @@
+"""GPU parity of the C++ host mirror (ccm_slam_amd/host/, libccm_host.so): ORBmatcher::SearchByProjection
+(both overloads) with the device Hamming kernel + ordered host resolution vs the oracle's sequential
+restatement — identical match tables (integer work, bit-exact); LocalBundleAdjustmentClient two-stage
+protocol vs the oracle; ORBextractor class vs the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ccm_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    lib = C.CDLL(os.path.join(ROOT, "ccm_slam_amd", "libccm_host.so"))
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _frame(oracle_lib, seed, t):
+    kps, desc = oracle_lib.OrbOracle(1000).extract(synth.gen_image(seed, t))
+    return kps, desc
+
+
+def test_search_by_projection_map_points(hostlib, oracle_lib):
+    kps, desc = _frame(oracle_lib, 1000, 0)
+    N = len(kps)
+    rng = np.random.default_rng(0)
+    sf = synth.scale_tables()[0]
+    # 3000 "local map points": most project near an existing feature and carry a noisy copy of its descriptor
+    n_mp = 3000
+    src = rng.integers(0, N, n_mp)
+    px = (kps["x"][src] + rng.normal(0, 2.0, n_mp)).astype(np.float32)
+    py = (kps["y"][src] + rng.normal(0, 2.0, n_mp)).astype(np.float32)
+    lvl = np.clip(kps["octave"][src] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    vcos = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    in_view = (rng.random(n_mp) < 0.9).astype(np.uint8)
+    mp_desc = desc[src].copy()
+    bits = np.unpackbits(mp_desc, axis=1)
+    flip = rng.random(bits.shape) < 0.08
+    mp_desc = np.packbits(bits ^ flip, axis=1)
+    frame_mp0 = -np.ones(N, np.int32)
+    frame_mp0[rng.integers(0, N, 50)] = 10_000   # features already holding an observed map point
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    exp_n, exp = oracle_lib.search_by_projection_mp(kps["x"], kps["y"], kps["octave"], desc, bounds, sf, in_view, px, py, lvl, vcos,
+                                                    mp_desc, 3.0, 0.8, frame_mp0)
+    got = frame_mp0.copy()
+    kx, ky, oc = (np.ascontiguousarray(kps[f]) for f in ("x", "y", "octave"))
+    n = hostlib.ccmh_search_by_projection_mp(0, _p(kx), _p(ky), _p(oc), _p(desc), N, *[C.c_float(b) for b in bounds], _p(sf), n_mp,
+                                             _p(in_view), _p(px), _p(py), _p(lvl), _p(vcos), _p(mp_desc), C.c_float(3.0), C.c_float(0.8),
+                                             _p(got))
+    assert n == exp_n and n > 500
+    assert np.array_equal(got, exp)
+
+
+def test_search_by_projection_last_frame(hostlib, oracle_lib):
+    k1, d1 = _frame(oracle_lib, 1000, 0)
+    k2, d2 = _frame(oracle_lib, 1000, 1)   # scene shifted by one pixel
+    rng = np.random.default_rng(1)
+    sf = synth.scale_tables()[0]
+    n_last = len(k1)
+    valid = (rng.random(n_last) < 0.6).astype(np.uint8)
+    u = (k1["x"] - np.float32(1.0) + rng.normal(0, 1.0, n_last)).astype(np.float32)
+    v = (k1["y"] - np.float32(1.0) + rng.normal(0, 1.0, n_last)).astype(np.float32)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    cur0 = -np.ones(len(k2), np.int32)
+    args = (k2["x"], k2["y"], k2["octave"], k2["angle"], d2, bounds, sf, valid, u, v, k1["octave"], k1["angle"], d1)
+    exp_n, exp = oracle_lib.search_by_projection_last(*args, 7.0, 1, cur0)
+    got = cur0.copy()
+    kx, ky, oc, ka = (np.ascontiguousarray(k2[f]) for f in ("x", "y", "octave", "angle"))
+    lo, la = np.ascontiguousarray(k1["octave"]), np.ascontiguousarray(k1["angle"])
+    n = hostlib.ccmh_search_by_projection_last(0, _p(kx), _p(ky), _p(oc), _p(ka), _p(d2), len(k2), *[C.c_float(b) for b in bounds], _p(sf),
+                                               n_last, _p(valid), _p(u), _p(v), _p(lo), _p(la), _p(d1), C.c_float(7.0), 1, _p(got))
+    assert n == exp_n and n > 200
+    assert np.array_equal(got, exp)
+
+
+def test_local_ba_client_two_stage(hostlib, oracle_lib):
+    prob = synth.make_ba_config("lba_c2")
+    cam = prob["cam_qt"].copy(); pts = prob["pt_xyz"].copy()
+    erase = np.zeros(prob["n_edge"], np.uint8)
+    rc = hostlib.ccmh_local_ba(0, prob["n_cam"], prob["n_pt"], prob["n_edge"], _p(cam), _p(prob["cam_fixed"]), _p(prob["cam_K"]), _p(pts),
+                               _p(prob["e_cam"]), _p(prob["e_pt"]), _p(np.ascontiguousarray(prob["e_obs"])), _p(prob["e_info"]), _p(erase))
+    assert rc == 0
+    p1 = dict(prob); p1["huber_delta"] = float(np.float32(np.sqrt(np.float32(5.991))))
+    ocam, opts, ochi2, odpos, _ = oracle_lib.ba_optimize(p1, 5)
+    level = np.zeros(prob["n_edge"], np.uint8); level[(ochi2 > 5.991) | (odpos == 0)] = 1
+    p2 = dict(prob); p2.update(cam_qt=ocam, pt_xyz=opts, e_level=level, huber_delta=0.0)
+    ocam2, opts2, ochi2b, odpos2, _ = oracle_lib.ba_optimize(p2, 10, chi2_in=ochi2)
+    dt, dr = synth.pose_errors(cam, ocam2)
+    assert dt.max() <= 1e-5 and dr.max() <= 1e-4
+    assert (erase != ((ochi2b > 5.991) | (odpos2 == 0))).sum() <= 2
+
+
+def test_orb_extractor_class(hostlib, oracle_lib):
+    img = synth.gen_image(1002, 4)
+    okps, odesc = oracle_lib.OrbOracle(1000).extract(img)
+    kps = np.zeros(1100, oracle_lib.KP_DTYPE); desc = np.zeros((1100, 32), np.uint8)
+    n = hostlib.ccmh_orb_extract(0, 1000, _p(img), 752, 480, _p(kps), _p(desc), 1100)
+    assert n == len(okps) and np.array_equal(desc[:n], odesc) and np.array_equal(kps[:n], okps)
