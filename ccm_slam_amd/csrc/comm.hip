@@ -4,6 +4,11 @@
 #include "common.h"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <cstdlib>
+
+// CCM_FORCE_ALLREDUCE=1 issues the collectives even on a 1-rank communicator (a legal, degenerate all-reduce):
+// lets the single-GPU test box exercise the exact RCCL call sequence of the sharded global BA.
+static bool force_collectives() { static int v = -1; if (v < 0) { const char* e = std::getenv("CCM_FORCE_ALLREDUCE"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
 
 static_assert(sizeof(ncclUniqueId) == 128, "ccm_comm_unique_id assumes a 128-byte ncclUniqueId");
 
@@ -38,7 +43,7 @@ extern "C" int ccm_comm_destroy(ccm_ctx* ctx) {
 
 // in-place sum all-reduce of n doubles on the ctx stream
 int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
-  if (ctx->comm_nranks <= 1) return CCM_OK;
+  if (ctx->comm_nranks <= 1 && !(ctx->comm && force_collectives())) return CCM_OK;
   if (!ctx->comm) return ccm_set_error(ctx, CCM_E_STATE, "all-reduce requested but no communicator attached");
   ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
   if (r != ncclSuccess) return ccm_set_error(ctx, CCM_E_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
@@ -46,7 +51,7 @@ int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
 }
 
 int ccm_allreduce_max_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
-  if (ctx->comm_nranks <= 1) return CCM_OK;
+  if (ctx->comm_nranks <= 1 && !(ctx->comm && force_collectives())) return CCM_OK;
   if (!ctx->comm) return ccm_set_error(ctx, CCM_E_STATE, "all-reduce requested but no communicator attached");
   ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream);
   if (r != ncclSuccess) return ccm_set_error(ctx, CCM_E_COMM, std::string("ncclAllReduce(max): ") + ncclGetErrorString(r));
