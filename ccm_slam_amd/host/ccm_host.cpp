@@ -226,6 +226,213 @@ int ORBmatcher::SearchByProjection(FrameView& C, const LastFrameProjections& las
   return nmatches;
 }
 
+// ---- BoW-bucketed / triangulation / initialisation searches ---------------------------------------------
+namespace {
+// common node ids of two ordered FeatureVectors, ascending (the merge-join with lower_bound jumps, ORBmatcher.cpp:199-283)
+std::vector<std::pair<int, int>> commonNodes(const FeatureVectorView& a, const FeatureVectorView& b) {
+  std::vector<std::pair<int, int>> r;
+  int i = 0, j = 0;
+  while (i < a.nn && j < b.nn) {
+    if (a.node[i] == b.node[j]) { r.emplace_back(i, j); i++; j++; }
+    else if (a.node[i] < b.node[j]) i = (int)(std::lower_bound(a.node, a.node + a.nn, b.node[j]) - a.node);
+    else j = (int)(std::lower_bound(b.node, b.node + b.nn, a.node[i]) - b.node);
+  }
+  return r;
+}
+int histBin(float rot) {
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * (1.0f / ORBmatcher::HISTO_LENGTH));
+  if (bin == ORBmatcher::HISTO_LENGTH) bin = 0;
+  return bin;
+}
+// queries = features of `a` in bucket order that pass `keep`; candidate list of each = the whole bucket of `b`
+template <typename Keep>
+void bucketQueries(const KeysView& a, const KeysView& b, Keep keep, std::vector<int32_t>& q_of, std::vector<int32_t>& off,
+                   std::vector<int32_t>& idx, std::vector<uint8_t>& qdesc) {
+  off.assign(1, 0);
+  for (auto pr : commonNodes(a.fv, b.fv))
+    for (int s1 = a.fv.off[pr.first]; s1 < a.fv.off[pr.first + 1]; s1++) {
+      const int i1 = a.fv.idx[s1];
+      if (!keep(i1)) continue;
+      q_of.push_back(i1);
+      idx.insert(idx.end(), b.fv.idx + b.fv.off[pr.second], b.fv.idx + b.fv.off[pr.second + 1]);
+      off.push_back((int32_t)idx.size());
+      qdesc.insert(qdesc.end(), a.desc + (size_t)i1 * 32, a.desc + (size_t)i1 * 32 + 32);
+    }
+}
+}  // namespace
+
+void ORBmatcher::distances(const std::vector<uint8_t>& qdesc, int Q, const uint8_t* tdesc, int T, const std::vector<int32_t>& off,
+                           const std::vector<int32_t>& idx, std::vector<uint16_t>& dist) {
+  dist.assign(std::max<size_t>(idx.size(), 1), 0);
+  if (Q == 0 || idx.empty()) return;
+  check(ccm_hamming_csr(ctx_.get(), qdesc.data(), Q, tdesc, T, off.data(), idx.data(), dist.data(), nullptr, nullptr, nullptr), ctx_.get(),
+        "ccm_hamming_csr");
+}
+
+int ORBmatcher::SearchByBoW(const KeysView& KF, const KeysView& F, std::vector<int32_t>& matchesF) {
+  matchesF.assign(F.N, -1);
+  std::vector<int32_t> q_of, off, idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  bucketQueries(KF, F, [&](int i) { return KF.hasMapPoint[i] != 0; }, q_of, off, idx, qdesc);
+  distances(qdesc, (int)q_of.size(), F.desc, F.N, off, idx, dist);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int realIdxF = idx[s];
+      if (matchesF[realIdxF] >= 0) continue;
+      const int d = dist[s];
+      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdxF = realIdxF; }
+      else if (d < bestDist2) bestDist2 = d;
+    }
+    if (bestDist1 <= TH_LOW && static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {
+      matchesF[bestIdxF] = q_of[q];
+      if (mbCheckOrientation) rotHist[histBin(KF.keys[q_of[q]].angle - F.keys[bestIdxF].angle)].push_back(bestIdxF);
+      nmatches++;
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matchesF[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchByBoW_KF(const KeysView& K1, const KeysView& K2, std::vector<int32_t>& matches12) {
+  matches12.assign(K1.N, -1);
+  std::vector<int32_t> q_of, off, idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  bucketQueries(K1, K2, [&](int i) { return K1.hasMapPoint[i] != 0; }, q_of, off, idx, qdesc);
+  distances(qdesc, (int)q_of.size(), K2.desc, K2.N, off, idx, dist);
+  std::vector<char> vbMatched2(K2.N, 0);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int idx2 = idx[s];
+      if (vbMatched2[idx2] || !K2.hasMapPoint[idx2]) continue;
+      const int d = dist[s];
+      if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = idx2; }
+      else if (d < bestDist2) bestDist2 = d;
+    }
+    if (bestDist1 < TH_LOW && static_cast<float>(bestDist1) < mfNNratio * static_cast<float>(bestDist2)) {   // strict '<' here (:641)
+      matches12[q_of[q]] = bestIdx2;
+      vbMatched2[bestIdx2] = 1;
+      if (mbCheckOrientation) rotHist[histBin(K1.keys[q_of[q]].angle - K2.keys[bestIdx2].angle)].push_back(q_of[q]);
+      nmatches++;
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matches12[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchForTriangulation(const KeysView& K1, const KeysView& K2, const float F12[9], float ex, float ey, const float* sigma2_2,
+                                       const float* sf2, std::vector<int32_t>& matches12) {
+  matches12.assign(K1.N, -1);
+  std::vector<int32_t> q_of, off, idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  bucketQueries(K1, K2, [&](int i) { return K1.hasMapPoint[i] == 0; }, q_of, off, idx, qdesc);   // only features WITHOUT a map point (:745-749)
+  distances(qdesc, (int)q_of.size(), K2.desc, K2.N, off, idx, dist);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    const KeyPoint& kp1 = K1.keys[q_of[q]];
+    int bestDist = TH_LOW, bestIdx2 = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int idx2 = idx[s];
+      if (K2.hasMapPoint[idx2]) continue;          // vbMatched2 is never set by the reference (:761,:789)
+      const int d = dist[s];
+      if (d > TH_LOW || d > bestDist) continue;
+      const KeyPoint& kp2 = K2.keys[idx2];
+      const float distex = ex - kp2.x, distey = ey - kp2.y;
+      if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
+      // CheckDistEpipolarLine (:159-176)
+      const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+      const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+      const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+      const float num = a * kp2.x + b * kp2.y + c;
+      const float den = a * a + b * b;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (dsqr < 3.84 * sigma2_2[kp2.octave]) { bestIdx2 = idx2; bestDist = d; }
+    }
+    if (bestIdx2 >= 0) {
+      matches12[q_of[q]] = bestIdx2;
+      nmatches++;
+      if (mbCheckOrientation) rotHist[histBin(kp1.angle - K2.keys[bestIdx2].angle)].push_back(q_of[q]);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matches12[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+int ORBmatcher::SearchForInitialization(const KeysView& F1, const FrameView& F2, std::vector<float>& prev, std::vector<int32_t>& vnMatches12, int windowSize) {
+  vnMatches12.assign(F1.N, -1);
+  FrameGrid grid(F2);
+  std::vector<int32_t> q_of, off(1, 0), idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  for (int i1 = 0; i1 < F1.N; i1++) {
+    const int level1 = F1.keys[i1].octave;
+    if (level1 > 0) continue;
+    const size_t before = idx.size();
+    grid.featuresInArea(prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1, idx);
+    if (idx.size() == before) continue;
+    q_of.push_back(i1); off.push_back((int32_t)idx.size());
+    qdesc.insert(qdesc.end(), F1.desc + (size_t)i1 * 32, F1.desc + (size_t)i1 * 32 + 32);
+  }
+  distances(qdesc, (int)q_of.size(), F2.mDescriptors, F2.N, off, idx, dist);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(F2.N, INT32_MAX), vnMatches21(F2.N, -1);
+  int nmatches = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    const int i1 = q_of[q];
+    int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int i2 = idx[s];
+      const int d = dist[s];
+      if (vMatchedDistance[i2] <= d) continue;
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+      else if (d < bestDist2) bestDist2 = d;
+    }
+    if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * mfNNratio) {
+      if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }   // steal-back (:506-510)
+      vnMatches12[i1] = bestIdx2;
+      vnMatches21[bestIdx2] = i1;
+      vMatchedDistance[bestIdx2] = bestDist;
+      nmatches++;
+      if (mbCheckOrientation) rotHist[histBin(F1.keys[i1].angle - F2.mvKeysUn[bestIdx2].angle)].push_back(i1);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i]) if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < F1.N; i1++)
+    if (vnMatches12[i1] >= 0) { prev[2 * i1] = F2.mvKeysUn[vnMatches12[i1]].x; prev[2 * i1 + 1] = F2.mvKeysUn[vnMatches12[i1]].y; }
+  return nmatches;
+}
+
 // ---- Optimizer ---------------------------------------------------------------------------------------
 int Optimizer::PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, const double* Xw, const double* obs,
                                       const double* invSigma2, const double K[4], std::vector<uint8_t>& outlier) {
@@ -339,6 +546,58 @@ int ccmh_orb_extract(int device, int nfeatures, const uint8_t* img, int w, int h
     const int n = std::min<int>((int)k.size(), cap);
     std::memcpy(kps_out, k.data(), sizeof(cslam::KeyPoint) * n);
     std::memcpy(desc_out, d.data(), (size_t)n * 32);
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+}
+
+// ---- C wrappers for the BoW / triangulation / initialisation searches --------------------------------------
+namespace {
+std::vector<cslam::KeyPoint> mk_keys(const float* x, const float* y, const int32_t* oct, const float* ang, int N) {
+  std::vector<cslam::KeyPoint> k(N);
+  for (int i = 0; i < N; i++) k[i] = cslam::KeyPoint{x[i], y[i], 31.f, ang ? ang[i] : 0.f, 0.f, oct ? oct[i] : 0};
+  return k;
+}
+}
+extern "C" {
+// mode 0: SearchByBoW(KF,F) -> out[N2] ; 1: SearchByBoW(KF,KF) -> out[N1] ; 2: SearchForTriangulation -> out[N1]
+int ccmh_search_bow(int device, int mode, const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const int32_t* n2,
+                    const int32_t* o2, const int32_t* i2, int nn2, const uint8_t* has1, const uint8_t* has2, const uint8_t* d1,
+                    const float* x1, const float* y1, const float* a1, int N1, const uint8_t* d2, const float* x2, const float* y2,
+                    const int32_t* oct2, const float* a2, int N2, const float* F12, float ex, float ey, const float* sigma2_2,
+                    const float* sf2, float nnratio, int check_ori, int32_t* out) {
+  try {
+    cslam::HipContext ctx(device);
+    auto k1 = mk_keys(x1, y1, nullptr, a1, N1), k2 = mk_keys(x2, y2, oct2, a2, N2);
+    cslam::KeysView A; A.N = N1; A.keys = k1.data(); A.desc = d1; A.hasMapPoint = has1; A.fv = cslam::FeatureVectorView{nn1, n1, o1, i1};
+    cslam::KeysView B; B.N = N2; B.keys = k2.data(); B.desc = d2; B.hasMapPoint = has2; B.fv = cslam::FeatureVectorView{nn2, n2, o2, i2};
+    cslam::ORBmatcher m(ctx, nnratio, check_ori != 0);
+    std::vector<int32_t> r; int n = 0;
+    if (mode == 0) n = m.SearchByBoW(A, B, r);
+    else if (mode == 1) n = m.SearchByBoW_KF(A, B, r);
+    else n = m.SearchForTriangulation(A, B, F12, ex, ey, sigma2_2, sf2, r);
+    std::memcpy(out, r.data(), r.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+
+int ccmh_search_for_initialization(int device, const float* x1, const float* y1, const int32_t* oct1, const float* a1, const uint8_t* d1, int N1,
+                                   const float* x2, const float* y2, const int32_t* oct2, const float* a2, const uint8_t* d2, int N2,
+                                   float minX, float minY, float maxX, float maxY, float* prev_xy, int window, float nnratio, int check_ori,
+                                   int32_t* matches12) {
+  try {
+    cslam::HipContext ctx(device);
+    auto k1 = mk_keys(x1, y1, oct1, a1, N1), k2 = mk_keys(x2, y2, oct2, a2, N2);
+    cslam::KeysView A; A.N = N1; A.keys = k1.data(); A.desc = d1;
+    std::vector<int32_t> dummy(N2, -1);
+    cslam::FrameView F; F.N = N2; F.mvKeysUn = k2.data(); F.mDescriptors = d2; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
+    F.mvpMapPoints = dummy.data();
+    std::vector<float> prev(prev_xy, prev_xy + 2 * (size_t)N1);
+    std::vector<int32_t> r;
+    cslam::ORBmatcher m(ctx, nnratio, check_ori != 0);
+    const int n = m.SearchForInitialization(A, F, prev, r, window);
+    std::memcpy(prev_xy, prev.data(), prev.size() * sizeof(float));
+    std::memcpy(matches12, r.data(), r.size() * sizeof(int32_t));
     return n;
   } catch (const std::exception&) { return -1000; }
 }

@@ -89,6 +89,17 @@ struct LastFrameProjections {
   const uint8_t* mpDescriptor = nullptr;    // n x 32, pMP->GetDescriptor()
 };
 
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened: ascending node ids + CSR of feature indices
+struct FeatureVectorView { int nn = 0; const int32_t* node = nullptr; const int32_t* off = nullptr; const int32_t* idx = nullptr; };
+// What the BoW / triangulation / initialisation searches read from a KeyFrame or Frame
+struct KeysView {
+  int N = 0;
+  const KeyPoint* keys = nullptr;           // mvKeysUn
+  const uint8_t* desc = nullptr;            // N x 32
+  const uint8_t* hasMapPoint = nullptr;     // vpMapPoints[i] && !isBad()
+  FeatureVectorView fv;
+};
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
@@ -99,7 +110,20 @@ class ORBmatcher {
   int SearchByProjection(FrameView& F, const TrackedMapPoints& mps, float th);
   // ORBmatcher.cpp:1350-1476.
   int SearchByProjection(FrameView& CurrentFrame, const LastFrameProjections& last, float th);
+  // SearchByBoW(kfptr pKF, Frame& F, ...) — ORBmatcher.cpp:178-306.  matchesF[F.N]: KF feature whose map point goes to F[i], or -1
+  int SearchByBoW(const KeysView& KF, const KeysView& F, std::vector<int32_t>& matchesF);
+  // SearchByBoW(kfptr, kfptr, ...) — ORBmatcher.cpp:565-698.  matches12[KF1.N]: feature of KF2 or -1
+  int SearchByBoW_KF(const KeysView& KF1, const KeysView& KF2, std::vector<int32_t>& matches12);
+  // SearchForTriangulation — ORBmatcher.cpp:700-852.  F12 row-major 3x3 f32; (ex,ey) epipole in image 2 (:708-714)
+  int SearchForTriangulation(const KeysView& KF1, const KeysView& KF2, const float F12[9], float ex, float ey, const float* sigma2_2,
+                             const float* scaleFactors2, std::vector<int32_t>& matches12);
+  // SearchForInitialization — ORBmatcher.cpp:448-563.  F2 needs the grid bounds; prevMatched (x,y pairs) is updated in place
+  int SearchForInitialization(const KeysView& F1, const FrameView& F2, std::vector<float>& vbPrevMatched, std::vector<int32_t>& vnMatches12,
+                              int windowSize = 10);
  private:
+  // distances of every (query, candidate) slot in one device launch
+  void distances(const std::vector<uint8_t>& qdesc, int Q, const uint8_t* tdesc, int T, const std::vector<int32_t>& off,
+                 const std::vector<int32_t>& idx, std::vector<uint16_t>& dist);
   HipContext& ctx_;
   float mfNNratio; bool mbCheckOrientation;
 };

@@ -312,3 +312,57 @@ def distribute_octree(kps, minX, maxX, minY, maxY, N):
     n = lib().ora_distribute_octree(kps.ctypes.data_as(C.c_void_p), kps.size, minX, maxX, minY, maxY, N,
                                     out.ctypes.data_as(C.c_void_p), out.size)
     return out[:n]
+
+
+# ---- BoW-bucketed / triangulation / initialisation searches ------------------------------------------
+def _fv(fv):
+    node, off, idx = (np.ascontiguousarray(a, np.int32) for a in fv)
+    return node, off, idx
+
+
+def search_by_bow_kf_frame(fv_kf, fv_f, kf_has_mp, kf_desc, kf_angle, f_desc, f_angle, nnratio, check_ori):
+    n1, o1, i1 = _fv(fv_kf); n2, o2, i2 = _fv(fv_f)
+    f_n = f_desc.shape[0]
+    out = np.zeros(f_n, np.int32)
+    n = lib().ora_search_by_bow_kf_frame(_p(n1, C.c_int32), _p(o1, C.c_int32), _p(i1, C.c_int32), n1.size, _p(n2, C.c_int32), _p(o2, C.c_int32),
+                                         _p(i2, C.c_int32), n2.size, _p(np.ascontiguousarray(kf_has_mp, np.uint8), C.c_uint8),
+                                         _p(np.ascontiguousarray(kf_desc, np.uint8), C.c_uint8), _p(np.ascontiguousarray(kf_angle, np.float32), C.c_float),
+                                         _p(np.ascontiguousarray(f_desc, np.uint8), C.c_uint8), _p(np.ascontiguousarray(f_angle, np.float32), C.c_float),
+                                         f_n, C.c_float(nnratio), int(check_ori), _p(out, C.c_int32))
+    return int(n), out
+
+
+def search_by_bow_kf_kf(fv1, fv2, has1, has2, d1, a1, d2, a2, nnratio, check_ori):
+    n1, o1, i1 = _fv(fv1); n2, o2, i2 = _fv(fv2)
+    out = np.zeros(d1.shape[0], np.int32)
+    n = lib().ora_search_by_bow_kf_kf(_p(n1, C.c_int32), _p(o1, C.c_int32), _p(i1, C.c_int32), n1.size, _p(n2, C.c_int32), _p(o2, C.c_int32),
+                                      _p(i2, C.c_int32), n2.size, _p(np.ascontiguousarray(has1, np.uint8), C.c_uint8), _p(np.ascontiguousarray(has2, np.uint8), C.c_uint8),
+                                      _p(np.ascontiguousarray(d1, np.uint8), C.c_uint8), _p(np.ascontiguousarray(a1, np.float32), C.c_float), d1.shape[0],
+                                      _p(np.ascontiguousarray(d2, np.uint8), C.c_uint8), _p(np.ascontiguousarray(a2, np.float32), C.c_float), d2.shape[0],
+                                      C.c_float(nnratio), int(check_ori), _p(out, C.c_int32))
+    return int(n), out
+
+
+def search_for_triangulation(fv1, fv2, has1, has2, d1, x1, y1, a1, d2, x2, y2, oct2, a2, F12, ex, ey, sigma2_2, sf2, check_ori):
+    n1, o1, i1 = _fv(fv1); n2, o2, i2 = _fv(fv2)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    out = np.zeros(d1.shape[0], np.int32)
+    n = lib().ora_search_for_triangulation(_p(n1, C.c_int32), _p(o1, C.c_int32), _p(i1, C.c_int32), n1.size, _p(n2, C.c_int32), _p(o2, C.c_int32),
+                                           _p(i2, C.c_int32), n2.size, _p(np.ascontiguousarray(has1, np.uint8), C.c_uint8), _p(np.ascontiguousarray(has2, np.uint8), C.c_uint8),
+                                           _p(np.ascontiguousarray(d1, np.uint8), C.c_uint8), _p(f32(x1), C.c_float), _p(f32(y1), C.c_float), _p(f32(a1), C.c_float), d1.shape[0],
+                                           _p(np.ascontiguousarray(d2, np.uint8), C.c_uint8), _p(f32(x2), C.c_float), _p(f32(y2), C.c_float),
+                                           _p(np.ascontiguousarray(oct2, np.int32), C.c_int32), _p(f32(a2), C.c_float), d2.shape[0], _p(f32(F12), C.c_float),
+                                           C.c_float(ex), C.c_float(ey), _p(f32(sigma2_2), C.c_float), _p(f32(sf2), C.c_float), int(check_ori), _p(out, C.c_int32))
+    return int(n), out
+
+
+def search_for_initialization(k1, d1, k2, d2, bounds, prev_xy, window, nnratio, check_ori):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    prev = f32(prev_xy).copy()
+    out = np.zeros(len(k1), np.int32)
+    n = lib().ora_search_for_initialization(_p(f32(k1["x"]), C.c_float), _p(f32(k1["y"]), C.c_float), _p(np.ascontiguousarray(k1["octave"], np.int32), C.c_int32),
+                                            _p(f32(k1["angle"]), C.c_float), _p(np.ascontiguousarray(d1, np.uint8), C.c_uint8), len(k1),
+                                            _p(f32(k2["x"]), C.c_float), _p(f32(k2["y"]), C.c_float), _p(np.ascontiguousarray(k2["octave"], np.int32), C.c_int32),
+                                            _p(f32(k2["angle"]), C.c_float), _p(np.ascontiguousarray(d2, np.uint8), C.c_uint8), len(k2),
+                                            *[C.c_float(b) for b in bounds], _p(prev, C.c_float), int(window), C.c_float(nnratio), int(check_ori), _p(out, C.c_int32))
+    return int(n), out, prev

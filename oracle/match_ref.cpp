@@ -252,3 +252,219 @@ int ora_search_by_projection_last(const float* kx, const float* ky, const int32_
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// BoW-bucketed searches.  A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) is passed
+// flat: ascending node ids fv_node[nn], fv_off[nn+1], fv_idx[] (feature indices in insertion order).
+// ================================================================================================
+namespace {
+struct FV { const int32_t* node; const int32_t* off; const int32_t* idx; int nn; };
+// the merge-join of two ordered maps with lower_bound jumps (ORBmatcher.cpp:199-283) visits exactly the
+// common node ids in ascending order; returns pairs (position in a, position in b)
+std::vector<std::pair<int, int>> common_nodes(const FV& a, const FV& b) {
+  std::vector<std::pair<int, int>> r;
+  int i = 0, j = 0;
+  while (i < a.nn && j < b.nn) {
+    if (a.node[i] == b.node[j]) { r.push_back({i, j}); i++; j++; }
+    else if (a.node[i] < b.node[j]) i = (int)(std::lower_bound(a.node, a.node + a.nn, b.node[j]) - a.node);
+    else j = (int)(std::lower_bound(b.node, b.node + b.nn, a.node[i]) - b.node);
+  }
+  return r;
+}
+int hist_bin(float rot) {   // rotation histogram bin, factor = 1/HISTO_LENGTH (upstream quirk)
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * (1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByBoW(kfptr pKF, Frame &F, vector<mpptr>&) — ORBmatcher.cpp:178-306.
+// kf_has_mp[i] = vpMapPointsKF[i] && !isBad().  matches_f[F.N] out: KF feature index whose map point was
+// assigned to the frame feature, or -1.  Returns nmatches.
+int ora_search_by_bow_kf_frame(const int32_t* kf_node, const int32_t* kf_off, const int32_t* kf_idx, int kf_nn,
+                               const int32_t* f_node, const int32_t* f_off, const int32_t* f_idx, int f_nn,
+                               const uint8_t* kf_has_mp, const uint8_t* kf_desc, const float* kf_angle,
+                               const uint8_t* f_desc, const float* f_angle, int f_n, float nnratio, int check_ori,
+                               int32_t* matches_f) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  for (int i = 0; i < f_n; i++) matches_f[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  const FV a{kf_node, kf_off, kf_idx, kf_nn}, b{f_node, f_off, f_idx, f_nn};
+  for (auto pr : common_nodes(a, b)) {
+    for (int s1 = kf_off[pr.first]; s1 < kf_off[pr.first + 1]; s1++) {
+      const int realIdxKF = kf_idx[s1];
+      if (!kf_has_mp[realIdxKF]) continue;
+      int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+      for (int s2 = f_off[pr.second]; s2 < f_off[pr.second + 1]; s2++) {
+        const int realIdxF = f_idx[s2];
+        if (matches_f[realIdxF] >= 0) continue;
+        const int dist = ora_descriptor_distance(kf_desc + (size_t)realIdxKF * 32, f_desc + (size_t)realIdxF * 32);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 <= TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+        matches_f[bestIdxF] = realIdxKF;
+        if (check_ori) rotHist[hist_bin(kf_angle[realIdxKF] - f_angle[bestIdxF])].push_back(bestIdxF);
+        nmatches++;
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matches_f[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByBoW(kfptr pKF1, kfptr pKF2, vector<mpptr>&) — ORBmatcher.cpp:565-698 (strict < TH_LOW).
+// matches12[n1] out: feature index in KF2 or -1.
+int ora_search_by_bow_kf_kf(const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const int32_t* n2, const int32_t* o2,
+                            const int32_t* i2, int nn2, const uint8_t* has_mp1, const uint8_t* has_mp2, const uint8_t* desc1,
+                            const float* angle1, int N1, const uint8_t* desc2, const float* angle2, int N2, float nnratio,
+                            int check_ori, int32_t* matches12) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<char> vbMatched2(N2, 0);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  const FV a{n1, o1, i1, nn1}, b{n2, o2, i2, nn2};
+  for (auto pr : common_nodes(a, b)) {
+    for (int s1 = o1[pr.first]; s1 < o1[pr.first + 1]; s1++) {
+      const int idx1 = i1[s1];
+      if (!has_mp1[idx1]) continue;
+      int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+      for (int s2 = o2[pr.second]; s2 < o2[pr.second + 1]; s2++) {
+        const int idx2 = i2[s2];
+        if (vbMatched2[idx2] || !has_mp2[idx2]) continue;
+        const int dist = ora_descriptor_distance(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      if (bestDist1 < TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+        matches12[idx1] = bestIdx2;
+        vbMatched2[bestIdx2] = 1;
+        if (check_ori) rotHist[hist_bin(angle1[idx1] - angle2[bestIdx2])].push_back(idx1);
+        nmatches++;
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matches12[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation — ORBmatcher.cpp:700-852 (+ CheckDistEpipolarLine :159-176).
+// F12 row-major 3x3 f32, epipole (ex,ey) in image 2 computed by the caller (:708-714), sigma2 = pKF2->mvLevelSigma2,
+// sf2 = pKF2->mvScaleFactors.  Note: the reference never sets vbMatched2 (kept).
+int ora_search_for_triangulation(const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const int32_t* n2, const int32_t* o2,
+                                 const int32_t* i2, int nn2, const uint8_t* has_mp1, const uint8_t* has_mp2, const uint8_t* desc1,
+                                 const float* x1, const float* y1, const float* angle1, int N1, const uint8_t* desc2, const float* x2,
+                                 const float* y2, const int32_t* oct2, const float* angle2, int N2, const float* F12, float ex, float ey,
+                                 const float* sigma2_2, const float* sf2, int check_ori, int32_t* matches12) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0;
+  const FV a{n1, o1, i1, nn1}, b{n2, o2, i2, nn2};
+  for (auto pr : common_nodes(a, b)) {
+    for (int s1 = o1[pr.first]; s1 < o1[pr.first + 1]; s1++) {
+      const int idx1 = i1[s1];
+      if (has_mp1[idx1]) continue;
+      int bestDist = TH_LOW, bestIdx2 = -1;
+      for (int s2 = o2[pr.second]; s2 < o2[pr.second + 1]; s2++) {
+        const int idx2 = i2[s2];
+        if (has_mp2[idx2]) continue;
+        const int dist = ora_descriptor_distance(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+        if (dist > TH_LOW || dist > bestDist) continue;
+        const float distex = ex - x2[idx2], distey = ey - y2[idx2];
+        if (distex * distex + distey * distey < 100 * sf2[oct2[idx2]]) continue;
+        // CheckDistEpipolarLine
+        const float la = x1[idx1] * F12[0] + y1[idx1] * F12[3] + F12[6];
+        const float lb = x1[idx1] * F12[1] + y1[idx1] * F12[4] + F12[7];
+        const float lc = x1[idx1] * F12[2] + y1[idx1] * F12[5] + F12[8];
+        const float num = la * x2[idx2] + lb * y2[idx2] + lc;
+        const float den = la * la + lb * lb;
+        if (den == 0) continue;
+        const float dsqr = num * num / den;
+        if (dsqr < 3.84 * sigma2_2[oct2[idx2]]) { bestIdx2 = idx2; bestDist = dist; }
+      }
+      if (bestIdx2 >= 0) {
+        matches12[idx1] = bestIdx2;
+        nmatches++;
+        if (check_ori) rotHist[hist_bin(angle1[idx1] - angle2[bestIdx2])].push_back(idx1);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int k : rotHist[i]) { matches12[k] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchForInitialization — ORBmatcher.cpp:448-563.  prev_xy in/out (vbPrevMatched), matches12 out.
+int ora_search_for_initialization(const float* x1, const float* y1, const int32_t* oct1, const float* angle1, const uint8_t* desc1, int N1,
+                                  const float* x2, const float* y2, const int32_t* oct2, const float* angle2, const uint8_t* desc2, int N2,
+                                  float minX, float minY, float maxX, float maxY, float* prev_xy, int window, float nnratio,
+                                  int check_ori, int32_t* matches12) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  Grid* g = new Grid();
+  build_grid(*g, x2, y2, oct2, N2, minX, minY, maxX, maxY);
+  for (int i = 0; i < N1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(N2, INT32_MAX), vnMatches21(N2, -1);
+  int nmatches = 0;
+  std::vector<int> vIndices2;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int level1 = oct1[i1];
+    if (level1 > 0) continue;
+    features_in_area(*g, prev_xy[2 * i1], prev_xy[2 * i1 + 1], (float)window, level1, level1, vIndices2);
+    if (vIndices2.empty()) continue;
+    int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      const int dist = ora_descriptor_distance(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+      if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+      matches12[i1] = bestIdx2;
+      vnMatches21[bestIdx2] = i1;
+      vMatchedDistance[bestIdx2] = bestDist;
+      nmatches++;
+      if (check_ori) rotHist[hist_bin(angle1[i1] - angle2[bestIdx2])].push_back(i1);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i]) if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (int i1 = 0; i1 < N1; i1++) if (matches12[i1] >= 0) { prev_xy[2 * i1] = x2[matches12[i1]]; prev_xy[2 * i1 + 1] = y2[matches12[i1]]; }
+  delete g;
+  return nmatches;
+}
+
+}  // extern "C"

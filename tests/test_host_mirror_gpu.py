@@ -105,3 +105,84 @@ def test_orb_extractor_class(hostlib, oracle_lib):
     kps = np.zeros(1100, oracle_lib.KP_DTYPE); desc = np.zeros((1100, 32), np.uint8)
     n = hostlib.ccmh_orb_extract(0, 1000, _p(img), 752, 480, _p(kps), _p(desc), 1100)
     assert n == len(okps) and np.array_equal(desc[:n], odesc) and np.array_equal(kps[:n], okps)
+
+
+# ---- BoW-bucketed, triangulation and initialisation searches (M3-M6) ------------------------------------
+def _feature_vector(desc, seed, n_nodes=60):
+    """synthetic DBoW2 FeatureVector: node = f(first descriptor bits) so that similar descriptors mostly share a
+    node; returns (node ids ascending, CSR offsets, feature indices in insertion order)"""
+    node_of = (desc[:, 0].astype(int) * 7 + (desc[:, 1] >> 5) + seed) % n_nodes
+    nodes = np.unique(node_of)
+    off = [0]
+    idx = []
+    for nd in nodes:
+        m = np.nonzero(node_of == nd)[0]
+        idx.extend(m.tolist())
+        off.append(len(idx))
+    return nodes.astype(np.int32), np.array(off, np.int32), np.array(idx, np.int32)
+
+
+def _two_frames(oracle_lib):
+    k1, d1 = _frame(oracle_lib, 1000, 0)
+    k2, d2 = _frame(oracle_lib, 1000, 1)
+    return k1, d1, k2, d2
+
+
+def _bow_args(k1, d1, k2, d2, fv1, fv2, has1, has2):
+    c = np.ascontiguousarray
+    return [_p(fv1[0]), _p(fv1[1]), _p(fv1[2]), fv1[0].size, _p(fv2[0]), _p(fv2[1]), _p(fv2[2]), fv2[0].size, _p(has1), _p(has2), _p(d1),
+            _p(c(k1["x"])), _p(c(k1["y"])), _p(c(k1["angle"])), len(k1), _p(d2), _p(c(k2["x"])), _p(c(k2["y"])), _p(c(k2["octave"])),
+            _p(c(k2["angle"])), len(k2)]
+
+
+def test_search_by_bow_kf_frame_and_kf_kf(hostlib, oracle_lib):
+    k1, d1, k2, d2 = _two_frames(oracle_lib)
+    rng = np.random.default_rng(3)
+    fv1, fv2 = _feature_vector(d1, 0), _feature_vector(d2, 0)
+    has1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    zero9 = np.zeros(9, np.float32); sf = synth.scale_tables()[0]; s2 = synth.scale_tables()[2]
+    # KF -> Frame (<= TH_LOW, ratio 0.7)
+    exp_n, exp = oracle_lib.search_by_bow_kf_frame(fv1, fv2, has1, d1, k1["angle"], d2, k2["angle"], 0.7, 1)
+    got = np.zeros(len(k2), np.int32)
+    n = hostlib.ccmh_search_bow(0, 0, *_bow_args(k1, d1, k2, d2, fv1, fv2, has1, has2), _p(zero9), C.c_float(0), C.c_float(0), _p(s2), _p(sf),
+                                C.c_float(0.7), 1, _p(got))
+    assert n == exp_n and n > 100 and np.array_equal(got, exp)
+    # KF -> KF (strict < TH_LOW, both sides need map points)
+    exp_n, exp = oracle_lib.search_by_bow_kf_kf(fv1, fv2, has1, has2, d1, k1["angle"], d2, k2["angle"], 0.75, 1)
+    got = np.zeros(len(k1), np.int32)
+    n = hostlib.ccmh_search_bow(0, 1, *_bow_args(k1, d1, k2, d2, fv1, fv2, has1, has2), _p(zero9), C.c_float(0), C.c_float(0), _p(s2), _p(sf),
+                                C.c_float(0.75), 1, _p(got))
+    assert n == exp_n and n > 50 and np.array_equal(got, exp)
+
+
+def test_search_for_triangulation(hostlib, oracle_lib):
+    k1, d1, k2, d2 = _two_frames(oracle_lib)
+    rng = np.random.default_rng(4)
+    fv1, fv2 = _feature_vector(d1, 0), _feature_vector(d2, 0)
+    has1 = (rng.random(len(k1)) < 0.4).astype(np.uint8)
+    has2 = (rng.random(len(k2)) < 0.4).astype(np.uint8)
+    # pure x-translation between the views: F = [t]_x, epipolar lines are horizontal; epipole far to the right
+    F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    sf, _, s2, _ = synth.scale_tables()
+    exp_n, exp = oracle_lib.search_for_triangulation(fv1, fv2, has1, has2, d1, k1["x"], k1["y"], k1["angle"], d2, k2["x"], k2["y"], k2["octave"],
+                                                     k2["angle"], F12, 5000.0, 240.0, s2, sf, 0)
+    got = np.zeros(len(k1), np.int32)
+    n = hostlib.ccmh_search_bow(0, 2, *_bow_args(k1, d1, k2, d2, fv1, fv2, has1, has2), _p(F12), C.c_float(5000.0), C.c_float(240.0), _p(s2), _p(sf),
+                                C.c_float(0.6), 0, _p(got))
+    assert n == exp_n and n > 50 and np.array_equal(got, exp)
+
+
+def test_search_for_initialization(hostlib, oracle_lib):
+    k1, d1 = oracle_lib.OrbOracle(2000).extract(synth.gen_image(1000, 0))
+    k2, d2 = oracle_lib.OrbOracle(2000).extract(synth.gen_image(1000, 2))
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32).ravel()
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    exp_n, exp, exp_prev = oracle_lib.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, 1)
+    got = np.zeros(len(k1), np.int32); gprev = prev.copy()
+    c = np.ascontiguousarray
+    n = hostlib.ccmh_search_for_initialization(0, _p(c(k1["x"])), _p(c(k1["y"])), _p(c(k1["octave"])), _p(c(k1["angle"])), _p(d1), len(k1),
+                                               _p(c(k2["x"])), _p(c(k2["y"])), _p(c(k2["octave"])), _p(c(k2["angle"])), _p(d2), len(k2),
+                                               *[C.c_float(b) for b in bounds], _p(gprev), 100, C.c_float(0.9), 1, _p(got))
+    assert n == exp_n and n > 100
+    assert np.array_equal(got, exp) and np.array_equal(gprev, exp_prev)
