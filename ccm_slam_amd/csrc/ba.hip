@@ -491,6 +491,110 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
+// ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
+// A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
+// the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
+constexpr int kSmallTPB = 1024;
+constexpr int kSmallMaxCp = 256;
+
+__device__ __forceinline__ double block_dot_small(double v, double* red /* [16] */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < kSmallTPB / kWave; i++) s += red[i];
+  return s;   // identical in every thread
+}
+
+__global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda, double rel_tol, int max_it) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = 6 * d.Cp;
+  double* xs = sm; double* rs = xs + n; double* zs = rs + n; double* ps = zs + n; double* qs = ps + n;
+  double* Mi = qs + n;               // [Cp][36]
+  double* red = Mi + 36 * d.Cp;      // [16]
+  // all LDS in the dynamic region (a static __shared__ in front of it would misalign the f64 arrays, guide G17)
+  int& fail_s = *reinterpret_cast<int*>(red + 16);
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  if (t == 0) fail_s = 0;
+  __syncthreads();
+  if (t < d.Cp) {
+    double A[36], Inv[36];
+    const double* S = d.S + 36 * (size_t)t;
+#pragma unroll
+    for (int k = 0; k < 36; k++) A[k] = S[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) A[k * 7] += lambda;
+    if (!ba_spd6_inv(A, Inv)) { fail_s = 1; for (int k = 0; k < 36; k++) Inv[k] = (k % 7 == 0) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 36; k++) Mi[36 * t + k] = Inv[k];
+  }
+  for (int i = t; i < n; i += kSmallTPB) { xs[i] = 0; rs[i] = d.bs[i]; }
+  __syncthreads();
+  for (int i = t; i < n; i += kSmallTPB) {
+    const int row = i / 6, a = i % 6;
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) s += Mi[36 * row + a * 6 + c] * rs[6 * row + c];
+    zs[i] = s; ps[i] = s;
+  }
+  __syncthreads();
+  double part = 0;
+  for (int i = t; i < n; i += kSmallTPB) part += rs[i] * zs[i];
+  double rz = block_dot_small(part, red);
+  const double rz0 = rz;
+  int k = 0, fail = fail_s;
+  for (; k < max_it; k++) {
+    if (rz <= rel_tol * rel_tol * rz0 || !(rz > 0.0)) { if (rz != rz) fail = 1; break; }
+    // q = (S + lambda I) p : one wave per block row, 8 blocks in flight (same lane mapping as ba_pcg_spmv)
+    for (int i = wv; i < d.Cp; i += kSmallTPB / kWave) {
+      const int g = lane >> 3, r = lane & 7;
+      double acc = 0;
+      if (r < 6) {
+        for (int s = d.row_off[i] + g; s < d.row_off[i + 1]; s += 8) {
+          const int j = d.row_col[s];
+          const uint32_t bt = d.row_blk[s];
+          const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+          if (bt & kTransposeBit) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += B[c * 6 + r] * ps[6 * j + c];
+          } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc += B[r * 6 + c] * ps[6 * j + c];
+          }
+        }
+      }
+      acc += __shfl_xor(acc, 8, kWave); acc += __shfl_xor(acc, 16, kWave); acc += __shfl_xor(acc, 32, kWave);
+      if (lane < 6) qs[6 * i + lane] = acc + lambda * ps[6 * i + lane];
+    }
+    __syncthreads();
+    part = 0;
+    for (int i = t; i < n; i += kSmallTPB) part += ps[i] * qs[i];
+    const double pq = block_dot_small(part, red);
+    if (!(pq > 0.0)) { fail = 1; break; }
+    const double alpha = rz / pq;
+    for (int i = t; i < n; i += kSmallTPB) { xs[i] += alpha * ps[i]; rs[i] -= alpha * qs[i]; }
+    __syncthreads();
+    part = 0;
+    for (int i = t; i < n; i += kSmallTPB) {
+      const int row = i / 6, a = i % 6;
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) s += Mi[36 * row + a * 6 + c] * rs[6 * row + c];
+      zs[i] = s;
+      part += rs[i] * s;
+    }
+    const double rz_new = block_dot_small(part, red);
+    const double beta = rz_new / rz;
+    for (int i = t; i < n; i += kSmallTPB) ps[i] = zs[i] + beta * ps[i];
+    rz = rz_new;
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += kSmallTPB) d.x[i] = xs[i];
+  if (t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = fail; }
+}
+
 // ---- apply the step to a trial state, chi2 of the trial ---------------------------------------
 // cameras: T_trial = exp(dx) * T ; partial of sum x (lambda x + b_p)                   [CCM_K_BA_UPDATE]
 __global__ __launch_bounds__(kTPB) void ba_update_cams(BaDev d, int cur, double lambda, int add_lambda_term) {
@@ -952,6 +1056,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   *ok = true;
   *pcg_iters = 0;
+  bool small_path = false;
+  int small_flags[4] = {0, 0, 0, 0};
   if (d.Cp) {
     {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
@@ -965,28 +1071,40 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     // ---- PCG ----
     const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-10;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(ba_pcg_init, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, lambda, tol);
     int flags[4] = {0, 0, 0, 0};
-    const int chunk = 24;
-    int k = 0;
-    while (k < max_it) {
-      const int kend = std::min(max_it, k + chunk);
-      for (; k < kend; k++) {
-        {
-          ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-          hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, k);
-        }
-        {
-          ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
-          hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-        }
+    if (d.Cp <= kSmallMaxCp) {
+      // one launch, no host round trip: the flags are read back after the trial kernels are queued
+      const size_t lds = (size_t)(5 * 6 * d.Cp + 36 * d.Cp + 18) * sizeof(double);
+      static bool attr_set = false;
+      if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+      {
+        ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
+        hipLaunchKernelGGL(ba_pcg_small, dim3(1), dim3(kSmallTPB), lds, ctx->stream, d, lambda, tol, max_it);
       }
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-      CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-      if (flags[0]) break;
+      small_path = true;
+    } else {
+      CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
+      hipLaunchKernelGGL(ba_pcg_init, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, lambda, tol);
+      const int chunk = 24;
+      int k = 0;
+      while (k < max_it) {
+        const int kend = std::min(max_it, k + chunk);
+        for (; k < kend; k++) {
+          {
+            ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
+            hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, k);
+          }
+          {
+            ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
+            hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+          }
+        }
+        CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (flags[0]) break;
+      }
+      *pcg_iters = flags[0] ? flags[1] : k;
     }
-    *pcg_iters = flags[0] ? flags[1] : k;
     if (flags[2]) *ok = false;   // not SPD / NaN: linear solver failure (levenberg.cpp:126-127)
   }
   if (d.Cp) {
@@ -999,9 +1117,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
   RC(ccm_allreduce_f64(ctx, d.scal, 2));
+  if (small_path) CCM_HIP_CHECK(ctx, hipMemcpyAsync(small_flags, d.pcg_flag, sizeof(small_flags), hipMemcpyDeviceToHost, ctx->stream));
   double s[4];
   RC(read_scalars(ba, s));
   CCM_HIP_CHECK(ctx, hipGetLastError());
+  if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
   *temp_chi = s[0];
   *scale = s[1];
   return CCM_OK;

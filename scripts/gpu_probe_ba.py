@@ -12,7 +12,7 @@ if which == "small":
     prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=60, n_points=5000, seed=21)
     iters = 8
 elif which == "lba":
-    prob = synth.make_ba_config("lba_c2"); iters = 5
+    prob = synth.make_ba_config("lba_c2"); iters = 15
 else:
     prob = synth.make_ba_config(which); iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 print("problem", which, prob["n_cam"], prob["n_pt"], prob["n_edge"], flush=True)
