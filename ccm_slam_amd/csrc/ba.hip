@@ -305,17 +305,18 @@ __global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
   }
 }
 
-// off-diagonal Schur blocks: one wave per block, lane = element (r,c)   [CCM_K_BA_SCHUR_OFF]
+// off-diagonal Schur blocks: one workgroup per block, lane = element (r,c), the block's pair instances are
+// strided over the 4 waves and summed through LDS in a fixed order            [CCM_K_BA_SCHUR_OFF]
 //   S_ij = - sum_inst W_a Dinv W_c^T
 __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave);
-  if (b >= d.nOff) return;
+  __shared__ double part[kTPB / kWave][36];
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int b = blockIdx.x;
   const int r = lane / 6, c = lane % 6;
   double acc = 0;
   if (lane < 36) {
     const int s0 = d.inst_off[b], s1 = d.inst_off[b + 1];
-    for (int s = s0; s < s1; s++) {
+    for (int s = s0 + wv; s < s1; s += kTPB / kWave) {
       const int ea = d.inst_a[s], ec = d.inst_c[s];
       const int l = d.ed_pt[ea];
       const double* Wa = d.W + 18 * (size_t)ea + 3 * r;
@@ -327,8 +328,10 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
       const double y2 = a0 * Di[2] + a1 * Di[4] + a2 * Di[5];
       acc += y0 * Wc[0] + y1 * Wc[1] + y2 * Wc[2];
     }
-    d.S[36 * (size_t)(d.Cp + b) + lane] = -acc;
+    part[wv][lane] = acc;
   }
+  __syncthreads();
+  if (wv == 0 && lane < 36) d.S[36 * (size_t)(d.Cp + b) + lane] = -(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
@@ -508,12 +511,24 @@ __device__ __forceinline__ double block_dot_small(double v, double* red /* [16] 
   return s;   // identical in every thread
 }
 
-__global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda, double rel_tol, int max_it) {
+__global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda, double rel_tol, int max_it, int stage_S, int n_entries) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = 6 * d.Cp;
   double* xs = sm; double* rs = xs + n; double* zs = rs + n; double* ps = zs + n; double* qs = ps + n;
   double* Mi = qs + n;               // [Cp][36]
-  double* red = Mi + 36 * d.Cp;      // [16]
+  double* red = Mi + 36 * d.Cp;      // [16] + flag word
+  // optional LDS copy of the whole reduced matrix and its block-CSR structure (local-BA sizes fit)
+  double* Sl = red + 18;             // [(Cp+nOff)*36]
+  int* rowoff_l = reinterpret_cast<int*>(Sl + (stage_S ? 36 * (size_t)(d.Cp + d.nOff) : 0));
+  int* rowcol_l = rowoff_l + (d.Cp + 1);
+  uint32_t* rowblk_l = reinterpret_cast<uint32_t*>(rowcol_l + n_entries);
+  const double* Sm = d.S; const int* roff = d.row_off; const int* rcol = d.row_col; const uint32_t* rblk = d.row_blk;
+  if (stage_S) {
+    for (int i = threadIdx.x; i < 36 * (d.Cp + d.nOff); i += kSmallTPB) Sl[i] = d.S[i];
+    for (int i = threadIdx.x; i <= d.Cp; i += kSmallTPB) rowoff_l[i] = d.row_off[i];
+    for (int i = threadIdx.x; i < n_entries; i += kSmallTPB) { rowcol_l[i] = d.row_col[i]; rowblk_l[i] = d.row_blk[i]; }
+    Sm = Sl; roff = rowoff_l; rcol = rowcol_l; rblk = rowblk_l;
+  }
   // all LDS in the dynamic region (a static __shared__ in front of it would misalign the f64 arrays, guide G17)
   int& fail_s = *reinterpret_cast<int*>(red + 16);
   const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
@@ -552,10 +567,10 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
       const int g = lane >> 3, r = lane & 7;
       double acc = 0;
       if (r < 6) {
-        for (int s = d.row_off[i] + g; s < d.row_off[i + 1]; s += 8) {
-          const int j = d.row_col[s];
-          const uint32_t bt = d.row_blk[s];
-          const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+        for (int s = roff[i] + g; s < roff[i + 1]; s += 8) {
+          const int j = rcol[s];
+          const uint32_t bt = rblk[s];
+          const double* B = Sm + 36 * (size_t)(bt & ~kTransposeBit);
           if (bt & kTransposeBit) {
 #pragma unroll
             for (int c = 0; c < 6; c++) acc += B[c * 6 + r] * ps[6 * j + c];
@@ -1065,7 +1080,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
-      hipLaunchKernelGGL(ba_schur_off, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+      hipLaunchKernelGGL(ba_schur_off, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
     // ---- PCG ----
@@ -1074,12 +1089,15 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     int flags[4] = {0, 0, 0, 0};
     if (d.Cp <= kSmallMaxCp) {
       // one launch, no host round trip: the flags are read back after the trial kernels are queued
-      const size_t lds = (size_t)(5 * 6 * d.Cp + 36 * d.Cp + 18) * sizeof(double);
+      size_t lds = (size_t)(5 * 6 * d.Cp + 36 * d.Cp + 18) * sizeof(double);
+      const size_t lds_S = 36 * (size_t)(d.Cp + d.nOff) * sizeof(double) + ((size_t)d.Cp + 1 + 2 * (size_t)ba->n_row_entries) * sizeof(int) + 16;
+      const int stage_S = (lds + lds_S <= 150 * 1024) ? 1 : 0;
+      if (stage_S) lds += lds_S;
       static bool attr_set = false;
       if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-        hipLaunchKernelGGL(ba_pcg_small, dim3(1), dim3(kSmallTPB), lds, ctx->stream, d, lambda, tol, max_it);
+        hipLaunchKernelGGL(ba_pcg_small, dim3(1), dim3(kSmallTPB), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
       }
       small_path = true;
     } else {
