@@ -308,9 +308,31 @@ __global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
 // off-diagonal Schur blocks: one workgroup per block, lane = element (r,c), the block's pair instances are
 // strided over the 4 waves and summed through LDS in a fixed order            [CCM_K_BA_SCHUR_OFF]
 //   S_ij = - sum_inst W_a Dinv W_c^T
+// WPB = waves cooperating on one block: 4 when there are few blocks (local BA: latency bound, more parallel
+// instance streams), 1 for large maps (bandwidth bound; 4 blocks per workgroup)
+template <int WPB>
 __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
   __shared__ double part[kTPB / kWave][36];
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  if (WPB == 1) {
+    const int b1 = blockIdx.x * (kTPB / kWave) + wv;
+    if (b1 >= d.nOff || lane >= 36) return;
+    const int r1 = lane / 6, c1 = lane % 6;
+    double acc1 = 0;
+    for (int s = d.inst_off[b1]; s < d.inst_off[b1 + 1]; s++) {
+      const int ea = d.inst_a[s], ec = d.inst_c[s];
+      const double* Wa = d.W + 18 * (size_t)ea + 3 * r1;
+      const double* Wc = d.W + 18 * (size_t)ec + 3 * c1;
+      const double* Di = d.Dinv + 6 * (size_t)d.ed_pt[ea];
+      const double a0 = Wa[0], a1 = Wa[1], a2 = Wa[2];
+      const double y0 = a0 * Di[0] + a1 * Di[1] + a2 * Di[2];
+      const double y1 = a0 * Di[1] + a1 * Di[3] + a2 * Di[4];
+      const double y2 = a0 * Di[2] + a1 * Di[4] + a2 * Di[5];
+      acc1 += y0 * Wc[0] + y1 * Wc[1] + y2 * Wc[2];
+    }
+    d.S[36 * (size_t)(d.Cp + b1) + lane] = -acc1;
+    return;
+  }
   const int b = blockIdx.x;
   const int r = lane / 6, c = lane % 6;
   double acc = 0;
@@ -497,20 +519,22 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
 // A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
 // the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
-constexpr int kSmallTPB = 1024;
 constexpr int kSmallMaxCp = 256;
 
+template <int TPB>
 __device__ __forceinline__ double block_dot_small(double v, double* red /* [16] */) {
   v = wave_sum(v);
+  if (TPB == kWave) return v;   // single wave: the butterfly already left the full sum in every lane
   __syncthreads();
   if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
   __syncthreads();
   double s = 0;
 #pragma unroll
-  for (int i = 0; i < kSmallTPB / kWave; i++) s += red[i];
+  for (int i = 0; i < TPB / kWave; i++) s += red[i];
   return s;   // identical in every thread
 }
 
+template <int kSmallTPB>
 __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda, double rel_tol, int max_it, int stage_S, int n_entries) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = 6 * d.Cp;
@@ -557,7 +581,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
   __syncthreads();
   double part = 0;
   for (int i = t; i < n; i += kSmallTPB) part += rs[i] * zs[i];
-  double rz = block_dot_small(part, red);
+  double rz = block_dot_small<kSmallTPB>(part, red);
   const double rz0 = rz;
   int k = 0, fail = fail_s;
   for (; k < max_it; k++) {
@@ -586,7 +610,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
     __syncthreads();
     part = 0;
     for (int i = t; i < n; i += kSmallTPB) part += ps[i] * qs[i];
-    const double pq = block_dot_small(part, red);
+    const double pq = block_dot_small<kSmallTPB>(part, red);
     if (!(pq > 0.0)) { fail = 1; break; }
     const double alpha = rz / pq;
     for (int i = t; i < n; i += kSmallTPB) { xs[i] += alpha * ps[i]; rs[i] -= alpha * qs[i]; }
@@ -600,7 +624,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
       zs[i] = s;
       part += rs[i] * s;
     }
-    const double rz_new = block_dot_small(part, red);
+    const double rz_new = block_dot_small<kSmallTPB>(part, red);
     const double beta = rz_new / rz;
     for (int i = t; i < n; i += kSmallTPB) ps[i] = zs[i] + beta * ps[i];
     rz = rz_new;
@@ -1080,7 +1104,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
-      hipLaunchKernelGGL(ba_schur_off, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
+      if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
+      else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
     // ---- PCG ----
@@ -1094,10 +1119,18 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       const int stage_S = (lds + lds_S <= 150 * 1024) ? 1 : 0;
       if (stage_S) lds += lds_S;
       static bool attr_set = false;
-      if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+      if (!attr_set) {
+        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+      }
       {
+        // workgroup size by problem size: one wave (no barriers at all) up to 48 cameras, 4 waves up to 128, 16 beyond
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-        hipLaunchKernelGGL(ba_pcg_small, dim3(1), dim3(kSmallTPB), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
+        if (d.Cp <= 48) hipLaunchKernelGGL(ba_pcg_small<64>, dim3(1), dim3(64), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
+        else if (d.Cp <= 128) hipLaunchKernelGGL(ba_pcg_small<256>, dim3(1), dim3(256), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
+        else hipLaunchKernelGGL(ba_pcg_small<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
       }
       small_path = true;
     } else {
