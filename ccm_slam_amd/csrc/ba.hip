@@ -313,9 +313,9 @@ __global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
 template <int WPB>
 __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
   __shared__ double part[kTPB / kWave][36];
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   if (WPB == 1) {
-    const int b1 = blockIdx.x * (kTPB / kWave) + wv;
+    const int b1 = blockIdx.x * (kTPB / kWave) + wv;   // wave-uniform: instance lists arrive through scalar loads
     if (b1 >= d.nOff || lane >= 36) return;
     const int r1 = lane / 6, c1 = lane % 6;
     double acc1 = 0;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
   }
   // all LDS in the dynamic region (a static __shared__ in front of it would misalign the f64 arrays, guide G17)
   int& fail_s = *reinterpret_cast<int*>(red + 16);
-  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(t / kWave);
   if (t == 0) fail_s = 0;
   __syncthreads();
   if (t < d.Cp) {
@@ -1120,17 +1120,14 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (stage_S) lds += lds_S;
       static bool attr_set = false;
       if (!attr_set) {
-        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
       }
       {
-        // workgroup size by problem size: one wave (no barriers at all) up to 48 cameras, 4 waves up to 128, 16 beyond
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-        if (d.Cp <= 48) hipLaunchKernelGGL(ba_pcg_small<64>, dim3(1), dim3(64), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
-        else if (d.Cp <= 128) hipLaunchKernelGGL(ba_pcg_small<256>, dim3(1), dim3(256), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
-        else hipLaunchKernelGGL(ba_pcg_small<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
+        // measured on lba_c2 (30 free cameras, ~64 PCG iterations per solve): 16 waves 460 us, 1 wave 1420 us — the
+        // row products are LDS-latency chains, so more waves (rows in flight) win even with barriers
+        hipLaunchKernelGGL(ba_pcg_small<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
       }
       small_path = true;
     } else {
