@@ -433,6 +433,60 @@ int ORBmatcher::SearchForInitialization(const KeysView& F1, const FrameView& F2,
   return nmatches;
 }
 
+int ORBmatcher::ProjectedSearch(const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate,
+                                int distThreshold, int32_t* matched, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+  bestIdx.assign(P.n, -1); bestDist.assign(P.n, INT32_MAX);
+  FrameGrid grid(KF);
+  std::vector<int32_t> q_of, off(1, 0), idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  for (int i = 0; i < P.n; i++) {
+    if (!P.valid[i]) continue;
+    const int lvl = P.level[i];
+    const size_t before = idx.size();
+    std::vector<int32_t> win;
+    grid.featuresInArea(P.u[i], P.v[i], th * KF.mvScaleFactors[lvl], -1, -1, win);   // KeyFrame::GetFeaturesInArea: no level filter
+    for (int k : win) {
+      const int kpLevel = KF.mvKeysUn[k].octave;
+      if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+      if (chi2Gate) {
+        const float ex = P.u[i] - KF.mvKeysUn[k].x, ey = P.v[i] - KF.mvKeysUn[k].y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+      }
+      idx.push_back(k);
+    }
+    if (idx.size() == before) continue;
+    q_of.push_back(i); off.push_back((int32_t)idx.size());
+    qdesc.insert(qdesc.end(), P.desc + (size_t)i * 32, P.desc + (size_t)i * 32 + 32);
+  }
+  distances(qdesc, (int)q_of.size(), KF.mDescriptors, KF.N, off, idx, dist);
+  int nacc = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    const int i = q_of[q];
+    int bd = INT32_MAX, bi = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int k = idx[s];
+      if (matched && matched[k] >= 0) continue;     // claims made earlier in this loop are honoured
+      if (dist[s] < bd) { bd = dist[s]; bi = k; }
+    }
+    if (bd <= distThreshold) {
+      bestIdx[i] = bi; bestDist[i] = bd;
+      if (matched && claim && !(P.noClaim && P.noClaim[i])) matched[bi] = i;
+      nacc++;
+    }
+  }
+  return nacc;
+}
+
+int ORBmatcher::MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12) {
+  int nFound = 0;
+  matches12.assign(vnMatch1.size(), -1);
+  for (size_t i1 = 0; i1 < vnMatch1.size(); i1++) {
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == (int)i1) { matches12[i1] = idx2; nFound++; }
+  }
+  return nFound;
+}
+
 // ---- Optimizer ---------------------------------------------------------------------------------------
 int Optimizer::PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, const double* Xw, const double* obs,
                                       const double* invSigma2, const double K[4], std::vector<uint8_t>& outlier) {
@@ -601,4 +655,25 @@ int ccmh_search_for_initialization(int device, const float* x1, const float* y1,
     return n;
   } catch (const std::exception&) { return -1000; }
 }
+}
+
+extern "C" int ccmh_projected_window_search(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float minX,
+                                            float minY, float maxX, float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts,
+                                            const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, float th,
+                                            int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim,
+                                            int32_t* best_idx, int32_t* best_dist) {
+  try {
+    cslam::HipContext ctx(device);
+    auto kps = mk_keys(kx, ky, oct, nullptr, N);
+    std::vector<int32_t> dummy(N, -1);
+    cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = kdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
+    F.mvScaleFactors = scale_factors; F.mvpMapPoints = dummy.data();
+    cslam::ORBmatcher::ProjectedPoints P; P.n = n_pts; P.valid = valid; P.u = u; P.v = v; P.level = level; P.desc = pdesc; P.noClaim = no_claim;
+    cslam::ORBmatcher m(ctx);
+    std::vector<int32_t> bi, bd;
+    const int n = m.ProjectedSearch(F, inv_sigma2, P, th, chi2_gate != 0, dist_threshold, matched, claim != 0, bi, bd);
+    std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
+    std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
 }

@@ -120,6 +120,16 @@ class ORBmatcher {
   // SearchForInitialization — ORBmatcher.cpp:448-563.  F2 needs the grid bounds; prevMatched (x,y pairs) is updated in place
   int SearchForInitialization(const KeysView& F1, const FrameView& F2, std::vector<float>& vbPrevMatched, std::vector<int32_t>& vnMatches12,
                               int windowSize = 10);
+  // The projected window search shared by Fuse (:854-993, chi2 gate), Fuse with Sim3 (:995-1122), SearchByProjection(kfptr,
+  // Scw, ...) (:308-446, skips and claims vpMatched) and both directions of SearchBySim3 (:1124-1348, TH_HIGH).  The caller
+  // supplies the outcome of the f32 projection / depth / viewing-angle tests (valid, u, v, predicted level) and applies the
+  // map mutations (Replace / AddObservation / RemapMapPointMatch) in order from bestIdx, as the reference does after its loop.
+  struct ProjectedPoints { int n = 0; const uint8_t* valid = nullptr; const float* u = nullptr; const float* v = nullptr;
+                           const int32_t* level = nullptr; const uint8_t* desc = nullptr; const uint8_t* noClaim = nullptr; };
+  int ProjectedSearch(const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate, int distThreshold,
+                      int32_t* matched /* nullable in/out [KF.N] */, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
+  // SearchBySim3's agreement step (:1318-1345) on the two directional results
+  static int MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12);
  private:
   // distances of every (query, candidate) slot in one device launch
   void distances(const std::vector<uint8_t>& qdesc, int Q, const uint8_t* tdesc, int T, const std::vector<int32_t>& off,

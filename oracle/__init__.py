@@ -366,3 +366,20 @@ def search_for_initialization(k1, d1, k2, d2, bounds, prev_xy, window, nnratio, 
                                             _p(f32(k2["angle"]), C.c_float), _p(np.ascontiguousarray(d2, np.uint8), C.c_uint8), len(k2),
                                             *[C.c_float(b) for b in bounds], _p(prev, C.c_float), int(window), C.c_float(nnratio), int(check_ori), _p(out, C.c_int32))
     return int(n), out, prev
+
+
+def projected_window_search(kx, ky, octave, kdesc, bounds, scale_factors, inv_sigma2, valid, u, v, level, pdesc, th, chi2_gate,
+                            dist_threshold, matched=None, claim=False, no_claim=None):
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    n_pts = len(u)
+    bi = np.zeros(n_pts, np.int32); bd = np.zeros(n_pts, np.int32)
+    m = None if matched is None else np.ascontiguousarray(matched, np.int32).copy()
+    nc = None if no_claim is None else np.ascontiguousarray(no_claim, np.uint8)
+    n = lib().ora_projected_window_search(
+        _p(f32(kx), C.c_float), _p(f32(ky), C.c_float), _p(np.ascontiguousarray(octave, np.int32), C.c_int32),
+        _p(np.ascontiguousarray(kdesc, np.uint8), C.c_uint8), len(kx), *[C.c_float(b) for b in bounds], _p(f32(scale_factors), C.c_float),
+        _p(f32(inv_sigma2), C.c_float), n_pts, _p(np.ascontiguousarray(valid, np.uint8), C.c_uint8), _p(f32(u), C.c_float), _p(f32(v), C.c_float),
+        _p(np.ascontiguousarray(level, np.int32), C.c_int32), _p(np.ascontiguousarray(pdesc, np.uint8), C.c_uint8), C.c_float(th), int(chi2_gate),
+        int(dist_threshold), _p(m, C.c_int32) if m is not None else None, int(claim), _p(nc, C.c_uint8) if nc is not None else None,
+        _p(bi, C.c_int32), _p(bd, C.c_int32))
+    return int(n), bi, bd, m

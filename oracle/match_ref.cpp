@@ -468,3 +468,57 @@ int ora_search_for_initialization(const float* x1, const float* y1, const int32_
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Projected window searches on a KeyFrame: the common inner loop of
+//   Fuse(kfptr, vector<mpptr>, th)                      ORBmatcher.cpp:854-993   (chi2 gate :942-951, TH_LOW)
+//   Fuse(kfptr, Scw, points, th, replace)               ORBmatcher.cpp:995-1122  (no gate, TH_LOW)
+//   SearchByProjection(kfptr, Scw, points, matched, th) ORBmatcher.cpp:308-446   (skips vpMatched, claims, TH_LOW)
+//   SearchBySim3 (both directions)                       ORBmatcher.cpp:1124-1348 (no gate, TH_HIGH, mutual check)
+// The f32 projection / depth / viewing-angle tests that precede the loop (cv::Mat arithmetic on the KeyFrame
+// pose) stay with the caller: valid[i], u[i], v[i], level[i] are their outcome.
+// KeyFrame::GetFeaturesInArea(x,y,r) (KeyFrame.cpp:1162-1201) has no level filter; the loops filter
+// kpLevel in [nPredictedLevel-1, nPredictedLevel] themselves.
+//   chi2_gate:   skip candidates with e2 * invSigma2[kpLevel] > 5.99  (Fuse only)
+//   matched:     nullable in/out [N]; >= 0 entries are skipped; when `claim` is set, an accepted point i with
+//                no_claim[i] == 0 writes matched[bestIdx] = i (SearchByProjection's vpMatched)
+//   best_idx[i] = accepted feature or -1, best_dist[i] = its distance (INT32_MAX if no candidate)
+// Returns the number of accepted points.
+extern "C" int ora_projected_window_search(const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float minX,
+                                           float minY, float maxX, float maxY, const float* scale_factors, const float* inv_sigma2,
+                                           int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                           const uint8_t* pdesc, float th, int chi2_gate, int dist_threshold, int32_t* matched, int claim,
+                                           const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist) {
+  Grid* g = new Grid();
+  build_grid(*g, kx, ky, oct, N, minX, minY, maxX, maxY);
+  int n_acc = 0;
+  std::vector<int> vIndices;
+  for (int i = 0; i < n_pts; i++) {
+    best_idx[i] = -1; best_dist[i] = INT32_MAX;
+    if (!valid[i]) continue;
+    const int nPredictedLevel = level[i];
+    const float radius = th * scale_factors[nPredictedLevel];
+    features_in_area(*g, u[i], v[i], radius, -1, -1, vIndices);
+    if (vIndices.empty()) continue;
+    int bestDist = INT32_MAX, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (matched && matched[idx] >= 0) continue;
+      const int kpLevel = oct[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (chi2_gate) {
+        const float ex = u[i] - kx[idx], ey = v[i] - ky[idx];
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+      }
+      const int dist = ora_descriptor_distance(pdesc + (size_t)i * 32, kdesc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= dist_threshold) {
+      best_idx[i] = bestIdx; best_dist[i] = bestDist;
+      if (matched && claim && !(no_claim && no_claim[i])) matched[bestIdx] = i;
+      n_acc++;
+    }
+  }
+  delete g;
+  return n_acc;
+}

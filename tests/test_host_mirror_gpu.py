@@ -186,3 +186,39 @@ def test_search_for_initialization(hostlib, oracle_lib):
                                                *[C.c_float(b) for b in bounds], _p(gprev), 100, C.c_float(0.9), 1, _p(got))
     assert n == exp_n and n > 100
     assert np.array_equal(got, exp) and np.array_equal(gprev, exp_prev)
+
+
+# ---- projected window searches: Fuse, Fuse(Sim3), SearchByProjection(kfptr,Scw,..), SearchBySim3 (M7-M10) ----
+@pytest.mark.parametrize("name,chi2_gate,thr,use_matched,claim", [("fuse", 1, 50, 0, 0), ("fuse_sim3", 0, 50, 0, 0),
+                                                                 ("search_by_projection_sim3", 0, 50, 1, 1), ("search_by_sim3", 0, 100, 0, 0)])
+def test_projected_window_search(hostlib, oracle_lib, name, chi2_gate, thr, use_matched, claim):
+    kps, desc = _frame(oracle_lib, 1001, 0)
+    N = len(kps)
+    rng = np.random.default_rng(7)
+    sf, _, _, is2 = synth.scale_tables()
+    n_pts = 2500
+    src = rng.integers(0, N, n_pts)
+    u = (kps["x"][src] + rng.normal(0, 1.5, n_pts)).astype(np.float32)
+    v = (kps["y"][src] + rng.normal(0, 1.5, n_pts)).astype(np.float32)
+    level = np.clip(kps["octave"][src] + rng.integers(0, 2, n_pts), 0, 7).astype(np.int32)
+    valid = (rng.random(n_pts) < 0.85).astype(np.uint8)
+    pdesc = desc[src].copy()
+    bits = np.unpackbits(pdesc, axis=1)
+    pdesc = np.packbits(bits ^ (rng.random(bits.shape) < 0.06), axis=1)
+    matched0 = -np.ones(N, np.int32)
+    matched0[rng.integers(0, N, 80)] = 99_999
+    no_claim = (rng.random(n_pts) < 0.1).astype(np.uint8)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    th = 3.0 if name.startswith("fuse") else 7.5
+    exp_n, ebi, ebd, em = oracle_lib.projected_window_search(kps["x"], kps["y"], kps["octave"], desc, bounds, sf, is2, valid, u, v, level, pdesc, th,
+                                                             chi2_gate, thr, matched0 if use_matched else None, claim, no_claim)
+    c = np.ascontiguousarray
+    gbi = np.zeros(n_pts, np.int32); gbd = np.zeros(n_pts, np.int32)
+    gm = matched0.copy()
+    n = hostlib.ccmh_projected_window_search(0, _p(c(kps["x"])), _p(c(kps["y"])), _p(c(kps["octave"])), _p(desc), N, *[C.c_float(b) for b in bounds],
+                                             _p(sf), _p(is2), n_pts, _p(valid), _p(u), _p(v), _p(level), _p(pdesc), C.c_float(th), chi2_gate, thr,
+                                             _p(gm) if use_matched else None, claim, _p(no_claim), _p(gbi), _p(gbd))
+    assert n == exp_n and n > 300
+    assert np.array_equal(gbi, ebi) and np.array_equal(gbd, ebd)
+    if use_matched:
+        assert np.array_equal(gm, em)
