@@ -241,6 +241,8 @@ def main():
             out["speedup_vs_cpu_port"] = round((done / elapsed) / cpu["value"], 1)
         print(json.dumps(out))
     h.close()
+    if dist is not None:
+        dist.barrier()   # rank 0 is still busy with the tracking leg / JSON while the others arrive here
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
