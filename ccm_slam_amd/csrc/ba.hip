@@ -567,9 +567,17 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   if (t < 2 * m) {
     const int row = t % m, half = t / m;
     const int c0 = half ? m / 2 : 0, c1 = half ? m : m / 2;
-    double s = 0;
-    for (int col = c0; col < c1; col++) s += W[col * kCluN + row] * rc[col];
-    zpart[half][row] = s;
+    // 8 independent loads in flight per thread: the mat-vec is latency bound otherwise (W comes from L2 / MALL)
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int col = c0;
+    for (; col + 8 <= c1; col += 8) {
+      const double w0 = W[(col + 0) * kCluN + row], w1 = W[(col + 1) * kCluN + row], w2 = W[(col + 2) * kCluN + row], w3 = W[(col + 3) * kCluN + row];
+      const double w4 = W[(col + 4) * kCluN + row], w5 = W[(col + 5) * kCluN + row], w6 = W[(col + 6) * kCluN + row], w7 = W[(col + 7) * kCluN + row];
+      s0 += w0 * rc[col] + w4 * rc[col + 4]; s1 += w1 * rc[col + 1] + w5 * rc[col + 5];
+      s2 += w2 * rc[col + 2] + w6 * rc[col + 6]; s3 += w3 * rc[col + 3] + w7 * rc[col + 7];
+    }
+    for (; col < c1; col++) s0 += W[col * kCluN + row] * rc[col];
+    zpart[half][row] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   double rz = 0;
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
 // A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
 // the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
-constexpr int kSmallMaxCp = 256;
+constexpr int kSmallMaxCp = 64;   // measured: 7 us/iteration at 30 cameras, ~30 us at 119 (multi-kernel path: ~28 us)
 
 template <int TPB>
 __device__ __forceinline__ double block_dot_small(double v, double* red /* [16] */) {
