@@ -196,8 +196,18 @@ def main():
     }[dominant]
     avg_ms = kernel_ms / launches if launches else float("nan")
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    # HBM traffic per launch from the committed PMC passes of the same workload (profiles/pmc_latest.json, produced by
+    # scripts/profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied); PMC
+    # counters cannot be collected from inside this process, so this is the last profiled value, not a live one.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if args.workload == "gba_c4" and world == 1:
+            traffic = pmc["kernels"].get(dominant.lower(), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     roofline = {"kernel": dominant.lower(), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "launches": launches, "avg_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes}
 
     # ---- CPU baseline: the oracle (g2o restatement, 1 thread) on a bounded sample of the same workload
