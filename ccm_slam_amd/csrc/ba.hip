@@ -118,7 +118,7 @@ struct BaDev {
   double *ppq, *prz[2];      // partials
   double* pcg_scal;          // [0]=rz0 [1]=thresh^2  [2]=lambda
   int* pcg_flag;             // [0]=done [1]=iters [2]=fail
-  int n_wg_spmv, n_wg_upd;
+  int n_wg_spmv, n_wg_upd, n_wg_wave4;   // wave4: one wave per camera, 4 per workgroup
   // trial outputs
   double* edge_chi2;         // [Eloc]
   uint8_t* edge_depth;       // [Eloc]
@@ -459,12 +459,18 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, doub
 }
 
 // iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
+// Workgroup = 4 waves = 2 block rows, TWO waves per row: the row product is a chain of dependent loads
+// (index -> block -> vector), so splitting a row's blocks over two waves halves that chain; each wave keeps 8
+// blocks in flight (lane = g*8 + r: group g takes every 16th block starting at its own offset, r is the block row).
+constexpr int kRowsPerWG = 2;
 __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
-  __shared__ double lds[kTPB / kWave];
+  __shared__ double half_sum[kRowsPerWG][2][8];
+  __shared__ double lds[kRowsPerWG];
   if (d.pcg_flag[0]) return;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x / kWave;
-  const int i = blockIdx.x * (kTPB / kWave) + wv;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int rl = wv >> 1, h = wv & 1;            // local row, half
+  const int i = blockIdx.x * kRowsPerWG + rl;
   const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
   double beta = 0;
   if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
@@ -481,54 +487,48 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
   const double lambda = d.pcg_scal[2];
   const double* pold = d.p[k & 1];
   double* pnew = d.p[(k + 1) & 1];
-  double pq = 0;
-  if (i < d.Cp) {
-    // lane = g*8 + r: group g (0..7) takes every 8th block of the row, r (0..5) is the block row; each lane does
-    // one 1x6 . 6x1 product per block (48 contiguous bytes of the block), so 8 blocks are in flight per wave step
-    // and the dependent index -> block -> vector load chain is paid row_len/8 times instead of row_len times.
-    const int g = lane >> 3, r = lane & 7;
-    double acc = 0;
-    if (r < 6) {
-      const int s0 = d.row_off[i], s1 = d.row_off[i + 1];
-      for (int s = s0 + g; s < s1; s += 8) {
-        const int j = d.row_col[s];
-        const uint32_t bt = d.row_blk[s];
-        const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
-        const double* zj = d.z + 6 * (size_t)j;
-        const double* pj = pold + 6 * (size_t)j;
-        double v[6];
-        if (bt & kTransposeBit) {
+  double acc = 0;
+  const int g = lane >> 3, r = lane & 7;
+  if (i < d.Cp && r < 6) {
+    const int e0 = d.row_off[i], e1 = d.row_off[i + 1];
+    for (int s = e0 + h * 8 + g; s < e1; s += 16) {
+      const int j = d.row_col[s];
+      const uint32_t bt = d.row_blk[s];
+      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+      const double* zj = d.z + 6 * (size_t)j;
+      const double* pj = pold + 6 * (size_t)j;
+      double v[6];
+      if (bt & kTransposeBit) {
 #pragma unroll
-          for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
-        } else {
+        for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
+      } else {
 #pragma unroll
-          for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
+        for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
       }
+#pragma unroll
+      for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
     }
-    // sum over the 8 groups (lanes with equal r): fixed xor tree
-    acc += __shfl_xor(acc, 8, kWave);
-    acc += __shfl_xor(acc, 16, kWave);
-    acc += __shfl_xor(acc, 32, kWave);
+  }
+  // sum over the 8 groups (lanes with equal r): fixed xor tree
+  acc += __shfl_xor(acc, 8, kWave);
+  acc += __shfl_xor(acc, 16, kWave);
+  acc += __shfl_xor(acc, 32, kWave);
+  if (lane < 8) half_sum[rl][h][lane] = acc;
+  __syncthreads();
+  double pq = 0;
+  if (h == 0 && i < d.Cp) {
     if (lane < 6) {
       const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
-      const double qv = acc + lambda * pi;
+      const double qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * pi;
       d.q[6 * (size_t)i + lane] = qv;
       pnew[6 * (size_t)i + lane] = pi;
       pq = pi * qv;
     }
     pq = wave_sum(lane < 6 ? pq : 0.0);
-  }
+    if (lane == 0) lds[rl] = pq;
+  } else if (h == 0 && lane == 0) lds[rl] = 0.0;
   __syncthreads();
-  if (lane == 0) lds[wv] = (i < d.Cp) ? pq : 0.0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (int w = 0; w < kTPB / kWave; w++) s += lds[w];
-    d.ppq[blockIdx.x] = s;
-  }
+  if (threadIdx.x == 0) d.ppq[blockIdx.x] = lds[0] + lds[1];
 }
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
@@ -1041,7 +1041,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
   AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double)
   AL(Wc, (size_t)ccm_div_up(std::max(Cp, 1), kClu) * kCluN * kCluN, double)
-  d.n_wg_spmv = ccm_div_up(std::max(Cp, 1), kTPB / kWave); d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
+  d.n_wg_spmv = ccm_div_up(std::max(Cp, 1), kRowsPerWG); d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave); d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
   d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
   AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
   AL(pcg_scal, 4, double) AL(pcg_flag, 4, int)
@@ -1138,7 +1138,7 @@ int build_system(ccm_ba* ba) {
   }
   if (d.Cp) {
     ccm_prof_scope ps(ctx, CCM_K_BA_CAM);
-    hipLaunchKernelGGL(ba_linearize_cams, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+    hipLaunchKernelGGL(ba_linearize_cams, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d, ba->cur);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1180,7 +1180,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   if (d.Cp) {
     {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
-      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d);
+      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
