@@ -938,38 +938,55 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   const int Eloc = ba->Eloc = ee - eb;
 
   // ---- global off-diagonal block structure + own pair instances ----
-  struct Inst { uint64_t key; int ea, ec; };
-  std::vector<uint64_t> all_keys;
-  std::vector<Inst> own;
+  // every (ia < ic) camera pair of every landmark, in landmark order; two stable counting-sort passes (by ic,
+  // then by ia) order them by block while keeping the landmark order inside a block — O(n + Cp), no comparison sort
+  struct Inst { int ia, ic, ea, ec; };
+  std::vector<Inst> inst;
+  {
+    size_t total = 0;
+    for (int l = 0; l < Lp; l++) { const size_t k = (size_t)(g_pt_off[l + 1] - g_pt_off[l]); total += k * (k - 1) / 2; }
+    inst.reserve(total);
+  }
   for (int l = 0; l < Lp; l++) {
     const int k0 = g_pt_off[l], k1 = g_pt_off[l + 1];
-    const bool mine = l >= lb && l < le;
     for (int a = k0; a < k1; a++) {
       const int ia = ba->cam_slot[P->e_cam[order[a]]];
       if (ia < 0) continue;
       for (int c = a + 1; c < k1; c++) {
         const int ic = ba->cam_slot[P->e_cam[order[c]]];
         if (ic == ia) continue;   // two observations of one landmark in one camera: contributes to the diagonal only
-        const uint64_t key = ((uint64_t)(uint32_t)ia << 32) | (uint32_t)ic;   // ia < ic by the sort
-        all_keys.push_back(key);
-        if (mine) own.push_back(Inst{key, a - eb, c - eb});
+        inst.push_back(Inst{ia, ic, a, c});   // ia < ic by the sort; a, c are GLOBAL positions in the landmark-sorted edge list
       }
     }
   }
-  std::sort(all_keys.begin(), all_keys.end());
-  all_keys.erase(std::unique(all_keys.begin(), all_keys.end()), all_keys.end());
-  const int nOff = ba->nOff = (int)all_keys.size();
-  std::stable_sort(own.begin(), own.end(), [](const Inst& x, const Inst& y) { return x.key < y.key; });
-  ba->n_inst = (int64_t)own.size();
-  std::vector<int> inst_off(nOff + 1, 0), inst_a(own.size()), inst_c(own.size());
+  {
+    std::vector<Inst> tmp(inst.size());
+    std::vector<int> cnt(Cp + 1);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (const Inst& x : inst) cnt[x.ic + 1]++;
+    for (int i = 0; i < Cp; i++) cnt[i + 1] += cnt[i];
+    for (const Inst& x : inst) tmp[cnt[x.ic]++] = x;
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (const Inst& x : tmp) cnt[x.ia + 1]++;
+    for (int i = 0; i < Cp; i++) cnt[i + 1] += cnt[i];
+    for (const Inst& x : tmp) inst[cnt[x.ia]++] = x;
+  }
+  std::vector<uint64_t> all_keys;
+  std::vector<int> inst_off, inst_a, inst_c;
+  inst_off.push_back(0);
   {
     size_t s = 0;
-    for (int b = 0; b < nOff; b++) {
-      inst_off[b] = (int)s;
-      while (s < own.size() && own[s].key == all_keys[b]) { inst_a[s] = own[s].ea; inst_c[s] = own[s].ec; s++; }
+    while (s < inst.size()) {
+      const int ia = inst[s].ia, ic = inst[s].ic;
+      all_keys.push_back(((uint64_t)(uint32_t)ia << 32) | (uint32_t)ic);
+      for (; s < inst.size() && inst[s].ia == ia && inst[s].ic == ic; s++)
+        if (inst[s].ea >= eb && inst[s].ea < ee) { inst_a.push_back(inst[s].ea - eb); inst_c.push_back(inst[s].ec - eb); }   // own landmark
+      inst_off.push_back((int)inst_a.size());
     }
-    inst_off[nOff] = (int)s;
   }
+  const int nOff = ba->nOff = (int)all_keys.size();
+  ba->n_inst = (int64_t)inst_a.size();
+  { std::vector<Inst>().swap(inst); }
   // ---- block CSR rows (full symmetric pattern) ----
   std::vector<int> row_cnt(Cp + 1, 0);
   for (int i = 0; i < Cp; i++) row_cnt[i + 1] = 1;
