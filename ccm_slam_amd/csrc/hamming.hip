@@ -132,6 +132,53 @@ __global__ __launch_bounds__(256) void hamming_csr_kernel(
   }
 }
 
+
+// ---- MapPoint::ComputeDistinctiveDescriptors (cslam/src/MapPoint.cpp:929-994), batched ----------------------
+// one wave per map point: lane i owns observation i (rows i, i+64, ... when a point has more than 64), computes
+// its N distances into a lane-private LDS row, selects the median (element of rank (int)(0.5*(N-1)) of the sorted
+// row, self-distance 0 included) by rank counting, then the wave picks the FIRST observation with the least median.
+constexpr int kDistinctMaxN = 256;
+__global__ __launch_bounds__(64) void distinctive_kernel(const uint32_t* __restrict__ desc, const int32_t* __restrict__ off, int P,
+                                                         int32_t* __restrict__ best_out) {
+  extern __shared__ uint16_t rows[];   // [64][kDistinctMaxN]
+  const int lane = threadIdx.x;
+  const int p = blockIdx.x;
+  if (p >= P) return;
+  const int o0 = off[p], N = off[p + 1] - o0;
+  if (N <= 0) { if (lane == 0) best_out[p] = -1; return; }
+  const int kth = (int)(0.5 * (N - 1));
+  uint32_t bestKey = 0xFFFFFFFFu;   // (median << 16) | index : min = least median, then first index
+  uint16_t* my = rows + lane * kDistinctMaxN;
+  for (int base = 0; base < N; base += 64) {
+    const int i = base + lane;
+    uint32_t key = 0xFFFFFFFFu;
+    if (i < N) {
+      uint32_t a[8];
+      const uint4* ap = reinterpret_cast<const uint4*>(desc + (size_t)(o0 + i) * 8);
+      const uint4 lo = ap[0], hi = ap[1];
+      a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w; a[4] = hi.x; a[5] = hi.y; a[6] = hi.z; a[7] = hi.w;
+      for (int j = 0; j < N; j++) {   // j is wave-uniform: the j-th descriptor arrives through scalar loads
+        const uint32_t* bp = desc + (size_t)(o0 + j) * 8;
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __builtin_popcount(a[k] ^ bp[k]);
+        my[j] = (uint16_t)d;
+      }
+      int median = 0;
+      for (int j = 0; j < N; j++) {
+        const int dj = my[j];
+        int rank = 0;
+        for (int l = 0; l < N; l++) { const int dl = my[l]; rank += (dl < dj) || (dl == dj && l < j); }
+        if (rank == kth) { median = dj; break; }
+      }
+      key = ((uint32_t)median << 16) | (uint32_t)i;
+    }
+    key = wave_min_u32(key);
+    bestKey = min(bestKey, key);
+  }
+  if (lane == 0) best_out[p] = (int)(bestKey & 0xFFFFu);
+}
+
 }  // namespace
 
 extern "C" int ccm_hamming_dense_best2_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
@@ -245,4 +292,27 @@ extern "C" int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint
     if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_csr: ") + hipGetErrorString(e));
   }
   return rc;
+}
+
+extern "C" int ccm_distinctive_descriptors(ccm_ctx* ctx, const uint8_t* desc, const int32_t* off, int P, int32_t* best_local_idx) {
+  if (!ctx || P < 0 || (P && (!off || !best_local_idx))) return ccm_set_error(ctx, CCM_E_ARG, "distinctive: bad args");
+  if (P == 0) return CCM_OK;
+  const int64_t total = off[P];
+  if (total < 0 || (total && !desc)) return ccm_set_error(ctx, CCM_E_ARG, "distinctive: bad offsets");
+  for (int p = 0; p < P; p++) {
+    const int n = off[p + 1] - off[p];
+    if (n < 0 || n > kDistinctMaxN) return ccm_set_error(ctx, CCM_E_ARG, "distinctive: a map point has more than 256 observations (or a negative count)");
+  }
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bd = ccm_align256((size_t)std::max<int64_t>(total, 1) * 32), bo = ccm_align256((size_t)(P + 1) * 4);
+  void* io = nullptr;
+  { int rc0 = ccm_io_scratch(ctx, bd + bo + (size_t)P * 4, &io); if (rc0) return rc0; }
+  uint8_t* d_desc = (uint8_t*)io; int32_t* d_off = (int32_t*)(d_desc + bd); int32_t* d_best = (int32_t*)((uint8_t*)d_off + bo);
+  if (total) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc, desc, (size_t)total * 32, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_off, off, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(distinctive_kernel, dim3(P), dim3(64), 64 * kDistinctMaxN * sizeof(uint16_t), ctx->stream, (const uint32_t*)d_desc, d_off, P, d_best);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(best_local_idx, d_best, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
 }

@@ -69,3 +69,13 @@ class DenseMatcherDev:
     def close(self):
         for p in (self.d_q, self.d_t, self.d_out):
             self.ctx.free(p)
+
+
+def distinctive_descriptors(ctx: Context, desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors batched (MapPoint.cpp:929-994): per point the local index of the
+    descriptor with the least median distance to the others."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(off, np.int32)
+    out = np.zeros(off.size - 1, np.int32)
+    check(lib().ccm_distinctive_descriptors(ctx.handle, _p(desc), _p(off), off.size - 1, _p(out)), ctx.handle)
+    return out

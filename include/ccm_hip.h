@@ -94,6 +94,13 @@ int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* 
                         uint16_t* d_cand_dist,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (cslam/src/MapPoint.cpp:929-994), batched over P map points:
+ * point p owns the descriptor rows off[p] .. off[p+1] (one per non-bad observing keyframe, in observation-map order);
+ * best_local_idx[p] = index (within its own list) of the descriptor with the least median Hamming distance to the
+ * others — median = element (int)(0.5*(N-1)) of the sorted row including the zero self distance, first minimum wins;
+ * -1 for an empty list.  At most 256 observations per point.                                                        */
+int ccm_distinctive_descriptors(ccm_ctx* ctx, const uint8_t* desc, const int32_t* off, int P, int32_t* best_local_idx);
+
 /* ---- ORB extraction -------------------------------------------------------------------
  * Replaces ORBextractor::ORBextractor / operator() (cslam/src/ORBextractor.cpp:579-639,
  * 1216-1278).  ccm_keypoint == cv::KeyPoint without class_id.                            */

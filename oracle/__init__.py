@@ -383,3 +383,10 @@ def projected_window_search(kx, ky, octave, kdesc, bounds, scale_factors, inv_si
         int(dist_threshold), _p(m, C.c_int32) if m is not None else None, int(claim), _p(nc, C.c_uint8) if nc is not None else None,
         _p(bi, C.c_int32), _p(bd, C.c_int32))
     return int(n), bi, bd, m
+
+
+def distinctive_descriptors(desc, off):
+    desc = np.ascontiguousarray(desc, np.uint8); off = np.ascontiguousarray(off, np.int32)
+    out = np.zeros(off.size - 1, np.int32)
+    lib().ora_distinctive_descriptors(_p(desc, C.c_uint8), _p(off, C.c_int32), off.size - 1, _p(out, C.c_int32))
+    return out

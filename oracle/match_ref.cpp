@@ -522,3 +522,28 @@ extern "C" int ora_projected_window_search(const float* kx, const float* ky, con
   delete g;
   return n_acc;
 }
+
+// MapPoint::ComputeDistinctiveDescriptors — cslam/src/MapPoint.cpp:929-994, batched flat restatement
+extern "C" void ora_distinctive_descriptors(const uint8_t* desc, const int32_t* off, int P, int32_t* best_local_idx) {
+  for (int p = 0; p < P; p++) {
+    const int N = off[p + 1] - off[p];
+    if (N <= 0) { best_local_idx[p] = -1; continue; }
+    const uint8_t* D = desc + (size_t)off[p] * 32;
+    std::vector<std::vector<float>> Distances(N, std::vector<float>(N, 0.f));
+    for (int i = 0; i < N; i++) {
+      Distances[i][i] = 0;
+      for (int j = i + 1; j < N; j++) {
+        const int distij = ora_descriptor_distance(D + (size_t)i * 32, D + (size_t)j * 32);
+        Distances[i][j] = (float)distij; Distances[j][i] = (float)distij;
+      }
+    }
+    int BestMedian = INT32_MAX, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+      std::sort(vDists.begin(), vDists.end());
+      const int median = vDists[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+    }
+    best_local_idx[p] = BestIdx;
+  }
+}

@@ -59,3 +59,18 @@ def test_full_size_property_self_match(ctx):
     d = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
     bi, bd, sd = matcher.hamming_dense_best2(ctx, d, d)
     assert np.array_equal(bi, np.arange(2000)) and (bd == 0).all() and (sd > 0).all()
+
+
+def test_distinctive_descriptors_matches_oracle(ctx, oracle_lib):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cpp:929-994) batched: median-of-distances medoid, first minimum."""
+    rng = np.random.default_rng(12)
+    counts = np.concatenate([[0, 1, 2, 3, 64, 65, 200, 256], rng.integers(1, 40, 3000)])
+    off = np.zeros(counts.size + 1, np.int32); off[1:] = np.cumsum(counts)
+    base = rng.integers(0, 256, (counts.size, 32), dtype=np.uint8)
+    desc = np.repeat(base, counts, axis=0)
+    bits = np.unpackbits(desc, axis=1)
+    desc = np.packbits(bits ^ (rng.random(bits.shape) < 0.1), axis=1)
+    desc[off[6]:off[6] + 5] = desc[off[6]]      # exact duplicates -> ties, first index must win
+    got = matcher.distinctive_descriptors(ctx, desc, off)
+    exp = oracle_lib.distinctive_descriptors(desc, off)
+    assert np.array_equal(got, exp) and got[0] == -1 and got[1] == 0
