@@ -179,6 +179,46 @@ __global__ __launch_bounds__(64) void distinctive_kernel(const uint32_t* __restr
   if (lane == 0) best_out[p] = (int)(bestKey & 0xFFFFu);
 }
 
+
+// ---- DBoW2 vocabulary tree descent (TemplatedVocabulary::transform, DBoW2/TemplatedVocabulary.h:1218-1260) -----
+// one wave per feature: at every level the lanes take one child each (k <= 64), the wave picks the child with the
+// least FORB::distance, FIRST minimum winning (strict '<' in child order); records the node at level nid_level.
+__global__ __launch_bounds__(256) void bow_descend_kernel(const uint32_t* __restrict__ desc, int N, const int32_t* __restrict__ child_off,
+                                                          const int32_t* __restrict__ child_id, const uint32_t* __restrict__ node_desc,
+                                                          int nid_level, int32_t* __restrict__ leaf_out, int32_t* __restrict__ nid_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  if (f >= N) return;
+  uint32_t a[8];
+  {
+    const uint32_t* ap = desc + (size_t)f * 8;   // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = ap[k];
+  }
+  int node = 0, level = 0, nid = 0;
+  while (true) {
+    const int c0 = child_off[node], c1 = child_off[node + 1];
+    if (c1 <= c0) break;   // leaf
+    ++level;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int base = c0; base < c1; base += kWave) {
+      uint32_t key = 0xFFFFFFFFu;
+      if (base + lane < c1) {
+        const int id = child_id[base + lane];
+        const uint4* bp = reinterpret_cast<const uint4*>(node_desc + (size_t)id * 8);
+        const uint4 lo = bp[0], hi = bp[1];
+        const int d = __builtin_popcount(a[0] ^ lo.x) + __builtin_popcount(a[1] ^ lo.y) + __builtin_popcount(a[2] ^ lo.z) + __builtin_popcount(a[3] ^ lo.w) +
+                      __builtin_popcount(a[4] ^ hi.x) + __builtin_popcount(a[5] ^ hi.y) + __builtin_popcount(a[6] ^ hi.z) + __builtin_popcount(a[7] ^ hi.w);
+        key = ((uint32_t)d << 20) | (uint32_t)(base + lane - c0);
+      }
+      best = min(best, wave_min_u32(key));
+    }
+    node = child_id[c0 + (int)(best & 0xFFFFFu)];
+    if (level == nid_level) nid = node;
+  }
+  if (lane == 0) { leaf_out[f] = node; nid_out[f] = nid; }
+}
+
 }  // namespace
 
 extern "C" int ccm_hamming_dense_best2_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
@@ -314,5 +354,67 @@ extern "C" int ccm_distinctive_descriptors(ccm_ctx* ctx, const uint8_t* desc, co
   CCM_HIP_CHECK(ctx, hipGetLastError());
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(best_local_idx, d_best, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
+// ---- vocabulary handle ------------------------------------------------------------------------------------
+struct ccm_vocab {
+  ccm_ctx* ctx; int n_nodes, L;
+  int32_t *d_child_off, *d_child_id; uint32_t* d_node_desc;
+  std::vector<int32_t> word_id; std::vector<double> weight;
+};
+
+extern "C" int ccm_vocab_create(ccm_ctx* ctx, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                                const int32_t* word_id, const double* weight, ccm_vocab** out) {
+  if (!ctx || !out || n_nodes <= 0 || !child_off || !node_desc || !word_id || !weight || L <= 0)
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_vocab_create: bad args");
+  const int n_child = child_off[n_nodes];
+  if (n_child < 0 || (n_child && !child_id)) return ccm_set_error(ctx, CCM_E_ARG, "ccm_vocab_create: bad children");
+  for (int i = 0; i < n_nodes; i++) {
+    const int k = child_off[i + 1] - child_off[i];
+    if (k < 0 || k >= (1 << 20)) return ccm_set_error(ctx, CCM_E_ARG, "ccm_vocab_create: bad child count");
+  }
+  for (int i = 0; i < n_child; i++) if (child_id[i] <= 0 || child_id[i] >= n_nodes) return ccm_set_error(ctx, CCM_E_ARG, "ccm_vocab_create: child id out of range");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ccm_vocab* v = new ccm_vocab();
+  v->ctx = ctx; v->n_nodes = n_nodes; v->L = L;
+  v->word_id.assign(word_id, word_id + n_nodes); v->weight.assign(weight, weight + n_nodes);
+  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_child_off, (size_t)(n_nodes + 1) * 4));
+  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_child_id, (size_t)std::max(n_child, 1) * 4));
+  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_node_desc, (size_t)n_nodes * 32));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_child_off, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_child) CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_child_id, child_id, (size_t)n_child * 4, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_node_desc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = v;
+  return CCM_OK;
+}
+
+extern "C" void ccm_vocab_destroy(ccm_vocab* v) {
+  if (!v) return;
+  hipSetDevice(v->ctx->device); hipStreamSynchronize(v->ctx->stream);
+  hipFree(v->d_child_off); hipFree(v->d_child_id); hipFree(v->d_node_desc);
+  delete v;
+}
+
+extern "C" int ccm_bow_transform(ccm_vocab* v, const uint8_t* desc, int N, int levelsup, int32_t* word_out, double* weight_out, int32_t* node_out) {
+  if (!v || N < 0 || (N && (!desc || !word_out || !weight_out || !node_out))) return ccm_set_error(v ? v->ctx : nullptr, CCM_E_ARG, "ccm_bow_transform: bad args");
+  if (N == 0) return CCM_OK;
+  ccm_ctx* ctx = v->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bd = ccm_align256((size_t)N * 32);
+  void* io = nullptr;
+  { int rc0 = ccm_io_scratch(ctx, bd + (size_t)N * 8, &io); if (rc0) return rc0; }
+  uint8_t* d_desc = (uint8_t*)io; int32_t* d_leaf = (int32_t*)(d_desc + bd); int32_t* d_nid = d_leaf + N;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc, desc, (size_t)N * 32, hipMemcpyHostToDevice, ctx->stream));
+  const int nid_level = v->L - levelsup;   // if <= 0 the node stays 0 (root), TemplatedVocabulary.h:1227
+  hipLaunchKernelGGL(bow_descend_kernel, dim3(ccm_div_up(N, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_desc, N, v->d_child_off, v->d_child_id,
+                     v->d_node_desc, nid_level, d_leaf, d_nid);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  std::vector<int32_t> leaf(N);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(leaf.data(), d_leaf, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(node_out, d_nid, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < N; i++) { word_out[i] = v->word_id[leaf[i]]; weight_out[i] = v->weight[leaf[i]]; }
   return CCM_OK;
 }

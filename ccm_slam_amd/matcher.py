@@ -79,3 +79,47 @@ def distinctive_descriptors(ctx: Context, desc, off):
     out = np.zeros(off.size - 1, np.int32)
     check(lib().ccm_distinctive_descriptors(ctx.handle, _p(desc), _p(off), off.size - 1, _p(out)), ctx.handle)
     return out
+
+
+class Vocabulary:
+    """Device copy of a DBoW2 vocabulary tree (ccm_vocab_*); transform() = TemplatedVocabulary::transform on a batch."""
+
+    def __init__(self, ctx: Context, vocab: dict):
+        self.ctx = ctx
+        self._keep = {k: np.ascontiguousarray(vocab[k]) for k in ("child_off", "child_id", "node_desc", "word_id", "weight")}
+        self._h = C.c_void_p()
+        k = self._keep
+        check(lib().ccm_vocab_create(ctx.handle, int(vocab["n_nodes"]), int(vocab["L"]), _p(k["child_off"]), _p(k["child_id"]), _p(k["node_desc"]),
+                                     _p(k["word_id"]), _p(k["weight"]), C.byref(self._h)), ctx.handle)
+        ctx.adopt(self)
+
+    def transform(self, desc, levelsup=4):
+        """returns (word_id[N], weight[N], node_id[N], BowVector ids, BowVector values (L1-normalised), FeatureVector as
+        (node ids ascending, CSR offsets, feature indices))"""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        N = desc.shape[0]
+        word = np.zeros(N, np.int32); w = np.zeros(N, np.float64); node = np.zeros(N, np.int32)
+        check(lib().ccm_bow_transform(self._h, _p(desc), N, int(levelsup), _p(word), _p(w), _p(node)), self.ctx.handle)
+        keep = w > 0                                   # stopped words are skipped (TemplatedVocabulary.h:1158)
+        # BowVector::addWeight in feature order, then L1 normalisation in ascending word order (BowVector.cpp:34-84)
+        acc = {}
+        for wid, wt in zip(word[keep].tolist(), w[keep].tolist()):
+            acc[wid] = acc.get(wid, 0.0) + wt
+        ids = np.array(sorted(acc), np.int32)
+        vals = np.array([acc[i] for i in ids.tolist()], np.float64)
+        norm = 0.0
+        for x in vals.tolist():
+            norm += abs(x)
+        if norm > 0.0:
+            vals = vals / norm
+        fidx = np.nonzero(keep)[0]
+        order = np.argsort(node[fidx], kind="stable")
+        nodes_sorted = node[fidx][order]
+        fv_nodes, starts = np.unique(nodes_sorted, return_index=True)
+        fv_off = np.append(starts, nodes_sorted.size).astype(np.int32)
+        return word, w, node, ids, vals, (fv_nodes.astype(np.int32), fv_off, fidx[order].astype(np.int32))
+
+    def close(self):
+        if self._h:
+            lib().ccm_vocab_destroy(self._h)
+            self._h = C.c_void_p()

@@ -372,3 +372,32 @@ def make_pose_problem(n: int = 300, seed: int = 0, outlier_frac: float = 0.1, po
     gt = np.concatenate([quat_from_R(R[None])[0], t])
     return dict(cam_qt=cam0, Xw=Xw, obs=obs, info=inv_s2[octave].astype(np.float64), K=np.array(EUROC_K), gt_cam_qt=gt,
                 is_outlier=out)
+
+
+def make_vocabulary(k: int = 10, L: int = 4, seed: int = 0, stop_frac: float = 0.02):
+    """Synthetic DBoW2-style vocabulary tree (the real ORBvoc.txt is a missing blob): complete k-ary
+    tree of depth L in breadth-first node order, node descriptors = parent's with ~12 % of the bits flipped, leaf words
+    numbered in node order, idf-like positive weights with a few stopped (zero-weight) words."""
+    rng = np.random.default_rng(seed)
+    n_nodes = (k ** (L + 1) - 1) // (k - 1)
+    n_inner = (k ** L - 1) // (k - 1)
+    child_off = np.zeros(n_nodes + 1, np.int32)
+    child_off[1:n_inner + 1] = np.arange(1, n_inner + 1) * k
+    child_off[n_inner + 1:] = n_inner * k
+    child_id = np.arange(1, n_inner * k + 1, dtype=np.int32)
+    desc = np.zeros((n_nodes, 32), np.uint8)
+    desc[0] = rng.integers(0, 256, 32, dtype=np.uint8)
+    parent = (np.arange(1, n_nodes) - 1) // k
+    level_start = 1
+    for lvl in range(1, L + 1):
+        cnt = k ** lvl
+        ids = np.arange(level_start, level_start + cnt)
+        bits = np.unpackbits(desc[parent[ids - 1]], axis=1)
+        desc[ids] = np.packbits(bits ^ (rng.random(bits.shape) < 0.12), axis=1)
+        level_start += cnt
+    word_id = -np.ones(n_nodes, np.int32)
+    word_id[n_inner:] = np.arange(n_nodes - n_inner)
+    weight = np.zeros(n_nodes)
+    weight[n_inner:] = rng.uniform(0.5, 6.0, n_nodes - n_inner)
+    weight[n_inner:][rng.random(n_nodes - n_inner) < stop_frac] = 0.0
+    return dict(n_nodes=n_nodes, L=L, child_off=child_off, child_id=child_id, node_desc=desc, word_id=word_id, weight=weight)

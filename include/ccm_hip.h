@@ -101,6 +101,19 @@ int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* 
  * -1 for an empty list.  At most 256 observations per point.                                                        */
 int ccm_distinctive_descriptors(ccm_ctx* ctx, const uint8_t* desc, const int32_t* off, int P, int32_t* best_local_idx);
 
+/* DBoW2 vocabulary transform: TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+ * (cslam/thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1260) for a batch of descriptors.  The tree is passed flat:
+ * node 0 is the root, children of node i are child_id[child_off[i] .. child_off[i+1]) in the vocabulary's child order
+ * (a leaf has none), node_desc is n_nodes x 32 bytes, word_id / weight are per node (meaningful on leaves), L = depth.
+ * Outputs per feature: word id, its weight (idf), and the node at level L - levelsup (0 when that level is <= 0).
+ * BowVector accumulation / L1 normalisation and the FeatureVector map are host work on these arrays
+ * (ccm_slam_amd/host: cslam::BowTransform; TemplatedVocabulary.h:1127-1190, BowVector.cpp:34-84).                     */
+typedef struct ccm_vocab ccm_vocab;
+int  ccm_vocab_create(ccm_ctx* ctx, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                      const int32_t* word_id, const double* weight, ccm_vocab** out);
+void ccm_vocab_destroy(ccm_vocab* v);
+int  ccm_bow_transform(ccm_vocab* v, const uint8_t* desc, int N, int levelsup, int32_t* word_out, double* weight_out, int32_t* node_out);
+
 /* ---- ORB extraction -------------------------------------------------------------------
  * Replaces ORBextractor::ORBextractor / operator() (cslam/src/ORBextractor.cpp:579-639,
  * 1216-1278).  ccm_keypoint == cv::KeyPoint without class_id.                            */

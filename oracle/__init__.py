@@ -390,3 +390,15 @@ def distinctive_descriptors(desc, off):
     out = np.zeros(off.size - 1, np.int32)
     lib().ora_distinctive_descriptors(_p(desc, C.c_uint8), _p(off, C.c_int32), off.size - 1, _p(out, C.c_int32))
     return out
+
+
+def bow_transform(vocab: dict, desc, levelsup=4):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    N = desc.shape[0]
+    word = np.zeros(N, np.int32); w = np.zeros(N, np.float64); node = np.zeros(N, np.int32)
+    bid = np.zeros(max(N, 1), np.int32); bval = np.zeros(max(N, 1), np.float64)
+    n = lib().ora_bow_transform(vocab["n_nodes"], vocab["L"], _p(vocab["child_off"], C.c_int32), _p(vocab["child_id"], C.c_int32),
+                                _p(vocab["node_desc"], C.c_uint8), _p(vocab["word_id"], C.c_int32), _p(vocab["weight"], C.c_double),
+                                _p(desc, C.c_uint8), N, int(levelsup), _p(word, C.c_int32), _p(w, C.c_double), _p(node, C.c_int32),
+                                _p(bid, C.c_int32), _p(bval, C.c_double))
+    return word, w, node, bid[:n], bval[:n]

@@ -547,3 +547,44 @@ extern "C" void ora_distinctive_descriptors(const uint8_t* desc, const int32_t* 
     best_local_idx[p] = BestIdx;
   }
 }
+
+// ================================================================================================
+// DBoW2: TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup)
+// cslam/thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1190 (TF_IDF weighting, L1 norm as ORBvoc uses) and the
+// per-feature descent :1218-1260; FORB::distance = the SWAR popcount (FORB.cpp:81-101); BowVector::addWeight /
+// normalize (BowVector.cpp:34-84); FeatureVector::addFeature (FeatureVector.cpp:31-45).
+// Flat tree: see ccm_vocab_create in include/ccm_hip.h.  Outputs: per feature (word, weight, node); bow_ids/bow_vals =
+// the normalised BowVector in ascending word order (returns its size); the FeatureVector follows from `node` grouped
+// in ascending node order with features in index order (tests build it with numpy).
+// ================================================================================================
+#include <map>
+extern "C" int ora_bow_transform(int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                                 const int32_t* word_id, const double* weight, const uint8_t* desc, int N, int levelsup,
+                                 int32_t* word_out, double* weight_out, int32_t* node_out, int32_t* bow_ids, double* bow_vals) {
+  (void)n_nodes;
+  std::map<int32_t, double> v;
+  for (int f = 0; f < N; f++) {
+    const int nid_level = L - levelsup;
+    int nid = 0, final_id = 0, current_level = 0;
+    while (child_off[final_id + 1] > child_off[final_id]) {
+      ++current_level;
+      const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
+      int best = child_id[c0];
+      double best_d = ora_descriptor_distance(desc + (size_t)f * 32, node_desc + (size_t)best * 32);
+      for (int s = c0 + 1; s < c1; s++) {
+        const int id = child_id[s];
+        const double d = ora_descriptor_distance(desc + (size_t)f * 32, node_desc + (size_t)id * 32);
+        if (d < best_d) { best_d = d; best = id; }
+      }
+      final_id = best;
+      if (current_level == nid_level) nid = final_id;
+    }
+    word_out[f] = word_id[final_id]; weight_out[f] = weight[final_id]; node_out[f] = nid;
+    if (weight[final_id] > 0) v[word_id[final_id]] += weight[final_id];   // addWeight; "stopped" words (w == 0) are skipped
+  }
+  double norm = 0.0;
+  for (auto& kv : v) norm += std::fabs(kv.second);
+  int n = 0;
+  for (auto& kv : v) { bow_ids[n] = kv.first; bow_vals[n] = norm > 0.0 ? kv.second / norm : kv.second; n++; }
+  return n;
+}

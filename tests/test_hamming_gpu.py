@@ -74,3 +74,27 @@ def test_distinctive_descriptors_matches_oracle(ctx, oracle_lib):
     got = matcher.distinctive_descriptors(ctx, desc, off)
     exp = oracle_lib.distinctive_descriptors(desc, off)
     assert np.array_equal(got, exp) and got[0] == -1 and got[1] == 0
+
+
+@pytest.mark.parametrize("k,L,levelsup", [(10, 4, 2), (10, 3, 4), (7, 5, 4)])
+def test_bow_transform_matches_oracle(ctx, oracle_lib, k, L, levelsup):
+    """DBoW2 TemplatedVocabulary::transform: tree descent on the device (bit-exact word / node ids, first-minimum child),
+    BowVector accumulation + L1 normalisation on the host (f64, same operation order => identical doubles)."""
+    vocab = synth.make_vocabulary(k, L, seed=3)
+    rng = np.random.default_rng(5)
+    leaves = np.nonzero(vocab["word_id"] >= 0)[0]
+    src = vocab["node_desc"][rng.choice(leaves, 1500)]
+    bits = np.unpackbits(src, axis=1)
+    desc = np.packbits(bits ^ (rng.random(bits.shape) < 0.05), axis=1)
+    desc[:20] = rng.integers(0, 256, (20, 32), dtype=np.uint8)
+    V = matcher.Vocabulary(ctx, vocab)
+    word, w, node, ids, vals, fv = V.transform(desc, levelsup)
+    oword, ow, onode, oids, ovals = oracle_lib.bow_transform(vocab, desc, levelsup)
+    assert np.array_equal(word, oword) and np.array_equal(node, onode) and np.array_equal(w, ow)
+    assert np.array_equal(ids, oids) and np.array_equal(vals, ovals)
+    if L - levelsup <= 0:
+        assert (node == 0).all()
+    # FeatureVector invariants: ascending nodes, every kept feature exactly once, features ascending inside a node
+    fn, fo, fi = fv
+    assert (np.diff(fn) > 0).all() and fi.size == (w > 0).sum() and all((np.diff(fi[fo[i]:fo[i + 1]]) > 0).all() for i in range(fn.size))
+    V.close()
