@@ -24,6 +24,7 @@
 #include "orb_math.h"
 #include "orb_pattern.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <list>
@@ -320,15 +321,19 @@ __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const ui
 // =================================================================================================
 struct Cand { float x, y, response; };
 
+// Nodes own a contiguous range [kb, ke) of a shared key array (candidate indices); splitting a node is a stable
+// 4-way partition of its range, so no per-node allocation happens (the first version kept a std::vector per
+// node and spent ~220 us per frame in malloc/free — more than all device work of the frame).
 struct ONode {
   int ulx, uly, urx, bry;          // UL.x, UL.y, UR.x, BR.y  (BL.x = UL.x, BL.y = BR.y, UR.y = UL.y, BR.x = UR.x)
-  std::vector<int> keys;           // indices into the candidate array, insertion order preserved
-  int prev = -1, next = -1;
-  bool noMore = false, alive = true;
+  int kb, ke;                      // key range, insertion order preserved
+  int prev, next;
+  bool noMore;
 };
 
 struct Octree {
   std::vector<ONode> nodes;
+  std::vector<int> keys, tmp;
   int head = -1, tail = -1, count = 0;
   void push_back(int id) { ONode& n = nodes[id]; n.prev = tail; n.next = -1; if (tail >= 0) nodes[tail].next = id; else head = id; tail = id; count++; }
   void push_front(int id) { ONode& n = nodes[id]; n.next = head; n.prev = -1; if (head >= 0) nodes[head].prev = id; else tail = id; head = id; count++; }
@@ -337,57 +342,79 @@ struct Octree {
     const int nx = n.next;
     if (n.prev >= 0) nodes[n.prev].next = n.next; else head = n.next;
     if (n.next >= 0) nodes[n.next].prev = n.prev; else tail = n.prev;
-    n.alive = false; count--;
+    count--;
     return nx;
   }
 };
 
 // splits node `id` into its four children (n1 UL, n2 UR, n3 BL, n4 BR); returns child ids (or -1 when empty)
 static void divide_node(Octree& T, int id, const Cand* c, int child[4]) {
-  const int ulx = T.nodes[id].ulx, uly = T.nodes[id].uly, urx = T.nodes[id].urx, bry = T.nodes[id].bry;
-  const int halfX = (int)std::ceil(static_cast<float>(urx - ulx) / 2);
-  const int halfY = (int)std::ceil(static_cast<float>(bry - uly) / 2);
-  const int midx = ulx + halfX, midy = uly + halfY;
-  ONode ch[4];
-  ch[0].ulx = ulx; ch[0].uly = uly; ch[0].urx = midx; ch[0].bry = midy;
-  ch[1].ulx = midx; ch[1].uly = uly; ch[1].urx = urx; ch[1].bry = midy;
-  ch[2].ulx = ulx; ch[2].uly = midy; ch[2].urx = midx; ch[2].bry = bry;
-  ch[3].ulx = midx; ch[3].uly = midy; ch[3].urx = urx; ch[3].bry = bry;
-  for (int k : T.nodes[id].keys) {
-    const Cand& kp = c[k];
-    if (kp.x < midx) { if (kp.y < midy) ch[0].keys.push_back(k); else ch[2].keys.push_back(k); }
-    else if (kp.y < midy) ch[1].keys.push_back(k);
-    else ch[3].keys.push_back(k);
+  const ONode P = T.nodes[id];
+  const int halfX = (int)std::ceil(static_cast<float>(P.urx - P.ulx) / 2);
+  const int halfY = (int)std::ceil(static_cast<float>(P.bry - P.uly) / 2);
+  const int midx = P.ulx + halfX, midy = P.uly + halfY;
+  int cnt[4] = {0, 0, 0, 0};
+  int* K = T.keys.data();
+  int* Tm = T.tmp.data();
+  for (int s = P.kb; s < P.ke; s++) {
+    const Cand& kp = c[K[s]];
+    const int q = (kp.x < midx) ? ((kp.y < midy) ? 0 : 2) : ((kp.y < midy) ? 1 : 3);
+    Tm[s] = q; cnt[q]++;
   }
+  int start[4] = {P.kb, P.kb + cnt[0], P.kb + cnt[0] + cnt[1], P.kb + cnt[0] + cnt[1] + cnt[2]};
+  // stable scatter through a small stack buffer when the node is small, else a heap scratch (rare: only near the roots)
+  {
+    const int n = P.ke - P.kb;
+    int stackbuf[512];
+    std::vector<int> heap;
+    int* buf = stackbuf;
+    if (n > 512) { heap.resize(n); buf = heap.data(); }
+    int pos[4] = {start[0] - P.kb, start[1] - P.kb, start[2] - P.kb, start[3] - P.kb};
+    for (int s = P.kb; s < P.ke; s++) buf[pos[Tm[s]]++] = K[s];
+    std::memcpy(K + P.kb, buf, sizeof(int) * n);
+  }
+  const int bx[4][4] = {{P.ulx, P.uly, midx, midy}, {midx, P.uly, P.urx, midy}, {P.ulx, midy, midx, P.bry}, {midx, midy, P.urx, P.bry}};
   for (int q = 0; q < 4; q++) {
-    if (ch[q].keys.empty()) { child[q] = -1; continue; }
-    ch[q].noMore = ch[q].keys.size() == 1;
+    if (cnt[q] == 0) { child[q] = -1; continue; }
+    ONode ch;
+    ch.ulx = bx[q][0]; ch.uly = bx[q][1]; ch.urx = bx[q][2]; ch.bry = bx[q][3];
+    ch.kb = start[q]; ch.ke = start[q] + cnt[q]; ch.prev = ch.next = -1; ch.noMore = cnt[q] == 1;
     child[q] = (int)T.nodes.size();
-    T.nodes.push_back(std::move(ch[q]));
+    T.nodes.push_back(ch);
   }
 }
 
 // returns the selected candidate indices in the reference's output order (front-to-back list order)
 static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int maxX, int minY, int maxY, int N) {
   Octree T;
-  T.nodes.reserve((size_t)n * 4 + 16);
+  T.nodes.reserve((size_t)std::min(n, 4 * N + 64) * 2 + 16);
+  T.keys.resize(n); T.tmp.resize(n);
   const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
   const float hX = static_cast<float>(maxX - minX) / nIni;
-  for (int i = 0; i < nIni; i++) {
-    ONode r;
-    r.ulx = (int)(hX * static_cast<float>(i)); r.urx = (int)(hX * static_cast<float>(i + 1)); r.uly = 0; r.bry = maxY - minY;
-    T.nodes.push_back(r);
-    T.push_back(i);
+  {
+    // bin the candidates by root (kp.pt.x / hX), stable
+    std::vector<int> rootOf(n), cnt(nIni + 1, 0);
+    for (int k = 0; k < n; k++) { rootOf[k] = (int)(c[k].x / hX); cnt[rootOf[k] + 1]++; }
+    for (int i = 0; i < nIni; i++) cnt[i + 1] += cnt[i];
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (int k = 0; k < n; k++) T.keys[pos[rootOf[k]]++] = k;
+    for (int i = 0; i < nIni; i++) {
+      ONode r;
+      r.ulx = (int)(hX * static_cast<float>(i)); r.urx = (int)(hX * static_cast<float>(i + 1)); r.uly = 0; r.bry = maxY - minY;
+      r.kb = cnt[i]; r.ke = cnt[i + 1]; r.prev = r.next = -1; r.noMore = false;
+      T.nodes.push_back(r);
+      T.push_back(i);
+    }
   }
-  for (int k = 0; k < n; k++) T.nodes[(int)(c[k].x / hX)].keys.push_back(k);
   for (int id = T.head; id >= 0;) {
     ONode& nd = T.nodes[id];
-    if (nd.keys.size() == 1) { nd.noMore = true; id = nd.next; }
-    else if (nd.keys.empty()) id = T.erase(id);
+    const int sz = nd.ke - nd.kb;
+    if (sz == 1) { nd.noMore = true; id = nd.next; }
+    else if (sz == 0) id = T.erase(id);
     else id = nd.next;
   }
   bool finish = false;
-  std::vector<std::pair<int, int>> sizeAndNode;   // (size, node id); node ids grow with creation order
+  std::vector<std::pair<int, int>> sizeAndNode, prevList;   // (size, node id); node ids grow with creation order
   while (!finish) {
     const int prevSize = T.count;
     int nToExpand = 0;
@@ -399,7 +426,8 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
       for (int q = 0; q < 4; q++) {
         if (child[q] < 0) continue;
         T.push_front(child[q]);
-        if (T.nodes[child[q]].keys.size() > 1) { nToExpand++; sizeAndNode.emplace_back((int)T.nodes[child[q]].keys.size(), child[q]); }
+        const int sz = T.nodes[child[q]].ke - T.nodes[child[q]].kb;
+        if (sz > 1) { nToExpand++; sizeAndNode.emplace_back(sz, child[q]); }
       }
       id = T.erase(id);
     }
@@ -407,7 +435,7 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
     else if (T.count + nToExpand * 3 > N) {
       while (!finish) {
         const int prev2 = T.count;
-        std::vector<std::pair<int, int>> prevList = sizeAndNode;
+        prevList = sizeAndNode;
         sizeAndNode.clear();
         // reference sorts pair<int,ExtractorNode*>; equal sizes tie on the heap address there — here on
         // creation order (the node id), the tie-break the oracle defines
@@ -419,7 +447,8 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
           for (int q = 0; q < 4; q++) {
             if (child[q] < 0) continue;
             T.push_front(child[q]);
-            if (T.nodes[child[q]].keys.size() > 1) sizeAndNode.emplace_back((int)T.nodes[child[q]].keys.size(), child[q]);
+            const int sz = T.nodes[child[q]].ke - T.nodes[child[q]].kb;
+            if (sz > 1) sizeAndNode.emplace_back(sz, child[q]);
           }
           T.erase(id);
           if (T.count >= N) break;
@@ -431,10 +460,10 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
   std::vector<int> result;
   result.reserve(T.count);
   for (int id = T.head; id >= 0; id = T.nodes[id].next) {
-    const std::vector<int>& ks = T.nodes[id].keys;
-    int best = ks[0];
+    const ONode& nd = T.nodes[id];
+    int best = T.keys[nd.kb];
     float maxResp = c[best].response;
-    for (size_t k = 1; k < ks.size(); k++) if (c[ks[k]].response > maxResp) { best = ks[k]; maxResp = c[best].response; }
+    for (int s = nd.kb + 1; s < nd.ke; s++) { const int k = T.keys[s]; if (c[k].response > maxResp) { best = k; maxResp = c[k].response; } }
     result.push_back(best);
   }
   return result;
@@ -463,6 +492,7 @@ struct ccm_orb {
   int* h_cand = nullptr;   // pinned
   KpIn* h_kin = nullptr;   // pinned
   hipEvent_t ev_cand = nullptr;
+  double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand;
 };
@@ -660,7 +690,11 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
   // wait for the candidate copy only (the blur kernel queued behind it keeps running)
-  CCM_HIP_CHECK(ctx, hipEventSynchronize(o->ev_cand));
+  {
+    const double w0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    CCM_HIP_CHECK(ctx, hipEventSynchronize(o->ev_cand));
+    o->t_wait_cand = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - w0;
+  }
   const int* offs = o->h_cand;
   const int total = offs[d.ncells];
   if (total > kCandFirstCopy) {
@@ -712,11 +746,16 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = orb_phase1(o))) return rc;
+  const double t1 = now();
   int n = 0;
   if ((rc = orb_host_select(o, &n))) return rc;
+  const double t3 = now();
   if ((rc = orb_phase2(o, n))) return rc;
+  const double t4 = now();
   const int nc = std::min(n, cap);
   if (nc) {
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(kps, o->d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToHost, ctx->stream));
@@ -729,7 +768,15 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
         CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, o->d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
       }
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const double t5 = now();
+  o->t_phase[0] = t1 - t0; o->t_phase[1] = o->t_wait_cand; o->t_phase[2] = (t3 - t1) - o->t_wait_cand; o->t_phase[3] = t4 - t3; o->t_phase[4] = t5 - t4; o->t_phase[5] = t5 - t0;
   *n_out = nc;
+  return CCM_OK;
+}
+
+extern "C" int ccm_orb_debug_timing(const ccm_orb* o, double out_ms[6]) {
+  if (!o || !out_ms) return CCM_E_ARG;
+  for (int i = 0; i < 6; i++) out_ms[i] = o->t_phase[i];
   return CCM_OK;
 }
 

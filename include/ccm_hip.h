@@ -150,6 +150,9 @@ int  ccm_orb_extract_batch_dev(ccm_orb* orb, const uint8_t* d_imgs, int n_frames
 /* intermediate products for parity tests (host copies; any pointer may be NULL):
  * FAST score map and blurred image of one level of the LAST extracted frame.              */
 int  ccm_orb_debug_level(ccm_orb* orb, int level, uint8_t* score_out, uint8_t* blur_out);
+/* host wall-clock phases of the last ccm_orb_extract call, ms: [queue phase 1, wait for candidates, octree, queue phase 2,
+ * wait + D2H, total] */
+int  ccm_orb_debug_timing(const ccm_orb* orb, double out_ms[6]);
 /* pre-octree FAST candidates of the last frame: returns count for the level, fills up to cap */
 int  ccm_orb_debug_candidates(ccm_orb* orb, int level, ccm_keypoint* out, int cap, int* n_out);
 

@@ -14,6 +14,10 @@ t = time.perf_counter()
 for i in range(16): kps, desc = ex(imgs[i])
 dt = (time.perf_counter() - t) / 16
 print(f"host-API extract: {dt*1e3:.3f} ms/frame = {1/dt:.1f} fps, n={len(kps)}")
+import ctypes as C
+from ccm_slam_amd._lib import lib
+tm = (C.c_double * 6)(); lib().ccm_orb_debug_timing(ex._h, tm)
+print("  phases ms [queue1, wait cand, octree, queue2, wait+D2H, total]:", [round(x, 4) for x in tm])
 ctx.prof_enable(-1); ctx.prof_reset()
 b = orb.OrbBatchDev(ctx, ex, imgs)
 b.run()
