@@ -334,6 +334,7 @@ struct ONode {
 struct Octree {
   std::vector<ONode> nodes;
   std::vector<int> keys, tmp;
+  std::vector<std::pair<int, int>> sizeAndNode, prevList;
   int head = -1, tail = -1, count = 0;
   void push_back(int id) { ONode& n = nodes[id]; n.prev = tail; n.next = -1; if (tail >= 0) nodes[tail].next = id; else head = id; tail = id; count++; }
   void push_front(int id) { ONode& n = nodes[id]; n.next = head; n.prev = -1; if (head >= 0) nodes[head].prev = id; else tail = id; head = id; count++; }
@@ -385,15 +386,17 @@ static void divide_node(Octree& T, int id, const Cand* c, int child[4]) {
 }
 
 // returns the selected candidate indices in the reference's output order (front-to-back list order)
-static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int maxX, int minY, int maxY, int N) {
-  Octree T;
+// `T` is a caller-owned workspace whose vectors keep their capacity from frame to frame
+static void distribute_octree(Octree& T, const Cand* c, int n, int minX, int maxX, int minY, int maxY, int N, std::vector<int>& result) {
+  T.nodes.clear(); T.head = T.tail = -1; T.count = 0;
   T.nodes.reserve((size_t)std::min(n, 4 * N + 64) * 2 + 16);
   T.keys.resize(n); T.tmp.resize(n);
   const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
   const float hX = static_cast<float>(maxX - minX) / nIni;
   {
     // bin the candidates by root (kp.pt.x / hX), stable
-    std::vector<int> rootOf(n), cnt(nIni + 1, 0);
+    std::vector<int>& rootOf = T.tmp;
+    std::vector<int> cnt(nIni + 1, 0);
     for (int k = 0; k < n; k++) { rootOf[k] = (int)(c[k].x / hX); cnt[rootOf[k] + 1]++; }
     for (int i = 0; i < nIni; i++) cnt[i + 1] += cnt[i];
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
@@ -414,7 +417,7 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
     else id = nd.next;
   }
   bool finish = false;
-  std::vector<std::pair<int, int>> sizeAndNode, prevList;   // (size, node id); node ids grow with creation order
+  std::vector<std::pair<int, int>>& sizeAndNode = T.sizeAndNode; std::vector<std::pair<int, int>>& prevList = T.prevList;   // (size, node id)
   while (!finish) {
     const int prevSize = T.count;
     int nToExpand = 0;
@@ -457,7 +460,7 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
       }
     }
   }
-  std::vector<int> result;
+  result.clear();
   result.reserve(T.count);
   for (int id = T.head; id >= 0; id = T.nodes[id].next) {
     const ONode& nd = T.nodes[id];
@@ -466,7 +469,6 @@ static std::vector<int> distribute_octree(const Cand* c, int n, int minX, int ma
     for (int s = nd.kb + 1; s < nd.ke; s++) { const int k = T.keys[s]; if (c[k].response > maxResp) { best = k; maxResp = c[k].response; } }
     result.push_back(best);
   }
-  return result;
 }
 
 }  // namespace
@@ -493,6 +495,7 @@ struct ccm_orb {
   KpIn* h_kin = nullptr;   // pinned
   hipEvent_t ev_cand = nullptr;
   double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
+  Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand;
 };
@@ -703,7 +706,7 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   const uint32_t* rec = (const uint32_t*)(o->h_cand + d.ncells + 1);
-  o->last_cand.assign(o->nlevels, {});
+  o->last_cand.resize(o->nlevels);
   int n = 0;
   for (int l = 0; l < o->nlevels; l++) {
     const LevelInfo& L = d.lv[l];
@@ -716,7 +719,8 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
     }
     if (cand.empty()) continue;
     const int minB = kEdge - 3;
-    std::vector<int> sel = distribute_octree(cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l]);
+    std::vector<int>& sel = o->sel_ws;
+    distribute_octree(o->tree_ws, cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
     for (int id : sel) {
       if (n >= o->kp_cap) break;
       o->h_kin[n++] = KpIn{(int16_t)((int)cand[id].x + minB), (int16_t)((int)cand[id].y + minB), (int16_t)l, (int16_t)cand[id].response};
@@ -831,7 +835,8 @@ extern "C" int ccm_orb_distribute_octree(const float* x, const float* y, const f
   std::vector<Cand> c(n);
   for (int i = 0; i < n; i++) c[i] = Cand{x[i], y[i], response[i]};
   std::vector<int> sel;
-  if (n) sel = distribute_octree(c.data(), n, minX, maxX, minY, maxY, N);
+  Octree ws;
+  if (n) distribute_octree(ws, c.data(), n, minX, maxX, minY, maxY, N, sel);
   *n_out = (int)sel.size();
   for (int i = 0; i < (int)sel.size() && i < cap && sel_out; i++) sel_out[i] = sel[i];
   return CCM_OK;
