@@ -487,6 +487,48 @@ int ORBmatcher::MutualAgreement(const std::vector<int32_t>& vnMatch1, const std:
   return nFound;
 }
 
+// ---- vocabulary transform / distinctive descriptors ------------------------------------------------------------
+ORBVocabulary::ORBVocabulary(HipContext& ctx, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                             const int32_t* word_id, const double* weight) {
+  check(ccm_vocab_create(ctx.get(), n_nodes, L, child_off, child_id, node_desc, word_id, weight, &voc_), ctx.get(), "ccm_vocab_create");
+}
+ORBVocabulary::~ORBVocabulary() { ccm_vocab_destroy(voc_); }
+
+void ORBVocabulary::transform(const uint8_t* descriptors, int N, BowVector& v, FeatureVector& fv, int levelsup) const {
+  v.word.clear(); v.value.clear(); fv.node.clear(); fv.off.assign(1, 0); fv.idx.clear();
+  if (N <= 0) return;
+  std::vector<int32_t> word(N), node(N); std::vector<double> w(N);
+  if (ccm_bow_transform(voc_, descriptors, N, levelsup, word.data(), w.data(), node.data()) != CCM_OK)
+    throw infrastructure_ex(std::string("ccm_bow_transform: ") + ccm_last_error(nullptr));
+  // TF_IDF weighting + L1 norm (ORBvoc): BowVector::addWeight in feature order, FeatureVector::addFeature, then normalize
+  std::vector<std::pair<int32_t, int>> bw, fn;   // (word, feature), (node, feature) for kept features
+  for (int i = 0; i < N; i++) if (w[i] > 0) { bw.emplace_back(word[i], i); fn.emplace_back(node[i], i); }   // "not stopped" (TemplatedVocabulary.h:1158)
+  std::stable_sort(bw.begin(), bw.end(), [](const std::pair<int32_t, int>& a, const std::pair<int32_t, int>& b) { return a.first < b.first; });
+  for (size_t s = 0; s < bw.size();) {
+    const int32_t id = bw[s].first;
+    double acc = 0.0;
+    bool first = true;
+    for (; s < bw.size() && bw[s].first == id; s++) { if (first) { acc = w[bw[s].second]; first = false; } else acc += w[bw[s].second]; }
+    v.word.push_back(id); v.value.push_back(acc);
+  }
+  double norm = 0.0;
+  for (double x : v.value) norm += std::fabs(x);
+  if (norm > 0.0) for (double& x : v.value) x /= norm;
+  std::stable_sort(fn.begin(), fn.end(), [](const std::pair<int32_t, int>& a, const std::pair<int32_t, int>& b) { return a.first < b.first; });
+  for (size_t s = 0; s < fn.size();) {
+    const int32_t id = fn[s].first;
+    fv.node.push_back(id);
+    for (; s < fn.size() && fn[s].first == id; s++) fv.idx.push_back(fn[s].second);
+    fv.off.push_back((int32_t)fv.idx.size());
+  }
+}
+
+std::vector<int32_t> ComputeDistinctiveDescriptors(HipContext& ctx, const uint8_t* desc, const std::vector<int32_t>& off) {
+  std::vector<int32_t> best(off.empty() ? 0 : off.size() - 1);
+  if (!best.empty()) check(ccm_distinctive_descriptors(ctx.get(), desc, off.data(), (int)best.size(), best.data()), ctx.get(), "ccm_distinctive_descriptors");
+  return best;
+}
+
 // ---- Optimizer ---------------------------------------------------------------------------------------
 int Optimizer::PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, const double* Xw, const double* obs,
                                       const double* invSigma2, const double K[4], std::vector<uint8_t>& outlier) {
@@ -675,5 +717,21 @@ extern "C" int ccmh_projected_window_search(int device, const float* kx, const f
     std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
     std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
     return n;
+  } catch (const std::exception&) { return -1000; }
+}
+
+extern "C" int ccmh_bow_transform(int device, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                                  const int32_t* word_id, const double* weight, const uint8_t* desc, int N, int levelsup, int32_t* bow_ids,
+                                  double* bow_vals, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_idx, int32_t* sizes /* [n_bow, n_fv_nodes, n_fv_idx] */) {
+  try {
+    cslam::HipContext ctx(device);
+    cslam::ORBVocabulary voc(ctx, n_nodes, L, child_off, child_id, node_desc, word_id, weight);
+    cslam::BowVector v; cslam::FeatureVector fv;
+    voc.transform(desc, N, v, fv, levelsup);
+    std::memcpy(bow_ids, v.word.data(), v.word.size() * 4); std::memcpy(bow_vals, v.value.data(), v.value.size() * 8);
+    std::memcpy(fv_nodes, fv.node.data(), fv.node.size() * 4); std::memcpy(fv_off, fv.off.data(), fv.off.size() * 4);
+    std::memcpy(fv_idx, fv.idx.data(), fv.idx.size() * 4);
+    sizes[0] = (int32_t)v.word.size(); sizes[1] = (int32_t)fv.node.size(); sizes[2] = (int32_t)fv.idx.size();
+    return 0;
   } catch (const std::exception&) { return -1000; }
 }

@@ -139,6 +139,26 @@ class ORBmatcher {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// ORBVocabulary::transform (DBoW2 TemplatedVocabulary<FORB>, thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1127-1260) as
+// KeyFrame::ComputeBoW / Frame::ComputeBoW call it (levelsup = 4), and MapPoint::ComputeDistinctiveDescriptors
+// (MapPoint.cpp:929-994) batched over many map points — SURVEY §8f rows 1 and 3.
+// ---------------------------------------------------------------------------------------------------
+struct BowVector { std::vector<int32_t> word; std::vector<double> value; };                       // ascending word ids, L1-normalised
+struct FeatureVector { std::vector<int32_t> node, off, idx; };                                     // ascending nodes, CSR, features in index order
+class ORBVocabulary {
+ public:
+  // flat tree, see ccm_vocab_create (include/ccm_hip.h)
+  ORBVocabulary(HipContext& ctx, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
+                const int32_t* word_id, const double* weight);
+  ~ORBVocabulary();
+  void transform(const uint8_t* descriptors, int N, BowVector& v, FeatureVector& fv, int levelsup = 4) const;
+ private:
+  ccm_vocab* voc_ = nullptr;
+};
+// best descriptor per map point: desc rows off[p]..off[p+1] are the observations of point p; returns local indices
+std::vector<int32_t> ComputeDistinctiveDescriptors(HipContext& ctx, const uint8_t* desc, const std::vector<int32_t>& off);
+
+// ---------------------------------------------------------------------------------------------------
 // Optimizer — cslam/include/cslam/Optimizer.h:84-112 (numerics; graph walking is the integrator's glue)
 // ---------------------------------------------------------------------------------------------------
 struct BAProblem {   // owning, f64 like g2o; filled from KeyFrames / MapPoints via Converter (Converter.cc:40-119)

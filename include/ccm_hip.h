@@ -107,7 +107,7 @@ int ccm_distinctive_descriptors(ccm_ctx* ctx, const uint8_t* desc, const int32_t
  * (a leaf has none), node_desc is n_nodes x 32 bytes, word_id / weight are per node (meaningful on leaves), L = depth.
  * Outputs per feature: word id, its weight (idf), and the node at level L - levelsup (0 when that level is <= 0).
  * BowVector accumulation / L1 normalisation and the FeatureVector map are host work on these arrays
- * (ccm_slam_amd/host: cslam::BowTransform; TemplatedVocabulary.h:1127-1190, BowVector.cpp:34-84).                     */
+ * (ccm_slam_amd/host: cslam::ORBVocabulary::transform; TemplatedVocabulary.h:1127-1190, BowVector.cpp:34-84).                     */
 typedef struct ccm_vocab ccm_vocab;
 int  ccm_vocab_create(ccm_ctx* ctx, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
                       const int32_t* word_id, const double* weight, ccm_vocab** out);

@@ -222,3 +222,24 @@ def test_projected_window_search(hostlib, oracle_lib, name, chi2_gate, thr, use_
     assert np.array_equal(gbi, ebi) and np.array_equal(gbd, ebd)
     if use_matched:
         assert np.array_equal(gm, em)
+
+
+def test_vocabulary_transform_class(hostlib, oracle_lib):
+    """cslam::ORBVocabulary::transform (host mirror): BowVector and FeatureVector identical to the oracle's restatement of
+    TemplatedVocabulary::transform (same f64 accumulation order => identical doubles)."""
+    vocab = synth.make_vocabulary(10, 4, seed=9)
+    _, desc = _frame(oracle_lib, 1000, 0)
+    N = len(desc)
+    oword, ow, onode, oids, ovals = oracle_lib.bow_transform(vocab, desc, 2)
+    ids = np.zeros(N, np.int32); vals = np.zeros(N); fn = np.zeros(N, np.int32); fo = np.zeros(N + 1, np.int32); fi = np.zeros(N, np.int32)
+    sizes = np.zeros(3, np.int32)
+    rc = hostlib.ccmh_bow_transform(0, vocab["n_nodes"], vocab["L"], _p(vocab["child_off"]), _p(vocab["child_id"]), _p(vocab["node_desc"]),
+                                    _p(vocab["word_id"]), _p(vocab["weight"]), _p(desc), N, 2, _p(ids), _p(vals), _p(fn), _p(fo), _p(fi), _p(sizes))
+    assert rc == 0
+    nb, nn, ni = sizes
+    assert np.array_equal(ids[:nb], oids) and np.array_equal(vals[:nb], ovals)
+    keep = ow > 0
+    exp_nodes = np.unique(onode[keep])
+    assert np.array_equal(fn[:nn], exp_nodes) and ni == keep.sum()
+    for k, nd in enumerate(exp_nodes):
+        assert np.array_equal(fi[fo[k]:fo[k + 1]], np.nonzero(keep & (onode == nd))[0])
