@@ -793,11 +793,6 @@ __global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d) {
   if (threadIdx.x == 0) { d.scal[0] = a; d.scal[1] = b; }
 }
 
-__global__ void ba_copy_cams(double* dst, const double* src, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
 __global__ void ba_scatter_points(double* full, const double* own, const int* own_slot /*local -> global landmark slot*/, int Lloc) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= Lloc) return;
