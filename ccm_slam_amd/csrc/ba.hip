@@ -470,7 +470,12 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int rl = wv >> 1, h = wv & 1;            // local row, half
-  const int i = blockIdx.x * kRowsPerWG + rl;
+  // XCD-aware row assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give
+  // XCD x the CONTIGUOUS row chunk x: covisible cameras are close in index, hence a block S_ij and its mirror use
+  // (row i and, transposed, row j) are read by the same XCD and the second read hits that XCD's 4 MiB L2.
+  const int per_xcd = gridDim.x >> 3;            // grid is padded to a multiple of 8 workgroups
+  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int i = wg * kRowsPerWG + rl;
   const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
   double beta = 0;
   if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
     if (lane == 0) lds[rl] = pq;
   } else if (h == 0 && lane == 0) lds[rl] = 0.0;
   __syncthreads();
-  if (threadIdx.x == 0) d.ppq[blockIdx.x] = lds[0] + lds[1];
+  if (threadIdx.x == 0) d.ppq[wg] = lds[0] + lds[1];
 }
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
@@ -1053,7 +1058,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
   AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double)
   AL(Wc, (size_t)ccm_div_up(std::max(Cp, 1), kClu) * kCluN * kCluN, double)
-  d.n_wg_spmv = ccm_div_up(std::max(Cp, 1), kRowsPerWG); d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave); d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
+  d.n_wg_spmv = ((ccm_div_up(std::max(Cp, 1), kRowsPerWG) + 7) / 8) * 8;   // padded to 8 (one chunk per XCD) d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave); d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
   d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
   AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
   AL(pcg_scal, 4, double) AL(pcg_flag, 4, int)
