@@ -496,42 +496,22 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
   const int g = lane >> 3, r = lane & 7;
   if (i < d.Cp && r < 6) {
     const int e0 = d.row_off[i], e1 = d.row_off[i + 1];
-    // software pipelined in batches of 4 steps: all index loads first, then all block / vector loads, then the
-    // FMAs — one dependent round trip per stage instead of one per step (the kernel is latency bound)
-    for (int sb = e0 + h * 8 + g; sb < e1; sb += 64) {
-      int jj[4]; uint32_t bb[4];
+    for (int s = e0 + h * 8 + g; s < e1; s += 16) {
+      const int j = d.row_col[s];
+      const uint32_t bt = d.row_blk[s];
+      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+      const double* zj = d.z + 6 * (size_t)j;
+      const double* pj = pold + 6 * (size_t)j;
+      double v[6];
+      if (bt & kTransposeBit) {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int s = sb + 16 * t;
-        const bool ok = s < e1;
-        jj[t] = ok ? d.row_col[s] : -1;
-        bb[t] = ok ? d.row_blk[s] : 0u;
-      }
-      double v[4][6], pz[4][6];
+        for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if (jj[t] >= 0) {
-          const double* B = d.S + 36 * (size_t)(bb[t] & ~kTransposeBit);
-          const double* zj = d.z + 6 * (size_t)jj[t];
-          const double* pj = pold + 6 * (size_t)jj[t];
-          if (bb[t] & kTransposeBit) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) v[t][c] = B[c * 6 + r];
-          } else {
-#pragma unroll
-            for (int c = 0; c < 6; c++) v[t][c] = B[r * 6 + c];
-          }
-#pragma unroll
-          for (int c = 0; c < 6; c++) pz[t][c] = zj[c] + beta * pj[c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < 6; c++) { v[t][c] = 0; pz[t][c] = 0; }
-        }
+        for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
       }
 #pragma unroll
-      for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc += v[t][c] * pz[t][c];
+      for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
     }
   }
   // sum over the 8 groups (lanes with equal r): fixed xor tree
