@@ -117,3 +117,30 @@ def test_full_size_gba_c4_parity_and_properties(ctx, oracle_lib):
     cam2, pts2, _, _ = h.download()
     assert np.array_equal(cam, cam2) and np.array_equal(pts, pts2) and st2.chi2_final == st.chi2_final
     h.close()
+
+
+def test_all_cameras_fixed_structure_only(ctx, oracle_lib):
+    """every keyframe fixed (e.g. a local BA whose window holds only keyframe 0 plus fixed observers): only landmarks move;
+    no reduced camera system exists (Cp = 0) — g2o then solves the landmark blocks alone."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=12, n_points=600, seed=17, n_fixed=12, loop_len=60)
+    assert prob["cam_fixed"].all()
+    cam, pts, chi2, dpos, st = optimizer.bundle_adjustment(ctx, prob, 6)
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 6)
+    assert np.array_equal(cam, prob["cam_qt"]) and st.iters_done == ost.iters_done
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final and np.abs(pts - opts).max() < 1e-6
+
+
+def test_empty_active_set_is_a_no_op(ctx):
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=6, n_points=100, seed=1, loop_len=40)
+    prob["e_level"] = np.ones(prob["n_edge"], np.uint8)    # every edge at level 1: nothing to optimise
+    cam, pts, chi2, dpos, st = optimizer.bundle_adjustment(ctx, prob, 5)
+    assert st.iters_done == 0 and np.array_equal(cam, prob["cam_qt"]) and np.array_equal(pts, prob["pt_xyz"])
+
+
+def test_bad_edge_index_is_rejected(ctx):
+    from ccm_slam_amd._lib import CcmError
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=6, n_points=100, seed=1, loop_len=40)
+    prob["e_cam"] = prob["e_cam"].copy()
+    prob["e_cam"][3] = prob["n_cam"] + 5
+    with pytest.raises(CcmError, match="out of range"):
+        optimizer.bundle_adjustment(ctx, prob, 2)
