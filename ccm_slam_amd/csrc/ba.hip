@@ -189,9 +189,9 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
     ba_map(T, X, Xc);
     double Jj[12];
     {
-      const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z, fx = K4[0], fy = K4[1];
-      Jj[0] = x * y / z_2 * fx; Jj[1] = -(1 + (x * x / z_2)) * fx; Jj[2] = y / z * fx; Jj[3] = -1. / z * fx; Jj[4] = 0; Jj[5] = x / z_2 * fx;
-      Jj[6] = (1 + y * y / z_2) * fy; Jj[7] = -x * y / z_2 * fy; Jj[8] = -x / z * fy; Jj[9] = 0; Jj[10] = -1. / z * fy; Jj[11] = y / z_2 * fy;
+      const double x = Xc[0], y = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz, fx = K4[0], fy = K4[1];
+      Jj[0] = x * y * iz2 * fx; Jj[1] = -(1 + (x * x * iz2)) * fx; Jj[2] = y * iz * fx; Jj[3] = -iz * fx; Jj[4] = 0; Jj[5] = x * iz2 * fx;
+      Jj[6] = (1 + y * y * iz2) * fy; Jj[7] = -x * y * iz2 * fy; Jj[8] = -x * iz * fy; Jj[9] = 0; Jj[10] = -iz * fy; Jj[11] = y * iz2 * fy;
     }
     const double om = d.info[e];
     double rho0, w;

@@ -38,7 +38,7 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
-  double L[36];
+  double L[36], inv[6];
 #pragma unroll
   for (int i = 0; i < 36; i++) L[i] = H[i];
 #pragma unroll
@@ -51,12 +51,14 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
     if (!(d > 0.0) || !isfinite(d)) return false;
     d = sqrt(d);
     L[j * 6 + j] = d;
+    const double id = 1.0 / d;   // 6 reciprocals in total instead of 27 divisions
+    inv[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double s = L[i * 6 + j];
 #pragma unroll
       for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-      L[i * 6 + j] = s / d;
+      L[i * 6 + j] = s * id;
     }
   }
 #pragma unroll
@@ -64,14 +66,14 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
     double s = b[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[i * 6 + k] * x[k];
-    x[i] = s / L[i * 6 + i];
+    x[i] = s * inv[i];
   }
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double s = x[i];
 #pragma unroll
     for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * x[k];
-    x[i] = s / L[i * 6 + i];
+    x[i] = s * inv[i];
   }
   return true;
 }
