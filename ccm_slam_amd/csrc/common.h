@@ -28,6 +28,7 @@ struct ccm_ctx {
   // reusable staging buffers
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_io = nullptr; size_t d_io_bytes = 0;   // staging for the host-pointer entry points
+  void* h_pin = nullptr; size_t h_pin_bytes = 0; // pinned host staging (one H2D / D2H per small call)
 };
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
@@ -51,6 +52,7 @@ struct ccm_prof_scope {
 // device scratch that grows on demand (never shrinks); contents undefined
 int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_io_scratch(ccm_ctx* ctx, size_t bytes, void** out);
+int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 static inline int ccm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

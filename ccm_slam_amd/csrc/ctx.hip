@@ -64,6 +64,7 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   for (auto e : ctx->ev_pool) hipEventDestroy(e);
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
   if (ctx->d_io) hipFree(ctx->d_io);
+  if (ctx->h_pin) hipHostFree(ctx->h_pin);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -171,5 +172,17 @@ extern "C" int ccm_prof_read(ccm_ctx* ctx, int kernel_class, int64_t* launches, 
   drain(ctx, ctx->prof[kernel_class]);
   if (launches) *launches = ctx->prof[kernel_class].launches;
   if (total_ms) *total_ms = ctx->prof[kernel_class].total_ms;
+  return CCM_OK;
+}
+
+int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->h_pin_bytes) {
+    if (ctx->h_pin) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
+    const size_t nb = ccm_align256(bytes * 2);
+    hipError_t e = hipHostMalloc(&ctx->h_pin, nb, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->h_pin_bytes = 0; return ccm_set_error(ctx, CCM_E_HIP, "pinned scratch hipHostMalloc failed"); }
+    ctx->h_pin_bytes = nb;
+  }
+  *out = ctx->h_pin;
   return CCM_OK;
 }

@@ -13,10 +13,14 @@
 #include "common.h"
 #include "ba_math.h"
 #include <cfloat>
+#include <cstring>
 
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kNW = 4;                 // waves per workgroup: edges are strided over 256 threads
+constexpr int kThreads = kWave * kNW;
+constexpr int kRedDoubles = 2 * kNW * 32;   // two ping-pong buffers of per-wave partials at the head of the LDS
 
 struct PoseOptArgs {
   int n;
@@ -30,12 +34,63 @@ struct PoseOptArgs {
   int* n_bad;           // out
 };
 
-// butterfly sum: every lane ends with the full (identically ordered) sum
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+
+// Block-wide sums with a fixed association order (=> deterministic, and every thread of every wave ends with the
+// same bits, which keeps the whole LM control flow uniform without broadcasting decisions).
+struct BlockRed {
+  double* buf;   // LDS [2][kNW][32]
+  int phase;
+  int lane, wave;
+
+  // one value: wave butterfly, then the kNW partials through LDS
+  __device__ __forceinline__ double sum1(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    double* b = buf + phase * (kNW * 32);
+    phase ^= 1;
+    if (lane == 0) b[wave * 32] = v;
+    __syncthreads();
+    double s = b[0];
+#pragma unroll
+    for (int w = 1; w < kNW; w++) s += b[w * 32];
+    return s;
+  }
+
+  // 27 values at once (upper triangle of H + b): a halving butterfly moves 16+8+4+2+1+1 = 32 f64 values through
+  // the cross-lane network instead of 27*6 = 162; lane l then owns the wave total of value l>>1, the waves meet
+  // in LDS, lanes 0..26 add the kNW partials and v_readlane hands every total to the whole wave as a scalar.
+  __device__ __forceinline__ void sum27(double* acc /* [32], entries 27..31 zero */) {
+#pragma unroll
+    for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
+      const bool hi = (lane & off) != 0;
+#pragma unroll
+      for (int k = 0; k < c; k++) {
+        const double send = hi ? acc[k] : acc[k + c];
+        const double keep = hi ? acc[k + c] : acc[k];
+        acc[k] = keep + __shfl_xor(send, off, kWave);
+      }
+    }
+    acc[0] += __shfl_xor(acc[0], 1, kWave);
+    double* b = buf + phase * (kNW * 32);
+    phase ^= 1;
+    if ((lane & 1) == 0) b[wave * 32 + (lane >> 1)] = acc[0];
+    __syncthreads();
+    double v = 0.0;
+    if (lane < 32) {
+      v = b[lane];
+#pragma unroll
+      for (int w = 1; w < kNW; w++) v += b[w * 32 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = bcast_lane(v, k);
+  }
+};
 
 __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
   double L[36], inv[6];
@@ -78,35 +133,39 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
   return true;
 }
 
-// ONE wave: no barriers at all.  Every lane carries the pose, H, b and the LM scalars in registers (the serial
-// 6x6 solve / exp map is executed once for the wave by SIMT anyway); edges are strided over the 64 lanes and
-// every reduction is a butterfly, so all lanes always agree and the control flow stays wave-uniform.
-__global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_lds) {
+// ONE workgroup of 4 waves.  Every thread carries the pose, H, b and the LM scalars in registers (the serial 6x6
+// solve / exp map is executed redundantly by all lanes, SIMT makes that free); edges are strided over the 256
+// threads, a thread always owns the same edges, and the only synchronisation is the barrier inside BlockRed
+// (2-3 per LM trial).  All threads see bit-identical sums, so every branch below is workgroup-uniform.
+__global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  BlockRed red{sm, 0, tid & 63, tid >> 6};
   const double delta = (double)(float)sqrt(5.991);
   const double K4[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
   BaPose T0 = ba_load_pose(a.cam);
   ba_normalize_rotation(T0);
   uint8_t* g_outlier = a.outlier;
   if (use_lds) {
-    // one wave has no other wave to hide global latency behind: stage the whole problem (64 B + 3 flags per
+    // a single workgroup has nothing to hide global latency behind: stage the whole problem (64 B + 3 flags per
     // edge) in LDS once; every later pass over the edges runs at LDS latency
-    double* lx = sm; double* lo = sm + 3 * (size_t)a.n; double* li = sm + 5 * (size_t)a.n; double* le = sm + 6 * (size_t)a.n;
-    uint8_t* lb = reinterpret_cast<uint8_t*>(sm + 8 * (size_t)a.n);
-    for (int i = lane; i < 3 * a.n; i += kWave) lx[i] = a.Xw[i];
-    for (int i = lane; i < 2 * a.n; i += kWave) lo[i] = a.obs[i];
-    for (int i = lane; i < a.n; i += kWave) li[i] = a.info[i];
+    double* base = sm + kRedDoubles;
+    double* lx = base; double* lo = base + 3 * (size_t)a.n; double* li = base + 5 * (size_t)a.n; double* le = base + 6 * (size_t)a.n;
+    uint8_t* lb = reinterpret_cast<uint8_t*>(base + 8 * (size_t)a.n);
+    for (int i = tid; i < 3 * a.n; i += kThreads) lx[i] = a.Xw[i];
+    for (int i = tid; i < 2 * a.n; i += kThreads) lo[i] = a.obs[i];
+    for (int i = tid; i < a.n; i += kThreads) li[i] = a.info[i];
     a.Xw = lx; a.obs = lo; a.info = li; a.err = le;
     a.level = lb; a.robust = lb + a.n; a.outlier = lb + 2 * (size_t)a.n;
+    __syncthreads();
   }
-  for (int i = lane; i < a.n; i += kWave) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
+  for (int i = tid; i < a.n; i += kThreads) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
   BaPose T = T0;
   int nBad = 0;
 
   auto chi2_active = [&](const BaPose& P) -> double {
     double c = 0.0;
-    for (int i = lane; i < a.n; i += kWave) {
+    for (int i = tid; i < a.n; i += kThreads) {
       if (a.level[i] != 0) continue;
       const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
       double e0, e1;
@@ -116,24 +175,28 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_l
       ba_huber((e0 * e0 + e1 * e1) * a.info[i], a.robust[i] ? delta : 0.0, rho0, w);
       c += rho0;
     }
-    return wsum(c);
+    return red.sum1(c);
   };
 
   for (int it = 0; it < 4; it++) {
     T = T0;                                     // vSE3->setEstimate(Converter::toSE3Quat(Frame.mTcw)) (:299)
     double cnt = 0.0;
-    for (int i = lane; i < a.n; i += kWave) cnt += (a.level[i] == 0) ? 1.0 : 0.0;
-    const int nact = (int)wsum(cnt);
+    for (int i = tid; i < a.n; i += kThreads) cnt += (a.level[i] == 0) ? 1.0 : 0.0;
+    const int nact = (int)red.sum1(cnt);
     if (nact > 0) {
       int nBadLM = 0;
       double lambda = 0, ni = 2;
+      bool err_current = false;                 // err[] / carriedChi hold the errors of the current estimate
+      double carriedChi = 0;
       for (int iter = 0; iter < 10; iter++) {
-        double currentChi = chi2_active(T);
+        // computeActiveErrors + activeRobustChi2 at the top of every g2o iteration; after an accepted trial the
+        // errors of T were just evaluated for tempChi, so the pass is skipped (same values, a third less edge work)
+        double currentChi = err_current ? carriedChi : chi2_active(T);
         const double iniChi = currentChi;
-        double acc[27];
+        double acc[32];
 #pragma unroll
-        for (int k = 0; k < 27; k++) acc[k] = 0;
-        for (int i = lane; i < a.n; i += kWave) {
+        for (int k = 0; k < 32; k++) acc[k] = 0;
+        for (int i = tid; i < a.n; i += kThreads) {
           if (a.level[i] != 0) continue;
           const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
           double Xc[3];
@@ -152,8 +215,7 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_l
 #pragma unroll
           for (int r = 0; r < 6; r++) acc[21 + r] += J[r] * o0 + J[6 + r] * o1;
         }
-#pragma unroll
-        for (int k = 0; k < 27; k++) acc[k] = wsum(acc[k]);
+        red.sum27(acc);
         double H[36], B[6];
         {
           int k = 0;
@@ -192,9 +254,11 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_l
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
             currentChi = tempChi;
+            err_current = true; carriedChi = tempChi;
           } else {
             lambda *= ni; ni *= 2;
             T = backup;
+            err_current = false;
           }
           qmax++;
         } while (rho < 0 && qmax < 10);
@@ -205,7 +269,7 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_l
     }
     // classification (:306-334)
     double bad = 0.0;
-    for (int i = lane; i < a.n; i += kWave) {
+    for (int i = tid; i < a.n; i += kThreads) {
       if (a.outlier[i]) {
         const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
         double e0, e1;
@@ -218,11 +282,11 @@ __global__ __launch_bounds__(kWave) void poseopt_kernel(PoseOptArgs a, int use_l
       else { a.outlier[i] = 0; a.level[i] = 0; }
       if (it == 2) a.robust[i] = 0;
     }
-    nBad = (int)wsum(bad);
+    nBad = (int)red.sum1(bad);
     if (a.n < 10) break;
   }
-  if (use_lds) for (int i = lane; i < a.n; i += kWave) g_outlier[i] = a.outlier[i];
-  if (lane == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
+  if (use_lds) for (int i = tid; i < a.n; i += kThreads) g_outlier[i] = a.outlier[i];
+  if (tid == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
 }
 
 }  // namespace
@@ -233,41 +297,54 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
     return ccm_set_error(ctx, CCM_E_ARG, "ccm_pose_optimize: bad args");
   if (n < 3) { *n_inlier = 0; return CCM_OK; }   // nInitialCorrespondences < 3 (:290-291)
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  // one scratch block: [cam 7 | Xw 3n | obs 2n | info n | err 2n] doubles, then level/robust/outlier bytes, n_bad int
-  const size_t nd = 7 + 8 * (size_t)n;
+  // one device block: [cam 7 | n_bad (8 B) | Xw 3n | obs 2n | info n | err 2n] doubles, then outlier/level/robust bytes.
+  // Inputs are packed into one pinned staging buffer => ONE H2D and ONE D2H per call instead of four + three.
+  const size_t n_in = 8 + 6 * (size_t)n;                  // doubles uploaded
+  const size_t nd = n_in + 2 * (size_t)n;
   const size_t bytes = nd * sizeof(double) + 3 * (size_t)n + 64;
   void* scratch = nullptr;
   int rc = ccm_scratch(ctx, bytes, &scratch);
   if (rc) return rc;
+  void* pin = nullptr;
+  rc = ccm_pin_scratch(ctx, n_in * sizeof(double) + (size_t)n + 64, &pin);
+  if (rc) return rc;
   double* d = (double*)scratch;
+  double* h = (double*)pin;
   PoseOptArgs a;
   a.n = n;
-  a.cam = d; a.Xw = d + 7; a.obs = d + 7 + 3 * (size_t)n; a.info = d + 7 + 5 * (size_t)n; a.err = d + 7 + 6 * (size_t)n;
+  a.cam = d; a.n_bad = (int*)(d + 7);
+  a.Xw = d + 8; a.obs = d + 8 + 3 * (size_t)n; a.info = d + 8 + 5 * (size_t)n; a.err = d + 8 + 6 * (size_t)n;
   uint8_t* bytes_base = (uint8_t*)(d + nd);
-  a.level = bytes_base; a.robust = bytes_base + n; a.outlier = bytes_base + 2 * (size_t)n;
-  a.n_bad = (int*)(bytes_base + ((3 * (size_t)n + 15) & ~(size_t)15));
+  a.outlier = bytes_base; a.level = bytes_base + n; a.robust = bytes_base + 2 * (size_t)n;
   for (int k = 0; k < 4; k++) a.K[k] = K[k];
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(a.cam, cam_qt, 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync((void*)a.Xw, Xw, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync((void*)a.obs, obs, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync((void*)a.info, info, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  memcpy(h, cam_qt, 7 * sizeof(double));
+  h[7] = 0;
+  memcpy(h + 8, Xw, 3 * (size_t)n * sizeof(double));
+  memcpy(h + 8 + 3 * (size_t)n, obs, 2 * (size_t)n * sizeof(double));
+  memcpy(h + 8 + 5 * (size_t)n, info, (size_t)n * sizeof(double));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
     // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
-    const size_t lds_bytes = 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
-    const int use_lds = lds_bytes <= 150 * 1024;
-    if (use_lds && lds_bytes > 64 * 1024) {
+    const size_t lds_full = kRedDoubles * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+    const int use_lds = lds_full <= 150 * 1024;
+    const size_t lds_bytes = use_lds ? lds_full : kRedDoubles * sizeof(double);
+    if (lds_bytes > 64 * 1024) {
       static bool attr_set = false;
       if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)poseopt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
     }
-    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kWave), use_lds ? lds_bytes : 0, ctx->stream, a, use_lds);
+    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kThreads), lds_bytes, ctx->stream, a, use_lds);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
-  int n_bad = 0;
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(cam_qt, a.cam, 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(outlier, a.outlier, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(&n_bad, a.n_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  // results: [cam 7 | n_bad] (64 B) and the n outlier bytes -> two small D2H into the pinned buffer
+  uint8_t* h_out = (uint8_t*)(h + 8);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, a.outlier, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(cam_qt, h, 7 * sizeof(double));
+  memcpy(outlier, h_out, (size_t)n);
+  int n_bad = 0;
+  memcpy(&n_bad, h + 7, sizeof(int));
   *n_inlier = n - n_bad;
   return CCM_OK;
 }
