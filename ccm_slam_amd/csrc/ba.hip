@@ -1281,6 +1281,32 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
 
 }  // namespace
 
+// Test hook for the sharded path: this rank's PARTIAL reduced camera system [S blocks | b_schur] of the
+// current state at the given lambda, exactly the buffer lm_trial hands to the RCCL all-reduce, without the all-reduce.
+// Summing the downloads of all ranks' handles must reproduce the single-rank system (tests/test_ba_gpu.py).
+extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count) {
+  if (!ba || !count) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  *count = ba->red_count;
+  if (!out) return CCM_OK;
+  if (cap < ba->red_count) return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_debug_partial_reduced: buffer too small");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  RC(build_system(ba));
+  if (d.Lloc) hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
+  if (d.Cp) {
+    hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
+    if (d.nOff) {
+      if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
+      else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+    }
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, ba->d_red, ba->red_count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CCM_OK;
+}
+
 extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volatile unsigned char* stop_flag, ccm_ba_stats* stats) {
   if (!ba) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;

@@ -73,6 +73,15 @@ class BAHandle:
         check(lib().ccm_ba_counts(self._h, *[C.byref(x) for x in v]), self.ctx.handle)
         return dict(zip(("edges", "points", "free_cams", "blocks", "pairs"), (x.value for x in v)))
 
+    def partial_reduced(self, lam: float) -> np.ndarray:
+        """Test hook: this rank's partial [S | b_schur] at the current state (ccm_ba_debug_partial_reduced)."""
+        n = C.c_size_t()
+        check(lib().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), None, C.c_size_t(0), C.byref(n)), self.ctx.handle)
+        out = np.zeros(n.value, np.float64)
+        check(lib().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), C.c_void_p(_vp(out)), C.c_size_t(out.size), C.byref(n)),
+              self.ctx.handle)
+        return out
+
     def close(self):
         if self._h:
             lib().ccm_ba_destroy(self._h)

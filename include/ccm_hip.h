@@ -225,6 +225,10 @@ int  ccm_ba_partition(const int64_t* weight, int n, int nranks, int32_t* begin_o
 int  ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts,
                    int64_t* n_free_cams, int64_t* n_blocks, int64_t* n_pairs);
 
+/* test hook: this rank's partial reduced camera system [36*(n_free_cams+n_blocks) S | 6*n_free_cams b]
+ * at the current state, i.e. the buffer the per-trial RCCL all-reduce sums; out == NULL only queries *count. */
+int  ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count);
+
 /* RCCL communicator for the sharded GBA.  id_bytes is an ncclUniqueId (128 bytes) produced by
  * ccm_comm_unique_id on rank 0 and broadcast by the launcher (bench.py uses torch.distributed). */
 int ccm_comm_unique_id(uint8_t id_bytes[128]);

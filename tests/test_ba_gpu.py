@@ -144,3 +144,28 @@ def test_bad_edge_index_is_rejected(ctx):
     prob["e_cam"][3] = prob["n_cam"] + 5
     with pytest.raises(CcmError, match="out of range"):
         optimizer.bundle_adjustment(ctx, prob, 2)
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_partial_systems_sum_to_the_single_rank_system(ctx, nranks):
+    """SURVEY §8e on the device: every rank's handle lays the reduced system out identically and the partial
+    [S | b_schur] buffers (what the per-trial RCCL all-reduce sums) add up to the unsharded system.  One GPU plays
+    all ranks in turn, so no communicator is involved; the collective itself is covered by tests/test_comm_gpu.py."""
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=12, n_points=900, seed=77)
+    lam = 3.7
+    full_h = optimizer.BAHandle(ctx, prob)
+    full = full_h.partial_reduced(lam)
+    cnt = full_h.counts()
+    acc = np.zeros_like(full)
+    pts = 0
+    for r in range(nranks):
+        h = optimizer.BAHandle(ctx, prob, rank=r, nranks=nranks)
+        part = h.partial_reduced(lam)
+        assert part.shape == full.shape
+        c = h.counts()
+        assert c["free_cams"] == cnt["free_cams"] and c["blocks"] == cnt["blocks"]
+        acc += part
+        h.close()
+    full_h.close()
+    scale = np.abs(full).max()
+    assert np.abs(acc - full).max() <= 1e-12 * scale
