@@ -12,15 +12,13 @@
 // result download.  Reductions use a fixed tree => run-to-run deterministic.
 #include "common.h"
 #include "ba_math.h"
+#include "block_red.h"
 #include <cfloat>
 #include <cstring>
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kNW = 4;                 // waves per workgroup: edges are strided over 256 threads
-constexpr int kThreads = kWave * kNW;
-constexpr int kRedDoubles = 2 * kNW * 32;   // two ping-pong buffers of per-wave partials at the head of the LDS
+using namespace blockred;
 
 struct PoseOptArgs {
   int n;
@@ -32,64 +30,6 @@ struct PoseOptArgs {
   uint8_t* robust;      // scratch [n]
   uint8_t* outlier;     // out [n]
   int* n_bad;           // out
-};
-
-__device__ __forceinline__ double bcast_lane(double v, int lane) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Block-wide sums with a fixed association order (=> deterministic, and every thread of every wave ends with the
-// same bits, which keeps the whole LM control flow uniform without broadcasting decisions).
-struct BlockRed {
-  double* buf;   // LDS [2][kNW][32]
-  int phase;
-  int lane, wave;
-
-  // one value: wave butterfly, then the kNW partials through LDS
-  __device__ __forceinline__ double sum1(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    double* b = buf + phase * (kNW * 32);
-    phase ^= 1;
-    if (lane == 0) b[wave * 32] = v;
-    __syncthreads();
-    double s = b[0];
-#pragma unroll
-    for (int w = 1; w < kNW; w++) s += b[w * 32];
-    return s;
-  }
-
-  // 27 values at once (upper triangle of H + b): a halving butterfly moves 16+8+4+2+1+1 = 32 f64 values through
-  // the cross-lane network instead of 27*6 = 162; lane l then owns the wave total of value l>>1, the waves meet
-  // in LDS, lanes 0..26 add the kNW partials and v_readlane hands every total to the whole wave as a scalar.
-  __device__ __forceinline__ void sum27(double* acc /* [32], entries 27..31 zero */) {
-#pragma unroll
-    for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
-      const bool hi = (lane & off) != 0;
-#pragma unroll
-      for (int k = 0; k < c; k++) {
-        const double send = hi ? acc[k] : acc[k + c];
-        const double keep = hi ? acc[k + c] : acc[k];
-        acc[k] = keep + __shfl_xor(send, off, kWave);
-      }
-    }
-    acc[0] += __shfl_xor(acc[0], 1, kWave);
-    double* b = buf + phase * (kNW * 32);
-    phase ^= 1;
-    if ((lane & 1) == 0) b[wave * 32 + (lane >> 1)] = acc[0];
-    __syncthreads();
-    double v = 0.0;
-    if (lane < 32) {
-      v = b[lane];
-#pragma unroll
-      for (int w = 1; w < kNW; w++) v += b[w * 32 + lane];
-    }
-#pragma unroll
-    for (int k = 0; k < 27; k++) acc[k] = bcast_lane(v, k);
-  }
 };
 
 __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, const double* b, double* x) {

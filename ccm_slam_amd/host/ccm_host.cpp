@@ -539,6 +539,17 @@ int Optimizer::PoseOptimizationClient(HipContext& ctx, double cam_qt[7], int n, 
   return ninl;
 }
 
+int Optimizer::OptimizeSim3(HipContext& ctx, double g2oS12[8], int n, const double* P1c, const double* P2c, const double* obs1,
+                            const double* obs2, const double* invSigma2_1, const double* invSigma2_2, const double K1[4],
+                            const double K2[4], float th2, bool bFixScale, std::vector<uint8_t>& keep) {
+  keep.assign(std::max(n, 1), 0);
+  int nin = 0;
+  check(ccm_sim3_optimize(ctx.get(), g2oS12, n, P1c, P2c, obs1, obs2, invSigma2_1, invSigma2_2, K1, K2, (double)th2,
+                          bFixScale ? 1 : 0, keep.data(), &nin), ctx.get(), "ccm_sim3_optimize");
+  keep.resize(n);
+  return nin;
+}
+
 static ccm_ba_problem make_problem(BAProblem& p, const uint8_t* level, double huber) {
   ccm_ba_problem c{};
   c.n_cam = p.n_cam(); c.n_pt = p.n_pt(); c.n_edge = p.n_edge();
@@ -630,6 +641,17 @@ int ccmh_local_ba(int device, int n_cam, int n_pt, int n_edge, double* cam_qt, c
     std::memcpy(pt_xyz, p.pt_xyz.data(), sizeof(double) * p.pt_xyz.size());
     std::memcpy(to_erase, er.data(), er.size());
     return 0;
+  } catch (const std::exception&) { return -1000; }
+}
+
+int ccmh_optimize_sim3(int device, double* sim3, int n, const double* P1c, const double* P2c, const double* obs1, const double* obs2,
+                       const double* info1, const double* info2, const double* K1, const double* K2, float th2, int fix_scale, uint8_t* keep) {
+  try {
+    cslam::HipContext ctx(device);
+    std::vector<uint8_t> k;
+    const int nin = cslam::Optimizer::OptimizeSim3(ctx, sim3, n, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2, fix_scale != 0, k);
+    if (n) std::memcpy(keep, k.data(), k.size());
+    return nin;
   } catch (const std::exception&) { return -1000; }
 }
 

@@ -184,6 +184,12 @@ class Optimizer {
   // BundleAdjustmentClient / MapFusionGBA numerics (Optimizer.cpp:163-167, 786-797): optimize(nIterations), Huber sqrt(5.99)
   static void GlobalBundleAdjustment(HipContext& ctx, BAProblem& p, int nIterations, bool* pbStopFlag, bool bRobust,
                                      ccm_ba_stats* stats = nullptr);
+  // OptimizeSim3 (Optimizer.cpp:861-1056).  Pair i of the valid correspondences (:911-947): P1c / P2c = the points in
+  // their own keyframe's camera frame, obs = undistorted keypoints, invSigma2 per octave.  g2oS12 = [qx qy qz qw tx ty tz s]
+  // in/out; keep[i] = 0 where the reference nulls vpMatches1[idx]; returns nIn (0 => g2oS12 untouched).
+  static int OptimizeSim3(HipContext& ctx, double g2oS12[8], int n, const double* P1c, const double* P2c, const double* obs1,
+                          const double* obs2, const double* invSigma2_1, const double* invSigma2_2, const double K1[4],
+                          const double K2[4], float th2, bool bFixScale, std::vector<uint8_t>& keep);
 };
 
 }  // namespace cslam

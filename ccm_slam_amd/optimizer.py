@@ -145,3 +145,17 @@ def pose_optimization(ctx: Context, cam_qt, Xw, obs, info, K):
                                   C.c_void_p(_vp(info)), C.c_void_p(_vp(K)), C.c_void_p(_vp(outl)), C.byref(ninl)),
           ctx.handle)
     return cam, outl[:n], ninl.value
+
+
+def sim3_optimization(ctx: Context, sim3, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2: float = 10.0, fix_scale: bool = False):
+    """Optimizer::OptimizeSim3 (Optimizer.cpp:861-1056) through ccm_sim3_optimize.  Returns (sim3[8], inlier flags, nIn)."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    s = f(sim3).copy()
+    P1c, P2c, obs1, obs2, info1, info2, K1, K2 = map(f, (P1c, P2c, obs1, obs2, info1, info2, K1, K2))
+    n = P1c.shape[0] if P1c.ndim == 2 else P1c.size // 3
+    inl = np.zeros(max(n, 1), np.uint8)
+    nin = C.c_int(0)
+    v = lambda a: C.c_void_p(_vp(a))
+    check(lib().ccm_sim3_optimize(ctx.handle, v(s), n, v(P1c), v(P2c), v(obs1), v(obs2), v(info1), v(info2), v(K1), v(K2),
+                                  C.c_double(th2), int(bool(fix_scale)), v(inl), C.byref(nin)), ctx.handle)
+    return s, inl[:n], nin.value

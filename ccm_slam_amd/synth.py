@@ -374,6 +374,53 @@ def make_pose_problem(n: int = 300, seed: int = 0, outlier_frac: float = 0.1, po
                 is_outlier=out)
 
 
+def make_sim3_problem(n: int = 150, seed: int = 0, outlier_frac: float = 0.1, fix_scale: bool = False,
+                      sigma_r_deg: float = 1.0, sigma_t: float = 0.03, sigma_s: float = 0.02):
+    """One loop / map-match candidate for Optimizer::OptimizeSim3 (Optimizer.cpp:861-1056): n map-point pairs, each point
+    given in its own keyframe's camera frame (P1c = R1w*X1+t1w, P2c likewise, f32-rounded like the cv::Mat products at
+    :925-936), undistorted f32 keypoints with octave-dependent noise in both keyframes, a fraction of wrong pairs, and a
+    perturbed initial S12 (the Sim3Solver RANSAC estimate).  sim3 layout = [qx qy qz qw tx ty tz s]."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = EUROC_K
+    s_true = 1.0 if fix_scale else float(rng.uniform(0.8, 1.25))
+    R12 = rodrigues(rng.normal(size=(1, 3)) * np.deg2rad(6.0))[0]
+    t12 = rng.uniform(-0.4, 0.4, 3)
+    P1, P2 = [], []
+    while len(P2) < n:
+        depth = rng.uniform(2.0, 9.0)
+        u, v = rng.uniform(40, IMG_W - 40), rng.uniform(40, IMG_H - 40)
+        X2 = np.array([(u - cx) / fx * depth, (v - cy) / fy * depth, depth])
+        X1 = s_true * (R12 @ X2) + t12
+        if X1[2] < 0.8:
+            continue
+        u1, v1 = fx * X1[0] / X1[2] + cx, fy * X1[1] / X1[2] + cy
+        if not (20 < u1 < IMG_W - 20 and 20 < v1 < IMG_H - 20):
+            continue
+        P1.append(X1); P2.append(X2)
+    P1, P2 = np.array(P1), np.array(P2)
+    _, _, _, inv_s2 = scale_tables()
+    oct1 = np.clip(np.ceil(np.log(10.0 / P1[:, 2]) / np.log(SCALE)), 0, N_LEVELS - 1).astype(np.int64)
+    oct2 = np.clip(np.ceil(np.log(10.0 / P2[:, 2]) / np.log(SCALE)), 0, N_LEVELS - 1).astype(np.int64)
+
+    def proj(P):
+        return np.stack([fx * P[:, 0] / P[:, 2] + cx, fy * P[:, 1] / P[:, 2] + cy], 1)
+    obs1 = proj(P1) + rng.normal(size=(n, 2)) * (SCALE ** oct1)[:, None]
+    obs2 = proj(P2) + rng.normal(size=(n, 2)) * (SCALE ** oct2)[:, None]
+    out = rng.random(n) < outlier_frac
+    obs1 += out[:, None] * rng.uniform(8, 40, (n, 2)) * rng.choice([-1.0, 1.0], (n, 2))
+    # the two maps disagree slightly about the 3-D points
+    P1 = (P1 + rng.normal(size=P1.shape) * 0.01).astype(np.float32).astype(np.float64)
+    P2 = (P2 + rng.normal(size=P2.shape) * 0.01).astype(np.float32).astype(np.float64)
+    dR = rodrigues(rng.normal(size=(1, 3)) * np.deg2rad(sigma_r_deg))[0]
+    s0 = 1.0 if fix_scale else s_true * float(np.exp(rng.normal() * sigma_s))
+    sim0 = np.concatenate([quat_from_R((dR @ R12)[None])[0], t12 + rng.normal(size=3) * sigma_t, [s0]])
+    gt = np.concatenate([quat_from_R(R12[None])[0], t12, [s_true]])
+    return dict(sim3=sim0, P1c=P1, P2c=P2, obs1=obs1.astype(np.float32).astype(np.float64),
+                obs2=obs2.astype(np.float32).astype(np.float64), info1=inv_s2[oct1].astype(np.float64),
+                info2=inv_s2[oct2].astype(np.float64), K1=np.array(EUROC_K), K2=np.array(EUROC_K), th2=10.0,
+                fix_scale=bool(fix_scale), gt_sim3=gt, is_outlier=out)
+
+
 def make_vocabulary(k: int = 10, L: int = 4, seed: int = 0, stop_frac: float = 0.02):
     """Synthetic DBoW2-style vocabulary tree (the real ORBvoc.txt is a missing blob): complete k-ary
     tree of depth L in breadth-first node order, node descriptors = parent's with ~12 % of the bits flipped, leaf words

@@ -60,7 +60,7 @@ enum {
   CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
   CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
   CCM_K_BA_SCHUR_DIAG, CCM_K_BA_SCHUR_OFF, CCM_K_BA_PCG_SPMV, CCM_K_BA_PCG_UPDATE,
-  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_COUNT
+  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_COUNT
 };
 int ccm_prof_enable(ccm_ctx* ctx, int kernel_class /* -1: all, -2: none */);
 int ccm_prof_reset(ccm_ctx* ctx);
@@ -243,6 +243,19 @@ int ccm_comm_destroy(ccm_ctx* ctx);
 int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const double* Xw /*n*3*/,
                       const double* obs /*n*2*/, const double* info /*n*/, const double K[4],
                       uint8_t* outlier, int* n_inlier);
+
+/* Sim3 between two keyframes from matched map points: Optimizer::OptimizeSim3 (Optimizer.cpp:861-1056).
+ * sim3 = g2oS12 as [qx qy qz qw tx ty tz s] (in: Sim3Solver estimate, out: optimised; untouched when the call
+ * returns *n_inlier = 0 because fewer than 10 pairs survive the first pass, :1015-1016).  Per valid pair i
+ * (the shim filters null / bad map points and i2 < 0, :911-947): P1c = R1w*X1+t1w and P2c = R2w*X2+t2w (the fixed
+ * VertexSBAPointXYZ estimates), obs1/obs2 = undistorted keypoints in KF1/KF2, info = mvInvLevelSigma2[octave].
+ * Edges EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ (types_seven_dof_expmap.h:133-172) with g2o's numeric
+ * Jacobians (base_binary_edge.hpp:129-196), Huber (float)sqrt(th2), optimize(5) + optimize(10|5).
+ * inlier[i] = 0 where the reference nulls vpMatches1[idx]. */
+int  ccm_sim3_optimize(ccm_ctx* ctx, double sim3[8], int n, const double* P1c, const double* P2c,
+                       const double* obs1, const double* obs2, const double* info1, const double* info2,
+                       const double K1[4], const double K2[4], double th2, int fix_scale,
+                       uint8_t* inlier, int* n_inlier);
 
 #ifdef __cplusplus
 }

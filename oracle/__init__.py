@@ -205,6 +205,21 @@ def pose_optimize(cam_qt, Xw, obs, info, K):
     return cam, outl[:n], int(ninl)
 
 
+def sim3_optimize(sim3, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2=10.0, fix_scale=False):
+    """Optimizer::OptimizeSim3 restated (ora_sim3_optimize).  Returns (sim3, inlier flags, nIn)."""
+    f = lambda a: np.ascontiguousarray(a, np.float64)
+    s = f(sim3).copy()
+    P1c, P2c, obs1, obs2, info1, info2, K1, K2 = map(f, (P1c, P2c, obs1, obs2, info1, info2, K1, K2))
+    n = P1c.shape[0]
+    inl = np.zeros(max(n, 1), np.uint8)
+    fn = lib().ora_sim3_optimize
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_double, C.c_int, C.c_void_p]
+    nin = fn(s.ctypes.data, n, P1c.ctypes.data, P2c.ctypes.data, obs1.ctypes.data, obs2.ctypes.data, info1.ctypes.data,
+             info2.ctypes.data, K1.ctypes.data, K2.ctypes.data, float(th2), int(bool(fix_scale)), inl.ctypes.data)
+    return s, inl[:n], int(nin)
+
+
 # ---- ORB extractor ---------------------------------------------------------------------------------
 KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
                      ("response", np.float32), ("octave", np.int32)])

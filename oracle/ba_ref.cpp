@@ -815,6 +815,90 @@ int ora_ba_partial_system(int n_cam, int n_pt, int n_edge, const double* cam_qt,
 }
 
 // ------------------------------------------------------------------------------------------------
+// g2o::Sim3 (thirdparty/g2o/g2o/types/sim3.h).  The quaternion is NOT re-normalised by operator* or by the
+// exponential-map constructor, exactly as upstream.
+struct Sim3 { Quat r; double t[3]; double s; };
+
+// Sim3(const Vector7d& update) (sim3.h:72-140); update = [omega(3), upsilon(3), sigma]
+inline Sim3 sim3_exp(const double u[7]) {
+  const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+  const double sigma = u[6];
+  const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+  const M3 Om = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+  M3 Om2;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double a = 0; for (int k = 0; k < 3; k++) a += Om[i * 3 + k] * Om[k * 3 + j];
+    Om2[i * 3 + j] = a;
+  }
+  Sim3 S;
+  S.s = std::exp(sigma);
+  const double eps = 0.00001;
+  double A, B, C;
+  M3 R;
+  auto small_R = [&]() { for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i]; };
+  auto full_R = [&]() {
+    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta);
+    for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+  };
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (theta < eps) { A = 1. / 2.; B = 1. / 6.; small_R(); }
+    else {
+      const double theta2 = theta * theta;
+      A = (1 - std::cos(theta)) / theta2;
+      B = (theta - std::sin(theta)) / (theta2 * theta);
+      full_R();
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (theta < eps) {
+      const double sigma2 = sigma * sigma;
+      A = ((sigma - 1) * S.s + 1) / sigma2;
+      B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+      small_R();
+    } else {
+      full_R();
+      const double a = S.s * std::sin(theta), b = S.s * std::cos(theta);
+      const double theta2 = theta * theta, sigma2 = sigma * sigma;
+      const double c = theta2 + sigma2;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+    }
+  }
+  S.r = RtoQ(R);
+  for (int i = 0; i < 3; i++) {
+    double acc = 0;
+    for (int k = 0; k < 3; k++) {
+      const double W = A * Om[i * 3 + k] + B * Om2[i * 3 + k] + C * ((i == k) ? 1.0 : 0.0);
+      acc += W * up[k];
+    }
+    S.t[i] = acc;
+  }
+  return S;
+}
+inline Sim3 sim3_mul(const Sim3& a, const Sim3& b) {      // sim3.h:272-278
+  Sim3 r;
+  r.r = qmul(a.r, b.r);
+  double rt[3]; qrot(a.r, b.t, rt);
+  for (int i = 0; i < 3; i++) r.t[i] = a.s * rt[i] + a.t[i];
+  r.s = a.s * b.s;
+  return r;
+}
+inline Sim3 sim3_inv(const Sim3& a) {                     // sim3.h:240-243
+  Sim3 r;
+  r.r = {-a.r.x, -a.r.y, -a.r.z, a.r.w};
+  const double k = -1. / a.s;
+  const double v[3] = {k * a.t[0], k * a.t[1], k * a.t[2]};
+  qrot(r.r, v, r.t);
+  r.s = 1. / a.s;
+  return r;
+}
+inline void sim3_map(const Sim3& S, const double X[3], double out[3]) {   // sim3.h:142-144
+  double r[3]; qrot(S.r, X, r);
+  for (int i = 0; i < 3; i++) out[i] = S.s * r[i] + S.t[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Optimizer::PoseOptimizationClient — cslam/src/Optimizer.cpp:215-347, flat restatement.
 // One SE3 vertex, unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.h:143-171,
 // .cpp:266-288), Huber delta = (float)sqrt(5.991), 4 rounds x optimize(10) restarted from the input
@@ -918,6 +1002,147 @@ int ora_pose_optimize(double* cam_qt, int n, const double* Xw, const double* obs
   cam_qt[0] = T.q.x; cam_qt[1] = T.q.y; cam_qt[2] = T.q.z; cam_qt[3] = T.q.w;
   cam_qt[4] = T.t[0]; cam_qt[5] = T.t[1]; cam_qt[6] = T.t[2];
   return n - nBad;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer::OptimizeSim3 — cslam/src/Optimizer.cpp:861-1056, flat restatement.
+// One VertexSim3Expmap (oplus: Sim3(update) * estimate, update[6] zeroed when _fix_scale,
+// types_seven_dof_expmap.h:58-67); per correspondence i two edges with FIXED point vertices:
+//   e12_i (EdgeSim3ProjectXYZ, :133-151):        obs1 - cam_map1(project(S12.map(P2c)))
+//   e21_i (EdgeInverseSim3ProjectXYZ, :154-172): obs2 - cam_map2(project(S12.inverse().map(P1c)))
+// info = invSigma2 * I, Huber delta = (float)sqrt(th2).  Neither edge overrides linearizeOplus, so g2o
+// differentiates NUMERICALLY (base_binary_edge.hpp:129-196: central differences, delta 1e-9, through the
+// vertex oplus) — restated literally because it defines the reference's Jacobian to ~1e-7.
+// BlockSolverX + LinearSolverDense (7x7), Levenberg.  optimize(5); drop pairs with chi2 > th2 on either edge;
+// optimize(10 if any dropped else 5) on the rest; count inliers.  Returns 0 and leaves sim3 untouched when
+// fewer than 10 pairs survive the first pass (:1015-1016).
+// sim3 = [qx qy qz qw tx ty tz s];  inlier[i] = 1 while vpMatches1[idx] stays non-null.
+int ora_sim3_optimize(double* sim3, int n, const double* P1c, const double* P2c, const double* obs1, const double* obs2,
+                      const double* info1, const double* info2, const double* K1, const double* K2, double th2, int fix_scale,
+                      uint8_t* inlier) {
+  Sim3 S;
+  S.r = {sim3[0], sim3[1], sim3[2], sim3[3]};
+  S.t[0] = sim3[4]; S.t[1] = sim3[5]; S.t[2] = sim3[6]; S.s = sim3[7];
+  const double delta = (double)(float)std::sqrt((float)th2);   // const float deltaHuber = sqrt(th2), th2 is float (:908)
+  vector<uint8_t> alive(n, 1);
+  vector<double> err(4 * (size_t)n, 0.0);   // [e12 (2) | e21 (2)] per pair
+  for (int i = 0; i < n; i++) inlier[i] = 1;
+  auto err12 = [&](const Sim3& X, int i, double e[2]) {
+    double p[3]; sim3_map(X, P2c + 3 * (size_t)i, p);
+    e[0] = obs1[2 * i] - ((p[0] / p[2]) * K1[0] + K1[2]);
+    e[1] = obs1[2 * i + 1] - ((p[1] / p[2]) * K1[1] + K1[3]);
+  };
+  auto err21 = [&](const Sim3& Xinv, int i, double e[2]) {
+    double p[3]; sim3_map(Xinv, P1c + 3 * (size_t)i, p);
+    e[0] = obs2[2 * i] - ((p[0] / p[2]) * K2[0] + K2[2]);
+    e[1] = obs2[2 * i + 1] - ((p[1] / p[2]) * K2[1] + K2[3]);
+  };
+  auto oplus = [&](const Sim3& X, const double* upd) {
+    double u[7]; for (int k = 0; k < 7; k++) u[k] = upd[k];
+    if (fix_scale) u[6] = 0;
+    return sim3_mul(sim3_exp(u), X);
+  };
+  auto chi2_of = [&](const double* e, double om) { return (e[0] * e[0] + e[1] * e[1]) * om; };
+  auto optimize = [&](int iters) {
+    vector<int> act;
+    for (int i = 0; i < n; i++) if (alive[i]) act.push_back(i);
+    if (act.empty()) return;
+    double lambda = 0, ni = 2; int nBadLM = 0;
+    auto chi2_active = [&]() {
+      const Sim3 Sinv = sim3_inv(S);
+      double chi = 0;
+      for (int i : act) {
+        err12(S, i, &err[4 * (size_t)i]);
+        err21(Sinv, i, &err[4 * (size_t)i + 2]);
+        double rho[3];
+        huber(chi2_of(&err[4 * (size_t)i], info1[i]), delta, rho); chi += rho[0];
+        huber(chi2_of(&err[4 * (size_t)i + 2], info2[i]), delta, rho); chi += rho[0];
+      }
+      return chi;
+    };
+    for (int iter = 0; iter < iters; iter++) {
+      double currentChi = chi2_active();
+      const double iniChi = currentChi;
+      // numeric Jacobians: the 14 perturbed estimates are the same for every edge
+      Sim3 Sp[7], Sm[7], Spi[7], Smi[7];
+      const double dlt = 1e-9, scalar = 1.0 / (2 * dlt);
+      for (int d = 0; d < 7; d++) {
+        double add[7] = {0, 0, 0, 0, 0, 0, 0};
+        add[d] = dlt;  Sp[d] = oplus(S, add); Spi[d] = sim3_inv(Sp[d]);
+        add[d] = -dlt; Sm[d] = oplus(S, add); Smi[d] = sim3_inv(Sm[d]);
+      }
+      double H[49] = {0}, b[7] = {0};
+      auto add_edge = [&](const double J[14], const double* e, double om) {
+        double rho[3]; huber(chi2_of(e, om), delta, rho);
+        const double w = rho[1];
+        const double o0 = -om * e[0] * w, o1 = -om * e[1] * w, wom = w * om;
+        for (int r = 0; r < 7; r++) {
+          b[r] += J[r] * o0 + J[7 + r] * o1;
+          for (int c = 0; c < 7; c++) H[r * 7 + c] += (J[r] * wom) * J[c] + (J[7 + r] * wom) * J[7 + c];
+        }
+      };
+      for (int i : act) {
+        double J[14];
+        for (int d = 0; d < 7; d++) {
+          double ep[2], em[2];
+          err12(Sp[d], i, ep); err12(Sm[d], i, em);
+          J[d] = scalar * (ep[0] - em[0]); J[7 + d] = scalar * (ep[1] - em[1]);
+        }
+        add_edge(J, &err[4 * (size_t)i], info1[i]);
+        for (int d = 0; d < 7; d++) {
+          double ep[2], em[2];
+          err21(Spi[d], i, ep); err21(Smi[d], i, em);
+          J[d] = scalar * (ep[0] - em[0]); J[7 + d] = scalar * (ep[1] - em[1]);
+        }
+        add_edge(J, &err[4 * (size_t)i + 2], info2[i]);
+      }
+      if (iter == 0) { double m = 0; for (int j = 0; j < 7; j++) m = std::max(std::fabs(H[j * 8]), m); lambda = 1e-5 * m; ni = 2; nBadLM = 0; }
+      double rho = 0, tempChi; int qmax = 0; double xs[7];
+      do {
+        const Sim3 backup = S;
+        vector<double> A(49);
+        for (int q = 0; q < 49; q++) A[q] = H[q];
+        for (int q = 0; q < 7; q++) A[q * 8] += lambda;
+        const bool ok2 = dense_chol_solve(A, 7, b, xs);
+        if (!ok2) for (int q = 0; q < 7; q++) xs[q] = 0;
+        S = oplus(S, xs);
+        tempChi = chi2_active();
+        if (!ok2) tempChi = std::numeric_limits<double>::max();
+        rho = currentChi - tempChi;
+        double scale = 0;
+        for (int j = 0; j < 7; j++) scale += xs[j] * (lambda * xs[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2; currentChi = tempChi;
+        } else { lambda *= ni; ni *= 2; S = backup; }
+        qmax++;
+      } while (rho < 0 && qmax < 10);
+      if (qmax == 10 || rho == 0) break;
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+      if (nBadLM >= 3) break;
+    }
+  };
+  optimize(5);
+  int nBad = 0;
+  for (int i = 0; i < n; i++)   // e->chi2() reads the _error of the last evaluated trial (no recompute after a rejected step)
+    if (chi2_of(&err[4 * (size_t)i], info1[i]) > th2 || chi2_of(&err[4 * (size_t)i + 2], info2[i]) > th2) { alive[i] = 0; inlier[i] = 0; nBad++; }
+  const int more = nBad > 0 ? 10 : 5;
+  if (n - nBad < 10) return 0;
+  optimize(more);
+  int nIn = 0;
+  for (int i = 0; i < n; i++) {
+    if (!alive[i]) continue;
+    if (chi2_of(&err[4 * (size_t)i], info1[i]) > th2 || chi2_of(&err[4 * (size_t)i + 2], info2[i]) > th2) inlier[i] = 0;
+    else nIn++;
+  }
+  sim3[0] = S.r.x; sim3[1] = S.r.y; sim3[2] = S.r.z; sim3[3] = S.r.w;
+  sim3[4] = S.t[0]; sim3[5] = S.t[1]; sim3[6] = S.t[2]; sim3[7] = S.s;
+  return nIn;
 }
 
 }  // extern "C"

@@ -243,3 +243,16 @@ def test_vocabulary_transform_class(hostlib, oracle_lib):
     assert np.array_equal(fn[:nn], exp_nodes) and ni == keep.sum()
     for k, nd in enumerate(exp_nodes):
         assert np.array_equal(fi[fo[k]:fo[k + 1]], np.nonzero(keep & (onode == nd))[0])
+
+
+def test_optimize_sim3_class_method(hostlib, oracle_lib):
+    p = synth.make_sim3_problem(120, 11)
+    s = p["sim3"].copy()
+    keep = np.zeros(120, np.uint8)
+    f = lambda a: _p(np.ascontiguousarray(a, np.float64))
+    arrs = [np.ascontiguousarray(p[k], np.float64) for k in ("P1c", "P2c", "obs1", "obs2", "info1", "info2", "K1", "K2")]
+    hostlib.ccmh_optimize_sim3.argtypes = [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_void_p]
+    nin = hostlib.ccmh_optimize_sim3(0, _p(s), 120, *[_p(a) for a in arrs], 10.0, 0, _p(keep))
+    so, keepo, nino = oracle_lib.sim3_optimize(p["sim3"], p["P1c"], p["P2c"], p["obs1"], p["obs2"], p["info1"], p["info2"], p["K1"], p["K2"], 10.0, False)
+    assert nin == nino and np.array_equal(keep, keepo)
+    assert np.abs(s - so).max() < 1e-6
