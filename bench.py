@@ -181,6 +181,8 @@ def main():
     E, L, C, B, P = counts["edges"], counts["points"], counts["free_cams"], counts["blocks"], counts["pairs"]
     n_off = B - C
     alg_bytes = {
+        # persistent single-launch PCG: one launch = (CG iterations of one LM trial) x the per-iteration figure below
+        "BA_PCG_PERSIST": (288.0 * B + 4 * 48.0 * C) * (pcg / max(launches, 1)),
         # q = S p over the symmetric block matrix read once + z,p in, q,p out
         "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,
         "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,

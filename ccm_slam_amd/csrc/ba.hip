@@ -600,6 +600,509 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
+// ---- persistent PCG: the WHOLE solve of one LM trial in one cooperative launch ---------------------------------
+// The multi-kernel iteration above costs two launches (~22 us on gba_c4) for ~15 MB of traffic: launch gaps and the
+// dependent index -> block -> vector chains dominate, not HBM.  Here one 16-wave workgroup OWNS one preconditioner
+// cluster (16 cameras) for the entire solve:
+//   * it assembles and factors its 96x96 block once and keeps the explicit inverse W in LDS (72 KiB) — the
+//     preconditioner apply never touches global memory again;
+//   * x, r, q of its rows live in LDS; only z and p (needed by covisible neighbours) go through global memory, with
+//     device-coherent (sc1) loads / stores, so NO cache flush or invalidate is needed at the grid barriers and the
+//     S blocks of the cluster's rows stay resident in the XCD's L2 from one iteration to the next;
+//   * per iteration the p = z + beta p_old entries of the cluster's ~100-200 distinct neighbour columns are fetched
+//     ONCE into LDS (one coherent round trip, all 1024 threads), the row products then read S from L2 and p from
+//     LDS; the CSR structure of the rows is staged in LDS as well;
+//   * one wave per block row, 16 blocks in flight per wave;
+//   * workgroup b runs on XCD b % 8 and takes cluster (b%8)*per_xcd + b/8, so the S blocks shared by neighbouring
+//     clusters are served by one XCD's L2;
+//   * two grid barriers per iteration (after q = S p for p.q, after z = W r for r.z) built on one monotonic
+//     device-scope counter; the dot products are reduced from per-workgroup partials in a fixed order, so every
+//     workgroup derives bit-identical alpha / beta / convergence decisions and the loop stays grid-uniform.
+// A barrier gives up after a bounded spin (abort flag -> solver failure -> LM rejects the step) so a scheduling
+// accident can never hang the device.  Cooperative launch guarantees co-residency; the host uses this path when
+// the cluster count fits (<= 4096 free cameras on 256 CUs), the multi-kernel path otherwise.
+constexpr int kPersTPB = 1024;
+constexpr int kPersWaves = kPersTPB / kWave;
+constexpr long kPersMaxSpins = 3000000;    // x ~60 ns sleep: ~0.2 s per barrier worst case
+constexpr int kPersIdxCap = 3072;          // CSR entries of one cluster's rows (staged in LDS)
+constexpr int kPersColCap = 640;           // distinct neighbour columns of one cluster
+
+struct PersArgs {
+  double lambda, rel_tol;
+  int max_it, n_clu;
+  unsigned* bar;        // [1] abort flag
+  unsigned long long* slots;   // [2][gridDim.x][2]: p.q exchange, r.z exchange
+  unsigned long long epoch_base;   // unique per launch: stale slots of earlier solves never validate
+  const int* uoff;      // [n_clu+1] offsets into ucol
+  const int* ucol;      // distinct columns of each cluster's rows, ascending
+  const int* loc;       // [n_row_entries] position of the entry's column in its cluster's ucol list
+  long long* dbg;       // optional [16] phase clocks of workgroup 0 (wall_clock64 ticks, 10 ns), accumulated over iterations
+};
+
+// a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double in the PCG loop)
+__device__ __forceinline__ double pers_uniform(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double coh_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Grid-wide "barrier + deterministic sum" in one step, without atomics (256 arrivals on one counter serialise at the
+// memory side: measured 6 us per barrier): every workgroup publishes its partial in its own 16-byte slot as
+// {bits(value), bits(value) ^ key(epoch)} and then polls ALL slots (one per thread) until every slot validates against
+// the current epoch's key; the xor check also rejects torn 16-byte reads.  The values are then summed in a fixed order,
+// so every workgroup obtains bit-identical totals.  All cross-workgroup data (z, p, q, slots) moves with device-coherent
+// accesses, so the only ordering needed is: drain this workgroup's stores, meet, publish.
+__device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg, double mine, unsigned long long epoch, unsigned* abort_flag,
+                                              double* red /* [kPersWaves] */, double* total) {
+  const int t = threadIdx.x;
+  const unsigned long long key = 0x9E3779B97F4A7C15ull * epoch;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
+    __hip_atomic_store(slots + 2 * blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + 2 * blockIdx.x + 1, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // only wave 0 polls (4 slots per lane): 16x fewer coherent loads in flight than polling with every thread, which
+  // measurably slowed the workgroups that were still computing
+  double v = 0;
+  bool alive = true;
+  __shared__ int poll_state;
+  if (t < kWave) {
+    for (long spins = 0;; spins++) {
+      bool ok = true;
+      v = 0;
+      for (int i = t; i < nwg; i += kWave) {
+        const unsigned long long b0 = __hip_atomic_load(slots + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b1 = __hip_atomic_load(slots + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((b0 ^ b1) != key) ok = false; else v += __longlong_as_double((long long)b0);
+      }
+      if (__all(ok)) { if (t == 0) poll_state = 1; break; }
+      if (spins > kPersMaxSpins || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        if (t == 0) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); poll_state = 0; }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    v = wave_sum(v);
+    if (t == 0) red[0] = v;
+  }
+  __syncthreads();
+  alive = poll_state != 0;
+  *total = pers_uniform(red[0]);
+  __syncthreads();   // red is reused by the caller's block sums
+  return alive;
+}
+
+#define PERS_TICK(slot) { if (timing) { const long long tn_ = wall_clock64(); tacc[slot] += tn_ - tacc[12]; tacc[12] = tn_; } }
+
+// Assemble the damped 96x96 block of one cluster from the block-CSR rows, factor it (Cholesky blocked by camera) and
+// leave W = (block)^-1 in A.  Kept out of line so that its register-hungry 6x6 temporaries do not compete with the
+// register-resident S rows of the PCG loop.
+__device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibuf, const int* row_off, const int* row_col,
+                                                 const uint32_t* row_blk, const double* S, int s0, int s1, double lambda, bool has,
+                                                 long long* tacc, bool timing) {
+  constexpr int N = kCluN;
+  const int t = threadIdx.x;
+  const int nrows = s1 - s0;
+  const int m = 6 * nrows;
+  // ---- init 1: assemble the damped dense block of the cluster ----
+  for (int i = t; i < N * N; i += kPersTPB) { A[i] = 0; Li[i] = 0; }
+  __syncthreads();
+  if (has) {
+    const int grp = t / 36, e = t % 36, r = e / 6, cc = e % 6;
+    constexpr int kGroups = kPersTPB / 36;
+    if (grp < kGroups)
+      for (int i = s0; i < s1; i++)
+        for (int s = row_off[i] + grp; s < row_off[i + 1]; s += kGroups) {
+          const int j = row_col[s];
+          if (j < s0 || j >= s1) continue;
+          const uint32_t bt = row_blk[s];
+          const double* B = S + 36 * (size_t)(bt & ~kTransposeBit);
+          const double v = (bt & kTransposeBit) ? B[cc * 6 + r] : B[e];
+          A[(6 * (i - s0) + r) * N + 6 * (j - s0) + cc] = v + ((i == j && r == cc) ? lambda : 0.0);
+        }
+  }
+  __syncthreads();
+  PERS_TICK(7)
+  // ---- init 2: Cholesky A = L L^T blocked by camera (6 columns per step, 3 barriers per step instead of 18) ----
+  for (int J = 0; J < nrows; J++) {
+    const int c0 = 6 * J;
+    if (t == 0) {   // 6x6 diagonal block in registers
+      double B6[36];
+#pragma unroll
+      for (int q = 0; q < 36; q++) B6[q] = A[(c0 + q / 6) * N + c0 + q % 6];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double dj = B6[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) dj -= B6[j * 6 + k] * B6[j * 6 + k];
+        if (!(dj > 0.0)) { bad = true; dj = 1.0; }
+        dj = sqrt(dj);
+        B6[j * 6 + j] = dj;
+        const double inv = 1.0 / dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+          double sv = B6[i * 6 + j];
+#pragma unroll
+          for (int k = 0; k < j; k++) sv -= B6[i * 6 + k] * B6[j * 6 + k];
+          B6[i * 6 + j] = sv * inv;
+        }
+      }
+      if (bad) ibuf[1] = 1;
+#pragma unroll
+      for (int q = 0; q < 36; q++) if (q % 6 <= q / 6) A[(c0 + q / 6) * N + c0 + q % 6] = B6[q];
+    }
+    __syncthreads();
+    const int r0 = c0 + 6;
+    if (r0 + t < m) {   // panel: one thread per row below the diagonal block, X L_JJ^T = A_iJ
+      const int i = r0 + t;
+      double x[6];
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        double sv = A[i * N + c0 + cc];
+#pragma unroll
+        for (int k = 0; k < cc; k++) sv -= x[k] * A[(c0 + cc) * N + c0 + k];
+        x[cc] = sv / A[(c0 + cc) * N + c0 + cc];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) A[i * N + c0 + cc] = x[cc];
+    }
+    __syncthreads();
+    const int nr = m - r0;
+    for (int e = t; e < nr * nr; e += kPersTPB) {
+      const int i = r0 + e / nr, j = r0 + e % nr;
+      if (j <= i) {
+        double sv = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) sv += A[i * N + c0 + cc] * A[j * N + c0 + cc];
+        A[i * N + j] -= sv;
+      }
+    }
+    __syncthreads();
+  }
+  PERS_TICK(8)
+  // ---- init 3: Li = L^-1 blocked.  With D = blockdiag(L_JJ): L = D M (M unit block-diagonal), L^-1 = M^-1 D^-1 ----
+  // 3a: Li_JJ = L_JJ^-1 (one thread per camera)
+  if (t < nrows) {
+    const int c0 = 6 * t;
+    double X[21];   // packed lower triangle of the inverse
+#pragma unroll
+    for (int col = 0; col < 6; col++)
+#pragma unroll
+      for (int i = col; i < 6; i++) {
+        double sv = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = col; k < i; k++) sv -= A[(c0 + i) * N + c0 + k] * X[k * (k + 1) / 2 + col];
+        X[i * (i + 1) / 2 + col] = sv / A[(c0 + i) * N + c0 + i];
+      }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int col = 0; col <= i; col++) Li[(c0 + i) * N + c0 + col] = X[i * (i + 1) / 2 + col];
+  }
+  __syncthreads();
+  // 3b: M_IK = Li_II L_IK for every strictly-lower block, in place in A (read row of Li_II, column of L_IK)
+  {
+    const int nblk = nrows * (nrows - 1) / 2;
+    for (int e = t; e < nblk * 36; e += kPersTPB) {
+      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
+      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
+      while (I * (I - 1) / 2 > bi) I--;
+      while ((I + 1) * I / 2 <= bi) I++;
+      const int K = bi - I * (I - 1) / 2;
+      double sv = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) sv += Li[(6 * I + ar) * N + 6 * I + q] * A[(6 * I + q) * N + 6 * K + bc];
+      Li[(6 * K + bc) * N + 6 * I + ar] = sv;   // parked transposed in the (unused) upper triangle of Li
+    }
+  }
+  __syncthreads();
+  {
+    const int nblk = nrows * (nrows - 1) / 2;
+    for (int e = t; e < nblk * 36; e += kPersTPB) {
+      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
+      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
+      while (I * (I - 1) / 2 > bi) I--;
+      while ((I + 1) * I / 2 <= bi) I++;
+      const int K = bi - I * (I - 1) / 2;
+      A[(6 * I + ar) * N + 6 * K + bc] = Li[(6 * K + bc) * N + 6 * I + ar];   // M_IK back into A's lower triangle
+    }
+  }
+  __syncthreads();
+  // 3c: Minv_IJ = -sum_{K=J}^{I-1} M_IK Minv_KJ (Minv_JJ = I), by block distance; results in Li's lower triangle,
+  // still missing the right factor Li_JJ
+  for (int dl = 1; dl < nrows; dl++) {
+    const int cnt = (nrows - dl) * 36;
+    if (t < cnt) {
+      const int J = t / 36, el = t % 36, ar = el / 6, bc = el % 6, I = J + dl;
+      double sv = A[(6 * I + ar) * N + 6 * J + bc];          // K = J term: M_IJ * I
+      for (int K = J + 1; K < I; K++)
+#pragma unroll
+        for (int q = 0; q < 6; q++) sv += A[(6 * I + ar) * N + 6 * K + q] * Li[(6 * K + q) * N + 6 * J + bc];
+      Li[(6 * I + ar) * N + 6 * J + bc] = -sv;
+    }
+    __syncthreads();
+  }
+  // 3d: Li_IJ = Minv_IJ Li_JJ (off-diagonal blocks): read, barrier, write
+  {
+    const int nblk = nrows * (nrows - 1) / 2;
+    double keep[5];   // <= ceil(120*36/1024) = 5 elements per thread
+    int ne = 0;
+    for (int e = t; e < nblk * 36; e += kPersTPB, ne++) {
+      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
+      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
+      while (I * (I - 1) / 2 > bi) I--;
+      while ((I + 1) * I / 2 <= bi) I++;
+      const int J = bi - I * (I - 1) / 2;
+      double sv = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) sv += Li[(6 * I + ar) * N + 6 * J + q] * Li[(6 * J + q) * N + 6 * J + bc];
+      keep[ne] = sv;
+    }
+    __syncthreads();
+    ne = 0;
+    for (int e = t; e < nblk * 36; e += kPersTPB, ne++) {
+      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
+      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
+      while (I * (I - 1) / 2 > bi) I--;
+      while ((I + 1) * I / 2 <= bi) I++;
+      const int J = bi - I * (I - 1) / 2;
+      Li[(6 * I + ar) * N + 6 * J + bc] = keep[ne];
+    }
+  }
+  __syncthreads();
+  // the upper triangle of Li still holds the parked M^T: clear it so that Li is a clean lower-triangular inverse
+  for (int e = t; e < m * m; e += kPersTPB) { const int ar = e / m, bc = e % m; if (bc / 6 > ar / 6) Li[ar * N + bc] = 0.0; }
+  __syncthreads();
+  PERS_TICK(9)
+  // ---- init 4: W = Li^T Li into the A region (the factor is dead) ----
+  for (int e = t; e < m * m; e += kPersTPB) {
+    const int ar = e / m, bcol = e % m;
+    double sv = 0;
+    for (int k = max(ar, bcol); k < m; k++) sv += Li[k * N + ar] * Li[k * N + bcol];
+    A[ar * N + bcol] = sv;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int N = kCluN;
+  double* A = sm;                          // [96][96]: dense cluster block -> Cholesky factor -> W = inverse
+  double* Li = sm + N * N;                 // [96][96]: inverse factor during init, then staged structure + neighbour p
+  double* rc = Li + N * N;                 // r of the own rows
+  double* xs = rc + N;                     // x
+  double* ps = xs + N;                     // p
+  double* qs = ps + N;                     // q
+  double* zs = qs + N;                     // z
+  double* zpart = zs + N;                  // [8][96]
+  double* red = zpart + 8 * N;             // [16]
+  int* ibuf = reinterpret_cast<int*>(red + kPersWaves);   // [0]=ok flag of the barrier, [1]=bad pivot
+  const int t = threadIdx.x, lane = t & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(t / kWave);
+  const int nwg = gridDim.x;               // padded to a multiple of 8
+  const int per_xcd = nwg >> 3;
+  // TWO workgroups per cluster: unit u owns rows [8u, 8u+8) (x, p, q, z of those rows and their S blocks in registers);
+  // both units of a cluster factor the same 96x96 block redundantly and keep the full r of the cluster, so the only
+  // extra exchange is the partner's q (48 values) after the first barrier.
+  const int u = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int c = u >> 1, hu = u & 1;
+  const bool has = c < a.n_clu;
+  const int s0 = has ? c * kClu : 0, s1 = has ? min(d.Cp, s0 + kClu) : 0;
+  const int nrows = s1 - s0;
+  const int m = 6 * nrows;
+  const int o0 = has ? min(s1, s0 + (kClu / 2) * hu) : 0, o1 = has ? min(s1, o0 + kClu / 2) : 0;   // own rows
+  const int nown = o1 - o0;
+  const int mo = 6 * nown;                 // own unknowns
+  const int ob = 6 * (o0 - s0);            // their offset inside the cluster vectors
+  unsigned long long* slots_pq = a.slots;
+  unsigned long long* slots_rz = a.slots + 2 * (size_t)nwg;
+  unsigned long long epoch = a.epoch_base;
+  const double lambda = a.lambda;
+  if (t < 2) ibuf[t] = (t == 0) ? 1 : 0;
+  // optional phase clocks of workgroup 0 / thread 0, accumulated in LDS so that they cost no registers
+  long long* tacc = reinterpret_cast<long long*>(ibuf + 4);   // [13]: 12 phases + last stamp
+  const bool timing = a.dbg != nullptr && blockIdx.x == 0 && t == 0;
+  if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
+  pers_factor_cluster(A, Li, ibuf, d.row_off, d.row_col, d.row_blk, d.S, s0, s1, lambda, has, tacc, timing);
+  // PCG start: x = 0, r = bs, z = W r, p_{-1} = 0
+  if (t < N) { xs[t] = 0; ps[t] = 0; qs[t] = 0; zs[t] = 0; rc[t] = (t < m) ? d.bs[6 * (size_t)s0 + t] : 0.0; }   // xs/ps/zs: own rows; rc/qs: cluster
+  __syncthreads();
+  PERS_TICK(10)
+  // the Li region is dead now: off[32] | loc[kPersIdxCap] | blk[kPersIdxCap] | ucol[kPersColCap] ints, then p of the
+  // neighbour columns [6 * kPersColCap] doubles and the two half-row sums [16][2][8]
+  int* l_off = reinterpret_cast<int*>(Li);
+  int* l_loc = l_off + 32;
+  uint32_t* l_blk = reinterpret_cast<uint32_t*>(l_loc + kPersIdxCap);
+  int* l_ucol = reinterpret_cast<int*>(l_blk + kPersIdxCap);
+  double* pl = reinterpret_cast<double*>(l_ucol + kPersColCap);
+  double* half_sum = pl + 6 * kPersColCap;
+  const int e_base = has ? d.row_off[o0] : 0;
+  const int n_ent = has ? d.row_off[o1] - e_base : 0;
+  const int u_base = has ? a.uoff[u] : 0;
+  const int nu = has ? a.uoff[u + 1] - u_base : 0;
+  if (has) {
+    if (t <= nown) l_off[t] = d.row_off[o0 + t] - e_base;
+    for (int s = t; s < n_ent; s += kPersTPB) { l_loc[s] = a.loc[e_base + s]; l_blk[s] = d.row_blk[e_base + s]; }
+    for (int s = t; s < nu; s += kPersTPB) l_ucol[s] = a.ucol[u_base + s];
+  }
+  if (t < 6) pl[t] = 0.0;   // padding entries of the register-resident rows point at column slot 0
+  __syncthreads();
+  // ---- the S blocks of the own rows go into REGISTERS once: two waves per row, 8 entries in flight per wave,
+  // lane (g, r) keeps row r of its entries (transposition resolved here).  Rows longer than 16*kPersRegEnt blocks
+  // read the tail from global memory every iteration.
+  constexpr int kPersRegEnt = 6;
+  const int row_l = wv >> 1, half = wv & 1, g = lane >> 3, r = lane & 7;
+  const bool row_ok = has && row_l < nown && r < 6;
+  double sreg[kPersRegEnt][6];
+  int jreg[kPersRegEnt];
+  int e_tail = 0, e_end = 0;
+  {
+    const int e0 = row_ok ? l_off[row_l] : 0;
+    e_end = row_ok ? l_off[row_l + 1] : 0;
+#pragma unroll
+    for (int k = 0; k < kPersRegEnt; k++) {
+      const int s = e0 + half * 8 + g + 16 * k;
+      const bool v = row_ok && s < e_end;
+      jreg[k] = v ? 6 * l_loc[s] : 0;
+      const uint32_t bt = v ? l_blk[s] : 0u;
+      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+#pragma unroll
+      for (int q = 0; q < 6; q++) sreg[k][q] = v ? ((bt & kTransposeBit) ? B[q * 6 + r] : B[r * 6 + q]) : 0.0;
+    }
+    e_tail = e0 + half * 8 + g + 16 * kPersRegEnt;
+  }
+  auto apply_W = [&]() {          // z(own rows) = W[own rows, :] rc; publishes them; returns this thread's share of r.z
+    {
+      const int row = t % (N / 2), prt = t / (N / 2);       // 48 rows x 16 column parts (6 columns each) = 768 threads
+      if (prt < 16) {
+        double sv = 0;
+        if (row < mo) {
+          const int c0 = prt * 6;
+#pragma unroll
+          for (int col = 0; col < 6; col++) sv += A[(c0 + col) * N + ob + row] * rc[c0 + col];   // W symmetric: column access
+        }
+        zpart[prt * (N / 2) + row] = sv;
+      }
+    }
+    __syncthreads();
+    double rz = 0;
+    if (t < mo) {
+      double z = zpart[t];
+#pragma unroll
+      for (int q = 1; q < 16; q++) z += zpart[q * (N / 2) + t];
+      zs[t] = z;
+      coh_store(d.z + 6 * (size_t)o0 + t, z);
+      rz = rc[ob + t] * z;
+    }
+    return rz;
+  };
+  auto block_total = [&](double v) {   // fixed-order workgroup sum, valid in every thread
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    double sv = 0;
+#pragma unroll
+    for (int w = 0; w < kPersWaves; w++) sv += red[w];
+    return sv;
+  };
+  double rz_init = 0;
+  {
+    double rz = apply_W();
+    if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
+    rz_init = block_total(rz);
+    if (has && ibuf[1]) rz_init = __longlong_as_double(0x7ff8000000000000ll);   // bad pivot -> NaN -> grid-wide failure
+  }
+  int fail = 0, k = 0;
+  double rz = 0;
+  bool alive = pers_exchange(slots_rz, nwg, rz_init, ++epoch, a.bar + 1, red, &rz);
+  const double rz0 = rz;
+  const double thresh = a.rel_tol * a.rel_tol;
+  double rz_prev = rz;
+  if (!alive) fail = 1;
+  PERS_TICK(11)
+  for (; alive && k < a.max_it; k++) {
+    if (rz <= thresh * rz0 || !(rz > 0.0)) { if (rz != rz) fail = 1; break; }
+    const double beta = pers_uniform((k == 0) ? 0.0 : rz / rz_prev);
+    const double* pold = d.p[k & 1];
+    double* pnew = d.p[(k + 1) & 1];
+    // ---- p = z + beta p_old of every neighbour column, once, into LDS ----
+    for (int idx = t; idx < 6 * nu; idx += kPersTPB) {
+      const int j = l_ucol[idx / 6], q = idx % 6;
+      pl[idx] = coh_load(d.z + 6 * (size_t)j + q) + beta * coh_load(pold + 6 * (size_t)j + q);
+    }
+    __syncthreads();
+    PERS_TICK(0)
+    // ---- q = (S + lambda I) p for the own rows: registers x LDS ----
+    {
+      double acc = 0;
+#pragma unroll
+      for (int kk = 0; kk < kPersRegEnt; kk++) {
+        const double* pj = pl + jreg[kk];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += sreg[kk][q] * pj[q];
+      }
+      for (int s = e_tail; s < e_end; s += 16) {   // tail of very long rows
+        const uint32_t bt = l_blk[s];
+        const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+        const double* pj = pl + 6 * l_loc[s];
+#pragma unroll
+        for (int q = 0; q < 6; q++) acc += ((bt & kTransposeBit) ? B[q * 6 + r] : B[r * 6 + q]) * pj[q];
+      }
+      acc += __shfl_xor(acc, 8, kWave);
+      acc += __shfl_xor(acc, 16, kWave);
+      acc += __shfl_xor(acc, 32, kWave);
+      if (lane < 8) half_sum[(row_l * 2 + half) * 8 + lane] = acc;
+    }
+    __syncthreads();
+    double pq_t = 0;
+    if (t < mo) {
+      const int rw = t / 6, cc = t % 6;
+      const double pi = zs[t] + beta * ps[t];
+      const double qv = (half_sum[(rw * 2) * 8 + cc] + half_sum[(rw * 2 + 1) * 8 + cc]) + lambda * pi;
+      ps[t] = pi;
+      qs[ob + t] = qv;
+      coh_store(pnew + 6 * (size_t)o0 + t, pi);
+      coh_store(d.q + 6 * (size_t)o0 + t, qv);     // the partner unit needs it for its copy of r
+      pq_t = pi * qv;
+    }
+    const double pqt = block_total(pq_t);
+    PERS_TICK(1)
+    double pq = 0;
+    alive = pers_exchange(slots_pq, nwg, pqt, ++epoch, a.bar + 1, red, &pq);
+    PERS_TICK(2)
+    if (!alive) { fail = 1; break; }
+    const double q_partner = (t < m && !(t >= ob && t < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + t) : 0.0;
+    if (!(pq > 0.0)) { fail = 1; break; }   // not positive definite (or NaN): solver failure -> LM rejects the step
+    PERS_TICK(3)
+    const double alpha = pers_uniform(rz / pq);
+    if (t < mo) xs[t] += alpha * ps[t];
+    if (t < m) rc[t] -= alpha * ((t >= ob && t < ob + mo) ? qs[t] : q_partner);
+    __syncthreads();
+    const double rzt = block_total(apply_W());
+    PERS_TICK(4)
+    rz_prev = rz;
+    alive = pers_exchange(slots_rz, nwg, rzt, ++epoch, a.bar + 1, red, &rz);
+    PERS_TICK(5)
+    if (!alive) { fail = 1; break; }
+    PERS_TICK(6)
+  }
+#undef PERS_TICK
+  if (timing) { for (int q = 0; q < 12; q++) a.dbg[q] += tacc[q]; a.dbg[12] += k; a.dbg[13] += 1; }
+  if (t < mo) d.x[6 * (size_t)o0 + t] = xs[t];
+  if (blockIdx.x == 0 && t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = fail; }
+}
+
+static inline size_t pers_lds_bytes() {
+  return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves) * sizeof(double) + 16 + 14 * sizeof(long long);
+}
+
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
 // A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
 // the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
@@ -823,6 +1326,9 @@ struct ccm_ba {
   BaDev d{};
   int cur = 0;
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
+  unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
+  int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr;
+  unsigned long long pers_launch = 0;
   double* d_pt_full = nullptr; int* d_own_slot = nullptr;
   double* d_hpp_full = nullptr;
   double ms_setup = 0;
@@ -1012,6 +1518,28 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     }
   }
   ba->n_row_entries = row_cnt[Cp];
+  // persistent PCG: per cluster the ascending list of distinct columns its rows touch + every entry's position in it
+  std::vector<int> pers_uoff, pers_ucol, pers_loc;
+  bool pers_fits = Cp > kSmallMaxCp;
+  if (pers_fits) {
+    const int n_clu = 2 * ccm_div_up(Cp, kClu);   // units of kClu/2 rows (two workgroups per cluster)
+    pers_uoff.assign(n_clu + 1, 0);
+    pers_loc.resize(row_cnt[Cp]);
+    std::vector<int> mark(Cp, -1), cols;
+    for (int c = 0; c < n_clu && pers_fits; c++) {
+      const int r0 = std::min(Cp, (c >> 1) * kClu + (c & 1) * (kClu / 2)), r1 = std::min({Cp, r0 + kClu / 2, ((c >> 1) + 1) * kClu});
+      cols.clear();
+      for (int s2 = row_cnt[r0]; s2 < row_cnt[r1]; s2++) if (mark[row_col[s2]] != c) { mark[row_col[s2]] = c; cols.push_back(row_col[s2]); }
+      std::sort(cols.begin(), cols.end());
+      if ((int)cols.size() > kPersColCap || row_cnt[r1] - row_cnt[r0] > kPersIdxCap) { pers_fits = false; break; }
+      // reuse mark as column -> local index for this cluster (values >= n_clu never collide with cluster ids < n_clu)
+      for (size_t q = 0; q < cols.size(); q++) mark[cols[q]] = n_clu + (int)q;
+      for (int s2 = row_cnt[r0]; s2 < row_cnt[r1]; s2++) pers_loc[s2] = mark[row_col[s2]] - n_clu;
+      for (size_t q = 0; q < cols.size(); q++) mark[cols[q]] = -1;
+      pers_ucol.insert(pers_ucol.end(), cols.begin(), cols.end());
+      pers_uoff[c + 1] = (int)pers_ucol.size();
+    }
+  }
 
   // ---- local edge arrays ----
   std::vector<int> pt_off(Lloc + 1), ed_cam(Eloc), ed_cslot(Eloc), ed_pt(Eloc);
@@ -1072,6 +1600,25 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
   if (int rc = dev_alloc<double>(ba, 3 * (size_t)std::max(Lp, 1), &ba->d_pt_full)) return fail(rc);
   if (int rc = dev_alloc<double>(ba, 36 * (size_t)std::max(Cp, 1), &ba->d_hpp_full)) return fail(rc);
+  // persistent single-launch PCG: usable when every cluster's workgroup can be co-resident (cooperative launch)
+  ba->pers_grid = 0;
+  if (pers_fits && !getenv("CCM_BA_NO_PERSIST")) {
+    const int n_clu = ccm_div_up(Cp, kClu);
+    const int grid = ((2 * n_clu + 7) / 8) * 8;   // two workgroups per cluster
+    const size_t lds = pers_lds_bytes();
+    int per_cu = 0, n_cu = 0;
+    if (hipFuncSetAttribute((const void*)ba_pcg_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_pcg_persist, kPersTPB, lds) == hipSuccess &&
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid) {
+      if (int rc2 = dev_alloc<unsigned>(ba, 4 + 2 * 16, &ba->d_pers_bar)) return fail(rc2);   // + debug clocks
+      if (int rc2 = dev_alloc<double>(ba, 4 * (size_t)grid, &ba->d_pers_part)) return fail(rc2);   // [2][grid] 16-byte slots
+      if (int rc2 = dev_upload(ba, pers_uoff, &ba->d_pers_uoff)) return fail(rc2);
+      if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
+      if (int rc2 = dev_upload(ba, pers_loc, &ba->d_pers_loc)) return fail(rc2);
+      ba->pers_grid = grid;
+    }
+    (void)hipGetLastError();
+  }
   int rc = ccm_ba_reset_state(ba, P->cam_qt, P->pt_xyz);
   if (rc) return fail(rc);
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1229,6 +1776,22 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         hipLaunchKernelGGL(ba_pcg_small<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
       }
       small_path = true;
+    } else if (ba->pers_grid) {
+      // whole solve in one cooperative launch; flags are read back together with the trial scalars
+      CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pers_bar, 0, 4 * sizeof(unsigned), ctx->stream));
+      PersArgs pa;
+      pa.lambda = lambda; pa.rel_tol = tol; pa.max_it = max_it; pa.n_clu = ccm_div_up(d.Cp, kClu);
+      pa.bar = ba->d_pers_bar; pa.slots = (unsigned long long*)ba->d_pers_part;
+      pa.epoch_base = (++ba->pers_launch) << 20;
+      pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
+      pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
+      void* kargs[2] = {(void*)&d, (void*)&pa};
+      {
+        ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
+        CCM_HIP_CHECK(ctx, hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
+                                                      (unsigned)pers_lds_bytes(), ctx->stream));
+      }
+      small_path = true;
     } else {
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
       {
@@ -1307,6 +1870,17 @@ extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* o
   return CCM_OK;
 }
 
+static void pers_dbg_dump(ccm_ba* ba) {
+  if (!ba->pers_grid || !getenv("CCM_BA_PERS_DBG")) return;
+  long long h[16];
+  hipMemcpy(h, ba->d_pers_bar + 4, sizeof(h), hipMemcpyDeviceToHost);
+  const double it = (double)std::max<long long>(h[12], 1), nl = (double)std::max<long long>(h[13], 1);
+  fprintf(stderr, "[ccm_ba] persistent PCG, workgroup 0: %lld iterations in %lld launches; us/iteration: stage_p %.2f spmv+dot %.2f barrier1 %.2f "
+          "sum_pq %.2f update+W %.2f barrier2 %.2f sum_rz %.2f | us/launch: assemble %.1f cholesky %.1f inverse %.1f W %.1f start %.1f\n",
+          h[12], h[13], h[0] * 0.01 / it, h[1] * 0.01 / it, h[2] * 0.01 / it, h[3] * 0.01 / it, h[4] * 0.01 / it, h[5] * 0.01 / it, h[6] * 0.01 / it,
+          h[7] * 0.01 / nl, h[8] * 0.01 / nl, h[9] * 0.01 / nl, h[10] * 0.01 / nl, h[11] * 0.01 / nl);
+}
+
 extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volatile unsigned char* stop_flag, ccm_ba_stats* stats) {
   if (!ba) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
@@ -1374,6 +1948,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   st.ms_iters = now_ms() - t_start;
   st.ms_total = st.ms_iters + st.ms_setup;
   if (stats) *stats = st;
+  pers_dbg_dump(ba);
   return CCM_OK;
 }
 

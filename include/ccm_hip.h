@@ -60,7 +60,7 @@ enum {
   CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
   CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
   CCM_K_BA_SCHUR_DIAG, CCM_K_BA_SCHUR_OFF, CCM_K_BA_PCG_SPMV, CCM_K_BA_PCG_UPDATE,
-  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_COUNT
+  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_BA_PCG_PERSIST, CCM_K_COUNT
 };
 int ccm_prof_enable(ccm_ctx* ctx, int kernel_class /* -1: all, -2: none */);
 int ccm_prof_reset(ccm_ctx* ctx);
