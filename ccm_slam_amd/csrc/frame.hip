@@ -1,0 +1,284 @@
+// frame.hip — the per-frame glue between extraction and matching on the device:
+// Frame::UndistortKeyPoints / ComputeImageBounds / AssignFeaturesToGrid (cslam/src/Frame.cpp:103-118, 284-330) and the
+// candidate enumeration of Frame::GetFeaturesInArea (:200-253) + KeyFrame::GetFeaturesInArea (KeyFrame.cpp:1162-1201) for a
+// whole batch of window queries, followed by the Hamming distances of every (query, candidate) slot.
+// The host receives the candidate CSR in the reference's order (ix-major, iy, insertion order) and replays the
+// sequential claim rules on it; it no longer builds the grid or walks cells itself.
+#include "common.h"
+#include "frame_math.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+struct ccm_frame {
+  ccm_ctx* ctx = nullptr;
+  FrameCam cam{};
+  FrameBounds b{};
+  int distorted = 0, N = 0, cap = 0;
+  // device: [xy_un 2N f32 | octave N i32 | cell_idx N i32 | cell_off 3601 i32] + descriptors N x 32
+  float* d_xy = nullptr; int* d_oct = nullptr; int* d_cell_idx = nullptr; int* d_cell_off = nullptr; uint8_t* d_desc = nullptr;
+  ccm_keypoint* d_kps = nullptr;
+};
+
+namespace {
+
+constexpr int kCells = kGridCols * kGridRows;
+constexpr int kGridTPB = 1024;
+
+// one workgroup: undistort, bin, exclusive scan, place, restore insertion order inside every cell
+__global__ __launch_bounds__(kGridTPB) void frame_grid_kernel(const ccm_keypoint* kps, int N, FrameCam cam, FrameBounds b, int distorted,
+                                                              float* xy, int* oct, int* cell_off, int* cell_idx) {
+  __shared__ int cnt[kCells + 1];
+  __shared__ int part[kGridTPB];
+  const int t = threadIdx.x;
+  for (int i = t; i <= kCells; i += kGridTPB) cnt[i] = 0;
+  __syncthreads();
+  for (int i = t; i < N; i += kGridTPB) {
+    float x = kps[i].x, y = kps[i].y;
+    if (distorted) frame_undistort_point(cam, x, y, x, y);
+    xy[2 * i] = x; xy[2 * i + 1] = y;
+    oct[i] = kps[i].octave;
+    const int c = frame_cell_of(b, x, y);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan of 3600 counters: 4 cells per thread
+  constexpr int kPer = (kCells + kGridTPB - 1) / kGridTPB;
+  int loc[kPer], s = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) { const int c = t * kPer + k; loc[k] = (c < kCells) ? cnt[c] : 0; s += loc[k]; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < kGridTPB; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = part[t] - s;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int c = t * kPer + k;
+    if (c < kCells) { cell_off[c] = base; cnt[c] = base; base += loc[k]; }
+  }
+  if (t == kGridTPB - 1) cell_off[kCells] = part[t];
+  __syncthreads();
+  for (int i = t; i < N; i += kGridTPB) {
+    const int c = frame_cell_of(b, xy[2 * i], xy[2 * i + 1]);
+    if (c >= 0) cell_idx[atomicAdd(&cnt[c], 1)] = i;
+  }
+  __syncthreads();
+  // push_back order = ascending feature index: insertion sort of every (tiny) cell
+  for (int c = t; c < kCells; c += kGridTPB) {
+    const int e0 = cell_off[c], e1 = cnt[c];
+    for (int a = e0 + 1; a < e1; a++) {
+      const int v = cell_idx[a];
+      int q = a - 1;
+      while (q >= e0 && cell_idx[q] > v) { cell_idx[q + 1] = cell_idx[q]; q--; }
+      cell_idx[q + 1] = v;
+    }
+  }
+}
+
+struct WinQ { const float* u; const float* v; const float* r; const int* minl; const int* maxl; };
+
+// pass 0: count, pass 1: fill.  One thread per query walks its cells in the reference's order.
+template <int FILL>
+__global__ void frame_window_kernel(int Q, WinQ q, FrameBounds b, const float* xy, const int* oct, const int* cell_off, const int* cell_idx,
+                                    int* cnt, const int* off, int* out_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Q) return;
+  const float x = q.u[i], y = q.v[i], r = q.r[i];
+  const int minLevel = q.minl[i], maxLevel = q.maxl[i];
+  int x0, x1, y0, y1, n = 0;
+  int w = FILL ? off[i] : 0;
+  if (frame_cell_range(b, x, y, r, x0, x1, y0, y1)) {
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = x0; ix <= x1; ix++)
+      for (int iy = y0; iy <= y1; iy++) {
+        const int c = ix * kGridRows + iy;
+        for (int s = cell_off[c]; s < cell_off[c + 1]; s++) {
+          const int k = cell_idx[s];
+          if (bCheckLevels) {
+            if (oct[k] < minLevel) continue;
+            if (maxLevel >= 0 && oct[k] > maxLevel) continue;
+          }
+          const float distx = xy[2 * k] - x, disty = xy[2 * k + 1] - y;
+          if (fabsf(distx) < r && fabsf(disty) < r) {
+            if (FILL) out_idx[w++] = k;
+            n++;
+          }
+        }
+      }
+  }
+  if (!FILL) cnt[i] = n;
+}
+
+// exclusive scan of the per-query counts (one workgroup; Q is at most a few 10^4)
+__global__ __launch_bounds__(1024) void frame_scan_kernel(const int* cnt, int Q, int* off) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (Q + 1023) / 1024;
+  const int i0 = t * per, i1 = min(Q, i0 + per);
+  int s = 0;
+  for (int i = i0; i < i1; i++) s += cnt[i];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int base = part[t] - s;
+  for (int i = i0; i < i1; i++) { off[i] = base; base += cnt[i]; }
+  if (t == 1023) off[Q] = part[t];
+}
+
+int frame_reserve(ccm_frame* f, int n) {
+  if (n <= f->cap) return CCM_OK;
+  ccm_ctx* ctx = f->ctx;
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_desc, (void*)f->d_kps}) if (p) hipFree(p);
+  const int cap = std::max(2048, n + n / 2);
+  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_xy, 2 * sizeof(float) * (size_t)cap));
+  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_oct, sizeof(int) * (size_t)cap));
+  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_cell_idx, sizeof(int) * (size_t)cap));
+  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_desc, 32 * (size_t)cap));
+  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_kps, sizeof(ccm_keypoint) * (size_t)cap));
+  f->cap = cap;
+  return CCM_OK;
+}
+
+}  // namespace
+
+extern "C" int ccm_frame_create(ccm_ctx* ctx, const float K[4], const float* dist, int n_dist, int img_w, int img_h, ccm_frame** out) {
+  if (!ctx || !K || !out || n_dist < 0 || n_dist > 5 || (n_dist && !dist) || img_w <= 0 || img_h <= 0)
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_frame_create: bad args");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ccm_frame* f = new ccm_frame();
+  f->ctx = ctx;
+  f->cam.fx = K[0]; f->cam.fy = K[1]; f->cam.cx = K[2]; f->cam.cy = K[3];
+  double d5[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < n_dist; i++) d5[i] = dist[i];
+  f->cam.k1 = d5[0]; f->cam.k2 = d5[1]; f->cam.p1 = d5[2]; f->cam.p2 = d5[3]; f->cam.k3 = d5[4];
+  f->distorted = (n_dist > 0 && dist[0] != 0.0f) ? 1 : 0;          // mDistCoef.at<float>(0) != 0.0 (Frame.cpp:286, 316)
+  // ComputeImageBounds (Frame.cpp:314-347)
+  if (f->distorted) {
+    const float cx[4] = {0.f, (float)img_w, 0.f, (float)img_w}, cy[4] = {0.f, 0.f, (float)img_h, (float)img_h};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) frame_undistort_point(f->cam, cx[i], cy[i], ux[i], uy[i]);
+    f->b.minX = std::min(ux[0], ux[2]); f->b.maxX = std::max(ux[1], ux[3]);
+    f->b.minY = std::min(uy[0], uy[1]); f->b.maxY = std::max(uy[2], uy[3]);
+  } else {
+    f->b.minX = 0.f; f->b.maxX = (float)img_w; f->b.minY = 0.f; f->b.maxY = (float)img_h;
+  }
+  f->b.wInv = static_cast<float>(kGridCols) / static_cast<float>(f->b.maxX - f->b.minX);   // Frame.cpp:87-88
+  f->b.hInv = static_cast<float>(kGridRows) / static_cast<float>(f->b.maxY - f->b.minY);
+  if (hipMalloc(&f->d_cell_off, sizeof(int) * (kCells + 1)) != hipSuccess) { delete f; return ccm_set_error(ctx, CCM_E_HIP, "ccm_frame_create: hipMalloc"); }
+  *out = f;
+  return CCM_OK;
+}
+
+extern "C" void ccm_frame_destroy(ccm_frame* f) {
+  if (!f) return;
+  hipSetDevice(f->ctx->device);
+  hipStreamSynchronize(f->ctx->stream);
+  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_cell_off, (void*)f->d_desc, (void*)f->d_kps}) if (p) hipFree(p);
+  delete f;
+}
+
+extern "C" int ccm_frame_bounds(const ccm_frame* f, float bounds[4]) {
+  if (!f || !bounds) return CCM_E_ARG;
+  bounds[0] = f->b.minX; bounds[1] = f->b.minY; bounds[2] = f->b.maxX; bounds[3] = f->b.maxY;
+  return CCM_OK;
+}
+
+extern "C" int ccm_frame_set_keypoints(ccm_frame* f, const ccm_keypoint* kps, const uint8_t* desc, int n) {
+  if (!f || n < 0 || (n && (!kps || !desc))) return f ? ccm_set_error(f->ctx, CCM_E_ARG, "ccm_frame_set_keypoints: bad args") : CCM_E_ARG;
+  ccm_ctx* ctx = f->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int rc = frame_reserve(f, n)) return rc;
+  f->N = n;
+  if (n) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(f->d_kps, kps, sizeof(ccm_keypoint) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(f->d_desc, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  }
+  hipLaunchKernelGGL(frame_grid_kernel, dim3(1), dim3(kGridTPB), 0, ctx->stream, f->d_kps, n, f->cam, f->b, f->distorted, f->d_xy, f->d_oct,
+                     f->d_cell_off, f->d_cell_idx);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+extern "C" int ccm_frame_get(ccm_frame* f, float* xy_un, int32_t* cell_off, int32_t* cell_idx) {
+  if (!f) return CCM_E_ARG;
+  ccm_ctx* ctx = f->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (xy_un && f->N) CCM_HIP_CHECK(ctx, hipMemcpyAsync(xy_un, f->d_xy, 2 * sizeof(float) * (size_t)f->N, hipMemcpyDeviceToHost, ctx->stream));
+  if (cell_off) CCM_HIP_CHECK(ctx, hipMemcpyAsync(cell_off, f->d_cell_off, sizeof(int) * (kCells + 1), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (cell_idx) {
+    int total = 0;
+    CCM_HIP_CHECK(ctx, hipMemcpy(&total, f->d_cell_off + kCells, sizeof(int), hipMemcpyDeviceToHost));
+    if (total) CCM_HIP_CHECK(ctx, hipMemcpy(cell_idx, f->d_cell_idx, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost));
+  }
+  return CCM_OK;
+}
+
+extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, const float* v, const float* r, const int32_t* min_level,
+                                       const int32_t* max_level, const uint8_t* qdesc, int32_t* cand_off, int32_t* cand_idx, uint16_t* cand_dist,
+                                       int64_t cap, int64_t* n_cand) {
+  if (!f || Q < 0 || !cand_off || !n_cand || (Q && (!u || !v || !r || !min_level || !max_level || !qdesc)) || cap < 0 || (cap && (!cand_idx || !cand_dist)))
+    return f ? ccm_set_error(f->ctx, CCM_E_ARG, "ccm_frame_window_search: bad args") : CCM_E_ARG;
+  ccm_ctx* ctx = f->ctx;
+  *n_cand = 0;
+  cand_off[0] = 0;
+  if (Q == 0) return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // device staging: [u | v | r | minl | maxl] (5Q words) | qdesc (32Q) | cnt (Q) | off (Q+1) | idx (cap) | dist (cap u16)
+  const size_t wQ = (size_t)Q;
+  const size_t bytes = ccm_align256(20 * wQ) + ccm_align256(32 * wQ) + ccm_align256(4 * wQ) + ccm_align256(4 * (wQ + 1)) + ccm_align256(4 * (size_t)cap) +
+                       ccm_align256(2 * (size_t)cap) + 256;
+  void* scratch = nullptr;
+  if (int rc = ccm_io_scratch(ctx, bytes, &scratch)) return rc;
+  uint8_t* base = (uint8_t*)scratch;
+  float* d_q = (float*)base; base += ccm_align256(20 * wQ);
+  uint8_t* d_qdesc = base; base += ccm_align256(32 * wQ);
+  int* d_cnt = (int*)base; base += ccm_align256(4 * wQ);
+  int* d_off = (int*)base; base += ccm_align256(4 * (wQ + 1));
+  int* d_idx = (int*)base; base += ccm_align256(4 * (size_t)cap);
+  uint16_t* d_dist = (uint16_t*)base;
+  void* pin = nullptr;
+  if (int rc = ccm_pin_scratch(ctx, 52 * wQ + 4 * (wQ + 1) + 6 * (size_t)cap + 64, &pin)) return rc;
+  uint8_t* h = (uint8_t*)pin;
+  memcpy(h, u, 4 * wQ); memcpy(h + 4 * wQ, v, 4 * wQ); memcpy(h + 8 * wQ, r, 4 * wQ);
+  memcpy(h + 12 * wQ, min_level, 4 * wQ); memcpy(h + 16 * wQ, max_level, 4 * wQ);
+  memcpy(h + 20 * wQ, qdesc, 32 * wQ);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, h, 20 * wQ, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_qdesc, h + 20 * wQ, 32 * wQ, hipMemcpyHostToDevice, ctx->stream));
+  WinQ wq{d_q, d_q + wQ, d_q + 2 * wQ, (const int*)(d_q + 3 * wQ), (const int*)(d_q + 4 * wQ)};
+  const int nb = ccm_div_up(Q, 128);
+  hipLaunchKernelGGL(frame_window_kernel<0>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx, d_cnt,
+                     (const int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, Q, d_off);
+  int* h_off = (int*)(h + 52 * wQ);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_off, d_off, 4 * (wQ + 1), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t total = h_off[Q];
+  memcpy(cand_off, h_off, 4 * (wQ + 1));
+  *n_cand = total;
+  if (total > cap) return cap ? ccm_set_error(ctx, CCM_E_ARG, "ccm_frame_window_search: candidate capacity too small") : CCM_OK;   // cap == 0: sizing call
+  if (total == 0) return CCM_OK;
+  hipLaunchKernelGGL(frame_window_kernel<1>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx,
+                     (int*)nullptr, (const int*)d_off, d_idx);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  if (int rc = ccm_hamming_csr_dev(ctx, d_qdesc, Q, f->d_desc, f->N, d_off, d_idx, total, d_dist, nullptr, nullptr, nullptr)) return rc;
+  uint8_t* h_idx = h + 52 * wQ + 4 * (wQ + 1);
+  uint8_t* h_dist = h_idx + 4 * (size_t)cap;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_idx, d_idx, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_dist, d_dist, 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(cand_idx, h_idx, 4 * (size_t)total);
+  memcpy(cand_dist, h_dist, 2 * (size_t)total);
+  return CCM_OK;
+}

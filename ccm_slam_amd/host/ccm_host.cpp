@@ -174,6 +174,75 @@ int ORBmatcher::SearchByProjection(FrameView& F, const TrackedMapPoints& mps, fl
   return nmatches;
 }
 
+FrameGridDev::FrameGridDev(HipContext& ctx, const float K[4], const float* distCoef, int nDist, int width, int height) : ctx_(ctx) {
+  check(ccm_frame_create(ctx.get(), K, distCoef, nDist, width, height, &f_), ctx.get(), "ccm_frame_create");
+  float b[4];
+  ccm_frame_bounds(f_, b);
+  mnMinX = b[0]; mnMinY = b[1]; mnMaxX = b[2]; mnMaxY = b[3];
+}
+FrameGridDev::~FrameGridDev() { ccm_frame_destroy(f_); }
+
+void FrameGridDev::SetKeyPoints(const std::vector<KeyPoint>& mvKeys, const uint8_t* mDescriptors, std::vector<KeyPoint>& mvKeysUn) {
+  static_assert(sizeof(KeyPoint) == sizeof(ccm_keypoint), "KeyPoint must mirror ccm_keypoint");
+  const int n = (int)mvKeys.size();
+  check(ccm_frame_set_keypoints(f_, reinterpret_cast<const ccm_keypoint*>(mvKeys.data()), mDescriptors, n), ctx_.get(), "ccm_frame_set_keypoints");
+  std::vector<float> xy(2 * (size_t)std::max(n, 1));
+  check(ccm_frame_get(f_, xy.data(), nullptr, nullptr), ctx_.get(), "ccm_frame_get");
+  mvKeysUn = mvKeys;                                                  // kp = mvKeys[i]; kp.pt = undistorted (Frame.cpp:304-311)
+  for (int i = 0; i < n; i++) { mvKeysUn[i].x = xy[2 * i]; mvKeysUn[i].y = xy[2 * i + 1]; }
+}
+
+// SearchByProjection(Frame&, vector<mpptr>&, th) with the device grid: ONE ccm_frame_window_search call produces every
+// candidate list (GetFeaturesInArea order) and distance; the ordered claim replay below is unchanged.
+int ORBmatcher::SearchByProjection(FrameGridDev& grid, FrameView& F, const TrackedMapPoints& mps, float th) {
+  const bool bFactor = th != 1.0;
+  std::vector<int32_t> q_of, minl, maxl;
+  std::vector<float> u, v, r;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < mps.n; i++) {
+    if (!mps.mbTrackInView[i]) continue;
+    const int lvl = mps.mnTrackScaleLevel[i];
+    float rad = (mps.mTrackViewCos[i] > 0.998) ? 2.5f : 4.0f;   // RadiusByViewingCos (:150-156)
+    if (bFactor) rad *= th;
+    q_of.push_back(i);
+    u.push_back(mps.mTrackProjX[i]); v.push_back(mps.mTrackProjY[i]); r.push_back(rad * F.mvScaleFactors[lvl]);
+    minl.push_back(lvl - 1); maxl.push_back(lvl);
+    qdesc.insert(qdesc.end(), mps.mDescriptor + (size_t)i * 32, mps.mDescriptor + (size_t)i * 32 + 32);
+  }
+  const int Q = (int)q_of.size();
+  if (Q == 0) return 0;
+  std::vector<int32_t> off(Q + 1), idx;
+  std::vector<uint16_t> dist;
+  int64_t n = 0;
+  // typical lists hold a handful of features; grow once if the guess was short
+  idx.resize((size_t)Q * 16 + 1024); dist.resize(idx.size());
+  int rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
+                                   dist.data(), (int64_t)idx.size(), &n);
+  if (rc == CCM_E_ARG && n > (int64_t)idx.size()) {
+    idx.resize((size_t)n); dist.resize((size_t)n);
+    rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
+                                 dist.data(), n, &n);
+  }
+  check(rc, ctx_.get(), "ccm_frame_window_search");
+  int nmatches = 0;
+  for (int q = 0; q < Q; q++) {
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int k = idx[s];
+      if (F.mvpMapPoints[k] >= 0) continue;   // F.mvpMapPoints[idx] && Observations() > 0
+      const int d = dist[s];
+      if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = F.mvKeysUn[k].octave; bestIdx = k; }
+      else if (d < bestDist2) { bestLevel2 = F.mvKeysUn[k].octave; bestDist2 = d; }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      F.mvpMapPoints[bestIdx] = q_of[q];
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 int ORBmatcher::SearchByProjection(FrameView& C, const LastFrameProjections& last, float th) {
   FrameGrid grid(C);
   std::vector<int32_t> q_of, off(1, 0), idx;
@@ -641,6 +710,29 @@ int ccmh_local_ba(int device, int n_cam, int n_pt, int n_edge, double* cam_qt, c
     std::memcpy(pt_xyz, p.pt_xyz.data(), sizeof(double) * p.pt_xyz.size());
     std::memcpy(to_erase, er.data(), er.size());
     return 0;
+  } catch (const std::exception&) { return -1000; }
+}
+
+// SearchByProjection(Frame, map points) through the device grid: raw (distorted) keypoints in, match table + undistorted xy out
+int ccmh_search_by_projection_mp_dev(int device, const float* K, const float* dist, int n_dist, int w, int h, const void* kps_raw, const uint8_t* fdesc,
+                                     int N, const float* scale_factors, int n_mp, const uint8_t* in_view, const float* px, const float* py,
+                                     const int32_t* lvl, const float* vcos, const uint8_t* mp_desc, float th, float nnratio, int32_t* frame_mp,
+                                     float* xy_un_out) {
+  try {
+    cslam::HipContext ctx(device);
+    cslam::FrameGridDev grid(ctx, K, dist, n_dist, w, h);
+    std::vector<cslam::KeyPoint> keys((const cslam::KeyPoint*)kps_raw, (const cslam::KeyPoint*)kps_raw + N), keysUn;
+    grid.SetKeyPoints(keys, fdesc, keysUn);
+    for (int i = 0; i < N; i++) { xy_un_out[2 * i] = keysUn[i].x; xy_un_out[2 * i + 1] = keysUn[i].y; }
+    cslam::FrameView F;
+    F.N = N; F.mvKeysUn = keysUn.data(); F.mDescriptors = fdesc;
+    F.mnMinX = grid.mnMinX; F.mnMinY = grid.mnMinY; F.mnMaxX = grid.mnMaxX; F.mnMaxY = grid.mnMaxY;
+    F.mvScaleFactors = scale_factors; F.mvpMapPoints = frame_mp;
+    cslam::TrackedMapPoints mps;
+    mps.n = n_mp; mps.mbTrackInView = in_view; mps.mTrackProjX = px; mps.mTrackProjY = py; mps.mnTrackScaleLevel = lvl; mps.mTrackViewCos = vcos;
+    mps.mDescriptor = mp_desc;
+    cslam::ORBmatcher m(ctx, nnratio, true);
+    return m.SearchByProjection(grid, F, mps, th);
   } catch (const std::exception&) { return -1000; }
 }
 

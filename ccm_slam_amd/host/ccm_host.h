@@ -100,6 +100,24 @@ struct KeysView {
   FeatureVectorView fv;
 };
 
+// Device-resident grid of one Frame / KeyFrame (ccm_frame_*): undistorted keypoints, bounds, 75x48 cells, descriptors.
+// Replaces Frame::UndistortKeyPoints / ComputeImageBounds / AssignFeaturesToGrid (Frame.cpp:103-118, 284-347) and serves
+// batched GetFeaturesInArea + Hamming queries to the matcher.
+class FrameGridDev {
+ public:
+  FrameGridDev(HipContext& ctx, const float K[4], const float* distCoef, int nDist, int width, int height);
+  ~FrameGridDev();
+  FrameGridDev(const FrameGridDev&) = delete;
+  FrameGridDev& operator=(const FrameGridDev&) = delete;
+  // mvKeys + mDescriptors in; mvKeysUn out (same order), bounds available afterwards
+  void SetKeyPoints(const std::vector<KeyPoint>& mvKeys, const uint8_t* mDescriptors, std::vector<KeyPoint>& mvKeysUn);
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+  ccm_frame* get() const { return f_; }
+ private:
+  HipContext& ctx_;
+  ccm_frame* f_ = nullptr;
+};
+
 class ORBmatcher {
  public:
   static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
@@ -108,6 +126,8 @@ class ORBmatcher {
   static int DescriptorDistance(const uint8_t* a, const uint8_t* b);
   // ORBmatcher.cpp:71-148.  Returns nmatches; F.mvpMapPoints[idx] = index of the matched map point.
   int SearchByProjection(FrameView& F, const TrackedMapPoints& mps, float th);
+  // same, with the candidate lists and distances produced on the device from the frame's resident grid (no host grid walk)
+  int SearchByProjection(FrameGridDev& grid, FrameView& F, const TrackedMapPoints& mps, float th);
   // ORBmatcher.cpp:1350-1476.
   int SearchByProjection(FrameView& CurrentFrame, const LastFrameProjections& last, float th);
   // SearchByBoW(kfptr pKF, Frame& F, ...) — ORBmatcher.cpp:178-306.  matchesF[F.N]: KF feature whose map point goes to F[i], or -1

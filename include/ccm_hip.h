@@ -156,6 +156,27 @@ int  ccm_orb_debug_timing(const ccm_orb* orb, double out_ms[6]);
 /* pre-octree FAST candidates of the last frame: returns count for the level, fills up to cap */
 int  ccm_orb_debug_candidates(ccm_orb* orb, int level, ccm_keypoint* out, int cap, int* n_out);
 
+/* Per-frame glue between extraction and matching.  A ccm_frame holds, on the device, what the
+ * window searches read from a Frame / KeyFrame: undistorted keypoints (Frame::UndistortKeyPoints, Frame.cpp:284-312 —
+ * cv::undistortPoints with P = K, five fixed-point iterations), the image bounds (ComputeImageBounds, :314-347), the
+ * 75x48 grid (AssignFeaturesToGrid / PosInGrid, :103-118, :254-265) and the descriptors.
+ * K = fx fy cx cy (mK, f32); dist = mDistCoef k1 k2 p1 p2 [k3] (n_dist 0, 4 or 5; dist[0] == 0 means "no distortion",
+ * :286).  ccm_frame_window_search evaluates a batch of Frame::GetFeaturesInArea(u, v, r, minLevel, maxLevel) calls
+ * (:200-253; pass -1, -1 for KeyFrame::GetFeaturesInArea, KeyFrame.cpp:1162-1201) and the Hamming distance of every
+ * candidate to the query's descriptor: cand_off[Q+1], cand_idx / cand_dist in the reference's enumeration order
+ * (ix-major, iy, insertion order), ready for the host's ordered resolution pass.  Call it with cap = 0 to size. */
+typedef struct ccm_frame ccm_frame;
+int  ccm_frame_create(ccm_ctx* ctx, const float K[4], const float* dist, int n_dist, int img_w, int img_h, ccm_frame** out);
+void ccm_frame_destroy(ccm_frame* f);
+int  ccm_frame_bounds(const ccm_frame* f, float bounds[4] /* mnMinX mnMinY mnMaxX mnMaxY */);
+int  ccm_frame_set_keypoints(ccm_frame* f, const ccm_keypoint* kps /* mvKeys */, const uint8_t* desc /* n x 32 */, int n);
+int  ccm_frame_get(ccm_frame* f, float* xy_un /* n x 2, nullable */, int32_t* cell_off /* 75*48+1, nullable */,
+                   int32_t* cell_idx /* <= n, nullable */);
+int  ccm_frame_window_search(ccm_frame* f, int Q, const float* u, const float* v, const float* r,
+                             const int32_t* min_level, const int32_t* max_level, const uint8_t* qdesc /* Q x 32 */,
+                             int32_t* cand_off /* Q+1 */, int32_t* cand_idx, uint16_t* cand_dist, int64_t cap,
+                             int64_t* n_cand);
+
 /* ---- bundle adjustment ----------------------------------------------------------------
  * Replaces the g2o machinery driven by Optimizer::BundleAdjustmentClient /
  * LocalBundleAdjustmentClient / MapFusionGBA (cslam/src/Optimizer.cpp:40-212, 349-644,

@@ -99,6 +99,30 @@ def grid_candidates(kx, ky, octave, bounds, qx, qy, qr, qminl, qmaxl):
     return off, idx[:n]
 
 
+def build_grid(kx, ky, bounds):
+    kx, ky = np.ascontiguousarray(kx, np.float32), np.ascontiguousarray(ky, np.float32)
+    off = np.zeros(75 * 48 + 1, np.int32)
+    idx = np.zeros(max(kx.size, 1), np.int32)
+    lib().ora_build_grid(_p(kx, C.c_float), _p(ky, C.c_float), int(kx.size), *[C.c_float(b) for b in bounds], _p(off, C.c_int32), _p(idx, C.c_int32))
+    return off, idx[:off[-1]]
+
+
+def undistort_points(K, dist, xy):
+    """Frame::UndistortKeyPoints restated (ora_undistort_points)."""
+    K = np.ascontiguousarray(K, np.float32); dist = np.ascontiguousarray(dist, np.float32)
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty_like(xy)
+    lib().ora_undistort_points(_p(K, C.c_float), _p(dist, C.c_float), int(dist.size), _p(xy, C.c_float), xy.shape[0], _p(out, C.c_float))
+    return out
+
+
+def image_bounds(K, dist, w, h):
+    K = np.ascontiguousarray(K, np.float32); dist = np.ascontiguousarray(dist, np.float32)
+    b = np.zeros(4, np.float32)
+    lib().ora_image_bounds(_p(K, C.c_float), _p(dist, C.c_float), int(dist.size), int(w), int(h), _p(b, C.c_float))
+    return b
+
+
 def search_by_projection_mp(kx, ky, octave, fdesc, bounds, scale_factors, mp_in_view, mp_proj_x, mp_proj_y, mp_level,
                             mp_view_cos, mp_desc, th, nnratio, frame_mp):
     f32 = lambda a: np.ascontiguousarray(a, np.float32)

@@ -588,3 +588,80 @@ extern "C" int ora_bow_transform(int n_nodes, int L, const int32_t* child_off, c
   for (auto& kv : v) { bow_ids[n] = kv.first; bow_vals[n] = norm > 0.0 ? kv.second / norm : kv.second; n++; }
   return n;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints / ComputeImageBounds (cslam/src/Frame.cpp:284-347).  cv::undistortPoints is [EXT]: OpenCV
+// 4.2.0 imgproc/src/undistort.dispatch.cpp cvUndistortPointsInternal with cameraMatrix = mK (CV_32F widened to f64),
+// distCoeffs = mDistCoef (k1 k2 p1 p2 [k3]; k4..k6, s1..s4, tau = 0), R = I, P = mK and the wrapper's default criteria
+// TermCriteria(MAX_ITER, 5, 0.01): five fixed-point iterations in f64, no epsilon exit, result stored as f32.
+namespace {
+struct UndCam { double fx, fy, cx, cy, k[14]; };
+void und_point(const UndCam& c, float xin, float yin, float* xo, float* yo) {
+  double x = xin, y = yin;
+  const double u = x, v = y;
+  const double ifx = 1. / c.fx, ify = 1. / c.fy;
+  x = (x - c.cx) * ifx;
+  y = (y - c.cy) * ify;
+  const double* k = c.k;
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+    if (icdist < 0) { x = (u - c.cx) * ifx; y = (v - c.cy) * ify; break; }
+    const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+    const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  const double RR[3][3] = {{c.fx, 0, c.cx}, {0, c.fy, c.cy}, {0, 0, 1}};
+  const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+  const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+  const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+  *xo = (float)(xx * ww);
+  *yo = (float)(yy * ww);
+}
+UndCam make_cam(const float* K, const float* dist, int n_dist) {
+  UndCam c{};
+  c.fx = K[0]; c.fy = K[1]; c.cx = K[2]; c.cy = K[3];
+  for (int i = 0; i < 14; i++) c.k[i] = 0;
+  for (int i = 0; i < n_dist && i < 5; i++) c.k[i] = dist[i];
+  return c;
+}
+}  // namespace
+
+extern "C" void ora_undistort_points(const float* K, const float* dist, int n_dist, const float* xy_in, int n, float* xy_out) {
+  if (n_dist == 0 || dist[0] == 0.0f) {   // mDistCoef.at<float>(0)==0.0 => mvKeysUn = mvKeys (Frame.cpp:286-290)
+    for (int i = 0; i < 2 * n; i++) xy_out[i] = xy_in[i];
+    return;
+  }
+  const UndCam c = make_cam(K, dist, n_dist);
+  for (int i = 0; i < n; i++) und_point(c, xy_in[2 * i], xy_in[2 * i + 1], &xy_out[2 * i], &xy_out[2 * i + 1]);
+}
+
+// ComputeImageBounds (Frame.cpp:314-347): bounds[4] = mnMinX mnMinY mnMaxX mnMaxY
+extern "C" void ora_image_bounds(const float* K, const float* dist, int n_dist, int w, int h, float* bounds) {
+  if (n_dist == 0 || dist[0] == 0.0f) { bounds[0] = 0.f; bounds[1] = 0.f; bounds[2] = (float)w; bounds[3] = (float)h; return; }
+  const UndCam c = make_cam(K, dist, n_dist);
+  const float cx[4] = {0.f, (float)w, 0.f, (float)w}, cy[4] = {0.f, 0.f, (float)h, (float)h};
+  float ux[4], uy[4];
+  for (int i = 0; i < 4; i++) und_point(c, cx[i], cy[i], &ux[i], &uy[i]);
+  bounds[0] = std::min(ux[0], ux[2]); bounds[2] = std::max(ux[1], ux[3]);
+  bounds[1] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+}
+
+// AssignFeaturesToGrid (Frame.cpp:103-118) flattened: cell c = x * GRID_ROWS + y, members in push_back order
+extern "C" void ora_build_grid(const float* kx, const float* ky, int N, float minX, float minY, float maxX, float maxY,
+                               int32_t* cell_off /* COLS*ROWS+1 */, int32_t* cell_idx /* N */) {
+  Grid* g = new Grid();
+  std::vector<int32_t> oct(N > 0 ? N : 1, 0);
+  build_grid(*g, kx, ky, oct.data(), N, minX, minY, maxX, maxY);
+  int n = 0;
+  for (int x = 0; x < GRID_COLS; x++)
+    for (int y = 0; y < GRID_ROWS; y++) {
+      cell_off[x * GRID_ROWS + y] = n;
+      for (int k : g->cell[x][y]) cell_idx[n++] = k;
+    }
+  cell_off[GRID_COLS * GRID_ROWS] = n;
+  delete g;
+}

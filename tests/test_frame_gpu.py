@@ -1,0 +1,73 @@
+"""Frame glue on the device (ccm_frame_*) vs the oracle: undistorted keypoints, image bounds, the 75x48 grid and the
+batched GetFeaturesInArea + Hamming window search.  Everything here is f32 / integer work restated operation by operation,
+so the bar is bit-exact: identical floats, identical candidate lists in identical order, identical distances."""
+import numpy as np
+import pytest
+
+from ccm_slam_amd import synth
+from ccm_slam_amd.frame import GRID_COLS, GRID_ROWS, FrameGrid
+
+pytestmark = pytest.mark.gpu
+
+EUROC_K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+EUROC_D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)   # cslam/conf/vi_euroc.yaml
+
+
+def _kps(oracle_lib, seed=1000, t=3, n=1000):
+    return oracle_lib.OrbOracle(n).extract(synth.gen_image(seed, t))
+
+
+@pytest.mark.parametrize("dist", [EUROC_D, np.zeros(4, np.float32), np.array([-0.3, 0.1, 0.001, -0.0005, 0.02], np.float32)])
+def test_undistort_bounds_and_grid_match_the_oracle(ctx, oracle_lib, dist):
+    kps, desc = _kps(oracle_lib)
+    fg = FrameGrid(ctx, EUROC_K, dist, 752, 480)
+    b = fg.bounds
+    assert np.array_equal(b, oracle_lib.image_bounds(EUROC_K, dist, 752, 480))
+    fg.set_keypoints(kps, desc)
+    xy, off, idx = fg.get()
+    xy_o = oracle_lib.undistort_points(EUROC_K, dist, np.stack([kps["x"], kps["y"]], 1))
+    assert np.array_equal(xy, xy_o)                        # bit-identical floats
+    off_o, idx_o = oracle_lib.build_grid(xy_o[:, 0], xy_o[:, 1], b)
+    assert np.array_equal(off, off_o) and np.array_equal(idx, idx_o)   # same cells, insertion (index) order inside each
+    assert off[-1] > 0.9 * len(kps)
+    fg.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_window_search_candidates_and_distances(ctx, oracle_lib, seed):
+    kps, desc = _kps(oracle_lib, t=5 + seed)
+    fg = FrameGrid(ctx, EUROC_K, EUROC_D, 752, 480)
+    fg.set_keypoints(kps, desc)
+    xy, _, _ = fg.get()
+    b = fg.bounds
+    rng = np.random.default_rng(seed)
+    Q = 3000
+    # queries around real features (tracked map points) plus some far outside the image
+    base = xy[rng.integers(0, xy.shape[0], Q)] + rng.normal(size=(Q, 2)).astype(np.float32) * 6
+    base[:50] = rng.uniform(-400, 1400, (50, 2))
+    u, v = base[:, 0].astype(np.float32), base[:, 1].astype(np.float32)
+    lvl = rng.integers(0, 8, Q).astype(np.int32)
+    r = (rng.choice([2.5, 4.0, 7.0, 15.0], Q) * 1.2 ** lvl).astype(np.float32)
+    minl = np.where(rng.random(Q) < 0.2, -1, lvl - 1).astype(np.int32)
+    maxl = np.where(minl < 0, -1, lvl).astype(np.int32)
+    minl[100:120] = 0; maxl[100:120] = -1                  # bCheckLevels false / open upper end
+    qdesc = desc[rng.integers(0, desc.shape[0], Q)].copy()
+    qdesc[:, :4] ^= rng.integers(0, 256, (Q, 4), dtype=np.uint8)
+    off, idx, dist = fg.window_search(u, v, r, minl, maxl, qdesc)
+    off_o, idx_o = oracle_lib.grid_candidates(xy[:, 0], xy[:, 1], kps["octave"], b, u, v, r, minl, maxl)
+    assert np.array_equal(off, off_o) and np.array_equal(idx, idx_o)
+    dist_o, _, _, _ = oracle_lib.hamming_csr(qdesc, desc, off_o, idx_o)
+    assert np.array_equal(dist, dist_o)
+    assert idx.size > Q                                     # the test exercises real lists
+    fg.close()
+
+
+def test_empty_frame_and_empty_queries(ctx):
+    fg = FrameGrid(ctx, EUROC_K, EUROC_D, 752, 480)
+    kp = np.zeros(0, dtype=[("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"), ("octave", "i4")])
+    fg.set_keypoints(kp, np.zeros((0, 32), np.uint8))
+    off, idx, dist = fg.window_search(np.array([10.0]), np.array([10.0]), np.array([50.0]), [-1], [-1], np.zeros((1, 32), np.uint8))
+    assert off.tolist() == [0, 0] and idx.size == 0
+    off, idx, dist = fg.window_search([], [], [], [], [], np.zeros((0, 32), np.uint8))
+    assert off.tolist() == [0]
+    fg.close()

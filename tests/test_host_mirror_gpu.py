@@ -256,3 +256,37 @@ def test_optimize_sim3_class_method(hostlib, oracle_lib):
     so, keepo, nino = oracle_lib.sim3_optimize(p["sim3"], p["P1c"], p["P2c"], p["obs1"], p["obs2"], p["info1"], p["info2"], p["K1"], p["K2"], 10.0, False)
     assert nin == nino and np.array_equal(keep, keepo)
     assert np.abs(s - so).max() < 1e-6
+
+
+def test_search_by_projection_through_the_device_grid(hostlib, oracle_lib):
+    """Frame glue on the device end to end: raw (distorted) keypoints -> undistort + grid on the GPU -> ONE window-search
+    launch sequence -> ordered claim replay.  Expected result: the oracle's undistortion feeding the oracle's M1."""
+    kps, desc = _frame(oracle_lib, 1000, 7)
+    N = len(kps)
+    K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+    xy_o = oracle_lib.undistort_points(K, D, np.stack([kps["x"], kps["y"]], 1))
+    bounds = oracle_lib.image_bounds(K, D, 752, 480)
+    rng = np.random.default_rng(3)
+    sf = synth.scale_tables()[0]
+    n_mp = 4000
+    src = rng.integers(0, N, n_mp)
+    px = (xy_o[src, 0] + rng.normal(0, 2.0, n_mp)).astype(np.float32)
+    py = (xy_o[src, 1] + rng.normal(0, 2.0, n_mp)).astype(np.float32)
+    lvl = np.clip(kps["octave"][src] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+    vcos = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    in_view = (rng.random(n_mp) < 0.9).astype(np.uint8)
+    bits = np.unpackbits(desc[src], axis=1)
+    mp_desc = np.packbits(bits ^ (rng.random(bits.shape) < 0.08), axis=1)
+    frame_mp0 = -np.ones(N, np.int32)
+    frame_mp0[rng.integers(0, N, 50)] = 10_000
+    exp_n, exp = oracle_lib.search_by_projection_mp(xy_o[:, 0], xy_o[:, 1], kps["octave"], desc, tuple(float(b) for b in bounds), sf, in_view,
+                                                    px, py, lvl, vcos, mp_desc, 3.0, 0.8, frame_mp0)
+    got = frame_mp0.copy()
+    xy_un = np.zeros((N, 2), np.float32)
+    kraw = np.ascontiguousarray(kps)
+    n = hostlib.ccmh_search_by_projection_mp_dev(0, _p(K), _p(D), 4, 752, 480, _p(kraw), _p(desc), N, _p(sf), n_mp, _p(in_view), _p(px), _p(py),
+                                                 _p(lvl), _p(vcos), _p(mp_desc), C.c_float(3.0), C.c_float(0.8), _p(got), _p(xy_un))
+    assert np.array_equal(xy_un, xy_o)
+    assert n == exp_n and n > 500
+    assert np.array_equal(got, exp)

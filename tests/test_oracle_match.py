@@ -95,3 +95,31 @@ def test_search_by_projection_last_rotation_histogram():
                                               np.ones(8, np.float32), np.ones(n_f, np.uint8), kx, ky, np.zeros(n_f, np.int32),
                                               l_angle, desc, 7.0, 1, -np.ones(n_f, np.int32))
     assert n == 12 and cur[5] == -1 and (np.delete(cur, 5) == np.delete(np.arange(n_f), 5)).all()
+
+
+def test_undistort_restatement_inverts_the_distortion_model(oracle_lib):
+    """cv::undistortPoints restated (five fixed-point iterations, P = K): applying the forward Brown-Conrady model to the
+    result must give back the input pixel to the accuracy five iterations reach; zero distortion is the identity; the
+    image bounds are the undistorted corners (Frame.cpp:314-347)."""
+    import numpy as np
+    K = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+    rng = np.random.default_rng(0)
+    xy = np.stack([rng.uniform(0, 752, 500), rng.uniform(0, 480, 500)], 1).astype(np.float32)
+    un = oracle_lib.undistort_points(K, D, xy).astype(np.float64)
+    x = (un[:, 0] - K[2]) / K[0]; y = (un[:, 1] - K[3]) / K[1]; r2 = x * x + y * y
+    cd = 1 + D[0] * r2 + D[1] * r2 * r2
+    xd = x * cd + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x); yd = y * cd + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
+    back = np.stack([xd * K[0] + K[2], yd * K[1] + K[3]], 1)
+    err = np.abs(back - xy).max(axis=1)
+    centre = np.hypot(xy[:, 0] - K[2], xy[:, 1] - K[3]) < 200
+    assert err[centre].max() < 5e-3 and err.max() < 0.5          # five iterations: converged near the centre, close at the corners
+    assert np.array_equal(oracle_lib.undistort_points(K, np.zeros(4, np.float32), xy), xy)
+    b = oracle_lib.image_bounds(K, D, 752, 480)
+    assert b[0] < 0 and b[1] < 0 and b[2] > 752 and b[3] > 480    # barrel distortion: the undistorted image is larger
+    assert np.array_equal(oracle_lib.image_bounds(K, np.zeros(4, np.float32), 752, 480), np.array([0, 0, 752, 480], np.float32))
+    off, idx = oracle_lib.build_grid(un[:, 0].astype(np.float32), un[:, 1].astype(np.float32), b)
+    assert off[-1] == 500 and sorted(idx.tolist()) == list(range(500))
+    for c in range(75 * 48):
+        seg = idx[off[c]:off[c + 1]]
+        assert (np.diff(seg) > 0).all()                           # push_back order
