@@ -135,6 +135,19 @@ __global__ __launch_bounds__(1024) void frame_scan_kernel(const int* cnt, int Q,
   if (t == 1023) off[Q] = part[t];
 }
 
+// Tracking::SearchLocalPoints' isInFrustum loop (Tracking.cpp:~770-800 / Frame.cpp:139-198): one thread per map point
+__global__ void frame_frustum_kernel(FrustumFrame fr, int n, const float* P, const float* Pn, const float* dmin, const float* dmax,
+                                     float cos_limit, uint8_t* in_view, float* pu, float* pv, int* lvl, float* pcos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float p[3] = {P[3 * i], P[3 * i + 1], P[3 * i + 2]}, nn[3] = {Pn[3 * i], Pn[3 * i + 1], Pn[3 * i + 2]};
+  float u = 0, v = 0, c = 0;
+  int l = 0;
+  const bool ok = frame_in_frustum(fr, p, nn, dmin[i], dmax[i], cos_limit, u, v, l, c);
+  in_view[i] = ok ? 1 : 0;
+  pu[i] = u; pv[i] = v; lvl[i] = l; pcos[i] = c;
+}
+
 int frame_reserve(ccm_frame* f, int n) {
   if (n <= f->cap) return CCM_OK;
   ccm_ctx* ctx = f->ctx;
@@ -280,5 +293,38 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(cand_idx, h_idx, 4 * (size_t)total);
   memcpy(cand_dist, h_dist, 2 * (size_t)total);
+  return CCM_OK;
+}
+
+extern "C" int ccm_frame_frustum(ccm_ctx* ctx, const ccm_frustum_frame* fr, int n, const float* P, const float* normal, const float* min_dist,
+                                 const float* max_dist, float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y, int32_t* level,
+                                 float* view_cos) {
+  if (!ctx || !fr || n < 0 || (n && (!P || !normal || !min_dist || !max_dist || !in_view || !proj_x || !proj_y || !level || !view_cos)))
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_frame_frustum: bad args");
+  if (n == 0) return CCM_OK;
+  static_assert(sizeof(ccm_frustum_frame) == sizeof(FrustumFrame), "ccm_frustum_frame must mirror FrustumFrame");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  FrustumFrame f;
+  memcpy(&f, fr, sizeof(f));
+  const size_t wn = (size_t)n;
+  // device: P 3n | normal 3n | dmin n | dmax n (8n floats in) ; u n | v n | cos n | level n | in_view n bytes (out)
+  void* scratch = nullptr;
+  if (int rc = ccm_io_scratch(ctx, 4 * 8 * wn + 4 * 4 * wn + wn + 256, &scratch)) return rc;
+  void* pin = nullptr;
+  if (int rc = ccm_pin_scratch(ctx, 4 * 8 * wn + 4 * 4 * wn + wn + 64, &pin)) return rc;
+  float* d_in = (float*)scratch;
+  float* d_out = d_in + 8 * wn;
+  uint8_t* d_flag = (uint8_t*)(d_out + 4 * wn);
+  float* h = (float*)pin;
+  memcpy(h, P, 12 * wn); memcpy(h + 3 * wn, normal, 12 * wn); memcpy(h + 6 * wn, min_dist, 4 * wn); memcpy(h + 7 * wn, max_dist, 4 * wn);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, 32 * wn, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(frame_frustum_kernel, dim3(ccm_div_up(n, 256)), dim3(256), 0, ctx->stream, f, n, d_in, d_in + 3 * wn, d_in + 6 * wn, d_in + 7 * wn,
+                     viewing_cos_limit, d_flag, d_out, d_out + wn, (int*)(d_out + 3 * wn), d_out + 2 * wn);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  float* h_out = h + 8 * wn;
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, 16 * wn + wn, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(proj_x, h_out, 4 * wn); memcpy(proj_y, h_out + wn, 4 * wn); memcpy(view_cos, h_out + 2 * wn, 4 * wn);
+  memcpy(level, h_out + 3 * wn, 4 * wn); memcpy(in_view, h_out + 4 * wn, wn);
   return CCM_OK;
 }

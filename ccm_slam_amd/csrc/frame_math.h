@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include "orb_math.h"
 
 #define FR_HD __host__ __device__ __forceinline__
 
@@ -57,5 +58,54 @@ FR_HD bool frame_cell_range(const FrameBounds& b, float x, float y, float r, int
   if (y0 >= kGridRows) return false;
   y1 = min(kGridRows - 1, (int)ceilf((y - b.minY + r) * b.hInv));
   if (y1 < 0) return false;
+  return true;
+}
+
+// Frame::isInFrustum (Frame.cpp:139-198) for one map point, [EXT] cv::Mat arithmetic restated:
+//  * mRcw*P+mtcw is one cv::gemm(A 3x3, B 3x1, alpha 1, C, beta 1): OpenCV's small-matrix path (core/src/matmul.simd.hpp,
+//    case len == 3) forms t = a0*b0 + a1*b1 + a2*b2 in f32, left to right, then d = (float)(t*alpha + c*beta) in f64;
+//    the baseline (non-FMA) build is restated — an AVX2-dispatched OpenCV may contract the f32 sum (parity unpinned);
+//  * P - mOw in f32; cv::norm (NORM_L2, CV_32F) accumulates v*v in f64 and returns sqrt in f64, stored to a float;
+//  * Mat::dot accumulates in f64; viewCos = (float)(dot / (double)dist);
+//  * PredictScale: ceil(logf(mfMaxDistance / dist) / mfLogScaleFactor) clamped to [0, nLevels) (MapPoint.cpp:854-869).
+struct FrustumFrame {
+  float Rcw[9], tcw[3], Ow[3];
+  float fx, fy, cx, cy;
+  float minX, maxX, minY, maxY;
+  float logScaleFactor;
+  int nScaleLevels;
+};
+
+FR_HD bool frame_in_frustum(const FrustumFrame& f, const float P[3], const float Pn[3], float mfMinDistance, float mfMaxDistance,
+                            float viewingCosLimit, float& u_out, float& v_out, int& level_out, float& cos_out) {
+  float Pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float t = f.Rcw[3 * i] * P[0] + f.Rcw[3 * i + 1] * P[1] + f.Rcw[3 * i + 2] * P[2];
+    Pc[i] = (float)((double)t * 1.0 + (double)f.tcw[i] * 1.0);
+  }
+  if (Pc[2] < 0.0f) return false;
+  const float invz = 1.0f / Pc[2];
+  const float u = f.fx * Pc[0] * invz + f.cx;
+  const float v = f.fy * Pc[1] * invz + f.cy;
+  if (u < f.minX || u > f.maxX) return false;
+  if (v < f.minY || v > f.maxY) return false;
+  const float maxDistance = 1.2f * mfMaxDistance, minDistance = 0.8f * mfMinDistance;   // MapPoint.cpp:825-835
+  const float PO[3] = {P[0] - f.Ow[0], P[1] - f.Ow[1], P[2] - f.Ow[2]};
+  double s2 = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) s2 += (double)PO[i] * PO[i];
+  const float dist = (float)sqrt(s2);
+  if (dist < minDistance || dist > maxDistance) return false;
+  double dot = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) dot += (double)PO[i] * Pn[i];
+  const float viewCos = (float)(dot / dist);
+  if (viewCos < viewingCosLimit) return false;
+  const float ratio = mfMaxDistance / dist;
+  int nScale = (int)ceilf(orbm::logf_glibc(ratio) / f.logScaleFactor);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= f.nScaleLevels) nScale = f.nScaleLevels - 1;
+  u_out = u; v_out = v; level_out = nScale; cos_out = viewCos;
   return true;
 }

@@ -124,4 +124,39 @@ ORB_HD int cv_round(float v) {
 #endif
 }
 
+
+// glibc logf (sysdeps/ieee754/flt-32/e_logf.c, Szabolcs Nagy's scheme; table and polynomial read from this image's
+// libm.so.6 and identical to the published __logf_data): log(x) = log1p(z/c - 1) + log(c) + k ln2 in f64, NOT correctly
+// rounded, so MapPoint::PredictScale's ceil(log(ratio)/mfLogScaleFactor) (MapPoint.cpp:845,862) needs the same scheme.
+// Positive normal finite x only (ratio = mfMaxDistance / dist > 0); the special-case prologue of the libm is omitted.
+ORB_HD float logf_glibc(float x) {
+  const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+      {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+      {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+      {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+      {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+      {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  const double Ln2 = 0x1.62e42fefa39efp-1;
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  const uint32_t ix = as_u32(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> (23 - 4)) % 16);
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  union { uint32_t u; float f; } zf; zf.u = iz;
+  const double z = (double)zf.f;
+  const double invc = T[i][0], logc = T[i][1];
+  const double r = z * invc - 1;
+  const double y0 = logc + (double)k * Ln2;
+  const double r2 = r * r;
+  double y = A1 * r + A2;
+  y = A0 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
 }  // namespace orbm

@@ -68,3 +68,25 @@ class FrameGrid:
         if self._h:
             lib().ccm_frame_destroy(self._h)
             self._h = C.c_void_p()
+
+
+class FrustumFrame(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("minX", C.c_float), ("maxX", C.c_float), ("minY", C.c_float), ("maxY", C.c_float),
+                ("logScaleFactor", C.c_float), ("nScaleLevels", C.c_int32)]
+
+
+def is_in_frustum(ctx: Context, frame24, n_levels: int, P, normal, dmin, dmax, cos_limit: float = 0.5):
+    """Frame::isInFrustum for a batch of map points (ccm_frame_frustum); frame24 as in oracle.is_in_frustum."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    fr = f32(frame24)
+    st = FrustumFrame()
+    C.memmove(C.byref(st), fr.ctypes.data, 24 * 4)
+    st.nScaleLevels = int(n_levels)
+    P, normal, dmin, dmax = f32(P).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(dmin), f32(dmax)
+    n = P.shape[0]
+    inv = np.zeros(max(n, 1), np.uint8); u = np.zeros(max(n, 1), np.float32); v = np.zeros(max(n, 1), np.float32)
+    lvl = np.zeros(max(n, 1), np.int32); cs = np.zeros(max(n, 1), np.float32)
+    check(lib().ccm_frame_frustum(ctx.handle, C.byref(st), n, _p(P), _p(normal), _p(dmin), _p(dmax), C.c_float(cos_limit), _p(inv), _p(u), _p(v),
+                                  _p(lvl), _p(cs)), ctx.handle)
+    return inv[:n], u[:n], v[:n], lvl[:n], cs[:n]

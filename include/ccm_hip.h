@@ -177,6 +177,22 @@ int  ccm_frame_window_search(ccm_frame* f, int Q, const float* u, const float* v
                              int32_t* cand_off /* Q+1 */, int32_t* cand_idx, uint16_t* cand_dist, int64_t cap,
                              int64_t* n_cand);
 
+/* Frame::isInFrustum (Frame.cpp:139-198) for a batch of map points — Tracking::SearchLocalPoints' visibility loop.
+ * The struct carries what the frame contributes (mRcw row-major, mtcw, mOw, intrinsics, image bounds, mfLogScaleFactor,
+ * mnScaleLevels); per point: world position, mean viewing direction (GetNormal), mfMinDistance / mfMaxDistance.
+ * Outputs = mbTrackInView, mTrackProjX/Y, mnTrackScaleLevel (PredictScale, MapPoint.cpp:854-869), mTrackViewCos. */
+typedef struct {
+  float Rcw[9], tcw[3], Ow[3];
+  float fx, fy, cx, cy;
+  float minX, maxX, minY, maxY;
+  float logScaleFactor;
+  int32_t nScaleLevels;
+} ccm_frustum_frame;
+int  ccm_frame_frustum(ccm_ctx* ctx, const ccm_frustum_frame* fr, int n, const float* P /* n x 3 */,
+                       const float* normal /* n x 3 */, const float* min_dist, const float* max_dist,
+                       float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y, int32_t* level,
+                       float* view_cos);
+
 /* ---- bundle adjustment ----------------------------------------------------------------
  * Replaces the g2o machinery driven by Optimizer::BundleAdjustmentClient /
  * LocalBundleAdjustmentClient / MapFusionGBA (cslam/src/Optimizer.cpp:40-212, 349-644,

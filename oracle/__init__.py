@@ -107,6 +107,19 @@ def build_grid(kx, ky, bounds):
     return off, idx[:off[-1]]
 
 
+def is_in_frustum(frame24, n_levels, P, normal, dmin, dmax, cos_limit=0.5):
+    """Frame::isInFrustum restated (ora_is_in_frustum).  frame24 = Rcw 9 | tcw 3 | Ow 3 | fx fy cx cy | minX maxX minY maxY | logSF."""
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    frame24, P, normal, dmin, dmax = f32(frame24), f32(P).reshape(-1, 3), f32(normal).reshape(-1, 3), f32(dmin), f32(dmax)
+    n = P.shape[0]
+    inv = np.zeros(max(n, 1), np.uint8); u = np.zeros(max(n, 1), np.float32); v = np.zeros(max(n, 1), np.float32)
+    lvl = np.zeros(max(n, 1), np.int32); cs = np.zeros(max(n, 1), np.float32)
+    lib().ora_is_in_frustum(_p(frame24, C.c_float), int(n_levels), n, _p(P, C.c_float), _p(normal, C.c_float), _p(dmin, C.c_float),
+                            _p(dmax, C.c_float), C.c_float(cos_limit), _p(inv, C.c_uint8), _p(u, C.c_float), _p(v, C.c_float),
+                            _p(lvl, C.c_int32), _p(cs, C.c_float))
+    return inv[:n], u[:n], v[:n], lvl[:n], cs[:n]
+
+
 def undistort_points(K, dist, xy):
     """Frame::UndistortKeyPoints restated (ora_undistort_points)."""
     K = np.ascontiguousarray(K, np.float32); dist = np.ascontiguousarray(dist, np.float32)

@@ -665,3 +665,49 @@ extern "C" void ora_build_grid(const float* kx, const float* ky, int N, float mi
   cell_off[GRID_COLS * GRID_ROWS] = n;
   delete g;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::isInFrustum (cslam/src/Frame.cpp:139-198) over a batch of map points, flat restatement.
+// frame = [Rcw 9 | tcw 3 | Ow 3 | fx fy cx cy | minX maxX minY maxY | logScaleFactor] (f32) + nScaleLevels.
+// cv::Mat arithmetic is [EXT] (OpenCV 4.2.0): mRcw*P+mtcw = gemm small-matrix path (f32 sum of three products, then
+// (float)(t*alpha + c*beta) in f64; baseline non-FMA build); cv::norm / Mat::dot accumulate in f64.
+extern "C" void ora_is_in_frustum(const float* frame, int nScaleLevels, int n, const float* P, const float* Pn, const float* dmin,
+                                  const float* dmax, float viewingCosLimit, uint8_t* in_view, float* pu, float* pv, int32_t* lvl,
+                                  float* pcos) {
+  const float* R = frame; const float* t = frame + 9; const float* Ow = frame + 12;
+  const float fx = frame[15], fy = frame[16], cx = frame[17], cy = frame[18];
+  const float minX = frame[19], maxX = frame[20], minY = frame[21], maxY = frame[22], logSF = frame[23];
+  for (int i = 0; i < n; i++) {
+    in_view[i] = 0; pu[i] = 0; pv[i] = 0; lvl[i] = 0; pcos[i] = 0;      // pMP->mbTrackInView = false (:141)
+    const float* X = P + 3 * (size_t)i;
+    float Pc[3];
+    for (int r = 0; r < 3; r++) {
+      const float acc = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2];
+      Pc[r] = (float)((double)acc * 1.0 + (double)t[r] * 1.0);
+    }
+    const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+    if (PcZ < 0.0f) continue;
+    const float invz = 1.0f / PcZ;
+    const float u = fx * PcX * invz + cx;
+    const float v = fy * PcY * invz + cy;
+    if (u < minX || u > maxX) continue;
+    if (v < minY || v > maxY) continue;
+    const float maxDistance = 1.2f * dmax[i];      // MapPoint::GetMaxDistanceInvariance (MapPoint.cpp:831-835)
+    const float minDistance = 0.8f * dmin[i];
+    const float PO[3] = {X[0] - Ow[0], X[1] - Ow[1], X[2] - Ow[2]};
+    double s2 = 0;
+    for (int k = 0; k < 3; k++) s2 += (double)PO[k] * PO[k];
+    const float dist = (float)std::sqrt(s2);
+    if (dist < minDistance || dist > maxDistance) continue;
+    double dot = 0;
+    for (int k = 0; k < 3; k++) dot += (double)PO[k] * Pn[3 * (size_t)i + k];
+    const float viewCos = (float)(dot / dist);
+    if (viewCos < viewingCosLimit) continue;
+    const float ratio = dmax[i] / dist;             // MapPoint::PredictScale (MapPoint.cpp:854-869)
+    int nScale = (int)std::ceil(std::log(ratio) / logSF);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nScaleLevels) nScale = nScaleLevels - 1;
+    in_view[i] = 1; pu[i] = u; pv[i] = v; lvl[i] = nScale; pcos[i] = viewCos;
+  }
+}

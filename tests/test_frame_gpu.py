@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from ccm_slam_amd import synth
-from ccm_slam_amd.frame import GRID_COLS, GRID_ROWS, FrameGrid
+from ccm_slam_amd.frame import GRID_COLS, GRID_ROWS, FrameGrid, is_in_frustum
 
 pytestmark = pytest.mark.gpu
 
@@ -71,3 +71,34 @@ def test_empty_frame_and_empty_queries(ctx):
     off, idx, dist = fg.window_search([], [], [], [], [], np.zeros((0, 32), np.uint8))
     assert off.tolist() == [0]
     fg.close()
+
+
+def _frustum_case(seed, n=20000):
+    rng = np.random.default_rng(seed)
+    R, t, _ = synth._agent_loop(40, 0)
+    R, t = R[5].astype(np.float32), t[5].astype(np.float32)
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    b = np.array([-135.79564, 895.5073, -92.875015, 565.5531], np.float32)   # minX maxX minY maxY of the EuRoC camera
+    frame24 = np.concatenate([R.ravel(), t, Ow, EUROC_K, b, [np.float32(np.log(np.float32(1.2)))]]).astype(np.float32)
+    # points all around the camera: in front / behind / outside the image / too far / too close / bad viewing angle
+    P = (Ow + rng.normal(size=(n, 3)) * 6).astype(np.float32)
+    view = P - Ow
+    normal = view / np.linalg.norm(view, axis=1, keepdims=True)
+    normal = (normal + rng.normal(size=(n, 3)) * rng.choice([0.05, 0.8], (n, 1))).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True).astype(np.float32)
+    d = np.linalg.norm(view, axis=1)
+    dmax = (d * rng.uniform(0.6, 4.0, n)).astype(np.float32)
+    dmin = (dmax / np.float32(1.2 ** 7)).astype(np.float32)
+    return frame24, P, normal.astype(np.float32), dmin, dmax
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_frustum_cull_matches_the_oracle_bit_for_bit(ctx, oracle_lib, seed):
+    frame24, P, normal, dmin, dmax = _frustum_case(seed)
+    got = is_in_frustum(ctx, frame24, 8, P, normal, dmin, dmax, 0.5)
+    exp = oracle_lib.is_in_frustum(frame24, 8, P, normal, dmin, dmax, 0.5)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    frac = got[0].mean()
+    assert 0.02 < frac < 0.6                                  # every rejection branch and the accept branch are exercised
+    assert len(np.unique(got[3][got[0] == 1])) >= 6           # predicted levels span the pyramid

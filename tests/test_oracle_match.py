@@ -123,3 +123,19 @@ def test_undistort_restatement_inverts_the_distortion_model(oracle_lib):
     for c in range(75 * 48):
         seg = idx[off[c]:off[c + 1]]
         assert (np.diff(seg) > 0).all()                           # push_back order
+
+
+def test_frustum_oracle_on_hand_built_points(oracle_lib):
+    """Frame::isInFrustum restated: identity pose, EuRoC intrinsics; one point per branch of Frame.cpp:139-198."""
+    import numpy as np
+    K = [458.654, 457.296, 367.215, 248.375]
+    frame = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1] + [0, 0, 0] + [0, 0, 0] + K + [0, 752, 0, 480] + [np.log(np.float32(1.2))], np.float32)
+    P = np.array([[0, 0, 4], [0, 0, -4], [10, 0, 4], [0, 0, 4], [0, 0, 4], [0, 0, 4], [0.5, 0.2, 8]], np.float32)
+    nrm = np.array([[0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1], [0, 0, 1], [1, 0, 0], [0, 0, 1]], np.float32)
+    dmax = np.array([8, 8, 8, 3, 80, 8, 8], np.float32)      # 1.2*3 < 4: too far; min = dmax/1.2^7: 80 -> 22 > 4/0.8: too close
+    dmin = (dmax / np.float32(1.2 ** 7)).astype(np.float32)
+    inv, u, v, lvl, cs = oracle_lib.is_in_frustum(frame, 8, P, nrm, dmin, dmax, 0.5)
+    assert inv.tolist() == [1, 0, 0, 0, 0, 0, 1]
+    assert u[0] == np.float32(367.215) and v[0] == np.float32(248.375) and cs[0] == 1.0
+    assert lvl[0] == int(np.ceil(np.log(np.float32(2.0)) / np.log(np.float32(1.2))))   # ceil(3.80) = 4
+    assert lvl[6] in (0, 1)                                                               # ratio just below 1

@@ -20,6 +20,13 @@ extern "C" long check_trig(unsigned lo, unsigned hi, unsigned step) {
     bad += (memcmp(&c1, &c2, 4) != 0) + (memcmp(&s1, &s2, 4) != 0); }
   return bad;
 }
+extern "C" long check_logf(unsigned lo, unsigned hi, unsigned step) {
+  long bad = 0;
+  for (unsigned long u = lo; u <= hi; u += step) { unsigned v = (unsigned)u; float a; memcpy(&a, &v, 4);
+    float l1 = logf(a), l2 = orbm::logf_glibc(a);
+    bad += (memcmp(&l1, &l2, 4) != 0); }
+  return bad;
+}
 extern "C" float my_atan2(float y, float x) { return orbm::fast_atan2(y, x); }
 extern "C" int my_round(float v) { return orbm::cv_round(v); }
 ''' % ROOT
@@ -33,6 +40,7 @@ def _helper():
     subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", so, "-lm"])
     lib = C.CDLL(so)
     lib.check_trig.restype = C.c_long
+    lib.check_logf.restype = C.c_long
     lib.my_atan2.restype = C.c_float
     return lib
 
@@ -58,3 +66,11 @@ def test_cv_round_half_to_even():
     lib = _helper()
     for v, e in [(0.5, 0), (1.5, 2), (2.5, 2), (-0.5, 0), (-1.5, -2), (2.4999, 2), (-7.5, -8), (13.0, 13)]:
         assert lib.my_round(C.c_float(v)) == e
+
+
+def test_logf_bit_exact_vs_libm():
+    """MapPoint::PredictScale takes ceil(log(ratio)/logScaleFactor) in f32; glibc's logf is not correctly rounded, so the
+    device restates its algorithm.  Every 97th positive normal float here; the exhaustive run over all 2 130 706 432
+    positive normal floats found 0 mismatches."""
+    lib = _helper()
+    assert lib.check_logf(0x00800000, 0x7f7fffff, 97) == 0
