@@ -85,13 +85,14 @@ struct WinQ { const float* u; const float* v; const float* r; const int* minl; c
 // pass 0: count, pass 1: fill.  One thread per query walks its cells in the reference's order.
 template <int FILL>
 __global__ void frame_window_kernel(int Q, WinQ q, FrameBounds b, const float* xy, const int* oct, const int* cell_off, const int* cell_idx,
-                                    int* cnt, const int* off, int* out_idx) {
+                                    int* cnt, const int* off, int* out_idx, int cap = 0x7fffffff) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Q) return;
   const float x = q.u[i], y = q.v[i], r = q.r[i];
   const int minLevel = q.minl[i], maxLevel = q.maxl[i];
   int x0, x1, y0, y1, n = 0;
   int w = FILL ? off[i] : 0;
+  if (FILL && off[i + 1] > cap) return;   // would cross the caller's capacity: the host reports the shortfall
   if (frame_cell_range(b, x, y, r, x0, x1, y0, y1)) {
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
     for (int ix = x0; ix <= x1; ix++)
@@ -272,27 +273,35 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
   WinQ wq{d_q, d_q + wQ, d_q + 2 * wQ, (const int*)(d_q + 3 * wQ), (const int*)(d_q + 4 * wQ)};
   const int nb = ccm_div_up(Q, 128);
   hipLaunchKernelGGL(frame_window_kernel<0>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx, d_cnt,
-                     (const int*)nullptr, (int*)nullptr);
+                     (const int*)nullptr, (int*)nullptr, 0);
   hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, Q, d_off);
   int* h_off = (int*)(h + 52 * wQ);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_off, d_off, 4 * (wQ + 1), hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  const int64_t total = h_off[Q];
-  memcpy(cand_off, h_off, 4 * (wQ + 1));
-  *n_cand = total;
-  if (total > cap) return cap ? ccm_set_error(ctx, CCM_E_ARG, "ccm_frame_window_search: candidate capacity too small") : CCM_OK;   // cap == 0: sizing call
-  if (total == 0) return CCM_OK;
-  hipLaunchKernelGGL(frame_window_kernel<1>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx,
-                     (int*)nullptr, (const int*)d_off, d_idx);
-  CCM_HIP_CHECK(ctx, hipGetLastError());
-  if (int rc = ccm_hamming_csr_dev(ctx, d_qdesc, Q, f->d_desc, f->N, d_off, d_idx, total, d_dist, nullptr, nullptr, nullptr)) return rc;
   uint8_t* h_idx = h + 52 * wQ + 4 * (wQ + 1);
   uint8_t* h_dist = h_idx + 4 * (size_t)cap;
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_idx, d_idx, 4 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_dist, d_dist, 2 * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  if (cap > 0) {
+    // optimistic single-sync path: fill and distances are queued behind the scan without waiting for the total; the
+    // fill kernel never writes past cap (queries whose list would cross it are skipped) and the total is checked after
+    hipLaunchKernelGGL(frame_window_kernel<1>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx,
+                       (int*)nullptr, (const int*)d_off, d_idx, (int)std::min<int64_t>(cap, 0x7fffffff));
+    CCM_HIP_CHECK(ctx, hipGetLastError());
+    if (int rc = ccm_hamming_csr_dev(ctx, d_qdesc, Q, f->d_desc, f->N, d_off, d_idx, cap, d_dist, nullptr, nullptr, nullptr)) return rc;
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_off, d_off, 4 * (wQ + 1), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_idx, d_idx, 4 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_dist, d_dist, 2 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t total = h_off[Q];
+    memcpy(cand_off, h_off, 4 * (wQ + 1));
+    *n_cand = total;
+    if (total > cap) return ccm_set_error(ctx, CCM_E_ARG, "ccm_frame_window_search: candidate capacity too small");
+    memcpy(cand_idx, h_idx, 4 * (size_t)total);
+    memcpy(cand_dist, h_dist, 2 * (size_t)total);
+    return CCM_OK;
+  }
+  // sizing call (cap == 0): counts only
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_off, d_off, 4 * (wQ + 1), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(cand_idx, h_idx, 4 * (size_t)total);
-  memcpy(cand_dist, h_dist, 2 * (size_t)total);
+  memcpy(cand_off, h_off, 4 * (wQ + 1));
+  *n_cand = h_off[Q];
   return CCM_OK;
 }
 

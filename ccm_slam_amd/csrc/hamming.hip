@@ -86,11 +86,12 @@ __global__ __launch_bounds__(256) void hamming_csr_kernel(
     const uint32_t* __restrict__ q, int Q, const uint32_t* __restrict__ t,
     const int32_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx,
     uint16_t* __restrict__ cand_dist, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
-    int32_t* __restrict__ second_dist) {
+    int32_t* __restrict__ second_dist, long long n_cand) {
   const int lane = threadIdx.x & (kWave - 1);
   const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave));
   if (qi >= Q) return;
   const int c0 = cand_off[qi], c1 = cand_off[qi + 1];
+  if ((long long)c1 > n_cand) return;   // list lies (partly) beyond the buffers the caller sized: never touch it
   uint32_t qa[8];
   {
     const uint32_t* qp = q + (size_t)qi * 8;   // wave-uniform address
@@ -280,7 +281,7 @@ extern "C" int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, cons
                                    const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
                                    uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist,
                                    int32_t* d_second_dist) {
-  (void)T; (void)n_cand;
+  (void)T;
   if (!ctx || Q < 0) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: bad args");
   if (d_best_idx && (!d_best_dist || !d_second_dist)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: best2 outputs must be all set or all NULL");
   if (Q == 0) return CCM_OK;
@@ -288,7 +289,7 @@ extern "C" int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, cons
   {
     ccm_prof_scope ps(ctx, CCM_K_HAMMING_CSR);
     hipLaunchKernelGGL(hamming_csr_kernel, dim3(ccm_div_up(Q, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q,
-                       (const uint32_t*)d_t, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist);
+                       (const uint32_t*)d_t, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist, (long long)n_cand);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;

@@ -58,10 +58,15 @@ class FrameGrid:
         off = np.zeros(Q + 1, np.int32)
         n = C.c_int64(0)
         args = (self._h, Q, _p(u), _p(v), _p(r), _p(min_level), _p(max_level), _p(qdesc), _p(off))
-        check(lib().ccm_frame_window_search(*args, None, None, C.c_int64(0), C.byref(n)), self.ctx.handle)
-        idx = np.zeros(max(n.value, 1), np.int32)
-        dist = np.zeros(max(n.value, 1), np.uint16)
-        check(lib().ccm_frame_window_search(*args, _p(idx), _p(dist), C.c_int64(idx.size), C.byref(n)), self.ctx.handle)
+        cap = 24 * Q + 1024                                    # typical lists are short; one retry with the exact size otherwise
+        idx = np.zeros(cap, np.int32)
+        dist = np.zeros(cap, np.uint16)
+        rc = lib().ccm_frame_window_search(*args, _p(idx), _p(dist), C.c_int64(cap), C.byref(n))
+        if rc != 0 and n.value > cap:
+            idx = np.zeros(n.value, np.int32)
+            dist = np.zeros(n.value, np.uint16)
+            rc = lib().ccm_frame_window_search(*args, _p(idx), _p(dist), C.c_int64(idx.size), C.byref(n))
+        check(rc, self.ctx.handle)
         return off, idx[:n.value], dist[:n.value]
 
     def close(self):

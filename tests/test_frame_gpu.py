@@ -102,3 +102,24 @@ def test_frustum_cull_matches_the_oracle_bit_for_bit(ctx, oracle_lib, seed):
     frac = got[0].mean()
     assert 0.02 < frac < 0.6                                  # every rejection branch and the accept branch are exercised
     assert len(np.unique(got[3][got[0] == 1])) >= 6           # predicted levels span the pyramid
+
+
+def test_window_search_capacity_shortfall_is_reported_not_overrun(ctx, oracle_lib):
+    import ctypes as C
+    from ccm_slam_amd._lib import lib
+    kps, desc = _kps(oracle_lib, t=9)
+    fg = FrameGrid(ctx, EUROC_K, EUROC_D, 752, 480)
+    fg.set_keypoints(kps, desc)
+    xy, _, _ = fg.get()
+    Q = 500
+    u = np.ascontiguousarray(xy[:Q, 0]); v = np.ascontiguousarray(xy[:Q, 1])
+    r = np.full(Q, 60.0, np.float32); ml = np.full(Q, -1, np.int32)
+    qd = np.ascontiguousarray(desc[:Q])
+    off = np.zeros(Q + 1, np.int32); idx = np.full(64, -7, np.int32); dist = np.full(64, 9999, np.uint16); n = C.c_int64(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().ccm_frame_window_search(fg._h, Q, p(u), p(v), p(r), p(ml), p(ml), p(qd), p(off), p(idx), p(dist), C.c_int64(64), C.byref(n))
+    assert rc != 0 and n.value > 64 and off[-1] == n.value          # the true size comes back for the retry
+    assert (idx == -7).all() and (dist == 9999).all()               # nothing was written into the short buffers
+    off2, idx2, dist2 = fg.window_search(u, v, r, ml, ml, qd)       # the wrapper retries with the exact size
+    assert idx2.size == n.value and np.array_equal(off2, off)
+    fg.close()
