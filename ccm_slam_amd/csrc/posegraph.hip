@@ -1,0 +1,560 @@
+// posegraph.hip — Optimizer::OptimizeEssentialGraphLoopClosure / MapFusion numerics (cslam/src/Optimizer.cpp:1058-1331,
+// 1333-1566): 7-DoF pose graph over keyframes.  Reference structure: one VertexSim3Expmap per keyframe (estimate Siw,
+// one vertex fixed, _fix_scale), one EdgeSim3 per spanning-tree / loop / covisibility link (vertex(0) = i, vertex(1) = j,
+// measurement Sji, information I7; error = log(Sji * Siw * Sjw^-1), types_seven_dof_expmap.h:98-121), BlockSolver_7_3 +
+// LinearSolverEigen, Levenberg with setUserLambdaInit(1e-16), optimize(20).  EdgeSim3 does not override linearizeOplus:
+// both 7x7 Jacobians are g2o's central differences through the vertex oplus (base_binary_edge.hpp:129-196, delta 1e-9),
+// which is where g2o spends its time on this problem (28 exp/log evaluations per edge per iteration).
+//
+// Device design: the numeric differentiation is embarrassingly parallel — one lane per (edge, vertex side, dimension,
+// sign) — so `pg_linearize` runs 29 lanes per edge (28 perturbed errors + the base error).  H is assembled by gather
+// (one wave per 7x7 block walks the edges that contribute to it: no atomics, fixed order), the damped system is solved
+// with block-Jacobi PCG on the block-CSR matrix (two launches per iteration, device-resident scalars, the same scheme
+// as ba.hip's multi-kernel path with 7x7 blocks) and the LM control loop stays on the host like
+// optimization_algorithm_levenberg.cpp:61-164.  The graph walk that picks the edges and the SE3 / map-point write-back
+// (Optimizer.cpp:1268-1330) stay with the caller.
+#include "common.h"
+#include "sim3_math.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTPB = 256;
+constexpr uint32_t kT = 0x80000000u;   // transpose bit of a row entry
+
+struct PgDev {
+  int V, F, E, nBlk;          // vertices, free vertices, active edges, blocks (F diagonal first)
+  int fix_scale;
+  double* S[2];               // [V*8] current / trial
+  const int* slot;            // [V] free slot or -1
+  const int* free_v;          // [F] vertex of slot
+  const int *ei, *ej;         // [E]
+  const double* meas;         // [E*8]
+  double* err;                // [E*7] errors of the last evaluated state (computeActiveErrors)
+  double* J;                  // [E][2][49]  J[k*7+d]
+  double* H;                  // [nBlk*49]
+  double* b;                  // [F*7]
+  // structure
+  const int* blk_off; const int* blk_edge;        // per block: contributing edges; entry = edge*4 + (side_row*2 + side_col)
+  const int* vtx_off; const int* vtx_edge;        // per free slot: incident (edge*2 + side)
+  const int* row_off; const int* row_col; const uint32_t* row_blk;
+  // PCG
+  double *x, *r, *z, *q, *p[2], *Minv;
+  double *ppq, *prz[2];
+  double* scal;               // [0]=rz0 [1]=thresh^2 [2]=lambda ; [4]=chi2 [5]=scale
+  int* flag;                  // [0]=done [1]=iters [2]=fail
+  double* part;               // partial sums of chi2 / scale
+  int n_wg_row, n_wg_upd, n_wg_edge;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n) {
+  const int lane = threadIdx.x & (kWave - 1);
+  double s = 0;
+  for (int i = lane; i < n; i += kWave) s += p[i];
+  return wave_sum(s);
+}
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) lds[threadIdx.x / kWave] = v;
+  __syncthreads();
+  double s = 0;
+#pragma unroll
+  for (int w = 0; w < kTPB / kWave; w++) s += lds[w];
+  return s;
+}
+
+__device__ __forceinline__ Sim3d pg_oplus(const Sim3d& X, const double* upd, int fix_scale) {
+  double u[7];
+#pragma unroll
+  for (int k = 0; k < 7; k++) u[k] = upd[k];
+  if (fix_scale) u[6] = 0;                       // VertexSim3Expmap::oplusImpl (types_seven_dof_expmap.h:58-67)
+  return sim3_mul(sim3_exp(u), X);
+}
+__device__ __forceinline__ void pg_edge_error(const Sim3d& C, const Sim3d& Si, const Sim3d& Sj, double err[7]) {
+  const Sim3d Eo = sim3_mul(sim3_mul(C, Si), sim3_inv(Sj));   // EdgeSim3::computeError (:104-112)
+  sim3_log(Eo, err);
+}
+
+// errors + chi2 of state `which` (computeActiveErrors + activeChi2): thread per edge       [also used for the trial]
+__global__ __launch_bounds__(kTPB) void pg_chi2(PgDev d, int which) {
+  __shared__ double lds[kTPB / kWave];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double c2 = 0;
+  if (e < d.E) {
+    const Sim3d C = sim3_load(d.meas + 8 * (size_t)e);
+    const Sim3d Si = sim3_load(d.S[which] + 8 * (size_t)d.ei[e]), Sj = sim3_load(d.S[which] + 8 * (size_t)d.ej[e]);
+    double er[7];
+    pg_edge_error(C, Si, Sj, er);
+#pragma unroll
+    for (int k = 0; k < 7; k++) { d.err[7 * (size_t)e + k] = er[k]; c2 += er[k] * er[k]; }
+  }
+  const double s = block_sum(c2, lds);
+  if (threadIdx.x == 0) d.part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(kTPB) void pg_reduce(PgDev d, int n, int dst) {
+  __shared__ double lds[kTPB / kWave];
+  double s = 0;
+  for (int i = threadIdx.x; i < n; i += kTPB) s += d.part[i];
+  const double tot = block_sum(s, lds);
+  if (threadIdx.x == 0) d.scal[dst] = tot;
+}
+
+// numeric Jacobians: 32 lanes per edge; lane l < 28 -> side = l / 14, dim = (l % 14) / 2, sign = l & 1
+__global__ __launch_bounds__(kTPB) void pg_linearize(PgDev d, int cur) {
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+  const int l = threadIdx.x & 31;
+  if (e >= d.E) return;
+  const int vi = d.ei[e], vj = d.ej[e];
+  const Sim3d C = sim3_load(d.meas + 8 * (size_t)e);
+  Sim3d Si = sim3_load(d.S[cur] + 8 * (size_t)vi), Sj = sim3_load(d.S[cur] + 8 * (size_t)vj);
+  const int side = l / 14, dim = (l % 14) >> 1;
+  const bool active = l < 28 && (side == 0 ? d.slot[vi] >= 0 : d.slot[vj] >= 0);
+  double er[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (active) {
+    double add[7] = {0, 0, 0, 0, 0, 0, 0};
+    const double dl = (l & 1) ? -1e-9 : 1e-9;
+#pragma unroll
+    for (int k = 0; k < 7; k++) if (k == dim) add[k] = dl;
+    if (side == 0) Si = pg_oplus(Si, add, d.fix_scale); else Sj = pg_oplus(Sj, add, d.fix_scale);
+    pg_edge_error(C, Si, Sj, er);
+  }
+  // column = scalar * (e+ - e-): the minus lane sits next to the plus lane
+  const double scalar = 1.0 / (2 * 1e-9);
+  double* Jout = d.J + 98 * (size_t)e + 49 * side;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const double other = __shfl_xor(er[k], 1, kWave);
+    if (l < 28 && !(l & 1)) Jout[k * 7 + dim] = active ? scalar * (er[k] - other) : 0.0;
+  }
+}
+
+// H blocks by gather: one wave per block, lane = element (p, q); b by gather: one wave per free vertex
+__global__ __launch_bounds__(kTPB) void pg_assemble(PgDev d) {
+  const int w = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (w < d.nBlk) {
+    if (lane < 49) {
+      const int p = lane / 7, q = lane % 7;
+      double acc = 0;
+      for (int s = d.blk_off[w]; s < d.blk_off[w + 1]; s++) {
+        const int code = d.blk_edge[s];
+        const int e = code >> 2, sr = (code >> 1) & 1, sc = code & 1;
+        const double* A = d.J + 98 * (size_t)e + 49 * sr;
+        const double* B = d.J + 98 * (size_t)e + 49 * sc;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += A[k * 7 + p] * B[k * 7 + q];
+      }
+      d.H[49 * (size_t)w + lane] = acc;
+    }
+  } else if (w < d.nBlk + d.F) {
+    const int a = w - d.nBlk;
+    if (lane < 7) {
+      double acc = 0;
+      for (int s = d.vtx_off[a]; s < d.vtx_off[a + 1]; s++) {
+        const int code = d.vtx_edge[s];
+        const int e = code >> 1, side = code & 1;
+        const double* Jm = d.J + 98 * (size_t)e + 49 * side;
+        const double* er = d.err + 7 * (size_t)e;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += Jm[k * 7 + lane] * (-er[k]);
+      }
+      d.b[7 * (size_t)a + lane] = acc;
+    }
+  }
+}
+
+// ---- block-Jacobi PCG on (H + lambda I) x = b, 7x7 blocks ----
+__global__ __launch_bounds__(kTPB) void pg_pcg_init(PgDev d, double lambda, double rel_tol) {
+  __shared__ double lds[kTPB / kWave];
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  double rz = 0;
+  bool bad = false;
+  if (a < d.F) {
+    // Minv = (H_aa + lambda I)^-1 by Cholesky + triangular inverse, in registers
+    double L[49], X[28];
+#pragma unroll
+    for (int i = 0; i < 49; i++) L[i] = d.H[49 * (size_t)a + i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) L[i * 8] += lambda;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      double dj = L[j * 7 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dj -= L[j * 7 + k] * L[j * 7 + k];
+      if (!(dj > 0.0)) { bad = true; dj = 1.0; }
+      dj = sqrt(dj);
+      L[j * 7 + j] = dj;
+      const double inv = 1.0 / dj;
+#pragma unroll
+      for (int i = j + 1; i < 7; i++) {
+        double s = L[i * 7 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[i * 7 + k] * L[j * 7 + k];
+        L[i * 7 + j] = s * inv;
+      }
+    }
+#pragma unroll
+    for (int col = 0; col < 7; col++)
+#pragma unroll
+      for (int i = col; i < 7; i++) {
+        double s = (i == col) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = col; k < i; k++) s -= L[i * 7 + k] * X[k * (k + 1) / 2 + col];
+        X[i * (i + 1) / 2 + col] = s / L[i * 7 + i];
+      }
+    double r[7], z[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) r[i] = d.b[7 * (size_t)a + i];
+#pragma unroll
+    for (int p = 0; p < 7; p++)
+#pragma unroll
+      for (int q = 0; q < 7; q++) {
+        double s = 0;
+#pragma unroll
+        for (int k = (p > q ? p : q); k < 7; k++) s += X[k * (k + 1) / 2 + p] * X[k * (k + 1) / 2 + q];
+        d.Minv[49 * (size_t)a + p * 7 + q] = s;
+        L[p * 7 + q] = s;
+      }
+#pragma unroll
+    for (int p = 0; p < 7; p++) {
+      double s = 0;
+#pragma unroll
+      for (int q = 0; q < 7; q++) s += L[p * 7 + q] * r[q];
+      z[p] = s;
+      rz += r[p] * s;
+      const size_t g = 7 * (size_t)a + p;
+      d.x[g] = 0; d.r[g] = r[p]; d.z[g] = s; d.p[0][g] = 0;
+    }
+  }
+  const double tot = block_sum(rz, lds);
+  if (threadIdx.x == 0) d.prz[0][blockIdx.x] = tot;
+  if (bad) d.flag[2] = 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d.scal[1] = rel_tol * rel_tol; d.scal[2] = lambda; }
+}
+
+// iteration k: p = z + beta p_old on the fly, q = (H + lambda I) p, partial p.q — one wave per block row
+__global__ __launch_bounds__(kTPB) void pg_pcg_spmv(PgDev d, int k) {
+  __shared__ double lds[kTPB / kWave];
+  if (d.flag[0]) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x / kWave;
+  const int i = blockIdx.x * (kTPB / kWave) + wv;
+  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  double beta = 0;
+  if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.scal[0] = rz_k; }
+  else beta = rz_k / sum_partials(d.prz[(k + 1) & 1], d.n_wg_upd);
+  const double rz0 = (k == 0) ? rz_k : d.scal[0];
+  if (rz_k <= d.scal[1] * rz0 || !(rz_k > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flag[0] = 1; d.flag[1] = k; if (rz_k != rz_k) d.flag[2] = 1; }
+    return;
+  }
+  const double lambda = d.scal[2];
+  const double* pold = d.p[k & 1];
+  double* pnew = d.p[(k + 1) & 1];
+  const int g = lane >> 3, r = lane & 7;
+  double acc = 0;
+  if (i < d.F && r < 7) {
+    for (int s = d.row_off[i] + g; s < d.row_off[i + 1]; s += 8) {
+      const int j = d.row_col[s];
+      const uint32_t bt = d.row_blk[s];
+      const double* B = d.H + 49 * (size_t)(bt & ~kT);
+#pragma unroll
+      for (int c = 0; c < 7; c++) {
+        const double v = (bt & kT) ? B[c * 7 + r] : B[r * 7 + c];
+        acc += v * (d.z[7 * (size_t)j + c] + beta * pold[7 * (size_t)j + c]);
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 8, kWave);
+  acc += __shfl_xor(acc, 16, kWave);
+  acc += __shfl_xor(acc, 32, kWave);
+  double pq = 0;
+  if (i < d.F && lane < 7) {
+    const double pi = d.z[7 * (size_t)i + lane] + beta * pold[7 * (size_t)i + lane];
+    const double qv = acc + lambda * pi;
+    d.q[7 * (size_t)i + lane] = qv;
+    pnew[7 * (size_t)i + lane] = pi;
+    pq = pi * qv;
+  }
+  pq = wave_sum(pq);
+  if (lane == 0) lds[wv] = pq;
+  __syncthreads();
+  if (threadIdx.x == 0) d.ppq[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
+// alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z — 8 lanes per vertex (7 active)
+__global__ __launch_bounds__(kTPB) void pg_pcg_update(PgDev d, int k) {
+  __shared__ double lds[kTPB / kWave];
+  __shared__ double rs[kTPB];
+  const int t = threadIdx.x;
+  const int a = blockIdx.x * (kTPB / 8) + (t >> 3), c = t & 7;
+  const bool on = a < d.F && c < 7;
+  const int done = d.flag[0];
+  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  const double pq = sum_partials(d.ppq, d.n_wg_row);
+  if (done) return;
+  if (!(pq > 0.0)) {
+    if (blockIdx.x == 0 && t == 0) { d.flag[0] = 1; d.flag[1] = k; d.flag[2] = 1; }
+    return;
+  }
+  const double alpha = rz_k / pq;
+  const size_t g = 7 * (size_t)a + c;
+  double rv = 0;
+  if (on) {
+    const double* p = d.p[(k + 1) & 1];
+    d.x[g] += alpha * p[g];
+    rv = d.r[g] - alpha * d.q[g];
+    d.r[g] = rv;
+  }
+  rs[t] = rv;
+  __syncthreads();
+  double rz = 0;
+  if (on) {
+    const double* M = d.Minv + 49 * (size_t)a + 7 * c;
+    double z = 0;
+#pragma unroll
+    for (int q = 0; q < 7; q++) z += M[q] * rs[(t & ~7) + q];
+    d.z[g] = z;
+    rz = rv * z;
+  }
+  const double tot = block_sum(rz, lds);
+  if (t == 0) {
+    d.prz[(k + 1) & 1][blockIdx.x] = tot;
+    if (blockIdx.x == 0) d.flag[1] = k + 1;
+  }
+}
+
+// trial state = oplus(current, x) for free vertices, copy for fixed ones; partial of sum x (lambda x + b)
+__global__ __launch_bounds__(kTPB) void pg_apply(PgDev d, int cur, double lambda) {
+  __shared__ double lds[kTPB / kWave];
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  double sc = 0;
+  if (v < d.V) {
+    const int a = d.slot[v];
+    Sim3d S = sim3_load(d.S[cur] + 8 * (size_t)v);
+    if (a >= 0) {
+      double u[7];
+#pragma unroll
+      for (int k = 0; k < 7; k++) { u[k] = d.x[7 * (size_t)a + k]; sc += u[k] * (lambda * u[k] + d.b[7 * (size_t)a + k]); }
+      S = pg_oplus(S, u, d.fix_scale);
+    }
+    sim3_store(d.S[cur ^ 1] + 8 * (size_t)v, S);
+  }
+  const double s = block_sum(sc, lds);
+  if (threadIdx.x == 0) d.part[blockIdx.x] = s;
+}
+
+template <typename T>
+int up(ccm_ctx* ctx, std::vector<void*>& allocs, const std::vector<T>& v, T** out) {
+  void* p = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
+  allocs.push_back(p);
+  if (!v.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *out = (T*)p;
+  return CCM_OK;
+}
+template <typename T>
+int al(ccm_ctx* ctx, std::vector<void*>& allocs, size_t n, T** out) {
+  void* p = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+  allocs.push_back(p);
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), ctx->stream));
+  *out = (T*)p;
+  return CCM_OK;
+}
+
+}  // namespace
+
+#define PG_RC(x) do { int rc_ = (x); if (rc_) { for (void* p_ : allocs) hipFree(p_); return rc_; } } while (0)
+
+extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, const uint8_t* fixed, int fix_scale, int n_edge,
+                                       const int32_t* e_i, const int32_t* e_j, const double* meas, int max_iters, double lambda_init,
+                                       const volatile unsigned char* stop_flag, ccm_pg_stats* stats) {
+  if (!ctx || n_vert < 0 || n_edge < 0 || (n_vert && (!sim3 || !fixed)) || (n_edge && (!e_i || !e_j || !meas)) || max_iters < 0)
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_pose_graph_optimize: bad args");
+  ccm_pg_stats st{};
+  if (stats) *stats = st;
+  for (int e = 0; e < n_edge; e++)
+    if (e_i[e] < 0 || e_i[e] >= n_vert || e_j[e] < 0 || e_j[e] >= n_vert || e_i[e] == e_j[e])
+      return ccm_set_error(ctx, CCM_E_ARG, "ccm_pose_graph_optimize: edge vertex index out of range");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // ---- structure (host): slots, active edges, blocks, gather lists, block-CSR rows ----
+  std::vector<int> slot(n_vert, -1), free_v;
+  for (int v = 0; v < n_vert; v++) if (!fixed[v]) { slot[v] = (int)free_v.size(); free_v.push_back(v); }
+  const int F = (int)free_v.size();
+  std::vector<int> ei, ej; std::vector<double> ms;
+  for (int e = 0; e < n_edge; e++) {
+    if (fixed[e_i[e]] && fixed[e_j[e]]) continue;       // not in the active set (all vertices fixed)
+    ei.push_back(e_i[e]); ej.push_back(e_j[e]);
+    ms.insert(ms.end(), meas + 8 * (size_t)e, meas + 8 * (size_t)e + 8);
+  }
+  const int E = (int)ei.size();
+  if (F == 0 || E == 0) return CCM_OK;
+  std::map<std::pair<int, int>, int> blk;
+  std::vector<std::pair<int, int>> keys;
+  for (int a = 0; a < F; a++) { blk[{a, a}] = a; keys.push_back({a, a}); }
+  for (int e = 0; e < E; e++) {
+    const int a = slot[ei[e]], b = slot[ej[e]];
+    if (a < 0 || b < 0) continue;
+    const std::pair<int, int> k{std::min(a, b), std::max(a, b)};
+    if (!blk.count(k)) { blk[k] = (int)keys.size(); keys.push_back(k); }
+  }
+  const int nBlk = (int)keys.size();
+  std::vector<std::vector<int>> bl(nBlk), vl(F);
+  for (int e = 0; e < E; e++) {
+    const int a = slot[ei[e]], b = slot[ej[e]];
+    if (a >= 0) { bl[a].push_back(e * 4 + 0); vl[a].push_back(e * 2 + 0); }                  // Ji^T Ji
+    if (b >= 0) { bl[b].push_back(e * 4 + 3); vl[b].push_back(e * 2 + 1); }                  // Jj^T Jj
+    if (a >= 0 && b >= 0) bl[blk[{std::min(a, b), std::max(a, b)}]].push_back(e * 4 + (a < b ? 1 : 2));   // rows = lower slot's side
+  }
+  std::vector<int> blk_off(nBlk + 1, 0), blk_edge, vtx_off(F + 1, 0), vtx_edge;
+  for (int k = 0; k < nBlk; k++) { blk_edge.insert(blk_edge.end(), bl[k].begin(), bl[k].end()); blk_off[k + 1] = (int)blk_edge.size(); }
+  for (int a = 0; a < F; a++) { vtx_edge.insert(vtx_edge.end(), vl[a].begin(), vl[a].end()); vtx_off[a + 1] = (int)vtx_edge.size(); }
+  std::vector<std::vector<std::pair<int, uint32_t>>> rows(F);
+  for (int k = 0; k < nBlk; k++) {
+    const int a = keys[k].first, b = keys[k].second;
+    rows[a].push_back({b, (uint32_t)k});
+    if (a != b) rows[b].push_back({a, (uint32_t)k | kT});
+  }
+  std::vector<int> row_off(F + 1, 0), row_col; std::vector<uint32_t> row_blk;
+  for (int a = 0; a < F; a++) {
+    std::sort(rows[a].begin(), rows[a].end(), [](const std::pair<int, uint32_t>& x, const std::pair<int, uint32_t>& y) { return x.first < y.first; });
+    for (auto& pr : rows[a]) { row_col.push_back(pr.first); row_blk.push_back(pr.second); }
+    row_off[a + 1] = (int)row_col.size();
+  }
+  // ---- device state ----
+  std::vector<void*> allocs;
+  PgDev d{};
+  d.V = n_vert; d.F = F; d.E = E; d.nBlk = nBlk; d.fix_scale = fix_scale ? 1 : 0;
+  std::vector<double> s0(sim3, sim3 + 8 * (size_t)n_vert);
+  int *p_i = nullptr; uint32_t* p_u = nullptr; double* p_d = nullptr;
+  PG_RC(up(ctx, allocs, s0, &d.S[0])); PG_RC(up(ctx, allocs, s0, &d.S[1]));
+  PG_RC(up(ctx, allocs, slot, &p_i)); d.slot = p_i;
+  PG_RC(up(ctx, allocs, free_v, &p_i)); d.free_v = p_i;
+  PG_RC(up(ctx, allocs, ei, &p_i)); d.ei = p_i;
+  PG_RC(up(ctx, allocs, ej, &p_i)); d.ej = p_i;
+  PG_RC(up(ctx, allocs, ms, &p_d)); d.meas = p_d;
+  PG_RC(up(ctx, allocs, blk_off, &p_i)); d.blk_off = p_i;
+  PG_RC(up(ctx, allocs, blk_edge, &p_i)); d.blk_edge = p_i;
+  PG_RC(up(ctx, allocs, vtx_off, &p_i)); d.vtx_off = p_i;
+  PG_RC(up(ctx, allocs, vtx_edge, &p_i)); d.vtx_edge = p_i;
+  PG_RC(up(ctx, allocs, row_off, &p_i)); d.row_off = p_i;
+  PG_RC(up(ctx, allocs, row_col, &p_i)); d.row_col = p_i;
+  PG_RC(up(ctx, allocs, row_blk, &p_u)); d.row_blk = p_u;
+  d.n_wg_row = ccm_div_up(F, kTPB / kWave); d.n_wg_upd = ccm_div_up(F, kTPB / 8); d.n_wg_edge = ccm_div_up(E, kTPB);
+  const int n_wg_init = ccm_div_up(F, kTPB), n_wg_v = ccm_div_up(n_vert, kTPB);
+  PG_RC(al(ctx, allocs, 7 * (size_t)E, &d.err)); PG_RC(al(ctx, allocs, 98 * (size_t)E, &d.J));
+  PG_RC(al(ctx, allocs, 49 * (size_t)nBlk, &d.H)); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.b));
+  PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.x)); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.r)); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.z));
+  PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.q)); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.p[0])); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.p[1]));
+  PG_RC(al(ctx, allocs, 49 * (size_t)F, &d.Minv));
+  PG_RC(al(ctx, allocs, (size_t)d.n_wg_row, &d.ppq));
+  // prz is written by pg_pcg_init (n_wg_init workgroups) and pg_pcg_update (n_wg_upd): size for the larger, sum n_wg_upd
+  PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[0])); PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[1]));
+  PG_RC(al(ctx, allocs, 8, &d.scal)); PG_RC(al(ctx, allocs, 4, &d.flag));
+  PG_RC(al(ctx, allocs, (size_t)std::max({d.n_wg_edge, n_wg_v, 1}), &d.part));
+  auto cleanup = [&]() { hipStreamSynchronize(ctx->stream); for (void* p : allocs) hipFree(p); };
+  auto read_scal = [&](int idx, double* out) -> int {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, d.scal + idx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return CCM_OK;
+  };
+  auto chi2_of = [&](int which, double* out) -> int {
+    hipLaunchKernelGGL(pg_chi2, dim3(d.n_wg_edge), dim3(kTPB), 0, ctx->stream, d, which);
+    hipLaunchKernelGGL(pg_reduce, dim3(1), dim3(kTPB), 0, ctx->stream, d, d.n_wg_edge, 4);
+    return read_scal(4, out);
+  };
+  // ---- Levenberg-Marquardt (optimization_algorithm_levenberg.cpp:61-164) ----
+  int cur = 0, rc = CCM_OK;
+  double lambda = lambda_init, ni = 2;
+  int nBad = 0;
+  double currentChi = 0;
+  for (int iter = 0; iter < max_iters && rc == CCM_OK; iter++) {
+    if (stop_flag && *stop_flag) break;
+    if ((rc = chi2_of(cur, &currentChi))) break;
+    if (iter == 0) st.chi2_initial = currentChi;
+    const double iniChi = currentChi;
+    hipLaunchKernelGGL(pg_linearize, dim3(ccm_div_up((int64_t)E * 32, kTPB)), dim3(kTPB), 0, ctx->stream, d, cur);
+    hipLaunchKernelGGL(pg_assemble, dim3(ccm_div_up(nBlk + F, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+    if (iter == 0 && !(lambda_init > 0)) {   // computeLambdaInit without a user value: tau * max diagonal
+      std::vector<double> Hd(49 * (size_t)F);
+      if (hipMemcpyAsync(Hd.data(), d.H, Hd.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: H readback"); break; }
+      double m = 0;
+      for (int a = 0; a < F; a++) for (int k = 0; k < 7; k++) m = std::max(m, std::fabs(Hd[49 * (size_t)a + k * 8]));
+      lambda = 1e-5 * m;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      // solve (H + lambda I) x = b
+      hipMemsetAsync(d.flag, 0, 4 * sizeof(int), ctx->stream);
+      hipMemsetAsync(d.prz[0], 0, sizeof(double) * (size_t)std::max(d.n_wg_upd, n_wg_init), ctx->stream);   // stale partials of the previous solve
+      hipMemsetAsync(d.prz[1], 0, sizeof(double) * (size_t)std::max(d.n_wg_upd, n_wg_init), ctx->stream);
+      hipLaunchKernelGGL(pg_pcg_init, dim3(n_wg_init), dim3(kTPB), 0, ctx->stream, d, lambda, 1e-10);
+      // pg_pcg_init leaves its partial sums in the first n_wg_init slots; the consumers sum n_wg_upd (>= n_wg_init) slots,
+      // the remainder is zero from the allocation / stays zero
+      int flags[4] = {0, 0, 0, 0};
+      const int max_it = std::min(50000, 10 * 7 * F + 100);
+      int k = 0;
+      while (k < max_it) {
+        const int kend = std::min(max_it, k + 32);
+        for (; k < kend; k++) {
+          hipLaunchKernelGGL(pg_pcg_spmv, dim3(d.n_wg_row), dim3(kTPB), 0, ctx->stream, d, k);
+          hipLaunchKernelGGL(pg_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+        }
+        if (hipMemcpyAsync(flags, d.flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: flag readback"); break; }
+        if (flags[0]) break;
+      }
+      if (rc) break;
+      const bool ok2 = !flags[2];
+      st.pcg_iters += flags[0] ? flags[1] : k;
+      if (!ok2) hipMemsetAsync(d.x, 0, 7 * (size_t)F * sizeof(double), ctx->stream);
+      hipLaunchKernelGGL(pg_apply, dim3(n_wg_v), dim3(kTPB), 0, ctx->stream, d, cur, lambda);
+      hipLaunchKernelGGL(pg_reduce, dim3(1), dim3(kTPB), 0, ctx->stream, d, n_wg_v, 5);
+      double tempChi = 0, scale = 0;
+      if ((rc = chi2_of(cur ^ 1, &tempChi))) break;
+      if ((rc = read_scal(5, &scale))) break;
+      st.lm_trials++;
+      if (!ok2) tempChi = DBL_MAX;
+      scale += 1e-3;
+      rho = (currentChi - tempChi) / scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2;
+        currentChi = tempChi;
+        cur ^= 1;
+      } else {
+        lambda *= ni; ni *= 2;
+      }
+      qmax++;
+    } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+    if (rc) break;
+    st.iters_done++;
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) break;
+  }
+  if (rc == CCM_OK) {
+    st.chi2_final = currentChi; st.lambda_final = lambda;
+    if (hipMemcpyAsync(sim3, d.S[cur], 8 * (size_t)n_vert * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+      rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: result readback");
+  }
+  cleanup();
+  if (stats) *stats = st;
+  return rc;
+}

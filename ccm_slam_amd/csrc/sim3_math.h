@@ -111,3 +111,95 @@ BA_HD void sim3_map(const Sim3d& S, const double X[3], double out[3]) {
   ba_qrot(S.qx, S.qy, S.qz, S.qw, X, r);
   out[0] = S.s * r[0] + S.tx; out[1] = S.s * r[1] + S.ty; out[2] = S.s * r[2] + S.tz;
 }
+
+// Eigen::PartialPivLU<Matrix3d>(W).solve(t) as used by Sim3::log (sim3.h:216): unblocked LU with row pivoting on the
+// largest |entry| of the column, unit-lower forward and upper back substitution.  Register-only (no dynamic indexing).
+BA_HD void sim3_lu3_solve(const double W[9], const double t[3], double x[3]) {
+  double a00 = W[0], a01 = W[1], a02 = W[2], a10 = W[3], a11 = W[4], a12 = W[5], a20 = W[6], a21 = W[7], a22 = W[8];
+  double y0 = t[0], y1 = t[1], y2 = t[2];
+#define SIM3_SWAP(p, q) { const double tmp_ = p; p = q; q = tmp_; }
+  // column 0: rows 0..2 (first maximum wins, like Eigen's maxCoeff)
+  {
+    int best = 0; double bv = fabs(a00);
+    if (fabs(a10) > bv) { bv = fabs(a10); best = 1; }
+    if (fabs(a20) > bv) { best = 2; }
+    if (best == 1) { SIM3_SWAP(a00, a10) SIM3_SWAP(a01, a11) SIM3_SWAP(a02, a12) SIM3_SWAP(y0, y1) }
+    else if (best == 2) { SIM3_SWAP(a00, a20) SIM3_SWAP(a01, a21) SIM3_SWAP(a02, a22) SIM3_SWAP(y0, y2) }
+  }
+  a10 /= a00; a20 /= a00;
+  a11 -= a10 * a01; a12 -= a10 * a02;
+  a21 -= a20 * a01; a22 -= a20 * a02;
+  // column 1: rows 1..2
+  if (fabs(a21) > fabs(a11)) { SIM3_SWAP(a10, a20) SIM3_SWAP(a11, a21) SIM3_SWAP(a12, a22) SIM3_SWAP(y1, y2) }
+#undef SIM3_SWAP
+  a21 /= a11;
+  a22 -= a21 * a12;
+  y1 -= a10 * y0;
+  y2 -= a20 * y0; y2 -= a21 * y1;
+  x[2] = y2 / a22;
+  x[1] = (y1 - a12 * x[2]) / a11;
+  x[0] = (y0 - a01 * x[1] - a02 * x[2]) / a00;
+}
+
+// Sim3::log (sim3.h:146-237) -> [omega(3), upsilon(3), sigma]
+BA_HD void sim3_log(const Sim3d& S, double res[7]) {
+  const double sigma = log(S.s);
+  BaPose q{S.qx, S.qy, S.qz, S.qw, 0, 0, 0};
+  double R[9];
+  ba_q_to_R(q, R);
+  const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+  const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  double omega[3];
+  const double eps = 0.00001;
+  double A, B, C;
+  const bool small = d > 1 - eps;
+  double theta = 0;
+  if (small) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i];
+  } else {
+    theta = acos(d);
+    const double k = theta / (2 * sqrt(1 - d * d));
+#pragma unroll
+    for (int i = 0; i < 3; i++) omega[i] = k * dR[i];
+  }
+  if (fabs(sigma) < eps) {
+    C = 1;
+    if (small) { A = 1. / 2.; B = 1. / 6.; }
+    else {
+      const double theta2 = theta * theta;
+      A = (1 - cos(theta)) / (theta2);
+      B = (theta - sin(theta)) / (theta2 * theta);
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (small) {
+      const double sigma2 = sigma * sigma;
+      A = ((sigma - 1) * S.s + 1) / (sigma2);
+      B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+    } else {
+      const double theta2 = theta * theta;
+      const double a = S.s * sin(theta), b = S.s * cos(theta);
+      const double c = theta2 + sigma * sigma;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+    }
+  }
+  const double Om[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+  double W[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc += Om[i * 3 + k] * Om[k * 3 + j];
+      W[i * 3 + j] = A * Om[i * 3 + j] + B * acc + C * ((i == j) ? 1.0 : 0.0);
+    }
+  const double t[3] = {S.tx, S.ty, S.tz};
+  double ups[3];
+  sim3_lu3_solve(W, t, ups);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { res[i] = omega[i]; res[i + 3] = ups[i]; }
+  res[6] = sigma;
+}

@@ -159,3 +159,22 @@ def sim3_optimization(ctx: Context, sim3, P1c, P2c, obs1, obs2, info1, info2, K1
     check(lib().ccm_sim3_optimize(ctx.handle, v(s), n, v(P1c), v(P2c), v(obs1), v(obs2), v(info1), v(info2), v(K1), v(K2),
                                   C.c_double(th2), int(bool(fix_scale)), v(inl), C.byref(nin)), ctx.handle)
     return s, inl[:n], nin.value
+
+
+class PGStats(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("lm_trials", C.c_int32), ("pcg_iters", C.c_int32), ("reserved", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+def pose_graph_optimization(ctx: Context, pg: dict, max_iters: int = 20, lambda_init: float = 1e-16):
+    """OptimizeEssentialGraph{LoopClosure,MapFusion} numerics (Optimizer.cpp:1058-1566) through ccm_pose_graph_optimize.
+    pg: sim3[n,8], fixed[n], fix_scale, e_i, e_j, meas[m,8] (synth.make_pose_graph layout).  Returns (sim3, stats)."""
+    sim3 = np.ascontiguousarray(pg["sim3"], np.float64).copy()
+    fixed = np.ascontiguousarray(pg["fixed"], np.uint8)
+    e_i, e_j = np.ascontiguousarray(pg["e_i"], np.int32), np.ascontiguousarray(pg["e_j"], np.int32)
+    meas = np.ascontiguousarray(pg["meas"], np.float64)
+    st = PGStats()
+    v = lambda a: C.c_void_p(_vp(a))
+    check(lib().ccm_pose_graph_optimize(ctx.handle, int(sim3.shape[0]), v(sim3), v(fixed), int(bool(pg["fix_scale"])), int(e_i.size), v(e_i), v(e_j),
+                                        v(meas), int(max_iters), C.c_double(lambda_init), None, C.byref(st)), ctx.handle)
+    return sim3, st

@@ -421,6 +421,50 @@ def make_sim3_problem(n: int = 150, seed: int = 0, outlier_frac: float = 0.1, fi
                 fix_scale=bool(fix_scale), gt_sim3=gt, is_outlier=out)
 
 
+def make_pose_graph(n_kf: int = 120, seed: int = 0, fix_scale: bool = False, drift_t: float = 0.01, drift_r_deg: float = 0.15,
+                    drift_s: float = 0.002, n_loop: int = 3, covis: int = 4):
+    """Essential-graph problem for Optimizer::OptimizeEssentialGraph{LoopClosure,MapFusion} (Optimizer.cpp:1058-1566): one
+    agent drives a closed loop; the keyframe poses Siw drift (translation, rotation and, unless fix_scale, scale); spanning-
+    tree and covisibility edges carry the relative Sim3 of the DRIFTED trajectory (zero error at the start, :1166-1260), the
+    loop edges carry the true relative Sim3 between the ends of the loop (:1122-1160).  Vertex 0 (the loop keyframe) is
+    fixed.  Layout: sim3[n,8] = qx qy qz qw tx ty tz s (world -> camera), edges (i, j, Sji) with Sji = Sjw * Swi."""
+    rng = np.random.default_rng(seed)
+    R_true, t_true, _ = _agent_loop(n_kf, 0)
+
+    def mul(a, b):      # Sim3 product (R, t, s)
+        return a[0] @ b[0], a[2] * (a[0] @ b[1]) + a[1], a[2] * b[2]
+
+    def inv(a):
+        Rt = a[0].T
+        return Rt, Rt @ (-a[1] / a[2]), 1.0 / a[2]
+    truth = [(R_true[k], t_true[k], 1.0) for k in range(n_kf)]
+    est = [truth[0]]
+    for k in range(1, n_kf):
+        rel = mul(truth[k], inv(truth[k - 1]))                       # S_k,k-1
+        dR = rodrigues(rng.normal(size=(1, 3)) * np.deg2rad(drift_r_deg))[0]
+        ds = 1.0 if fix_scale else float(np.exp(rng.normal() * drift_s))
+        noisy = (dR @ rel[0], rel[1] + rng.normal(size=3) * drift_t, rel[2] * ds)
+        est.append(mul(noisy, est[k - 1]))
+    e_i, e_j, meas = [], [], []
+
+    def add(i, j, Sji):
+        e_i.append(i); e_j.append(j)
+        meas.append(np.concatenate([quat_from_R(Sji[0][None])[0], Sji[1], [Sji[2]]]))
+    for k in range(1, n_kf):                                          # spanning tree: child i = k, parent j = k-1
+        add(k, k - 1, mul(est[k - 1], inv(est[k])))
+        for d in range(2, covis + 1):                                 # covisibility edges to earlier keyframes
+            if k - d >= 0 and rng.random() < 0.8:
+                add(k, k - d, mul(est[k - d], inv(est[k])))
+    for q in range(n_loop):                                           # loop connections: last keyframes <-> first ones, true geometry
+        i, j = n_kf - 1 - q, q
+        add(i, j, mul(truth[j], inv(truth[i])))
+    sim3 = np.stack([np.concatenate([quat_from_R(e[0][None])[0], e[1], [e[2]]]) for e in est])
+    gt = np.stack([np.concatenate([quat_from_R(e[0][None])[0], e[1], [e[2]]]) for e in truth])
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return dict(sim3=sim3, fixed=fixed, fix_scale=bool(fix_scale), e_i=np.array(e_i, np.int32), e_j=np.array(e_j, np.int32),
+                meas=np.stack(meas), gt_sim3=gt, n_vert=n_kf, n_edge=len(e_i))
+
+
 def make_vocabulary(k: int = 10, L: int = 4, seed: int = 0, stop_frac: float = 0.02):
     """Synthetic DBoW2-style vocabulary tree (the real ORBvoc.txt is a missing blob): complete k-ary
     tree of depth L in breadth-first node order, node descriptors = parent's with ~12 % of the bits flipped, leaf words

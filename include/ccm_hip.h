@@ -294,6 +294,23 @@ int  ccm_sim3_optimize(ccm_ctx* ctx, double sim3[8], int n, const double* P1c, c
                        const double K1[4], const double K2[4], double th2, int fix_scale,
                        uint8_t* inlier, int* n_inlier);
 
+/* Pose-graph numerics of Optimizer::OptimizeEssentialGraphLoopClosure / MapFusion (Optimizer.cpp:1058-1331, 1333-1566):
+ * vertices = keyframes with estimate Siw as [qx qy qz qw tx ty tz s] (fixed[v] = the loop keyframe, fix_scale =
+ * bFixScale), edges = EdgeSim3 with vertex(0) = e_i, vertex(1) = e_j, measurement Sji (same 8-double layout) and
+ * information I7 (types_seven_dof_expmap.h:98-121); g2o's numeric Jacobians (base_binary_edge.hpp:129-196),
+ * BlockSolver_7_3 + Levenberg with setUserLambdaInit(lambda_init = 1e-16 in the reference; <= 0 selects g2o's
+ * tau * max-diagonal rule), optimize(max_iters = 20).  The caller keeps the graph walk that chooses the edges
+ * (spanning tree, loop edges, covisibility >= minFeat, :1122-1260) and the SE3 / map-point write-back (:1268-1330).
+ * The reduced solve is block-Jacobi PCG (relative tolerance 1e-10) instead of Eigen's sparse LDLT. */
+typedef struct {
+  int32_t iters_done, lm_trials, pcg_iters, reserved;
+  double chi2_initial, chi2_final, lambda_final;
+} ccm_pg_stats;
+int  ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3 /* n_vert x 8, in/out */, const uint8_t* fixed,
+                             int fix_scale, int n_edge, const int32_t* e_i, const int32_t* e_j,
+                             const double* meas /* n_edge x 8 */, int max_iters, double lambda_init,
+                             const volatile unsigned char* stop_flag /* nullable */, ccm_pg_stats* stats /* nullable */);
+
 #ifdef __cplusplus
 }
 #endif

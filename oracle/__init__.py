@@ -257,6 +257,26 @@ def sim3_optimize(sim3, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2=10.0, fi
     return s, inl[:n], int(nin)
 
 
+class PGStats(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("lm_trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
+def pose_graph_optimize(pg, max_iters=20, lambda_init=1e-16):
+    """OptimizeEssentialGraph* numerics restated (ora_pose_graph_optimize).  Returns (sim3[n,8], stats)."""
+    sim3 = np.ascontiguousarray(pg["sim3"], np.float64).copy()
+    fixed = np.ascontiguousarray(pg["fixed"], np.uint8)
+    e_i, e_j = np.ascontiguousarray(pg["e_i"], np.int32), np.ascontiguousarray(pg["e_j"], np.int32)
+    meas = np.ascontiguousarray(pg["meas"], np.float64)
+    st = PGStats()
+    fn = lib().ora_pose_graph_optimize
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    fn(sim3.shape[0], sim3.ctypes.data, fixed.ctypes.data, int(bool(pg["fix_scale"])), e_i.size, e_i.ctypes.data, e_j.ctypes.data,
+       meas.ctypes.data, int(max_iters), float(lambda_init), C.addressof(st))
+    return sim3, st
+
+
 # ---- ORB extractor ---------------------------------------------------------------------------------
 KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
                      ("response", np.float32), ("octave", np.int32)])

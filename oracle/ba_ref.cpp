@@ -204,11 +204,13 @@ bool dense_chol_solve(vector<double>& A, int n, const double* b, double* x) {
 }
 
 // ----- block sparse Cholesky with greedy minimum-degree ordering -------------------------------
-struct BlockChol {
+template <int BS>
+struct BlockCholT {
+  static constexpr int BB = BS * BS;
   int nb = 0;
   vector<int> perm, iperm;            // perm[k] = original block eliminated k-th
   vector<vector<int>> cstruct;        // per eliminated column k: sorted rows (positions > k)
-  vector<vector<double>> Lcol;        // per column: (1 + |cstruct|) blocks of 36 (diag first)
+  vector<vector<double>> Lcol;        // per column: (1 + |cstruct|) blocks of BB (diag first)
   bool analysed = false;
 
   void analyse(int n, const vector<std::pair<int, int>>& upper_blocks) {
@@ -239,24 +241,24 @@ struct BlockChol {
       std::sort(cstruct[k].begin(), cstruct[k].end());
     }
     Lcol.assign(n, {});
-    for (int k = 0; k < n; k++) Lcol[k].assign((cstruct[k].size() + 1) * 36, 0.0);
+    for (int k = 0; k < n; k++) Lcol[k].assign((cstruct[k].size() + 1) * BB, 0.0);
     analysed = true;
   }
 
-  static void chol6(double* A, bool& ok) {   // lower Cholesky in place (row-major), upper part ignored
-    for (int j = 0; j < 6; j++) {
-      double d = A[j * 6 + j];
-      for (int k = 0; k < j; k++) d -= A[j * 6 + k] * A[j * 6 + k];
+  static void cholB(double* A, bool& ok) {   // lower Cholesky in place (row-major), upper part ignored
+    for (int j = 0; j < BS; j++) {
+      double d = A[j * BS + j];
+      for (int k = 0; k < j; k++) d -= A[j * BS + k] * A[j * BS + k];
       if (!(d > 0.0) || !std::isfinite(d)) { ok = false; return; }
       d = std::sqrt(d);
-      A[j * 6 + j] = d;
-      for (int i = j + 1; i < 6; i++) {
-        double s = A[i * 6 + j];
-        for (int k = 0; k < j; k++) s -= A[i * 6 + k] * A[j * 6 + k];
-        A[i * 6 + j] = s / d;
+      A[j * BS + j] = d;
+      for (int i = j + 1; i < BS; i++) {
+        double s = A[i * BS + j];
+        for (int k = 0; k < j; k++) s -= A[i * BS + k] * A[j * BS + k];
+        A[i * BS + j] = s / d;
       }
     }
-    for (int i = 0; i < 6; i++) for (int j = i + 1; j < 6; j++) A[i * 6 + j] = 0.0;
+    for (int i = 0; i < BS; i++) for (int j = i + 1; j < BS; j++) A[i * BS + j] = 0.0;
   }
 
   // blocks: map (i<=j) -> 6x6 row-major (block (i,j) of the symmetric matrix, upper part)
@@ -267,88 +269,90 @@ struct BlockChol {
     for (size_t kb = 0; kb < keys.size(); kb++) {
       const int i = keys[kb].first, j = keys[kb].second;
       const int pi = iperm[i], pj = iperm[j];
-      const double* B = &vals[kb * 36];   // block (i,j)
-      if (pi == pj) { std::memcpy(&Lcol[pi][0], B, 36 * sizeof(double)); continue; }
+      const double* B = &vals[kb * BB];   // block (i,j)
+      if (pi == pj) { std::memcpy(&Lcol[pi][0], B, BB * sizeof(double)); continue; }
       const int col = std::min(pi, pj), row = std::max(pi, pj);
       const auto& cs = cstruct[col];
       const int pos = (int)(std::lower_bound(cs.begin(), cs.end(), row) - cs.begin());
-      double* dst = &Lcol[col][(size_t)(pos + 1) * 36];
+      double* dst = &Lcol[col][(size_t)(pos + 1) * BB];
       // need block (row_node, col_node) of A: if row corresponds to j (pj>pi) it is B^T, else B
-      if (pj > pi) { for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) dst[r * 6 + c] = B[c * 6 + r]; }
-      else std::memcpy(dst, B, 36 * sizeof(double));
+      if (pj > pi) { for (int r = 0; r < BS; r++) for (int c = 0; c < BS; c++) dst[r * BS + c] = B[c * BS + r]; }
+      else std::memcpy(dst, B, BB * sizeof(double));
     }
     bool ok = true;
     for (int k = 0; k < n && ok; k++) {
       double* D = &Lcol[k][0];
-      chol6(D, ok);
+      cholB(D, ok);
       if (!ok) break;
       const auto& cs = cstruct[k];
       const int m = (int)cs.size();
       // L_rk = A_rk * L_kk^{-T}
       for (int r = 0; r < m; r++) {
-        double* A = &Lcol[k][(size_t)(r + 1) * 36];
-        for (int row = 0; row < 6; row++)
-          for (int j = 0; j < 6; j++) {
-            double s = A[row * 6 + j];
-            for (int p = 0; p < j; p++) s -= A[row * 6 + p] * D[j * 6 + p];
-            A[row * 6 + j] = s / D[j * 6 + j];
+        double* A = &Lcol[k][(size_t)(r + 1) * BB];
+        for (int row = 0; row < BS; row++)
+          for (int j = 0; j < BS; j++) {
+            double s = A[row * BS + j];
+            for (int p = 0; p < j; p++) s -= A[row * BS + p] * D[j * BS + p];
+            A[row * BS + j] = s / D[j * BS + j];
           }
       }
       // trailing update
       for (int c = 0; c < m; c++) {
         const int colc = cs[c];
-        const double* Lc = &Lcol[k][(size_t)(c + 1) * 36];
+        const double* Lc = &Lcol[k][(size_t)(c + 1) * BB];
         const auto& cs2 = cstruct[colc];
         {  // diagonal block of column colc
           double* T = &Lcol[colc][0];
-          for (int i = 0; i < 6; i++) for (int j = 0; j <= i; j++) {
-            double s = 0; for (int p = 0; p < 6; p++) s += Lc[i * 6 + p] * Lc[j * 6 + p];
-            T[i * 6 + j] -= s;
+          for (int i = 0; i < BS; i++) for (int j = 0; j <= i; j++) {
+            double s = 0; for (int p = 0; p < BS; p++) s += Lc[i * BS + p] * Lc[j * BS + p];
+            T[i * BS + j] -= s;
           }
         }
         size_t pos = 0;
         for (int r = c + 1; r < m; r++) {
           const int rowr = cs[r];
           while (cs2[pos] < rowr) pos++;
-          double* T = &Lcol[colc][(pos + 1) * 36];
-          const double* Lr = &Lcol[k][(size_t)(r + 1) * 36];
-          for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
-            double s = 0; for (int p = 0; p < 6; p++) s += Lr[i * 6 + p] * Lc[j * 6 + p];
-            T[i * 6 + j] -= s;
+          double* T = &Lcol[colc][(pos + 1) * BB];
+          const double* Lr = &Lcol[k][(size_t)(r + 1) * BB];
+          for (int i = 0; i < BS; i++) for (int j = 0; j < BS; j++) {
+            double s = 0; for (int p = 0; p < BS; p++) s += Lr[i * BS + p] * Lc[j * BS + p];
+            T[i * BS + j] -= s;
           }
         }
       }
     }
     if (!ok) return false;
     // solve L y = Pb ; L^T z = y
-    vector<double> y((size_t)n * 6);
-    for (int k = 0; k < n; k++) for (int i = 0; i < 6; i++) y[(size_t)k * 6 + i] = b[(size_t)perm[k] * 6 + i];
+    vector<double> y((size_t)n * BS);
+    for (int k = 0; k < n; k++) for (int i = 0; i < BS; i++) y[(size_t)k * BS + i] = b[(size_t)perm[k] * BS + i];
     for (int k = 0; k < n; k++) {
       const double* D = &Lcol[k][0];
-      double* yk = &y[(size_t)k * 6];
-      for (int i = 0; i < 6; i++) { double s = yk[i]; for (int p = 0; p < i; p++) s -= D[i * 6 + p] * yk[p]; yk[i] = s / D[i * 6 + i]; }
+      double* yk = &y[(size_t)k * BS];
+      for (int i = 0; i < BS; i++) { double s = yk[i]; for (int p = 0; p < i; p++) s -= D[i * BS + p] * yk[p]; yk[i] = s / D[i * BS + i]; }
       const auto& cs = cstruct[k];
       for (size_t r = 0; r < cs.size(); r++) {
-        const double* L = &Lcol[k][(r + 1) * 36];
-        double* yr = &y[(size_t)cs[r] * 6];
-        for (int i = 0; i < 6; i++) { double s = 0; for (int p = 0; p < 6; p++) s += L[i * 6 + p] * yk[p]; yr[i] -= s; }
+        const double* L = &Lcol[k][(r + 1) * BB];
+        double* yr = &y[(size_t)cs[r] * BS];
+        for (int i = 0; i < BS; i++) { double s = 0; for (int p = 0; p < BS; p++) s += L[i * BS + p] * yk[p]; yr[i] -= s; }
       }
     }
     for (int k = n - 1; k >= 0; k--) {
       const double* D = &Lcol[k][0];
-      double* yk = &y[(size_t)k * 6];
+      double* yk = &y[(size_t)k * BS];
       const auto& cs = cstruct[k];
       for (size_t r = 0; r < cs.size(); r++) {
-        const double* L = &Lcol[k][(r + 1) * 36];
-        const double* yr = &y[(size_t)cs[r] * 6];
-        for (int p = 0; p < 6; p++) { double s = 0; for (int i = 0; i < 6; i++) s += L[i * 6 + p] * yr[i]; yk[p] -= s; }
+        const double* L = &Lcol[k][(r + 1) * BB];
+        const double* yr = &y[(size_t)cs[r] * BS];
+        for (int p = 0; p < BS; p++) { double s = 0; for (int i = 0; i < BS; i++) s += L[i * BS + p] * yr[i]; yk[p] -= s; }
       }
-      for (int i = 5; i >= 0; i--) { double s = yk[i]; for (int p = i + 1; p < 6; p++) s -= D[p * 6 + i] * yk[p]; yk[i] = s / D[i * 6 + i]; }
+      for (int i = (BS - 1); i >= 0; i--) { double s = yk[i]; for (int p = i + 1; p < BS; p++) s -= D[p * BS + i] * yk[p]; yk[i] = s / D[i * BS + i]; }
     }
-    for (int k = 0; k < n; k++) for (int i = 0; i < 6; i++) x[(size_t)perm[k] * 6 + i] = y[(size_t)k * 6 + i];
+    for (int k = 0; k < n; k++) for (int i = 0; i < BS; i++) x[(size_t)perm[k] * BS + i] = y[(size_t)k * BS + i];
     return true;
   }
 };
+
+typedef BlockCholT<6> BlockChol;
 
 // ------------------------------------------------------------------------------------------------
 struct Timers { double residuals = 0, quadratic = 0, schur = 0, linear = 0, update = 0, structure = 0; };
@@ -898,6 +902,76 @@ inline void sim3_map(const Sim3& S, const double X[3], double out[3]) {   // sim
   for (int i = 0; i < 3; i++) out[i] = S.s * r[i] + S.t[i];
 }
 
+// Eigen::PartialPivLU<Matrix3d>(W).solve(t) (Sim3::log uses W.lu().solve(t), sim3.h:216): unblocked partial-pivot LU,
+// row swap on the largest |entry| of the column, unit-lower forward and upper back substitution
+inline void lu3_solve(const M3 Win, const double t[3], double x[3]) {
+  double a[9]; for (int i = 0; i < 9; i++) a[i] = Win[i];
+  int piv[3] = {0, 1, 2};
+  for (int k = 0; k < 3; k++) {
+    int best = k; double bv = std::fabs(a[k * 3 + k]);
+    for (int r = k + 1; r < 3; r++) if (std::fabs(a[r * 3 + k]) > bv) { bv = std::fabs(a[r * 3 + k]); best = r; }
+    if (best != k) { for (int c = 0; c < 3; c++) std::swap(a[k * 3 + c], a[best * 3 + c]); std::swap(piv[k], piv[best]); }
+    for (int r = k + 1; r < 3; r++) a[r * 3 + k] /= a[k * 3 + k];
+    for (int r = k + 1; r < 3; r++) for (int c = k + 1; c < 3; c++) a[r * 3 + c] -= a[r * 3 + k] * a[k * 3 + c];
+  }
+  double y[3] = {t[piv[0]], t[piv[1]], t[piv[2]]};
+  y[1] -= a[3] * y[0];
+  y[2] -= a[6] * y[0]; y[2] -= a[7] * y[1];
+  x[2] = y[2] / a[8];
+  x[1] = (y[1] - a[5] * x[2]) / a[4];
+  x[0] = (y[0] - a[1] * x[1] - a[2] * x[2]) / a[0];
+}
+
+// Sim3::log (sim3.h:146-237) -> [omega(3), upsilon(3), sigma]
+inline void sim3_log(const Sim3& S, double res[7]) {
+  const double sigma = std::log(S.s);
+  M3 R; qtoR(S.r, R);
+  const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+  const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};   // deltaR (se3_ops.hpp:40-47)
+  double omega[3];
+  const double eps = 0.00001;
+  double A, B, C;
+  auto small_angle = [&]() { for (int i = 0; i < 3; i++) omega[i] = 0.5 * dR[i]; };
+  auto big_angle = [&](double theta) { const double k = theta / (2 * std::sqrt(1 - d * d)); for (int i = 0; i < 3; i++) omega[i] = k * dR[i]; };
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (d > 1 - eps) { small_angle(); A = 1. / 2.; B = 1. / 6.; }
+    else {
+      const double theta = std::acos(d), theta2 = theta * theta;
+      big_angle(theta);
+      A = (1 - std::cos(theta)) / (theta2);
+      B = (theta - std::sin(theta)) / (theta2 * theta);
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (d > 1 - eps) {
+      const double sigma2 = sigma * sigma;
+      small_angle();
+      A = ((sigma - 1) * S.s + 1) / (sigma2);
+      B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+    } else {
+      const double theta = std::acos(d);
+      big_angle(theta);
+      const double theta2 = theta * theta;
+      const double a = S.s * std::sin(theta), b = S.s * std::cos(theta);
+      const double c = theta2 + sigma * sigma;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+    }
+  }
+  const M3 Om = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+  M3 Om2, W;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double acc = 0; for (int k = 0; k < 3; k++) acc += Om[i * 3 + k] * Om[k * 3 + j];
+    Om2[i * 3 + j] = acc;
+  }
+  for (int i = 0; i < 9; i++) W[i] = A * Om[i] + B * Om2[i] + C * ((i % 4 == 0) ? 1.0 : 0.0);
+  double ups[3];
+  lu3_solve(W, S.t, ups);
+  for (int i = 0; i < 3; i++) { res[i] = omega[i]; res[i + 3] = ups[i]; }
+  res[6] = sigma;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Optimizer::PoseOptimizationClient — cslam/src/Optimizer.cpp:215-347, flat restatement.
 // One SE3 vertex, unary EdgeSE3ProjectXYZOnlyPose edges (types_six_dof_expmap.h:143-171,
@@ -1143,6 +1217,149 @@ int ora_sim3_optimize(double* sim3, int n, const double* P1c, const double* P2c,
   sim3[0] = S.r.x; sim3[1] = S.r.y; sim3[2] = S.r.z; sim3[3] = S.r.w;
   sim3[4] = S.t[0]; sim3[5] = S.t[1]; sim3[6] = S.t[2]; sim3[7] = S.s;
   return nIn;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer::OptimizeEssentialGraphLoopClosure / MapFusion numerics — cslam/src/Optimizer.cpp:1058-1331, 1333-1566.
+// Flat restatement of what both functions hand to g2o: VertexSim3Expmap per keyframe (estimate Siw, one vertex fixed,
+// _fix_scale), EdgeSim3 per spanning-tree / loop / covisibility link with vertex(0) = i, vertex(1) = j, measurement
+// Sji and information I7 (types_seven_dof_expmap.h:98-121: error = log(Sji * Siw * Sjw^-1)); BlockSolver_7_3 with
+// LinearSolverEigen, Levenberg with setUserLambdaInit(1e-16), optimize(20).  EdgeSim3 does not override
+// linearizeOplus, so both 7x7 Jacobians come from g2o's numeric differentiation (base_binary_edge.hpp:129-196).
+// The graph walking that chooses the edges and the SE3 / map-point write-back (:1268-1330) stay with the caller.
+struct ora_pg_stats { int32_t iters_done, lm_trials; double chi2_initial, chi2_final, lambda_final; };
+
+int ora_pose_graph_optimize(int n_vert, double* sim3, const uint8_t* fixed, int fix_scale, int n_edge, const int32_t* e_i, const int32_t* e_j,
+                            const double* meas, int max_iters, double lambda_init, ora_pg_stats* stats) {
+  vector<Sim3> S(n_vert), C(n_edge);
+  auto load = [](const double* p) { Sim3 x; x.r = {p[0], p[1], p[2], p[3]}; x.t[0] = p[4]; x.t[1] = p[5]; x.t[2] = p[6]; x.s = p[7]; return x; };
+  for (int v = 0; v < n_vert; v++) S[v] = load(sim3 + 8 * (size_t)v);
+  for (int e = 0; e < n_edge; e++) C[e] = load(meas + 8 * (size_t)e);
+  // index mapping: non-fixed vertices in id order (sparse_optimizer.cpp:166-190)
+  vector<int> slot(n_vert, -1); int nfree = 0;
+  for (int v = 0; v < n_vert; v++) if (!fixed[v]) slot[v] = nfree++;
+  // active edges: not both vertices fixed
+  vector<int> act;
+  for (int e = 0; e < n_edge; e++) if (!(fixed[e_i[e]] && fixed[e_j[e]])) act.push_back(e);
+  ora_pg_stats st{}; st.iters_done = 0; st.lm_trials = 0;
+  if (nfree == 0 || act.empty()) { if (stats) *stats = st; return 0; }
+  auto oplus = [&](const Sim3& X, const double* upd) {
+    double u[7]; for (int k = 0; k < 7; k++) u[k] = upd[k];
+    if (fix_scale) u[6] = 0;
+    return sim3_mul(sim3_exp(u), X);
+  };
+  auto edge_error = [&](int e, const Sim3& Si, const Sim3& Sj, double err[7]) {
+    const Sim3 E = sim3_mul(sim3_mul(C[e], Si), sim3_inv(Sj));
+    sim3_log(E, err);
+  };
+  vector<double> err(7 * (size_t)n_edge, 0.0);
+  auto chi2_active = [&]() {
+    double chi = 0;
+    for (int e : act) {
+      double* er = &err[7 * (size_t)e];
+      edge_error(e, S[e_i[e]], S[e_j[e]], er);
+      double c2 = 0; for (int k = 0; k < 7; k++) c2 += er[k] * er[k];
+      chi += c2;
+    }
+    return chi;
+  };
+  // block structure: diagonal + one upper block per connected pair of free vertices
+  std::map<std::pair<int, int>, int> blk;
+  vector<std::pair<int, int>> keys;
+  for (int v = 0; v < nfree; v++) { blk[{v, v}] = (int)keys.size(); keys.push_back({v, v}); }
+  for (int e : act) {
+    const int a = slot[e_i[e]], b = slot[e_j[e]];
+    if (a < 0 || b < 0 || a == b) continue;
+    const std::pair<int, int> k{std::min(a, b), std::max(a, b)};
+    if (!blk.count(k)) { blk[k] = (int)keys.size(); keys.push_back(k); }
+  }
+  BlockCholT<7> chol;
+  chol.analyse(nfree, keys);
+  vector<double> H(49 * keys.size()), bvec(7 * (size_t)nfree), x(7 * (size_t)nfree);
+  double lambda = lambda_init, ni = 2; int nBad = 0;
+  double currentChi = 0;
+  for (int iter = 0; iter < max_iters; iter++) {
+    currentChi = chi2_active();
+    if (iter == 0) st.chi2_initial = currentChi;
+    const double iniChi = currentChi;
+    std::fill(H.begin(), H.end(), 0.0); std::fill(bvec.begin(), bvec.end(), 0.0);
+    const double dlt = 1e-9, scalar = 1.0 / (2 * dlt);
+    for (int e : act) {
+      const int vi = e_i[e], vj = e_j[e];
+      const int a = slot[vi], b = slot[vj];
+      double Ji[49], Jj[49];   // [row k of the error][column d]
+      for (int side = 0; side < 2; side++) {
+        if ((side == 0 ? a : b) < 0) continue;
+        double* J = side == 0 ? Ji : Jj;
+        for (int d = 0; d < 7; d++) {
+          double add[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7], em[7];
+          add[d] = dlt;
+          if (side == 0) edge_error(e, oplus(S[vi], add), S[vj], ep); else edge_error(e, S[vi], oplus(S[vj], add), ep);
+          add[d] = -dlt;
+          if (side == 0) edge_error(e, oplus(S[vi], add), S[vj], em); else edge_error(e, S[vi], oplus(S[vj], add), em);
+          for (int k = 0; k < 7; k++) J[k * 7 + d] = scalar * (ep[k] - em[k]);
+        }
+      }
+      const double* er = &err[7 * (size_t)e];
+      auto addJtJ = [&](int r, int c, const double* A, const double* B, bool transpose_store) {
+        double* Hb = &H[49 * (size_t)blk[{std::min(r, c), std::max(r, c)}]];
+        for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) {
+          double acc = 0; for (int k = 0; k < 7; k++) acc += A[k * 7 + p] * B[k * 7 + q];
+          if (transpose_store) Hb[q * 7 + p] += acc; else Hb[p * 7 + q] += acc;
+        }
+      };
+      if (a >= 0) {
+        for (int p = 0; p < 7; p++) { double acc = 0; for (int k = 0; k < 7; k++) acc += Ji[k * 7 + p] * (-er[k]); bvec[7 * (size_t)a + p] += acc; }
+        addJtJ(a, a, Ji, Ji, false);
+        if (b >= 0 && a != b) addJtJ(a, b, Ji, Jj, a > b);   // block (a,b) = Ji^T Jj; stored in the upper block (min,max)
+      }
+      if (b >= 0) {
+        for (int p = 0; p < 7; p++) { double acc = 0; for (int k = 0; k < 7; k++) acc += Jj[k * 7 + p] * (-er[k]); bvec[7 * (size_t)b + p] += acc; }
+        addJtJ(b, b, Jj, Jj, false);
+      }
+    }
+    if (iter == 0 && !(lambda_init > 0)) {   // computeLambdaInit (levenberg.cpp:167-181) when no user value is set
+      double m = 0;
+      for (int v = 0; v < nfree; v++) for (int k = 0; k < 7; k++) m = std::max(m, std::fabs(H[49 * (size_t)v + k * 8]));
+      lambda = 1e-5 * m;
+    }
+    double rho = 0, tempChi; int qmax = 0;
+    do {
+      vector<Sim3> backup = S;
+      vector<double> Hd = H;
+      for (int v = 0; v < nfree; v++) for (int k = 0; k < 7; k++) Hd[49 * (size_t)v + k * 8] += lambda;
+      const bool ok2 = chol.factor_solve(keys, Hd, bvec.data(), x.data());
+      if (!ok2) std::fill(x.begin(), x.end(), 0.0);
+      for (int v = 0; v < n_vert; v++) if (slot[v] >= 0) S[v] = oplus(S[v], &x[7 * (size_t)slot[v]]);
+      tempChi = chi2_active();
+      st.lm_trials++;
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (size_t j = 0; j < x.size(); j++) scale += x[j] * (lambda * x[j] + bvec[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;
+      } else { lambda *= ni; ni *= 2; S = backup; }
+      qmax++;
+    } while (rho < 0 && qmax < 10);
+    st.iters_done++;
+    if (qmax == 10 || rho == 0) break;
+    if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+    if (nBad >= 3) break;
+  }
+  st.chi2_final = currentChi; st.lambda_final = lambda;
+  for (int v = 0; v < n_vert; v++) {
+    double* p = sim3 + 8 * (size_t)v;
+    p[0] = S[v].r.x; p[1] = S[v].r.y; p[2] = S[v].r.z; p[3] = S[v].r.w; p[4] = S[v].t[0]; p[5] = S[v].t[1]; p[6] = S[v].t[2]; p[7] = S[v].s;
+  }
+  if (stats) *stats = st;
+  return st.iters_done;
 }
 
 }  // extern "C"
