@@ -53,6 +53,8 @@ struct ccm_prof_scope {
 int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_io_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out);
+// dense_chol.hip: SPD solve on the device (N multiple of 64, padding = identity), see the definition for the contract
+int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 static inline int ccm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,206 @@
+// dense_chol.hip — dense f64 Cholesky solve on the device, used for the small SPD system of the pose-graph optimiser
+// (posegraph.hip: 7 x keyframes unknowns).  g2o factors that system with a sparse direct solver; reproducing its
+// Levenberg-Marquardt path needs the step exact, and the matrix is small enough (<= ~2 GB) to treat densely.
+//
+// Blocked right-looking factorisation with 64x64 tiles, row-major lower triangle in place:
+//   chol_diag   (1 workgroup)      L_jj = chol(A_jj) in LDS, Li_jj = L_jj^-1 kept for the panel and the solves
+//   chol_panel  (1 wg / tile row)  L_ij = A_ij Li_jj^T                     } one 64x64x64 product per workgroup on the
+//   chol_update (1 wg / tile pair) A_ik -= L_ij L_kj^T  (i >= k > j)       } f64 matrix cores (v_mfma_f64_16x16x4_f64)
+// then tile-wise forward / backward substitution.  MFMA operand layout (guide, "f64 MFMA does NOT use these maps"):
+// A: lane l holds A[l & 15][l >> 4], B: lane l holds B[l >> 4][l & 15], D: reg r of lane l is D[(l >> 4) + 4 r][l & 15].
+#include "common.h"
+#include <vector>
+
+namespace {
+
+constexpr int NB = 64;            // tile size
+constexpr int LD = NB + 1;        // padded LDS row stride (doubles): 16 lanes reading one column hit 16 different banks
+constexpr int kTPB = 256;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// D(64x64) = As(64x64) * Bs(64x64)^T, both in LDS with stride LD; wave w owns rows 16w..16w+15, acc[s] = 16x16 subtile s
+__device__ __forceinline__ void tile_abt(const double* As, const double* Bs, v4d acc[4], int wave, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+  for (int kk = 0; kk < NB / 4; kk++) {
+    const int k = 4 * kk + kq;
+    const double a = As[(16 * wave + i) * LD + k];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const double b = Bs[(16 * s + i) * LD + k];
+      acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_tile(double* dst, const double* src, int ld_src) {
+  for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[r * LD + c] = src[(size_t)r * ld_src + c]; }
+}
+
+// L_jj and its inverse.  info: first failing global column + 1, like LAPACK
+__global__ __launch_bounds__(kTPB) void chol_diag(double* A, int N, int j, double* Linv_all, int* info) {
+  __shared__ double L[NB * LD], Li[NB * LD];
+  const int t = threadIdx.x;
+  double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
+  load_tile(L, Ajj, N);
+  for (int e = t; e < NB * LD; e += kTPB) Li[e] = 0;
+  __syncthreads();
+  for (int c = 0; c < NB; c++) {
+    if (t == 0) {
+      const double d = L[c * LD + c];
+      if (!(d > 0.0)) { if (*info == 0) *info = j * NB + c + 1; L[c * LD + c] = 1.0; } else L[c * LD + c] = sqrt(d);
+    }
+    __syncthreads();
+    const double dinv = 1.0 / L[c * LD + c];
+    for (int r = c + 1 + t; r < NB; r += kTPB) L[r * LD + c] *= dinv;
+    __syncthreads();
+    const int nr = NB - c - 1;
+    for (int e = t; e < nr * nr; e += kTPB) {
+      const int r = c + 1 + e / nr, cc = c + 1 + e % nr;
+      if (cc <= r) L[r * LD + cc] -= L[r * LD + c] * L[cc * LD + c];
+    }
+    __syncthreads();
+  }
+  if (t < NB) {   // column t of L^-1 by forward substitution
+    for (int r = t; r < NB; r++) {
+      double s = (r == t) ? 1.0 : 0.0;
+      for (int k = t; k < r; k++) s -= L[r * LD + k] * Li[k * LD + t];
+      Li[r * LD + t] = s / L[r * LD + r];
+    }
+  }
+  __syncthreads();
+  double* Lg = Linv_all + (size_t)j * NB * NB;
+  for (int e = t; e < NB * NB; e += kTPB) {
+    const int r = e / NB, c = e % NB;
+    Ajj[(size_t)r * N + c] = (c <= r) ? L[r * LD + c] : 0.0;
+    Lg[e] = Li[r * LD + c];
+  }
+}
+
+// tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
+__global__ __launch_bounds__(kTPB) void chol_panel(double* A, int N, int j, const double* Linv_all) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int i = j + 1 + blockIdx.x;
+  double* Aij = A + ((size_t)i * NB) * N + (size_t)j * NB;
+  load_tile(As, Aij, N);
+  load_tile(Bs, Linv_all + (size_t)j * NB * NB, NB);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  tile_abt(As, Bs, acc, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Aij[(size_t)(16 * wave + (lane >> 4) + 4 * r) * N + 16 * s + (lane & 15)] = acc[s][r];
+}
+
+// trailing update: pair index p -> (i, k) with i >= k > j;  A_ik -= L_ij L_kj^T
+__global__ __launch_bounds__(kTPB) void chol_update(double* A, int N, int j) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int p = blockIdx.x;
+  int ii = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+  while (ii * (ii + 1) / 2 > p) ii--;
+  while ((ii + 1) * (ii + 2) / 2 <= p) ii++;
+  const int kk = p - ii * (ii + 1) / 2;
+  const int i = j + 1 + ii, k = j + 1 + kk;
+  load_tile(As, A + ((size_t)i * NB) * N + (size_t)j * NB, N);
+  load_tile(Bs, A + ((size_t)k * NB) * N + (size_t)j * NB, N);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  tile_abt(As, Bs, acc, wave, lane);
+  double* Aik = A + ((size_t)i * NB) * N + (size_t)k * NB;
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Aik[(size_t)(16 * wave + (lane >> 4) + 4 * r) * N + 16 * s + (lane & 15)] -= acc[s][r];
+}
+
+// forward: y_j = Li_jj b_j ; backward: x_j = Li_jj^T b_j  (one workgroup, 64 outputs)
+__global__ __launch_bounds__(NB) void chol_solve_diag(double* b, int j, const double* Linv_all, int transpose) {
+  __shared__ double v[NB];
+  const int t = threadIdx.x;
+  const double* Li = Linv_all + (size_t)j * NB * NB;
+  v[t] = b[(size_t)j * NB + t];
+  __syncthreads();
+  double s = 0;
+  if (!transpose) { for (int k = 0; k <= t; k++) s += Li[t * NB + k] * v[k]; }
+  else { for (int k = t; k < NB; k++) s += Li[k * NB + t] * v[k]; }
+  b[(size_t)j * NB + t] = s;
+}
+// forward: b_i -= L_ij y_j (i > j) ; backward: b_k -= L_jk^T x_j (k < j);  one workgroup per tile
+__global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, double* b, int j, int transpose) {
+  __shared__ double v[NB];
+  const int t = threadIdx.x;
+  v[t] = b[(size_t)j * NB + t];
+  __syncthreads();
+  double s = 0;
+  if (!transpose) {
+    const int i = j + 1 + blockIdx.x;
+    const double* Lij = A + ((size_t)i * NB + t) * N + (size_t)j * NB;
+    for (int k = 0; k < NB; k++) s += Lij[k] * v[k];
+    b[(size_t)i * NB + t] -= s;
+  } else {
+    const int k = blockIdx.x;
+    const double* Ljk = A + ((size_t)j * NB) * N + (size_t)k * NB + t;
+    for (int r = 0; r < NB; r++) s += Ljk[(size_t)r * N] * v[r];
+    b[(size_t)k * NB + t] -= s;
+  }
+}
+
+}  // namespace
+
+// Solves A x = b for a symmetric positive definite A.  d_A: N x N row-major with N = n rounded up to 64 (ccm_dense_padded)
+// and the padding rows / columns already set to the identity; only the lower triangle is read; destroyed.  d_b: [N], in: rhs,
+// out: x.  d_linv: scratch [N/64][64*64].  d_info: device int, set to (first non-positive pivot + 1) or left 0.
+int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info) {
+  if (N % NB) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: N must be a multiple of 64");
+  const int T = N / NB;
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
+  for (int j = 0; j < T; j++) {
+    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(kTPB), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    const int rem = T - j - 1;
+    if (rem > 0) {
+      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv);
+      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j);
+    }
+  }
+  for (int j = 0; j < T; j++) {
+    hipLaunchKernelGGL(chol_solve_diag, dim3(1), dim3(NB), 0, ctx->stream, d_b, j, (const double*)d_linv, 0);
+    if (T - j - 1 > 0) hipLaunchKernelGGL(chol_solve_update, dim3(T - j - 1), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 0);
+  }
+  for (int j = T - 1; j >= 0; j--) {
+    hipLaunchKernelGGL(chol_solve_diag, dim3(1), dim3(NB), 0, ctx->stream, d_b, j, (const double*)d_linv, 1);
+    if (j > 0) hipLaunchKernelGGL(chol_solve_update, dim3(j), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 1);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+// Test hook: host matrix (n x n row-major, symmetric positive definite) and rhs in, solution out.
+extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info) {
+  if (!ctx || !A || !b || !x || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_dense_solve: bad args");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int N = ((n + NB - 1) / NB) * NB;
+  std::vector<double> Ap((size_t)N * N, 0.0), bp(N, 0.0);
+  for (int i = 0; i < N; i++) {
+    if (i < n) { for (int c = 0; c < n; c++) Ap[(size_t)i * N + c] = A[(size_t)i * n + c]; bp[i] = b[i]; }
+    else Ap[(size_t)i * N + i] = 1.0;
+  }
+  double *dA = nullptr, *db = nullptr, *dl = nullptr; int* di = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&dA, Ap.size() * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&db, N * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&dl, (size_t)N * NB * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&di, sizeof(int)));
+  hipMemcpyAsync(dA, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(db, bp.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  int rc = ccm_dense_chol_solve_dev(ctx, dA, N, db, dl, di);
+  if (rc == CCM_OK) {
+    hipMemcpyAsync(bp.data(), db, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(info, di, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_debug_dense_solve: sync");
+    for (int i = 0; i < n; i++) x[i] = bp[i];
+  }
+  hipFree(dA); hipFree(db); hipFree(dl); hipFree(di);
+  return rc;
+}

@@ -7,11 +7,12 @@
 // which is where g2o spends its time on this problem (28 exp/log evaluations per edge per iteration).
 //
 // Device design: the numeric differentiation is embarrassingly parallel — one lane per (edge, vertex side, dimension,
-// sign) — so `pg_linearize` runs 29 lanes per edge (28 perturbed errors + the base error).  H is assembled by gather
-// (one wave per 7x7 block walks the edges that contribute to it: no atomics, fixed order), the damped system is solved
-// with block-Jacobi PCG on the block-CSR matrix (two launches per iteration, device-resident scalars, the same scheme
-// as ba.hip's multi-kernel path with 7x7 blocks) and the LM control loop stays on the host like
-// optimization_algorithm_levenberg.cpp:61-164.  The graph walk that picks the edges and the SE3 / map-point write-back
+// sign) — so `pg_linearize` runs 28 lanes per edge.  H is assembled by gather (one wave per 7x7 block walks the edges that
+// contribute to it: no atomics, fixed order).  The damped system is solved EXACTLY by default (dense MFMA-f64 Cholesky,
+// dense_chol.hip): only an exact step reproduces which LM trials g2o accepts.  CCM_PG_SOLVER=pcg (and graphs above 24 000
+// unknowns) use PCG with a spanning-forest preconditioner instead — ~110 iterations whatever the chain length, several times
+// faster on large graphs, but an inexact-Newton path that ends in a different (equally converged) point.  The LM control
+// loop stays on the host like optimization_algorithm_levenberg.cpp:61-164.  The graph walk that picks the edges and the SE3 / map-point write-back
 // (Optimizer.cpp:1268-1330) stay with the caller.
 #include "common.h"
 #include "sim3_math.h"
@@ -50,6 +51,11 @@ struct PgDev {
   double* scal;               // [0]=rz0 [1]=thresh^2 [2]=lambda ; [4]=chi2 [5]=scale
   int* flag;                  // [0]=done [1]=iters [2]=fail
   double* part;               // partial sums of chi2 / scale
+  // spanning-forest preconditioner (see pg_tree_setup); use_tree = 0 -> block-Jacobi
+  int use_tree;
+  const int* t_parent; const int* t_code; const int* t_order; const int* t_pos; const int* t_out;
+  const int* ends_off; const int* ends_idx;
+  double* Binv; double* Dinv;  // [F*49] each
   int n_wg_row, n_wg_upd, n_wg_edge;
 };
 
@@ -356,6 +362,267 @@ __global__ __launch_bounds__(kTPB) void pg_apply(PgDev d, int cur, double lambda
   if (threadIdx.x == 0) d.part[blockIdx.x] = s;
 }
 
+
+// ---- spanning-forest preconditioner ------------------------------------------------------------------------------
+// Block-Jacobi PCG needs O(chain length) iterations on a pose graph (measured 923 per solve at 400 keyframes, ~4000 at
+// 2000) because the low-frequency modes of the keyframe chain are invisible to a local preconditioner.  The tree part of
+// H, T = sum over the edges of a spanning forest of [Jk Jp]^T [Jk Jp], can be inverted exactly and in parallel:
+// with B_root = I and, down the tree, W_k = -Jp B_p^-1, B_k = W_k^-1 Jk, every tree residual reads
+// Jk dk + Jp dp = W_k (B_k dk - B_p dp), i.e. in the transported variables y = B d the tree is a plain difference operator
+// G and T = B^T G^T D G B with D_k = W_k^T W_k.  Hence T^-1 = B^-1 P D^-1 P^T B^-T where P sums along root paths (P^T sums
+// over subtrees): two prefix scans in DFS order and three small mat-vecs per node.  The off-tree (covisibility) edges have
+// bounded stretch, so the preconditioned system needs ~110 iterations whatever the number of keyframes (measured 105 /
+// 117 at 120 / 400 keyframes in an offline study of the same matrices).  The forest is chosen on the host (Kruskal by
+// |i - j|, rooted at the fixed vertices), the recursion runs on the device once per LM iteration (J changes, lambda does
+// not enter: it is 1e-16 in the reference).
+constexpr int kPgTreeMaxF = 2600;   // DFS-ordered 7-vectors of all nodes must fit the LDS of the single apply workgroup
+
+// 7x7 inverse by Gauss-Jordan with partial pivoting, one wave, matrices in LDS ([49] row-major); A is destroyed
+__device__ __forceinline__ void inv7_wave(double* A, double* Ainv, int lane) {
+  const int r = lane / 7, c = lane % 7;
+  if (lane < 49) Ainv[lane] = (r == c) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int col = 0; col < 7; col++) {
+    int piv = col;
+    double bv = fabs(A[col * 7 + col]);
+    for (int rr = col + 1; rr < 7; rr++) { const double v = fabs(A[rr * 7 + col]); if (v > bv) { bv = v; piv = rr; } }   // uniform: every lane computes it
+    __syncthreads();
+    if (piv != col && lane < 7) {
+      const double a0 = A[col * 7 + lane], a1 = A[piv * 7 + lane]; A[col * 7 + lane] = a1; A[piv * 7 + lane] = a0;
+      const double b0 = Ainv[col * 7 + lane], b1 = Ainv[piv * 7 + lane]; Ainv[col * 7 + lane] = b1; Ainv[piv * 7 + lane] = b0;
+    }
+    __syncthreads();
+    const double pinv = 1.0 / A[col * 7 + col];
+    __syncthreads();
+    if (lane < 7) { A[col * 7 + lane] *= pinv; Ainv[col * 7 + lane] *= pinv; }
+    __syncthreads();
+    double fa = 0, fi = 0, f = 0;
+    if (lane < 49 && r != col) { f = A[r * 7 + col]; fa = A[col * 7 + c]; fi = Ainv[col * 7 + c]; }
+    __syncthreads();
+    if (lane < 49 && r != col) { A[r * 7 + c] -= f * fa; Ainv[r * 7 + c] -= f * fi; }
+    __syncthreads();
+  }
+}
+
+// one wave walks the forest in DFS preorder (parents first): Binv_k = Jk^-1 W_k, Dinv_k = W_k^-1 W_k^-T
+__global__ __launch_bounds__(kWave) void pg_tree_setup(PgDev d, double lambda) {
+  __shared__ double Jk[49], Jp[49], W[49], Wi[49], Ji[49], tmp[49];
+  const int lane = threadIdx.x;
+  const int r = lane / 7, c = lane % 7;
+  for (int pos = 0; pos < d.F; pos++) {
+    const int a = d.t_order[pos];
+    const int code = d.t_code[a], par = d.t_parent[a];
+    if (code < 0) {
+      // root of a component without a fixed vertex: no tree edge, D = its own damped diagonal block, B = I
+      if (lane < 49) { W[lane] = d.H[49 * (size_t)a + lane] + ((r == c) ? lambda + 1e-12 : 0.0); }
+      __syncthreads();
+      inv7_wave(W, Wi, lane);
+      if (lane < 49) { d.Dinv[49 * (size_t)a + lane] = Wi[lane]; d.Binv[49 * (size_t)a + lane] = (r == c) ? 1.0 : 0.0; }
+      __syncthreads();
+      continue;
+    }
+    const int e = code >> 1, side = code & 1;
+    if (lane < 49) {
+      double jk = d.J[98 * (size_t)e + 49 * side + lane], jp = d.J[98 * (size_t)e + 49 * (side ^ 1) + lane];
+      if (d.fix_scale) {   // the scale row / column of a fixed-scale graph is identically zero: decouple it with a unit entry
+        if (r == 6 || c == 6) { jk = (r == 6 && c == 6) ? 1.0 : 0.0; jp = (r == 6 && c == 6) ? -1.0 : 0.0; }
+      }
+      Jk[lane] = jk; Jp[lane] = jp;
+    }
+    __syncthreads();
+    if (lane < 49) {
+      if (par < 0) W[lane] = Jk[lane];       // parent is a fixed vertex: residual = Jk dk, B = I
+      else {
+        double acc = 0;
+        const double* Bp = d.Binv + 49 * (size_t)par;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += Jp[r * 7 + k] * Bp[k * 7 + c];
+        W[lane] = -acc;
+      }
+      tmp[lane] = (par < 0) ? Jk[lane] : W[lane];
+    }
+    __syncthreads();
+    if (lane < 49) W[lane] = tmp[lane];
+    __syncthreads();
+    if (lane < 49) tmp[lane] = W[lane];       // keep W: inv7 destroys its input
+    __syncthreads();
+    inv7_wave(tmp, Wi, lane);                 // Wi = W^-1
+    if (lane < 49) {
+      double acc = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) acc += Wi[r * 7 + k] * Wi[c * 7 + k];   // W^-1 W^-T
+      d.Dinv[49 * (size_t)a + lane] = acc;
+    }
+    if (par < 0) {
+      if (lane < 49) d.Binv[49 * (size_t)a + lane] = (r == c) ? 1.0 : 0.0;
+    } else {
+      if (lane < 49) tmp[lane] = Jk[lane];
+      __syncthreads();
+      inv7_wave(tmp, Ji, lane);               // Ji = Jk^-1
+      if (lane < 49) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += Ji[r * 7 + k] * W[k * 7 + c];   // B^-1 = Jk^-1 W
+        d.Binv[49 * (size_t)a + lane] = acc;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+// inclusive scan over positions of the F x 7 array in LDS (component-wise), 1024 threads
+__device__ __forceinline__ void pg_scan7(double* buf, int F, double* tot /* [128*8] */) {
+  const int t = threadIdx.x;
+  const int c = t & 7, chunk = t >> 3;            // 128 chunks x 8 lanes (7 components)
+  const int per = (F + 127) / 128;
+  const int p0 = chunk * per, p1 = min(F, p0 + per);
+  double s = 0;
+  if (c < 7) for (int p = p0; p < p1; p++) { s += buf[p * 7 + c]; buf[p * 7 + c] = s; }
+  tot[chunk * 8 + c] = s;
+  __syncthreads();
+  if (t < 7) { double run = 0; for (int k = 0; k < 128; k++) { const double v = tot[k * 8 + t]; tot[k * 8 + t] = run; run += v; } }   // exclusive chunk offsets
+  __syncthreads();
+  if (c < 7) { const double o = tot[chunk * 8 + c]; for (int p = p0; p < p1; p++) buf[p * 7 + c] += o; }
+  __syncthreads();
+}
+
+// z = B^-1 P D^-1 P^T B^-T r and r.z, one 1024-thread workgroup; slot = which prz buffer receives r.z
+__global__ __launch_bounds__(1024) void pg_precond(PgDev d, int slot_out, int k_next) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* buf = sm;                         // [F*7]
+  double* tot = sm + 7 * (size_t)d.F;       // [128*8]
+  double* red = tot + 1024;                 // [16]
+  if (d.flag[0]) return;
+  const int t = threadIdx.x;
+  const int F = d.F;
+  // a. t = B^-T r, stored at the node's DFS position
+  for (int i = t; i < 8 * F; i += 1024) {
+    const int a = i >> 3, c = i & 7;
+    if (c < 7) {
+      const double* Bi = d.Binv + 49 * (size_t)a;
+      double acc = 0;
+#pragma unroll
+      for (int q = 0; q < 7; q++) acc += Bi[q * 7 + c] * d.r[7 * (size_t)a + q];
+      buf[d.t_pos[a] * 7 + c] = acc;
+    }
+  }
+  __syncthreads();
+  pg_scan7(buf, F, tot);
+  // b. u = subtree sums, w = D^-1 u  (u through global scratch q, w through global scratch p-unused slot? -> x is live, use q and z)
+  for (int i = t; i < 8 * F; i += 1024) {
+    const int a = i >> 3, c = i & 7;
+    if (c < 7) {
+      const int p0 = d.t_pos[a], p1 = d.t_out[a];
+      d.q[7 * (size_t)a + c] = buf[(p1 - 1) * 7 + c] - (p0 > 0 ? buf[(p0 - 1) * 7 + c] : 0.0);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = t; i < 8 * F; i += 1024) {
+    const int a = i >> 3, c = i & 7;
+    if (c < 7) {
+      const double* Di = d.Dinv + 49 * (size_t)a + 7 * c;
+      double acc = 0;
+#pragma unroll
+      for (int q = 0; q < 7; q++) acc += Di[q] * d.q[7 * (size_t)a + q];
+      d.z[7 * (size_t)a + c] = acc;            // w, parked in z
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // c. ancestor sums: difference array over DFS positions, then a prefix scan
+  for (int i = t; i < 8 * F; i += 1024) {
+    const int pos = i >> 3, c = i & 7;
+    if (c < 7) {
+      double v = d.z[7 * (size_t)d.t_order[pos] + c];
+      for (int s = d.ends_off[pos]; s < d.ends_off[pos + 1]; s++) v -= d.z[7 * (size_t)d.ends_idx[s] + c];
+      buf[pos * 7 + c] = v;
+    }
+  }
+  __syncthreads();
+  pg_scan7(buf, F, tot);
+  // d. z = B^-1 y ; r.z
+  double rz = 0;
+  for (int i = t; i < 8 * F; i += 1024) {
+    const int a = i >> 3, c = i & 7;
+    if (c < 7) {
+      const double* Bi = d.Binv + 49 * (size_t)a + 7 * c;
+      const double* y = buf + d.t_pos[a] * 7;
+      double acc = 0;
+#pragma unroll
+      for (int q = 0; q < 7; q++) acc += Bi[q] * y[q];
+      d.q[7 * (size_t)a + c] = acc;            // final z, staged in q (z still holds w for other threads)
+      rz += d.r[7 * (size_t)a + c] * acc;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = t; i < 7 * F; i += 1024) d.z[i] = d.q[i];
+  rz = wave_sum(rz);
+  if ((t & (kWave - 1)) == 0) red[t / kWave] = rz;
+  __syncthreads();
+  if (t == 0) {
+    double s = 0;
+    for (int w = 0; w < 16; w++) s += red[w];
+    d.prz[slot_out][0] = s;
+    // The tree inverse amplifies the rounding noise of r in the low-frequency directions, so on a right-hand side that is
+    // itself noise (LM trials at convergence) r.z can stall above rel_tol^2 * r0.z0 although the iterate has reached the
+    // accuracy f64 allows.  Stop when r.z has not improved by 10 % for 40 iterations.
+    if (k_next == 0) { d.scal[6] = s; d.scal[7] = 0; }
+    else if (s < 0.9 * d.scal[6]) { d.scal[6] = s; d.scal[7] = (double)k_next; }
+    else if ((double)k_next - d.scal[7] > 40.0) { d.flag[0] = 1; d.flag[1] = k_next; d.flag[3] = 1; }
+  }
+}
+
+// tree-preconditioned variant of the PCG update: alpha, x, r only (z and r.z come from pg_precond)
+__global__ __launch_bounds__(kTPB) void pg_pcg_update_xr(PgDev d, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int done = d.flag[0];
+  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  const double pq = sum_partials(d.ppq, d.n_wg_row);
+  if (done) return;
+  if (!(pq > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.flag[0] = 1; d.flag[1] = k; d.flag[2] = 1; }
+    return;
+  }
+  const double alpha = rz_k / pq;
+  if (i < 7 * d.F) {
+    const double* p = d.p[(k + 1) & 1];
+    d.x[i] += alpha * p[i];
+    d.r[i] -= alpha * d.q[i];
+  }
+  if (i == 0) d.flag[1] = k + 1;
+}
+
+// tree variant of the start: x = 0, r = b, p_{-1} = 0 (z and r.z come from pg_precond)
+__global__ __launch_bounds__(kTPB) void pg_pcg_start(PgDev d, double lambda, double rel_tol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 7 * d.F) { d.x[i] = 0; d.r[i] = d.b[i]; d.p[0][i] = 0; }
+  if (i == 0) { d.scal[1] = rel_tol * rel_tol; d.scal[2] = lambda; }
+}
+
+
+// ---- exact dense solve (default) -----------------------------------------------------------------------------------
+// g2o solves the pose graph with a sparse direct factorisation; reproducing its LM path (which steps are accepted)
+// needs the weakly constrained chain modes of the step resolved exactly, which is precisely what an iterative solver
+// finds last.  The system is small (7 x keyframes <= ~14 000 unknowns), so the default scatters the block matrix into a
+// dense array and factors it with the blocked MFMA-f64 Cholesky of dense_chol.hip.
+// dense A (row-major N x N, N = 7F rounded up to 64, full symmetric, identity on the padding) = H + lambda I; rhs = b
+__global__ __launch_bounds__(kTPB) void pg_dense_fill(PgDev d, const int* blk_a, const int* blk_b, double* A, double* rhs, double lambda, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = 7 * d.F;
+  if (i < d.nBlk * 49) {
+    const int k = i / 49, el = i % 49, p = el / 7, q = el % 7;
+    const int a = blk_a[k], b = blk_b[k];
+    double v = d.H[i];
+    if (a == b && p == q) v += lambda;
+    A[(7 * (size_t)a + p) * N + (7 * (size_t)b + q)] = v;
+    if (a != b) A[(7 * (size_t)b + q) * N + (7 * (size_t)a + p)] = v;
+  }
+  if (i < N) { rhs[i] = (i < n) ? d.b[i] : 0.0; if (i >= n) A[(size_t)i * N + i] = 1.0; }
+}
+
 template <typename T>
 int up(ccm_ctx* ctx, std::vector<void*>& allocs, const std::vector<T>& v, T** out) {
   void* p = nullptr;
@@ -434,6 +701,53 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     for (auto& pr : rows[a]) { row_col.push_back(pr.first); row_blk.push_back(pr.second); }
     row_off[a + 1] = (int)row_col.size();
   }
+  // ---- spanning forest for the preconditioner: Kruskal by |i - j| (local edges first), all fixed vertices = one root ----
+  const bool use_tree = F <= kPgTreeMaxF && !getenv("CCM_PG_NO_TREE");
+  std::vector<int> t_parent(F, -1), t_code(F, -1), t_order, t_pos(F, 0), t_out(F, 0), ends_off(F + 2, 0), ends_idx;
+  if (use_tree) {
+    std::vector<int> eo(E);
+    for (int e = 0; e < E; e++) eo[e] = e;
+    std::stable_sort(eo.begin(), eo.end(), [&](int x, int y) { return std::abs(ei[x] - ej[x]) < std::abs(ei[y] - ej[y]); });
+    std::vector<int> uf(F + 1);                       // node F = the fixed super-node
+    for (int i = 0; i <= F; i++) uf[i] = i;
+    auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+    std::vector<std::vector<std::pair<int, int>>> adj(F + 1);   // (neighbour, edge)
+    for (int e : eo) {
+      const int a = slot[ei[e]] < 0 ? F : slot[ei[e]], b = slot[ej[e]] < 0 ? F : slot[ej[e]];
+      const int ra = find(a), rb = find(b);
+      if (ra == rb) continue;
+      uf[ra] = rb;
+      adj[a].push_back({b, e}); adj[b].push_back({a, e});
+    }
+    // DFS preorder from the fixed super-node, then from every still unvisited node (components without a fixed vertex)
+    std::vector<char> seen(F + 1, 0);
+    std::vector<std::pair<int, int>> stack;          // (node, next child index)
+    auto dfs = [&](int root) {
+      stack.clear(); stack.push_back({root, 0}); seen[root] = 1;
+      if (root < F) { t_pos[root] = (int)t_order.size(); t_order.push_back(root); }
+      while (!stack.empty()) {
+        auto& top = stack.back();
+        const int u = top.first;
+        if (top.second < (int)adj[u].size()) {
+          const auto [v, e] = adj[u][top.second++];
+          if (seen[v]) continue;
+          seen[v] = 1;
+          t_parent[v] = (u == F) ? -1 : u;
+          t_code[v] = e * 2 + (slot[ei[e]] == v ? 0 : 1);
+          t_pos[v] = (int)t_order.size(); t_order.push_back(v);
+          stack.push_back({v, 0});
+        } else {
+          if (u < F) t_out[u] = (int)t_order.size();
+          stack.pop_back();
+        }
+      }
+    };
+    dfs(F);
+    for (int a = 0; a < F; a++) if (!seen[a]) dfs(a);
+    std::vector<std::vector<int>> ends(F + 1);
+    for (int a = 0; a < F; a++) ends[t_out[a]].push_back(a);
+    for (int pos = 0; pos <= F; pos++) { ends_idx.insert(ends_idx.end(), ends[pos].begin(), ends[pos].end()); ends_off[pos + 1] = (int)ends_idx.size(); }
+  }
   // ---- device state ----
   std::vector<void*> allocs;
   PgDev d{};
@@ -453,7 +767,32 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   PG_RC(up(ctx, allocs, row_off, &p_i)); d.row_off = p_i;
   PG_RC(up(ctx, allocs, row_col, &p_i)); d.row_col = p_i;
   PG_RC(up(ctx, allocs, row_blk, &p_u)); d.row_blk = p_u;
-  d.n_wg_row = ccm_div_up(F, kTPB / kWave); d.n_wg_upd = ccm_div_up(F, kTPB / 8); d.n_wg_edge = ccm_div_up(E, kTPB);
+  // solver: exact dense Cholesky (default, reproduces the reference's LM path) or tree-preconditioned PCG (CCM_PG_SOLVER=pcg, or
+  // graphs whose dense matrix would not fit the budget below: faster, but an inexact-Newton path)
+  const char* solver_env = getenv("CCM_PG_SOLVER");
+  const size_t n_dense = 7 * (size_t)F;
+  const int N_dense = (int)((n_dense + 63) / 64) * 64;
+  const bool use_dense = !(solver_env && !strcmp(solver_env, "pcg")) && n_dense <= 24000;
+  double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
+  if (use_dense) {
+    std::vector<int> ka(nBlk), kb(nBlk);
+    for (int k = 0; k < nBlk; k++) { ka[k] = keys[k].first; kb[k] = keys[k].second; }
+    PG_RC(up(ctx, allocs, ka, &d_blk_a)); PG_RC(up(ctx, allocs, kb, &d_blk_b));
+    PG_RC(al(ctx, allocs, (size_t)N_dense * N_dense, &d_A)); PG_RC(al(ctx, allocs, (size_t)N_dense, &d_rhs)); PG_RC(al(ctx, allocs, 4, &d_info));
+    PG_RC(al(ctx, allocs, (size_t)N_dense * 64, &d_linv));
+  }
+  d.use_tree = use_tree ? 1 : 0;
+  if (use_tree) {
+    PG_RC(up(ctx, allocs, t_parent, &p_i)); d.t_parent = p_i;
+    PG_RC(up(ctx, allocs, t_code, &p_i)); d.t_code = p_i;
+    PG_RC(up(ctx, allocs, t_order, &p_i)); d.t_order = p_i;
+    PG_RC(up(ctx, allocs, t_pos, &p_i)); d.t_pos = p_i;
+    PG_RC(up(ctx, allocs, t_out, &p_i)); d.t_out = p_i;
+    PG_RC(up(ctx, allocs, ends_off, &p_i)); d.ends_off = p_i;
+    PG_RC(up(ctx, allocs, ends_idx, &p_i)); d.ends_idx = p_i;
+    PG_RC(al(ctx, allocs, 49 * (size_t)F, &d.Binv)); PG_RC(al(ctx, allocs, 49 * (size_t)F, &d.Dinv));
+  }
+  d.n_wg_row = ccm_div_up(F, kTPB / kWave); d.n_wg_upd = use_tree ? 1 : ccm_div_up(F, kTPB / 8); d.n_wg_edge = ccm_div_up(E, kTPB);
   const int n_wg_init = ccm_div_up(F, kTPB), n_wg_v = ccm_div_up(n_vert, kTPB);
   PG_RC(al(ctx, allocs, 7 * (size_t)E, &d.err)); PG_RC(al(ctx, allocs, 98 * (size_t)E, &d.J));
   PG_RC(al(ctx, allocs, 49 * (size_t)nBlk, &d.H)); PG_RC(al(ctx, allocs, 7 * (size_t)F, &d.b));
@@ -488,6 +827,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     const double iniChi = currentChi;
     hipLaunchKernelGGL(pg_linearize, dim3(ccm_div_up((int64_t)E * 32, kTPB)), dim3(kTPB), 0, ctx->stream, d, cur);
     hipLaunchKernelGGL(pg_assemble, dim3(ccm_div_up(nBlk + F, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+    if (use_tree && !use_dense) hipLaunchKernelGGL(pg_tree_setup, dim3(1), dim3(kWave), 0, ctx->stream, d, lambda);
     if (iter == 0 && !(lambda_init > 0)) {   // computeLambdaInit without a user value: tau * max diagonal
       std::vector<double> Hd(49 * (size_t)F);
       if (hipMemcpyAsync(Hd.data(), d.H, Hd.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: H readback"); break; }
@@ -502,7 +842,49 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
       hipMemsetAsync(d.flag, 0, 4 * sizeof(int), ctx->stream);
       hipMemsetAsync(d.prz[0], 0, sizeof(double) * (size_t)std::max(d.n_wg_upd, n_wg_init), ctx->stream);   // stale partials of the previous solve
       hipMemsetAsync(d.prz[1], 0, sizeof(double) * (size_t)std::max(d.n_wg_upd, n_wg_init), ctx->stream);
-      hipLaunchKernelGGL(pg_pcg_init, dim3(n_wg_init), dim3(kTPB), 0, ctx->stream, d, lambda, 1e-10);
+      const size_t lds_pc = (7 * (size_t)F + 1024 + 16) * sizeof(double);
+      if (use_dense) {
+        int info = 0;
+        hipMemsetAsync(d_A, 0, (size_t)N_dense * N_dense * sizeof(double), ctx->stream);
+        hipLaunchKernelGGL(pg_dense_fill, dim3(ccm_div_up(std::max(nBlk * 49, N_dense), kTPB)), dim3(kTPB), 0, ctx->stream, d, d_blk_a, d_blk_b, d_A, d_rhs,
+                           lambda, N_dense);
+        if ((rc = ccm_dense_chol_solve_dev(ctx, d_A, N_dense, d_rhs, d_linv, d_info))) break;
+        if (hipMemcpyAsync(d.x, d_rhs, n_dense * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+          rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: dense solve readback"); break;
+        }
+        const bool ok_d = info == 0;     // > 0: leading minor not positive definite -> solver failure, LM rejects the step
+        if (!ok_d) hipMemsetAsync(d.x, 0, 7 * (size_t)F * sizeof(double), ctx->stream);
+        hipLaunchKernelGGL(pg_apply, dim3(n_wg_v), dim3(kTPB), 0, ctx->stream, d, cur, lambda);
+        hipLaunchKernelGGL(pg_reduce, dim3(1), dim3(kTPB), 0, ctx->stream, d, n_wg_v, 5);
+        double tempChi = 0, scale = 0;
+        if ((rc = chi2_of(cur ^ 1, &tempChi))) break;
+        if ((rc = read_scal(5, &scale))) break;
+        st.lm_trials++;
+        if (!ok_d) tempChi = DBL_MAX;
+        scale += 1e-3;
+        rho = (currentChi - tempChi) / scale;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = std::min(alpha, 2. / 3.);
+          lambda *= std::max(1. / 3., alpha);
+          ni = 2;
+          currentChi = tempChi;
+          cur ^= 1;
+        } else {
+          lambda *= ni; ni *= 2;
+        }
+        qmax++;
+        continue;
+      }
+      if (use_tree) {
+        static bool attr_set = false;
+        if (!attr_set) { if (hipFuncSetAttribute((const void*)pg_precond, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: LDS attribute"); break; } attr_set = true; }
+        hipLaunchKernelGGL(pg_pcg_start, dim3(ccm_div_up(7 * F, kTPB)), dim3(kTPB), 0, ctx->stream, d, lambda, 1e-10);
+        hipLaunchKernelGGL(pg_precond, dim3(1), dim3(1024), lds_pc, ctx->stream, d, 0, 0);
+      } else {
+        hipLaunchKernelGGL(pg_pcg_init, dim3(n_wg_init), dim3(kTPB), 0, ctx->stream, d, lambda, 1e-10);
+      }
       // pg_pcg_init leaves its partial sums in the first n_wg_init slots; the consumers sum n_wg_upd (>= n_wg_init) slots,
       // the remainder is zero from the allocation / stays zero
       int flags[4] = {0, 0, 0, 0};
@@ -512,7 +894,12 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
         const int kend = std::min(max_it, k + 32);
         for (; k < kend; k++) {
           hipLaunchKernelGGL(pg_pcg_spmv, dim3(d.n_wg_row), dim3(kTPB), 0, ctx->stream, d, k);
-          hipLaunchKernelGGL(pg_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+          if (use_tree) {
+            hipLaunchKernelGGL(pg_pcg_update_xr, dim3(ccm_div_up(7 * F, kTPB)), dim3(kTPB), 0, ctx->stream, d, k);
+            hipLaunchKernelGGL(pg_precond, dim3(1), dim3(1024), lds_pc, ctx->stream, d, (k + 1) & 1, k + 1);
+          } else {
+            hipLaunchKernelGGL(pg_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+          }
         }
         if (hipMemcpyAsync(flags, d.flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: flag readback"); break; }
         if (flags[0]) break;

@@ -619,6 +619,15 @@ int Optimizer::OptimizeSim3(HipContext& ctx, double g2oS12[8], int n, const doub
   return nin;
 }
 
+void Optimizer::OptimizeEssentialGraph(HipContext& ctx, std::vector<double>& vScw, const std::vector<uint8_t>& fixed, bool bFixScale,
+                                       const std::vector<int32_t>& e_i, const std::vector<int32_t>& e_j, const std::vector<double>& Sji,
+                                       ccm_pg_stats* stats) {
+  const int n_vert = (int)fixed.size(), n_edge = (int)e_i.size();
+  if ((int)vScw.size() != 8 * n_vert || (int)e_j.size() != n_edge || (int)Sji.size() != 8 * n_edge) throw infrastructure_ex("OptimizeEssentialGraph: inconsistent sizes");
+  check(ccm_pose_graph_optimize(ctx.get(), n_vert, vScw.data(), fixed.data(), bFixScale ? 1 : 0, n_edge, e_i.data(), e_j.data(), Sji.data(), 20, 1e-16,
+                                nullptr, stats), ctx.get(), "ccm_pose_graph_optimize");
+}
+
 static ccm_ba_problem make_problem(BAProblem& p, const uint8_t* level, double huber) {
   ccm_ba_problem c{};
   c.n_cam = p.n_cam(); c.n_pt = p.n_pt(); c.n_edge = p.n_edge();

@@ -210,6 +210,13 @@ class Optimizer {
   static int OptimizeSim3(HipContext& ctx, double g2oS12[8], int n, const double* P1c, const double* P2c, const double* obs1,
                           const double* obs2, const double* invSigma2_1, const double* invSigma2_2, const double K1[4],
                           const double K2[4], float th2, bool bFixScale, std::vector<uint8_t>& keep);
+  // OptimizeEssentialGraphLoopClosure / MapFusion numerics (Optimizer.cpp:1058-1331, 1333-1566): the caller builds the vertex
+  // list (Siw per keyframe as [qx qy qz qw tx ty tz s], fixed = pLoopKF) and the edge list (i, j, Sji) exactly as the two
+  // functions do (:1122-1260: loop connections, spanning tree, loop edges, covisibility >= minFeat) and applies the write-back
+  // (:1268-1330) from the optimised vertices.  optimize(20) with setUserLambdaInit(1e-16).
+  static void OptimizeEssentialGraph(HipContext& ctx, std::vector<double>& vScw, const std::vector<uint8_t>& fixed, bool bFixScale,
+                                     const std::vector<int32_t>& e_i, const std::vector<int32_t>& e_j, const std::vector<double>& Sji,
+                                     ccm_pg_stats* stats = nullptr);
 };
 
 }  // namespace cslam

@@ -178,3 +178,11 @@ def pose_graph_optimization(ctx: Context, pg: dict, max_iters: int = 20, lambda_
     check(lib().ccm_pose_graph_optimize(ctx.handle, int(sim3.shape[0]), v(sim3), v(fixed), int(bool(pg["fix_scale"])), int(e_i.size), v(e_i), v(e_j),
                                         v(meas), int(max_iters), C.c_double(lambda_init), None, C.byref(st)), ctx.handle)
     return sim3, st
+
+
+def debug_dense_solve(ctx: Context, A, b):
+    """Test hook: SPD solve through the device's blocked MFMA-f64 Cholesky (ccm_debug_dense_solve)."""
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b); info = C.c_int(0)
+    check(lib().ccm_debug_dense_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info)), ctx.handle)
+    return x, info.value

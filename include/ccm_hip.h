@@ -301,7 +301,8 @@ int  ccm_sim3_optimize(ccm_ctx* ctx, double sim3[8], int n, const double* P1c, c
  * BlockSolver_7_3 + Levenberg with setUserLambdaInit(lambda_init = 1e-16 in the reference; <= 0 selects g2o's
  * tau * max-diagonal rule), optimize(max_iters = 20).  The caller keeps the graph walk that chooses the edges
  * (spanning tree, loop edges, covisibility >= minFeat, :1122-1260) and the SE3 / map-point write-back (:1268-1330).
- * The reduced solve is block-Jacobi PCG (relative tolerance 1e-10) instead of Eigen's sparse LDLT. */
+ * The linear solve is a dense f64 Cholesky on the device (exact, like Eigen's sparse LDLT in the reference); the environment
+ * variable CCM_PG_SOLVER=pcg selects a tree-preconditioned PCG instead (faster on large graphs, inexact-Newton path). */
 typedef struct {
   int32_t iters_done, lm_trials, pcg_iters, reserved;
   double chi2_initial, chi2_final, lambda_final;
@@ -310,6 +311,9 @@ int  ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3 /* n_vert x 
                              int fix_scale, int n_edge, const int32_t* e_i, const int32_t* e_j,
                              const double* meas /* n_edge x 8 */, int max_iters, double lambda_init,
                              const volatile unsigned char* stop_flag /* nullable */, ccm_pg_stats* stats /* nullable */);
+/* test hook for the dense f64 Cholesky (MFMA tiles) behind ccm_pose_graph_optimize: solves A x = b for a host matrix
+ * (n x n row-major, symmetric positive definite); *info = 0 or (first non-positive pivot + 1). */
+int  ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info);
 
 #ifdef __cplusplus
 }

@@ -1362,4 +1362,45 @@ int ora_pose_graph_optimize(int n_vert, double* sim3, const uint8_t* fixed, int 
   return st.iters_done;
 }
 
+
+// Debug export for preconditioner studies: dense H (7F x 7F, row-major, no lambda), b, and the numeric Jacobians of every
+// edge ([E][2][49], zero for fixed sides) at the given state.  Free slots in vertex order.
+int ora_pose_graph_system(int n_vert, const double* sim3, const uint8_t* fixed, int fix_scale, int n_edge, const int32_t* e_i,
+                          const int32_t* e_j, const double* meas, double* Hdense, double* bout, double* Jout) {
+  vector<Sim3> S(n_vert), C(n_edge);
+  auto load = [](const double* p) { Sim3 x; x.r = {p[0], p[1], p[2], p[3]}; x.t[0] = p[4]; x.t[1] = p[5]; x.t[2] = p[6]; x.s = p[7]; return x; };
+  for (int v = 0; v < n_vert; v++) S[v] = load(sim3 + 8 * (size_t)v);
+  for (int e = 0; e < n_edge; e++) C[e] = load(meas + 8 * (size_t)e);
+  vector<int> slot(n_vert, -1); int F = 0;
+  for (int v = 0; v < n_vert; v++) if (!fixed[v]) slot[v] = F++;
+  const size_t n = 7 * (size_t)F;
+  std::fill(Hdense, Hdense + n * n, 0.0); std::fill(bout, bout + n, 0.0); std::fill(Jout, Jout + 98 * (size_t)n_edge, 0.0);
+  auto oplus = [&](const Sim3& X, const double* upd) { double u[7]; for (int k = 0; k < 7; k++) u[k] = upd[k]; if (fix_scale) u[6] = 0; return sim3_mul(sim3_exp(u), X); };
+  auto edge_error = [&](int e, const Sim3& Si, const Sim3& Sj, double err[7]) { sim3_log(sim3_mul(sim3_mul(C[e], Si), sim3_inv(Sj)), err); };
+  const double dlt = 1e-9, scalar = 1.0 / (2 * dlt);
+  for (int e = 0; e < n_edge; e++) {
+    const int vi = e_i[e], vj = e_j[e], a = slot[vi], b = slot[vj];
+    if (a < 0 && b < 0) continue;
+    double er[7]; edge_error(e, S[vi], S[vj], er);
+    double* Ji = Jout + 98 * (size_t)e; double* Jj = Ji + 49;
+    for (int side = 0; side < 2; side++) {
+      if ((side == 0 ? a : b) < 0) continue;
+      double* J = side == 0 ? Ji : Jj;
+      for (int d = 0; d < 7; d++) {
+        double add[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7], em[7];
+        add[d] = dlt; if (side == 0) edge_error(e, oplus(S[vi], add), S[vj], ep); else edge_error(e, S[vi], oplus(S[vj], add), ep);
+        add[d] = -dlt; if (side == 0) edge_error(e, oplus(S[vi], add), S[vj], em); else edge_error(e, S[vi], oplus(S[vj], add), em);
+        for (int k = 0; k < 7; k++) J[k * 7 + d] = scalar * (ep[k] - em[k]);
+      }
+    }
+    auto acc = [&](int r, int c, const double* A, const double* B) {
+      for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) { double s2 = 0; for (int k = 0; k < 7; k++) s2 += A[k * 7 + p] * B[k * 7 + q]; Hdense[(7 * (size_t)r + p) * n + 7 * (size_t)c + q] += s2; }
+    };
+    if (a >= 0) { acc(a, a, Ji, Ji); for (int p = 0; p < 7; p++) for (int k = 0; k < 7; k++) bout[7 * (size_t)a + p] -= Ji[k * 7 + p] * er[k]; }
+    if (b >= 0) { acc(b, b, Jj, Jj); for (int p = 0; p < 7; p++) for (int k = 0; k < 7; k++) bout[7 * (size_t)b + p] -= Jj[k * 7 + p] * er[k]; }
+    if (a >= 0 && b >= 0) { acc(a, b, Ji, Jj); acc(b, a, Jj, Ji); }
+  }
+  return F;
+}
+
 }  // extern "C"

@@ -55,3 +55,23 @@ def test_bad_edge_index_is_rejected(ctx):
     pg["e_j"] = pg["e_j"].copy(); pg["e_j"][2] = 99
     with pytest.raises(Exception):
         optimizer.pose_graph_optimization(ctx, pg)
+
+
+@pytest.mark.parametrize("n", [7, 64, 100, 257, 1000])
+def test_dense_mfma_cholesky_solves_spd_systems(ctx, n):
+    """The blocked f64 Cholesky behind the pose-graph solve (dense_chol.hip: 64x64 tiles on v_mfma_f64_16x16x4) against
+    numpy on random SPD matrices; sizes cover a single partial tile, exact tiles and several tile rows with padding."""
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    x, info = optimizer.debug_dense_solve(ctx, A, b)
+    assert info == 0
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()) * n
+
+
+def test_dense_cholesky_reports_a_non_positive_pivot(ctx):
+    A = np.eye(70); A[40, 40] = -1.0
+    x, info = optimizer.debug_dense_solve(ctx, A, np.ones(70))
+    assert info == 41
