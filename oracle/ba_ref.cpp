@@ -1403,4 +1403,8 @@ int ora_pose_graph_system(int n_vert, const double* sim3, const uint8_t* fixed, 
   return F;
 }
 
+
+// test hook: out = log(exp(u)) of g2o::Sim3 (sim3.h:72-140, 146-237)
+void ora_sim3_exp_log(const double* u, double* out) { sim3_log(sim3_exp(u), out); }
+
 }  // extern "C"

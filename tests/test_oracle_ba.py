@@ -150,3 +150,37 @@ def test_sim3_oracle_fixed_scale_and_early_return(oracle_lib):
     p = synth.make_sim3_problem(8, 5)
     sim, inl, nin = oracle_lib.sim3_optimize(p["sim3"], p["P1c"], p["P2c"], p["obs1"], p["obs2"], p["info1"], p["info2"], p["K1"], p["K2"], 10.0, False)
     assert nin == 0 and np.array_equal(sim, p["sim3"])  # fewer than 10 correspondences: return 0, S12 untouched
+
+
+def test_sim3_log_inverts_exp_in_every_branch(oracle_lib):
+    """g2o::Sim3 exponential / logarithm restated (sim3.h:72-237): log(exp(u)) = u in all four (theta, sigma) branches."""
+    import ctypes as C
+    import numpy as np
+    fn = oracle_lib.lib().ora_sim3_exp_log
+    rng = np.random.default_rng(0)
+    cases = [rng.normal(size=7) * 0.3 for _ in range(20)]
+    cases += [np.r_[rng.normal(size=3) * 1e-7, rng.normal(size=3), 0.2], np.r_[rng.normal(size=3) * 0.4, rng.normal(size=3), 1e-8],
+              np.r_[np.zeros(3), rng.normal(size=3), 0.0], np.r_[rng.normal(size=3) * 1e-7, rng.normal(size=3), 1e-9]]
+    for u in cases:
+        u = np.ascontiguousarray(u, np.float64); out = np.zeros(7)
+        fn(u.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        assert np.abs(out - u).max() < 1e-9, (u, out)
+
+
+def test_pose_graph_oracle_properties(oracle_lib):
+    """OptimizeEssentialGraph numerics restated: a drift-consistent graph is a fixed point; closing the loop spreads the
+    error (chi2 drops by orders of magnitude), the fixed keyframe does not move, a fixed-scale graph keeps every scale."""
+    import numpy as np
+    from ccm_slam_amd import synth
+    pg = synth.make_pose_graph(50, 2, n_loop=0)
+    s, st = oracle_lib.pose_graph_optimize(pg)
+    assert st.chi2_initial < 1e-20 and np.abs(s - pg["sim3"]).max() < 1e-9
+    for fs in (False, True):
+        pg = synth.make_pose_graph(80, 1, fix_scale=fs)
+        s, st = oracle_lib.pose_graph_optimize(pg)
+        assert st.chi2_final < 0.05 * st.chi2_initial
+        assert np.array_equal(s[0], pg["sim3"][0])
+        if fs:
+            assert np.array_equal(s[:, 7], pg["sim3"][:, 7])
+        else:
+            assert np.abs(s[:, 7] - 1).max() < 0.1
