@@ -1322,7 +1322,7 @@ struct ccm_ba {
   int lp_begin = 0, lp_end = 0;
   std::vector<int> slot_cam, cam_slot, slot_pt, pt_slot;
   std::vector<int> loc_edge_orig;       // local edge -> original edge index
-  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> allocs;   // pooled blocks (ccm_pool_get)
   BaDev d{};
   int cur = 0;
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
@@ -1341,8 +1341,9 @@ int dev_upload(ccm_ba* ba, const std::vector<T>& v, T** out) {
   ccm_ctx* ctx = ba->ctx;
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
-  CCM_HIP_CHECK(ctx, hipMalloc(&p, bytes));
-  ba->allocs.push_back(p);
+  size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, bytes, &p, &actual)) return rc;
+  ba->allocs.push_back({p, actual});
   if (!v.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   *out = (T*)p;
   return CCM_OK;
@@ -1352,8 +1353,9 @@ int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
   ccm_ctx* ctx = ba->ctx;
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-  CCM_HIP_CHECK(ctx, hipMalloc(&p, bytes));
-  ba->allocs.push_back(p);
+  size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, bytes, &p, &actual)) return rc;
+  ba->allocs.push_back({p, actual});
   if (zero) CCM_HIP_CHECK(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
   *out = (T*)p;
   return CCM_OK;
@@ -1630,7 +1632,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
 extern "C" void ccm_ba_destroy(ccm_ba* ba) {
   if (!ba) return;
   if (ba->ctx) { hipSetDevice(ba->ctx->device); hipStreamSynchronize(ba->ctx->stream); }
-  for (void* p : ba->allocs) hipFree(p);
+  for (auto& pr : ba->allocs) ccm_pool_put(ba->ctx, pr.first, pr.second);
   delete ba;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 #include <mutex>
@@ -29,6 +30,9 @@ struct ccm_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_io = nullptr; size_t d_io_bytes = 0;   // staging for the host-pointer entry points
   void* h_pin = nullptr; size_t h_pin_bytes = 0; // pinned host staging (one H2D / D2H per small call)
+  // size-bucketed cache of device blocks released by BA handles: a local BA builds a fresh problem for every keyframe, and
+  // ~45 hipMalloc + hipFree per problem cost more than the host-side structure build itself
+  std::multimap<size_t, void*> pool_free; size_t pool_bytes = 0;
 };
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
@@ -53,6 +57,9 @@ struct ccm_prof_scope {
 int ccm_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_io_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out);
+// pooled device blocks: *actual receives the bucket size to hand back to ccm_pool_put
+int ccm_pool_get(ccm_ctx* ctx, size_t bytes, void** out, size_t* actual);
+void ccm_pool_put(ccm_ctx* ctx, void* p, size_t actual);
 // dense_chol.hip: SPD solve on the device (N multiple of 64, padding = identity), see the definition for the contract
 int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }

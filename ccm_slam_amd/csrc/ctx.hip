@@ -65,6 +65,7 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  for (auto& kv : ctx->pool_free) hipFree(kv.second);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -185,4 +186,36 @@ int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
   }
   *out = ctx->h_pin;
   return CCM_OK;
+}
+
+// buckets: 4 KiB, then {1, 1.5} x 2^k — at most 50 % slack, few distinct sizes
+static size_t pool_bucket(size_t bytes) {
+  for (size_t b = 4096;; b *= 2) {
+    if (b >= bytes) return b;
+    if (b + b / 2 >= bytes) return b + b / 2;
+  }
+}
+
+int ccm_pool_get(ccm_ctx* ctx, size_t bytes, void** out, size_t* actual) {
+  const size_t b = pool_bucket(bytes);
+  auto it = ctx->pool_free.find(b);
+  if (it != ctx->pool_free.end()) { *out = it->second; ctx->pool_free.erase(it); ctx->pool_bytes -= b; *actual = b; return CCM_OK; }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, b);
+  if (e != hipSuccess) {   // give the cache back to the driver and retry once
+    for (auto& kv : ctx->pool_free) hipFree(kv.second);
+    ctx->pool_free.clear(); ctx->pool_bytes = 0;
+    e = hipMalloc(&p, b);
+  }
+  if (e != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, std::string("pooled hipMalloc failed: ") + hipGetErrorString(e));
+  *out = p; *actual = b;
+  return CCM_OK;
+}
+
+void ccm_pool_put(ccm_ctx* ctx, void* p, size_t actual) {
+  constexpr size_t kKeep = (size_t)16 << 30;   // retain at most 16 GiB of idle blocks (288 GB of HBM per GPU)
+  if (!p) return;
+  if (ctx->pool_bytes + actual > kKeep) { hipFree(p); return; }
+  ctx->pool_free.emplace(actual, p);
+  ctx->pool_bytes += actual;
 }

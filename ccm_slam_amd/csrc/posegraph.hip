@@ -623,20 +623,23 @@ __global__ __launch_bounds__(kTPB) void pg_dense_fill(PgDev d, const int* blk_a,
   if (i < N) { rhs[i] = (i < n) ? d.b[i] : 0.0; if (i >= n) A[(size_t)i * N + i] = 1.0; }
 }
 
+typedef std::vector<std::pair<void*, size_t>> PgAllocs;   // pooled blocks (ccm_pool_get / ccm_pool_put)
 template <typename T>
-int up(ccm_ctx* ctx, std::vector<void*>& allocs, const std::vector<T>& v, T** out) {
+int up(ccm_ctx* ctx, PgAllocs& allocs, const std::vector<T>& v, T** out) {
   void* p = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)));
-  allocs.push_back(p);
+  size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, std::max<size_t>(v.size(), 1) * sizeof(T), &p, &actual)) return rc;
+  allocs.push_back({p, actual});
   if (!v.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   *out = (T*)p;
   return CCM_OK;
 }
 template <typename T>
-int al(ccm_ctx* ctx, std::vector<void*>& allocs, size_t n, T** out) {
+int al(ccm_ctx* ctx, PgAllocs& allocs, size_t n, T** out) {
   void* p = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
-  allocs.push_back(p);
+  size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, std::max<size_t>(n, 1) * sizeof(T), &p, &actual)) return rc;
+  allocs.push_back({p, actual});
   CCM_HIP_CHECK(ctx, hipMemsetAsync(p, 0, std::max<size_t>(n, 1) * sizeof(T), ctx->stream));
   *out = (T*)p;
   return CCM_OK;
@@ -644,7 +647,7 @@ int al(ccm_ctx* ctx, std::vector<void*>& allocs, size_t n, T** out) {
 
 }  // namespace
 
-#define PG_RC(x) do { int rc_ = (x); if (rc_) { for (void* p_ : allocs) hipFree(p_); return rc_; } } while (0)
+#define PG_RC(x) do { int rc_ = (x); if (rc_) { hipStreamSynchronize(ctx->stream); for (auto& p_ : allocs) ccm_pool_put(ctx, p_.first, p_.second); return rc_; } } while (0)
 
 extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, const uint8_t* fixed, int fix_scale, int n_edge,
                                        const int32_t* e_i, const int32_t* e_j, const double* meas, int max_iters, double lambda_init,
@@ -749,7 +752,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     for (int pos = 0; pos <= F; pos++) { ends_idx.insert(ends_idx.end(), ends[pos].begin(), ends[pos].end()); ends_off[pos + 1] = (int)ends_idx.size(); }
   }
   // ---- device state ----
-  std::vector<void*> allocs;
+  PgAllocs allocs;
   PgDev d{};
   d.V = n_vert; d.F = F; d.E = E; d.nBlk = nBlk; d.fix_scale = fix_scale ? 1 : 0;
   std::vector<double> s0(sim3, sim3 + 8 * (size_t)n_vert);
@@ -804,7 +807,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[0])); PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[1]));
   PG_RC(al(ctx, allocs, 8, &d.scal)); PG_RC(al(ctx, allocs, 4, &d.flag));
   PG_RC(al(ctx, allocs, (size_t)std::max({d.n_wg_edge, n_wg_v, 1}), &d.part));
-  auto cleanup = [&]() { hipStreamSynchronize(ctx->stream); for (void* p : allocs) hipFree(p); };
+  auto cleanup = [&]() { hipStreamSynchronize(ctx->stream); for (auto& p : allocs) ccm_pool_put(ctx, p.first, p.second); };
   auto read_scal = [&](int idx, double* out) -> int {
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, d.scal + idx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
