@@ -192,6 +192,25 @@ void FrameGridDev::SetKeyPoints(const std::vector<KeyPoint>& mvKeys, const uint8
   for (int i = 0; i < n; i++) { mvKeysUn[i].x = xy[2 * i]; mvKeysUn[i].y = xy[2 * i + 1]; }
 }
 
+// every candidate list (GetFeaturesInArea order) and Hamming distance of a batch of window queries in one device call
+void ORBmatcher::deviceWindows(FrameGridDev& grid, const std::vector<float>& u, const std::vector<float>& v, const std::vector<float>& r,
+                               const std::vector<int32_t>& minl, const std::vector<int32_t>& maxl, const std::vector<uint8_t>& qdesc,
+                               std::vector<int32_t>& off, std::vector<int32_t>& idx, std::vector<uint16_t>& dist) {
+  const int Q = (int)u.size();
+  off.assign(Q + 1, 0);
+  int64_t n = 0;
+  idx.resize((size_t)Q * 16 + 1024); dist.resize(idx.size());   // typical lists hold a handful of features; grow once if short
+  int rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
+                                   dist.data(), (int64_t)idx.size(), &n);
+  if (rc == CCM_E_ARG && n > (int64_t)idx.size()) {
+    idx.resize((size_t)n); dist.resize((size_t)n);
+    rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
+                                 dist.data(), n, &n);
+  }
+  check(rc, ctx_.get(), "ccm_frame_window_search");
+  idx.resize((size_t)n); dist.resize((size_t)n);
+}
+
 // SearchByProjection(Frame&, vector<mpptr>&, th) with the device grid: ONE ccm_frame_window_search call produces every
 // candidate list (GetFeaturesInArea order) and distance; the ordered claim replay below is unchanged.
 int ORBmatcher::SearchByProjection(FrameGridDev& grid, FrameView& F, const TrackedMapPoints& mps, float th) {
@@ -211,19 +230,9 @@ int ORBmatcher::SearchByProjection(FrameGridDev& grid, FrameView& F, const Track
   }
   const int Q = (int)q_of.size();
   if (Q == 0) return 0;
-  std::vector<int32_t> off(Q + 1), idx;
+  std::vector<int32_t> off, idx;
   std::vector<uint16_t> dist;
-  int64_t n = 0;
-  // typical lists hold a handful of features; grow once if the guess was short
-  idx.resize((size_t)Q * 16 + 1024); dist.resize(idx.size());
-  int rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
-                                   dist.data(), (int64_t)idx.size(), &n);
-  if (rc == CCM_E_ARG && n > (int64_t)idx.size()) {
-    idx.resize((size_t)n); dist.resize((size_t)n);
-    rc = ccm_frame_window_search(grid.get(), Q, u.data(), v.data(), r.data(), minl.data(), maxl.data(), qdesc.data(), off.data(), idx.data(),
-                                 dist.data(), n, &n);
-  }
-  check(rc, ctx_.get(), "ccm_frame_window_search");
+  deviceWindows(grid, u, v, r, minl, maxl, qdesc, off, idx, dist);
   int nmatches = 0;
   for (int q = 0; q < Q; q++) {
     int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
@@ -265,6 +274,57 @@ int ORBmatcher::SearchByProjection(FrameView& C, const LastFrameProjections& las
     std::vector<uint16_t> dist(idx.size());
     check(ccm_hamming_csr(ctx_.get(), qdesc.data(), Q, C.mDescriptors, C.N, off.data(), idx.data(), dist.data(), nullptr, nullptr, nullptr),
           ctx_.get(), "ccm_hamming_csr");
+    for (int q = 0; q < Q; q++) {
+      int bestDist = 256, bestIdx2 = -1;
+      for (int s = off[q]; s < off[q + 1]; s++) {
+        const int k = idx[s];
+        if (C.mvpMapPoints[k] >= 0) continue;
+        if (dist[s] < bestDist) { bestDist = dist[s]; bestIdx2 = k; }
+      }
+      if (bestDist <= TH_HIGH) {
+        C.mvpMapPoints[bestIdx2] = q_of[q];
+        nmatches++;
+        if (mbCheckOrientation) {
+          float rot = last.angle[q_of[q]] - C.mvKeysUn[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(bestIdx2);
+        }
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (int k : rotHist[i]) { C.mvpMapPoints[k] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// SearchByProjection(Frame&, const Frame& LastFrame, th) with the device grid (ORBmatcher.cpp:1350-1476)
+int ORBmatcher::SearchByProjection(FrameGridDev& grid, FrameView& C, const LastFrameProjections& last, float th) {
+  std::vector<int32_t> q_of, minl, maxl;
+  std::vector<float> u, v, r;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < last.n; i++) {
+    if (!last.valid[i]) continue;
+    const int oct = last.octave[i];
+    q_of.push_back(i);
+    u.push_back(last.u[i]); v.push_back(last.v[i]); r.push_back(th * C.mvScaleFactors[oct]);
+    minl.push_back(oct - 1); maxl.push_back(oct + 1);
+    qdesc.insert(qdesc.end(), last.mpDescriptor + (size_t)i * 32, last.mpDescriptor + (size_t)i * 32 + 32);
+  }
+  const int Q = (int)q_of.size();
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;   // upstream quirk: 30-degree bins (:1358)
+  if (Q > 0) {
+    std::vector<int32_t> off, idx;
+    std::vector<uint16_t> dist;
+    deviceWindows(grid, u, v, r, minl, maxl, qdesc, off, idx, dist);
     for (int q = 0; q < Q; q++) {
       int bestDist = 256, bestIdx2 = -1;
       for (int s = off[q]; s < off[q + 1]; s++) {
@@ -742,6 +802,27 @@ int ccmh_search_by_projection_mp_dev(int device, const float* K, const float* di
     mps.mDescriptor = mp_desc;
     cslam::ORBmatcher m(ctx, nnratio, true);
     return m.SearchByProjection(grid, F, mps, th);
+  } catch (const std::exception&) { return -1000; }
+}
+
+// SearchByProjection(Frame, LastFrame) through the device grid; keypoints given already undistorted (no distortion coefficients)
+int ccmh_search_by_projection_last_dev(int device, const void* kps_un, const uint8_t* cdesc, int N, int w, int h, const float* scale_factors, int n_last,
+                                       const uint8_t* valid, const float* u, const float* v, const int32_t* oct, const float* angle, const uint8_t* mp_desc,
+                                       float th, int check_ori, int32_t* frame_mp) {
+  try {
+    cslam::HipContext ctx(device);
+    const float K[4] = {1.f, 1.f, 0.f, 0.f};
+    cslam::FrameGridDev grid(ctx, K, nullptr, 0, w, h);
+    std::vector<cslam::KeyPoint> keys((const cslam::KeyPoint*)kps_un, (const cslam::KeyPoint*)kps_un + N), keysUn;
+    grid.SetKeyPoints(keys, cdesc, keysUn);
+    cslam::FrameView C;
+    C.N = N; C.mvKeysUn = keysUn.data(); C.mDescriptors = cdesc;
+    C.mnMinX = grid.mnMinX; C.mnMinY = grid.mnMinY; C.mnMaxX = grid.mnMaxX; C.mnMaxY = grid.mnMaxY;
+    C.mvScaleFactors = scale_factors; C.mvpMapPoints = frame_mp;
+    cslam::LastFrameProjections L;
+    L.n = n_last; L.valid = valid; L.u = u; L.v = v; L.octave = oct; L.angle = angle; L.mpDescriptor = mp_desc;
+    cslam::ORBmatcher m(ctx, 0.9f, check_ori != 0);
+    return m.SearchByProjection(grid, C, L, th);
   } catch (const std::exception&) { return -1000; }
 }
 

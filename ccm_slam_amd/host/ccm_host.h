@@ -128,6 +128,7 @@ class ORBmatcher {
   int SearchByProjection(FrameView& F, const TrackedMapPoints& mps, float th);
   // same, with the candidate lists and distances produced on the device from the frame's resident grid (no host grid walk)
   int SearchByProjection(FrameGridDev& grid, FrameView& F, const TrackedMapPoints& mps, float th);
+  int SearchByProjection(FrameGridDev& grid, FrameView& CurrentFrame, const LastFrameProjections& last, float th);
   // ORBmatcher.cpp:1350-1476.
   int SearchByProjection(FrameView& CurrentFrame, const LastFrameProjections& last, float th);
   // SearchByBoW(kfptr pKF, Frame& F, ...) — ORBmatcher.cpp:178-306.  matchesF[F.N]: KF feature whose map point goes to F[i], or -1
@@ -151,6 +152,9 @@ class ORBmatcher {
   // SearchBySim3's agreement step (:1318-1345) on the two directional results
   static int MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12);
  private:
+  void deviceWindows(FrameGridDev& grid, const std::vector<float>& u, const std::vector<float>& v, const std::vector<float>& r,
+                     const std::vector<int32_t>& minl, const std::vector<int32_t>& maxl, const std::vector<uint8_t>& qdesc,
+                     std::vector<int32_t>& off, std::vector<int32_t>& idx, std::vector<uint16_t>& dist);
   // distances of every (query, candidate) slot in one device launch
   void distances(const std::vector<uint8_t>& qdesc, int Q, const uint8_t* tdesc, int T, const std::vector<int32_t>& off,
                  const std::vector<int32_t>& idx, std::vector<uint16_t>& dist);

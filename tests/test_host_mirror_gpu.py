@@ -80,6 +80,11 @@ def test_search_by_projection_last_frame(hostlib, oracle_lib):
                                                n_last, _p(valid), _p(u), _p(v), _p(lo), _p(la), _p(d1), C.c_float(7.0), 1, _p(got))
     assert n == exp_n and n > 200
     assert np.array_equal(got, exp)
+    # the same search with the grid, the candidate lists and the distances produced on the device
+    got2 = cur0.copy()
+    n2 = hostlib.ccmh_search_by_projection_last_dev(0, _p(np.ascontiguousarray(k2)), _p(d2), len(k2), 752, 480, _p(sf), n_last, _p(valid), _p(u), _p(v),
+                                                    _p(lo), _p(la), _p(d1), C.c_float(7.0), 1, _p(got2))
+    assert n2 == exp_n and np.array_equal(got2, exp)
 
 
 def test_local_ba_client_two_stage(hostlib, oracle_lib):
