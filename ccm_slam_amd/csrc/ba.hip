@@ -32,6 +32,9 @@
 #include <numeric>
 
 int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n);   // comm.hip
+int ccm_ba_build_pairs(ccm_ctx* ctx, const std::vector<int>& g_pt_off, const std::vector<int>& cslot_g, int Cp, int lb, int le, int eb,
+                       std::vector<uint64_t>& all_keys, int** d_inst_off, int** d_inst_a, int** d_inst_c, int64_t* n_inst,
+                       std::vector<std::pair<void*, size_t>>& keep);   // ba_structure.hip
 int ccm_allreduce_max_f64(ccm_ctx* ctx, double* d_buf, size_t n);
 
 namespace {
@@ -1393,6 +1396,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (P->e_cam[e] < 0 || P->e_cam[e] >= P->n_cam || P->e_pt[e] < 0 || P->e_pt[e] >= P->n_pt)
       return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: edge index out of range");
   const double t0 = now_ms();
+  const bool setup_dbg = getenv("CCM_BA_SETUP_DBG") != nullptr;
+  double t_last = t0;
+  auto lap = [&](const char* what) { if (setup_dbg) { const double t = now_ms(); fprintf(stderr, "[ccm_ba] setup %-22s %7.2f ms\n", what, t - t_last); t_last = t; } };
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ccm_ba* ba = new ccm_ba();
   ba->ctx = ctx; ba->rank = rank; ba->nranks = nranks;
@@ -1415,6 +1421,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   const int Cp = ba->Cp = (int)ba->slot_cam.size();
   const int Lp = ba->Lp = (int)ba->slot_pt.size();
 
+  lap("active set");
   // ---- edges sorted by (landmark slot, pose slot) — fixed cameras (slot -1) first ----
   std::vector<int> order(act.size());
   {
@@ -1431,6 +1438,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   for (size_t k = 0; k < order.size(); k++) g_pt_off[ba->pt_slot[P->e_pt[order[k]]] + 1]++;
   for (int l = 0; l < Lp; l++) g_pt_off[l + 1] += g_pt_off[l];
 
+  lap("edge sort");
   // ---- shard the landmarks: weight = pair instances + edges ----
   std::vector<int64_t> weight(Lp);
   for (int l = 0; l < Lp; l++) {
@@ -1445,56 +1453,19 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   const int eb = g_pt_off[lb], ee = g_pt_off[le];
   const int Eloc = ba->Eloc = ee - eb;
 
-  // ---- global off-diagonal block structure + own pair instances ----
-  // every (ia < ic) camera pair of every landmark, in landmark order; two stable counting-sort passes (by ic,
-  // then by ia) order them by block while keeping the landmark order inside a block — O(n + Cp), no comparison sort
-  struct Inst { int ia, ic, ea, ec; };
-  std::vector<Inst> inst;
-  {
-    size_t total = 0;
-    for (int l = 0; l < Lp; l++) { const size_t k = (size_t)(g_pt_off[l + 1] - g_pt_off[l]); total += k * (k - 1) / 2; }
-    inst.reserve(total);
-  }
-  for (int l = 0; l < Lp; l++) {
-    const int k0 = g_pt_off[l], k1 = g_pt_off[l + 1];
-    for (int a = k0; a < k1; a++) {
-      const int ia = ba->cam_slot[P->e_cam[order[a]]];
-      if (ia < 0) continue;
-      for (int c = a + 1; c < k1; c++) {
-        const int ic = ba->cam_slot[P->e_cam[order[c]]];
-        if (ic == ia) continue;   // two observations of one landmark in one camera: contributes to the diagonal only
-        inst.push_back(Inst{ia, ic, a, c});   // ia < ic by the sort; a, c are GLOBAL positions in the landmark-sorted edge list
-      }
-    }
-  }
-  {
-    std::vector<Inst> tmp(inst.size());
-    std::vector<int> cnt(Cp + 1);
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (const Inst& x : inst) cnt[x.ic + 1]++;
-    for (int i = 0; i < Cp; i++) cnt[i + 1] += cnt[i];
-    for (const Inst& x : inst) tmp[cnt[x.ic]++] = x;
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (const Inst& x : tmp) cnt[x.ia + 1]++;
-    for (int i = 0; i < Cp; i++) cnt[i + 1] += cnt[i];
-    for (const Inst& x : tmp) inst[cnt[x.ia]++] = x;
-  }
+  lap("shard");
+  // ---- global off-diagonal block structure + own pair instances: built on the device (ba_structure.hip) ----
   std::vector<uint64_t> all_keys;
-  std::vector<int> inst_off, inst_a, inst_c;
-  inst_off.push_back(0);
+  int *d_inst_off = nullptr, *d_inst_a = nullptr, *d_inst_c = nullptr;
   {
-    size_t s = 0;
-    while (s < inst.size()) {
-      const int ia = inst[s].ia, ic = inst[s].ic;
-      all_keys.push_back(((uint64_t)(uint32_t)ia << 32) | (uint32_t)ic);
-      for (; s < inst.size() && inst[s].ia == ia && inst[s].ic == ic; s++)
-        if (inst[s].ea >= eb && inst[s].ea < ee) { inst_a.push_back(inst[s].ea - eb); inst_c.push_back(inst[s].ec - eb); }   // own landmark
-      inst_off.push_back((int)inst_a.size());
-    }
+    std::vector<int> cslot_g(order.size());
+    for (size_t k = 0; k < order.size(); k++) cslot_g[k] = ba->cam_slot[P->e_cam[order[k]]];
+    int64_t n_inst = 0;
+    if (int rc = ccm_ba_build_pairs(ctx, g_pt_off, cslot_g, Cp, lb, le, eb, all_keys, &d_inst_off, &d_inst_a, &d_inst_c, &n_inst, ba->allocs)) return fail(rc);
+    ba->n_inst = n_inst;
   }
+  lap("pair structure (device)");
   const int nOff = ba->nOff = (int)all_keys.size();
-  ba->n_inst = (int64_t)inst_a.size();
-  { std::vector<Inst>().swap(inst); }
   // ---- block CSR rows (full symmetric pattern) ----
   std::vector<int> row_cnt(Cp + 1, 0);
   for (int i = 0; i < Cp; i++) row_cnt[i + 1] = 1;
@@ -1543,6 +1514,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     }
   }
 
+  lap("rows + persist lists");
   // ---- local edge arrays ----
   std::vector<int> pt_off(Lloc + 1), ed_cam(Eloc), ed_cslot(Eloc), ed_pt(Eloc);
   std::vector<double> obs(2 * (size_t)Eloc), info(Eloc);
@@ -1566,6 +1538,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   std::vector<int> own_slot(Lloc);
   for (int l = 0; l < Lloc; l++) own_slot[l] = lb + l;
 
+  lap("local arrays");
   // ---- upload ----
   BaDev& d = ba->d;
   d.n_cam = P->n_cam; d.Cp = Cp; d.Lloc = Lloc; d.Eloc = Eloc; d.nOff = nOff; d.huber = P->huber_delta;
@@ -1576,7 +1549,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
 #define UP(vec, field, T) { T* _p = nullptr; if (int rc = dev_upload(ba, vec, &_p)) return fail(rc); d.field = _p; }
   UP(ba->slot_cam, slot_cam, int) UP(pt_off, pt_off, int) UP(ed_cam, ed_cam, int) UP(ed_cslot, ed_cslot, int)
   UP(ed_pt, ed_pt, int) UP(obs, obs, double) UP(info, info, double) UP(cam_off, cam_off, int) UP(cam_edge, cam_edge, int)
-  UP(inst_off, inst_off, int) UP(inst_a, inst_a, int) UP(inst_c, inst_c, int)
+  d.inst_off = d_inst_off; d.inst_a = d_inst_a; d.inst_c = d_inst_c;
   UP(row_cnt, row_off, int) UP(row_col, row_col, int) UP(row_blk, row_blk, uint32_t)
 #undef UP
   if (int rc = dev_upload(ba, own_slot, &ba->d_own_slot)) return fail(rc);
@@ -1624,6 +1597,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   int rc = ccm_ba_reset_state(ba, P->cam_qt, P->pt_xyz);
   if (rc) return fail(rc);
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  lap("alloc + upload");
   ba->ms_setup = now_ms() - t0;
   *out = ba;
   return CCM_OK;
