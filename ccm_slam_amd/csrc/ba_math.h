@@ -55,18 +55,24 @@ BA_HD void ba_R_to_q(const double m[9], BaPose& T) {
     t = 0.5 / t;
     T.qx = (m[7] - m[5]) * t; T.qy = (m[2] - m[6]) * t; T.qz = (m[3] - m[1]) * t;
   } else {
+    // Eigen picks the largest diagonal entry i and sets j = (i+1)%3, k = (j+1)%3; written out per case so that m[] is never
+    // indexed with a run-time value (that would move the matrix to scratch memory on the device)
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-    double c[3];
-    c[i] = 0.5 * t;
-    t = 0.5 / t;
-    T.qw = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    c[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    c[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-    T.qx = c[0]; T.qy = c[1]; T.qz = c[2];
+    if (m[8] > ((i == 0) ? m[0] : m[4])) i = 2;
+    if (i == 0) {          // j = 1, k = 2
+      t = sqrt(m[0] - m[4] - m[8] + 1.0);
+      T.qx = 0.5 * t; t = 0.5 / t;
+      T.qw = (m[7] - m[5]) * t; T.qy = (m[3] + m[1]) * t; T.qz = (m[6] + m[2]) * t;
+    } else if (i == 1) {   // j = 2, k = 0
+      t = sqrt(m[4] - m[8] - m[0] + 1.0);
+      T.qy = 0.5 * t; t = 0.5 / t;
+      T.qw = (m[2] - m[6]) * t; T.qz = (m[7] + m[5]) * t; T.qx = (m[1] + m[3]) * t;
+    } else {               // j = 0, k = 1
+      t = sqrt(m[8] - m[0] - m[4] + 1.0);
+      T.qz = 0.5 * t; t = 0.5 / t;
+      T.qw = (m[3] - m[1]) * t; T.qx = (m[2] + m[6]) * t; T.qy = (m[5] + m[7]) * t;
+    }
   }
 }
 

@@ -178,7 +178,10 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
           const BaPose backup = T;
           double xs[6] = {0, 0, 0, 0, 0, 0};
           const bool ok2 = chol6_solve(H, lambda, B, xs);
-          if (!ok2) { for (int k = 0; k < 6; k++) xs[k] = 0; }
+          if (!ok2) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) xs[k] = 0;
+          }
           T = ba_oplus(xs, T);
           double tempChi = chi2_active(T);
           if (!ok2) tempChi = DBL_MAX;
