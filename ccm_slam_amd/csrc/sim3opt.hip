@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kThreads) void sim3opt_kernel(Sim3OptArgs a, int us
       const double scalar = 1.0 / (2 * 1e-9);
       for (int i = tid; i < n; i += kThreads) {
         if (!a.alive[i]) continue;
-#pragma unroll
-        for (int side = 0; side < 2; side++) {
+#pragma unroll 1
+        for (int side = 0; side < 2; side++) {   // not unrolled: the 14 perturbed Sim3 of both sides at once do not fit the register file
           const double* P = side ? a.P1c + 3 * i : a.P2c + 3 * i;
           const double* ob = side ? a.obs2 + 2 * i : a.obs1 + 2 * i;
           const double* KK = side ? K2 : K1;
