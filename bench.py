@@ -232,7 +232,8 @@ def main():
         "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,
         "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,
         # per pair instance two 6x3 W blocks + symmetric Dinv, per block one 6x6 store
-        "BA_SCHUR_OFF": (144.0 * 2 + 48.0 + 8.0) * P + 288.0 * n_off,
+        # row-centric form: per pair instance one 6x3 W block + 2 indices, per observation W + Dinv once, per block one 6x6 store
+        "BA_SCHUR_OFF": (144.0 + 8.0) * P + (144.0 + 48.0) * E + 288.0 * n_off,
         "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
         "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + 144.0) * E + (24.0 + 72.0) * L,
         "BA_CAM": (24.0 + 24.0 + 8.0) * E + (56.0 + 288.0 + 48.0) * C,

@@ -111,6 +111,9 @@ struct BaDev {
   const int* inst_off;       // [nOff+1]
   const int* inst_a;         // edge with the block-row camera
   const int* inst_c;         // edge with the block-col camera
+  const int* inst_al;        // rank of inst_a's edge inside its camera's edge list (row-centric Schur kernel)
+  const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
+  int max_cam_edges;         // longest per-camera edge list on this rank
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]
@@ -358,6 +361,66 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
   }
   __syncthreads();
   if (wv == 0 && lane < 36) d.S[36 * (size_t)(d.Cp + b) + lane] = -(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
+}
+
+// off-diagonal Schur blocks, row-centric: one workgroup per free camera i.  Y_e = W_e Dinv_l (6x3) of ALL observations of
+// camera i is formed once into LDS (the per-block kernel above re-reads W_a and Dinv and redoes the 6x3x3 product for
+// every pair instance: 336 B and 27 flops per instance instead of 152 B and 9), then the waves walk the blocks (i, j > i)
+// of the row and every instance costs one 144-byte W_c row read plus LDS.  Same arithmetic in the same order as
+// ba_schur_off, hence bit-identical blocks.                                                   [CCM_K_BA_SCHUR_OFF]
+constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
+constexpr int kRowTPB = 1024;        // 8 waves walk the row's blocks: the instance stream is latency bound, so more streams win
+__global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
+  extern __shared__ __attribute__((aligned(16))) double Ys[];
+  const int i = blockIdx.x;
+  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
+  for (int t = threadIdx.x; t < ne * 6; t += kRowTPB) {
+    const int k = t / 6, r = t % 6;
+    const int e = d.cam_edge[base + k];
+    const double* Wa = d.W + 18 * (size_t)e + 3 * r;
+    const double* Di = d.Dinv + 6 * (size_t)d.ed_pt[e];
+    const double a0 = Wa[0], a1 = Wa[1], a2 = Wa[2];
+    Ys[t * 3 + 0] = a0 * Di[0] + a1 * Di[1] + a2 * Di[2];
+    Ys[t * 3 + 1] = a0 * Di[1] + a1 * Di[3] + a2 * Di[4];
+    Ys[t * 3 + 2] = a0 * Di[2] + a1 * Di[4] + a2 * Di[5];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (lane >= 36) return;
+  const int r = lane / 6, c = lane % 6;
+  for (int b = d.rowblk_off[i] + wv; b < d.rowblk_off[i + 1]; b += kRowTPB / kWave) {
+    double acc = 0;
+    const int s1 = d.inst_off[b + 1];
+    int s = d.inst_off[b];
+    for (; s + 3 < s1; s += 4) {      // four instances in flight; the sums stay in instance order
+      double w[4][3];
+      const double* y[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const double* Wc = d.W + 18 * (size_t)d.inst_c[s + q] + 3 * c;
+        w[q][0] = Wc[0]; w[q][1] = Wc[1]; w[q][2] = Wc[2];
+        y[q] = Ys + (d.inst_al[s + q] * 6 + r) * 3;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc += y[q][0] * w[q][0] + y[q][1] * w[q][1] + y[q][2] * w[q][2];
+    }
+    for (; s < s1; s++) {
+      const double* Wc0 = d.W + 18 * (size_t)d.inst_c[s] + 3 * c;
+      const double* y0 = Ys + (d.inst_al[s] * 6 + r) * 3;
+      acc += y0[0] * Wc0[0] + y0[1] * Wc0[1] + y0[2] * Wc0[2];
+    }
+    d.S[36 * (size_t)(d.Cp + b) + lane] = -acc;
+  }
+}
+
+// rank of every observation inside its camera's list, then per pair instance the rank of its row-side observation
+__global__ void ba_edge_rank(BaDev d, int* rank) {
+  const int i = blockIdx.x;
+  for (int s = d.cam_off[i] + threadIdx.x; s < d.cam_off[i + 1]; s += blockDim.x) rank[d.cam_edge[s]] = s - d.cam_off[i];
+}
+__global__ void ba_inst_rank(const int* inst_a, const int* rank, int n, int* inst_al) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) inst_al[s] = rank[inst_a[s]];
 }
 
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
@@ -1550,6 +1613,20 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   UP(ba->slot_cam, slot_cam, int) UP(pt_off, pt_off, int) UP(ed_cam, ed_cam, int) UP(ed_cslot, ed_cslot, int)
   UP(ed_pt, ed_pt, int) UP(obs, obs, double) UP(info, info, double) UP(cam_off, cam_off, int) UP(cam_edge, cam_edge, int)
   d.inst_off = d_inst_off; d.inst_a = d_inst_a; d.inst_c = d_inst_c;
+  {
+    std::vector<int> rowblk_off(Cp + 1, 0);
+    for (int b = 0; b < nOff; b++) rowblk_off[(int)(all_keys[b] >> 32) + 1]++;
+    for (int i = 0; i < Cp; i++) rowblk_off[i + 1] += rowblk_off[i];
+    int* p_rb = nullptr; if (int rc = dev_upload(ba, rowblk_off, &p_rb)) return fail(rc); d.rowblk_off = p_rb;
+    d.max_cam_edges = 0;
+    for (int i = 0; i < Cp; i++) d.max_cam_edges = std::max(d.max_cam_edges, cam_off[i + 1] - cam_off[i]);
+    int *p_rank = nullptr, *p_al = nullptr;
+    if (int rc = dev_alloc<int>(ba, (size_t)std::max(Eloc, 1), &p_rank, false)) return fail(rc);
+    if (int rc = dev_alloc<int>(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al, false)) return fail(rc);
+    d.inst_al = p_al;
+    if (Cp) hipLaunchKernelGGL(ba_edge_rank, dim3(Cp), dim3(kTPB), 0, ctx->stream, d, p_rank);
+    if (ba->n_inst) hipLaunchKernelGGL(ba_inst_rank, dim3(ccm_div_up(ba->n_inst, kTPB)), dim3(kTPB), 0, ctx->stream, d.inst_a, (const int*)p_rank, (int)ba->n_inst, p_al);
+  }
   UP(row_cnt, row_off, int) UP(row_col, row_col, int) UP(row_blk, row_blk, uint32_t)
 #undef UP
   if (int rc = dev_upload(ba, own_slot, &ba->d_own_slot)) return fail(rc);
@@ -1727,7 +1804,12 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
-      else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+      else if (d.max_cam_edges <= kRowMaxEdges) {
+        const size_t lds_row = (size_t)d.max_cam_edges * 18 * sizeof(double);
+        static bool attr_row = false;
+        if (!attr_row) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, kRowMaxEdges * 18 * (int)sizeof(double))); attr_row = true; }
+        hipLaunchKernelGGL(ba_schur_row, dim3(d.Cp), dim3(kRowTPB), lds_row, ctx->stream, d);
+      } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
     // ---- PCG ----
