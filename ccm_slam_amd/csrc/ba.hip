@@ -1834,7 +1834,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         hipLaunchKernelGGL(ba_pcg_small<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, lambda, tol, max_it, stage_S, (int)ba->n_row_entries);
       }
       small_path = true;
-    } else if (ba->pers_grid) {
+    } else {
+    bool persist_ok = false;
+    if (ba->pers_grid) {
       // whole solve in one cooperative launch; flags are read back together with the trial scalars
       CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pers_bar, 0, 4 * sizeof(unsigned), ctx->stream));
       PersArgs pa;
@@ -1846,11 +1848,14 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       void* kargs[2] = {(void*)&d, (void*)&pa};
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
-        CCM_HIP_CHECK(ctx, hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
-                                                      (unsigned)pers_lds_bytes(), ctx->stream));
+        const hipError_t le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
+                                                         (unsigned)pers_lds_bytes(), ctx->stream);
+        if (le == hipSuccess) persist_ok = true;
+        else { (void)hipGetLastError(); ba->pers_grid = 0; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
       }
-      small_path = true;
-    } else {
+      if (persist_ok) small_path = true;
+    }
+    if (!persist_ok) {
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
       {
         static bool init_attr = false;
@@ -1877,6 +1882,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (flags[0]) break;
       }
       *pcg_iters = flags[0] ? flags[1] : k;
+    }
     }
     if (flags[2]) *ok = false;   // not SPD / NaN: linear solver failure (levenberg.cpp:126-127)
   }
