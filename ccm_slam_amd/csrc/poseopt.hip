@@ -240,31 +240,36 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
     return ccm_set_error(ctx, CCM_E_ARG, "ccm_pose_optimize: bad args");
   if (n < 3) { *n_inlier = 0; return CCM_OK; }   // nInitialCorrespondences < 3 (:290-291)
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  // one device block: [cam 7 | n_bad (8 B) | Xw 3n | obs 2n | info n | err 2n] doubles, then outlier/level/robust bytes.
-  // Inputs are packed into one pinned staging buffer => ONE H2D and ONE D2H per call instead of four + three.
-  const size_t n_in = 8 + 6 * (size_t)n;                  // doubles uploaded
+  // one device block: [cam 7 | n_bad (8 B) | outlier bytes (n, padded to 8) | Xw 3n | obs 2n | info n | err 2n] doubles, then the
+  // level / robust bytes.  Inputs travel in one pinned staging buffer => ONE H2D; the results (pose, count, outlier flags)
+  // are contiguous at the head of the block => ONE D2H.
+  const size_t n_ob = ((size_t)n + 7) / 8;                // doubles holding the outlier bytes
+  const size_t n_in = 8 + n_ob + 6 * (size_t)n;           // doubles uploaded
   const size_t nd = n_in + 2 * (size_t)n;
-  const size_t bytes = nd * sizeof(double) + 3 * (size_t)n + 64;
+  const size_t bytes = nd * sizeof(double) + 2 * (size_t)n + 64;
   void* scratch = nullptr;
   int rc = ccm_scratch(ctx, bytes, &scratch);
   if (rc) return rc;
   void* pin = nullptr;
-  rc = ccm_pin_scratch(ctx, n_in * sizeof(double) + (size_t)n + 64, &pin);
+  rc = ccm_pin_scratch(ctx, n_in * sizeof(double) + 64, &pin);
   if (rc) return rc;
   double* d = (double*)scratch;
   double* h = (double*)pin;
   PoseOptArgs a;
   a.n = n;
   a.cam = d; a.n_bad = (int*)(d + 7);
-  a.Xw = d + 8; a.obs = d + 8 + 3 * (size_t)n; a.info = d + 8 + 5 * (size_t)n; a.err = d + 8 + 6 * (size_t)n;
+  a.outlier = (uint8_t*)(d + 8);
+  double* din = d + 8 + n_ob;
+  a.Xw = din; a.obs = din + 3 * (size_t)n; a.info = din + 5 * (size_t)n; a.err = din + 6 * (size_t)n;
   uint8_t* bytes_base = (uint8_t*)(d + nd);
-  a.outlier = bytes_base; a.level = bytes_base + n; a.robust = bytes_base + 2 * (size_t)n;
+  a.level = bytes_base; a.robust = bytes_base + n;
   for (int k = 0; k < 4; k++) a.K[k] = K[k];
   memcpy(h, cam_qt, 7 * sizeof(double));
   h[7] = 0;
-  memcpy(h + 8, Xw, 3 * (size_t)n * sizeof(double));
-  memcpy(h + 8 + 3 * (size_t)n, obs, 2 * (size_t)n * sizeof(double));
-  memcpy(h + 8 + 5 * (size_t)n, info, (size_t)n * sizeof(double));
+  double* hin = h + 8 + n_ob;
+  memcpy(hin, Xw, 3 * (size_t)n * sizeof(double));
+  memcpy(hin + 3 * (size_t)n, obs, 2 * (size_t)n * sizeof(double));
+  memcpy(hin + 5 * (size_t)n, info, (size_t)n * sizeof(double));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
@@ -279,10 +284,8 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
     hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kThreads), lds_bytes, ctx->stream, a, use_lds);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
-  // results: [cam 7 | n_bad] (64 B) and the n outlier bytes -> two small D2H into the pinned buffer
   uint8_t* h_out = (uint8_t*)(h + 8);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, a.outlier, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, (8 + n_ob) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(cam_qt, h, 7 * sizeof(double));
   memcpy(outlier, h_out, (size_t)n);
