@@ -82,37 +82,61 @@ __global__ __launch_bounds__(kGridTPB) void frame_grid_kernel(const ccm_keypoint
 
 struct WinQ { const float* u; const float* v; const float* r; const int* minl; const int* maxl; };
 
-// pass 0: count, pass 1: fill.  One thread per query walks its cells in the reference's order.
+// pass 0: count, pass 1: fill.  16 lanes per query: the cells of the window are enumerated in the reference's order
+// (ix-major, then iy) and dealt to the lanes 16 at a time; a lane walks its (tiny) cell, a 16-wide prefix sum gives every
+// cell its slot range, so the list comes out in exactly the order GetFeaturesInArea produces.  (One thread per query
+// walked ~36 cells through three dependent loads each: 50 us per pass.)
+constexpr int kQL = 16;   // lanes per query
 template <int FILL>
 __global__ void frame_window_kernel(int Q, WinQ q, FrameBounds b, const float* xy, const int* oct, const int* cell_off, const int* cell_idx,
                                     int* cnt, const int* off, int* out_idx, int cap = 0x7fffffff) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Q) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid / kQL, sub = gid % kQL;
+  if (i >= Q) return;                                       // whole 16-lane groups leave together
   const float x = q.u[i], y = q.v[i], r = q.r[i];
   const int minLevel = q.minl[i], maxLevel = q.maxl[i];
-  int x0, x1, y0, y1, n = 0;
-  int w = FILL ? off[i] : 0;
   if (FILL && off[i + 1] > cap) return;   // would cross the caller's capacity: the host reports the shortfall
+  int x0, x1, y0, y1;
+  int total = 0;
   if (frame_cell_range(b, x, y, r, x0, x1, y0, y1)) {
     const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
-    for (int ix = x0; ix <= x1; ix++)
-      for (int iy = y0; iy <= y1; iy++) {
-        const int c = ix * kGridRows + iy;
-        for (int s = cell_off[c]; s < cell_off[c + 1]; s++) {
+    const int ny = y1 - y0 + 1, ncell = (x1 - x0 + 1) * ny;
+    int carry = FILL ? off[i] : 0;
+    for (int base = 0; base < ncell; base += kQL) {
+      const int j = base + sub;
+      int n = 0, e0 = 0, e1 = 0;
+      if (j < ncell) {
+        const int c = (x0 + j / ny) * kGridRows + (y0 + j % ny);
+        e0 = cell_off[c]; e1 = cell_off[c + 1];
+        for (int s = e0; s < e1; s++) {
           const int k = cell_idx[s];
           if (bCheckLevels) {
             if (oct[k] < minLevel) continue;
             if (maxLevel >= 0 && oct[k] > maxLevel) continue;
           }
-          const float distx = xy[2 * k] - x, disty = xy[2 * k + 1] - y;
-          if (fabsf(distx) < r && fabsf(disty) < r) {
-            if (FILL) out_idx[w++] = k;
-            n++;
-          }
+          if (fabsf(xy[2 * k] - x) < r && fabsf(xy[2 * k + 1] - y) < r) n++;
         }
       }
+      int incl = n;                                          // inclusive prefix over the 16 lanes of the group
+#pragma unroll
+      for (int d = 1; d < kQL; d <<= 1) { const int v = __shfl_up(incl, d, kQL); if (sub >= d) incl += v; }
+      const int chunk_total = __shfl(incl, kQL - 1, kQL);
+      if (FILL && n) {
+        int w = carry + incl - n;
+        for (int s = e0; s < e1; s++) {
+          const int k = cell_idx[s];
+          if (bCheckLevels) {
+            if (oct[k] < minLevel) continue;
+            if (maxLevel >= 0 && oct[k] > maxLevel) continue;
+          }
+          if (fabsf(xy[2 * k] - x) < r && fabsf(xy[2 * k + 1] - y) < r) out_idx[w++] = k;
+        }
+      }
+      carry += chunk_total;
+      total += chunk_total;
+    }
   }
-  if (!FILL) cnt[i] = n;
+  if (!FILL && sub == 0) cnt[i] = total;
 }
 
 // exclusive scan of the per-query counts (one workgroup; Q is at most a few 10^4)
@@ -271,7 +295,7 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, h, 20 * wQ, hipMemcpyHostToDevice, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_qdesc, h + 20 * wQ, 32 * wQ, hipMemcpyHostToDevice, ctx->stream));
   WinQ wq{d_q, d_q + wQ, d_q + 2 * wQ, (const int*)(d_q + 3 * wQ), (const int*)(d_q + 4 * wQ)};
-  const int nb = ccm_div_up(Q, 128);
+  const int nb = ccm_div_up((int64_t)Q * kQL, 128);
   hipLaunchKernelGGL(frame_window_kernel<0>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx, d_cnt,
                      (const int*)nullptr, (int*)nullptr, 0);
   hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, Q, d_off);
