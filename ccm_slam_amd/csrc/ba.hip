@@ -1813,7 +1813,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
     // ---- PCG ----
-    const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-10;
+    const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-8;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
     int flags[4] = {0, 0, 0, 0};
     if (d.Cp <= kSmallMaxCp) {

@@ -217,7 +217,7 @@ typedef struct {
 typedef struct {
   int32_t max_iters;         /* optimizer.optimize(n)                                    */
   int32_t pcg_max_iters;     /* <=0: default 1000                                        */
-  double  pcg_rel_tol;       /* <=0: default 1e-10 (on sqrt(r.z / r0.z0))                */
+  double  pcg_rel_tol;       /* <=0: default 1e-8 on sqrt(r.z / r0.z0); see DESIGN.md 4.1  */
   double  lambda_init;       /* <=0: tau * max diag(H), tau = 1e-5 (levenberg.cpp:166-180) */
   int32_t verbose;
 } ccm_ba_options;
