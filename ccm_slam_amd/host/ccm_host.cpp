@@ -606,6 +606,49 @@ int ORBmatcher::ProjectedSearch(const FrameView& KF, const float* invLevelSigma2
   return nacc;
 }
 
+// ProjectedSearch with the keyframe's grid, candidate lists and distances produced on the device: the level window
+// [lvl-1, lvl] is applied by the window kernel, the chi2 gate (Fuse, :930-938) during the ordered resolution
+int ORBmatcher::ProjectedSearch(FrameGridDev& grid, const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate,
+                                int distThreshold, int32_t* matched, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
+  bestIdx.assign(P.n, -1); bestDist.assign(P.n, INT32_MAX);
+  std::vector<int32_t> q_of, minl, maxl;
+  std::vector<float> u, v, r;
+  std::vector<uint8_t> qdesc;
+  for (int i = 0; i < P.n; i++) {
+    if (!P.valid[i]) continue;
+    const int lvl = P.level[i];
+    q_of.push_back(i);
+    u.push_back(P.u[i]); v.push_back(P.v[i]); r.push_back(th * KF.mvScaleFactors[lvl]);
+    minl.push_back(lvl - 1); maxl.push_back(lvl);
+    qdesc.insert(qdesc.end(), P.desc + (size_t)i * 32, P.desc + (size_t)i * 32 + 32);
+  }
+  if (q_of.empty()) return 0;
+  std::vector<int32_t> off, idx;
+  std::vector<uint16_t> dist;
+  deviceWindows(grid, u, v, r, minl, maxl, qdesc, off, idx, dist);
+  int nacc = 0;
+  for (size_t q = 0; q < q_of.size(); q++) {
+    const int i = q_of[q];
+    int bd = INT32_MAX, bi = -1;
+    for (int s = off[q]; s < off[q + 1]; s++) {
+      const int k = idx[s];
+      if (chi2Gate) {
+        const float ex = P.u[i] - KF.mvKeysUn[k].x, ey = P.v[i] - KF.mvKeysUn[k].y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * invLevelSigma2[KF.mvKeysUn[k].octave] > 5.99) continue;
+      }
+      if (matched && matched[k] >= 0) continue;     // claims made earlier in this loop are honoured
+      if (dist[s] < bd) { bd = dist[s]; bi = k; }
+    }
+    if (bd <= distThreshold) {
+      bestIdx[i] = bi; bestDist[i] = bd;
+      if (matched && claim && !(P.noClaim && P.noClaim[i])) matched[bi] = i;
+      nacc++;
+    }
+  }
+  return nacc;
+}
+
 int ORBmatcher::MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12) {
   int nFound = 0;
   matches12.assign(vnMatch1.size(), -1);
@@ -918,6 +961,32 @@ extern "C" int ccmh_projected_window_search(int device, const float* kx, const f
     cslam::ORBmatcher m(ctx);
     std::vector<int32_t> bi, bd;
     const int n = m.ProjectedSearch(F, inv_sigma2, P, th, chi2_gate != 0, dist_threshold, matched, claim != 0, bi, bd);
+    std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
+    std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+
+// the same search through the device grid (bounds must be the plain image rectangle: 0, 0, maxX, maxY)
+extern "C" int ccmh_projected_window_search_dev(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float maxX,
+                                                float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts, const uint8_t* valid,
+                                                const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, float th, int chi2_gate,
+                                                int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx,
+                                                int32_t* best_dist) {
+  try {
+    cslam::HipContext ctx(device);
+    auto kps = mk_keys(kx, ky, oct, nullptr, N);
+    const float K[4] = {1.f, 1.f, 0.f, 0.f};
+    cslam::FrameGridDev grid(ctx, K, nullptr, 0, (int)maxX, (int)maxY);
+    std::vector<cslam::KeyPoint> keysUn;
+    grid.SetKeyPoints(kps, kdesc, keysUn);
+    std::vector<int32_t> dummy(N, -1);
+    cslam::FrameView F; F.N = N; F.mvKeysUn = keysUn.data(); F.mDescriptors = kdesc; F.mnMinX = grid.mnMinX; F.mnMinY = grid.mnMinY; F.mnMaxX = grid.mnMaxX;
+    F.mnMaxY = grid.mnMaxY; F.mvScaleFactors = scale_factors; F.mvpMapPoints = dummy.data();
+    cslam::ORBmatcher::ProjectedPoints P; P.n = n_pts; P.valid = valid; P.u = u; P.v = v; P.level = level; P.desc = pdesc; P.noClaim = no_claim;
+    cslam::ORBmatcher m(ctx);
+    std::vector<int32_t> bi, bd;
+    const int n = m.ProjectedSearch(grid, F, inv_sigma2, P, th, chi2_gate != 0, dist_threshold, matched, claim != 0, bi, bd);
     std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
     std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
     return n;

@@ -149,6 +149,8 @@ class ORBmatcher {
                            const int32_t* level = nullptr; const uint8_t* desc = nullptr; const uint8_t* noClaim = nullptr; };
   int ProjectedSearch(const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate, int distThreshold,
                       int32_t* matched /* nullable in/out [KF.N] */, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
+  int ProjectedSearch(FrameGridDev& grid, const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate,
+                      int distThreshold, int32_t* matched, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
   // SearchBySim3's agreement step (:1318-1345) on the two directional results
   static int MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12);
  private:

@@ -227,6 +227,15 @@ def test_projected_window_search(hostlib, oracle_lib, name, chi2_gate, thr, use_
     assert np.array_equal(gbi, ebi) and np.array_equal(gbd, ebd)
     if use_matched:
         assert np.array_equal(gm, em)
+    # same call with the keyframe grid, candidate lists and distances produced on the device
+    gbi2 = np.zeros(n_pts, np.int32); gbd2 = np.zeros(n_pts, np.int32)
+    gm2 = matched0.copy()
+    n2 = hostlib.ccmh_projected_window_search_dev(0, _p(c(kps["x"])), _p(c(kps["y"])), _p(c(kps["octave"])), _p(desc), N, C.c_float(752.0), C.c_float(480.0),
+                                                  _p(sf), _p(is2), n_pts, _p(valid), _p(u), _p(v), _p(level), _p(pdesc), C.c_float(th), chi2_gate, thr,
+                                                  _p(gm2) if use_matched else None, claim, _p(no_claim), _p(gbi2), _p(gbd2))
+    assert n2 == exp_n and np.array_equal(gbi2, ebi) and np.array_equal(gbd2, ebd)
+    if use_matched:
+        assert np.array_equal(gm2, em)
 
 
 def test_vocabulary_transform_class(hostlib, oracle_lib):
