@@ -721,13 +721,24 @@ __device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_st
 // the current epoch's key; the xor check also rejects torn 16-byte reads.  The values are then summed in a fixed order,
 // so every workgroup obtains bit-identical totals.  All cross-workgroup data (z, p, q, slots) moves with device-coherent
 // accesses, so the only ordering needed is: drain this workgroup's stores, meet, publish.
-__device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg, double mine, unsigned long long epoch, unsigned* abort_flag,
-                                              double* red /* [kPersWaves] */, double* total) {
+__device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg, double v_thread, bool force_nan, unsigned long long epoch,
+                                              unsigned* abort_flag, double* red /* [kPersWaves + 1] */, double* total) {
+  // v_thread: this thread's share of the workgroup's partial.  The workgroup sum, the publish and the grid-wide sum share
+  // two block barriers: wave sums -> LDS, (drain stores, barrier), thread 0 adds the 16 wave sums in a fixed order and
+  // publishes, wave 0 polls, (barrier), everybody reads the grid total from red[kPersWaves].
   const int t = threadIdx.x;
   const unsigned long long key = 0x9E3779B97F4A7C15ull * epoch;
+  {
+    const double ws = wave_sum(v_thread);
+    if ((t & (kWave - 1)) == 0) red[t / kWave] = ws;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) {
+    double mine = 0;
+#pragma unroll
+    for (int w = 0; w < kPersWaves; w++) mine += red[w];
+    if (force_nan) mine = __longlong_as_double(0x7ff8000000000000ll);
     const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
     __hip_atomic_store(slots + 2 * blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(slots + 2 * blockIdx.x + 1, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -754,12 +765,13 @@ __device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg
       __builtin_amdgcn_s_sleep(2);
     }
     v = wave_sum(v);
-    if (t == 0) red[0] = v;
+    if (t == 0) red[kPersWaves] = v;
   }
   __syncthreads();
   alive = poll_state != 0;
-  *total = pers_uniform(red[0]);
-  __syncthreads();   // red is reused by the caller's block sums
+  *total = pers_uniform(red[kPersWaves]);
+  // no trailing barrier: red[0..15] is rewritten only after every thread has passed the barrier above, red[16] and
+  // poll_state only after the first barrier of the next exchange
   return alive;
 }
 
@@ -968,7 +980,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   double* zs = qs + N;                     // z
   double* zpart = zs + N;                  // [8][96]
   double* red = zpart + 8 * N;             // [16]
-  int* ibuf = reinterpret_cast<int*>(red + kPersWaves);   // [0]=ok flag of the barrier, [1]=bad pivot
+  int* ibuf = reinterpret_cast<int*>(red + kPersWaves + 2);   // [0]=ok flag of the barrier, [1]=bad pivot
   const int t = threadIdx.x, lane = t & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(t / kWave);
   const int nwg = gridDim.x;               // padded to a multiple of 8
@@ -1068,26 +1080,14 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     }
     return rz;
   };
-  auto block_total = [&](double v) {   // fixed-order workgroup sum, valid in every thread
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) red[wv] = v;
-    __syncthreads();
-    double sv = 0;
-#pragma unroll
-    for (int w = 0; w < kPersWaves; w++) sv += red[w];
-    return sv;
-  };
-  double rz_init = 0;
-  {
-    double rz = apply_W();
-    if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
-    rz_init = block_total(rz);
-    if (has && ibuf[1]) rz_init = __longlong_as_double(0x7ff8000000000000ll);   // bad pivot -> NaN -> grid-wide failure
-  }
   int fail = 0, k = 0;
   double rz = 0;
-  bool alive = pers_exchange(slots_rz, nwg, rz_init, ++epoch, a.bar + 1, red, &rz);
+  bool alive;
+  {
+    const double rz_t = apply_W();
+    if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
+    alive = pers_exchange(slots_rz, nwg, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz);   // bad pivot -> NaN -> grid-wide failure
+  }
   const double rz0 = rz;
   const double thresh = a.rel_tol * a.rel_tol;
   double rz_prev = rz;
@@ -1138,10 +1138,9 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       coh_store(d.q + 6 * (size_t)o0 + t, qv);     // the partner unit needs it for its copy of r
       pq_t = pi * qv;
     }
-    const double pqt = block_total(pq_t);
     PERS_TICK(1)
     double pq = 0;
-    alive = pers_exchange(slots_pq, nwg, pqt, ++epoch, a.bar + 1, red, &pq);
+    alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq);
     PERS_TICK(2)
     if (!alive) { fail = 1; break; }
     const double q_partner = (t < m && !(t >= ob && t < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + t) : 0.0;
@@ -1151,10 +1150,10 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     if (t < mo) xs[t] += alpha * ps[t];
     if (t < m) rc[t] -= alpha * ((t >= ob && t < ob + mo) ? qs[t] : q_partner);
     __syncthreads();
-    const double rzt = block_total(apply_W());
+    const double rz_t2 = apply_W();
     PERS_TICK(4)
     rz_prev = rz;
-    alive = pers_exchange(slots_rz, nwg, rzt, ++epoch, a.bar + 1, red, &rz);
+    alive = pers_exchange(slots_rz, nwg, rz_t2, false, ++epoch, a.bar + 1, red, &rz);
     PERS_TICK(5)
     if (!alive) { fail = 1; break; }
     PERS_TICK(6)
@@ -1166,7 +1165,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 }
 
 static inline size_t pers_lds_bytes() {
-  return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves) * sizeof(double) + 16 + 14 * sizeof(long long);
+  return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves + 2) * sizeof(double) + 16 + 14 * sizeof(long long);
 }
 
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
