@@ -62,6 +62,7 @@ int ccm_pool_get(ccm_ctx* ctx, size_t bytes, void** out, size_t* actual);
 void ccm_pool_put(ccm_ctx* ctx, void* p, size_t actual);
 // dense_chol.hip: SPD solve on the device (N multiple of 64, padding = identity), see the definition for the contract
 int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info);
+int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv, double* d_X, double* d_Ainv, int* d_info);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 static inline int ccm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -148,6 +148,77 @@ __global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, 
   }
 }
 
+// load a tile transposed: dst[c][r] = src[r][c]
+__device__ __forceinline__ void load_tile_t(double* dst, const double* src, int ld_src) {
+  for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[c * LD + r] = src[(size_t)r * ld_src + c]; }
+}
+__device__ __forceinline__ void store_acc(double* dst, int ld, const v4d acc[4], int wave, int lane, double sign) {
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) dst[(size_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * s + (lane & 15)] = sign * acc[s][r];
+}
+
+// X = L^-1 (lower triangular, tiles in X's lower triangle): workgroup j owns block column j and walks down it,
+// X_jj = Li_jj, X_ij = -Li_ii * sum_{k=j}^{i-1} L_ik X_kj   (every X_kj it needs is its own earlier output)
+__global__ __launch_bounds__(kTPB) void chol_tri_inverse(const double* A, int N, const double* Linv_all, double* X) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int j = blockIdx.x, T = N / NB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int e = threadIdx.x; e < NB * NB; e += kTPB) X[((size_t)j * NB + e / NB) * N + (size_t)j * NB + e % NB] = Linv_all[(size_t)j * NB * NB + e];
+  __threadfence_block();
+  __syncthreads();
+  for (int i = j + 1; i < T; i++) {
+    v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int k = j; k < i; k++) {
+      load_tile(As, A + ((size_t)i * NB) * N + (size_t)k * NB, N);                 // L_ik
+      load_tile_t(Bs, X + ((size_t)k * NB) * N + (size_t)j * NB, N);               // X_kj^T  => As * Bs^T = L_ik X_kj
+      __syncthreads();
+      tile_abt(As, Bs, acc, wave, lane);
+      __syncthreads();
+    }
+    // Bs <- acc^T (so that Li_ii * acc = As * Bs^T), As <- Li_ii
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Bs[(16 * s + (lane & 15)) * LD + 16 * wave + (lane >> 4) + 4 * r] = acc[s][r];
+    load_tile(As, Linv_all + (size_t)i * NB * NB, NB);
+    __syncthreads();
+    v4d out[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    tile_abt(As, Bs, out, wave, lane);
+    store_acc(X + ((size_t)i * NB) * N + (size_t)j * NB, N, out, wave, lane, -1.0);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// Ainv = X^T X: tile (p, q), p >= q: sum_{k >= p} X_kp^T X_kq ; mirrored into (q, p)
+__global__ __launch_bounds__(kTPB) void chol_xtx(const double* X, int N, double* Ainv) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int T = N / NB;
+  const int pi = blockIdx.x;
+  int p = (int)((sqrtf(8.0f * (float)pi + 1.0f) - 1.0f) * 0.5f);
+  while (p * (p + 1) / 2 > pi) p--;
+  while ((p + 1) * (p + 2) / 2 <= pi) p++;
+  const int q = pi - p * (p + 1) / 2;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int k = p; k < T; k++) {
+    load_tile_t(As, X + ((size_t)k * NB) * N + (size_t)p * NB, N);   // X_kp^T
+    load_tile_t(Bs, X + ((size_t)k * NB) * N + (size_t)q * NB, N);   // X_kq^T  => As * Bs^T = X_kp^T X_kq
+    __syncthreads();
+    tile_abt(As, Bs, acc, wave, lane);
+    __syncthreads();
+  }
+  store_acc(Ainv + ((size_t)p * NB) * N + (size_t)q * NB, N, acc, wave, lane, 1.0);
+  if (p != q) {
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) Ainv[((size_t)q * NB + 16 * s + (lane & 15)) * N + (size_t)p * NB + 16 * wave + (lane >> 4) + 4 * r] = acc[s][r];
+  }
+}
+
 }  // namespace
 
 // Solves A x = b for a symmetric positive definite A.  d_A: N x N row-major with N = n rounded up to 64 (ccm_dense_padded)
@@ -202,5 +273,54 @@ extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double
     for (int i = 0; i < n; i++) x[i] = bp[i];
   }
   hipFree(dA); hipFree(db); hipFree(dl); hipFree(di);
+  return rc;
+}
+
+// Explicit inverse of a symmetric positive definite matrix (same layout contract as ccm_dense_chol_solve_dev; d_A is
+// destroyed, d_X is N x N scratch whose lower tiles receive L^-1, d_Ainv receives the full symmetric inverse).
+int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv, double* d_X, double* d_Ainv, int* d_info) {
+  if (N % NB) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: N must be a multiple of 64");
+  const int T = N / NB;
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
+  for (int j = 0; j < T; j++) {
+    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(kTPB), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    const int rem = T - j - 1;
+    if (rem > 0) {
+      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv);
+      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j);
+    }
+  }
+  hipLaunchKernelGGL(chol_tri_inverse, dim3(T), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X);
+  hipLaunchKernelGGL(chol_xtx, dim3(T * (T + 1) / 2), dim3(kTPB), 0, ctx->stream, (const double*)d_X, N, d_Ainv);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+// Test hook: inverse of a host SPD matrix (n x n row-major) through the tile kernels above.
+extern "C" int ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info) {
+  if (!ctx || !A || !Ainv || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_dense_inverse: bad args");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int N = ((n + NB - 1) / NB) * NB;
+  std::vector<double> Ap((size_t)N * N, 0.0);
+  for (int i = 0; i < N; i++) {
+    if (i < n) { for (int c = 0; c < n; c++) Ap[(size_t)i * N + c] = A[(size_t)i * n + c]; }
+    else Ap[(size_t)i * N + i] = 1.0;
+  }
+  double *dA = nullptr, *dl = nullptr, *dX = nullptr, *dI = nullptr; int* di = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&dA, Ap.size() * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&dX, Ap.size() * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&dI, Ap.size() * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&dl, (size_t)N * NB * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&di, sizeof(int)));
+  hipMemcpyAsync(dA, Ap.data(), Ap.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  hipMemsetAsync(dX, 0, Ap.size() * sizeof(double), ctx->stream);
+  int rc = ccm_dense_chol_inverse_dev(ctx, dA, N, dl, dX, dI, di);
+  if (rc == CCM_OK) {
+    hipMemcpyAsync(Ap.data(), dI, Ap.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(info, di, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_debug_dense_inverse: sync");
+    for (int i = 0; i < n; i++) for (int c = 0; c < n; c++) Ainv[(size_t)i * n + c] = Ap[(size_t)i * N + c];
+  }
+  hipFree(dA); hipFree(dX); hipFree(dI); hipFree(dl); hipFree(di);
   return rc;
 }

@@ -186,3 +186,11 @@ def debug_dense_solve(ctx: Context, A, b):
     x = np.zeros_like(b); info = C.c_int(0)
     check(lib().ccm_debug_dense_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info)), ctx.handle)
     return x, info.value
+
+
+def debug_dense_inverse(ctx: Context, A):
+    """Test hook: explicit SPD inverse through the tile kernels of dense_chol.hip (ccm_debug_dense_inverse)."""
+    A = np.ascontiguousarray(A, np.float64)
+    out = np.zeros_like(A); info = C.c_int(0)
+    check(lib().ccm_debug_dense_inverse(ctx.handle, C.c_void_p(_vp(A)), int(A.shape[0]), C.c_void_p(_vp(out)), C.byref(info)), ctx.handle)
+    return out, info.value

@@ -314,6 +314,8 @@ int  ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3 /* n_vert x 
 /* test hook for the dense f64 Cholesky (MFMA tiles) behind ccm_pose_graph_optimize: solves A x = b for a host matrix
  * (n x n row-major, symmetric positive definite); *info = 0 or (first non-positive pivot + 1). */
 int  ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info);
+/* same machinery, explicit inverse (used for the coarse level of the BA preconditioner) */
+int  ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info);
 
 #ifdef __cplusplus
 }

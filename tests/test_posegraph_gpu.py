@@ -75,3 +75,14 @@ def test_dense_cholesky_reports_a_non_positive_pivot(ctx):
     A = np.eye(70); A[40, 40] = -1.0
     x, info = optimizer.debug_dense_solve(ctx, A, np.ones(70))
     assert info == 41
+
+
+@pytest.mark.parametrize("n", [30, 64, 200, 375])
+def test_dense_inverse_tiles(ctx, n):
+    rng = np.random.default_rng(n)
+    M = rng.normal(size=(n, n))
+    A = M @ M.T + n * np.eye(n)
+    Ai, info = optimizer.debug_dense_inverse(ctx, A)
+    assert info == 0
+    assert np.abs(Ai @ A - np.eye(n)).max() < 1e-10
+    assert np.abs(Ai - Ai.T).max() == 0.0      # mirrored tiles: exactly symmetric
