@@ -666,6 +666,79 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
+// ---- coarse level of the two-level preconditioner ------------------------------------------------------------------
+// Cluster block-Jacobi cannot see the smooth error modes of a long trajectory (rigid drifts of whole map sections), so the
+// CG iteration count grows with the map.  Coarse space: one rigid-body twist (6 unknowns) per aggregate of kAgg
+// consecutive cameras, prolongated to camera k by the adjoint P_k = Ad(T_cw,k) (a world-frame twist xi moves camera k by
+// the left perturbation Ad(T_cw) xi).  Ac = P^T (S + lambda I) P is dense and small (6 * Cp / kAgg unknowns, 375 for the
+// 4-agent map); its explicit inverse is formed once per LM trial by the tile kernels of dense_chol.hip and the persistent
+// PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Offline study on 600-keyframe systems (same matrices): 296 -> 75 CG
+// iterations at lambda 0.3, 69 -> 38 at lambda 30, independent of the map size.
+constexpr int kAgg = 32;   // cameras per aggregate = 2 clusters = 4 persistent units
+
+__global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.Cp) return;
+  const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)d.slot_cam[i]);
+  double R[9];
+  ba_q_to_R(T, R);
+  const double t[3] = {T.tx, T.ty, T.tz};
+  // [t]x R
+  double tR[9];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    tR[0 * 3 + c] = -t[2] * R[3 + c] + t[1] * R[6 + c];
+    tR[1 * 3 + c] = t[2] * R[0 + c] - t[0] * R[6 + c];
+    tR[2 * 3 + c] = -t[1] * R[0 + c] + t[0] * R[3 + c];
+  }
+  double* P = Pm + 36 * (size_t)i;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      P[r * 6 + c] = R[r * 3 + c]; P[r * 6 + 3 + c] = 0.0;
+      P[(3 + r) * 6 + c] = tR[r * 3 + c]; P[(3 + r) * 6 + 3 + c] = R[r * 3 + c];
+    }
+}
+
+// one wave per coarse block (a <= a'): Ac_aa' = sum over the S blocks (i in a, j in a') of P_i^T (S_ij [+ lambda I]) P_j; an
+// off-diagonal S block inside one aggregate also contributes its transpose.  Fixed entry order => deterministic.
+__global__ __launch_bounds__(kTPB) void ba_coarse_assemble(BaDev d, const double* Pm, const int* cb_off, const int* cb_ent, const int* cb_ab, int n_cb,
+                                                           const int* blk_i, const int* blk_j, double lambda, double* Ac, int Nc) {
+  const int w = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  if (w >= n_cb) return;
+  const int a = cb_ab[2 * w], b = cb_ab[2 * w + 1];
+  const int r = (lane < 36) ? lane / 6 : 0, c = (lane < 36) ? lane % 6 : 0;
+  double acc = 0;
+  for (int s = cb_off[w]; s < cb_off[w + 1]; s++) {
+    const int code = cb_ent[s];
+    const int blk = code >> 1, both = code & 1;
+    const int i = blk_i[blk], j = blk_j[blk];
+    const double* B = d.S + 36 * (size_t)blk;
+    const double* Pi = Pm + 36 * (size_t)i;
+    const double* Pj = Pm + 36 * (size_t)j;
+    double m = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      double tq = 0;
+#pragma unroll
+      for (int p = 0; p < 6; p++) tq += Pi[p * 6 + r] * (B[p * 6 + q] + ((i == j && p == q) ? lambda : 0.0));
+      m += tq * Pj[q * 6 + c];
+    }
+    const double mt = __shfl(m, c * 6 + r, kWave);
+    acc += both ? (m + mt) : m;
+  }
+  if (lane < 36) {
+    Ac[(size_t)(6 * a + r) * Nc + 6 * b + c] = acc;
+    if (a != b) Ac[(size_t)(6 * b + c) * Nc + 6 * a + r] = acc;
+  }
+}
+__global__ void ba_coarse_pad(double* Ac, int nc, int Nc) {
+  const int i = nc + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Nc) Ac[(size_t)i * Nc + i] = 1.0;
+}
+
 // ---- persistent PCG: the WHOLE solve of one LM trial in one cooperative launch ---------------------------------
 // The multi-kernel iteration above costs two launches (~22 us on gba_c4) for ~15 MB of traffic: launch gaps and the
 // dependent index -> block -> vector chains dominate, not HBM.  Here one 16-wave workgroup OWNS one preconditioner
@@ -1394,6 +1467,10 @@ struct ccm_ba {
   unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
   int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr;
   unsigned long long pers_launch = 0;
+  // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
+  int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
+  double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
+  int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
   double* d_pt_full = nullptr; int* d_own_slot = nullptr;
   double* d_hpp_full = nullptr;
   double ms_setup = 0;
@@ -1667,6 +1744,36 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_loc, &ba->d_pers_loc)) return fail(rc2);
       ba->pers_grid = grid;
+      // coarse level: aggregates of kAgg cameras; block lists of Ac = P^T S P
+      if (!getenv("CCM_BA_NO_COARSE")) {
+        const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
+        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && 4 * na <= grid) {
+          std::map<std::pair<int, int>, std::vector<int>> cb;
+          for (int i = 0; i < Cp; i++) cb[{i / kAgg, i / kAgg}].push_back(i * 2);
+          std::vector<int> bi(Cp + nOff), bj(Cp + nOff);
+          for (int i = 0; i < Cp; i++) { bi[i] = i; bj[i] = i; }
+          for (int b = 0; b < nOff; b++) {
+            const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
+            bi[Cp + b] = i; bj[Cp + b] = j;
+            const int a = i / kAgg, a2 = j / kAgg;   // i < j => a <= a2
+            cb[{a, a2}].push_back((Cp + b) * 2 + (a == a2 ? 1 : 0));
+          }
+          std::vector<int> cb_off(1, 0), cb_ent, cb_ab;
+          for (auto& kv : cb) { cb_ab.push_back(kv.first.first); cb_ab.push_back(kv.first.second); cb_ent.insert(cb_ent.end(), kv.second.begin(), kv.second.end()); cb_off.push_back((int)cb_ent.size()); }
+          if (int rc2 = dev_upload(ba, cb_off, &ba->d_cb_off)) return fail(rc2);
+          if (int rc2 = dev_upload(ba, cb_ent, &ba->d_cb_ent)) return fail(rc2);
+          if (int rc2 = dev_upload(ba, cb_ab, &ba->d_cb_ab)) return fail(rc2);
+          if (int rc2 = dev_upload(ba, bi, &ba->d_blk_i)) return fail(rc2);
+          if (int rc2 = dev_upload(ba, bj, &ba->d_blk_j)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, 36 * (size_t)Cp, &ba->d_cP)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cA)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cX)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return fail(rc2);
+          if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return fail(rc2);
+          ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
+        }
+      }
     }
     (void)hipGetLastError();
   }
@@ -1780,6 +1887,21 @@ int max_diag(ccm_ba* ba, double* out) {
   RC(read_scalars(ba, s));
   *out = s[2];
   return CCM_OK;
+}
+
+// coarse operator of the current linearisation at this lambda and its explicit inverse (needs S of the trial)
+int coarse_build(ccm_ba* ba, double lambda) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  const int Nc = ba->coarse_Nc, nc = 6 * ba->coarse_na;
+  hipLaunchKernelGGL(ba_coarse_P, dim3(ccm_div_up(d.Cp, kTPB)), dim3(kTPB), 0, ctx->stream, d, ba->cur, ba->d_cP);
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, (size_t)Nc * Nc * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ccm_div_up(ba->coarse_ncb, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
+                     (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
+                     lambda, ba->d_cA, Nc);
+  if (Nc > nc) hipLaunchKernelGGL(ba_coarse_pad, dim3(1), dim3(64), 0, ctx->stream, ba->d_cA, nc, Nc);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return ccm_dense_chol_inverse_dev(ctx, ba->d_cA, Nc, ba->d_cLinv, ba->d_cX, ba->d_cAinv, ba->d_cinfo);
 }
 
 // one LM trial: solve with lambda, write trial state, return tempChi, scale, ok
@@ -1910,6 +2032,38 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
 // Test hook for the sharded path: this rank's PARTIAL reduced camera system [S blocks | b_schur] of the
 // current state at the given lambda, exactly the buffer lm_trial hands to the RCCL all-reduce, without the all-reduce.
 // Summing the downloads of all ranks' handles must reproduce the single-rank system (tests/test_ba_gpu.py).
+// Test hook: coarse operator Ac = P^T (S + lambda I) P of the current state and its inverse ([6 na]^2 each, row-major), plus
+// the prolongation blocks P_k ([Cp][36]).  *na = 0 when the coarse level is not in use for this problem.
+extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap) {
+  if (!ba || !na) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  *na = ba->coarse_na;
+  if (!ba->coarse_na || !Ac) return CCM_OK;
+  const size_t nc = 6 * (size_t)ba->coarse_na, Nc = (size_t)ba->coarse_Nc;
+  if (cap < nc * nc) return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_debug_coarse: buffer too small");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  RC(build_system(ba));
+  if (d.Lloc) hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
+  hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
+  if (d.nOff) hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+  // the inverse destroys d_cA: assemble twice
+  RC(coarse_build(ba, lambda));
+  std::vector<double> buf(Nc * Nc);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(buf.data(), ba->d_cAinv, buf.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (Ainv) for (size_t r = 0; r < nc; r++) for (size_t c = 0; c < nc; c++) Ainv[r * nc + c] = buf[r * Nc + c];
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, Nc * Nc * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ccm_div_up(ba->coarse_ncb, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
+                     (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
+                     lambda, ba->d_cA, (int)Nc);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(buf.data(), ba->d_cA, buf.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t r = 0; r < nc; r++) for (size_t c = 0; c < nc; c++) Ac[r * nc + c] = buf[r * Nc + c];
+  if (Pm) { CCM_HIP_CHECK(ctx, hipMemcpy(Pm, ba->d_cP, 36 * (size_t)d.Cp * sizeof(double), hipMemcpyDeviceToHost)); }
+  return CCM_OK;
+}
+
 extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count) {
   if (!ba || !count) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;

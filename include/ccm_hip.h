@@ -266,6 +266,10 @@ int  ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_
  * at the current state, i.e. the buffer the per-trial RCCL all-reduce sums; out == NULL only queries *count. */
 int  ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count);
 
+/* test hook: coarse level of the two-level PCG preconditioner at the current state: *na aggregates (0 = not in use), Ac and
+ * its inverse [6 na x 6 na], prolongation blocks P_k = Ad(T_cw,k) [n_free_cams x 36]; cap = doubles available in Ac / Ainv. */
+int  ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap);
+
 /* RCCL communicator for the sharded GBA.  id_bytes is an ncclUniqueId (128 bytes) produced by
  * ccm_comm_unique_id on rank 0 and broadcast by the launcher (bench.py uses torch.distributed). */
 int ccm_comm_unique_id(uint8_t id_bytes[128]);
