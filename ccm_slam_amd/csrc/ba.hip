@@ -776,6 +776,9 @@ struct PersArgs {
   const int* ucol;      // distinct columns of each cluster's rows, ascending
   const int* loc;       // [n_row_entries] position of the entry's column in its cluster's ucol list
   long long* dbg;       // optional [16] phase clocks of workgroup 0 (wall_clock64 ticks, 10 ns), accumulated over iterations
+  // coarse level (nullptr = cluster-Jacobi only): explicit inverse [Nc x Nc], prolongation blocks [Cp][36], aggregates
+  const double* Ainv; const double* Pm; int na, Nc;
+  unsigned long long* wslots;   // [gridDim.x][8]: wide exchange slots (scalar + the unit's 6 coarse components + check word)
 };
 
 // a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double in the PCG loop)
@@ -795,7 +798,8 @@ __device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_st
 // so every workgroup obtains bit-identical totals.  All cross-workgroup data (z, p, q, slots) moves with device-coherent
 // accesses, so the only ordering needed is: drain this workgroup's stores, meet, publish.
 __device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg, double v_thread, bool force_nan, unsigned long long epoch,
-                                              unsigned* abort_flag, double* red /* [kPersWaves + 1] */, double* total) {
+                                              unsigned* abort_flag, double* red /* [kPersWaves + 1] */, double* total,
+                                              int unit = -1, unsigned long long* wslots = nullptr, const double* cpart = nullptr, double* gath = nullptr) {
   // v_thread: this thread's share of the workgroup's partial.  The workgroup sum, the publish and the grid-wide sum share
   // two block barriers: wave sums -> LDS, (drain stores, barrier), thread 0 adds the 16 wave sums in a fixed order and
   // publishes, wave 0 polls, (barrier), everybody reads the grid total from red[kPersWaves].
@@ -813,8 +817,20 @@ __device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg
     for (int w = 0; w < kPersWaves; w++) mine += red[w];
     if (force_nan) mine = __longlong_as_double(0x7ff8000000000000ll);
     const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
-    __hip_atomic_store(slots + 2 * blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(slots + 2 * blockIdx.x + 1, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wslots) {   // wide slot of logical unit `unit`: [scalar, 6 coarse components, key ^ xor of the seven]
+      unsigned long long chk = key ^ bits;
+      __hip_atomic_store(wslots + 8 * unit, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const unsigned long long cb = (unsigned long long)__double_as_longlong(cpart[c]);
+        chk ^= cb;
+        __hip_atomic_store(wslots + 8 * unit + 1 + c, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_store(wslots + 8 * unit + 7, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(slots + 2 * blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slots + 2 * blockIdx.x + 1, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // only wave 0 polls (4 slots per lane): 16x fewer coherent loads in flight than polling with every thread, which
   // measurably slowed the workgroups that were still computing
@@ -825,6 +841,19 @@ __device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg
     for (long spins = 0;; spins++) {
       bool ok = true;
       v = 0;
+      if (wslots) {
+        for (int i = t; i < nwg; i += kWave) {
+          unsigned long long w[8], chk = 0;
+#pragma unroll
+          for (int c = 0; c < 8; c++) { w[c] = __hip_atomic_load(wslots + 8 * i + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); chk ^= w[c]; }
+          if (chk != key) ok = false;
+          else {
+            v += __longlong_as_double((long long)w[0]);
+#pragma unroll
+            for (int c = 0; c < 6; c++) gath[6 * i + c] = __longlong_as_double((long long)w[1 + c]);
+          }
+        }
+      } else
       for (int i = t; i < nwg; i += kWave) {
         const unsigned long long b0 = __hip_atomic_load(slots + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long b1 = __hip_atomic_load(slots + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1081,6 +1110,46 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   const bool timing = a.dbg != nullptr && blockIdx.x == 0 && t == 0;
   if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
   pers_factor_cluster(A, Li, ibuf, d.row_off, d.row_col, d.row_blk, d.S, s0, s1, lambda, has, tacc, timing);
+  // keep only the unit's own 48 rows of W, transposed (WT[col][row]: conflict-free for the mat-vec); the other half of the
+  // A region then holds the coarse level: Ac^-1 rows of the unit's aggregate | coarse residual | gathered unit parts | own P_k
+  {
+    double wreg[5];
+    int nw = 0;
+    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) wreg[nw] = A[(e / (N / 2)) * N + ob + e % (N / 2)];
+    __syncthreads();
+    nw = 0;
+    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) A[e] = wreg[nw];
+  }
+  const bool coarse = a.Ainv != nullptr;
+  const int Nc = a.Nc, nca = 6 * a.na;
+  double* ainv_l = A + N * (N / 2);          // [6][Nc]
+  double* rco = ainv_l + 6 * Nc;             // [Nc]
+  double* gath = rco + Nc;                   // [6 * nwg]
+  double* pown = gath + 6 * nwg;             // [8][36]
+  double* ypart = pown + 8 * 36;             // [4][6]
+  double* cpart = ypart + 24;                // [6]
+  const int agg = c / (kAgg / kClu);         // aggregate of the unit's cluster
+  if (coarse) {
+    for (int e = t; e < 6 * Nc; e += kPersTPB) ainv_l[e] = has ? a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0;
+    for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;
+    for (int e = t; e < 8 * 36; e += kPersTPB) pown[e] = (e / 36 < nown) ? a.Pm[36 * (size_t)o0 + e] : 0.0;
+    if (t < 6) cpart[t] = 0.0;
+  }
+  __syncthreads();
+  // unit part of the coarse restriction P^T v for the own rows: wave 0, lane = (camera, component)
+  auto coarse_restrict = [&](const double* vec /* LDS, own 48 entries */) {
+    if (wv == 0) {
+      const int kk = lane / 6, rr = lane % 6;
+      const double val = (lane < mo) ? vec[lane] : 0.0;
+      double out[6];
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) out[cc] = wave_sum((lane < 48) ? pown[kk * 36 + rr * 6 + cc] * val : 0.0);
+      if (lane == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) cpart[cc] = out[cc];
+      }
+    }
+  };
   // PCG start: x = 0, r = bs, z = W r, p_{-1} = 0
   if (t < N) { xs[t] = 0; ps[t] = 0; qs[t] = 0; zs[t] = 0; rc[t] = (t < m) ? d.bs[6 * (size_t)s0 + t] : 0.0; }   // xs/ps/zs: own rows; rc/qs: cluster
   __syncthreads();
@@ -1128,7 +1197,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     }
     e_tail = e0 + half * 8 + g + 16 * kPersRegEnt;
   }
-  auto apply_W = [&]() {          // z(own rows) = W[own rows, :] rc; publishes them; returns this thread's share of r.z
+  auto apply_W = [&]() {          // z(own rows) = W[own rows, :] rc (+ coarse correction); publishes them; returns this thread's share of r.z
     {
       const int row = t % (N / 2), prt = t / (N / 2);       // 48 rows x 16 column parts (6 columns each) = 768 threads
       if (prt < 16) {
@@ -1136,9 +1205,19 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
         if (row < mo) {
           const int c0 = prt * 6;
 #pragma unroll
-          for (int col = 0; col < 6; col++) sv += A[(c0 + col) * N + ob + row] * rc[c0 + col];   // W symmetric: column access
+          for (int col = 0; col < 6; col++) sv += A[(c0 + col) * (N / 2) + row] * rc[c0 + col];
         }
         zpart[prt * (N / 2) + row] = sv;
+      } else if (coarse) {                                  // the last 4 waves: y = Ac^-1[aggregate rows] * coarse residual
+        const int tt = t - 16 * (N / 2);
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = tt; j < nca; j += kPersTPB - 16 * (N / 2)) {
+          const double rj = rco[j];
+#pragma unroll
+          for (int r6 = 0; r6 < 6; r6++) acc[r6] += ainv_l[r6 * Nc + j] * rj;
+        }
+#pragma unroll
+        for (int r6 = 0; r6 < 6; r6++) { const double ws = wave_sum(acc[r6]); if (lane == 0) ypart[(wv - 12) * 6 + r6] = ws; }
       }
     }
     __syncthreads();
@@ -1147,6 +1226,11 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       double z = zpart[t];
 #pragma unroll
       for (int q = 1; q < 16; q++) z += zpart[q * (N / 2) + t];
+      if (coarse) {
+        const int kk = t / 6, rr = t % 6;
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * (((ypart[cc] + ypart[6 + cc]) + ypart[12 + cc]) + ypart[18 + cc]);
+      }
       zs[t] = z;
       coh_store(d.z + 6 * (size_t)o0 + t, z);
       rz = rc[ob + t] * z;
@@ -1155,11 +1239,28 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   };
   int fail = 0, k = 0;
   double rz = 0;
-  bool alive;
+  bool alive = true;
+  auto coarse_accumulate = [&](double scale) {   // coarse residual += scale * (gathered unit parts summed per aggregate, fixed order)
+    if (t < nca) {
+      const int aa = t / 6, cc = t % 6;
+      double sgm = 0;
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++) { const int uu = 4 * aa + mm; if (uu < nwg) sgm += gath[6 * uu + cc]; }
+      rco[t] += scale * sgm;
+    }
+  };
+  if (coarse) {   // coarse residual of r0 = b: one extra exchange before the first preconditioner application
+    coarse_restrict(rc + ob);
+    double dummy = 0;
+    alive = pers_exchange(slots_rz, nwg, 0.0, false, ++epoch, a.bar + 1, red, &dummy, u, a.wslots, cpart, gath);
+    coarse_accumulate(1.0);
+    __syncthreads();
+  }
   {
     const double rz_t = apply_W();
     if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
-    alive = pers_exchange(slots_rz, nwg, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz);   // bad pivot -> NaN -> grid-wide failure
+    const bool alive2 = pers_exchange(slots_rz, nwg, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz);   // bad pivot -> NaN -> grid-wide failure
+    alive = alive && alive2;
   }
   const double rz0 = rz;
   const double thresh = a.rel_tol * a.rel_tol;
@@ -1211,9 +1312,11 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       coh_store(d.q + 6 * (size_t)o0 + t, qv);     // the partner unit needs it for its copy of r
       pq_t = pi * qv;
     }
+    if (coarse) { __syncthreads(); coarse_restrict(qs + ob); }
     PERS_TICK(1)
     double pq = 0;
-    alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq);
+    if (coarse) alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq, u, a.wslots, cpart, gath);
+    else alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq);
     PERS_TICK(2)
     if (!alive) { fail = 1; break; }
     const double q_partner = (t < m && !(t >= ob && t < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + t) : 0.0;
@@ -1222,6 +1325,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     const double alpha = pers_uniform(rz / pq);
     if (t < mo) xs[t] += alpha * ps[t];
     if (t < m) rc[t] -= alpha * ((t >= ob && t < ob + mo) ? qs[t] : q_partner);
+    if (coarse) coarse_accumulate(-alpha);        // P^T r follows the recurrence of r: no second gather per iteration
     __syncthreads();
     const double rz_t2 = apply_W();
     PERS_TICK(4)
@@ -1470,6 +1574,7 @@ struct ccm_ba {
   // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
   int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
+  unsigned long long* d_wslots = nullptr;
   int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
   double* d_pt_full = nullptr; int* d_own_slot = nullptr;
   double* d_hpp_full = nullptr;
@@ -1771,6 +1876,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
           if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return fail(rc2);
           if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return fail(rc2);
           if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return fail(rc2);
+          if (int rc2 = dev_alloc<unsigned long long>(ba, 8 * (size_t)grid, &ba->d_wslots)) return fail(rc2);
           ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
         }
       }
@@ -1966,6 +2072,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.epoch_base = (++ba->pers_launch) << 20;
       pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
       pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
+      pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.wslots = nullptr;
+      if (ba->coarse_na) {
+        RC(coarse_build(ba, lambda));
+        pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.wslots = ba->d_wslots;
+      }
       void* kargs[2] = {(void*)&d, (void*)&pa};
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
