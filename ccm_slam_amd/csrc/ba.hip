@@ -675,6 +675,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 // PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Offline study on 600-keyframe systems (same matrices): 296 -> 75 CG
 // iterations at lambda 0.3, 69 -> 38 at lambda 30, independent of the map size.
 constexpr int kAgg = 32;   // cameras per aggregate = 2 clusters = 4 persistent units
+constexpr int kCoarseOnIters = 100, kCoarseOffIters = 30;
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -701,37 +702,75 @@ __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
     }
 }
 
-// one wave per coarse block (a <= a'): Ac_aa' = sum over the S blocks (i in a, j in a') of P_i^T (S_ij [+ lambda I]) P_j; an
-// off-diagonal S block inside one aggregate also contributes its transpose.  Fixed entry order => deterministic.
-__global__ __launch_bounds__(kTPB) void ba_coarse_assemble(BaDev d, const double* Pm, const int* cb_off, const int* cb_ent, const int* cb_ab, int n_cb,
-                                                           const int* blk_i, const int* blk_j, double lambda, double* Ac, int Nc) {
-  const int w = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
-  const int lane = threadIdx.x & (kWave - 1);
-  if (w >= n_cb) return;
+// one workgroup (16 waves) per coarse block (a <= a'): Ac_aa' = sum over the S blocks (i in a, j in a') of
+// P_i^T (S_ij [+ lambda I]) P_j; an off-diagonal S block inside one aggregate also contributes its transpose.  The work is
+// pure latency (entry -> block index -> cameras -> three 6x6 matrices), so every wave takes kCoarseBatch consecutive
+// entries at a time, stages their matrices in its own LDS slice with coalesced loads (all chains of a batch in flight
+// together) and multiplies out of LDS.  The 16 partial sums are added in a fixed order => deterministic.
+constexpr int kCoarseTPB = 1024;
+constexpr int kCoarseBatch = 4;
+__global__ __launch_bounds__(kCoarseTPB) void ba_coarse_assemble(BaDev d, const double* Pm, const int* cb_off, const int* cb_ent, const int* cb_ab, int n_cb,
+                                                                 const int* blk_i, const int* blk_j, double lambda, double* Ac, int Nc) {
+  constexpr int kNW = kCoarseTPB / kWave;
+  __shared__ double stage[kNW][kCoarseBatch][3][36];   // [S block | P_i | P_j]
+  __shared__ double part[kNW][36];
+  const int w = blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
   const int a = cb_ab[2 * w], b = cb_ab[2 * w + 1];
-  const int r = (lane < 36) ? lane / 6 : 0, c = (lane < 36) ? lane % 6 : 0;
+  const bool el = lane < 36;
+  const int r = el ? lane / 6 : 0, c = el ? lane % 6 : 0;
+  const int end = cb_off[w + 1];
   double acc = 0;
-  for (int s = cb_off[w]; s < cb_off[w + 1]; s++) {
-    const int code = cb_ent[s];
-    const int blk = code >> 1, both = code & 1;
-    const int i = blk_i[blk], j = blk_j[blk];
-    const double* B = d.S + 36 * (size_t)blk;
-    const double* Pi = Pm + 36 * (size_t)i;
-    const double* Pj = Pm + 36 * (size_t)j;
-    double m = 0;
+  for (int s0 = cb_off[w] + wv * kCoarseBatch; s0 < end; s0 += kNW * kCoarseBatch) {
+    int code[kCoarseBatch], ci[kCoarseBatch], cj[kCoarseBatch];
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-      double tq = 0;
+    for (int u = 0; u < kCoarseBatch; u++) code[u] = (s0 + u < end) ? cb_ent[s0 + u] : -1;
 #pragma unroll
-      for (int p = 0; p < 6; p++) tq += Pi[p * 6 + r] * (B[p * 6 + q] + ((i == j && p == q) ? lambda : 0.0));
-      m += tq * Pj[q * 6 + c];
+    for (int u = 0; u < kCoarseBatch; u++) { const int blk = (code[u] >= 0) ? code[u] >> 1 : 0; ci[u] = blk_i[blk]; cj[u] = blk_j[blk]; }
+    double vb[kCoarseBatch], vi[kCoarseBatch], vj[kCoarseBatch];
+#pragma unroll
+    for (int u = 0; u < kCoarseBatch; u++) {
+      const int blk = (code[u] >= 0) ? code[u] >> 1 : 0;
+      vb[u] = el ? d.S[36 * (size_t)blk + lane] : 0.0;
+      vi[u] = el ? Pm[36 * (size_t)ci[u] + lane] : 0.0;
+      vj[u] = el ? Pm[36 * (size_t)cj[u] + lane] : 0.0;
     }
-    const double mt = __shfl(m, c * 6 + r, kWave);
-    acc += both ? (m + mt) : m;
+    if (el) {
+#pragma unroll
+      for (int u = 0; u < kCoarseBatch; u++) {
+        stage[wv][u][0][lane] = vb[u] + ((ci[u] == cj[u] && r == c) ? lambda : 0.0);
+        stage[wv][u][1][lane] = vi[u];
+        stage[wv][u][2][lane] = vj[u];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slice is private to this wave and LDS executes a wave's accesses in order
+#pragma unroll
+    for (int u = 0; u < kCoarseBatch; u++) {
+      if (code[u] < 0) continue;
+      const double* B = stage[wv][u][0];
+      const double* Pi = stage[wv][u][1];
+      const double* Pj = stage[wv][u][2];
+      double m = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) {
+        double tq = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++) tq += Pi[p * 6 + r] * B[p * 6 + q];
+        m += tq * Pj[q * 6 + c];
+      }
+      const double mt = __shfl(m, c * 6 + r, kWave);
+      acc += (code[u] & 1) ? (m + mt) : m;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (lane < 36) {
-    Ac[(size_t)(6 * a + r) * Nc + 6 * b + c] = acc;
-    if (a != b) Ac[(size_t)(6 * b + c) * Nc + 6 * a + r] = acc;
+  if (el) part[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && el) {
+    double tot = 0;
+#pragma unroll
+    for (int k = 0; k < kNW; k++) tot += part[k][lane];
+    Ac[(size_t)(6 * a + r) * Nc + 6 * b + c] = tot;
+    if (a != b) Ac[(size_t)(6 * b + c) * Nc + 6 * a + r] = tot;
   }
 }
 __global__ void ba_coarse_pad(double* Ac, int nc, int Nc) {
@@ -770,7 +809,7 @@ struct PersArgs {
   double lambda, rel_tol;
   int max_it, n_clu;
   unsigned* bar;        // [1] abort flag
-  unsigned long long* slots;   // [2][gridDim.x][2]: p.q exchange, r.z exchange
+  unsigned long long* slots;   // [2][2][grid]: p.q exchange, r.z exchange (word-major 16-byte slots)
   unsigned long long epoch_base;   // unique per launch: stale slots of earlier solves never validate
   const int* uoff;      // [n_clu+1] offsets into ucol
   const int* ucol;      // distinct columns of each cluster's rows, ascending
@@ -778,7 +817,7 @@ struct PersArgs {
   long long* dbg;       // optional [16] phase clocks of workgroup 0 (wall_clock64 ticks, 10 ns), accumulated over iterations
   // coarse level (nullptr = cluster-Jacobi only): explicit inverse [Nc x Nc], prolongation blocks [Cp][36], aggregates
   const double* Ainv; const double* Pm; int na, Nc;
-  unsigned long long* wslots;   // [gridDim.x][8]: wide exchange slots (scalar + the unit's 6 coarse components + check word)
+  double* cparts;              // [6][grid]: the units' parts of the coarse restriction P^T q, component-major; exchanged like p, q and z
 };
 
 // a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double in the PCG loop)
@@ -797,12 +836,16 @@ __device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_st
 // the current epoch's key; the xor check also rejects torn 16-byte reads.  The values are then summed in a fixed order,
 // so every workgroup obtains bit-identical totals.  All cross-workgroup data (z, p, q, slots) moves with device-coherent
 // accesses, so the only ordering needed is: drain this workgroup's stores, meet, publish.
-__device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg, double v_thread, bool force_nan, unsigned long long epoch,
-                                              unsigned* abort_flag, double* red /* [kPersWaves + 1] */, double* total,
-                                              int unit = -1, unsigned long long* wslots = nullptr, const double* cpart = nullptr, double* gath = nullptr) {
-  // v_thread: this thread's share of the workgroup's partial.  The workgroup sum, the publish and the grid-wide sum share
-  // two block barriers: wave sums -> LDS, (drain stores, barrier), thread 0 adds the 16 wave sums in a fixed order and
-  // publishes, wave 0 polls, (barrier), everybody reads the grid total from red[kPersWaves].
+__device__ __forceinline__ bool pers_exchange(unsigned long long* slots /* [2][nwg] */, int nwg, int me, double v_thread, bool force_nan,
+                                              unsigned long long epoch, unsigned* abort_flag, double* red /* [kPersWaves + 4] */,
+                                              double* total, int* poll_fail /* LDS, sticky: an aborted exchange ends the solve */) {
+  // v_thread: this thread's share of the unit's partial.  The unit sum, the publish and the grid-wide sum share two block
+  // barriers: wave sums -> LDS, (drain stores, barrier), thread 0 adds the 16 wave sums in a fixed order and publishes,
+  // wave 0 polls (lane = source units t, t+64, ...; nwg <= 256), (barrier), everybody reads the grid total.
+  // The slot words are stored WORD-MAJOR (word w of unit i at slots[w * nwg + i]) so that a wave's load of one word is
+  // 512 contiguous bytes.  Variants measured and dropped: polling with 4 or 16 waves (slows the units still computing),
+  // wide slots that also carried the coarse components (8-12 us per exchange; they now travel like p, q and z), and
+  // pushing the value into per-unit inboxes (64K scattered write-through stores per exchange).
   const int t = threadIdx.x;
   const unsigned long long key = 0x9E3779B97F4A7C15ull * epoch;
   {
@@ -817,63 +860,40 @@ __device__ __forceinline__ bool pers_exchange(unsigned long long* slots, int nwg
     for (int w = 0; w < kPersWaves; w++) mine += red[w];
     if (force_nan) mine = __longlong_as_double(0x7ff8000000000000ll);
     const unsigned long long bits = (unsigned long long)__double_as_longlong(mine);
-    if (wslots) {   // wide slot of logical unit `unit`: [scalar, 6 coarse components, key ^ xor of the seven]
-      unsigned long long chk = key ^ bits;
-      __hip_atomic_store(wslots + 8 * unit, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const unsigned long long cb = (unsigned long long)__double_as_longlong(cpart[c]);
-        chk ^= cb;
-        __hip_atomic_store(wslots + 8 * unit + 1 + c, cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __hip_atomic_store(wslots + 8 * unit + 7, chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(slots + 2 * blockIdx.x, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(slots + 2 * blockIdx.x + 1, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __hip_atomic_store(slots + me, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + nwg + me, bits ^ key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // only wave 0 polls (4 slots per lane): 16x fewer coherent loads in flight than polling with every thread, which
-  // measurably slowed the workgroups that were still computing
-  double v = 0;
-  bool alive = true;
-  __shared__ int poll_state;
   if (t < kWave) {
+    constexpr int kPer = 4;    // slots per lane
+    unsigned done = 0;
+    double val[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { val[j] = 0; if (t + j * kWave >= nwg) done |= 1u << j; }
+    bool ok_w = true;
     for (long spins = 0;; spins++) {
-      bool ok = true;
-      v = 0;
-      if (wslots) {
-        for (int i = t; i < nwg; i += kWave) {
-          unsigned long long w[8], chk = 0;
 #pragma unroll
-          for (int c = 0; c < 8; c++) { w[c] = __hip_atomic_load(wslots + 8 * i + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); chk ^= w[c]; }
-          if (chk != key) ok = false;
-          else {
-            v += __longlong_as_double((long long)w[0]);
-#pragma unroll
-            for (int c = 0; c < 6; c++) gath[6 * i + c] = __longlong_as_double((long long)w[1 + c]);
-          }
-        }
-      } else
-      for (int i = t; i < nwg; i += kWave) {
-        const unsigned long long b0 = __hip_atomic_load(slots + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long b1 = __hip_atomic_load(slots + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((b0 ^ b1) != key) ok = false; else v += __longlong_as_double((long long)b0);
+      for (int j = 0; j < kPer; j++) {
+        if (done & (1u << j)) continue;   // a slot that validated is not read again
+        const unsigned long long* in = slots + t + j * kWave;
+        const unsigned long long b0 = __hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b1 = __hip_atomic_load(in + nwg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((b0 ^ b1) == key) { done |= 1u << j; val[j] = __longlong_as_double((long long)b0); }
       }
-      if (__all(ok)) { if (t == 0) poll_state = 1; break; }
-      if (spins > kPersMaxSpins || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        if (t == 0) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); poll_state = 0; }
-        break;
-      }
+      if (__all(done == (1u << kPer) - 1u)) break;
+      if (spins > kPersMaxSpins || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok_w = false; break; }
       __builtin_amdgcn_s_sleep(2);
     }
-    v = wave_sum(v);
-    if (t == 0) red[kPersWaves] = v;
+    const double v = wave_sum(((val[0] + val[1]) + val[2]) + val[3]);
+    if (t == 0) {
+      red[kPersWaves] = v;
+      if (!ok_w) { *poll_fail = 1; __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
   }
   __syncthreads();
-  alive = poll_state != 0;
+  const bool alive = *poll_fail == 0;
   *total = pers_uniform(red[kPersWaves]);
-  // no trailing barrier: red[0..15] is rewritten only after every thread has passed the barrier above, red[16] and
-  // poll_state only after the first barrier of the next exchange
+  // no trailing barrier: red[0..15] is rewritten only after every thread has passed the barrier above, red[16] only
+  // after the first barrier of the next exchange
   return alive;
 }
 
@@ -1082,7 +1102,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   double* zs = qs + N;                     // z
   double* zpart = zs + N;                  // [8][96]
   double* red = zpart + 8 * N;             // [16]
-  int* ibuf = reinterpret_cast<int*>(red + kPersWaves + 2);   // [0]=ok flag of the barrier, [1]=bad pivot
+  int* ibuf = reinterpret_cast<int*>(red + kPersWaves + 4);   // [0]=ok flag of the barrier, [1]=bad pivot
   const int t = threadIdx.x, lane = t & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(t / kWave);
   const int nwg = gridDim.x;               // padded to a multiple of 8
@@ -1104,7 +1124,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   unsigned long long* slots_rz = a.slots + 2 * (size_t)nwg;
   unsigned long long epoch = a.epoch_base;
   const double lambda = a.lambda;
-  if (t < 2) ibuf[t] = (t == 0) ? 1 : 0;
+  if (t < 4) ibuf[t] = (t == 0) ? 1 : 0;   // [2] = exchange failure flag
   // optional phase clocks of workgroup 0 / thread 0, accumulated in LDS so that they cost no registers
   long long* tacc = reinterpret_cast<long long*>(ibuf + 4);   // [13]: 12 phases + last stamp
   const bool timing = a.dbg != nullptr && blockIdx.x == 0 && t == 0;
@@ -1124,31 +1144,40 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   const int Nc = a.Nc, nca = 6 * a.na;
   double* ainv_l = A + N * (N / 2);          // [6][Nc]
   double* rco = ainv_l + 6 * Nc;             // [Nc]
-  double* gath = rco + Nc;                   // [6 * nwg]
-  double* pown = gath + 6 * nwg;             // [8][36]
-  double* ypart = pown + 8 * 36;             // [4][6]
-  double* cpart = ypart + 24;                // [6]
+  double* pown = rco + Nc;                   // [8][36]
+  double* ypart = pown + 8 * 36;             // [6]
   const int agg = c / (kAgg / kClu);         // aggregate of the unit's cluster
   if (coarse) {
     for (int e = t; e < 6 * Nc; e += kPersTPB) ainv_l[e] = has ? a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0;
     for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;
     for (int e = t; e < 8 * 36; e += kPersTPB) pown[e] = (e / 36 < nown) ? a.Pm[36 * (size_t)o0 + e] : 0.0;
-    if (t < 6) cpart[t] = 0.0;
   }
   __syncthreads();
-  // unit part of the coarse restriction P^T v for the own rows: wave 0, lane = (camera, component)
+  // unit part of the coarse restriction P^T v for the own rows: wave 0, lane = (component c, camera k); the 8 camera
+  // terms of a component sit in 8 neighbouring lanes.  Published component-major for the other units.
   auto coarse_restrict = [&](const double* vec /* LDS, own 48 entries */) {
     if (wv == 0) {
-      const int kk = lane / 6, rr = lane % 6;
-      const double val = (lane < mo) ? vec[lane] : 0.0;
-      double out[6];
+      const int cc = lane >> 3, kk = lane & 7;
+      double sv = 0;
+      if (cc < 6 && kk < nown) {
 #pragma unroll
-      for (int cc = 0; cc < 6; cc++) out[cc] = wave_sum((lane < 48) ? pown[kk * 36 + rr * 6 + cc] * val : 0.0);
-      if (lane == 0) {
-#pragma unroll
-        for (int cc = 0; cc < 6; cc++) cpart[cc] = out[cc];
+        for (int rr = 0; rr < 6; rr++) sv += pown[kk * 36 + rr * 6 + cc] * vec[6 * kk + rr];
       }
+      sv += __shfl_xor(sv, 1, kWave);
+      sv += __shfl_xor(sv, 2, kWave);
+      sv += __shfl_xor(sv, 4, kWave);
+      if (cc < 6 && kk == 0) coh_store(a.cparts + (size_t)cc * nwg + u, sv);
     }
+  };
+  // sum of the 4 units' parts of aggregate t / 6, component t % 6 (valid after the exchange that follows coarse_restrict)
+  auto coarse_gather = [&]() {
+    double sgm = 0;
+    if (coarse && t < nca) {
+      const double* cp = a.cparts + (size_t)(t % 6) * nwg + 4 * (t / 6);
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++) if (4 * (t / 6) + mm < nwg) sgm += coh_load(cp + mm);
+    }
+    return sgm;
   };
   // PCG start: x = 0, r = bs, z = W r, p_{-1} = 0
   if (t < N) { xs[t] = 0; ps[t] = 0; qs[t] = 0; zs[t] = 0; rc[t] = (t < m) ? d.bs[6 * (size_t)s0 + t] : 0.0; }   // xs/ps/zs: own rows; rc/qs: cluster
@@ -1199,25 +1228,21 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   }
   auto apply_W = [&]() {          // z(own rows) = W[own rows, :] rc (+ coarse correction); publishes them; returns this thread's share of r.z
     {
-      const int row = t % (N / 2), prt = t / (N / 2);       // 48 rows x 16 column parts (6 columns each) = 768 threads
-      if (prt < 16) {
+      const int row = t % (N / 2), prt = t / (N / 2);       // 48 rows x 8 column parts (12 columns each) = waves 0..5
+      if (prt < 8) {
         double sv = 0;
         if (row < mo) {
-          const int c0 = prt * 6;
+          const int c0 = prt * 12;
 #pragma unroll
-          for (int col = 0; col < 6; col++) sv += A[(c0 + col) * (N / 2) + row] * rc[c0 + col];
+          for (int col = 0; col < 12; col++) sv += A[(c0 + col) * (N / 2) + row] * rc[c0 + col];
         }
         zpart[prt * (N / 2) + row] = sv;
-      } else if (coarse) {                                  // the last 4 waves: y = Ac^-1[aggregate rows] * coarse residual
-        const int tt = t - 16 * (N / 2);
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        for (int j = tt; j < nca; j += kPersTPB - 16 * (N / 2)) {
-          const double rj = rco[j];
-#pragma unroll
-          for (int r6 = 0; r6 < 6; r6++) acc[r6] += ainv_l[r6 * Nc + j] * rj;
-        }
-#pragma unroll
-        for (int r6 = 0; r6 < 6; r6++) { const double ws = wave_sum(acc[r6]); if (lane == 0) ypart[(wv - 12) * 6 + r6] = ws; }
+      } else if (coarse && wv < 12) {                       // waves 6..11: y[wv - 6] = Ac^-1[aggregate row] . coarse residual
+        const double* ar = ainv_l + (wv - 6) * Nc;
+        double acc = 0;
+        for (int j = lane; j < nca; j += kWave) acc += ar[j] * rco[j];
+        acc = wave_sum(acc);
+        if (lane == 0) ypart[wv - 6] = acc;
       }
     }
     __syncthreads();
@@ -1225,11 +1250,11 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     if (t < mo) {
       double z = zpart[t];
 #pragma unroll
-      for (int q = 1; q < 16; q++) z += zpart[q * (N / 2) + t];
+      for (int q = 1; q < 8; q++) z += zpart[q * (N / 2) + t];
       if (coarse) {
         const int kk = t / 6, rr = t % 6;
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * (((ypart[cc] + ypart[6 + cc]) + ypart[12 + cc]) + ypart[18 + cc]);
+        for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * ypart[cc];
       }
       zs[t] = z;
       coh_store(d.z + 6 * (size_t)o0 + t, z);
@@ -1240,26 +1265,18 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   int fail = 0, k = 0;
   double rz = 0;
   bool alive = true;
-  auto coarse_accumulate = [&](double scale) {   // coarse residual += scale * (gathered unit parts summed per aggregate, fixed order)
-    if (t < nca) {
-      const int aa = t / 6, cc = t % 6;
-      double sgm = 0;
-#pragma unroll
-      for (int mm = 0; mm < 4; mm++) { const int uu = 4 * aa + mm; if (uu < nwg) sgm += gath[6 * uu + cc]; }
-      rco[t] += scale * sgm;
-    }
-  };
   if (coarse) {   // coarse residual of r0 = b: one extra exchange before the first preconditioner application
     coarse_restrict(rc + ob);
     double dummy = 0;
-    alive = pers_exchange(slots_rz, nwg, 0.0, false, ++epoch, a.bar + 1, red, &dummy, u, a.wslots, cpart, gath);
-    coarse_accumulate(1.0);
+    alive = pers_exchange(slots_rz, nwg, u, 0.0, false, ++epoch, a.bar + 1, red, &dummy, ibuf + 2);
+    const double cg0 = coarse_gather();
+    if (t < nca) rco[t] += cg0;
     __syncthreads();
   }
   {
     const double rz_t = apply_W();
     if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
-    const bool alive2 = pers_exchange(slots_rz, nwg, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz);   // bad pivot -> NaN -> grid-wide failure
+    const bool alive2 = pers_exchange(slots_rz, nwg, u, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz, ibuf + 2);   // bad pivot -> NaN -> grid-wide failure
     alive = alive && alive2;
   }
   const double rz0 = rz;
@@ -1315,22 +1332,22 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     if (coarse) { __syncthreads(); coarse_restrict(qs + ob); }
     PERS_TICK(1)
     double pq = 0;
-    if (coarse) alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq, u, a.wslots, cpart, gath);
-    else alive = pers_exchange(slots_pq, nwg, pq_t, false, ++epoch, a.bar + 1, red, &pq);
+    alive = pers_exchange(slots_pq, nwg, u, pq_t, false, ++epoch, a.bar + 1, red, &pq, ibuf + 2);
     PERS_TICK(2)
     if (!alive) { fail = 1; break; }
     const double q_partner = (t < m && !(t >= ob && t < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + t) : 0.0;
+    const double cg = coarse_gather();       // P^T q of every aggregate
     if (!(pq > 0.0)) { fail = 1; break; }   // not positive definite (or NaN): solver failure -> LM rejects the step
     PERS_TICK(3)
     const double alpha = pers_uniform(rz / pq);
     if (t < mo) xs[t] += alpha * ps[t];
     if (t < m) rc[t] -= alpha * ((t >= ob && t < ob + mo) ? qs[t] : q_partner);
-    if (coarse) coarse_accumulate(-alpha);        // P^T r follows the recurrence of r: no second gather per iteration
+    if (coarse && t < nca) rco[t] -= alpha * cg;  // P^T r follows the recurrence of r: no second gather per iteration
     __syncthreads();
     const double rz_t2 = apply_W();
     PERS_TICK(4)
     rz_prev = rz;
-    alive = pers_exchange(slots_rz, nwg, rz_t2, false, ++epoch, a.bar + 1, red, &rz);
+    alive = pers_exchange(slots_rz, nwg, u, rz_t2, false, ++epoch, a.bar + 1, red, &rz, ibuf + 2);
     PERS_TICK(5)
     if (!alive) { fail = 1; break; }
     PERS_TICK(6)
@@ -1338,11 +1355,14 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 #undef PERS_TICK
   if (timing) { for (int q = 0; q < 12; q++) a.dbg[q] += tacc[q]; a.dbg[12] += k; a.dbg[13] += 1; }
   if (t < mo) d.x[6 * (size_t)o0 + t] = xs[t];
-  if (blockIdx.x == 0 && t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = fail; }
+  if (blockIdx.x == 0 && t == 0) {
+    d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = fail;
+    d.pcg_flag[3] = ibuf[2] | (int)__hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // an exchange timed out: not a numeric failure
+  }
 }
 
 static inline size_t pers_lds_bytes() {
-  return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves + 2) * sizeof(double) + 16 + 14 * sizeof(long long);
+  return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves + 4) * sizeof(double) + 16 + 14 * sizeof(long long);
 }
 
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
@@ -1573,8 +1593,13 @@ struct ccm_ba {
   unsigned long long pers_launch = 0;
   // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
   int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
+  // The coarse level costs a dense inverse per trial (~0.5 ms) and ~25% per CG iteration; it pays only when the
+  // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
+  // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
+  bool coarse_active = false, coarse_used = false;
+  int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
-  unsigned long long* d_wslots = nullptr;
+  double* d_cparts = nullptr;
   int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
   double* d_pt_full = nullptr; int* d_own_slot = nullptr;
   double* d_hpp_full = nullptr;
@@ -1842,9 +1867,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     int per_cu = 0, n_cu = 0;
     if (hipFuncSetAttribute((const void*)ba_pcg_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_pcg_persist, kPersTPB, lds) == hipSuccess &&
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid) {
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid && grid <= 4 * kWave) {
       if (int rc2 = dev_alloc<unsigned>(ba, 4 + 2 * 16, &ba->d_pers_bar)) return fail(rc2);   // + debug clocks
-      if (int rc2 = dev_alloc<double>(ba, 4 * (size_t)grid, &ba->d_pers_part)) return fail(rc2);   // [2][grid] 16-byte slots
+      if (int rc2 = dev_alloc<double>(ba, 4 * (size_t)grid, &ba->d_pers_part)) return fail(rc2);   // [2][2][grid] slot words
       if (int rc2 = dev_upload(ba, pers_uoff, &ba->d_pers_uoff)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_loc, &ba->d_pers_loc)) return fail(rc2);
@@ -1876,8 +1901,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
           if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return fail(rc2);
           if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return fail(rc2);
           if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return fail(rc2);
-          if (int rc2 = dev_alloc<unsigned long long>(ba, 8 * (size_t)grid, &ba->d_wslots)) return fail(rc2);
+          if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)grid, &ba->d_cparts)) return fail(rc2);
           ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
+          if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
         }
       }
     }
@@ -2002,7 +2028,7 @@ int coarse_build(ccm_ba* ba, double lambda) {
   const int Nc = ba->coarse_Nc, nc = 6 * ba->coarse_na;
   hipLaunchKernelGGL(ba_coarse_P, dim3(ccm_div_up(d.Cp, kTPB)), dim3(kTPB), 0, ctx->stream, d, ba->cur, ba->d_cP);
   CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, (size_t)Nc * Nc * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ccm_div_up(ba->coarse_ncb, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
+  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ba->coarse_ncb), dim3(kCoarseTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
                      (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
                      lambda, ba->d_cA, Nc);
   if (Nc > nc) hipLaunchKernelGGL(ba_coarse_pad, dim3(1), dim3(64), 0, ctx->stream, ba->d_cA, nc, Nc);
@@ -2072,15 +2098,33 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.epoch_base = (++ba->pers_launch) << 20;
       pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
       pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
-      pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.wslots = nullptr;
-      if (ba->coarse_na) {
+      pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
+      const bool use_coarse = ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
+      ba->coarse_used = use_coarse;
+      if (use_coarse) {
+        if (getenv("CCM_BA_COARSE_DBG")) {
+          hipStreamSynchronize(ctx->stream); const double tc0 = now_ms();
+          RC(coarse_build(ba, lambda));
+          const double tc1 = now_ms(); hipStreamSynchronize(ctx->stream);
+          fprintf(stderr, "[ccm_ba] coarse_build: enqueue %.3f ms, complete %.3f ms\n", tc1 - tc0, now_ms() - tc0);
+        } else
         RC(coarse_build(ba, lambda));
-        pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.wslots = ba->d_wslots;
+        pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.cparts = ba->d_cparts;
       }
       void* kargs[2] = {(void*)&d, (void*)&pa};
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
-        const hipError_t le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
+        // A cooperative launch guarantees co-residency but, measured with rocprofv3 on MI355X / ROCm 7.2, leaves the
+        // GPU idle for ~0.55 ms before the kernel starts (18 launches: 10.5 ms of 53); an ordinary launch starts after
+        // ~13 us.  The grid was sized at create time to fit the device at the kernel's occupancy, so on a stream whose
+        // earlier work has drained all workgroups become resident; if they ever do not (device shared with another
+        // long-running kernel), the bounded spins of pers_exchange abort the solve, pcg_flag[3] reports it and the trial
+        // is repeated on the multi-kernel path below.  CCM_BA_COOP_LAUNCH=1 selects the cooperative launch.
+        hipError_t le;
+        static const bool coop = getenv("CCM_BA_COOP_LAUNCH") != nullptr;
+        if (!coop) { hipLaunchKernelGGL(ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), pers_lds_bytes(), ctx->stream, d, pa); le = hipGetLastError(); }
+        else
+        le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
                                                          (unsigned)pers_lds_bytes(), ctx->stream);
         if (le == hipSuccess) persist_ok = true;
         else { (void)hipGetLastError(); ba->pers_grid = 0; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
@@ -2132,7 +2176,15 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   double s[4];
   RC(read_scalars(ba, s));
   CCM_HIP_CHECK(ctx, hipGetLastError());
+  if (small_path && ba->pers_grid && small_flags[3]) {   // the persistent kernel could not hold its grid exchange: never again on this handle
+    ba->pers_grid = 0;
+    return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
+  }
   if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
+  if (ba->coarse_na && small_path) {
+    if (!ba->coarse_used && *pcg_iters >= kCoarseOnIters) ba->coarse_active = true;
+    else if (ba->coarse_used && *pcg_iters <= kCoarseOffIters) ba->coarse_active = false;
+  }
   *temp_chi = s[0];
   *scale = s[1];
   return CCM_OK;
@@ -2165,7 +2217,7 @@ extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* A
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (Ainv) for (size_t r = 0; r < nc; r++) for (size_t c = 0; c < nc; c++) Ainv[r * nc + c] = buf[r * Nc + c];
   CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, Nc * Nc * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ccm_div_up(ba->coarse_ncb, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
+  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ba->coarse_ncb), dim3(kCoarseTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
                      (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
                      lambda, ba->d_cA, (int)Nc);
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(buf.data(), ba->d_cA, buf.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -2217,6 +2269,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ccm_ba_options opt{};
   if (opt_in) opt = *opt_in;
+  ba->coarse_active = false;   // every run starts from the same preconditioner state
   const double t_start = now_ms();
   ccm_ba_stats st{};
   st.ms_setup = ba->ms_setup;

@@ -77,6 +77,69 @@ __global__ __launch_bounds__(kTPB) void chol_diag(double* A, int N, int j, doubl
   }
 }
 
+// Single-wave variant of chol_diag for latency-critical small systems (the coarse level of the BA preconditioner is
+// re-inverted for every LM trial).  The block version above spends three block barriers per column (~130 us per tile).
+// Measured alternatives with one wave: tile in registers and every multiplier travelling by v_readlane, 88 us; tile in
+// LDS, left-looking, two LDS reads per term, 96 us (nothing hides the LDS latency of a lone wave).  This one keeps lane
+// i's ROW in registers and reads only the pivot row from LDS (uniform address = broadcast, two doubles per read), so a
+// term costs one FMA plus half a read with no dependence between the reads: left-looking column form, fully unrolled,
+// four accumulators.  L^-1 follows by forward substitution, lane = column, x in registers, L rows broadcast the same way.
+__device__ __forceinline__ double bcast64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
+  constexpr int LR = NB + 2;   // even row stride: rows stay 16-byte aligned for the paired broadcast reads
+  __shared__ __attribute__((aligned(16))) double L[NB * LR];
+  __shared__ double rdiag[NB];
+  const int lane = threadIdx.x;
+  double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
+  for (int e = lane; e < NB * NB; e += NB) { const int r = e / NB, c = e % NB; L[r * LR + c] = Ajj[(size_t)r * N + c]; }
+  __syncthreads();
+  int bad_col = 0;
+  {
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) row[k] = L[lane * LR + k];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+      const double* Lc = L + c * LR;                 // row c of L: entries k < c were written by lane c at columns k
+      double acc[4] = {row[c], 0.0, 0.0, 0.0};       // lane i: A_ic - sum_{k<c} L_ik L_ck
+#pragma unroll
+      for (int k = 0; k < c; k++) acc[k & 3] -= row[k] * Lc[k];
+      const double sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      double dd = bcast64(sv, c);
+      if (!(dd > 0.0)) { if (!bad_col) bad_col = c + 1; dd = 1.0; }
+      const double l = sqrt(dd), inv = 1.0 / l;
+      row[c] = (lane == c) ? l : sv * inv;           // lanes < c hold the (unused) upper part
+      L[lane * LR + c] = row[c];
+      if (lane == c) rdiag[c] = inv;
+      __syncthreads();
+    }
+  }
+  if (bad_col && lane == 0 && *info == 0) *info = j * NB + bad_col;
+  double* Lg = Linv_all + (size_t)j * NB * NB;
+  {
+    // X = L^-1, lane = column t: x_r = (delta_rt - sum_{k<r} L_rk x_k) / L_rr  (x_k = 0 for k < t, so the bounds are uniform)
+    double x[NB];
+#pragma unroll
+    for (int r = 0; r < NB; r++) {
+      const double* Lrow = L + r * LR;
+      double acc[4] = {(r == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < r; k++) acc[k & 3] -= Lrow[k] * x[k];
+      x[r] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[r];
+      Lg[r * NB + lane] = x[r];
+    }
+  }
+  for (int e = lane; e < NB * NB; e += NB) {
+    const int r = e / NB, c = e % NB;
+    Ajj[(size_t)r * N + c] = (c <= r) ? L[r * LR + c] : 0.0;
+  }
+}
+
 // tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
 __global__ __launch_bounds__(kTPB) void chol_panel(double* A, int N, int j, const double* Linv_all) {
   __shared__ double As[NB * LD], Bs[NB * LD];
@@ -283,7 +346,7 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
   const int T = N / NB;
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(kTPB), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(64), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     const int rem = T - j - 1;
     if (rem > 0) {
       hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv);
