@@ -674,7 +674,11 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 // 4-agent map); its explicit inverse is formed once per LM trial by the tile kernels of dense_chol.hip and the persistent
 // PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Offline study on 600-keyframe systems (same matrices): 296 -> 75 CG
 // iterations at lambda 0.3, 69 -> 38 at lambda 30, independent of the map size.
-constexpr int kAgg = 32;   // cameras per aggregate = 2 clusters = 4 persistent units
+#ifndef CCM_KAGG
+#define CCM_KAGG 32
+#endif
+constexpr int kAgg = CCM_KAGG;   // cameras per aggregate (32 = 2 clusters = 4 persistent units)
+constexpr int kAggUnits = kAgg / 8;
 constexpr int kCoarseOnIters = 100, kCoarseOffIters = 30;
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
@@ -836,7 +840,7 @@ __device__ __forceinline__ void coh_store(double* p, double v) { __hip_atomic_st
 // the current epoch's key; the xor check also rejects torn 16-byte reads.  The values are then summed in a fixed order,
 // so every workgroup obtains bit-identical totals.  All cross-workgroup data (z, p, q, slots) moves with device-coherent
 // accesses, so the only ordering needed is: drain this workgroup's stores, meet, publish.
-__device__ __forceinline__ bool pers_exchange(unsigned long long* slots /* [2][nwg] */, int nwg, int me, double v_thread, bool force_nan,
+__device__ __forceinline__ bool pers_exchange(int t /* threadIdx.x */, unsigned long long* slots /* [2][nwg] */, int nwg, int me, double v_thread, bool force_nan,
                                               unsigned long long epoch, unsigned* abort_flag, double* red /* [kPersWaves + 4] */,
                                               double* total, int* poll_fail /* LDS, sticky: an aborted exchange ends the solve */) {
   // v_thread: this thread's share of the unit's partial.  The unit sum, the publish and the grid-wide sum share two block
@@ -846,7 +850,6 @@ __device__ __forceinline__ bool pers_exchange(unsigned long long* slots /* [2][n
   // 512 contiguous bytes.  Variants measured and dropped: polling with 4 or 16 waves (slows the units still computing),
   // wide slots that also carried the coarse components (8-12 us per exchange; they now travel like p, q and z), and
   // pushing the value into per-unit inboxes (64K scattered write-through stores per exchange).
-  const int t = threadIdx.x;
   const unsigned long long key = 0x9E3779B97F4A7C15ull * epoch;
   {
     const double ws = wave_sum(v_thread);
@@ -1153,11 +1156,16 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     for (int e = t; e < 8 * 36; e += kPersTPB) pown[e] = (e / 36 < nown) ? a.Pm[36 * (size_t)o0 + e] : 0.0;
   }
   __syncthreads();
+  // Loop-invariant per-thread indices (everything derived from threadIdx) must NOT stay live across the PCG loop: the
+  // 60 VGPRs of S blocks leave ~60 for the rest, and LLVM hoists every such index out of the loop and then spills it
+  // (29-50 scratch reloads per iteration measured).  tq / lq are re-laundered copies of t / lane, opaque to the
+  // optimiser, refreshed at the top of every iteration: the indices are recomputed (a few integer ops) instead.
+  int tq = t, lq = lane;
   // unit part of the coarse restriction P^T v for the own rows: wave 0, lane = (component c, camera k); the 8 camera
   // terms of a component sit in 8 neighbouring lanes.  Published component-major for the other units.
   auto coarse_restrict = [&](const double* vec /* LDS, own 48 entries */) {
     if (wv == 0) {
-      const int cc = lane >> 3, kk = lane & 7;
+      const int cc = lq >> 3, kk = lq & 7;
       double sv = 0;
       if (cc < 6 && kk < nown) {
 #pragma unroll
@@ -1169,13 +1177,13 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       if (cc < 6 && kk == 0) coh_store(a.cparts + (size_t)cc * nwg + u, sv);
     }
   };
-  // sum of the 4 units' parts of aggregate t / 6, component t % 6 (valid after the exchange that follows coarse_restrict)
+  // sum of the 4 units' parts of aggregate tq / 6, component tq % 6 (valid after the exchange that follows coarse_restrict)
   auto coarse_gather = [&]() {
     double sgm = 0;
-    if (coarse && t < nca) {
-      const double* cp = a.cparts + (size_t)(t % 6) * nwg + 4 * (t / 6);
+    if (coarse && tq < nca) {
+      const double* cp = a.cparts + (size_t)(tq % 6) * nwg + kAggUnits * (tq / 6);
 #pragma unroll
-      for (int mm = 0; mm < 4; mm++) if (4 * (t / 6) + mm < nwg) sgm += coh_load(cp + mm);
+      for (int mm = 0; mm < kAggUnits; mm++) if (kAggUnits * (tq / 6) + mm < nwg) sgm += coh_load(cp + mm);
     }
     return sgm;
   };
@@ -1202,21 +1210,22 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   }
   if (t < 6) pl[t] = 0.0;   // padding entries of the register-resident rows point at column slot 0
   __syncthreads();
-  // ---- the S blocks of the own rows go into REGISTERS once: two waves per row, 8 entries in flight per wave,
-  // lane (g, r) keeps row r of its entries (transposition resolved here).  Rows longer than 16*kPersRegEnt blocks
+  // ---- the S blocks of the own rows go into REGISTERS once: two waves per row, 10 entries in flight per wave (60 of
+  // the 64 lanes: with 8 groups of 8 lanes a quarter of the lanes idled and the same 100-block capacity cost 12 more
+  // VGPRs, which the 128-register budget of a 16-wave workgroup does not have), lane (g, r) = (lane / 6, lane % 6)
+  // keeps row r of its entries (transposition resolved here).  Rows longer than 20*kPersRegEnt blocks
   // read the tail from global memory every iteration.
-  constexpr int kPersRegEnt = 6;
-  const int row_l = wv >> 1, half = wv & 1, g = lane >> 3, r = lane & 7;
-  const bool row_ok = has && row_l < nown && r < 6;
+  constexpr int kPersRegEnt = 5;
+  const int row_l = wv >> 1, half = wv & 1, g = lane / 6, r = lane % 6;
+  const bool row_ok = has && row_l < nown && g < 10;
   double sreg[kPersRegEnt][6];
   int jreg[kPersRegEnt];
-  int e_tail = 0, e_end = 0;
   {
     const int e0 = row_ok ? l_off[row_l] : 0;
-    e_end = row_ok ? l_off[row_l + 1] : 0;
+    const int e_end = row_ok ? l_off[row_l + 1] : 0;
 #pragma unroll
     for (int k = 0; k < kPersRegEnt; k++) {
-      const int s = e0 + half * 8 + g + 16 * k;
+      const int s = e0 + half * 10 + g + 20 * k;
       const bool v = row_ok && s < e_end;
       jreg[k] = v ? 6 * l_loc[s] : 0;
       const uint32_t bt = v ? l_blk[s] : 0u;
@@ -1224,11 +1233,10 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 #pragma unroll
       for (int q = 0; q < 6; q++) sreg[k][q] = v ? ((bt & kTransposeBit) ? B[q * 6 + r] : B[r * 6 + q]) : 0.0;
     }
-    e_tail = e0 + half * 8 + g + 16 * kPersRegEnt;
   }
   auto apply_W = [&]() {          // z(own rows) = W[own rows, :] rc (+ coarse correction); publishes them; returns this thread's share of r.z
     {
-      const int row = t % (N / 2), prt = t / (N / 2);       // 48 rows x 8 column parts (12 columns each) = waves 0..5
+      const int row = tq % (N / 2), prt = tq / (N / 2);       // 48 rows x 8 column parts (12 columns each) = waves 0..5
       if (prt < 8) {
         double sv = 0;
         if (row < mo) {
@@ -1240,25 +1248,25 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       } else if (coarse && wv < 12) {                       // waves 6..11: y[wv - 6] = Ac^-1[aggregate row] . coarse residual
         const double* ar = ainv_l + (wv - 6) * Nc;
         double acc = 0;
-        for (int j = lane; j < nca; j += kWave) acc += ar[j] * rco[j];
+        for (int j = lq; j < nca; j += kWave) acc += ar[j] * rco[j];
         acc = wave_sum(acc);
-        if (lane == 0) ypart[wv - 6] = acc;
+        if (lq == 0) ypart[wv - 6] = acc;
       }
     }
     __syncthreads();
     double rz = 0;
-    if (t < mo) {
-      double z = zpart[t];
+    if (tq < mo) {
+      double z = zpart[tq];
 #pragma unroll
-      for (int q = 1; q < 8; q++) z += zpart[q * (N / 2) + t];
+      for (int q = 1; q < 8; q++) z += zpart[q * (N / 2) + tq];
       if (coarse) {
-        const int kk = t / 6, rr = t % 6;
+        const int kk = tq / 6, rr = tq % 6;
 #pragma unroll
         for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * ypart[cc];
       }
-      zs[t] = z;
-      coh_store(d.z + 6 * (size_t)o0 + t, z);
-      rz = rc[ob + t] * z;
+      zs[tq] = z;
+      coh_store(d.z + 6 * (size_t)o0 + tq, z);
+      rz = rc[ob + tq] * z;
     }
     return rz;
   };
@@ -1268,7 +1276,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   if (coarse) {   // coarse residual of r0 = b: one extra exchange before the first preconditioner application
     coarse_restrict(rc + ob);
     double dummy = 0;
-    alive = pers_exchange(slots_rz, nwg, u, 0.0, false, ++epoch, a.bar + 1, red, &dummy, ibuf + 2);
+    alive = pers_exchange(tq, slots_rz, nwg, u, 0.0, false, ++epoch, a.bar + 1, red, &dummy, ibuf + 2);
     const double cg0 = coarse_gather();
     if (t < nca) rco[t] += cg0;
     __syncthreads();
@@ -1276,7 +1284,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   {
     const double rz_t = apply_W();
     if (t < mo) coh_store(d.p[0] + 6 * (size_t)o0 + t, 0.0);
-    const bool alive2 = pers_exchange(slots_rz, nwg, u, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz, ibuf + 2);   // bad pivot -> NaN -> grid-wide failure
+    const bool alive2 = pers_exchange(tq, slots_rz, nwg, u, rz_t, has && ibuf[1], ++epoch, a.bar + 1, red, &rz, ibuf + 2);   // bad pivot -> NaN -> grid-wide failure
     alive = alive && alive2;
   }
   const double rz0 = rz;
@@ -1285,12 +1293,13 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   if (!alive) fail = 1;
   PERS_TICK(11)
   for (; alive && k < a.max_it; k++) {
+    tq = t; asm volatile("" : "+v"(tq)); lq = tq & (kWave - 1);
     if (rz <= thresh * rz0 || !(rz > 0.0)) { if (rz != rz) fail = 1; break; }
     const double beta = pers_uniform((k == 0) ? 0.0 : rz / rz_prev);
     const double* pold = d.p[k & 1];
     double* pnew = d.p[(k + 1) & 1];
     // ---- p = z + beta p_old of every neighbour column, once, into LDS ----
-    for (int idx = t; idx < 6 * nu; idx += kPersTPB) {
+    for (int idx = tq; idx < 6 * nu; idx += kPersTPB) {
       const int j = l_ucol[idx / 6], q = idx % 6;
       pl[idx] = coh_load(d.z + 6 * (size_t)j + q) + beta * coh_load(pold + 6 * (size_t)j + q);
     }
@@ -1301,53 +1310,63 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       double acc = 0;
 #pragma unroll
       for (int kk = 0; kk < kPersRegEnt; kk++) {
-        const double* pj = pl + jreg[kk];
+        // tie the entry's LDS address to the running sum: left alone, the compiler hoists all 30 p loads (60 VGPRs) above
+        // the first multiply and pushes half of the S registers into scratch; the other three waves of the SIMD cover
+        // the LDS latency of one entry at a time
+        int jo = jreg[kk];
+        asm volatile("" : "+v"(jo), "+v"(acc));
+        const double* pj = pl + jo;
 #pragma unroll
         for (int q = 0; q < 6; q++) acc += sreg[kk][q] * pj[q];
       }
-      for (int s = e_tail; s < e_end; s += 16) {   // tail of very long rows
-        const uint32_t bt = l_blk[s];
-        const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
-        const double* pj = pl + 6 * l_loc[s];
+      {   // tail of very long rows (bounds re-read from LDS: two broadcast loads instead of two live registers)
+        const int gq = lq / 6, rq = lq - 6 * gq;
+        const bool rowq = has && row_l < nown && gq < 10;
+        const int e_endq = rowq ? l_off[row_l + 1] : 0;
+        for (int s = (rowq ? l_off[row_l] : 0) + half * 10 + gq + 20 * kPersRegEnt; s < e_endq; s += 20) {
+          const uint32_t bt = l_blk[s];
+          const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+          const double* pj = pl + 6 * l_loc[s];
 #pragma unroll
-        for (int q = 0; q < 6; q++) acc += ((bt & kTransposeBit) ? B[q * 6 + r] : B[r * 6 + q]) * pj[q];
+          for (int q = 0; q < 6; q++) acc += ((bt & kTransposeBit) ? B[q * 6 + rq] : B[rq * 6 + q]) * pj[q];
+        }
       }
-      acc += __shfl_xor(acc, 8, kWave);
-      acc += __shfl_xor(acc, 16, kWave);
-      acc += __shfl_xor(acc, 32, kWave);
-      if (lane < 8) half_sum[(row_l * 2 + half) * 8 + lane] = acc;
+      acc += __shfl_down(acc, 30, kWave);                    // groups g and g + 5
+      const double pr = acc + __shfl_down(acc, 6, kWave);     // (0,1) at g = 0, (2,3) at g = 2
+      acc = (pr + __shfl_down(pr, 12, kWave)) + __shfl_down(acc, 24, kWave);
+      if (lq < 6) half_sum[(row_l * 2 + half) * 8 + lq] = acc;
     }
     __syncthreads();
     double pq_t = 0;
-    if (t < mo) {
-      const int rw = t / 6, cc = t % 6;
-      const double pi = zs[t] + beta * ps[t];
+    if (tq < mo) {
+      const int rw = tq / 6, cc = tq % 6;
+      const double pi = zs[tq] + beta * ps[tq];
       const double qv = (half_sum[(rw * 2) * 8 + cc] + half_sum[(rw * 2 + 1) * 8 + cc]) + lambda * pi;
-      ps[t] = pi;
-      qs[ob + t] = qv;
-      coh_store(pnew + 6 * (size_t)o0 + t, pi);
-      coh_store(d.q + 6 * (size_t)o0 + t, qv);     // the partner unit needs it for its copy of r
+      ps[tq] = pi;
+      qs[ob + tq] = qv;
+      coh_store(pnew + 6 * (size_t)o0 + tq, pi);
+      coh_store(d.q + 6 * (size_t)o0 + tq, qv);     // the partner unit needs it for its copy of r
       pq_t = pi * qv;
     }
     if (coarse) { __syncthreads(); coarse_restrict(qs + ob); }
     PERS_TICK(1)
     double pq = 0;
-    alive = pers_exchange(slots_pq, nwg, u, pq_t, false, ++epoch, a.bar + 1, red, &pq, ibuf + 2);
+    alive = pers_exchange(tq, slots_pq, nwg, u, pq_t, false, ++epoch, a.bar + 1, red, &pq, ibuf + 2);
     PERS_TICK(2)
     if (!alive) { fail = 1; break; }
-    const double q_partner = (t < m && !(t >= ob && t < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + t) : 0.0;
+    const double q_partner = (tq < m && !(tq >= ob && tq < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + tq) : 0.0;
     const double cg = coarse_gather();       // P^T q of every aggregate
     if (!(pq > 0.0)) { fail = 1; break; }   // not positive definite (or NaN): solver failure -> LM rejects the step
     PERS_TICK(3)
     const double alpha = pers_uniform(rz / pq);
-    if (t < mo) xs[t] += alpha * ps[t];
-    if (t < m) rc[t] -= alpha * ((t >= ob && t < ob + mo) ? qs[t] : q_partner);
-    if (coarse && t < nca) rco[t] -= alpha * cg;  // P^T r follows the recurrence of r: no second gather per iteration
+    if (tq < mo) xs[tq] += alpha * ps[tq];
+    if (tq < m) rc[tq] -= alpha * ((tq >= ob && tq < ob + mo) ? qs[tq] : q_partner);
+    if (coarse && tq < nca) rco[tq] -= alpha * cg;  // P^T r follows the recurrence of r: no second gather per iteration
     __syncthreads();
     const double rz_t2 = apply_W();
     PERS_TICK(4)
     rz_prev = rz;
-    alive = pers_exchange(slots_rz, nwg, u, rz_t2, false, ++epoch, a.bar + 1, red, &rz, ibuf + 2);
+    alive = pers_exchange(tq, slots_rz, nwg, u, rz_t2, false, ++epoch, a.bar + 1, red, &rz, ibuf + 2);
     PERS_TICK(5)
     if (!alive) { fail = 1; break; }
     PERS_TICK(6)
@@ -1877,7 +1896,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       // coarse level: aggregates of kAgg cameras; block lists of Ac = P^T S P
       if (!getenv("CCM_BA_NO_COARSE")) {
         const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
-        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && 4 * na <= grid) {
+        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && kAggUnits * na <= grid + kAggUnits - 1) {
           std::map<std::pair<int, int>, std::vector<int>> cb;
           for (int i = 0; i < Cp; i++) cb[{i / kAgg, i / kAgg}].push_back(i * 2);
           std::vector<int> bi(Cp + nOff), bj(Cp + nOff);
