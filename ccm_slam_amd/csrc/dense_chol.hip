@@ -95,29 +95,44 @@ __global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, do
   __shared__ double rdiag[NB];
   const int lane = threadIdx.x;
   double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
-  for (int e = lane; e < NB * NB; e += NB) { const int r = e / NB, c = e % NB; L[r * LR + c] = Ajj[(size_t)r * N + c]; }
+  {   // all 64 row loads in flight at once (a rolled loop pays the global latency 64 times)
+    double tmp[NB];
+#pragma unroll
+    for (int r = 0; r < NB; r++) tmp[r] = Ajj[(size_t)r * N + lane];
+#pragma unroll
+    for (int r = 0; r < NB; r++) L[r * LR + lane] = tmp[r];
+  }
   __syncthreads();
   int bad_col = 0;
   {
-    double row[NB];
+    double row[NB], cur[NB], nxt[NB];
 #pragma unroll
-    for (int k = 0; k < NB; k++) row[k] = L[lane * LR + k];
+    for (int k = 0; k < NB; k++) { row[k] = L[lane * LR + k]; cur[k] = 0.0; nxt[k] = 0.0; }
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NB; c++) {
-      const double* Lc = L + c * LR;                 // row c of L: entries k < c were written by lane c at columns k
-      double acc[4] = {row[c], 0.0, 0.0, 0.0};       // lane i: A_ic - sum_{k<c} L_ik L_ck
+      // cur[k] = L_ck (k < c), fetched during the previous column.  lane i: A_ic - sum_{k<c} L_ik L_ck
+      double acc[4] = {row[c], 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int k = 0; k < c; k++) acc[k & 3] -= row[k] * Lc[k];
+      for (int k = 0; k < c; k++) acc[k & 3] = __builtin_fma(-row[k], cur[k], acc[k & 3]);
+      // prefetch the old part of the NEXT pivot row (entries k < c were stored in earlier columns) so that the LDS
+      // latency overlaps the sqrt chain below; its newest entry L_{c+1,c} comes by v_readlane from lane c+1's register
+      if (c + 1 < NB) {
+#pragma unroll
+        for (int k = 0; k < c; k++) nxt[k] = L[(c + 1) * LR + k];
+      }
       const double sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       double dd = bcast64(sv, c);
       if (!(dd > 0.0)) { if (!bad_col) bad_col = c + 1; dd = 1.0; }
-      const double l = sqrt(dd), inv = 1.0 / l;
+      const double inv = rsqrt(dd), l = dd * inv;
       row[c] = (lane == c) ? l : sv * inv;           // lanes < c hold the (unused) upper part
-      L[lane * LR + c] = row[c];
+      L[lane * LR + c] = row[c];                     // no barrier: one wave, and LDS executes a wave's accesses in order
       if (lane == c) rdiag[c] = inv;
-      __syncthreads();
+      if (c + 1 < NB) nxt[c] = bcast64(row[c], c + 1);
+#pragma unroll
+      for (int k = 0; k <= c; k++) cur[k] = nxt[k];
     }
+    __syncthreads();
   }
   if (bad_col && lane == 0 && *info == 0) *info = j * NB + bad_col;
   double* Lg = Linv_all + (size_t)j * NB * NB;
@@ -129,15 +144,13 @@ __global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, do
       const double* Lrow = L + r * LR;
       double acc[4] = {(r == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int k = 0; k < r; k++) acc[k & 3] -= Lrow[k] * x[k];
+      for (int k = 0; k < r; k++) acc[k & 3] = __builtin_fma(-Lrow[k], x[k], acc[k & 3]);
       x[r] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[r];
       Lg[r * NB + lane] = x[r];
     }
   }
-  for (int e = lane; e < NB * NB; e += NB) {
-    const int r = e / NB, c = e % NB;
-    Ajj[(size_t)r * N + c] = (c <= r) ? L[r * LR + c] : 0.0;
-  }
+#pragma unroll
+  for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
 }
 
 // tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
