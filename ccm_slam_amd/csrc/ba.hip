@@ -114,6 +114,11 @@ struct BaDev {
   const int* inst_al;        // rank of inst_a's edge inside its camera's edge list (row-centric Schur kernel)
   const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
   int max_cam_edges;         // longest per-camera edge list on this rank
+  // row-centric Schur kernel: work units = (block, chunk of <= row_chunk consecutive pair instances), dealt to the waves
+  const int* unit_tab;       // [n_units][3]: block, first instance, end instance
+  const int* row_unit_off;   // [Cp+1] units of block row i
+  const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
+  int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]
@@ -366,50 +371,136 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // off-diagonal Schur blocks, row-centric: one workgroup per free camera i.  Y_e = W_e Dinv_l (6x3) of ALL observations of
 // camera i is formed once into LDS (the per-block kernel above re-reads W_a and Dinv and redoes the 6x3x3 product for
 // every pair instance: 336 B and 27 flops per instance instead of 152 B and 9), then the waves walk the blocks (i, j > i)
-// of the row and every instance costs one 144-byte W_c row read plus LDS.  Same arithmetic in the same order as
-// ba_schur_off, hence bit-identical blocks.                                                   [CCM_K_BA_SCHUR_OFF]
+// of the row and every instance costs one 144-byte W_c row read plus LDS.                [CCM_K_BA_SCHUR_OFF]
 constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
 constexpr int kRowTPB = 1024;        // 8 waves walk the row's blocks: the instance stream is latency bound, so more streams win
 __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
-  const int i = blockIdx.x;
+  // Workgroup b runs on XCD b % 8.  Every W_c row is read by ~3 block rows, and those are rows of covisible, i.e.
+  // neighbouring, keyframes: with row = blockIdx the neighbours sit on 8 different L2s and each fetches its own copy
+  // (PMC: 0.55-1.1 GB per launch for 137 MB of W — the kernel ran at the fabric's bandwidth, not on latency); here XCD x
+  // walks the contiguous row range [x * per, (x + 1) * per), so rows in flight on one L2 share their W_c rows.
+  const int per_xcd = gridDim.x >> 3;
+  const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (i >= d.Cp) return;
   const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
-  for (int t = threadIdx.x; t < ne * 6; t += kRowTPB) {
-    const int k = t / 6, r = t % 6;
-    const int e = d.cam_edge[base + k];
-    const double* Wa = d.W + 18 * (size_t)e + 3 * r;
-    const double* Di = d.Dinv + 6 * (size_t)d.ed_pt[e];
-    const double a0 = Wa[0], a1 = Wa[1], a2 = Wa[2];
-    Ys[t * 3 + 0] = a0 * Di[0] + a1 * Di[1] + a2 * Di[2];
-    Ys[t * 3 + 1] = a0 * Di[1] + a1 * Di[3] + a2 * Di[4];
-    Ys[t * 3 + 2] = a0 * Di[2] + a1 * Di[4] + a2 * Di[5];
+  // up to 4 (observation, row) items per thread with their three dependent load levels in flight together
+  for (int t0 = threadIdx.x; t0 < ne * 6; t0 += 4 * kRowTPB) {
+    int e[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int t = t0 + q * kRowTPB; e[q] = (t < ne * 6) ? d.cam_edge[base + t / 6] : -1; }
+    int pt[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pt[q] = (e[q] >= 0) ? d.ed_pt[e[q]] : 0;
+    double a[4][3], D[4][6];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = t0 + q * kRowTPB;
+      const double* Wa = d.W + 18 * (size_t)max(e[q], 0) + 3 * (t % 6);
+      const double* Di = d.Dinv + 6 * (size_t)pt[q];
+      a[q][0] = Wa[0]; a[q][1] = Wa[1]; a[q][2] = Wa[2];
+#pragma unroll
+      for (int z = 0; z < 6; z++) D[q][z] = Di[z];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = t0 + q * kRowTPB;
+      if (e[q] < 0) continue;
+      Ys[t * 3 + 0] = a[q][0] * D[q][0] + a[q][1] * D[q][1] + a[q][2] * D[q][2];
+      Ys[t * 3 + 1] = a[q][0] * D[q][1] + a[q][1] * D[q][3] + a[q][2] * D[q][4];
+      Ys[t * 3 + 2] = a[q][0] * D[q][2] + a[q][1] * D[q][4] + a[q][2] * D[q][5];
+    }
   }
+  if (threadIdx.x == 0) Ys[d.max_cam_edges * 18 + d.row_units_max * 36] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  if (lane >= 36) return;
-  const int r = lane / 6, c = lane % 6;
-  for (int b = d.rowblk_off[i] + wv; b < d.rowblk_off[i + 1]; b += kRowTPB / kWave) {
-    double acc = 0;
-    const int s1 = d.inst_off[b + 1];
-    int s = d.inst_off[b];
-    for (; s + 3 < s1; s += 4) {      // four instances in flight; the sums stay in instance order
-      double w[4][3];
-      const double* y[4];
+  // One wave per block.  S_ij = -[Y_a1 Y_a2 ...] [W_c1 W_c2 ...]^T is a 6 x 6 product with inner dimension 3 per pair
+  // instance: it goes through v_mfma_f64_16x16x4 with ONE instance per instruction (k = 0..2 the landmark axes, k = 3
+  // zero): A operand = Y (lane (i, k) = (lane & 15, lane >> 4) supplies Y[i][k]), B operand = W_c (lane (j, k) supplies
+  // W_c[j][k]).  Not for the flops — 14% of the tile is used — but for the LOAD count: with lane = output element every
+  // instance cost three 8-byte loads per lane from global and three from LDS, each operand fetched six times over, and
+  // the kernel sat on the CU's address path (330 us; deeper prefetch changed nothing); here every operand element is
+  // fetched once (18 lanes x 8 bytes per instance from each side).  The two index arrays are read 64 instances at a
+  // time, one per lane, and handed out by v_readlane; 8 instances are in flight.  Instance order is kept.
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  // TWO instances per MFMA: the even one in tile rows / columns 0..5, the odd one in 8..13 (they share only the k axis, so
+  // their products land in different 6x6 corners of D and the cross terms are ignored).  Measured: the f64 MFMA costs
+  // 64 cycles of its SIMD and a wave-wide load ~16 cycles of the CU's address path whatever it fetches, so per-instance
+  // instruction count, not bytes or latency, set the kernel's time (286 us with one instance per instruction, 203 us
+  // of it without the MFMA; forcing every W_c read into a 147 KB window changed nothing).
+  const int j = lane & 15, kq = lane >> 4;
+  const int odd = (j >> 3) & 1, jj = j & 7;
+  const bool on = jj < 6 && kq < 3;
+  const int woff = on ? 3 * jj + kq : 0;
+  const unsigned wbyte = 8u * (unsigned)woff;
+  double* part = Ys + (size_t)d.max_cam_edges * 18;
+  const int zslot = d.max_cam_edges * 18 + d.row_units_max * 36;   // one zero behind the partial sums
+  const int u_first = d.row_unit_off[i], u_last = d.row_unit_off[i + 1];
+  // Software pipeline over the wave's units: the table entry and the two index vectors of the NEXT unit (two dependent
+  // load levels) are requested before the W_c rows of the current one, so that a unit exposes one memory latency
+  // instead of three (a CU holds one workgroup = 16 waves here: nothing else hides them).
+  int u = u_first + wv;
+  int n = 0, ic = 0, ia = 0;
+  if (u < u_last) {
+    const int s0 = d.unit_tab[3 * u + 1];
+    n = d.unit_tab[3 * u + 2] - s0;
+    ic = (lane < n) ? d.inst_c[s0 + lane] : 0;
+    ia = (lane < n) ? d.inst_al[s0 + lane] : 0;
+  }
+  while (u < u_last) {
+    const int un = u + kRowTPB / kWave;
+    int nn = 0, icn = 0, ian = 0;
+    if (un < u_last) {
+      const int s0 = d.unit_tab[3 * un + 1];
+      nn = d.unit_tab[3 * un + 2] - s0;
+      icn = (lane < nn) ? d.inst_c[s0 + lane] : 0;
+      ian = (lane < nn) ? d.inst_al[s0 + lane] : 0;
+    }
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    int q0 = 0;
+    for (; q0 + 32 <= n; q0 += 32) {
+      double wv8[16], yv8[16];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const double* Wc = d.W + 18 * (size_t)d.inst_c[s + q] + 3 * c;
-        w[q][0] = Wc[0]; w[q][1] = Wc[1]; w[q][2] = Wc[2];
-        y[q] = Ys + (d.inst_al[s + q] * 6 + r) * 3;
+      for (int q = 0; q < 16; q++) {
+        const int ce = __builtin_amdgcn_readlane(ic, q0 + 2 * q), co = __builtin_amdgcn_readlane(ic, q0 + 2 * q + 1);
+        const int ae = __builtin_amdgcn_readlane(ia, q0 + 2 * q), ao = __builtin_amdgcn_readlane(ia, q0 + 2 * q + 1);
+        // switched-off lanes read an LDS zero for Y and any (finite) W: one select on a 32-bit LDS index instead of four
+        // on the operands; W is addressed as base + 32-bit byte offset (the launch checks 144 E < 2^32)
+        wv8[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(d.W) + (144u * (unsigned)(odd ? co : ce) + wbyte));
+        yv8[q] = Ys[on ? (odd ? ao : ae) * 18 + woff : zslot];
       }
 #pragma unroll
-      for (int q = 0; q < 4; q++) acc += y[q][0] * w[q][0] + y[q][1] * w[q][1] + y[q][2] * w[q][2];
+      for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
     }
-    for (; s < s1; s++) {
-      const double* Wc0 = d.W + 18 * (size_t)d.inst_c[s] + 3 * c;
-      const double* y0 = Ys + (d.inst_al[s] * 6 + r) * 3;
-      acc += y0[0] * Wc0[0] + y0[1] * Wc0[1] + y0[2] * Wc0[2];
+    for (; q0 < n; q0 += 2) {   // pairs; the odd half is switched off for a last single instance
+      const bool have_odd = q0 + 1 < n;
+      const int ce = __builtin_amdgcn_readlane(ic, q0), co = __builtin_amdgcn_readlane(ic, have_odd ? q0 + 1 : q0);
+      const int ae = __builtin_amdgcn_readlane(ia, q0), ao = __builtin_amdgcn_readlane(ia, have_odd ? q0 + 1 : q0);
+      const bool use = on && (!odd || have_odd);
+      const double wl = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(d.W) + (144u * (unsigned)(odd ? co : ce) + wbyte));
+      const double yl = Ys[use ? (odd ? ao : ae) * 18 + woff : zslot];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yl, wl, acc, 0, 0, 0);
     }
-    d.S[36 * (size_t)(d.Cp + b) + lane] = -acc;
+    // D register r of lane (j, kq) is D[kq + 4 r][j]: even instances in D[0..5][0..5] (r = 0, 1; j < 6), odd ones in
+    // D[8..13][8..13] (r = 2, 3; j = 8..13) -> added to the even sum of lane j - 8
+    const double b0 = __shfl_down(acc[2], 8, kWave), b1 = __shfl_down(acc[3], 8, kWave);
+    if (j < 6) {
+      double* pu = part + 36 * (size_t)(u - u_first);
+      pu[kq * 6 + j] = acc[0] + b0;
+      if (kq < 2) pu[(kq + 4) * 6 + j] = acc[1] + b1;
+    }
+    u = un; n = nn; ic = icn; ia = ian;
+  }
+  __syncthreads();
+  {
+    const int grp = threadIdx.x / 36, el = threadIdx.x % 36;
+    constexpr int kGroups = kRowTPB / 36;
+    if (grp < kGroups)
+      for (int b = d.rowblk_off[i] + grp; b < d.rowblk_off[i + 1]; b += kGroups) {
+        double sum = 0;
+        for (int u = d.blk_unit0[b]; u < d.blk_unit0[b + 1]; u++) sum += part[36 * (size_t)(u - u_first) + el];
+        d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
+      }
   }
 }
 
@@ -1849,6 +1940,38 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (int rc = dev_alloc<int>(ba, (size_t)std::max(Eloc, 1), &p_rank, false)) return fail(rc);
     if (int rc = dev_alloc<int>(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al, false)) return fail(rc);
     d.inst_al = p_al;
+    d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0;
+    if (nOff > 8192 && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 32)) {
+      std::vector<int> h_off((size_t)nOff + 1);
+      if (hipMemcpyAsync(h_off.data(), d_inst_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: instance offsets read-back"));
+      const size_t lds_free = 158 * 1024 - 16 - (size_t)d.max_cam_edges * 18 * sizeof(double);
+      const int units_cap = (int)(lds_free / (36 * sizeof(double)));
+      for (int chunk = kWave; chunk <= kWave && !d.row_units_max; chunk *= 2) {   // a unit = one 64-instance index vector
+        int worst = 0;
+        for (int i = 0; i < Cp; i++) {
+          int nu = 0;
+          for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) nu += std::max(1, ccm_div_up(h_off[b + 1] - h_off[b], chunk));
+          worst = std::max(worst, nu);
+        }
+        if (worst > units_cap) continue;
+        std::vector<int> tab, row_u(Cp + 1, 0), blk_u((size_t)nOff + 1, 0);
+        for (int i = 0; i < Cp; i++) {
+          for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) {
+            blk_u[b] = (int)tab.size() / 3;
+            int s0 = h_off[b];
+            do { const int s1 = std::min(h_off[b + 1], s0 + chunk); tab.push_back(b); tab.push_back(s0); tab.push_back(s1); s0 = s1; } while (s0 < h_off[b + 1]);
+          }
+          row_u[i + 1] = (int)tab.size() / 3;
+        }
+        blk_u[nOff] = (int)tab.size() / 3;
+        int *p_t = nullptr, *p_r = nullptr, *p_b = nullptr;
+        if (int rc = dev_upload(ba, tab, &p_t)) return fail(rc);
+        if (int rc = dev_upload(ba, row_u, &p_r)) return fail(rc);
+        if (int rc = dev_upload(ba, blk_u, &p_b)) return fail(rc);
+        d.unit_tab = p_t; d.row_unit_off = p_r; d.blk_unit0 = p_b; d.row_units_max = std::max(worst, 1);
+      }
+    }
     if (Cp) hipLaunchKernelGGL(ba_edge_rank, dim3(Cp), dim3(kTPB), 0, ctx->stream, d, p_rank);
     if (ba->n_inst) hipLaunchKernelGGL(ba_inst_rank, dim3(ccm_div_up(ba->n_inst, kTPB)), dim3(kTPB), 0, ctx->stream, d.inst_a, (const int*)p_rank, (int)ba->n_inst, p_al);
   }
@@ -2076,11 +2199,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
-      else if (d.max_cam_edges <= kRowMaxEdges) {
-        const size_t lds_row = (size_t)d.max_cam_edges * 18 * sizeof(double);
+      else if (d.row_units_max) {
+        const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * 36 + 2) * sizeof(double);
         static bool attr_row = false;
-        if (!attr_row) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, kRowMaxEdges * 18 * (int)sizeof(double))); attr_row = true; }
-        hipLaunchKernelGGL(ba_schur_row, dim3(d.Cp), dim3(kRowTPB), lds_row, ctx->stream, d);
+        if (!attr_row) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr_row = true; }
+        hipLaunchKernelGGL(ba_schur_row, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
