@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   double* rco = ainv_l + 6 * Nc;             // [Nc]
   double* pown = rco + Nc;                   // [8][36]
   double* ypart = pown + 8 * 36;             // [6]
-  const int agg = c / (kAgg / kClu);         // aggregate of the unit's cluster
+  const int agg = u / kAggUnits;             // aggregate of the unit's cameras (kAgg is a multiple of the 8 cameras of a unit)
   if (coarse) {
     for (int e = t; e < 6 * Nc; e += kPersTPB) ainv_l[e] = has ? a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0;
     for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;

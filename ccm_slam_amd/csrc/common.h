@@ -61,7 +61,22 @@ int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out);
 int ccm_pool_get(ccm_ctx* ctx, size_t bytes, void** out, size_t* actual);
 void ccm_pool_put(ccm_ctx* ctx, void* p, size_t actual);
 // dense_chol.hip: SPD solve on the device (N multiple of 64, padding = identity), see the definition for the contract
-int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info);
+// Tile-level sparsity of a dense SPD system (64 x 64 tiles): which tiles of L can be non-zero, after symbolic fill.  The
+// factorisation and the substitutions then touch only those (pose graphs are near-banded: a few tiles per tile row).
+// Lists live on the device, the offsets also on the host (grid sizes).  nullptr plan = every lower tile.
+struct ccm_tile_plan {
+  int T = 0;
+  std::vector<int> h_col_off;    // [T+1] rows i > j with L_ij != 0 (panel of step j; forward substitution)
+  std::vector<int> h_upd_off;    // [T+1] pairs (i >= k) of those rows (trailing update of step j), packed i << 16 | k
+  std::vector<int> h_row_off;    // [T+1] columns k < j with L_jk != 0 (backward substitution)
+  const int* d_col_rows = nullptr;
+  const int* d_upd_pairs = nullptr;
+  const int* d_row_cols = nullptr;
+};
+// nz: T x T row-major flags of the lower triangle of A (tile (i, j), i >= j, non-zero); returns the host-side lists
+void ccm_tile_plan_symbolic(int T, const std::vector<char>& nz, ccm_tile_plan* plan, std::vector<int>* col_rows, std::vector<int>* upd_pairs,
+                            std::vector<int>* row_cols);
+int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info, const ccm_tile_plan* plan = nullptr);
 int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv, double* d_X, double* d_Ainv, int* d_info);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 

@@ -3,7 +3,7 @@
 // Levenberg-Marquardt path needs the step exact, and the matrix is small enough (<= ~2 GB) to treat densely.
 //
 // Blocked right-looking factorisation with 64x64 tiles, row-major lower triangle in place:
-//   chol_diag   (1 workgroup)      L_jj = chol(A_jj) in LDS, Li_jj = L_jj^-1 kept for the panel and the solves
+//   chol_diag_wave (1 wave)        L_jj = chol(A_jj), Li_jj = L_jj^-1 kept for the panel and the solves
 //   chol_panel  (1 wg / tile row)  L_ij = A_ij Li_jj^T                     } one 64x64x64 product per workgroup on the
 //   chol_update (1 wg / tile pair) A_ik -= L_ij L_kj^T  (i >= k > j)       } f64 matrix cores (v_mfma_f64_16x16x4_f64)
 // then tile-wise forward / backward substitution.  MFMA operand layout (guide, "f64 MFMA does NOT use these maps"):
@@ -37,48 +37,9 @@ __device__ __forceinline__ void load_tile(double* dst, const double* src, int ld
   for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[r * LD + c] = src[(size_t)r * ld_src + c]; }
 }
 
-// L_jj and its inverse.  info: first failing global column + 1, like LAPACK
-__global__ __launch_bounds__(kTPB) void chol_diag(double* A, int N, int j, double* Linv_all, int* info) {
-  __shared__ double L[NB * LD], Li[NB * LD];
-  const int t = threadIdx.x;
-  double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
-  load_tile(L, Ajj, N);
-  for (int e = t; e < NB * LD; e += kTPB) Li[e] = 0;
-  __syncthreads();
-  for (int c = 0; c < NB; c++) {
-    if (t == 0) {
-      const double d = L[c * LD + c];
-      if (!(d > 0.0)) { if (*info == 0) *info = j * NB + c + 1; L[c * LD + c] = 1.0; } else L[c * LD + c] = sqrt(d);
-    }
-    __syncthreads();
-    const double dinv = 1.0 / L[c * LD + c];
-    for (int r = c + 1 + t; r < NB; r += kTPB) L[r * LD + c] *= dinv;
-    __syncthreads();
-    const int nr = NB - c - 1;
-    for (int e = t; e < nr * nr; e += kTPB) {
-      const int r = c + 1 + e / nr, cc = c + 1 + e % nr;
-      if (cc <= r) L[r * LD + cc] -= L[r * LD + c] * L[cc * LD + c];
-    }
-    __syncthreads();
-  }
-  if (t < NB) {   // column t of L^-1 by forward substitution
-    for (int r = t; r < NB; r++) {
-      double s = (r == t) ? 1.0 : 0.0;
-      for (int k = t; k < r; k++) s -= L[r * LD + k] * Li[k * LD + t];
-      Li[r * LD + t] = s / L[r * LD + r];
-    }
-  }
-  __syncthreads();
-  double* Lg = Linv_all + (size_t)j * NB * NB;
-  for (int e = t; e < NB * NB; e += kTPB) {
-    const int r = e / NB, c = e % NB;
-    Ajj[(size_t)r * N + c] = (c <= r) ? L[r * LD + c] : 0.0;
-    Lg[e] = Li[r * LD + c];
-  }
-}
-
-// Single-wave variant of chol_diag for latency-critical small systems (the coarse level of the BA preconditioner is
-// re-inverted for every LM trial).  The block version above spends three block barriers per column (~130 us per tile).
+// L_jj and its inverse (info: first failing global column + 1, like LAPACK) by ONE wave: the diagonal tile is the serial
+// link of the factorisation (the coarse level of the BA preconditioner is re-inverted for every LM trial, the pose-graph
+// system has up to 219 of them per factorisation).  A 256-thread version with three block barriers per column took ~130 us per tile.
 // Measured alternatives with one wave: tile in registers and every multiplier travelling by v_readlane, 88 us; tile in
 // LDS, left-looking, two LDS reads per term, 96 us (nothing hides the LDS latency of a lone wave).  This one keeps lane
 // i's ROW in registers and reads only the pivot row from LDS (uniform address = broadcast, two doubles per read), so a
@@ -154,9 +115,9 @@ __global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, do
 }
 
 // tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
-__global__ __launch_bounds__(kTPB) void chol_panel(double* A, int N, int j, const double* Linv_all) {
+__global__ __launch_bounds__(kTPB) void chol_panel(double* A, int N, int j, const double* Linv_all, const int* rows /* nullptr: all rows below j */) {
   __shared__ double As[NB * LD], Bs[NB * LD];
-  const int i = j + 1 + blockIdx.x;
+  const int i = rows ? rows[blockIdx.x] : j + 1 + blockIdx.x;
   double* Aij = A + ((size_t)i * NB) * N + (size_t)j * NB;
   load_tile(As, Aij, N);
   load_tile(Bs, Linv_all + (size_t)j * NB * NB, NB);
@@ -171,14 +132,18 @@ __global__ __launch_bounds__(kTPB) void chol_panel(double* A, int N, int j, cons
 }
 
 // trailing update: pair index p -> (i, k) with i >= k > j;  A_ik -= L_ij L_kj^T
-__global__ __launch_bounds__(kTPB) void chol_update(double* A, int N, int j) {
+__global__ __launch_bounds__(kTPB) void chol_update(double* A, int N, int j, const int* pairs /* nullptr: every pair below j */) {
   __shared__ double As[NB * LD], Bs[NB * LD];
   const int p = blockIdx.x;
-  int ii = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
-  while (ii * (ii + 1) / 2 > p) ii--;
-  while ((ii + 1) * (ii + 2) / 2 <= p) ii++;
-  const int kk = p - ii * (ii + 1) / 2;
-  const int i = j + 1 + ii, k = j + 1 + kk;
+  int i, k;
+  if (pairs) { i = pairs[p] >> 16; k = pairs[p] & 0xffff; }
+  else {
+    int ii = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while (ii * (ii + 1) / 2 > p) ii--;
+    while ((ii + 1) * (ii + 2) / 2 <= p) ii++;
+    const int kk = p - ii * (ii + 1) / 2;
+    i = j + 1 + ii; k = j + 1 + kk;
+  }
   load_tile(As, A + ((size_t)i * NB) * N + (size_t)j * NB, N);
   load_tile(Bs, A + ((size_t)k * NB) * N + (size_t)j * NB, N);
   __syncthreads();
@@ -205,19 +170,19 @@ __global__ __launch_bounds__(NB) void chol_solve_diag(double* b, int j, const do
   b[(size_t)j * NB + t] = s;
 }
 // forward: b_i -= L_ij y_j (i > j) ; backward: b_k -= L_jk^T x_j (k < j);  one workgroup per tile
-__global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, double* b, int j, int transpose) {
+__global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, double* b, int j, int transpose, const int* list /* nullptr: all */) {
   __shared__ double v[NB];
   const int t = threadIdx.x;
   v[t] = b[(size_t)j * NB + t];
   __syncthreads();
   double s = 0;
   if (!transpose) {
-    const int i = j + 1 + blockIdx.x;
+    const int i = list ? list[blockIdx.x] : j + 1 + blockIdx.x;
     const double* Lij = A + ((size_t)i * NB + t) * N + (size_t)j * NB;
     for (int k = 0; k < NB; k++) s += Lij[k] * v[k];
     b[(size_t)i * NB + t] -= s;
   } else {
-    const int k = blockIdx.x;
+    const int k = list ? list[blockIdx.x] : blockIdx.x;
     const double* Ljk = A + ((size_t)j * NB) * N + (size_t)k * NB + t;
     for (int r = 0; r < NB; r++) s += Ljk[(size_t)r * N] * v[r];
     b[(size_t)k * NB + t] -= s;
@@ -300,28 +265,64 @@ __global__ __launch_bounds__(kTPB) void chol_xtx(const double* X, int N, double*
 // Solves A x = b for a symmetric positive definite A.  d_A: N x N row-major with N = n rounded up to 64 (ccm_dense_padded)
 // and the padding rows / columns already set to the identity; only the lower triangle is read; destroyed.  d_b: [N], in: rhs,
 // out: x.  d_linv: scratch [N/64][64*64].  d_info: device int, set to (first non-positive pivot + 1) or left 0.
-int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info) {
+int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info, const ccm_tile_plan* plan) {
   if (N % NB) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: N must be a multiple of 64");
   const int T = N / NB;
+  if (plan && (plan->T != T || T >= 65536)) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: tile plan does not match");
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag, dim3(1), dim3(kTPB), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(64), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    if (plan) {
+      const int nr = plan->h_col_off[j + 1] - plan->h_col_off[j], np = plan->h_upd_off[j + 1] - plan->h_upd_off[j];
+      if (nr) hipLaunchKernelGGL(chol_panel, dim3(nr), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, plan->d_col_rows + plan->h_col_off[j]);
+      if (np) hipLaunchKernelGGL(chol_update, dim3(np), dim3(kTPB), 0, ctx->stream, d_A, N, j, plan->d_upd_pairs + plan->h_upd_off[j]);
+      continue;
+    }
     const int rem = T - j - 1;
     if (rem > 0) {
-      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv);
-      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j);
+      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, (const int*)nullptr);
+      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const int*)nullptr);
     }
   }
   for (int j = 0; j < T; j++) {
     hipLaunchKernelGGL(chol_solve_diag, dim3(1), dim3(NB), 0, ctx->stream, d_b, j, (const double*)d_linv, 0);
-    if (T - j - 1 > 0) hipLaunchKernelGGL(chol_solve_update, dim3(T - j - 1), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 0);
+    if (plan) {
+      const int nr = plan->h_col_off[j + 1] - plan->h_col_off[j];
+      if (nr) hipLaunchKernelGGL(chol_solve_update, dim3(nr), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 0, plan->d_col_rows + plan->h_col_off[j]);
+    } else if (T - j - 1 > 0) hipLaunchKernelGGL(chol_solve_update, dim3(T - j - 1), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 0, (const int*)nullptr);
   }
   for (int j = T - 1; j >= 0; j--) {
     hipLaunchKernelGGL(chol_solve_diag, dim3(1), dim3(NB), 0, ctx->stream, d_b, j, (const double*)d_linv, 1);
-    if (j > 0) hipLaunchKernelGGL(chol_solve_update, dim3(j), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 1);
+    if (plan) {
+      const int nc = plan->h_row_off[j + 1] - plan->h_row_off[j];
+      if (nc) hipLaunchKernelGGL(chol_solve_update, dim3(nc), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 1, plan->d_row_cols + plan->h_row_off[j]);
+    } else if (j > 0) hipLaunchKernelGGL(chol_solve_update, dim3(j), dim3(NB), 0, ctx->stream, (const double*)d_A, N, d_b, j, 1, (const int*)nullptr);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
+}
+
+// Symbolic tile factorisation: eliminating tile column j connects every pair of rows below it.
+void ccm_tile_plan_symbolic(int T, const std::vector<char>& nz_in, ccm_tile_plan* plan, std::vector<int>* col_rows, std::vector<int>* upd_pairs,
+                            std::vector<int>* row_cols) {
+  std::vector<char> nz = nz_in;
+  plan->T = T;
+  plan->h_col_off.assign(1, 0); plan->h_upd_off.assign(1, 0); plan->h_row_off.assign(1, 0);
+  col_rows->clear(); upd_pairs->clear(); row_cols->clear();
+  std::vector<int> rows;
+  for (int j = 0; j < T; j++) {
+    rows.clear();
+    for (int i = j + 1; i < T; i++) if (nz[(size_t)i * T + j]) rows.push_back(i);
+    for (int i : rows) col_rows->push_back(i);
+    for (size_t a = 0; a < rows.size(); a++)
+      for (size_t b = 0; b <= a; b++) { nz[(size_t)rows[a] * T + rows[b]] = 1; upd_pairs->push_back((rows[a] << 16) | rows[b]); }
+    plan->h_col_off.push_back((int)col_rows->size());
+    plan->h_upd_off.push_back((int)upd_pairs->size());
+  }
+  for (int j = 0; j < T; j++) {
+    for (int k = 0; k < j; k++) if (nz[(size_t)j * T + k]) row_cols->push_back(k);
+    plan->h_row_off.push_back((int)row_cols->size());
+  }
 }
 
 // Test hook: host matrix (n x n row-major, symmetric positive definite) and rhs in, solution out.
@@ -362,8 +363,8 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
     hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(64), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     const int rem = T - j - 1;
     if (rem > 0) {
-      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv);
-      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j);
+      hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, (const int*)nullptr);
+      hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const int*)nullptr);
     }
   }
   hipLaunchKernelGGL(chol_tri_inverse, dim3(T), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X);

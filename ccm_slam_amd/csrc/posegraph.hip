@@ -777,12 +777,27 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   const int N_dense = (int)((n_dense + 63) / 64) * 64;
   const bool use_dense = !(solver_env && !strcmp(solver_env, "pcg")) && n_dense <= 24000;
   double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
+  ccm_tile_plan plan;
   if (use_dense) {
     std::vector<int> ka(nBlk), kb(nBlk);
     for (int k = 0; k < nBlk; k++) { ka[k] = keys[k].first; kb[k] = keys[k].second; }
     PG_RC(up(ctx, allocs, ka, &d_blk_a)); PG_RC(up(ctx, allocs, kb, &d_blk_b));
     PG_RC(al(ctx, allocs, (size_t)N_dense * N_dense, &d_A)); PG_RC(al(ctx, allocs, (size_t)N_dense, &d_rhs)); PG_RC(al(ctx, allocs, 4, &d_info));
     PG_RC(al(ctx, allocs, (size_t)N_dense * 64, &d_linv));
+    // tile-level sparsity: the essential graph is a near-banded chain plus loop edges, so most 64x64 tiles of the factor
+    // stay zero; the factorisation and the substitutions visit only the tiles a symbolic elimination marks
+    const int T = N_dense / 64;
+    std::vector<char> nz((size_t)T * T, 0);
+    for (int t = 0; t < T; t++) nz[(size_t)t * T + t] = 1;
+    for (int k = 0; k < nBlk; k++) {
+      const int a0 = 7 * ka[k] / 64, a1 = (7 * ka[k] + 6) / 64, b0 = 7 * kb[k] / 64, b1 = (7 * kb[k] + 6) / 64;
+      for (int ta = a0; ta <= a1; ta++) for (int tb = b0; tb <= b1; tb++) { nz[(size_t)std::max(ta, tb) * T + std::min(ta, tb)] = 1; }
+    }
+    std::vector<int> col_rows, upd_pairs, row_cols;
+    ccm_tile_plan_symbolic(T, nz, &plan, &col_rows, &upd_pairs, &row_cols);
+    int *p_cr = nullptr, *p_up = nullptr, *p_rc = nullptr;
+    PG_RC(up(ctx, allocs, col_rows, &p_cr)); PG_RC(up(ctx, allocs, upd_pairs, &p_up)); PG_RC(up(ctx, allocs, row_cols, &p_rc));
+    plan.d_col_rows = p_cr; plan.d_upd_pairs = p_up; plan.d_row_cols = p_rc;
   }
   d.use_tree = use_tree ? 1 : 0;
   if (use_tree) {
@@ -851,7 +866,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
         hipMemsetAsync(d_A, 0, (size_t)N_dense * N_dense * sizeof(double), ctx->stream);
         hipLaunchKernelGGL(pg_dense_fill, dim3(ccm_div_up(std::max(nBlk * 49, N_dense), kTPB)), dim3(kTPB), 0, ctx->stream, d, d_blk_a, d_blk_b, d_A, d_rhs,
                            lambda, N_dense);
-        if ((rc = ccm_dense_chol_solve_dev(ctx, d_A, N_dense, d_rhs, d_linv, d_info))) break;
+        if ((rc = ccm_dense_chol_solve_dev(ctx, d_A, N_dense, d_rhs, d_linv, d_info, getenv("CCM_PG_DENSE_FULL") ? nullptr : &plan))) break;
         if (hipMemcpyAsync(d.x, d_rhs, n_dense * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
           rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: dense solve readback"); break;
