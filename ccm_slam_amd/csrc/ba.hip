@@ -873,7 +873,7 @@ __global__ void ba_coarse_pad(double* Ac, int nc, int Nc) {
   if (i < Nc) Ac[(size_t)i * Nc + i] = 1.0;
 }
 
-// ---- persistent PCG: the WHOLE solve of one LM trial in one cooperative launch ---------------------------------
+// ---- persistent PCG: the WHOLE solve of one LM trial in one launch of co-resident workgroups -------------------
 // The multi-kernel iteration above costs two launches (~22 us on gba_c4) for ~15 MB of traffic: launch gaps and the
 // dependent index -> block -> vector chains dominate, not HBM.  Here one 16-wave workgroup OWNS one preconditioner
 // cluster (16 cameras) for the entire solve:
@@ -2034,7 +2034,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
   if (int rc = dev_alloc<double>(ba, 3 * (size_t)std::max(Lp, 1), &ba->d_pt_full)) return fail(rc);
   if (int rc = dev_alloc<double>(ba, 36 * (size_t)std::max(Cp, 1), &ba->d_hpp_full)) return fail(rc);
-  // persistent single-launch PCG: usable when every cluster's workgroup can be co-resident (cooperative launch)
+  // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device
   ba->pers_grid = 0;
   if (pers_fits && !getenv("CCM_BA_NO_PERSIST")) {
     const int n_clu = ccm_div_up(Cp, kClu);
@@ -2266,7 +2266,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     } else {
     bool persist_ok = false;
     if (ba->pers_grid) {
-      // whole solve in one cooperative launch; flags are read back together with the trial scalars
+      // whole solve in one launch; flags are read back together with the trial scalars
       CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pers_bar, 0, 4 * sizeof(unsigned), ctx->stream));
       PersArgs pa;
       pa.lambda = lambda; pa.rel_tol = tol; pa.max_it = max_it; pa.n_clu = ccm_div_up(d.Cp, kClu);

@@ -194,3 +194,25 @@ def test_coarse_level_matches_its_definition(ctx, oracle_lib):
     ref = Pd.T @ H @ Pd
     assert np.abs(Ac - ref).max() <= 1e-9 * np.abs(ref).max()
     assert np.abs(Ai @ ref - np.eye(6 * na)).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["always", "never", "adaptive"])
+def test_preconditioner_modes_agree_with_the_oracle(ctx, oracle_lib, mode, monkeypatch):
+    """The coarse level of the persistent PCG only changes how fast the reduced system is solved (relative residual
+    1e-8), never what is solved: forced on, forced off and switched adaptively the optimiser follows the oracle's LM
+    path to the same tolerances.  3 agents x 60 keyframes = 179 free cameras (persistent kernel, 6 aggregates)."""
+    monkeypatch.setenv("CCM_BA_COARSE", mode)
+    prob = synth.make_ba_problem(n_agents=3, kfs_per_agent=60, n_points=6000, seed=11)
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(6)
+    cam, pts, _, _ = h.download()
+    h.close()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 6)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
+    if mode == "always":
+        assert st.pcg_iters > 0
