@@ -1741,6 +1741,7 @@ struct ccm_ba {
   // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
   // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
   bool coarse_active = false, coarse_used = false;
+  double* h_rb = nullptr;    // pinned: [4 scalars | 4 flags] of a trial
   int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
   double* d_cparts = nullptr;
@@ -2025,10 +2026,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
   d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
   AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
-  AL(pcg_scal, 4, double) AL(pcg_flag, 4, int)
+  AL(pcg_scal, 4, double)
   AL(edge_chi2, Eloc, double) AL(edge_depth, Eloc, uint8_t)
-  AL(part_pt, 2 * (size_t)d.n_wg_pt, double) AL(part_cam, d.n_wg_cam, double) AL(scal, 4, double)
+  AL(part_pt, 2 * (size_t)d.n_wg_pt, double) AL(part_cam, d.n_wg_cam, double) AL(scal, 6, double)
 #undef AL
+  d.pcg_flag = reinterpret_cast<int*>(d.scal + 4);   // [scalars | PCG flags]: one 48-byte read-back per LM trial
+  if (hipHostMalloc(&ba->h_rb, 64, hipHostMallocDefault) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer"));
   ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
   if (int rc = dev_alloc<double>(ba, ba->red_count, &ba->d_red)) return fail(rc);
   d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
@@ -2098,6 +2101,7 @@ extern "C" void ccm_ba_destroy(ccm_ba* ba) {
   if (!ba) return;
   if (ba->ctx) { hipSetDevice(ba->ctx->device); hipStreamSynchronize(ba->ctx->stream); }
   for (auto& pr : ba->allocs) ccm_pool_put(ba->ctx, pr.first, pr.second);
+  if (ba->h_rb) hipHostFree(ba->h_rb);
   delete ba;
 }
 
@@ -2138,10 +2142,14 @@ extern "C" int ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t*
 
 namespace {
 
-int read_scalars(ccm_ba* ba, double out[4]) {
+// the trial scalars and the PCG flags in ONE copy into pinned memory (a pageable destination is staged by the runtime:
+// the two copies + syncs of a trial used to leave the GPU idle for ~90 us)
+int read_scalars(ccm_ba* ba, double out[4], int flags[4] = nullptr) {
   ccm_ctx* ctx = ba->ctx;
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, ba->d.scal, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->h_rb, ba->d.scal, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(out, ba->h_rb, 4 * sizeof(double));
+  if (flags) memcpy(flags, ba->h_rb + 4, 4 * sizeof(int));
   return CCM_OK;
 }
 
@@ -2348,9 +2356,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
   RC(ccm_allreduce_f64(ctx, d.scal, 2));
-  if (small_path) CCM_HIP_CHECK(ctx, hipMemcpyAsync(small_flags, d.pcg_flag, sizeof(small_flags), hipMemcpyDeviceToHost, ctx->stream));
   double s[4];
-  RC(read_scalars(ba, s));
+  RC(read_scalars(ba, s, small_flags));
   CCM_HIP_CHECK(ctx, hipGetLastError());
   if (small_path && ba->pers_grid && small_flags[3]) {   // the persistent kernel could not hold its grid exchange: never again on this handle
     ba->pers_grid = 0;
