@@ -193,70 +193,80 @@ __global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, 
 __device__ __forceinline__ void load_tile_t(double* dst, const double* src, int ld_src) {
   for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[c * LD + r] = src[(size_t)r * ld_src + c]; }
 }
-__device__ __forceinline__ void store_acc(double* dst, int ld, const v4d acc[4], int wave, int lane, double sign) {
-#pragma unroll
-  for (int s = 0; s < 4; s++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) dst[(size_t)(16 * wave + (lane >> 4) + 4 * r) * ld + 16 * s + (lane & 15)] = sign * acc[s][r];
+
+// D(64x16) = As(64x64) * Bs(16x64)^T: wave w owns rows 16w..16w+15
+__device__ __forceinline__ void tile_abt16(const double* As, const double* Bs, v4d& acc, int wave, int lane) {
+  const int i = lane & 15, kq = lane >> 4;
+#pragma unroll 4
+  for (int kk = 0; kk < NB / 4; kk++) {
+    const int k = 4 * kk + kq;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * wave + i) * LD + k], Bs[i * LD + k], acc, 0, 0, 0);
+  }
+}
+// strip of 16 columns of a tile, transposed: dst[c][r] = src[r][c0 + c]
+__device__ __forceinline__ void load_strip_t(double* dst, const double* src, int ld_src) {
+  for (int e = threadIdx.x; e < NB * 16; e += kTPB) { const int r = e / 16, c = e % 16; dst[c * LD + r] = src[(size_t)r * ld_src + c]; }
 }
 
-// X = L^-1 (lower triangular, tiles in X's lower triangle): workgroup j owns block column j and walks down it,
-// X_jj = Li_jj, X_ij = -Li_ii * sum_{k=j}^{i-1} L_ik X_kj   (every X_kj it needs is its own earlier output)
+// X = L^-1 (lower triangular, tiles in X's lower triangle): workgroup (j, s) owns the 16-column strip s of block column j and
+// walks down it, X_jj = Li_jj, X_ij = -Li_ii * sum_{k=j}^{i-1} L_ik X_kj   (every X_kj it needs is its own earlier
+// output).  The walk is a chain of dependent 64x64 products (20 for the first column of a 6-tile matrix); the strips
+// divide the MFMA work of each link by four.
 __global__ __launch_bounds__(kTPB) void chol_tri_inverse(const double* A, int N, const double* Linv_all, double* X) {
-  __shared__ double As[NB * LD], Bs[NB * LD];
-  const int j = blockIdx.x, T = N / NB;
+  __shared__ double As[NB * LD], Bs[16 * LD];
+  const int j = blockIdx.x, c0 = 16 * blockIdx.y, T = N / NB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int e = threadIdx.x; e < NB * NB; e += kTPB) X[((size_t)j * NB + e / NB) * N + (size_t)j * NB + e % NB] = Linv_all[(size_t)j * NB * NB + e];
+  const int i16 = lane & 15, kq = lane >> 4;
+  for (int e = threadIdx.x; e < NB * 16; e += kTPB) { const int r = e / 16, c = e % 16; X[((size_t)j * NB + r) * N + (size_t)j * NB + c0 + c] = Linv_all[(size_t)j * NB * NB + r * NB + c0 + c]; }
   __threadfence_block();
   __syncthreads();
   for (int i = j + 1; i < T; i++) {
-    v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4d acc = {0, 0, 0, 0};
     for (int k = j; k < i; k++) {
-      load_tile(As, A + ((size_t)i * NB) * N + (size_t)k * NB, N);                 // L_ik
-      load_tile_t(Bs, X + ((size_t)k * NB) * N + (size_t)j * NB, N);               // X_kj^T  => As * Bs^T = L_ik X_kj
+      load_tile(As, A + ((size_t)i * NB) * N + (size_t)k * NB, N);                        // L_ik
+      load_strip_t(Bs, X + ((size_t)k * NB) * N + (size_t)j * NB + c0, N);                // strip of X_kj, transposed
       __syncthreads();
-      tile_abt(As, Bs, acc, wave, lane);
+      tile_abt16(As, Bs, acc, wave, lane);
       __syncthreads();
     }
     // Bs <- acc^T (so that Li_ii * acc = As * Bs^T), As <- Li_ii
 #pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) Bs[(16 * s + (lane & 15)) * LD + 16 * wave + (lane >> 4) + 4 * r] = acc[s][r];
+    for (int r = 0; r < 4; r++) Bs[i16 * LD + 16 * wave + kq + 4 * r] = acc[r];
     load_tile(As, Linv_all + (size_t)i * NB * NB, NB);
     __syncthreads();
-    v4d out[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    tile_abt(As, Bs, out, wave, lane);
-    store_acc(X + ((size_t)i * NB) * N + (size_t)j * NB, N, out, wave, lane, -1.0);
+    v4d out = {0, 0, 0, 0};
+    tile_abt16(As, Bs, out, wave, lane);
+#pragma unroll
+    for (int r = 0; r < 4; r++) X[((size_t)i * NB + 16 * wave + kq + 4 * r) * N + (size_t)j * NB + c0 + i16] = -out[r];
     __threadfence_block();
     __syncthreads();
   }
 }
 
-// Ainv = X^T X: tile (p, q), p >= q: sum_{k >= p} X_kp^T X_kq ; mirrored into (q, p)
+// Ainv = X^T X: strip s (16 columns) of tile (p, q), p >= q: sum_{k >= p} X_kp^T X_kq ; mirrored into (q, p)
 __global__ __launch_bounds__(kTPB) void chol_xtx(const double* X, int N, double* Ainv) {
-  __shared__ double As[NB * LD], Bs[NB * LD];
+  __shared__ double As[NB * LD], Bs[16 * LD];
   const int T = N / NB;
-  const int pi = blockIdx.x;
+  const int pi = blockIdx.x, c0 = 16 * blockIdx.y;
   int p = (int)((sqrtf(8.0f * (float)pi + 1.0f) - 1.0f) * 0.5f);
   while (p * (p + 1) / 2 > pi) p--;
   while ((p + 1) * (p + 2) / 2 <= pi) p++;
   const int q = pi - p * (p + 1) / 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  const int i16 = lane & 15, kq = lane >> 4;
+  v4d acc = {0, 0, 0, 0};
   for (int k = p; k < T; k++) {
-    load_tile_t(As, X + ((size_t)k * NB) * N + (size_t)p * NB, N);   // X_kp^T
-    load_tile_t(Bs, X + ((size_t)k * NB) * N + (size_t)q * NB, N);   // X_kq^T  => As * Bs^T = X_kp^T X_kq
+    load_tile_t(As, X + ((size_t)k * NB) * N + (size_t)p * NB, N);            // X_kp^T
+    load_strip_t(Bs, X + ((size_t)k * NB) * N + (size_t)q * NB + c0, N);      // strip of X_kq, transposed => As * Bs^T = X_kp^T X_kq[:, strip]
     __syncthreads();
-    tile_abt(As, Bs, acc, wave, lane);
+    tile_abt16(As, Bs, acc, wave, lane);
     __syncthreads();
   }
-  store_acc(Ainv + ((size_t)p * NB) * N + (size_t)q * NB, N, acc, wave, lane, 1.0);
-  if (p != q) {
 #pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) Ainv[((size_t)q * NB + 16 * s + (lane & 15)) * N + (size_t)p * NB + 16 * wave + (lane >> 4) + 4 * r] = acc[s][r];
+  for (int r = 0; r < 4; r++) {
+    const int row = 16 * wave + kq + 4 * r, col = c0 + i16;
+    Ainv[((size_t)p * NB + row) * N + (size_t)q * NB + col] = acc[r];
+    if (p != q) Ainv[((size_t)q * NB + col) * N + (size_t)p * NB + row] = acc[r];
   }
 }
 
@@ -367,8 +377,8 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
       hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const int*)nullptr);
     }
   }
-  hipLaunchKernelGGL(chol_tri_inverse, dim3(T), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X);
-  hipLaunchKernelGGL(chol_xtx, dim3(T * (T + 1) / 2), dim3(kTPB), 0, ctx->stream, (const double*)d_X, N, d_Ainv);
+  hipLaunchKernelGGL(chol_tri_inverse, dim3(T, NB / 16), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X);
+  hipLaunchKernelGGL(chol_xtx, dim3(T * (T + 1) / 2, NB / 16), dim3(kTPB), 0, ctx->stream, (const double*)d_X, N, d_Ainv);
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
 }
