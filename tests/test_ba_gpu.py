@@ -216,3 +216,28 @@ def test_preconditioner_modes_agree_with_the_oracle(ctx, oracle_lib, mode, monke
     assert np.abs(pts - opts).max() <= 1e-4
     if mode == "always":
         assert st.pcg_iters > 0
+
+
+@pytest.mark.gpu
+def test_config5_10k_keyframes_multi_kernel_path(ctx, oracle_lib):
+    """BASELINE config 5 at full size (8 agents, 10 000 KFs / 300k landmarks / ~1.9M observations): above 2048 free
+    cameras the reduced system is solved by the multi-kernel PCG instead of the persistent kernel.  Two LM iterations
+    against the oracle (same tolerances as the other configs), plus the size-independent properties: chi2 decreases,
+    the fixed keyframe does not move, a second run is bit-identical."""
+    prob = synth.make_ba_config("gba_c5")
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(2)
+    cam, pts, _, _ = h.download()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 2)
+    assert st.iters_done == ost.iters_done == 2 and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
+    assert st.chi2_final < st.chi2_initial
+    assert np.array_equal(cam[0], prob["cam_qt"][0])
+    h.reset()
+    st2 = h.run(2)
+    cam2, pts2, _, _ = h.download()
+    assert np.array_equal(cam, cam2) and np.array_equal(pts, pts2) and st2.chi2_final == st.chi2_final
+    h.close()
