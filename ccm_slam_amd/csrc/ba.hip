@@ -137,6 +137,10 @@ struct BaDev {
   double* part_cam;          // [n_wg_cam]   scale partials (pose part)
   double* scal;              // [4]  chi2, scale, maxdiag, -
   int n_wg_pt, n_wg_cam;
+  // edge-parallel landmark kernels: chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
+  const int* chunk_off;      // [n_chunk+1] landmark ranges; nullptr: a landmark has more than kTPB observations -> thread-per-landmark kernels
+  int n_chunk;
+  int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,6 +181,58 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts(BaDev d, int cur) {
 #pragma unroll
   for (int i = 0; i < 6; i++) d.Hll[6 * (size_t)l + i] = H[i];
   d.bl[3 * (size_t)l] = b[0]; d.bl[3 * (size_t)l + 1] = b[1]; d.bl[3 * (size_t)l + 2] = b[2];
+}
+
+// Edge-parallel variant (default).  One thread per landmark leaves 150 000 threads = 2.3 waves per SIMD walking
+// dependent index -> pose -> observation chains (97 us, 2.7 TB/s); here a workgroup takes a chunk of consecutive
+// landmarks with <= 256 observations, one thread per OBSERVATION does the projection, Jacobians, robust weight and the
+// 6x3 W block (written as 144 contiguous bytes per thread, contiguous across the workgroup), parks the 9 landmark-side
+// contributions in LDS, and one thread per landmark adds them in observation order: the same additions in the same
+// order as the loop above, hence bit-identical Hll / b_l.
+__global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
+  __shared__ double hb[kTPB][9];
+  const int l0 = d.chunk_off[blockIdx.x], l1 = d.chunk_off[blockIdx.x + 1];
+  const int e0 = d.pt_off[l0], ne = d.pt_off[l1] - e0, nl = l1 - l0;
+  const int t = threadIdx.x;
+  if (t < ne) {
+    const int e = e0 + t, l = d.ed_pt[e], c = d.ed_cam[e];
+    const double X[3] = {d.pt[cur][3 * (size_t)l], d.pt[cur][3 * (size_t)l + 1], d.pt[cur][3 * (size_t)l + 2]};
+    const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+    const double* Kc = d.K + 4 * (size_t)c;
+    const double K4[4] = {Kc[0], Kc[1], Kc[2], Kc[3]};
+    double r0, r1;
+    ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+    double Ji[6], Jj[12];
+    ba_jacobians(T, K4, X, Ji, Jj);
+    const double om = d.info[e];
+    double rho0, w;
+    ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
+    const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    hb[t][0] = Ji[0] * o0 + Ji[3] * o1; hb[t][1] = Ji[1] * o0 + Ji[4] * o1; hb[t][2] = Ji[2] * o0 + Ji[5] * o1;
+    hb[t][3] = (Ji[0] * Ji[0] + Ji[3] * Ji[3]) * wom; hb[t][4] = (Ji[0] * Ji[1] + Ji[3] * Ji[4]) * wom;
+    hb[t][5] = (Ji[0] * Ji[2] + Ji[3] * Ji[5]) * wom; hb[t][6] = (Ji[1] * Ji[1] + Ji[4] * Ji[4]) * wom;
+    hb[t][7] = (Ji[1] * Ji[2] + Ji[4] * Ji[5]) * wom; hb[t][8] = (Ji[2] * Ji[2] + Ji[5] * Ji[5]) * wom;
+    if (d.ed_cslot[e] >= 0) {
+      double* W = d.W + 18 * (size_t)e;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[i * 3 + j] = (Jj[i] * Ji[j] + Jj[6 + i] * Ji[3 + j]) * wom;
+    }
+  }
+  __syncthreads();
+  if (t < nl) {
+    const int l = l0 + t;
+    double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int k = d.pt_off[l] - e0; k < d.pt_off[l + 1] - e0; k++) {
+      b[0] += hb[k][0]; b[1] += hb[k][1]; b[2] += hb[k][2];
+#pragma unroll
+      for (int i = 0; i < 6; i++) H[i] += hb[k][3 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) d.Hll[6 * (size_t)l + i] = H[i];
+    d.bl[3 * (size_t)l] = b[0]; d.bl[3 * (size_t)l + 1] = b[1]; d.bl[3 * (size_t)l + 2] = b[2];
+  }
 }
 
 // linearisation: camera side (one wave per free camera)                [CCM_K_BA_CAM]
@@ -1696,11 +1752,74 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2(BaDev d, int cur, double
   if (threadIdx.x == 0) { d.part_pt[2 * blockIdx.x] = s0; d.part_pt[2 * blockIdx.x + 1] = s1; }
 }
 
+// Edge-parallel variant (default, see ba_linearize_pts_e): one thread per observation forms W_e^T dp and later the
+// trial's residual, one thread per landmark does the 3x3 back-substitution in between.  (The W^T dp products of an
+// observation are summed before they are subtracted from b_l, so the landmark step differs from the loop above in the
+// last bits; the order is fixed, results are reproducible.)
+__global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, double lambda, int chi2_only) {
+  __shared__ double v[kTPB][3], Xs[kTPB][3];
+  __shared__ double lds[kTPB / kWave];
+  const int l0 = d.chunk_off[blockIdx.x], l1 = d.chunk_off[blockIdx.x + 1];
+  const int e0 = d.pt_off[l0], ne = d.pt_off[l1] - e0, nl = l1 - l0;
+  const int t = threadIdx.x;
+  const int trial = chi2_only ? cur : (cur ^ 1);
+  if (!chi2_only) {
+    if (t < ne) {
+      const int e = e0 + t, cs = d.ed_cslot[e];
+      double a0 = 0, a1 = 0, a2 = 0;
+      if (cs >= 0) {
+        const double* W = d.W + 18 * (size_t)e;
+        const double* xp = d.x + 6 * (size_t)cs;
+#pragma unroll
+        for (int r = 0; r < 6; r++) { a0 += W[r * 3] * xp[r]; a1 += W[r * 3 + 1] * xp[r]; a2 += W[r * 3 + 2] * xp[r]; }
+      }
+      v[t][0] = a0; v[t][1] = a1; v[t][2] = a2;
+    }
+    __syncthreads();
+  }
+  double chi = 0, sc = 0;
+  if (t < nl) {
+    const int l = l0 + t;
+    double X[3] = {d.pt[cur][3 * (size_t)l], d.pt[cur][3 * (size_t)l + 1], d.pt[cur][3 * (size_t)l + 2]};
+    if (!chi2_only) {
+      const double bl0 = d.bl[3 * (size_t)l], bl1 = d.bl[3 * (size_t)l + 1], bl2 = d.bl[3 * (size_t)l + 2];
+      double cl[3] = {bl0, bl1, bl2};
+      for (int k = d.pt_off[l] - e0; k < d.pt_off[l + 1] - e0; k++) { cl[0] -= v[k][0]; cl[1] -= v[k][1]; cl[2] -= v[k][2]; }
+      const double* Di = d.Dinv + 6 * (size_t)l;
+      const double dx0 = Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2];
+      const double dx1 = Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2];
+      const double dx2 = Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2];
+      sc = dx0 * (lambda * dx0 + bl0) + dx1 * (lambda * dx1 + bl1) + dx2 * (lambda * dx2 + bl2);
+      X[0] += dx0; X[1] += dx1; X[2] += dx2;
+      d.pt[trial][3 * (size_t)l] = X[0]; d.pt[trial][3 * (size_t)l + 1] = X[1]; d.pt[trial][3 * (size_t)l + 2] = X[2];
+    }
+    Xs[t][0] = X[0]; Xs[t][1] = X[1]; Xs[t][2] = X[2];
+  }
+  __syncthreads();
+  if (t < ne) {
+    const int e = e0 + t, c = d.ed_cam[e], ll = d.ed_pt[e] - l0;
+    const double X[3] = {Xs[ll][0], Xs[ll][1], Xs[ll][2]};
+    const BaPose T = ba_load_pose(d.cam[trial] + 7 * (size_t)c);
+    const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
+    double r0, r1;
+    const double zc = ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+    const double c2 = (r0 * r0 + r1 * r1) * d.info[e];
+    double rho0, w;
+    ba_huber(c2, d.huber, rho0, w);
+    chi = rho0;
+    d.edge_chi2[e] = c2;
+    d.edge_depth[e] = zc > 0.0;
+  }
+  const double s0 = block_sum(chi, lds);
+  const double s1 = block_sum(sc, lds);
+  if (threadIdx.x == 0) { d.part_pt[2 * blockIdx.x] = s0; d.part_pt[2 * blockIdx.x + 1] = s1; }
+}
+
 // final reduction of the trial scalars (single workgroup, fixed order)
 __global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d) {
   __shared__ double lds[kTPB / kWave];
   double chi = 0, sc = 0;
-  for (int i = threadIdx.x; i < d.n_wg_pt; i += kTPB) { chi += d.part_pt[2 * i]; sc += d.part_pt[2 * i + 1]; }
+  for (int i = threadIdx.x; i < d.n_part; i += kTPB) { chi += d.part_pt[2 * i]; sc += d.part_pt[2 * i + 1]; }
   for (int i = threadIdx.x; i < d.n_wg_cam; i += kTPB) sc += d.part_cam[i];
   const double a = block_sum(chi, lds);
   const double b = block_sum(sc, lds);
@@ -2025,10 +2144,26 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave);
   d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
   d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
+  d.chunk_off = nullptr; d.n_chunk = 0;
+  {
+    std::vector<int> chunk(1, 0);
+    bool fits = true;
+    for (int l = 0; l < Lloc && fits; l++) {
+      if (pt_off[l + 1] - pt_off[l] > kTPB) fits = false;
+      else if (pt_off[l + 1] - pt_off[chunk.back()] > kTPB || l + 1 - chunk.back() > kTPB) chunk.push_back(l);
+    }
+    if (fits && Lloc) {
+      chunk.push_back(Lloc);
+      int* p_ch = nullptr;
+      if (int rc = dev_upload(ba, chunk, &p_ch)) return fail(rc);
+      d.chunk_off = p_ch; d.n_chunk = (int)chunk.size() - 1;
+    }
+  }
+  d.n_part = d.chunk_off ? d.n_chunk : d.n_wg_pt;
   AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
   AL(pcg_scal, 4, double)
   AL(edge_chi2, Eloc, double) AL(edge_depth, Eloc, uint8_t)
-  AL(part_pt, 2 * (size_t)d.n_wg_pt, double) AL(part_cam, d.n_wg_cam, double) AL(scal, 6, double)
+  AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 6, double)
 #undef AL
   d.pcg_flag = reinterpret_cast<int*>(d.scal + 4);   // [scalars | PCG flags]: one 48-byte read-back per LM trial
   if (hipHostMalloc(&ba->h_rb, 64, hipHostMallocDefault) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer"));
@@ -2159,7 +2294,8 @@ int eval_chi2(ccm_ba* ba, double* chi) {
   BaDev& d = ba->d;
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_CHI2);
-    hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
+    if (d.chunk_off) hipLaunchKernelGGL(ba_backsub_chi2_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
+    else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
   }
   hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
@@ -2175,7 +2311,8 @@ int build_system(ccm_ba* ba) {
   BaDev& d = ba->d;
   if (d.Lloc) {
     ccm_prof_scope ps(ctx, CCM_K_BA_LINEARIZE);
-    hipLaunchKernelGGL(ba_linearize_pts, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+    if (d.chunk_off) hipLaunchKernelGGL(ba_linearize_pts_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+    else hipLaunchKernelGGL(ba_linearize_pts, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur);
   }
   if (d.Cp) {
     ccm_prof_scope ps(ctx, CCM_K_BA_CAM);
@@ -2352,7 +2489,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   } else hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_BACKSUB);
-    hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
+    if (d.chunk_off) hipLaunchKernelGGL(ba_backsub_chi2_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
+    else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
   }
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
   RC(ccm_allreduce_f64(ctx, d.scal, 2));

@@ -19,7 +19,7 @@ print("problem", which, prob["n_cam"], prob["n_pt"], prob["n_edge"], flush=True)
 t = time.time()
 h = optimizer.BAHandle(ctx, prob)
 print("create s", time.time() - t, h.counts(), flush=True)
-ctx.prof_enable(-1)
+ctx.prof_enable(-2 if os.environ.get("CCM_PROBE_NOPROF") else -1)
 ctx.prof_reset()
 t = time.time()
 st = h.run(iters, verbose=1)
