@@ -33,8 +33,14 @@ __device__ __forceinline__ void tile_abt(const double* As, const double* Bs, v4d
   }
 }
 
+// all 16 loads of a thread are issued before the first LDS store: as a rolled loop every tile paid the global latency 16
+// times, which was most of the 13-16 us of the one-product kernels
 __device__ __forceinline__ void load_tile(double* dst, const double* src, int ld_src) {
-  for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[r * LD + c] = src[(size_t)r * ld_src + c]; }
+  double v[NB * NB / kTPB];
+#pragma unroll
+  for (int q = 0; q < NB * NB / kTPB; q++) { const int e = threadIdx.x + q * kTPB; v[q] = src[(size_t)(e / NB) * ld_src + e % NB]; }
+#pragma unroll
+  for (int q = 0; q < NB * NB / kTPB; q++) { const int e = threadIdx.x + q * kTPB; dst[(e / NB) * LD + e % NB] = v[q]; }
 }
 
 // L_jj and its inverse (info: first failing global column + 1, like LAPACK) by ONE wave: the diagonal tile is the serial
@@ -191,7 +197,11 @@ __global__ __launch_bounds__(NB) void chol_solve_update(const double* A, int N, 
 
 // load a tile transposed: dst[c][r] = src[r][c]
 __device__ __forceinline__ void load_tile_t(double* dst, const double* src, int ld_src) {
-  for (int e = threadIdx.x; e < NB * NB; e += kTPB) { const int r = e / NB, c = e % NB; dst[c * LD + r] = src[(size_t)r * ld_src + c]; }
+  double v[NB * NB / kTPB];
+#pragma unroll
+  for (int q = 0; q < NB * NB / kTPB; q++) { const int e = threadIdx.x + q * kTPB; v[q] = src[(size_t)(e / NB) * ld_src + e % NB]; }
+#pragma unroll
+  for (int q = 0; q < NB * NB / kTPB; q++) { const int e = threadIdx.x + q * kTPB; dst[(e % NB) * LD + e / NB] = v[q]; }
 }
 
 // D(64x16) = As(64x64) * Bs(16x64)^T: wave w owns rows 16w..16w+15
@@ -205,7 +215,11 @@ __device__ __forceinline__ void tile_abt16(const double* As, const double* Bs, v
 }
 // strip of 16 columns of a tile, transposed: dst[c][r] = src[r][c0 + c]
 __device__ __forceinline__ void load_strip_t(double* dst, const double* src, int ld_src) {
-  for (int e = threadIdx.x; e < NB * 16; e += kTPB) { const int r = e / 16, c = e % 16; dst[c * LD + r] = src[(size_t)r * ld_src + c]; }
+  double v[NB * 16 / kTPB];
+#pragma unroll
+  for (int q = 0; q < NB * 16 / kTPB; q++) { const int e = threadIdx.x + q * kTPB; v[q] = src[(size_t)(e / 16) * ld_src + e % 16]; }
+#pragma unroll
+  for (int q = 0; q < NB * 16 / kTPB; q++) { const int e = threadIdx.x + q * kTPB; dst[(e % 16) * LD + e / 16] = v[q]; }
 }
 
 // X = L^-1 (lower triangular, tiles in X's lower triangle): workgroup (j, s) owns the 16-column strip s of block column j and
