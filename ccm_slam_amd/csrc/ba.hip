@@ -960,6 +960,7 @@ struct PersArgs {
   double lambda, rel_tol;
   int max_it, n_clu;
   unsigned* bar;        // [1] abort flag
+  const int* coff; const int* cij; const uint32_t* cblk;   // per cluster: entries inside its own 16x16 block (local row << 4 | column, S block)
   unsigned long long* slots;   // [2][2][grid]: p.q exchange, r.z exchange (word-major 16-byte slots)
   unsigned long long epoch_base;   // unique per launch: stale slots of earlier solves never validate
   const int* uoff;      // [n_clu+1] offsets into ucol
@@ -1052,8 +1053,8 @@ __device__ __forceinline__ bool pers_exchange(int t /* threadIdx.x */, unsigned 
 // Assemble the damped 96x96 block of one cluster from the block-CSR rows, factor it (Cholesky blocked by camera) and
 // leave W = (block)^-1 in A.  Kept out of line so that its register-hungry 6x6 temporaries do not compete with the
 // register-resident S rows of the PCG loop.
-__device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibuf, const int* row_off, const int* row_col,
-                                                 const uint32_t* row_blk, const double* S, int s0, int s1, double lambda, bool has,
+__device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibuf, const int* cij, const uint32_t* cblk, int c_lo, int c_hi,
+                                                 const double* S, int s0, int s1, double lambda, bool has,
                                                  long long* tacc, bool timing) {
   constexpr int N = kCluN;
   const int t = threadIdx.x;
@@ -1062,19 +1063,18 @@ __device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibu
   // ---- init 1: assemble the damped dense block of the cluster ----
   for (int i = t; i < N * N; i += kPersTPB) { A[i] = 0; Li[i] = 0; }
   __syncthreads();
-  if (has) {
+  if (has) {   // the cluster's own entries come from a host-built list: up to 10 independent (index, block) chains per thread in flight
     const int grp = t / 36, e = t % 36, r = e / 6, cc = e % 6;
     constexpr int kGroups = kPersTPB / 36;
     if (grp < kGroups)
-      for (int i = s0; i < s1; i++)
-        for (int s = row_off[i] + grp; s < row_off[i + 1]; s += kGroups) {
-          const int j = row_col[s];
-          if (j < s0 || j >= s1) continue;
-          const uint32_t bt = row_blk[s];
-          const double* B = S + 36 * (size_t)(bt & ~kTransposeBit);
-          const double v = (bt & kTransposeBit) ? B[cc * 6 + r] : B[e];
-          A[(6 * (i - s0) + r) * N + 6 * (j - s0) + cc] = v + ((i == j && r == cc) ? lambda : 0.0);
-        }
+#pragma unroll 4
+      for (int s = c_lo + grp; s < c_hi; s += kGroups) {
+        const int ij = cij[s], il = ij >> 4, jl = ij & 15;
+        const uint32_t bt = cblk[s];
+        const double* B = S + 36 * (size_t)(bt & ~kTransposeBit);
+        const double v = (bt & kTransposeBit) ? B[cc * 6 + r] : B[e];
+        A[(6 * il + r) * N + 6 * jl + cc] = v + ((il == jl && r == cc) ? lambda : 0.0);
+      }
   }
   __syncthreads();
   PERS_TICK(7)
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   long long* tacc = reinterpret_cast<long long*>(ibuf + 4);   // [13]: 12 phases + last stamp
   const bool timing = a.dbg != nullptr && blockIdx.x == 0 && t == 0;
   if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
-  pers_factor_cluster(A, Li, ibuf, d.row_off, d.row_col, d.row_blk, d.S, s0, s1, lambda, has, tacc, timing);
+  pers_factor_cluster(A, Li, ibuf, a.cij, a.cblk, has ? a.coff[c] : 0, has ? a.coff[c + 1] : 0, d.S, s0, s1, lambda, has, tacc, timing);
   // keep only the unit's own 48 rows of W, transposed (WT[col][row]: conflict-free for the mat-vec); the other half of the
   // A region then holds the coarse level: Ac^-1 rows of the unit's aggregate | coarse residual | gathered unit parts | own P_k
   {
@@ -1852,7 +1852,8 @@ struct ccm_ba {
   int cur = 0;
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
   unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
-  int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr;
+  int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
+  uint32_t* d_pers_cblk = nullptr;
   unsigned long long pers_launch = 0;
   // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
   int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
@@ -2025,7 +2026,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   }
   ba->n_row_entries = row_cnt[Cp];
   // persistent PCG: per cluster the ascending list of distinct columns its rows touch + every entry's position in it
-  std::vector<int> pers_uoff, pers_ucol, pers_loc;
+  std::vector<int> pers_uoff, pers_ucol, pers_loc, pers_coff, pers_cij;
+  std::vector<uint32_t> pers_cblk;
   bool pers_fits = Cp > kSmallMaxCp;
   if (pers_fits) {
     const int n_clu = 2 * ccm_div_up(Cp, kClu);   // units of kClu/2 rows (two workgroups per cluster)
@@ -2044,6 +2046,17 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       for (size_t q = 0; q < cols.size(); q++) mark[cols[q]] = -1;
       pers_ucol.insert(pers_ucol.end(), cols.begin(), cols.end());
       pers_uoff[c + 1] = (int)pers_ucol.size();
+    }
+    // block-CSR entries that fall inside each cluster's own 16x16 block (what the cluster factorisation assembles):
+    // local row << 4 | local column, and the entry's S block (with its transpose bit)
+    const int n_cl = ccm_div_up(Cp, kClu);
+    pers_coff.assign(n_cl + 1, 0);
+    for (int c = 0; c < n_cl; c++) {
+      const int r0 = c * kClu, r1 = std::min(Cp, r0 + kClu);
+      for (int i = r0; i < r1; i++)
+        for (int s2 = row_cnt[i]; s2 < row_cnt[i + 1]; s2++)
+          if (row_col[s2] >= r0 && row_col[s2] < r1) { pers_cij.push_back(((i - r0) << 4) | (row_col[s2] - r0)); pers_cblk.push_back(row_blk[s2]); }
+      pers_coff[c + 1] = (int)pers_cij.size();
     }
   }
 
@@ -2187,6 +2200,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       if (int rc2 = dev_upload(ba, pers_uoff, &ba->d_pers_uoff)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_loc, &ba->d_pers_loc)) return fail(rc2);
+      if (int rc2 = dev_upload(ba, pers_coff, &ba->d_pers_coff)) return fail(rc2);
+      if (int rc2 = dev_upload(ba, pers_cij, &ba->d_pers_cij)) return fail(rc2);
+      if (int rc2 = dev_upload(ba, pers_cblk, &ba->d_pers_cblk)) return fail(rc2);
       ba->pers_grid = grid;
       // coarse level: aggregates of kAgg cameras; block lists of Ac = P^T S P
       if (!getenv("CCM_BA_NO_COARSE")) {
@@ -2418,6 +2434,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.bar = ba->d_pers_bar; pa.slots = (unsigned long long*)ba->d_pers_part;
       pa.epoch_base = (++ba->pers_launch) << 20;
       pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
+      pa.coff = ba->d_pers_coff; pa.cij = ba->d_pers_cij; pa.cblk = ba->d_pers_cblk;
       pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
       pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
       const bool use_coarse = ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
