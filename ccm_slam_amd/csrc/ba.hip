@@ -1159,99 +1159,57 @@ __device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibu
   if (t < 6) Li[t] = 0.0;   // the reciprocal-pivot scratch lives in Li's first row
   __syncthreads();
   PERS_TICK(8)
-  // ---- init 3: Li = L^-1 blocked.  With D = blockdiag(L_JJ): L = D M (M unit block-diagonal), L^-1 = M^-1 D^-1 ----
-  // 3a: Li_JJ = L_JJ^-1 (one thread per camera)
-  if (t < nrows) {
-    const int c0 = 6 * t;
-    double X[21];   // packed lower triangle of the inverse
+  // ---- init 3: Li = L^-1 on 16x16 tiles (6 x 6 of them; Li is all zero on entry) ----
+  // 3a: the six diagonal tiles by forward substitution, one wave per tile, lane = column (pivot rows are LDS broadcasts);
+  // 3b: tiles at block distance dl = 1..5, one wave per tile: Li_IJ = -Li_II * sum_{K=J}^{I-1} L_IK Li_KJ on the f64 matrix
+  // cores (the 16x16 sum is parked in the mirror tile (J, I) of Li, which is zero before and after).  8 us instead of
+  // 35 us for the 6x6-blocked scalar version with its 15 barrier-separated block distances.
+  {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int lane = t & (kWave - 1), wave = t / kWave;
+    if (wave < 6 && lane < 16) {
+      const int b0 = 16 * wave, c = lane;
+      double x[16];
 #pragma unroll
-    for (int col = 0; col < 6; col++)
+      for (int r = 0; r < 16; r++) {
+        double sv = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int i = col; i < 6; i++) {
-        double sv = (i == col) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = col; k < i; k++) sv -= A[(c0 + i) * N + c0 + k] * X[k * (k + 1) / 2 + col];
-        X[i * (i + 1) / 2 + col] = sv / A[(c0 + i) * N + c0 + i];
+        for (int k = 0; k < r; k++) sv -= A[(b0 + r) * N + b0 + k] * x[k];
+        const double dg = A[(b0 + r) * N + b0 + r];
+        x[r] = (b0 + r < m) ? sv / dg : 0.0;          // rows beyond the cluster's cameras are padding
       }
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int col = 0; col <= i; col++) Li[(c0 + i) * N + c0 + col] = X[i * (i + 1) / 2 + col];
-  }
-  __syncthreads();
-  // 3b: M_IK = Li_II L_IK for every strictly-lower block, in place in A (read row of Li_II, column of L_IK)
-  {
-    const int nblk = nrows * (nrows - 1) / 2;
-    for (int e = t; e < nblk * 36; e += kPersTPB) {
-      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
-      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
-      while (I * (I - 1) / 2 > bi) I--;
-      while ((I + 1) * I / 2 <= bi) I++;
-      const int K = bi - I * (I - 1) / 2;
-      double sv = 0;
-#pragma unroll
-      for (int q = 0; q < 6; q++) sv += Li[(6 * I + ar) * N + 6 * I + q] * A[(6 * I + q) * N + 6 * K + bc];
-      Li[(6 * K + bc) * N + 6 * I + ar] = sv;   // parked transposed in the (unused) upper triangle of Li
-    }
-  }
-  __syncthreads();
-  {
-    const int nblk = nrows * (nrows - 1) / 2;
-    for (int e = t; e < nblk * 36; e += kPersTPB) {
-      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
-      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
-      while (I * (I - 1) / 2 > bi) I--;
-      while ((I + 1) * I / 2 <= bi) I++;
-      const int K = bi - I * (I - 1) / 2;
-      A[(6 * I + ar) * N + 6 * K + bc] = Li[(6 * K + bc) * N + 6 * I + ar];   // M_IK back into A's lower triangle
-    }
-  }
-  __syncthreads();
-  // 3c: Minv_IJ = -sum_{K=J}^{I-1} M_IK Minv_KJ (Minv_JJ = I), by block distance; results in Li's lower triangle,
-  // still missing the right factor Li_JJ
-  for (int dl = 1; dl < nrows; dl++) {
-    const int cnt = (nrows - dl) * 36;
-    if (t < cnt) {
-      const int J = t / 36, el = t % 36, ar = el / 6, bc = el % 6, I = J + dl;
-      double sv = A[(6 * I + ar) * N + 6 * J + bc];          // K = J term: M_IJ * I
-      for (int K = J + 1; K < I; K++)
-#pragma unroll
-        for (int q = 0; q < 6; q++) sv += A[(6 * I + ar) * N + 6 * K + q] * Li[(6 * K + q) * N + 6 * J + bc];
-      Li[(6 * I + ar) * N + 6 * J + bc] = -sv;
+      for (int r = 0; r < 16; r++) if (r >= c) Li[(b0 + r) * N + b0 + c] = x[r];
     }
     __syncthreads();
-  }
-  // 3d: Li_IJ = Minv_IJ Li_JJ (off-diagonal blocks): read, barrier, write
-  {
-    const int nblk = nrows * (nrows - 1) / 2;
-    double keep[5];   // <= ceil(120*36/1024) = 5 elements per thread
-    int ne = 0;
-    for (int e = t; e < nblk * 36; e += kPersTPB, ne++) {
-      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
-      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
-      while (I * (I - 1) / 2 > bi) I--;
-      while ((I + 1) * I / 2 <= bi) I++;
-      const int J = bi - I * (I - 1) / 2;
-      double sv = 0;
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int dl = 1; dl < 6; dl++) {
+      if (wave < 6 - dl) {
+        const int J = wave, I = wave + dl;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int K = J; K < I; K++)
 #pragma unroll
-      for (int q = 0; q < 6; q++) sv += Li[(6 * I + ar) * N + 6 * J + q] * Li[(6 * J + q) * N + 6 * J + bc];
-      keep[ne] = sv;
-    }
-    __syncthreads();
-    ne = 0;
-    for (int e = t; e < nblk * 36; e += kPersTPB, ne++) {
-      const int bi = e / 36, el = e % 36, ar = el / 6, bc = el % 6;
-      int I = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)bi)) * 0.5f);
-      while (I * (I - 1) / 2 > bi) I--;
-      while ((I + 1) * I / 2 <= bi) I++;
-      const int J = bi - I * (I - 1) / 2;
-      Li[(6 * I + ar) * N + 6 * J + bc] = keep[ne];
+          for (int kk = 0; kk < 4; kk++) {
+            const int k = 4 * kk + kq;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * I + i16) * N + 16 * K + k], Li[(16 * K + k) * N + 16 * J + i16], acc, 0, 0, 0);
+          }
+        double* scr = Li + (16 * J) * N + 16 * I;     // mirror tile (J, I): rows = k, columns = j of the parked sum
+#pragma unroll
+        for (int r = 0; r < 4; r++) scr[(kq + 4 * r) * N + i16] = acc[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave reads it back
+        v4d out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int k = 4 * kk + kq;
+          out = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * I + i16) * N + 16 * I + k], scr[k * N + i16], out, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++) { Li[(16 * I + kq + 4 * r) * N + 16 * J + i16] = -out[r]; scr[(kq + 4 * r) * N + i16] = 0.0; }
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
-  // the upper triangle of Li still holds the parked M^T: clear it so that Li is a clean lower-triangular inverse
-  for (int e = t; e < m * m; e += kPersTPB) { const int ar = e / m, bc = e % m; if (bc / 6 > ar / 6) Li[ar * N + bc] = 0.0; }
-  __syncthreads();
   PERS_TICK(9)
   // ---- init 4: W = Li^T Li into the A region (the factor is dead): 36 tiles of 16x16 on the f64 matrix cores, one wave
   // per tile; operand rows of Li are read straight from LDS (16 consecutive doubles per k: conflict-free); Li is lower
