@@ -495,13 +495,23 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   // Software pipeline over the wave's units: the table entry and the two index vectors of the NEXT unit (two dependent
   // load levels) are requested before the W_c rows of the current one, so that a unit exposes one memory latency
   // instead of three (a CU holds one workgroup = 16 waves here: nothing else hides them).
+  // PMC (rocprofv3, scripts/kpmc.sh): 21 VALU + 7 SALU instructions per MFMA (v_readlane pairs, 64-bit selects, two
+  // quarter-rate v_mul_lo_u32 for the x144 / x18 address scaling), VALU 35% and MFMA 23% busy, waves waiting 38% of
+  // their cycles.  So: the index vectors hold BYTE offsets (scaled once per 64 instances), each lane picks the entry of
+  // its own instance (even / odd) with one ds_bpermute per vector (the LDS pipe is idle), and the "switched off" lanes
+  // are handled by an and-mask on the Y offset: ~4 VALU instructions per MFMA.
+  const int pick = odd;                                   // lane's instance inside a pair
+  const unsigned ymask = on ? ~0u : 0u;
+  const unsigned ybyte = on ? 8u * (unsigned)woff : 8u * (unsigned)zslot;
+  const char* Wb = reinterpret_cast<const char*>(d.W);
+  const char* Yb = reinterpret_cast<const char*>(Ys);
   int u = u_first + wv;
   int n = 0, ic = 0, ia = 0;
   if (u < u_last) {
     const int s0 = d.unit_tab[3 * u + 1];
     n = d.unit_tab[3 * u + 2] - s0;
-    ic = (lane < n) ? d.inst_c[s0 + lane] : 0;
-    ia = (lane < n) ? d.inst_al[s0 + lane] : 0;
+    ic = (lane < n) ? 144 * d.inst_c[s0 + lane] : 0;
+    ia = (lane < n) ? 144 * d.inst_al[s0 + lane] : 0;
   }
   while (u < u_last) {
     const int un = u + kRowTPB / kWave;
@@ -509,8 +519,8 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
     if (un < u_last) {
       const int s0 = d.unit_tab[3 * un + 1];
       nn = d.unit_tab[3 * un + 2] - s0;
-      icn = (lane < nn) ? d.inst_c[s0 + lane] : 0;
-      ian = (lane < nn) ? d.inst_al[s0 + lane] : 0;
+      icn = (lane < nn) ? 144 * d.inst_c[s0 + lane] : 0;
+      ian = (lane < nn) ? 144 * d.inst_al[s0 + lane] : 0;
     }
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     int q0 = 0;
@@ -518,23 +528,19 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
       double wv8[16], yv8[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {
-        const int ce = __builtin_amdgcn_readlane(ic, q0 + 2 * q), co = __builtin_amdgcn_readlane(ic, q0 + 2 * q + 1);
-        const int ae = __builtin_amdgcn_readlane(ia, q0 + 2 * q), ao = __builtin_amdgcn_readlane(ia, q0 + 2 * q + 1);
-        // switched-off lanes read an LDS zero for Y and any (finite) W: one select on a 32-bit LDS index instead of four
-        // on the operands; W is addressed as base + 32-bit byte offset (the launch checks 144 E < 2^32)
-        wv8[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(d.W) + (144u * (unsigned)(odd ? co : ce) + wbyte));
-        yv8[q] = Ys[on ? (odd ? ao : ae) * 18 + woff : zslot];
+        const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
+        wv8[q] = *reinterpret_cast<const double*>(Wb + (cb + wbyte));        // switched-off lanes: any finite W times an LDS zero
+        yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
     }
     for (; q0 < n; q0 += 2) {   // pairs; the odd half is switched off for a last single instance
       const bool have_odd = q0 + 1 < n;
-      const int ce = __builtin_amdgcn_readlane(ic, q0), co = __builtin_amdgcn_readlane(ic, have_odd ? q0 + 1 : q0);
-      const int ae = __builtin_amdgcn_readlane(ia, q0), ao = __builtin_amdgcn_readlane(ia, have_odd ? q0 + 1 : q0);
+      const unsigned cb = (unsigned)__shfl(ic, (have_odd ? q0 + pick : q0), kWave), ab = (unsigned)__shfl(ia, (have_odd ? q0 + pick : q0), kWave);
       const bool use = on && (!odd || have_odd);
-      const double wl = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(d.W) + (144u * (unsigned)(odd ? co : ce) + wbyte));
-      const double yl = Ys[use ? (odd ? ao : ae) * 18 + woff : zslot];
+      const double wl = *reinterpret_cast<const double*>(Wb + (cb + wbyte));
+      const double yl = *reinterpret_cast<const double*>(Yb + (use ? ab + 8u * (unsigned)woff : 8u * (unsigned)zslot));
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yl, wl, acc, 0, 0, 0);
     }
     // D register r of lane (j, kq) is D[kq + 4 r][j]: even instances in D[0..5][0..5] (r = 0, 1; j < 6), odd ones in
