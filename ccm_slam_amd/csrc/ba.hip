@@ -966,6 +966,7 @@ struct PersArgs {
   double lambda, rel_tol;
   int max_it, n_clu;
   unsigned* bar;        // [1] abort flag
+  int test_abort;              // CCM_BA_TEST_ABORT: the last workgroup leaves at once (exercises the abort -> multi-kernel fallback)
   const int* coff; const int* cij; const uint32_t* cblk;   // per cluster: entries inside its own 16x16 block (local row << 4 | column, S block)
   unsigned long long* slots;   // [2][2][grid]: p.q exchange, r.z exchange (word-major 16-byte slots)
   unsigned long long epoch_base;   // unique per launch: stale slots of earlier solves never validate
@@ -1251,6 +1252,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   double* zpart = zs + N;                  // [8][96]
   double* red = zpart + 8 * N;             // [16]
   int* ibuf = reinterpret_cast<int*>(red + kPersWaves + 4);   // [0]=ok flag of the barrier, [1]=bad pivot
+  if (a.test_abort && blockIdx.x == gridDim.x - 1) return;
   const int t = threadIdx.x, lane = t & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(t / kWave);
   const int nwg = gridDim.x;               // padded to a multiple of 8
@@ -2399,6 +2401,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.epoch_base = (++ba->pers_launch) << 20;
       pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
       pa.coff = ba->d_pers_coff; pa.cij = ba->d_pers_cij; pa.cblk = ba->d_pers_cblk;
+      pa.test_abort = getenv("CCM_BA_TEST_ABORT") ? 1 : 0;
       pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
       pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
       const bool use_coarse = ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));

@@ -241,3 +241,29 @@ def test_config5_10k_keyframes_multi_kernel_path(ctx, oracle_lib):
     cam2, pts2, _, _ = h.download()
     assert np.array_equal(cam, cam2) and np.array_equal(pts, pts2) and st2.chi2_final == st.chi2_final
     h.close()
+
+
+@pytest.mark.gpu
+def test_persistent_kernel_abort_falls_back_to_the_multi_kernel_solver(ctx, oracle_lib, monkeypatch):
+    """The persistent PCG kernel needs all its workgroups resident at once.  If they are not, the bounded spins of its
+    grid exchange abort the solve, the host repeats the trial with the multi-kernel PCG and never uses the persistent
+    kernel on that handle again.  CCM_BA_TEST_ABORT makes one workgroup leave immediately: the result must still follow
+    the oracle, with exactly one (aborted) persistent launch and the rest of the solves on the multi-kernel path."""
+    from ccm_slam_amd._lib import K
+    monkeypatch.setenv("CCM_BA_TEST_ABORT", "1")
+    prob = synth.make_ba_problem(n_agents=3, kfs_per_agent=60, n_points=6000, seed=11)
+    h = optimizer.BAHandle(ctx, prob)
+    ctx.prof_enable(-1)
+    ctx.prof_reset()
+    st = h.run(3)
+    n_pers, _ = ctx.prof_read(K["BA_PCG_PERSIST"])
+    n_spmv, _ = ctx.prof_read(K["BA_PCG_SPMV"])
+    ctx.prof_enable(-2)
+    cam, pts, _, _ = h.download()
+    h.close()
+    assert n_pers == 1 and n_spmv > 0, (n_pers, n_spmv)
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 3)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
