@@ -235,6 +235,30 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
   }
 }
 
+// 27 wave-wide sums (upper triangle of a 6x6 + a 6-vector) with a halving butterfly: 16+8+4+2+1+1 = 32 cross-lane moves
+// instead of 27 x 6 = 162; afterwards lane l holds the total of value l >> 1 (values 27..31 are padding).  The selects are
+// on bit patterns so that the array stays in registers (see block_red.h).
+__device__ __forceinline__ double wave_sum27(double* acc /* [32], entries 27..31 zero */, int lane) {
+#pragma unroll
+  for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
+    const long long m = -(long long)((lane & off) != 0);
+#pragma unroll
+    for (int k = 0; k < c; k++) {
+      const long long lo = __double_as_longlong(acc[k]), hi = __double_as_longlong(acc[k + c]);
+      const double send = __longlong_as_double((lo & m) | (hi & ~m)), keep = __longlong_as_double((hi & m) | (lo & ~m));
+      acc[k] = keep + __shfl_xor(send, off, kWave);
+    }
+  }
+  return acc[0] + __shfl_xor(acc[0], 1, kWave);
+}
+// value index k (0..20) of the packed upper triangle -> (a, b), a <= b
+__device__ __forceinline__ void tri_ab(int k, int& a, int& b) {
+  a = 0;
+  int first = 0;                       // index of (a, a)
+  while (k >= first + 6 - a) { first += 6 - a; a++; }
+  b = a + (k - first);
+}
+
 // linearisation: camera side (one wave per free camera)                [CCM_K_BA_CAM]
 __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
   const int lane = threadIdx.x & (kWave - 1);
@@ -243,9 +267,9 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
   const int c = d.slot_cam[i];
   const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
   const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
-  double acc[27];
+  double acc[32];   // 27 sums + padding for the halving butterfly
 #pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int k = 0; k < 32; k++) acc[k] = 0;
   for (int s = d.cam_off[i] + lane; s < d.cam_off[i + 1]; s += kWave) {
     const int e = d.cam_edge[s];
     const int l = d.ed_pt[e];
@@ -272,14 +296,11 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[21 + a] += Jj[a] * o0 + Jj[6 + a] * o1;
   }
-#pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = wave_sum(acc[k]);
-  if (lane == 0) {
-    double* H = d.Hpp + 36 * (size_t)i;
-    int k = 0;
-    for (int a = 0; a < 6; a++)
-      for (int b = a; b < 6; b++) { H[a * 6 + b] = acc[k]; H[b * 6 + a] = acc[k]; k++; }
-    for (int a = 0; a < 6; a++) d.bp[6 * (size_t)i + a] = acc[21 + a];
+  const double tot = wave_sum27(acc, lane);
+  if ((lane & 1) == 0) {
+    const int k = lane >> 1;
+    if (k < 21) { int a, b; tri_ab(k, a, b); double* H = d.Hpp + 36 * (size_t)i; H[a * 6 + b] = tot; H[b * 6 + a] = tot; }
+    else if (k < 27) d.bp[6 * (size_t)i + k - 21] = tot;
   }
 }
 
@@ -333,9 +354,9 @@ __global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
   const int lane = threadIdx.x & (kWave - 1);
   const int i = blockIdx.x * (kTPB / kWave) + threadIdx.x / kWave;
   if (i >= d.Cp) return;
-  double acc[27];
+  double acc[32];   // 27 sums + padding for the halving butterfly
 #pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = 0;
+  for (int k = 0; k < 32; k++) acc[k] = 0;
   for (int s = d.cam_off[i] + lane; s < d.cam_off[i + 1]; s += kWave) {
     const int e = d.cam_edge[s];
     const int l = d.ed_pt[e];
@@ -361,15 +382,15 @@ __global__ __launch_bounds__(kTPB) void ba_schur_diag(BaDev d) {
 #pragma unroll
     for (int a = 0; a < 6; a++) acc[21 + a] += W[a * 3] * dl[0] + W[a * 3 + 1] * dl[1] + W[a * 3 + 2] * dl[2];
   }
-#pragma unroll
-  for (int k = 0; k < 27; k++) acc[k] = wave_sum(acc[k]);
-  if (lane == 0) {
-    const double* H = d.Hpp + 36 * (size_t)i;
-    double* S = d.S + 36 * (size_t)i;
-    int k = 0;
-    for (int a = 0; a < 6; a++)
-      for (int b = a; b < 6; b++) { const double v = H[a * 6 + b] - acc[k]; S[a * 6 + b] = v; S[b * 6 + a] = v; k++; }
-    for (int a = 0; a < 6; a++) d.bs[6 * (size_t)i + a] = d.bp[6 * (size_t)i + a] - acc[21 + a];
+  const double tot = wave_sum27(acc, lane);
+  if ((lane & 1) == 0) {
+    const int k = lane >> 1;
+    if (k < 21) {
+      int a, b; tri_ab(k, a, b);
+      const double v = d.Hpp[36 * (size_t)i + a * 6 + b] - tot;
+      double* S = d.S + 36 * (size_t)i;
+      S[a * 6 + b] = v; S[b * 6 + a] = v;
+    } else if (k < 27) d.bs[6 * (size_t)i + k - 21] = d.bp[6 * (size_t)i + k - 21] - tot;
   }
 }
 
