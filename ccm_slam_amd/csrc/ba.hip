@@ -450,6 +450,7 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // every pair instance: 336 B and 27 flops per instance instead of 152 B and 9), then the waves walk the blocks (i, j > i)
 // of the row and every instance costs one 144-byte W_c row read plus LDS.                [CCM_K_BA_SCHUR_OFF]
 constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
+constexpr int kRowSlot = 42;        // doubles per work-unit partial: 6x6 block + 6 (b_schur part of the diagonal units)
 constexpr int kRowTPB = 1024;        // 8 waves walk the row's blocks: the instance stream is latency bound, so more streams win
 __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
       Ys[t * 3 + 2] = a[q][0] * D[q][2] + a[q][1] * D[q][4] + a[q][2] * D[q][5];
     }
   }
-  if (threadIdx.x == 0) Ys[d.max_cam_edges * 18 + d.row_units_max * 36] = 0.0;
+  if (threadIdx.x < 18) Ys[d.max_cam_edges * 18 + d.row_units_max * kRowSlot + threadIdx.x] = 0.0;   // a whole zero row of Y
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   // One wave per block.  S_ij = -[Y_a1 Y_a2 ...] [W_c1 W_c2 ...]^T is a 6 x 6 product with inner dimension 3 per pair
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   const int woff = on ? 3 * jj + kq : 0;
   const unsigned wbyte = 8u * (unsigned)woff;
   double* part = Ys + (size_t)d.max_cam_edges * 18;
-  const int zslot = d.max_cam_edges * 18 + d.row_units_max * 36;   // one zero behind the partial sums
+  const int zslot = d.max_cam_edges * 18 + d.row_units_max * kRowSlot;   // one zero behind the partial sums
   const int u_first = d.row_unit_off[i], u_last = d.row_unit_off[i + 1];
   // Software pipeline over the wave's units: the table entry and the two index vectors of the NEXT unit (two dependent
   // load levels) are requested before the W_c rows of the current one, so that a unit exposes one memory latency
@@ -526,25 +527,67 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   const unsigned ybyte = on ? 8u * (unsigned)woff : 8u * (unsigned)zslot;
   const char* Wb = reinterpret_cast<const char*>(d.W);
   const char* Yb = reinterpret_cast<const char*>(Ys);
+  // A unit is either <= 64 pair instances of an off-diagonal block (table entry: block, first, end) or <= 64 of the
+  // camera's OWN observations (entry: -1, first, end) for the diagonal block: S_ii = Hpp_i - sum_e Y_e W_e^T and
+  // b_schur_i = b_p,i - sum_e Y_e b_l(e) are the same product with c = a = e and the landmark's b_l as a seventh column of
+  // the B operand (lanes j = 6 / 14).  The separate one-wave-per-camera kernel for the diagonal re-read W, D^-1 and the
+  // index chains that this workgroup has just loaded and took 56 us.
   int u = u_first + wv;
-  int n = 0, ic = 0, ia = 0;
-  if (u < u_last) {
-    const int s0 = d.unit_tab[3 * u + 1];
-    n = d.unit_tab[3 * u + 2] - s0;
-    ic = (lane < n) ? 144 * d.inst_c[s0 + lane] : 0;
-    ia = (lane < n) ? 144 * d.inst_al[s0 + lane] : 0;
-  }
+  int n = 0, ic = 0, ia = 0, il = 0, ublk = 0;
+  auto load_unit = [&](int uu, int& n_, int& ic_, int& ia_, int& il_, int& blk_) {
+    blk_ = d.unit_tab[3 * uu];
+    const int s0 = d.unit_tab[3 * uu + 1];
+    n_ = d.unit_tab[3 * uu + 2] - s0;
+    if (blk_ >= 0) {
+      ic_ = (lane < n_) ? 144 * d.inst_c[s0 + lane] : 0;
+      ia_ = (lane < n_) ? 144 * d.inst_al[s0 + lane] : 8 * zslot;   // padding instances multiply the zero row
+      il_ = 0;
+    } else {
+      const int e = (lane < n_) ? d.cam_edge[base + s0 + lane] : 0;
+      ic_ = 144 * e;
+      ia_ = (lane < n_) ? 144 * (s0 + lane) : 8 * zslot;
+      il_ = (lane < n_) ? 24 * d.ed_pt[e] : 0;
+    }
+  };
+  if (u < u_last) load_unit(u, n, ic, ia, il, ublk);
   while (u < u_last) {
     const int un = u + kRowTPB / kWave;
-    int nn = 0, icn = 0, ian = 0;
-    if (un < u_last) {
-      const int s0 = d.unit_tab[3 * un + 1];
-      nn = d.unit_tab[3 * un + 2] - s0;
-      icn = (lane < nn) ? 144 * d.inst_c[s0 + lane] : 0;
-      ian = (lane < nn) ? 144 * d.inst_al[s0 + lane] : 0;
-    }
+    int nn = 0, icn = 0, ian = 0, iln = 0, ublkn = 0;
+    if (un < u_last) load_unit(un, nn, icn, ian, iln, ublkn);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     int q0 = 0;
+    if (ublk < 0) {   // diagonal unit: lanes j = 6 / 14 feed b_l as the seventh column
+      const char* Lb = reinterpret_cast<const char*>(d.bl);
+      const bool c6 = jj == 6 && kq < 3;
+      const unsigned lbyte = 8u * (unsigned)kq;
+      for (; q0 + 32 <= n; q0 += 32) {
+        double wv8[16], yv8[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
+          const unsigned lb = (unsigned)__shfl(il, q0 + 2 * q + pick, kWave);
+          const char* src = c6 ? Lb + (lb + lbyte) : Wb + (cb + wbyte);
+          wv8[q] = *reinterpret_cast<const double*>(src);
+          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
+      }
+      for (; q0 < n; q0 += 16) {   // remainder in batches of 8 pairs; instances beyond n read the zero row of Y
+        double wv8[8], yv8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
+          const unsigned lb = (unsigned)__shfl(il, q0 + 2 * q + pick, kWave);
+          const char* src = c6 ? Lb + (lb + lbyte) : Wb + (cb + wbyte);
+          wv8[q] = *reinterpret_cast<const double*>(src);
+          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
+      }
+    }
+    if (ublk >= 0)
     for (; q0 + 32 <= n; q0 += 32) {
       double wv8[16], yv8[16];
 #pragma unroll
@@ -556,23 +599,30 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
 #pragma unroll
       for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
     }
-    for (; q0 < n; q0 += 2) {   // pairs; the odd half is switched off for a last single instance
-      const bool have_odd = q0 + 1 < n;
-      const unsigned cb = (unsigned)__shfl(ic, (have_odd ? q0 + pick : q0), kWave), ab = (unsigned)__shfl(ia, (have_odd ? q0 + pick : q0), kWave);
-      const bool use = on && (!odd || have_odd);
-      const double wl = *reinterpret_cast<const double*>(Wb + (cb + wbyte));
-      const double yl = *reinterpret_cast<const double*>(Yb + (use ? ab + 8u * (unsigned)woff : 8u * (unsigned)zslot));
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yl, wl, acc, 0, 0, 0);
-    }
+    if (ublk >= 0)
+      for (; q0 < n; q0 += 16) {   // remainder in batches of 8 pairs; instances beyond n read the zero row of Y
+        double wv8[8], yv8[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
+          wv8[q] = *reinterpret_cast<const double*>(Wb + (cb + wbyte));
+          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
+      }
     // D register r of lane (j, kq) is D[kq + 4 r][j]: even instances in D[0..5][0..5] (r = 0, 1; j < 6), odd ones in
     // D[8..13][8..13] (r = 2, 3; j = 8..13) -> added to the even sum of lane j - 8
     const double b0 = __shfl_down(acc[2], 8, kWave), b1 = __shfl_down(acc[3], 8, kWave);
+    double* pu = part + kRowSlot * (size_t)(u - u_first);
     if (j < 6) {
-      double* pu = part + 36 * (size_t)(u - u_first);
       pu[kq * 6 + j] = acc[0] + b0;
       if (kq < 2) pu[(kq + 4) * 6 + j] = acc[1] + b1;
+    } else if (j == 6 && ublk < 0) {   // seventh column: the b_schur part
+      pu[36 + kq] = acc[0] + b0;
+      if (kq < 2) pu[40 + kq] = acc[1] + b1;
     }
-    u = un; n = nn; ic = icn; ia = ian;
+    u = un; n = nn; ic = icn; ia = ian; il = iln; ublk = ublkn;
   }
   __syncthreads();
   {
@@ -581,9 +631,22 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
     if (grp < kGroups)
       for (int b = d.rowblk_off[i] + grp; b < d.rowblk_off[i + 1]; b += kGroups) {
         double sum = 0;
-        for (int u = d.blk_unit0[b]; u < d.blk_unit0[b + 1]; u++) sum += part[36 * (size_t)(u - u_first) + el];
+        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + kWave - 1) / kWave);
+        for (int u = ub; u < ue; u++) sum += part[kRowSlot * (size_t)(u - u_first) + el];
         d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
       }
+    // diagonal block and b_schur from the camera's own-observation units (the last ceil(ne / 64) units of the row); the
+    // upper triangle is mirrored so that S_ii is exactly symmetric
+    if (threadIdx.x < kRowSlot) {
+      const int el = threadIdx.x;
+      const int nd = (ne + kWave - 1) / kWave;
+      double sum = 0;
+      for (int u = u_last - nd; u < u_last; u++) sum += part[kRowSlot * (size_t)(u - u_first) + el];
+      if (el < 36) {
+        const int a = el / 6, b = el % 6;
+        if (a <= b) { const double v = d.Hpp[36 * (size_t)i + el] - sum; d.S[36 * (size_t)i + a * 6 + b] = v; d.S[36 * (size_t)i + b * 6 + a] = v; }
+      } else d.bs[6 * (size_t)i + el - 36] = d.bp[6 * (size_t)i + el - 36] - sum;
+    }
   }
 }
 
@@ -2099,12 +2162,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       std::vector<int> h_off((size_t)nOff + 1);
       if (hipMemcpyAsync(h_off.data(), d_inst_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: instance offsets read-back"));
-      const size_t lds_free = 158 * 1024 - 16 - (size_t)d.max_cam_edges * 18 * sizeof(double);
-      const int units_cap = (int)(lds_free / (36 * sizeof(double)));
+      const size_t lds_free = 158 * 1024 - 18 * sizeof(double) - (size_t)d.max_cam_edges * 18 * sizeof(double);
+      const int units_cap = (int)(lds_free / (kRowSlot * sizeof(double)));
       for (int chunk = kWave; chunk <= kWave && !d.row_units_max; chunk *= 2) {   // a unit = one 64-instance index vector
         int worst = 0;
         for (int i = 0; i < Cp; i++) {
-          int nu = 0;
+          int nu = ccm_div_up(cam_off[i + 1] - cam_off[i], chunk);   // diagonal units: the camera's own observations
           for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) nu += std::max(1, ccm_div_up(h_off[b + 1] - h_off[b], chunk));
           worst = std::max(worst, nu);
         }
@@ -2116,6 +2179,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
             int s0 = h_off[b];
             do { const int s1 = std::min(h_off[b + 1], s0 + chunk); tab.push_back(b); tab.push_back(s0); tab.push_back(s1); s0 = s1; } while (s0 < h_off[b + 1]);
           }
+          for (int s0 = 0, ne_i = cam_off[i + 1] - cam_off[i]; s0 < ne_i; s0 += chunk) { tab.push_back(-1); tab.push_back(s0); tab.push_back(std::min(ne_i, s0 + chunk)); }
           row_u[i + 1] = (int)tab.size() / 3;
         }
         blk_u[nOff] = (int)tab.size() / 3;
@@ -2376,13 +2440,14 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   if (d.Cp) {
     {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
-      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
+      const bool row_kernel = d.nOff > 8192 && d.row_units_max;   // the row kernel also forms the diagonal blocks and b_schur
+      if (!row_kernel) hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
-        const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * 36 + 2) * sizeof(double);
+        const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * kRowSlot + 18) * sizeof(double);
         static bool attr_row = false;
         if (!attr_row) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr_row = true; }
         hipLaunchKernelGGL(ba_schur_row, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
