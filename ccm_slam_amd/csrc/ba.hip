@@ -1141,6 +1141,14 @@ __device__ __forceinline__ bool pers_exchange(int t /* threadIdx.x */, unsigned 
 
 #define PERS_TICK(slot) { if (timing) { const long long tn_ = wall_clock64(); tacc[slot] += tn_ - tacc[12]; tacc[12] = tn_; } }
 
+__device__ __forceinline__ double pers_bcast(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  double r = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  asm volatile("" : "+v"(r));   // keep the value in VGPRs: as an SGPR-pair operand it trips the register-class verifier in this function
+  return r;
+}
+
 // Assemble the damped 96x96 block of one cluster from the block-CSR rows, factor it (Cholesky blocked by camera) and
 // leave W = (block)^-1 in A.  Kept out of line so that its register-hungry 6x6 temporaries do not compete with the
 // register-resident S rows of the PCG loop.
@@ -1167,87 +1175,82 @@ __device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibu
         A[(6 * il + r) * N + 6 * jl + cc] = v + ((il == jl && r == cc) ? lambda : 0.0);
       }
   }
+  if (m + t < N) A[(m + t) * N + m + t] = 1.0;   // unit diagonal on the padding rows of a short cluster: the factorisation needs no special case
   __syncthreads();
   PERS_TICK(7)
-  // ---- init 2: Cholesky A = L L^T blocked by camera (6 columns per step, 3 barriers per step instead of 18) ----
-  // diagonal 6x6 block by one thread (reciprocal square roots, no divisions), panel rows by one thread each (multiplies by
-  // the stored reciprocals), rank-6 trailing update on the f64 matrix cores (two k-steps of v_mfma_f64_16x16x4 per 16x16
-  // tile, tiles aligned to 16 with the rows above the trailing block masked to zero): 104 us -> ~25 us per cluster.
-  double* invd = Li;   // 6 reciprocal pivots of the current step (Li is not needed before init 3, which clears nothing it relies on here)
-  for (int J = 0; J < nrows; J++) {
-    const int c0 = 6 * J;
-    if (t == 0) {   // 6x6 diagonal block in registers
-      double B6[36];
+  // ---- init 2: Cholesky A = L L^T on 16x16 tiles: 6 steps of (diagonal tile | panel | trailing update) instead of 16
+  // camera-sized ones.  Diagonal tile: one wave, lane = row with its 16 entries in registers, pivot-row entries by
+  // v_readlane, reciprocal square roots.  Panel: one thread per row below, multiplies by the stored reciprocals.
+  // Trailing update: rank-16 on the f64 matrix cores (4 k-steps per 16x16 tile).  104 us (6-column steps, scalar
+  // update) -> 43 us (6-column steps, MFMA update) -> ~20 us.
+  double* invd = Li;   // 16 reciprocal pivots of the current step (Li is all zero otherwise and is restored below)
+  {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int lane = t & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(t / kWave);
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int T = 0; T < 6 && 16 * T < m; T++) {
+      const int b0 = 16 * T;
+      if (wave == 0) {
+        const int rl = lane & 15;                       // lanes 16..63 shadow lanes 0..15 (uniform control flow for v_readlane)
+        double row[16];
 #pragma unroll
-      for (int q = 0; q < 36; q++) B6[q] = A[(c0 + q / 6) * N + c0 + q % 6];
-      bool bad = false;
+        for (int k = 0; k < 16; k++) row[k] = A[(b0 + rl) * N + b0 + k];
+        bool bad = false;
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        double dj = B6[j * 6 + j];
+        for (int c = 0; c < 16; c++) {
+          double sv = row[c];
 #pragma unroll
-        for (int k = 0; k < j; k++) dj -= B6[j * 6 + k] * B6[j * 6 + k];
-        if (!(dj > 0.0)) { bad = true; dj = 1.0; }
-        const double inv = rsqrt(dj);
-        B6[j * 6 + j] = dj * inv;
-        invd[j] = inv;
+          for (int k = 0; k < c; k++) sv -= row[k] * pers_bcast(row[k], c);
+          double dd = pers_bcast(sv, c);
+          if (!(dd > 0.0)) { bad = true; dd = 1.0; }      // (padding rows of a short cluster carry a unit diagonal)
+          const double inv = rsqrt(dd);
+          row[c] = (rl == c) ? dd * inv : sv * inv;     // lanes above the diagonal hold unused values
+          if (lane == c) invd[c] = inv;
+        }
+        if (bad && lane == 0) ibuf[1] = 1;
+        if (lane < 16) {
 #pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-          double sv = B6[i * 6 + j];
-#pragma unroll
-          for (int k = 0; k < j; k++) sv -= B6[i * 6 + k] * B6[j * 6 + k];
-          B6[i * 6 + j] = sv * inv;
+          for (int k = 0; k < 16; k++) if (k <= lane) A[(b0 + lane) * N + b0 + k] = row[k];
         }
       }
-      if (bad) ibuf[1] = 1;
+      __syncthreads();
+      const int r0 = b0 + 16;
+      if (r0 + t < m) {   // panel: one thread per row below the diagonal tile, X L_TT^T = A_iT
+        const int i = r0 + t;
+        double x[16];
 #pragma unroll
-      for (int q = 0; q < 36; q++) if (q % 6 <= q / 6) A[(c0 + q / 6) * N + c0 + q % 6] = B6[q];
-    }
-    __syncthreads();
-    const int r0 = c0 + 6;
-    if (r0 + t < m) {   // panel: one thread per row below the diagonal block, X L_JJ^T = A_iJ
-      const int i = r0 + t;
-      double x[6];
+        for (int cc = 0; cc < 16; cc++) {
+          double sv = A[i * N + b0 + cc];
 #pragma unroll
-      for (int cc = 0; cc < 6; cc++) {
-        double sv = A[i * N + c0 + cc];
-#pragma unroll
-        for (int k = 0; k < cc; k++) sv -= x[k] * A[(c0 + cc) * N + c0 + k];
-        x[cc] = sv * invd[cc];
-      }
-#pragma unroll
-      for (int cc = 0; cc < 6; cc++) A[i * N + c0 + cc] = x[cc];
-    }
-    __syncthreads();
-    {   // trailing update A_ij -= sum_k X_ik X_jk over the lower 16x16 tiles that touch rows/cols >= r0
-      typedef double v4d __attribute__((ext_vector_type(4)));
-      const int lane = t & (kWave - 1), wave = t / kWave;
-      const int i16 = lane & 15, kq = lane >> 4;
-      const int T0 = r0 / 16;                       // first tile row/col with trailing entries
-      const int nt = 6 - T0, ntiles = nt * (nt + 1) / 2;
-      for (int tile = wave; tile < ntiles; tile += kPersWaves) {
-        int Ii = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
-        while (Ii * (Ii + 1) / 2 > tile) Ii--;
-        while ((Ii + 1) * (Ii + 2) / 2 <= tile) Ii++;
-        const int I = T0 + Ii, Jt = T0 + tile - Ii * (Ii + 1) / 2;
-        const int ra = 16 * I + i16, rb = 16 * Jt + i16;
-        const bool va = ra >= r0 && ra < m, vb = rb >= r0 && rb < m;
-        v4d acc = {0.0, 0.0, 0.0, 0.0};
-        {
-          const double a0 = va ? A[ra * N + c0 + kq] : 0.0, b0 = vb ? A[rb * N + c0 + kq] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-          const double a1 = (va && kq < 2) ? A[ra * N + c0 + 4 + kq] : 0.0, b1 = (vb && kq < 2) ? A[rb * N + c0 + 4 + kq] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+          for (int k = 0; k < cc; k++) sv -= x[k] * A[(b0 + cc) * N + b0 + k];
+          x[cc] = sv * invd[cc];
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = 16 * I + kq + 4 * r, col = 16 * Jt + i16;
-          if (col <= row) A[row * N + col] -= acc[r];
+        for (int cc = 0; cc < 16; cc++) A[i * N + b0 + cc] = x[cc];
+      }
+      __syncthreads();
+      {   // trailing update A_IJ -= X_I X_J^T over the lower tiles I >= J > T
+        const int nt = 5 - T, ntiles = nt * (nt + 1) / 2;
+        for (int tile = wave; tile < ntiles; tile += kPersWaves) {
+          int Ii = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+          while (Ii * (Ii + 1) / 2 > tile) Ii--;
+          while ((Ii + 1) * (Ii + 2) / 2 <= tile) Ii++;
+          const int I = T + 1 + Ii, Jt = T + 1 + tile - Ii * (Ii + 1) / 2;
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(16 * I + i16) * N + b0 + 4 * kk + kq], A[(16 * Jt + i16) * N + b0 + 4 * kk + kq], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * I + kq + 4 * r, col = 16 * Jt + i16;
+            if (col <= row) A[row * N + col] -= acc[r];
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
-  if (t < 6) Li[t] = 0.0;   // the reciprocal-pivot scratch lives in Li's first row
+  if (t < 16) Li[t] = 0.0;   // the reciprocal-pivot scratch lives in Li's first row
   __syncthreads();
   PERS_TICK(8)
   // ---- init 3: Li = L^-1 on 16x16 tiles (6 x 6 of them; Li is all zero on entry) ----
@@ -1735,9 +1738,10 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
 
 // ---- apply the step to a trial state, chi2 of the trial ---------------------------------------
 // cameras: T_trial = exp(dx) * T ; partial of sum x (lambda x + b_p)                   [CCM_K_BA_UPDATE]
-__global__ __launch_bounds__(kTPB) void ba_update_cams(BaDev d, int cur, double lambda, int add_lambda_term) {
+__global__ __launch_bounds__(kTPB) void ba_update_cams(BaDev d, int cur, double lambda, int add_lambda_term, unsigned* pers_flags /* nullable */) {
   __shared__ double lds[kTPB / kWave];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pers_flags && i < 4) pers_flags[i] = 0u;   // abort flag of the persistent PCG kernel, cleared for the next trial (saves a 5 us memset launch)
   double sc = 0;
   if (i < d.Cp) {
     const int c = d.slot_cam[i];
@@ -2247,6 +2251,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_pcg_persist, kPersTPB, lds) == hipSuccess &&
         hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid && grid <= 4 * kWave) {
       if (int rc2 = dev_alloc<unsigned>(ba, 4 + 2 * 16, &ba->d_pers_bar)) return fail(rc2);   // + debug clocks
+      if (hipMemsetAsync(ba->d_pers_bar, 0, (4 + 2 * 16) * sizeof(unsigned), ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: memset"));
       if (int rc2 = dev_alloc<double>(ba, 4 * (size_t)grid, &ba->d_pers_part)) return fail(rc2);   // [2][2][grid] slot words
       if (int rc2 = dev_upload(ba, pers_uoff, &ba->d_pers_uoff)) return fail(rc2);
       if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
@@ -2480,7 +2485,6 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     bool persist_ok = false;
     if (ba->pers_grid) {
       // whole solve in one launch; flags are read back together with the trial scalars
-      CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pers_bar, 0, 4 * sizeof(unsigned), ctx->stream));
       PersArgs pa;
       pa.lambda = lambda; pa.rel_tol = tol; pa.max_it = max_it; pa.n_clu = ccm_div_up(d.Cp, kClu);
       pa.bar = ba->d_pers_bar; pa.slots = (unsigned long long*)ba->d_pers_part;
@@ -2555,7 +2559,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   if (d.Cp) {
     ccm_prof_scope ps(ctx, CCM_K_BA_UPDATE);
-    hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0);
+    hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0, ba->pers_grid ? ba->d_pers_bar : (unsigned*)nullptr);
   } else hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_BACKSUB);
