@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 #endif
 constexpr int kAgg = CCM_KAGG;   // cameras per aggregate (32 = 2 clusters = 4 persistent units)
 constexpr int kAggUnits = kAgg / 8;
-constexpr int kCoarseOnIters = 100, kCoarseOffIters = 30;
+constexpr int kCoarseOnIters = 80, kCoarseOffIters = 35;   // a coarse build (0.38 ms) is worth ~35 CG iterations
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
