@@ -27,29 +27,30 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
 
 // Block-wide sums with a fixed association order (=> deterministic, and every thread of every wave ends with the
 // same bits, which keeps the whole LM control flow uniform without broadcasting decisions).
-struct BlockRed {
-  double* buf;   // LDS [2][kNW][64]
+template <int NW>
+struct BlockRedT {
+  double* buf;   // LDS [2][NW][64]
   int phase;
   int lane, wave;
 
-  // one value: wave butterfly, then the kNW partials through LDS
+  // one value: wave butterfly, then the NW partials through LDS
   __device__ __forceinline__ double sum1(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-    double* b = buf + phase * (kNW * 64);
+    double* b = buf + phase * (NW * 64);
     phase ^= 1;
     if (lane == 0) b[wave * 64] = v;
     __syncthreads();
     double s = b[0];
 #pragma unroll
-    for (int w = 1; w < kNW; w++) s += b[w * 64];
+    for (int w = 1; w < NW; w++) s += b[w * 64];
     return s;
   }
 
   // 27 values at once (upper triangle of H + b): a halving butterfly moves 16+8+4+2+1+1 = 32 f64 values through
   // the cross-lane network instead of 27*6 = 162; lane l then owns the wave total of value l>>1, the waves meet
-  // in LDS, lanes 0..26 add the kNW partials and v_readlane hands every total to the whole wave as a scalar.
-  __device__ __forceinline__ void sum27(double* acc /* [32], entries 27..31 zero */) {
+  // in LDS, lanes 0..26 add the NW partials and v_readlane hands every total to the whole wave as a scalar.
+  __device__ __forceinline__ void sum27(double* acc /* [32], entries 28..31 zero */) {
 #pragma unroll
     for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
       const bool hi = (lane & off) != 0;
@@ -62,7 +63,7 @@ struct BlockRed {
       }
     }
     acc[0] += __shfl_xor(acc[0], 1, kWave);
-    double* b = buf + phase * (kNW * 64);
+    double* b = buf + phase * (NW * 64);
     phase ^= 1;
     if ((lane & 1) == 0) b[wave * 64 + (lane >> 1)] = acc[0];
     __syncthreads();
@@ -70,10 +71,10 @@ struct BlockRed {
     if (lane < 32) {
       v = b[lane];
 #pragma unroll
-      for (int w = 1; w < kNW; w++) v += b[w * 64 + lane];
+      for (int w = 1; w < NW; w++) v += b[w * 64 + lane];
     }
 #pragma unroll
-    for (int k = 0; k < 27; k++) acc[k] = bcast_lane(v, k);
+    for (int k = 0; k < 28; k++) acc[k] = bcast_lane(v, k);   // entry 27 is free for a 28th value (e.g. a chi2 partial)
   }
   // up to 64 values (NV of them meaningful): halving butterfly 32+16+8+4+2+1 = 63 cross-lane moves, lane l then owns
   // the wave total of value l
@@ -90,16 +91,18 @@ struct BlockRed {
         acc[k] = keep + __shfl_xor(send, off, kWave);
       }
     }
-    double* b = buf + phase * (kNW * 64);
+    double* b = buf + phase * (NW * 64);
     phase ^= 1;
     b[wave * 64 + lane] = acc[0];
     __syncthreads();
     double v = b[lane];
 #pragma unroll
-    for (int w = 1; w < kNW; w++) v += b[w * 64 + lane];
+    for (int w = 1; w < NW; w++) v += b[w * 64 + lane];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = bcast_lane(v, k);
   }
 };
+using BlockRed = BlockRedT<kNW>;   // the 4-wave kernels (sim3opt.hip)
+
 
 }  // namespace blockred

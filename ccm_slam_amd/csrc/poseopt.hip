@@ -44,9 +44,8 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
 #pragma unroll
     for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
     if (!(d > 0.0) || !isfinite(d)) return false;
-    d = sqrt(d);
-    L[j * 6 + j] = d;
-    const double id = 1.0 / d;   // 6 reciprocals in total instead of 27 divisions
+    const double id = rsqrt(d);  // one reciprocal square root per pivot instead of a square root, a division and 27 more divisions
+    L[j * 6 + j] = d * id;
     inv[j] = id;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
@@ -77,10 +76,14 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
 // solve / exp map is executed redundantly by all lanes, SIMT makes that free); edges are strided over the 256
 // threads, a thread always owns the same edges, and the only synchronisation is the barrier inside BlockRed
 // (2-3 per LM trial).  All threads see bit-identical sums, so every branch below is workgroup-uniform.
-__global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int use_lds) {
+// Waves per workgroup, measured on a tracked frame (~1000 edges, host-API time per call): 2 waves 0.176 ms, 4 waves
+// 0.153 ms, 8 waves 0.180 ms — more waves shorten the f64 edge pass (~250 instructions per edge) but lengthen the two
+// block reductions and barriers of every LM trial.
+constexpr int kPoseWaves = 4, kPoseThreads = 64 * kPoseWaves, kPoseRed = 2 * kPoseWaves * 64;
+__global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tid = threadIdx.x;
-  BlockRed red{sm, 0, tid & 63, tid >> 6};
+  BlockRedT<kPoseWaves> red{sm, 0, tid & 63, tid >> 6};
   const double delta = (double)(float)sqrt(5.991);
   const double K4[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
   BaPose T0 = ba_load_pose(a.cam);
@@ -89,63 +92,51 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
   if (use_lds) {
     // a single workgroup has nothing to hide global latency behind: stage the whole problem (64 B + 3 flags per
     // edge) in LDS once; every later pass over the edges runs at LDS latency
-    double* base = sm + kRedDoubles;
+    double* base = sm + kPoseRed;
     double* lx = base; double* lo = base + 3 * (size_t)a.n; double* li = base + 5 * (size_t)a.n; double* le = base + 6 * (size_t)a.n;
     uint8_t* lb = reinterpret_cast<uint8_t*>(base + 8 * (size_t)a.n);
-    for (int i = tid; i < 3 * a.n; i += kThreads) lx[i] = a.Xw[i];
-    for (int i = tid; i < 2 * a.n; i += kThreads) lo[i] = a.obs[i];
-    for (int i = tid; i < a.n; i += kThreads) li[i] = a.info[i];
+    for (int i = tid; i < 3 * a.n; i += kPoseThreads) lx[i] = a.Xw[i];
+    for (int i = tid; i < 2 * a.n; i += kPoseThreads) lo[i] = a.obs[i];
+    for (int i = tid; i < a.n; i += kPoseThreads) li[i] = a.info[i];
     a.Xw = lx; a.obs = lo; a.info = li; a.err = le;
     a.level = lb; a.robust = lb + a.n; a.outlier = lb + 2 * (size_t)a.n;
     __syncthreads();
   }
-  for (int i = tid; i < a.n; i += kThreads) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
+  for (int i = tid; i < a.n; i += kPoseThreads) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
   BaPose T = T0;
   int nBad = 0;
-
-  auto chi2_active = [&](const BaPose& P) -> double {
-    double c = 0.0;
-    for (int i = tid; i < a.n; i += kThreads) {
-      if (a.level[i] != 0) continue;
-      const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
-      double e0, e1;
-      ba_residual(P, K4, X, a.obs[2 * i], a.obs[2 * i + 1], e0, e1);
-      a.err[2 * i] = e0; a.err[2 * i + 1] = e1;
-      double rho0, w;
-      ba_huber((e0 * e0 + e1 * e1) * a.info[i], a.robust[i] ? delta : 0.0, rho0, w);
-      c += rho0;
-    }
-    return red.sum1(c);
-  };
 
   for (int it = 0; it < 4; it++) {
     T = T0;                                     // vSE3->setEstimate(Converter::toSE3Quat(Frame.mTcw)) (:299)
     double cnt = 0.0;
-    for (int i = tid; i < a.n; i += kThreads) cnt += (a.level[i] == 0) ? 1.0 : 0.0;
+    for (int i = tid; i < a.n; i += kPoseThreads) cnt += (a.level[i] == 0) ? 1.0 : 0.0;
     const int nact = (int)red.sum1(cnt);
     if (nact > 0) {
       int nBadLM = 0;
       double lambda = 0, ni = 2;
-      bool err_current = false;                 // err[] / carriedChi hold the errors of the current estimate
-      double carriedChi = 0;
-      for (int iter = 0; iter < 10; iter++) {
-        // computeActiveErrors + activeRobustChi2 at the top of every g2o iteration; after an accepted trial the
-        // errors of T were just evaluated for tempChi, so the pass is skipped (same values, a third less edge work)
-        double currentChi = err_current ? carriedChi : chi2_active(T);
-        const double iniChi = currentChi;
-        double acc[32];
+      // One pass over the edges per LM trial: the pass that evaluates the trial state (errors, robust chi2 = tempChi)
+      // also accumulates that state's Jacobian products, so that an accepted trial hands the next iteration its
+      // linearisation (g2o: computeActiveErrors + linearizeSystem at the top of the next iteration, same values) and the
+      // 27 sums travel through one block reduction together with the chi2.  Rejected trials waste the Jacobian work.
+      bool lin_current = false;                 // acc[] holds the reduced H / b / chi2 of the current estimate T
+      double acc[32];
+      auto linearise = [&](const BaPose& P) {   // errors, chi2 (acc[27]) and Jacobian products (acc[0..26]) at P, reduced
 #pragma unroll
         for (int k = 0; k < 32; k++) acc[k] = 0;
-        for (int i = tid; i < a.n; i += kThreads) {
+        for (int i = tid; i < a.n; i += kPoseThreads) {
           if (a.level[i] != 0) continue;
           const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
+          double e0, e1;
+          ba_residual(P, K4, X, a.obs[2 * i], a.obs[2 * i + 1], e0, e1);
+          a.err[2 * i] = e0; a.err[2 * i + 1] = e1;
           double Xc[3];
-          ba_map(T, X, Xc);
+          ba_map(P, X, Xc);
           double J[12];
           ba_jacobian_pose_only(Xc, K4, J);
-          const double om = a.info[i], e0 = a.err[2 * i], e1 = a.err[2 * i + 1];
+          const double om = a.info[i];
           double rho0, w;
           ba_huber((e0 * e0 + e1 * e1) * om, a.robust[i] ? delta : 0.0, rho0, w);
+          acc[27] += rho0;
           const double o0 = -om * e0 * w, o1 = -om * e1 * w, wom = w * om;
           int k = 0;
 #pragma unroll
@@ -156,6 +147,11 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
           for (int r = 0; r < 6; r++) acc[21 + r] += J[r] * o0 + J[6 + r] * o1;
         }
         red.sum27(acc);
+      };
+      for (int iter = 0; iter < 10; iter++) {
+        if (!lin_current) linearise(T);
+        double currentChi = acc[27];
+        const double iniChi = currentChi;
         double H[36], B[6];
         {
           int k = 0;
@@ -183,7 +179,8 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
             for (int k = 0; k < 6; k++) xs[k] = 0;
           }
           T = ba_oplus(xs, T);
-          double tempChi = chi2_active(T);
+          linearise(T);
+          double tempChi = acc[27];
           if (!ok2) tempChi = DBL_MAX;
           double scale = 0;
 #pragma unroll
@@ -197,11 +194,11 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
             lambda *= fmax(1. / 3., alpha);
             ni = 2;
             currentChi = tempChi;
-            err_current = true; carriedChi = tempChi;
+            lin_current = true;                 // acc[] now belongs to the accepted estimate
           } else {
             lambda *= ni; ni *= 2;
             T = backup;
-            err_current = false;
+            lin_current = false;                // H, B (registers) still describe the backup estimate for the retry
           }
           qmax++;
         } while (rho < 0 && qmax < 10);
@@ -209,10 +206,12 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
         if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
         if (nBadLM >= 3) break;
       }
+      // (as in g2o, err[] keeps the errors of the LAST evaluated state, also when that trial was rejected: the inlier
+      // classification below reads e->chi2() without recomputing, Optimizer.cpp:306-334)
     }
     // classification (:306-334)
     double bad = 0.0;
-    for (int i = tid; i < a.n; i += kThreads) {
+    for (int i = tid; i < a.n; i += kPoseThreads) {
       if (a.outlier[i]) {
         const double X[3] = {a.Xw[3 * i], a.Xw[3 * i + 1], a.Xw[3 * i + 2]};
         double e0, e1;
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void poseopt_kernel(PoseOptArgs a, int us
     nBad = (int)red.sum1(bad);
     if (a.n < 10) break;
   }
-  if (use_lds) for (int i = tid; i < a.n; i += kThreads) g_outlier[i] = a.outlier[i];
+  if (use_lds) for (int i = tid; i < a.n; i += kPoseThreads) g_outlier[i] = a.outlier[i];
   if (tid == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
 }
 
@@ -274,14 +273,14 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
     // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
-    const size_t lds_full = kRedDoubles * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+    const size_t lds_full = kPoseRed * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
     const int use_lds = lds_full <= 150 * 1024;
-    const size_t lds_bytes = use_lds ? lds_full : kRedDoubles * sizeof(double);
+    const size_t lds_bytes = use_lds ? lds_full : kPoseRed * sizeof(double);
     if (lds_bytes > 64 * 1024) {
       static bool attr_set = false;
       if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)poseopt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
     }
-    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kThreads), lds_bytes, ctx->stream, a, use_lds);
+    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kPoseThreads), lds_bytes, ctx->stream, a, use_lds);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   uint8_t* h_out = (uint8_t*)(h + 8);
