@@ -1621,7 +1621,7 @@ static inline size_t pers_lds_bytes() {
 // ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
 // A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
 // the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
-constexpr int kSmallMaxCp = 64;   // measured: 7 us/iteration at 30 cameras, ~30 us at 119 (multi-kernel path: ~28 us)
+constexpr int kSmallMaxCp = 16;   // one cluster: the single-workgroup kernel; above, the persistent kernel with its 16-camera cluster preconditioner
 
 template <int TPB>
 __device__ __forceinline__ double block_dot_small(double v, double* red /* [16] */) {
