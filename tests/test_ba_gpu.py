@@ -267,3 +267,51 @@ def test_persistent_kernel_abort_falls_back_to_the_multi_kernel_solver(ctx, orac
     assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+
+
+def _dense_covisibility_problem(n_cam=300, n_pt=1100, seed=5):
+    """Every point seen by every camera: cameras with identity rotation scattered in a unit ball, points in a slab in front of
+    them.  Flat ccm_ba_problem layout like synth.make_ba_problem; initial state = truth + noise rounded to f32."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    c = rng.uniform(-1.0, 1.0, (n_cam, 3)) * np.array([1.0, 1.0, 0.5])
+    gt_cam = np.zeros((n_cam, 7)); gt_cam[:, 3] = 1.0; gt_cam[:, 4:7] = -c            # R = I, t = -c
+    gt_pt = np.column_stack([rng.uniform(-3, 3, n_pt), rng.uniform(-2, 2, n_pt), rng.uniform(4, 8, n_pt)])
+    e_cam = np.repeat(np.arange(n_cam, dtype=np.int32), n_pt)
+    e_pt = np.tile(np.arange(n_pt, dtype=np.int32), n_cam)
+    Xc = gt_pt[e_pt] - c[e_cam]
+    obs = np.column_stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy]) + rng.normal(0, 1.0, (e_cam.size, 2))
+    cam0 = gt_cam.copy()
+    cam0[:, 4:7] += rng.normal(0, 0.02, (n_cam, 3))
+    dq = rng.normal(0, 0.004, (n_cam, 3))
+    cam0[:, :3] = dq; cam0[:, :4] /= np.linalg.norm(cam0[:, :4], axis=1, keepdims=True)
+    cam0[0] = gt_cam[0]
+    fixed = np.zeros(n_cam, np.uint8); fixed[0] = 1
+    return {"n_cam": n_cam, "n_pt": n_pt, "n_edge": int(e_cam.size),
+            "cam_qt": cam0.astype(np.float32).astype(np.float64), "cam_fixed": fixed,
+            "cam_K": np.tile(np.array([fx, fy, cx, cy]), (n_cam, 1)),
+            "pt_xyz": (gt_pt + rng.normal(0, 0.03, gt_pt.shape)).astype(np.float32).astype(np.float64),
+            "e_cam": e_cam, "e_pt": e_pt, "e_obs": obs, "e_info": np.ones(e_cam.size), "e_level": np.zeros(e_cam.size, np.uint8),
+            "huber_delta": float(np.sqrt(5.991))}
+
+
+@pytest.mark.gpu
+def test_fallback_kernels_dense_covisibility(ctx, oracle_lib):
+    """A map whose shape defeats the fast paths: every point is observed by all 300 keyframes, so landmarks have more than
+    256 observations (thread-per-landmark linearisation / back-substitution instead of the chunked edge-parallel
+    kernels) and cameras more than 1000 (one-wave-per-block Schur kernel + separate diagonal kernel instead of the
+    row kernel), with 44 850 off-diagonal blocks.  Same tolerances against the oracle."""
+    prob = _dense_covisibility_problem()
+    per_cam = np.bincount(prob["e_cam"], minlength=prob["n_cam"])
+    per_pt = np.bincount(prob["e_pt"], minlength=prob["n_pt"])
+    assert per_cam.max() > 1000 and per_pt.max() > 256
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(3)
+    cam, pts, _, _ = h.download()
+    h.close()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 3)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
