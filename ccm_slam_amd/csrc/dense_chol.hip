@@ -50,64 +50,68 @@ __device__ __forceinline__ void load_tile(double* dst, const double* src, int ld
 // LDS, left-looking, two LDS reads per term, 96 us (nothing hides the LDS latency of a lone wave).  This one keeps lane
 // i's ROW in registers and reads only the pivot row from LDS (uniform address = broadcast, two doubles per read), so a
 // term costs one FMA plus half a read with no dependence between the reads: left-looking column form, fully unrolled,
-// four accumulators.  L^-1 follows by forward substitution, lane = column, x in registers, L rows broadcast the same way.
+// four accumulators.  L^-1 is a forward substitution, lane = column, x in registers, L rows broadcast the same way; it runs
+// on a second wave one column behind the factorisation (58 us -> 38 with FMA and the prefetched pivot row -> 30 with
+// all tile loads in flight -> 28 pipelined).
 __device__ __forceinline__ double bcast64(double v, int lane) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
+// Two waves in a software pipeline: wave 0 factors column c while wave 1 does row c-1 of the forward substitution for
+// L^-1 (it needs row c-1 of L and its reciprocal pivot, both final after step c-1); one block barrier per column.
+__global__ __launch_bounds__(128) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
   constexpr int LR = NB + 2;   // even row stride: rows stay 16-byte aligned for the paired broadcast reads
   __shared__ __attribute__((aligned(16))) double L[NB * LR];
   __shared__ double rdiag[NB];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
-  {   // all 64 row loads in flight at once (a rolled loop pays the global latency 64 times)
-    double tmp[NB];
+  double* Lg = Linv_all + (size_t)j * NB * NB;
+  {   // each wave brings half of the rows, all its loads in flight at once (a rolled loop pays the global latency per row)
+    double tmp[NB / 2];
 #pragma unroll
-    for (int r = 0; r < NB; r++) tmp[r] = Ajj[(size_t)r * N + lane];
+    for (int r = 0; r < NB / 2; r++) tmp[r] = Ajj[(size_t)(wv * (NB / 2) + r) * N + lane];
 #pragma unroll
-    for (int r = 0; r < NB; r++) L[r * LR + lane] = tmp[r];
+    for (int r = 0; r < NB / 2; r++) L[(wv * (NB / 2) + r) * LR + lane] = tmp[r];
   }
   __syncthreads();
   int bad_col = 0;
-  {
-    double row[NB], cur[NB], nxt[NB];
+  double row[NB], cur[NB], nxt[NB];   // wave 0: lane i's row of the tile, current / next pivot row (ping-pong indexing of one 2-D array instead of the copy: 52 us, the array leaves the registers)
+  double x[NB];                        // wave 1: lane t's column of L^-1
+  if (wv == 0) {
 #pragma unroll
     for (int k = 0; k < NB; k++) { row[k] = L[lane * LR + k]; cur[k] = 0.0; nxt[k] = 0.0; }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NB; c++) {
-      // cur[k] = L_ck (k < c), fetched during the previous column.  lane i: A_ic - sum_{k<c} L_ik L_ck
-      double acc[4] = {row[c], 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k = 0; k < c; k++) acc[k & 3] = __builtin_fma(-row[k], cur[k], acc[k & 3]);
-      // prefetch the old part of the NEXT pivot row (entries k < c were stored in earlier columns) so that the LDS
-      // latency overlaps the sqrt chain below; its newest entry L_{c+1,c} comes by v_readlane from lane c+1's register
-      if (c + 1 < NB) {
-#pragma unroll
-        for (int k = 0; k < c; k++) nxt[k] = L[(c + 1) * LR + k];
-      }
-      const double sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      double dd = bcast64(sv, c);
-      if (!(dd > 0.0)) { if (!bad_col) bad_col = c + 1; dd = 1.0; }
-      const double inv = rsqrt(dd), l = dd * inv;
-      row[c] = (lane == c) ? l : sv * inv;           // lanes < c hold the (unused) upper part
-      L[lane * LR + c] = row[c];                     // no barrier: one wave, and LDS executes a wave's accesses in order
-      if (lane == c) rdiag[c] = inv;
-      if (c + 1 < NB) nxt[c] = bcast64(row[c], c + 1);
-#pragma unroll
-      for (int k = 0; k <= c; k++) cur[k] = nxt[k];
-    }
-    __syncthreads();
   }
-  if (bad_col && lane == 0 && *info == 0) *info = j * NB + bad_col;
-  double* Lg = Linv_all + (size_t)j * NB * NB;
-  {
-    // X = L^-1, lane = column t: x_r = (delta_rt - sum_{k<r} L_rk x_k) / L_rr  (x_k = 0 for k < t, so the bounds are uniform)
-    double x[NB];
+  __syncthreads();
 #pragma unroll
-    for (int r = 0; r < NB; r++) {
+  for (int c = 0; c <= NB; c++) {
+    if (wv == 0) {
+      if (c < NB) {
+        // cur[k] = L_ck (k < c), fetched during the previous column.  lane i: A_ic - sum_{k<c} L_ik L_ck
+        double acc[4] = {row[c], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < c; k++) acc[k & 3] = __builtin_fma(-row[k], cur[k], acc[k & 3]);
+        // prefetch the old part of the NEXT pivot row (entries k < c were stored in earlier columns) so that the LDS
+        // latency overlaps the sqrt chain below; its newest entry L_{c+1,c} comes by v_readlane from lane c+1's register
+        if (c + 1 < NB) {
+#pragma unroll
+          for (int k = 0; k < c; k++) nxt[k] = L[(c + 1) * LR + k];
+        }
+        const double sv = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        double dd = bcast64(sv, c);
+        if (!(dd > 0.0)) { if (!bad_col) bad_col = c + 1; dd = 1.0; }
+        const double inv = rsqrt(dd), l = dd * inv;
+        row[c] = (lane == c) ? l : sv * inv;           // lanes < c hold the (unused) upper part
+        L[lane * LR + c] = row[c];
+        if (lane == c) rdiag[c] = inv;
+        if (c + 1 < NB) nxt[c] = bcast64(row[c], c + 1);
+#pragma unroll
+        for (int k = 0; k <= c; k++) cur[k] = nxt[k];
+      }
+    } else if (c >= 1) {
+      // X = L^-1, lane = column t: x_r = (delta_rt - sum_{k<r} L_rk x_k) / L_rr  (x_k = 0 for k < t, so the bounds are uniform)
+      const int r = c - 1;
       const double* Lrow = L + r * LR;
       double acc[4] = {(r == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -115,9 +119,13 @@ __global__ __launch_bounds__(64) void chol_diag_wave(double* A, int N, int j, do
       x[r] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[r];
       Lg[r * NB + lane] = x[r];
     }
+    __syncthreads();
   }
+  if (wv == 0) {
+    if (bad_col && lane == 0 && *info == 0) *info = j * NB + bad_col;
 #pragma unroll
-  for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
+    for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
+  }
 }
 
 // tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
@@ -295,7 +303,7 @@ int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, doub
   if (plan && (plan->T != T || T >= 65536)) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: tile plan does not match");
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(64), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     if (plan) {
       const int nr = plan->h_col_off[j + 1] - plan->h_col_off[j], np = plan->h_upd_off[j + 1] - plan->h_upd_off[j];
       if (nr) hipLaunchKernelGGL(chol_panel, dim3(nr), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, plan->d_col_rows + plan->h_col_off[j]);
@@ -384,7 +392,7 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
   const int T = N / NB;
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(64), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     const int rem = T - j - 1;
     if (rem > 0) {
       hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, (const int*)nullptr);
