@@ -2018,9 +2018,26 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     for (int l = 0; l < Lp; l++) cnt[l + 1] += cnt[l];
     std::vector<int> pos(cnt.begin(), cnt.end() - 1);
     for (int e : act) order[pos[ba->pt_slot[P->e_pt[e]]]++] = e;
-    for (int l = 0; l < Lp; l++)
-      std::stable_sort(order.begin() + cnt[l], order.begin() + cnt[l + 1],
-                       [&](int a, int b) { return ba->cam_slot[P->e_cam[a]] < ba->cam_slot[P->e_cam[b]]; });
+    // per-landmark order by pose slot: the lists are short (~6), so a stable insertion sort on precomputed keys instead of
+    // 150 000 std::stable_sort calls with their temporary buffers (6.5 -> ~2 ms of the set-up)
+    std::vector<int> key(order.size());
+    for (size_t k = 0; k < order.size(); k++) key[k] = ba->cam_slot[P->e_cam[order[k]]];
+    for (int l = 0; l < Lp; l++) {
+      const int b0 = cnt[l], b1 = cnt[l + 1];
+      if (b1 - b0 > 64) {
+        std::vector<std::pair<int, int>> tmp(b1 - b0);
+        for (int k = b0; k < b1; k++) tmp[k - b0] = {key[k], order[k]};
+        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+        for (int k = b0; k < b1; k++) order[k] = tmp[k - b0].second;
+        continue;
+      }
+      for (int k = b0 + 1; k < b1; k++) {
+        const int kk = key[k], ee = order[k];
+        int q = k - 1;
+        while (q >= b0 && key[q] > kk) { key[q + 1] = key[q]; order[q + 1] = order[q]; q--; }
+        key[q + 1] = kk; order[q + 1] = ee;
+      }
+    }
   }
   std::vector<int> g_pt_off(Lp + 1, 0);
   for (size_t k = 0; k < order.size(); k++) g_pt_off[ba->pt_slot[P->e_pt[order[k]]] + 1]++;
