@@ -2012,6 +2012,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   lap("active set");
   // ---- edges sorted by (landmark slot, pose slot) — fixed cameras (slot -1) first ----
   std::vector<int> order(act.size());
+  std::vector<int> g_pt_off;                    // [Lp+1] edge ranges of the landmark slots in `order`
   {
     std::vector<int> cnt(Lp + 1, 0);
     for (int e : act) cnt[ba->pt_slot[P->e_pt[e]] + 1]++;
@@ -2038,21 +2039,22 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
         key[q + 1] = kk; order[q + 1] = ee;
       }
     }
+    g_pt_off.swap(cnt);                          // the prefix sums of the counting sort are the landmark edge ranges
   }
-  std::vector<int> g_pt_off(Lp + 1, 0);
-  for (size_t k = 0; k < order.size(); k++) g_pt_off[ba->pt_slot[P->e_pt[order[k]]] + 1]++;
-  for (int l = 0; l < Lp; l++) g_pt_off[l + 1] += g_pt_off[l];
 
   lap("edge sort");
   // ---- shard the landmarks: weight = pair instances + edges ----
-  std::vector<int64_t> weight(Lp);
-  for (int l = 0; l < Lp; l++) {
-    int kf = 0;
-    for (int k = g_pt_off[l]; k < g_pt_off[l + 1]; k++) kf += ba->cam_slot[P->e_cam[order[k]]] >= 0;
-    weight[l] = (int64_t)kf * (kf + 1) / 2 + (g_pt_off[l + 1] - g_pt_off[l]);
-  }
   std::vector<int32_t> shard(nranks + 1);
-  ccm_ba_partition(weight.data(), Lp, nranks, shard.data());
+  if (nranks == 1) { shard[0] = 0; shard[1] = Lp; }   // nothing to balance: skip the weight pass over all edges
+  else {
+    std::vector<int64_t> weight(Lp);
+    for (int l = 0; l < Lp; l++) {
+      int kf = 0;
+      for (int k = g_pt_off[l]; k < g_pt_off[l + 1]; k++) kf += ba->cam_slot[P->e_cam[order[k]]] >= 0;
+      weight[l] = (int64_t)kf * (kf + 1) / 2 + (g_pt_off[l + 1] - g_pt_off[l]);
+    }
+    ccm_ba_partition(weight.data(), Lp, nranks, shard.data());
+  }
   const int lb = ba->lp_begin = shard[rank], le = ba->lp_end = shard[rank + 1];
   const int Lloc = ba->Lloc = le - lb;
   const int eb = g_pt_off[lb], ee = g_pt_off[le];
