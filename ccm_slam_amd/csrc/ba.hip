@@ -7,21 +7,24 @@
 //  types/types_six_dof_expmap.cpp:103-147, core/robust_kernel_impl.cpp:78-90).
 //
 // MI355X design (not a translation of g2o's pointer graph):
-//  * problem flattened to SoA buffers resident in HBM; edges sorted by landmark so that the
-//    landmark-side work (Hll, b_l, D^-1, back-substitution, chi2) is one thread per landmark over
-//    a contiguous edge range, and a per-camera edge list drives the camera-side work (Hpp, b_p,
-//    diagonal Schur blocks, b_schur) with one wave per camera and a wave reduction — no atomics,
-//    so every sum has a fixed order and the solver is bit-reproducible run to run;
-//  * off-diagonal Schur blocks are *gathered*: the host builds, once per problem, the list of
-//    (edge_a, edge_c) pair instances per block; one wave owns one 6x6 block (lane = matrix
-//    element) and streams its instances (W blocks are 144-byte contiguous rows);
-//  * reduced camera system solved by block-Jacobi preconditioned CG on the block-CSR matrix
-//    (two kernels per iteration, scalars stay on the device, deterministic two-stage reductions);
+//  * problem flattened to SoA buffers resident in HBM; edges sorted by landmark.  Landmark-side work (Hll, b_l, W,
+//    back-substitution, chi2) runs one thread per OBSERVATION on chunks of consecutive landmarks, with the per-landmark
+//    sums parked in LDS and added in observation order; camera-side work (Hpp, b_p) one wave per camera over its edge
+//    list with a halving-butterfly wave reduction — no atomics anywhere, so every sum has a fixed order and the solver
+//    is bit-reproducible run to run;
+//  * Schur blocks are *gathered*: the pair structure ((edge_a, edge_c) instances per block) is built once per problem
+//    on the device; a workgroup per camera row keeps Y = W D^-1 of the camera's observations in LDS and feeds work
+//    units of <= 64 pair instances, two instances per v_mfma_f64_16x16x4, to its 16 waves (off-diagonal AND diagonal
+//    blocks, b_schur as a seventh column);
+//  * reduced camera system: ONE persistent kernel per LM trial (16 < cameras <= 2048) runs the whole preconditioned CG —
+//    S rows in registers, the 16-camera cluster inverse in LDS, grid-wide steps by an atomics-free slot exchange, an
+//    adaptively switched coarse level of rigid-body modes per 32 cameras; <= 16 cameras: one workgroup; > 2048: two
+//    kernels per CG iteration;
 //  * sharding: landmarks (with all their edges) are partitioned across ranks, the
 //    camera state is replicated, and ONE RCCL all-reduce per LM trial sums
 //    [S blocks | b_schur] over xGMI; every rank then solves the identical reduced system.
 //  * LM control (lambda schedule, rho test, stop rules) runs on the host exactly as
-//    optimization_algorithm_levenberg.cpp:61-164 does; one 32-byte D2H read per trial.
+//    optimization_algorithm_levenberg.cpp:61-164 does; one 48-byte pinned D2H read per trial.
 #include "common.h"
 #include "ba_math.h"
 #include <algorithm>
