@@ -144,6 +144,12 @@ struct BaDev {
   const int* chunk_off;      // [n_chunk+1] landmark ranges; nullptr: a landmark has more than kTPB observations -> thread-per-landmark kernels
   int n_chunk;
   int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
+  // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
+  double* mk_cpart;          // [n_clusters][6] restriction parts P^T r of every cluster
+  double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
+  const double* mk_P;        // [Cp][36] prolongation blocks
+  const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse
+  int mk_on, mk_Nc, mk_na;   // mk_on: this trial's solve uses the coarse level
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -673,6 +679,24 @@ __global__ void ba_inst_rank(const int* inst_a, const int* rank, int n, int* ins
 constexpr int kClu = 16;            // cameras per cluster
 constexpr int kCluN = 6 * kClu;     // 96 unknowns
 
+// cluster part of the coarse restriction P^T r (6 values): the 6 products of every (camera, component) go through LDS
+// and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
+__device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m, const double* rc, double* prod) {
+  const int t = threadIdx.x;
+  if (t < m) {
+    const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
+    const double rv = rc[t];
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) prod[t * 6 + cc] = P[cc] * rv;
+  }
+  __syncthreads();
+  if (t < 6) {
+    double sv = 0;
+    for (int q = 0; q < m; q++) sv += prod[q * 6 + t];
+    d.mk_cpart[6 * (size_t)c + t] = sv;
+  }
+}
+
 __global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, double rel_tol) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* A = sm;                    // [96][96] dense block, then its Cholesky factor (lower)
@@ -762,6 +786,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, doub
     if (bad) d.pcg_flag[2] = 1;
     if (c == 0) { d.pcg_scal[1] = rel_tol * rel_tol; d.pcg_scal[2] = lambda; }
   }
+  if (d.mk_on) mk_restrict(d, c, s0, m, rc, A + kCluN);   // rows 1.. of A are free scratch now (row 0 holds yv)
 }
 
 // iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
@@ -782,11 +807,13 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
   const int per_xcd = gridDim.x >> 3;            // grid is padded to a multiple of 8 workgroups
   const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int i = wg * kRowsPerWG + rl;
-  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  if (d.mk_on) rz_k += sum_partials(d.mk_cry[k & 1], d.n_wg_upd);
   double beta = 0;
   if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
   else {
-    const double rz_prev = sum_partials(d.prz[(k + 1) & 1], d.n_wg_upd);
+    double rz_prev = sum_partials(d.prz[(k + 1) & 1], d.n_wg_upd);
+    if (d.mk_on) rz_prev += sum_partials(d.mk_cry[(k + 1) & 1], d.n_wg_upd);
     beta = rz_k / rz_prev;
   }
   const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
@@ -857,7 +884,8 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   const size_t g = 6 * (size_t)s0 + t;
   double xv = 0, rv = 0, qv = 0, pv = 0;
   if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g]; }
-  const double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
+  if (d.mk_on) rz_k += sum_partials(d.mk_cry[k & 1], d.n_wg_upd);
   const double pq = sum_partials(d.ppq, d.n_wg_spmv);
   if (done) return;
   if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
@@ -903,6 +931,54 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   if (t == 0) {
     d.prz[(k + 1) & 1][c] = ((red[0] + red[1]) + red[2]) + red[3];
     if (c == 0) d.pcg_flag[1] = k + 1;
+  }
+  if (d.mk_on) {
+    __shared__ double prod[6 * kCluN];
+    mk_restrict(d, c, s0, m, rc, prod);
+  }
+}
+
+// Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per cluster after ba_pcg_init / ba_pcg_update:
+// rc = P^T r summed per aggregate (two clusters), y = Ac^-1[aggregate rows] rc (each cluster recomputes the 6 values of its
+// aggregate: 6 x Nc multiply-adds, cheaper than another grid-wide step), z += P y for the cluster's cameras, and the
+// coarse part of r.z = rc_agg . y_agg, counted by the first cluster of every aggregate.
+__global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
+  extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * na]
+  __shared__ double ys[8];
+  if (d.pcg_flag[0]) return;
+  const int t = threadIdx.x, c = blockIdx.x;
+  const int lane = t & (kWave - 1), wv = t / kWave;
+  const int nca = 6 * d.mk_na, n_clu = d.n_wg_upd;
+  for (int e = t; e < nca; e += kTPB) {
+    const int a = e / 6, cc = e % 6;
+    double v = d.mk_cpart[6 * (size_t)(2 * a) + cc];
+    if (2 * a + 1 < n_clu) v += d.mk_cpart[6 * (size_t)(2 * a + 1) + cc];
+    rcs[e] = v;
+  }
+  __syncthreads();
+  const int agg = c >> 1;
+  for (int rr = wv; rr < 6; rr += kTPB / kWave) {
+    const double* ar = d.mk_Ainv + (size_t)(6 * agg + rr) * d.mk_Nc;
+    double acc = 0;
+    for (int jj = lane; jj < nca; jj += kWave) acc += ar[jj] * rcs[jj];
+    acc = wave_sum(acc);
+    if (lane == 0) ys[rr] = acc;
+  }
+  __syncthreads();
+  const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
+  const int m = 6 * (s1 - s0);
+  if (t < m) {
+    const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
+    double zc = 0;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) zc += P[cc] * ys[cc];
+    d.z[6 * (size_t)s0 + t] += zc;
+  }
+  if (t == 0) {
+    double sv = 0;
+    if ((c & 1) == 0)
+      for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
+    d.mk_cry[par][c] = sv;
   }
 }
 
@@ -1617,6 +1693,49 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   }
 }
 
+// Multi-kernel PCG start with the tile factorisation of the persistent kernel (one 16-wave workgroup per cluster): assembles
+// and inverts the damped cluster block, stores W for ba_pcg_update, sets x = 0, r = b, z = W r, p = 0 and the r.z partial.
+// The column-by-column ba_pcg_init took 1.43 ms per trial on 625 clusters (96 steps of three barriers); this one ~0.1 ms.
+__global__ __launch_bounds__(kPersTPB) void ba_pcg_init_tiles(BaDev d, double lambda, double rel_tol, const int* coff, const int* cij, const uint32_t* cblk) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int N = kCluN;
+  double* A = sm;
+  double* Li = sm + N * N;
+  double* rc = Li + N * N;                   // [96]
+  double* red = rc + N;                      // [16]
+  int* ibuf = reinterpret_cast<int*>(red + kPersWaves);
+  const int t = threadIdx.x, c = blockIdx.x;
+  const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
+  const int m = 6 * (s1 - s0);
+  if (t < 4) ibuf[t] = 0;
+  __syncthreads();
+  pers_factor_cluster(A, Li, ibuf, cij, cblk, coff[c], coff[c + 1], d.S, s0, s1, lambda, true, nullptr, false);
+  double* W = d.Wc + (size_t)c * N * N;
+  for (int e = t; e < N * N; e += kPersTPB) W[e] = A[e];
+  if (t < N) rc[t] = (t < m) ? d.bs[6 * (size_t)s0 + t] : 0.0;
+  __syncthreads();
+  double rz = 0;
+  if (t < m) {
+    double z = 0;
+    for (int col = 0; col < m; col++) z += A[col * N + t] * rc[col];   // W is symmetric: column access is conflict-free
+    const size_t g = 6 * (size_t)s0 + t;
+    d.x[g] = 0; d.r[g] = rc[t]; d.z[g] = z; d.p[0][g] = 0;
+    rz = rc[t] * z;
+  }
+  rz = wave_sum(rz);
+  if ((t & (kWave - 1)) == 0) red[t / kWave] = rz;
+  __syncthreads();
+  if (t == 0) {
+    double tot = 0;
+    for (int w = 0; w < kPersWaves; w++) tot += red[w];
+    d.prz[0][c] = tot;
+    d.prz[1][c] = 0;
+    if (ibuf[1]) d.pcg_flag[2] = 1;
+    if (c == 0) { d.pcg_scal[1] = rel_tol * rel_tol; d.pcg_scal[2] = lambda; }
+  }
+  if (d.mk_on) mk_restrict(d, c, s0, m, rc, Li);
+}
+
 static inline size_t pers_lds_bytes() {
   return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves + 4) * sizeof(double) + 16 + 14 * sizeof(long long);
 }
@@ -2262,6 +2381,38 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
   if (int rc = dev_alloc<double>(ba, 3 * (size_t)std::max(Lp, 1), &ba->d_pt_full)) return fail(rc);
   if (int rc = dev_alloc<double>(ba, 36 * (size_t)std::max(Cp, 1), &ba->d_hpp_full)) return fail(rc);
+  // coarse-level structures (SURVEY-free addition, see the comment at kAgg): block lists of Ac = P^T S P by aggregate pair,
+  // buffers for P, Ac, its inverse.  Used by the persistent kernel (cparts: one slot row per unit) and, for maps above
+  // 2048 free cameras, by the multi-kernel PCG (mk_*: per-cluster restriction parts and coarse scalar parts).
+  auto make_coarse = [&](int na, int Nc, int n_units) -> int {
+    std::map<std::pair<int, int>, std::vector<int>> cb;
+    for (int i = 0; i < Cp; i++) cb[{i / kAgg, i / kAgg}].push_back(i * 2);
+    std::vector<int> bi(Cp + nOff), bj(Cp + nOff);
+    for (int i = 0; i < Cp; i++) { bi[i] = i; bj[i] = i; }
+    for (int b = 0; b < nOff; b++) {
+      const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
+      bi[Cp + b] = i; bj[Cp + b] = j;
+      const int a = i / kAgg, a2 = j / kAgg;   // i < j => a <= a2
+      cb[{a, a2}].push_back((Cp + b) * 2 + (a == a2 ? 1 : 0));
+    }
+    std::vector<int> cb_off(1, 0), cb_ent, cb_ab;
+    for (auto& kv : cb) { cb_ab.push_back(kv.first.first); cb_ab.push_back(kv.first.second); cb_ent.insert(cb_ent.end(), kv.second.begin(), kv.second.end()); cb_off.push_back((int)cb_ent.size()); }
+    if (int rc2 = dev_upload(ba, cb_off, &ba->d_cb_off)) return rc2;
+    if (int rc2 = dev_upload(ba, cb_ent, &ba->d_cb_ent)) return rc2;
+    if (int rc2 = dev_upload(ba, cb_ab, &ba->d_cb_ab)) return rc2;
+    if (int rc2 = dev_upload(ba, bi, &ba->d_blk_i)) return rc2;
+    if (int rc2 = dev_upload(ba, bj, &ba->d_blk_j)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, 36 * (size_t)Cp, &ba->d_cP)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cA)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cX)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return rc2;
+    if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return rc2;
+    if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)std::max(n_units, 1), &ba->d_cparts)) return rc2;
+    ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
+    if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
+    return CCM_OK;
+  };
   // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device
   ba->pers_grid = 0;
   if (pers_fits && !getenv("CCM_BA_NO_PERSIST")) {
@@ -2285,37 +2436,29 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       // coarse level: aggregates of kAgg cameras; block lists of Ac = P^T S P
       if (!getenv("CCM_BA_NO_COARSE")) {
         const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
-        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && kAggUnits * na <= grid + kAggUnits - 1) {
-          std::map<std::pair<int, int>, std::vector<int>> cb;
-          for (int i = 0; i < Cp; i++) cb[{i / kAgg, i / kAgg}].push_back(i * 2);
-          std::vector<int> bi(Cp + nOff), bj(Cp + nOff);
-          for (int i = 0; i < Cp; i++) { bi[i] = i; bj[i] = i; }
-          for (int b = 0; b < nOff; b++) {
-            const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
-            bi[Cp + b] = i; bj[Cp + b] = j;
-            const int a = i / kAgg, a2 = j / kAgg;   // i < j => a <= a2
-            cb[{a, a2}].push_back((Cp + b) * 2 + (a == a2 ? 1 : 0));
-          }
-          std::vector<int> cb_off(1, 0), cb_ent, cb_ab;
-          for (auto& kv : cb) { cb_ab.push_back(kv.first.first); cb_ab.push_back(kv.first.second); cb_ent.insert(cb_ent.end(), kv.second.begin(), kv.second.end()); cb_off.push_back((int)cb_ent.size()); }
-          if (int rc2 = dev_upload(ba, cb_off, &ba->d_cb_off)) return fail(rc2);
-          if (int rc2 = dev_upload(ba, cb_ent, &ba->d_cb_ent)) return fail(rc2);
-          if (int rc2 = dev_upload(ba, cb_ab, &ba->d_cb_ab)) return fail(rc2);
-          if (int rc2 = dev_upload(ba, bi, &ba->d_blk_i)) return fail(rc2);
-          if (int rc2 = dev_upload(ba, bj, &ba->d_blk_j)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, 36 * (size_t)Cp, &ba->d_cP)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cA)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cX)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return fail(rc2);
-          if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return fail(rc2);
-          if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)grid, &ba->d_cparts)) return fail(rc2);
-          ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
-          if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
-        }
+        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && kAggUnits * na <= grid + kAggUnits - 1)
+          if (int rc2 = make_coarse(na, Nc, grid)) return fail(rc2);
       }
     }
     (void)hipGetLastError();
+  }
+  // maps too large for the persistent kernel: the same coarse level inside the multi-kernel PCG (kAgg = 2 clusters)
+  if (!ba->d_pers_coff && !pers_coff.empty()) {   // the cluster entry lists also serve the multi-kernel PCG's start kernel
+    if (int rc2 = dev_upload(ba, pers_coff, &ba->d_pers_coff)) return fail(rc2);
+    if (int rc2 = dev_upload(ba, pers_cij, &ba->d_pers_cij)) return fail(rc2);
+    if (int rc2 = dev_upload(ba, pers_cblk, &ba->d_pers_cblk)) return fail(rc2);
+  }
+  d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
+  if (!ba->pers_grid && Cp > kSmallMaxCp && !ba->coarse_na && !getenv("CCM_BA_NO_COARSE") && kAgg == 2 * kClu) {
+    const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
+    if (Nc <= 6144) {   // three Nc^2 f64 buffers: <= 0.9 GB
+      if (int rc2 = make_coarse(na, Nc, 0)) return fail(rc2);
+      const int n_clu = ccm_div_up(Cp, kClu);
+      if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)n_clu, &d.mk_cpart)) return fail(rc2);
+      if (int rc2 = dev_alloc<double>(ba, (size_t)n_clu, &d.mk_cry[0])) return fail(rc2);
+      if (int rc2 = dev_alloc<double>(ba, (size_t)n_clu, &d.mk_cry[1])) return fail(rc2);
+      d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
+    }
   }
   int rc = ccm_ba_reset_state(ba, P->cam_qt, P->pt_xyz);
   if (rc) return fail(rc);
@@ -2549,12 +2692,28 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (persist_ok) small_path = true;
     }
     if (!persist_ok) {
+      d.mk_on = 0;
+      if (d.mk_cpart && ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active))) {
+        RC(coarse_build(ba, lambda));
+        d.mk_on = 1;
+      }
+      ba->coarse_used = d.mk_on != 0;
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
       {
         static bool init_attr = false;
         const size_t lds_init = (size_t)(2 * kCluN * kCluN + kCluN + 8) * sizeof(double);
-        if (!init_attr) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_init)); init_attr = true; }
+        const size_t lds_tiles = (size_t)(2 * kCluN * kCluN + kCluN + kPersWaves) * sizeof(double) + 16;
+        if (!init_attr) {
+          CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_init));
+          CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
+          init_attr = true;
+        }
+        if (ba->d_pers_coff && !getenv("CCM_BA_OLD_INIT"))
+          hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
+                             (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
+        else
         hipLaunchKernelGGL(ba_pcg_init, dim3(d.n_wg_upd), dim3(kTPB), lds_init, ctx->stream, d, lambda, tol);
+        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)d.mk_na * sizeof(double), ctx->stream, d, 0);
       }
       const int chunk = 24;
       int k = 0;
@@ -2568,6 +2727,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
             hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)d.mk_na * sizeof(double), ctx->stream, d, (k + 1) & 1);
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
@@ -2598,7 +2758,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }
   if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
-  if (ba->coarse_na && small_path) {
+  if (ba->coarse_na && (small_path || d.mk_cpart)) {
     if (!ba->coarse_used && *pcg_iters >= kCoarseOnIters) ba->coarse_active = true;
     else if (ba->coarse_used && *pcg_iters <= kCoarseOffIters) ba->coarse_active = false;
   }

@@ -315,3 +315,29 @@ def test_fallback_kernels_dense_covisibility(ctx, oracle_lib):
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
     assert np.abs(pts - opts).max() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["always", "never"])
+def test_multi_kernel_pcg_with_and_without_the_coarse_level(ctx, oracle_lib, mode, monkeypatch):
+    """Maps above 2048 free cameras are solved by the multi-kernel PCG (tile factorisation start kernel, two kernels per
+    CG iteration, plus one for the coarse level).  CCM_BA_NO_PERSIST routes a 179-camera map through that path, with the
+    coarse level forced on / off: same LM path as the oracle either way."""
+    monkeypatch.setenv("CCM_BA_NO_PERSIST", "1")
+    monkeypatch.setenv("CCM_BA_COARSE", mode)
+    from ccm_slam_amd._lib import K
+    prob = synth.make_ba_problem(n_agents=3, kfs_per_agent=60, n_points=6000, seed=11)
+    h = optimizer.BAHandle(ctx, prob)
+    ctx.prof_enable(-1); ctx.prof_reset()
+    st = h.run(6)
+    n_pers, _ = ctx.prof_read(K["BA_PCG_PERSIST"]); n_spmv, _ = ctx.prof_read(K["BA_PCG_SPMV"])
+    ctx.prof_enable(-2)
+    cam, pts, _, _ = h.download()
+    h.close()
+    assert n_pers == 0 and n_spmv > 0
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 6)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
