@@ -697,97 +697,7 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
   }
 }
 
-__global__ __launch_bounds__(kTPB) void ba_pcg_init(BaDev d, double lambda, double rel_tol) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* A = sm;                    // [96][96] dense block, then its Cholesky factor (lower)
-  double* Li = sm + kCluN * kCluN;   // [96][96] inverse of the factor
-  double* rc = Li + kCluN * kCluN;   // [96]
-  double* red = rc + kCluN;          // [4]
-  int& bad = *reinterpret_cast<int*>(red + 4);
-  const int t = threadIdx.x, c = blockIdx.x;
-  const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
-  const int m = 6 * (s1 - s0);
-  if (t == 0) bad = 0;
-  for (int i = t; i < kCluN * kCluN; i += kTPB) { A[i] = 0; Li[i] = 0; }
-  __syncthreads();
-  // assemble: every CSR entry (i,j) of the cluster's rows with j inside the cluster
-  for (int i = s0; i < s1; i++)
-    for (int s = d.row_off[i] + t / 36; s < d.row_off[i + 1]; s += kTPB / 36) {
-      if (t >= (kTPB / 36) * 36) break;
-      const int j = d.row_col[s];
-      if (j < s0 || j >= s1) continue;
-      const uint32_t bt = d.row_blk[s];
-      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
-      const int e = t % 36, r = e / 6, cc = e % 6;
-      const double v = (bt & kTransposeBit) ? B[cc * 6 + r] : B[e];
-      A[(6 * (i - s0) + r) * kCluN + 6 * (j - s0) + cc] = v + ((i == j && r == cc) ? lambda : 0.0);
-    }
-  __syncthreads();
-  // Cholesky (lower) in place, column by column
-  for (int j = 0; j < m; j++) {
-    if (t == 0) {
-      const double dj = A[j * kCluN + j];
-      if (!(dj > 0.0)) { bad = 1; A[j * kCluN + j] = 1.0; } else A[j * kCluN + j] = sqrt(dj);
-    }
-    __syncthreads();
-    const double dinv = 1.0 / A[j * kCluN + j];
-    for (int i = j + 1 + t; i < m; i += kTPB) A[i * kCluN + j] *= dinv;
-    __syncthreads();
-    const int nr = m - j - 1;   // trailing rows
-    for (int e = t; e < nr * nr; e += kTPB) {
-      const int r = j + 1 + e / nr, cc = j + 1 + e % nr;
-      if (cc <= r) A[r * kCluN + cc] -= A[r * kCluN + j] * A[cc * kCluN + j];
-    }
-    __syncthreads();
-  }
-  // Li = L^-1 : thread c solves column c by forward substitution
-  if (t < m) {
-    for (int i = t; i < m; i++) {
-      double s = (i == t) ? 1.0 : 0.0;
-      for (int k = t; k < i; k++) s -= A[i * kCluN + k] * Li[k * kCluN + t];
-      Li[i * kCluN + t] = s / A[i * kCluN + i];
-    }
-  }
-  __syncthreads();
-  // W = Li^T Li  (symmetric), stored column-major == row-major
-  double* W = d.Wc + (size_t)c * kCluN * kCluN;
-  for (int e = t; e < m * m; e += kTPB) {
-    const int a = e / m, bcol = e % m;
-    double s = 0;
-    for (int k = max(a, bcol); k < m; k++) s += Li[k * kCluN + a] * Li[k * kCluN + bcol];
-    W[a * kCluN + bcol] = s;
-  }
-  // PCG start: x = 0, r = bs, z = W r, p_{-1} = 0
-  if (t < m) rc[t] = d.bs[6 * (size_t)s0 + t];
-  __syncthreads();
-  // z = W r = Li^T (Li r): two triangular mat-vecs out of LDS
-  double* yv = A;   // the factor is no longer needed: reuse its first row as scratch
-  __syncthreads();
-  if (t < m) {
-    double s = 0;
-    for (int k = 0; k <= t; k++) s += Li[t * kCluN + k] * rc[k];
-    yv[t] = s;
-  }
-  __syncthreads();
-  double rz = 0;
-  if (t < m) {
-    double s = 0;
-    for (int q = t; q < m; q++) s += Li[q * kCluN + t] * yv[q];
-    const size_t g = 6 * (size_t)s0 + t;
-    d.x[g] = 0; d.r[g] = rc[t]; d.z[g] = s; d.p[0][g] = 0;
-    rz = rc[t] * s;
-  }
-  rz = wave_sum(rz);
-  if ((t & (kWave - 1)) == 0) red[t / kWave] = rz;
-  __syncthreads();
-  if (t == 0) {
-    d.prz[0][c] = ((red[0] + red[1]) + red[2]) + red[3];
-    d.prz[1][c] = 0;
-    if (bad) d.pcg_flag[2] = 1;
-    if (c == 0) { d.pcg_scal[1] = rel_tol * rel_tol; d.pcg_scal[2] = lambda; }
-  }
-  if (d.mk_on) mk_restrict(d, c, s0, m, rc, A + kCluN);   // rows 1.. of A are free scratch now (row 0 holds yv)
-}
+// (the start kernel of this path, ba_pcg_init_tiles, is defined after the cluster factorisation it shares with the persistent kernel)
 
 // iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
 // Workgroup = 4 waves = 2 block rows, TWO waves per row: the row product is a chain of dependent loads
@@ -938,7 +848,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
-// Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per cluster after ba_pcg_init / ba_pcg_update:
+// Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per cluster after ba_pcg_init_tiles / ba_pcg_update:
 // rc = P^T r summed per aggregate (two clusters), y = Ac^-1[aggregate rows] rc (each cluster recomputes the 6 values of its
 // aggregate: 6 x Nc multiply-adds, cheaper than another grid-wide step), z += P y for the cluster's cameras, and the
 // coarse part of r.z = rc_agg . y_agg, counted by the first cluster of every aggregate.
@@ -1695,7 +1605,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 
 // Multi-kernel PCG start with the tile factorisation of the persistent kernel (one 16-wave workgroup per cluster): assembles
 // and inverts the damped cluster block, stores W for ba_pcg_update, sets x = 0, r = b, z = W r, p = 0 and the r.z partial.
-// The column-by-column ba_pcg_init took 1.43 ms per trial on 625 clusters (96 steps of three barriers); this one ~0.1 ms.
+// Its column-by-column predecessor took 1.43 ms per trial on 625 clusters (96 steps of three barriers); this one ~0.1 ms.
 __global__ __launch_bounds__(kPersTPB) void ba_pcg_init_tiles(BaDev d, double lambda, double rel_tol, const int* coff, const int* cij, const uint32_t* cblk) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int N = kCluN;
@@ -2701,18 +2611,14 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
       {
         static bool init_attr = false;
-        const size_t lds_init = (size_t)(2 * kCluN * kCluN + kCluN + 8) * sizeof(double);
         const size_t lds_tiles = (size_t)(2 * kCluN * kCluN + kCluN + kPersWaves) * sizeof(double) + 16;
         if (!init_attr) {
-          CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_init));
           CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
           init_attr = true;
         }
-        if (ba->d_pers_coff && !getenv("CCM_BA_OLD_INIT"))
-          hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
-                             (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
-        else
-        hipLaunchKernelGGL(ba_pcg_init, dim3(d.n_wg_upd), dim3(kTPB), lds_init, ctx->stream, d, lambda, tol);
+        if (!ba->d_pers_coff) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba: cluster entry lists missing");
+        hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
+                           (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
         if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)d.mk_na * sizeof(double), ctx->stream, d, 0);
       }
       const int chunk = 24;
