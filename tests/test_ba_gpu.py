@@ -341,3 +341,21 @@ def test_multi_kernel_pcg_with_and_without_the_coarse_level(ctx, oracle_lib, mod
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
     assert np.abs(pts - opts).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_config3_three_agent_map(ctx, oracle_lib):
+    """BASELINE config 3 at full size (3 agents x 400 keyframes, 90 000 landmarks): global BA after a map merge on one GPU,
+    4 LM iterations against the oracle."""
+    prob = synth.make_ba_config("gba_c3")
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(4)
+    cam, pts, _, _ = h.download()
+    h.close()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 4)
+    assert st.iters_done == ost.iters_done == 4 and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
+    assert np.array_equal(cam[0], prob["cam_qt"][0])
