@@ -1650,9 +1650,10 @@ static inline size_t pers_lds_bytes() {
   return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN + kPersWaves + 4) * sizeof(double) + 16 + 14 * sizeof(long long);
 }
 
-// ---- small reduced systems (local BA: tens of cameras): the whole PCG in ONE workgroup ---------------------
-// A multi-kernel PCG iteration costs two launches (~25 us) whatever the size; for Cp <= 256 the vectors and
-// the block-Jacobi preconditioner fit in LDS and a full iteration is a few block barriers (~2 us).
+// ---- very small reduced systems (<= 16 free cameras: initial maps, tiny local windows): the whole PCG in ONE workgroup ----
+// Vectors and the 6x6 block-Jacobi preconditioner live in LDS and an iteration is a few block barriers (~2 us).  Typical
+// local-BA sizes (tens of cameras) go through the persistent kernel instead: its 16-camera cluster preconditioner needs
+// a third of the iterations (lba_c2: 59 -> 19 per solve).
 constexpr int kSmallMaxCp = 16;   // one cluster: the single-workgroup kernel; above, the persistent kernel with its 16-camera cluster preconditioner
 
 template <int TPB>
