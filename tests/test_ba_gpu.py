@@ -359,3 +359,22 @@ def test_config3_three_agent_map(ctx, oracle_lib):
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
     assert np.abs(pts - opts).max() <= 1e-4
     assert np.array_equal(cam[0], prob["cam_qt"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kfs", [18, 26, 34, 49, 66])
+def test_camera_counts_around_the_cluster_size(ctx, oracle_lib, kfs):
+    """Free-camera counts that leave the last 16-camera cluster (and its second 8-row unit) partly or wholly empty:
+    17, 25, 33, 48, 65 free cameras through the persistent kernel."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=kfs, n_points=60 * kfs, seed=100 + kfs)
+    h = optimizer.BAHandle(ctx, prob)
+    assert h.counts()["free_cams"] == kfs - 1
+    st = h.run(5)
+    cam, pts, _, _ = h.download()
+    h.close()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 5)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
