@@ -2214,7 +2214,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (int rc = dev_alloc<int>(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al, false)) return fail(rc);
     d.inst_al = p_al;
     d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0;
-    if (nOff > 8192 && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 32)) {
+    if (nOff > 8192 && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
       std::vector<int> h_off((size_t)nOff + 1);
       if (hipMemcpyAsync(h_off.data(), d_inst_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: instance offsets read-back"));
