@@ -302,7 +302,8 @@ def main():
     extra = None
     if rank == 0:
         extra = tracking_leg(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
-        extra.update(local_ba_leg(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline)))
+        if world == 1:   # per-agent figure, independent of N; a single-rank solve has no business inside a sharded job's timing run
+            extra.update(local_ba_leg(ctx, with_cpu=not args.no_cpu_baseline))
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(done, 1)

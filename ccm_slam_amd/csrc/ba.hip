@@ -1987,6 +1987,18 @@ int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
 
 #define RC(x) do { int _rc = (x); if (_rc != CCM_OK) return _rc; } while (0)
 
+// Collectives of a BA handle.  A handle created for ONE rank never enters a collective, even when its context carries a
+// multi-rank communicator (bench.py runs a single-rank local BA on rank 0 of a sharded job: an all-reduce issued by that
+// rank alone would wait for its peers forever).
+static inline int ba_allreduce_sum(ccm_ba* ba, double* buf, size_t n) {
+  if (ba->nranks <= 1 && ba->ctx->comm_nranks > 1) return CCM_OK;
+  return ccm_allreduce_f64(ba->ctx, buf, n);
+}
+static inline int ba_allreduce_max(ccm_ba* ba, double* buf, size_t n) {
+  if (ba->nranks <= 1 && ba->ctx->comm_nranks > 1) return CCM_OK;
+  return ccm_allreduce_max_f64(ba->ctx, buf, n);
+}
+
 }  // namespace
 
 // Host-only partition of landmark slots into nranks contiguous ranges balanced by weight
@@ -2447,7 +2459,7 @@ int eval_chi2(ccm_ba* ba, double* chi) {
   }
   hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
-  RC(ccm_allreduce_f64(ctx, d.scal, 2));
+  RC(ba_allreduce_sum(ba, d.scal, 2));
   double s[4];
   RC(read_scalars(ba, s));
   *chi = s[0];
@@ -2477,13 +2489,13 @@ int max_diag(ccm_ba* ba, double* out) {
   const double* hpp = d.Hpp;
   if (ba->nranks > 1 && d.Cp) {
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_hpp_full, d.Hpp, 36 * (size_t)d.Cp * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    RC(ccm_allreduce_f64(ctx, ba->d_hpp_full, 36 * (size_t)d.Cp));
+    RC(ba_allreduce_sum(ba, ba->d_hpp_full, 36 * (size_t)d.Cp));
     hpp = ba->d_hpp_full;
   }
   const int nb = std::max(1, std::min(d.n_wg_pt, 512));   // partials live in part_pt (>= 2*n_wg_pt doubles)
   hipLaunchKernelGGL(ba_maxdiag, dim3(nb), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 0);
   hipLaunchKernelGGL(ba_maxdiag, dim3(1), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 1);
-  RC(ccm_allreduce_max_f64(ctx, d.scal + 2, 1));
+  RC(ba_allreduce_max(ba, d.scal + 2, 1));
   double s[4];
   RC(read_scalars(ba, s));
   *out = s[2];
@@ -2534,7 +2546,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         hipLaunchKernelGGL(ba_schur_row, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
-    RC(ccm_allreduce_f64(ctx, ba->d_red, ba->red_count));
+    RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
     // ---- PCG ----
     const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-8;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
@@ -2656,7 +2668,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
   }
   hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
-  RC(ccm_allreduce_f64(ctx, d.scal, 2));
+  RC(ba_allreduce_sum(ba, d.scal, 2));
   double s[4];
   RC(read_scalars(ba, s, small_flags));
   CCM_HIP_CHECK(ctx, hipGetLastError());
@@ -2833,7 +2845,7 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
     if (ba->nranks > 1) {
       CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pt_full, 0, pts.size() * sizeof(double), ctx->stream));
       if (ba->Lloc) hipLaunchKernelGGL(ba_scatter_points, dim3(ccm_div_up(ba->Lloc, kTPB)), dim3(kTPB), 0, ctx->stream, ba->d_pt_full, d.pt[ba->cur], ba->d_own_slot, ba->Lloc);
-      RC(ccm_allreduce_f64(ctx, ba->d_pt_full, pts.size()));
+      RC(ba_allreduce_sum(ba, ba->d_pt_full, pts.size()));
       CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), ba->d_pt_full, pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else {
       CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), d.pt[ba->cur], pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
