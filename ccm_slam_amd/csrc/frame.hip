@@ -273,35 +273,38 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
   cand_off[0] = 0;
   if (Q == 0) return CCM_OK;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  // device staging: [u | v | r | minl | maxl] (5Q words) | qdesc (32Q) | cnt (Q) | off (Q+1) | idx (cap) | dist (cap u16)
+  // device staging, mirrored byte for byte in one pinned block so that the inputs travel in ONE H2D copy and the results in
+  // ONE D2H copy:  in = [u | v | r | minl | maxl] (5Q words) | qdesc (32Q);  cnt (Q);  out = off (Q+1) | idx (cap) | dist (cap u16)
   const size_t wQ = (size_t)Q;
-  const size_t bytes = ccm_align256(20 * wQ) + ccm_align256(32 * wQ) + ccm_align256(4 * wQ) + ccm_align256(4 * (wQ + 1)) + ccm_align256(4 * (size_t)cap) +
-                       ccm_align256(2 * (size_t)cap) + 256;
+  const size_t o_desc = ccm_align256(20 * wQ), in_bytes = o_desc + ccm_align256(32 * wQ);
+  const size_t o_idx = ccm_align256(4 * (wQ + 1)), o_dist = o_idx + ccm_align256(4 * (size_t)cap), out_bytes = o_dist + ccm_align256(2 * (size_t)cap);
+  const size_t cnt_bytes = ccm_align256(4 * wQ);
   void* scratch = nullptr;
-  if (int rc = ccm_io_scratch(ctx, bytes, &scratch)) return rc;
-  uint8_t* base = (uint8_t*)scratch;
-  float* d_q = (float*)base; base += ccm_align256(20 * wQ);
-  uint8_t* d_qdesc = base; base += ccm_align256(32 * wQ);
-  int* d_cnt = (int*)base; base += ccm_align256(4 * wQ);
-  int* d_off = (int*)base; base += ccm_align256(4 * (wQ + 1));
-  int* d_idx = (int*)base; base += ccm_align256(4 * (size_t)cap);
-  uint16_t* d_dist = (uint16_t*)base;
+  if (int rc = ccm_io_scratch(ctx, in_bytes + cnt_bytes + out_bytes + 256, &scratch)) return rc;
+  uint8_t* d_in = (uint8_t*)scratch;
+  float* d_q = (float*)d_in;
+  uint8_t* d_qdesc = d_in + o_desc;
+  int* d_cnt = (int*)(d_in + in_bytes);
+  uint8_t* d_out = d_in + in_bytes + cnt_bytes;
+  int* d_off = (int*)d_out;
+  int* d_idx = (int*)(d_out + o_idx);
+  uint16_t* d_dist = (uint16_t*)(d_out + o_dist);
   void* pin = nullptr;
-  if (int rc = ccm_pin_scratch(ctx, 52 * wQ + 4 * (wQ + 1) + 6 * (size_t)cap + 64, &pin)) return rc;
+  if (int rc = ccm_pin_scratch(ctx, in_bytes + out_bytes + 64, &pin)) return rc;
   uint8_t* h = (uint8_t*)pin;
   memcpy(h, u, 4 * wQ); memcpy(h + 4 * wQ, v, 4 * wQ); memcpy(h + 8 * wQ, r, 4 * wQ);
   memcpy(h + 12 * wQ, min_level, 4 * wQ); memcpy(h + 16 * wQ, max_level, 4 * wQ);
-  memcpy(h + 20 * wQ, qdesc, 32 * wQ);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, h, 20 * wQ, hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_qdesc, h + 20 * wQ, 32 * wQ, hipMemcpyHostToDevice, ctx->stream));
+  memcpy(h + o_desc, qdesc, 32 * wQ);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_in, h, o_desc + 32 * wQ, hipMemcpyHostToDevice, ctx->stream));
   WinQ wq{d_q, d_q + wQ, d_q + 2 * wQ, (const int*)(d_q + 3 * wQ), (const int*)(d_q + 4 * wQ)};
   const int nb = ccm_div_up((int64_t)Q * kQL, 128);
   hipLaunchKernelGGL(frame_window_kernel<0>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx, d_cnt,
                      (const int*)nullptr, (int*)nullptr, 0);
   hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cnt, Q, d_off);
-  int* h_off = (int*)(h + 52 * wQ);
-  uint8_t* h_idx = h + 52 * wQ + 4 * (wQ + 1);
-  uint8_t* h_dist = h_idx + 4 * (size_t)cap;
+  uint8_t* h_out = h + in_bytes;
+  int* h_off = (int*)h_out;
+  uint8_t* h_idx = h_out + o_idx;
+  uint8_t* h_dist = h_out + o_dist;
   if (cap > 0) {
     // optimistic single-sync path: fill and distances are queued behind the scan without waiting for the total; the
     // fill kernel never writes past cap (queries whose list would cross it are skipped) and the total is checked after
@@ -309,9 +312,7 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
                        (int*)nullptr, (const int*)d_off, d_idx, (int)std::min<int64_t>(cap, 0x7fffffff));
     CCM_HIP_CHECK(ctx, hipGetLastError());
     if (int rc = ccm_hamming_csr_dev(ctx, d_qdesc, Q, f->d_desc, f->N, d_off, d_idx, cap, d_dist, nullptr, nullptr, nullptr)) return rc;
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_off, d_off, 4 * (wQ + 1), hipMemcpyDeviceToHost, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_idx, d_idx, 4 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_dist, d_dist, 2 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, o_dist + 2 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t total = h_off[Q];
     memcpy(cand_off, h_off, 4 * (wQ + 1));
