@@ -18,6 +18,7 @@ struct ccm_frame {
   // device: [xy_un 2N f32 | octave N i32 | cell_idx N i32 | cell_off 3601 i32] + descriptors N x 32
   float* d_xy = nullptr; int* d_oct = nullptr; int* d_cell_idx = nullptr; int* d_cell_off = nullptr; uint8_t* d_desc = nullptr;
   ccm_keypoint* d_kps = nullptr;
+  uint8_t* h_stage = nullptr;   // pinned mirror of the [desc | kps] block (own buffer: the upload is not synchronised at return)
 };
 
 namespace {
@@ -177,13 +178,18 @@ int frame_reserve(ccm_frame* f, int n) {
   if (n <= f->cap) return CCM_OK;
   ccm_ctx* ctx = f->ctx;
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_desc, (void*)f->d_kps}) if (p) hipFree(p);
+  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_desc}) if (p) hipFree(p);   // d_kps lives inside d_desc's block
   const int cap = std::max(2048, n + n / 2);
   CCM_HIP_CHECK(ctx, hipMalloc(&f->d_xy, 2 * sizeof(float) * (size_t)cap));
   CCM_HIP_CHECK(ctx, hipMalloc(&f->d_oct, sizeof(int) * (size_t)cap));
   CCM_HIP_CHECK(ctx, hipMalloc(&f->d_cell_idx, sizeof(int) * (size_t)cap));
-  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_desc, 32 * (size_t)cap));
-  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_kps, sizeof(ccm_keypoint) * (size_t)cap));
+  // descriptors and keypoints in ONE block [desc 32 cap | kps]: ccm_frame_set_keypoints uploads both with one copy
+  uint8_t* blk = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&blk, (32 + sizeof(ccm_keypoint)) * (size_t)cap + 256));
+  f->d_desc = blk;
+  f->d_kps = reinterpret_cast<ccm_keypoint*>(blk + ccm_align256(32 * (size_t)cap));
+  if (f->h_stage) hipHostFree(f->h_stage);
+  CCM_HIP_CHECK(ctx, hipHostMalloc(&f->h_stage, (32 + sizeof(ccm_keypoint)) * (size_t)cap + 256, hipHostMallocDefault));
   f->cap = cap;
   return CCM_OK;
 }
@@ -222,7 +228,8 @@ extern "C" void ccm_frame_destroy(ccm_frame* f) {
   if (!f) return;
   hipSetDevice(f->ctx->device);
   hipStreamSynchronize(f->ctx->stream);
-  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_cell_off, (void*)f->d_desc, (void*)f->d_kps}) if (p) hipFree(p);
+  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_cell_off, (void*)f->d_desc}) if (p) hipFree(p);   // d_kps is part of d_desc's block
+  if (f->h_stage) hipHostFree(f->h_stage);
   delete f;
 }
 
@@ -238,9 +245,12 @@ extern "C" int ccm_frame_set_keypoints(ccm_frame* f, const ccm_keypoint* kps, co
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int rc = frame_reserve(f, n)) return rc;
   f->N = n;
-  if (n) {
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(f->d_kps, kps, sizeof(ccm_keypoint) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(f->d_desc, desc, 32 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  if (n) {   // both arrays through the pinned staging block, laid out like the device block: one DMA instead of two pageable copies
+    const size_t o_k = ccm_align256(32 * (size_t)f->cap), bytes = o_k + sizeof(ccm_keypoint) * (size_t)n;
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the staging block may still feed the previous frame's copy
+    memcpy(f->h_stage, desc, 32 * (size_t)n);
+    memcpy(f->h_stage + o_k, kps, sizeof(ccm_keypoint) * (size_t)n);
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(f->d_desc, f->h_stage, bytes, hipMemcpyHostToDevice, ctx->stream));
   }
   hipLaunchKernelGGL(frame_grid_kernel, dim3(1), dim3(kGridTPB), 0, ctx->stream, f->d_kps, n, f->cam, f->b, f->distorted, f->d_xy, f->d_oct,
                      f->d_cell_off, f->d_cell_idx);
