@@ -493,6 +493,8 @@ struct ccm_orb {
   KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr; int kp_cap = 0;
   int* h_cand = nullptr;   // pinned
   KpIn* h_kin = nullptr;   // pinned
+  uint8_t* h_io = nullptr;  // pinned: the input image on the way in, [keypoints | descriptors] on the way out (one DMA each)
+  size_t h_io_bytes = 0;
   hipEvent_t ev_cand = nullptr;
   double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
   Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
@@ -503,12 +505,13 @@ struct ccm_orb {
 static void orb_free_geometry(ccm_orb* o) {
   hipFree(o->d_pyr); hipFree(o->d_score); hipFree(o->d_blur); hipFree(o->d_tabs); hipFree(o->d_cell_slots);
   hipFree(o->d_cell_counts); hipFree(o->d_cand); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
-  hipFree(o->d_kin); hipFree(o->d_kout); hipFree(o->d_desc);
+  hipFree(o->d_kin); hipFree(o->d_kout);   // d_desc is part of d_kout's block
   if (o->h_cand) hipHostFree(o->h_cand);
   if (o->h_kin) hipHostFree(o->h_kin);
+  if (o->h_io) hipHostFree(o->h_io);
   o->d_pyr = o->d_score = o->d_blur = nullptr; o->d_tabs = nullptr; o->d_cell_slots = nullptr; o->d_cell_counts = nullptr;
   o->d_cand = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->d_kin = nullptr; o->d_kout = nullptr; o->d_desc = nullptr;
-  o->h_cand = nullptr; o->h_kin = nullptr;
+  o->h_cand = nullptr; o->h_kin = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
 }
 
 extern "C" int ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
@@ -647,8 +650,15 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_level, tile_level.data(), tile_level.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_xy, tile_xy.data(), tile_xy.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_kout, (size_t)o->kp_cap * sizeof(ccm_keypoint)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_desc, (size_t)o->kp_cap * 32));
+  {   // keypoints and descriptors in one block [kout | desc] so that the results leave with one copy
+    uint8_t* blk = nullptr;
+    const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
+    CCM_HIP_CHECK(ctx, hipMalloc(&blk, o_d + (size_t)o->kp_cap * 32 + 256));
+    o->d_kout = reinterpret_cast<ccm_keypoint*>(blk);
+    o->d_desc = blk + o_d;
+    o->h_io_bytes = std::max((size_t)w * h, o_d + (size_t)o->kp_cap * 32) + 256;
+    CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_io, o->h_io_bytes, hipHostMallocDefault));
+  }
   CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int), hipHostMallocDefault));
   CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_kin, (size_t)o->kp_cap * sizeof(KpIn), hipHostMallocDefault));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -752,7 +762,9 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   const LevelInfo& L0 = o->dev.lv[0];
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
-  CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+  // the image goes through the pinned block (packed rows): a pageable source makes the runtime stage and wait
+  for (int y = 0; y < h; y++) memcpy(o->h_io + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+  CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, o->h_io, w, w, h, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = orb_phase1(o))) return rc;
   const double t1 = now();
   int n = 0;
@@ -761,10 +773,9 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   if ((rc = orb_phase2(o, n))) return rc;
   const double t4 = now();
   const int nc = std::min(n, cap);
-  if (nc) {
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(kps, o->d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToHost, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(desc, o->d_desc, (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
-  }
+  const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
+  // (the image upload from h_io completed before the host octree ran: the candidate read-back waited behind it)
+  if (nc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, o->d_kout, o_d + (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
   if (pyramid_out)
     for (int l = 0; l < o->nlevels; l++)
       if (pyramid_out[l]) {
@@ -772,6 +783,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
         CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, o->d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
       }
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (nc) { memcpy(kps, o->h_io, (size_t)nc * sizeof(ccm_keypoint)); memcpy(desc, o->h_io + o_d, (size_t)nc * 32); }
   const double t5 = now();
   o->t_phase[0] = t1 - t0; o->t_phase[1] = o->t_wait_cand; o->t_phase[2] = (t3 - t1) - o->t_wait_cand; o->t_phase[3] = t4 - t3; o->t_phase[4] = t5 - t4; o->t_phase[5] = t5 - t0;
   *n_out = nc;
