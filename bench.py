@@ -2,19 +2,24 @@
 """bench.py — headline measurement of the CCM-SLAM hot path on MI355X.
 
 Metric (BASELINE.json): "tracked fps/agent + global-BA ms/iter, EuRoC MH 4-agent merge @1/2/4/8 GPU".
-The JSON line's `value` is the global-BA rate (LM iterations / s, whole job) on the synthetic
-4-agent merged map `gba_c4` (2000 KFs, 150k landmarks, ~0.95M observations; SURVEY §8d config 4);
-`ms_per_step` is the global-BA ms/iter the metric names; the tracked-fps half of the metric is
+`value` is the global-BA rate (LM iterations / s, whole job) on the synthetic 4-agent merged map `gba_c4`
+(2000 KFs, 150k landmarks, ~0.95M observations); the tracked-fps half of the metric is
 reported in `extra.tracked_fps_per_agent` (per-stage times beside it).
 
-A "step" is one Levenberg–Marquardt iteration of Optimizer::MapFusionGBA's optimize() call
-(cslam/src/Optimizer.cpp:796-801): linearise all edges, then per LM trial Schur-eliminate the
-landmarks, solve the reduced camera system, back-substitute, update, evaluate chi2.
-With N > 1 GPUs the landmarks are sharded across ranks (one RCCL all-reduce of the reduced camera
-system per LM trial); the total problem is fixed => "scaling": "strong".
+A "step" is ONE complete global bundle adjustment as Optimizer::MapFusionGBA runs it (cslam/src/Optimizer.cpp:796-797):
+`optimizer.initializeOptimization(); optimizer.optimize(20)` from the initial (f32-rounded) estimate, ended by g2o's own
+stop rules — on gba_c4 that is 12 LM iterations / 18 LM trials (chi2 stagnation), exactly what the CPU oracle does on the
+same input (tests/golden/gba_c4_full.npz).  `ms_per_step` is the wall time of that call, the number the reference prints
+(:798-801); `config.ms_per_lm_iteration` (= the metric's "global-BA ms/iter") and `config.ms_per_lm_trial` are derived
+from the same timed region.  Per LM trial: Schur-eliminate the landmarks, solve the reduced camera system,
+back-substitute, update, evaluate chi2; per LM iteration additionally linearise all edges.
+With N > 1 GPUs the landmarks are sharded across ranks (one RCCL all-reduce of the reduced camera system per LM trial);
+the total problem is fixed => "scaling": "strong".
 
-Inputs are uploaded (and the Schur structure built) before the timed region; the timed region is
-exactly K LM iterations bracketed by barrier + device synchronise, MAX over ranks.
+Inputs are uploaded, the Schur structure built and the initial estimate saved in HBM before the timed region; the timed
+region is exactly K steps (each restoring the estimate device-to-device) bracketed by barrier + device synchronise, MAX
+over ranks.  `roofline` = the dominant kernel, `roofline_trial` = the whole LM trial against SURVEY §8(d)'s byte formula,
+`kernels` = every kernel class of the call (HIP events on the launching stream, taken in a second, untimed pass).
 """
 from __future__ import annotations
 
@@ -160,16 +165,73 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
     return out
 
 
+# ---- algorithmic HBM bytes per launch of every BA kernel class (E edges, L landmarks, C free cameras,
+# B Schur blocks incl. diagonal, P pair instances, n_off = B - C)
+def ba_kernel_bytes(counts):
+    E, L, C, B, P = (float(counts[k]) for k in ("edges", "points", "free_cams", "blocks", "pairs"))
+    n_off = B - C
+    return {
+        # what the persistent solve must move once per launch: S, b in; x out (S is held in registers, vectors in LDS, for
+        # the whole solve: every further byte is on-chip)
+        "BA_PCG_PERSIST": 288.0 * B + 2 * 48.0 * C,
+        "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,          # per CG iteration: S once + z, p in, q, p out
+        "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,
+        # row kernel: every observation's W and D^-1 once, every off-diagonal and diagonal block written once
+        "BA_SCHUR_OFF": 144.0 * E + 48.0 * L + 288.0 * B,
+        "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
+        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + 144.0) * E + (24.0 + 72.0) * L,
+        "BA_CAM": (24.0 + 24.0 + 8.0) * E + (56.0 + 288.0 + 48.0) * C,
+        "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
+        "BA_BACKSUB": (144.0 + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L,
+        "BA_UPDATE": (56.0 * 2 + 48.0 * 2) * C,
+        "BA_CHI2": (56.0 + 24.0 + 9.0 + 8.0) * E + 24.0 * L,
+        "BA_COARSE": 288.0 * B + 288.0 * C,               # S and the prolongation blocks once
+        "BA_REDUCE": 16.0 * (E / 256.0),
+    }
+
+
+KERNEL_OF_CLASS = {   # device kernel(s) behind every profiling class on the gba-sized path (names as rocprofv3 prints them)
+    "BA_LINEARIZE": "ba_linearize_pts_e", "BA_CAM": "ba_linearize_cams", "BA_DINV": "ba_dinv", "BA_SCHUR_DIAG": "ba_schur_diag",
+    "BA_SCHUR_OFF": "ba_schur_row", "BA_PCG_SPMV": "ba_pcg_spmv", "BA_PCG_UPDATE": "ba_pcg_update", "BA_BACKSUB": "ba_backsub_chi2_e",
+    "BA_UPDATE": "ba_update_cams", "BA_CHI2": "ba_backsub_chi2_e", "BA_PCG_PERSIST": "ba_pcg_persist",
+    "BA_COARSE": "ba_coarse_assemble+chol_*", "BA_REDUCE": "ba_reduce_scalars"}
+LIMITER = {"BA_PCG_PERSIST": "latency (grid exchange): two grid-wide exchanges of ~3.3 us per CG iteration, S stays in registers",
+           "BA_COARSE": "latency (dependent tile launches of the dense inverse)", "BA_REDUCE": "latency (single workgroup)",
+           "BA_UPDATE": "latency (launch)", "BA_DINV": "hbm"}
+
+
+def pmc_lookup(workload):
+    """profiles/pmc_latest.json (scripts/profile.sh + scripts/collect_profiles.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes over `bench.py --gba-only`, keyed by kernel AND grid so that launches of different problem sizes never mix).  PMC
+    counters cannot be collected from inside this process: these are the last committed values for this workload."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if pmc.get("workload") != workload:
+            return {}
+        out = {}
+        for ent in pmc["kernels"]:
+            cur = out.get(ent["kernel"])
+            if cur is None or ent["launches"] > cur["launches"]:
+                out[ent["kernel"]] = ent
+        return out
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)   # Opt.GBAIterations = 20 (cslam/conf/config.yaml:129)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="gba_c4")
+    ap.add_argument("--gba-iterations", type=int, default=20)   # Opt.GBAIterations = 20 (cslam/conf/config.yaml:129)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gba-only", action="store_true", help="skip the tracking / local-BA legs and the CPU baseline (profiling runs)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--pcg-max-iters", type=int, default=0)
     args = ap.parse_args()
+    if args.gba_only:
+        args.no_cpu_baseline = True
 
     import numpy as np
     import torch  # device sync + torch.distributed plumbing only
@@ -210,78 +272,81 @@ def main():
     h = optimizer.BAHandle(ctx, prob, rank=rank, nranks=world)
     setup_s = time.perf_counter() - t0
     counts = h.counts()
+    h.push_state()           # the f32-rounded initial estimate stays in HBM; every step starts from it (device-to-device)
 
-    def run_iters(n):
-        """exactly n LM iterations (re-entering optimize() if g2o's stop rule ends a call early)"""
-        done, trials, pcg = 0, 0, 0
-        while done < n:
-            st = h.run(n - done, pcg_max_iters=args.pcg_max_iters)
-            done += st.iters_done
-            trials += st.lm_trials
-            pcg += st.pcg_iters
-            if st.iters_done == 0:
-                break
-        return done, trials, pcg, st
+    def one_call():
+        """ONE step = one MapFusionGBA optimisation as the reference runs it (Optimizer.cpp:796-797):
+        optimizer.initializeOptimization(); optimizer.optimize(nIterations = 20) from the initial estimate, ended by g2o's own
+        stop rules (gba_c4: 12 LM iterations / 18 trials, chi2 stagnation)."""
+        h.pop_state()
+        return h.run(args.gba_iterations, pcg_max_iters=args.pcg_max_iters)
 
-    # ---- warmup: also finds the dominant kernel class (events on every class here, not in the timed run)
-    ctx.prof_enable(-1)
-    ctx.prof_reset()
-    if args.warmup > 0:
-        run_iters(args.warmup)
-    prof = {name: ctx.prof_read(k) for name, k in K.items() if name.startswith("BA_")}
-    dominant = max(prof, key=lambda n: prof[n][1]) if any(v[0] for v in prof.values()) else "BA_SCHUR_OFF"
-    h.reset()
-    ctx.prof_enable(K[dominant])
-    ctx.prof_reset()
+    # ---- warmup
+    for _ in range(args.warmup):
+        one_call()
 
-    # ---- timed region
+    # ---- timed region: exactly K steps, no per-kernel events
+    ctx.prof_enable(-2)
     barrier()
     t0 = time.perf_counter()
-    done, trials, pcg, st = run_iters(args.steps)
+    iters = trials = pcg = 0
+    for _ in range(args.steps):
+        st = one_call()
+        iters += st.iters_done
+        trials += st.lm_trials
+        pcg += st.pcg_iters
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    launches, kernel_ms = ctx.prof_read(K[dominant])
-    ctx.prof_enable(-2)
+    chi_hist, lam_hist, tr_hist = h.history()
+    steps = max(args.steps, 1)
+    call_ms = elapsed * 1e3 / steps
+    trial_ms = elapsed * 1e3 / max(trials, 1)
 
-    # ---- roofline of the dominant kernel (algorithmic bytes per launch, DESIGN.md §Kernels)
-    E, L, C, B, P = counts["edges"], counts["points"], counts["free_cams"], counts["blocks"], counts["pairs"]
-    n_off = B - C
-    alg_bytes = {
-        # persistent single-launch PCG: one launch = (CG iterations of one LM trial) x the per-iteration figure below
-        "BA_PCG_PERSIST": (288.0 * B + 4 * 48.0 * C) * (pcg / max(launches, 1)),
-        # q = S p over the symmetric block matrix read once + z,p in, q,p out
-        "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,
-        "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,
-        # per pair instance two 6x3 W blocks + symmetric Dinv, per block one 6x6 store
-        # row-centric form: per pair instance one 6x3 W block + 2 indices, per observation W + Dinv once, per block one 6x6 store
-        "BA_SCHUR_OFF": (144.0 + 8.0) * P + (144.0 + 48.0) * E + 288.0 * n_off,
-        "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
-        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + 144.0) * E + (24.0 + 72.0) * L,
-        "BA_CAM": (24.0 + 24.0 + 8.0) * E + (56.0 + 288.0 + 48.0) * C,
-        "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
-        "BA_BACKSUB": (144.0 + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L,
-        "BA_UPDATE": (56.0 * 2 + 48.0 * 2) * C,
-        "BA_CHI2": (56.0 + 24.0 + 9.0 + 8.0) * E + 24.0 * L,
-    }[dominant]
-    avg_ms = kernel_ms / launches if launches else float("nan")
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    # HBM traffic per launch from the committed PMC passes of the same workload (profiles/pmc_latest.json, produced by
-    # scripts/profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied); PMC
-    # counters cannot be collected from inside this process, so this is the last profiled value, not a live one.
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if args.workload == "gba_c4" and world == 1:
-            traffic = pmc["kernels"].get(dominant.lower(), {}).get("hbm_bytes_per_launch")
-    except Exception:
-        traffic = None
-    roofline = {"kernel": dominant.lower(), "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "launches": launches, "avg_us": round(avg_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes}
+    # ---- per-kernel pass (untimed): the same call once more with HIP events around every launch, on the launching stream
+    ctx.prof_enable(-1)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    stp = one_call()
+    ctx.sync()
+    prof_call_ms = (time.perf_counter() - t0) * 1e3
+    prof = {name: ctx.prof_read(k) for name, k in K.items() if name.startswith("BA_")}
+    ctx.prof_enable(-2)
+    kb = ba_kernel_bytes(counts)
+    pmc = pmc_lookup(args.workload) if world == 1 else {}
+    kernels = []
+    for name, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if not n:
+            continue
+        avg_us = ms * 1e3 / n
+        ach = kb[name] / (avg_us * 1e-6) / 1e9
+        ent = pmc.get(KERNEL_OF_CLASS[name].split("+")[0])
+        kernels.append({"class": name.lower(), "kernel": KERNEL_OF_CLASS[name], "launches_per_call": n, "avg_us": round(avg_us, 2),
+                        "ms_per_call": round(ms, 4), "algorithmic_bytes_per_launch": kb[name], "achieved_GBps": round(ach, 1),
+                        "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5), "limiter": LIMITER.get(name, "hbm"),
+                        "pmc_hbm_bytes_per_launch": ent["hbm_bytes_per_launch"] if ent else None,
+                        "pmc_avg_us": ent.get("avg_us") if ent else None, "pmc_grid": ent["grid"] if ent else None})
+    dom = kernels[0] if kernels else None
+    roofline = None
+    if dom:
+        # dominant kernel (largest share of the call).  `bound` names what limits it; achieved / frac are its ALGORITHMIC bytes
+        # over its measured duration against the HBM peak whatever the limiter, so the number stays comparable across rounds.
+        roofline = {"kernel": dom["kernel"], "bound": "hbm" if dom["limiter"] == "hbm" else dom["limiter"], "achieved": dom["achieved_GBps"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": dom["pmc_hbm_bytes_per_launch"],
+                    "launches": dom["launches_per_call"], "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                    "share_of_call": round(dom["ms_per_call"] / max(sum(k["ms_per_call"] for k in kernels), 1e-9), 3)}
+    # whole LM trial against the HBM roofline, SURVEY §8(d): bytes(trial) = 656 E + 312 L + 700 C + 576 S
+    E, L, C, B = counts["edges"], counts["points"], counts["free_cams"], counts["blocks"]
+    trial_bytes = 656.0 * E + 312.0 * L + 700.0 * C + 576.0 * B
+    trial_gbs = trial_bytes / (trial_ms * 1e-3) / 1e9
+    roofline_trial = {"what": "one LM trial, all kernels + host LM control, SURVEY 8(d) byte formula 656 E + 312 L + 700 C + 576 S",
+                      "bound": "hbm", "algorithmic_bytes_per_trial": trial_bytes, "ms_per_trial": round(trial_ms, 4),
+                      "achieved": round(trial_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(trial_gbs / HBM_PEAK_GBS, 5),
+                      "frac_of_achievable_6300": round(trial_gbs / 6300.0, 5),
+                      "kernel_ms_per_call": round(sum(k["ms_per_call"] for k in kernels), 3), "profiled_call_ms": round(prof_call_ms, 3)}
 
     # ---- CPU baseline: the oracle (g2o restatement, 1 thread) on a bounded sample of the same workload
     cpu = None
@@ -291,39 +356,54 @@ def main():
         _, _, _, _, ost = oracle.ba_optimize(prob, args.cpu_iters)
         it_ms = (ost.ms_total - ost.ms_structure) / max(ost.iters_done, 1)
         cpu = {"value": round(1e3 / it_ms, 5), "unit": "LM iter/s", "cores": 1, "kind": "port",
-               "ms_per_iter": round(it_ms, 2), "structure_ms": round(ost.ms_structure, 1),
-               "sample": f"{ost.iters_done} LM iterations ({ost.lm_trials} trials) of {args.workload}: "
-                         f"{prob['n_cam']} KFs, {prob['n_pt']} landmarks, {prob['n_edge']} observations; "
-                         "oracle/ba_ref.cpp -O2 -g single thread (g2o build flags), block-sparse Cholesky stand-in for Eigen SimplicialLDLT",
+               "ms_per_iter": round(it_ms, 2), "ms_per_trial": round((ost.ms_total - ost.ms_structure) / max(ost.lm_trials, 1), 2),
+               "structure_ms": round(ost.ms_structure, 1),
+               "sample": f"first {ost.iters_done} LM iterations ({ost.lm_trials} trials, all accepted at the first trial) of the same optimize(20) call on "
+                         f"{args.workload}: {prob['n_cam']} KFs, {prob['n_pt']} landmarks, {prob['n_edge']} observations; "
+                         "oracle/ba_ref.cpp -O2 -g single thread (g2o build flags), block-sparse Cholesky stand-in for Eigen SimplicialLDLT; "
+                         "compare per TRIAL (cpu ms_per_trial vs config.ms_per_lm_trial), the iteration mix of the full call differs",
                "phases_ms": {"residuals": round(ost.ms_residuals, 1), "quadratic_form": round(ost.ms_quadratic, 1),
                              "schur": round(ost.ms_schur, 1), "linear_solve": round(ost.ms_linear, 1)}}
+        try:
+            opt = oracle.ba_optimize_fast(prob, args.cpu_iters)
+            if opt:
+                cpu["optimistic"] = opt
+        except Exception as e:   # the optimistic build is optional
+            cpu["optimistic"] = {"error": str(e)}
 
     # ---- the other half of the metric: tracked fps / agent (rank 0 only; one agent = one GPU)
     extra = None
-    if rank == 0:
+    if rank == 0 and not args.gba_only:
         extra = tracking_leg(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
         if world == 1:   # per-agent figure, independent of N; a single-rank solve has no business inside a sharded job's timing run
             extra.update(local_ba_leg(ctx, with_cpu=not args.no_cpu_baseline))
 
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / max(done, 1)
         out = {
-            "metric": "global-BA LM iterations/s (4-agent merged map); ms_per_step = global-BA ms/iter",
-            "value": round(done / elapsed, 4), "unit": "LM iter/s", "n_gpus": world, "steps": done, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "global-BA LM iterations/s (4-agent merged map)",
+            "value": round(iters / elapsed, 4), "unit": "LM iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(call_ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: global BA (MapFusionGBA numerics), {prob['n_cam']} KFs / "
                                    f"{prob['n_pt']} landmarks / {prob['n_edge']} observations, Huber sqrt(5.99), "
                                    f"landmark-sharded x{world}",
-                       "lm_trials": trials, "pcg_iters": pcg, "schur_blocks": B, "pair_instances_rank0": P,
-                       "chi2_initial": st.chi2_initial if done == st.iters_done else None, "chi2_final": st.chi2_final,
+                       "step": f"one complete optimize({args.gba_iterations}) call from the initial estimate (Optimizer.cpp:796-797), ended by g2o's stop "
+                               "rules; ms_per_step is the wall time of that call, the figure the reference itself prints (:798-801)",
+                       "lm_iterations_per_step": iters // steps, "lm_trials_per_step": trials // steps, "pcg_iters_per_step": pcg // steps,
+                       "stop_reason": int(st.stop_reason), "ms_per_lm_iteration": round(elapsed * 1e3 / max(iters, 1), 4),
+                       "ms_per_lm_trial": round(trial_ms, 4),
+                       "trials_per_iteration": [int(x) for x in tr_hist], "chi2_per_iteration": [float(x) for x in chi_hist],
+                       "schur_blocks": B, "pair_instances_rank0": counts["pairs"],
+                       "chi2_initial": st.chi2_initial, "chi2_final": st.chi2_final,
                        "setup_ms_excluded": round(setup_s * 1e3, 1)},
             "roofline": roofline,
+            "roofline_trial": roofline_trial,
+            "kernels": kernels,
             "cpu_baseline": cpu,
             "extra": extra,
         }
         if cpu:
-            out["speedup_vs_cpu_port"] = round((done / elapsed) / cpu["value"], 1)
+            out["speedup_vs_cpu_port_per_trial"] = round(cpu["ms_per_trial"] / trial_ms, 1)
         print(json.dumps(out))
     h.close()
     if dist is not None:

@@ -138,7 +138,8 @@ struct BaDev {
   uint8_t* edge_depth;       // [Eloc]
   double* part_pt;           // [n_wg_pt*2]  (robust chi2, scale) partials
   double* part_cam;          // [n_wg_cam]   scale partials (pose part)
-  double* scal;              // [4]  chi2, scale, maxdiag, -
+  double* scal;              // [0] chi2 [1] scale [2] stop requested on any rank [3] persistent PCG gave up on any rank (0..3 are summed over
+                             // ranks in ONE all-reduce per trial) [4] maxdiag [5] - [6..7] = pcg_flag (4 ints)
   int n_wg_pt, n_wg_cam;
   // edge-parallel landmark kernels: chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
   const int* chunk_off;      // [n_chunk+1] landmark ranges; nullptr: a landmark has more than kTPB observations -> thread-per-landmark kernels
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
   }
 }
 
-// max |diag| of Hpp (after it has been summed over ranks) and of the own Hll  -> scal[2]
+// max |diag| of Hpp (after it has been summed over ranks) and of the own Hll  -> scal[4]
 // stage 1: grid-stride partial maxima (one per workgroup) ; stage 2 (final != 0): max of the partials
 __global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_full, double* partial, int n_partial, int final) {
   __shared__ double lds[kTPB];
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(kTPB) void ba_maxdiag(BaDev d, const double* hpp_fu
     if (threadIdx.x < s) lds[threadIdx.x] = fmax(lds[threadIdx.x], lds[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) { if (final) d.scal[2] = lds[0]; else partial[blockIdx.x] = lds[0]; }
+  if (threadIdx.x == 0) { if (final) d.scal[4] = lds[0]; else partial[blockIdx.x] = lds[0]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1903,14 +1904,21 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, doub
 }
 
 // final reduction of the trial scalars (single workgroup, fixed order)
-__global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d) {
+// stop_local / abort_local: this rank's view of the caller's stop flag and of a failed persistent-PCG launch; together with the
+// kernel-side give-up flag they ride in the same all-reduce as chi2, so that every rank of a sharded run takes the same
+// decision (a rank leaving the LM loop alone would leave its peers waiting in the next collective)
+__global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_local, int abort_local, int pers_trial) {
   __shared__ double lds[kTPB / kWave];
   double chi = 0, sc = 0;
   for (int i = threadIdx.x; i < d.n_part; i += kTPB) { chi += d.part_pt[2 * i]; sc += d.part_pt[2 * i + 1]; }
   for (int i = threadIdx.x; i < d.n_wg_cam; i += kTPB) sc += d.part_cam[i];
   const double a = block_sum(chi, lds);
   const double b = block_sum(sc, lds);
-  if (threadIdx.x == 0) { d.scal[0] = a; d.scal[1] = b; }
+  if (threadIdx.x == 0) {
+    d.scal[0] = a; d.scal[1] = b;
+    d.scal[2] = stop_local ? 1.0 : 0.0;
+    d.scal[3] = (abort_local || (pers_trial && d.pcg_flag[3])) ? 1.0 : 0.0;
+  }
 }
 
 __global__ void ba_scatter_points(double* full, const double* own, const int* own_slot /*local -> global landmark slot*/, int Lloc) {
@@ -1948,14 +1956,24 @@ struct ccm_ba {
   // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
   // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
   bool coarse_active = false, coarse_used = false;
-  double* h_rb = nullptr;    // pinned: [4 scalars | 4 flags] of a trial
+  double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial
   int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
   double* d_cparts = nullptr;
   int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
   double* d_pt_full = nullptr; int* d_own_slot = nullptr;
   double* d_hpp_full = nullptr;
+  double *d_saved_cam = nullptr, *d_saved_pt = nullptr;   // ccm_ba_push_state
   double ms_setup = 0;
+  // stop flag of the running ccm_ba_run (the reference's bool* pbStopFlag).  One rank: read where g2o calls terminate().
+  // Sharded: the local value rides in the per-trial all-reduce and only the reduced value (stop_any) is acted on.
+  const volatile unsigned char* stop_flag = nullptr;
+  bool stop_any = false;
+  bool stop_requested() const { return nranks > 1 ? stop_any : (stop_flag && *stop_flag); }
+  int stop_local() const { return (stop_flag && *stop_flag) ? 1 : 0; }
+  // per-iteration record of the last run (chi2 after the iteration, lambda, trials) and the optional per-trial callback
+  std::vector<double> hist_chi2, hist_lambda; std::vector<int32_t> hist_trials;
+  ccm_ba_trial_cb trial_cb = nullptr; void* trial_cb_user = nullptr;
 };
 
 namespace {
@@ -2295,9 +2313,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
   AL(pcg_scal, 4, double)
   AL(edge_chi2, Eloc, double) AL(edge_depth, Eloc, uint8_t)
-  AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 6, double)
+  AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 8, double)
 #undef AL
-  d.pcg_flag = reinterpret_cast<int*>(d.scal + 4);   // [scalars | PCG flags]: one 48-byte read-back per LM trial
+  d.pcg_flag = reinterpret_cast<int*>(d.scal + 6);   // [scalars | PCG flags]: one 64-byte read-back per LM trial
   if (hipHostMalloc(&ba->h_rb, 64, hipHostMallocDefault) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer"));
   ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
   if (int rc = dev_alloc<double>(ba, ba->red_count, &ba->d_red)) return fail(rc);
@@ -2424,6 +2442,31 @@ extern "C" int ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double
   return CCM_OK;
 }
 
+// SparseOptimizer::push() / pop() over all vertices (sparse_optimizer.cpp:600-613), device to device: the saved estimate stays
+// in HBM, so a benchmark can re-run the same optimisation without touching the host.
+extern "C" int ccm_ba_push_state(ccm_ba* ba) {
+  if (!ba) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nc = 7 * (size_t)ba->n_cam, np = 3 * (size_t)std::max(ba->Lloc, 1);
+  if (!ba->d_saved_cam) { RC(dev_alloc<double>(ba, nc, &ba->d_saved_cam, false)); RC(dev_alloc<double>(ba, np, &ba->d_saved_pt, false)); }
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_saved_cam, ba->d.cam[ba->cur], nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (ba->Lloc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_saved_pt, ba->d.pt[ba->cur], 3 * (size_t)ba->Lloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return CCM_OK;
+}
+extern "C" int ccm_ba_pop_state(ccm_ba* ba) {
+  if (!ba) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  if (!ba->d_saved_cam) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba_pop_state: nothing pushed");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  ba->cur = 0;
+  for (int k = 0; k < 2; k++) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.cam[k], ba->d_saved_cam, 7 * (size_t)ba->n_cam * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ba->Lloc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.pt[k], ba->d_saved_pt, 3 * (size_t)ba->Lloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return CCM_OK;
+}
+
 extern "C" int ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts, int64_t* n_free_cams,
                              int64_t* n_blocks, int64_t* n_pairs) {
   if (!ba) return CCM_E_ARG;
@@ -2439,12 +2482,12 @@ namespace {
 
 // the trial scalars and the PCG flags in ONE copy into pinned memory (a pageable destination is staged by the runtime:
 // the two copies + syncs of a trial used to leave the GPU idle for ~90 us)
-int read_scalars(ccm_ba* ba, double out[4], int flags[4] = nullptr) {
+int read_scalars(ccm_ba* ba, double out[6], int flags[4] = nullptr) {
   ccm_ctx* ctx = ba->ctx;
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->h_rb, ba->d.scal, 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->h_rb, ba->d.scal, 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  memcpy(out, ba->h_rb, 4 * sizeof(double));
-  if (flags) memcpy(flags, ba->h_rb + 4, 4 * sizeof(int));
+  memcpy(out, ba->h_rb, 6 * sizeof(double));
+  if (flags) memcpy(flags, ba->h_rb + 6, 4 * sizeof(int));
   return CCM_OK;
 }
 
@@ -2458,11 +2501,12 @@ int eval_chi2(ccm_ba* ba, double* chi) {
     else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
   }
   hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
-  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
-  RC(ba_allreduce_sum(ba, d.scal, 2));
-  double s[4];
+  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d, ba->stop_local(), 0, 0);
+  RC(ba_allreduce_sum(ba, d.scal, 4));
+  double s[6];
   RC(read_scalars(ba, s));
   *chi = s[0];
+  ba->stop_any = s[2] > 0.0;
   return CCM_OK;
 }
 
@@ -2495,10 +2539,10 @@ int max_diag(ccm_ba* ba, double* out) {
   const int nb = std::max(1, std::min(d.n_wg_pt, 512));   // partials live in part_pt (>= 2*n_wg_pt doubles)
   hipLaunchKernelGGL(ba_maxdiag, dim3(nb), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 0);
   hipLaunchKernelGGL(ba_maxdiag, dim3(1), dim3(kTPB), 0, ctx->stream, d, hpp, d.part_pt, nb, 1);
-  RC(ba_allreduce_max(ba, d.scal + 2, 1));
-  double s[4];
+  RC(ba_allreduce_max(ba, d.scal + 4, 1));
+  double s[6];
   RC(read_scalars(ba, s));
-  *out = s[2];
+  *out = s[4];
   return CCM_OK;
 }
 
@@ -2506,6 +2550,7 @@ int max_diag(ccm_ba* ba, double* out) {
 int coarse_build(ccm_ba* ba, double lambda) {
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
+  ccm_prof_scope ps(ctx, CCM_K_BA_COARSE);
   const int Nc = ba->coarse_Nc, nc = 6 * ba->coarse_na;
   hipLaunchKernelGGL(ba_coarse_P, dim3(ccm_div_up(d.Cp, kTPB)), dim3(kTPB), 0, ctx->stream, d, ba->cur, ba->d_cP);
   CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, (size_t)Nc * Nc * sizeof(double), ctx->stream));
@@ -2528,21 +2573,19 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   *ok = true;
   *pcg_iters = 0;
-  bool small_path = false;
+  bool small_path = false, pers_trial = false, pers_launch_failed = false;
   int small_flags[4] = {0, 0, 0, 0};
   if (d.Cp) {
-    {
+    if (!(d.nOff > 8192 && d.row_units_max)) {   // the row kernel also forms the diagonal blocks and b_schur
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
-      const bool row_kernel = d.nOff > 8192 && d.row_units_max;   // the row kernel also forms the diagonal blocks and b_schur
-      if (!row_kernel) hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
+      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
         const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * kRowSlot + 18) * sizeof(double);
-        static bool attr_row = false;
-        if (!attr_row) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_schur_row, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)); attr_row = true; }
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row, 158 * 1024);
         hipLaunchKernelGGL(ba_schur_row, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
@@ -2557,11 +2600,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       const size_t lds_S = 36 * (size_t)(d.Cp + d.nOff) * sizeof(double) + ((size_t)d.Cp + 1 + 2 * (size_t)ba->n_row_entries) * sizeof(int) + 16;
       const int stage_S = (lds + lds_S <= 150 * 1024) ? 1 : 0;
       if (stage_S) lds += lds_S;
-      static bool attr_set = false;
-      if (!attr_set) {
-        CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-      }
+      CCM_LDS_ATTR(ctx, CCM_LDS_BA_SMALL, ba_pcg_small<1024>, 150 * 1024);
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
         // measured on lba_c2 (30 free cameras, ~64 PCG iterations per solve): 16 waves 460 us, 1 wave 1420 us — the
@@ -2610,9 +2649,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
                                                          (unsigned)pers_lds_bytes(), ctx->stream);
         if (le == hipSuccess) persist_ok = true;
-        else { (void)hipGetLastError(); ba->pers_grid = 0; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
+        else { (void)hipGetLastError(); ba->pers_grid = 0; pers_launch_failed = true; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
       }
-      if (persist_ok) small_path = true;
+      if (persist_ok) small_path = pers_trial = true;
     }
     if (!persist_ok) {
       d.mk_on = 0;
@@ -2623,12 +2662,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       ba->coarse_used = d.mk_on != 0;
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
       {
-        static bool init_attr = false;
         const size_t lds_tiles = (size_t)(2 * kCluN * kCluN + kCluN + kPersWaves) * sizeof(double) + 16;
-        if (!init_attr) {
-          CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_pcg_init_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
-          init_attr = true;
-        }
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_TILES, ba_pcg_init_tiles, lds_tiles);
         if (!ba->d_pers_coff) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba: cluster entry lists missing");
         hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
                            (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
@@ -2667,12 +2702,19 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     if (d.chunk_off) hipLaunchKernelGGL(ba_backsub_chi2_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
     else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
   }
-  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d);
-  RC(ba_allreduce_sum(ba, d.scal, 2));
-  double s[4];
+  // a sharded run repeats the trial on EVERY rank when the persistent kernel gave up (or could not be launched) on ANY rank:
+  // the repeat issues the same collectives again, and all ranks must keep bit-identical camera states
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BA_REDUCE);
+    hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d, ba->stop_local(), (pers_launch_failed && ba->nranks > 1) ? 1 : 0,
+                       pers_trial ? 1 : 0);
+  }
+  RC(ba_allreduce_sum(ba, d.scal, 4));
+  double s[6];
   RC(read_scalars(ba, s, small_flags));
   CCM_HIP_CHECK(ctx, hipGetLastError());
-  if (small_path && ba->pers_grid && small_flags[3]) {   // the persistent kernel could not hold its grid exchange: never again on this handle
+  ba->stop_any = s[2] > 0.0;
+  if (s[3] > 0.0 && (pers_trial || pers_launch_failed)) {   // the persistent kernel could not hold its grid exchange: never again on this handle
     ba->pers_grid = 0;
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }
@@ -2766,6 +2808,8 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   ccm_ba_options opt{};
   if (opt_in) opt = *opt_in;
   ba->coarse_active = false;   // every run starts from the same preconditioner state
+  ba->stop_flag = stop_flag; ba->stop_any = false;
+  ba->hist_chi2.clear(); ba->hist_lambda.clear(); ba->hist_trials.clear();
   const double t_start = now_ms();
   ccm_ba_stats st{};
   st.ms_setup = ba->ms_setup;
@@ -2779,10 +2823,13 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   int rc = CCM_OK;
   const bool empty = (ba->n_act_edges == 0);
   for (int it = 0; it < opt.max_iters && !empty; it++) {
-    if (stop_flag && *stop_flag) { reason = 1; break; }
+    // optimize()'s `!terminate()` (sparse_optimizer.cpp:382).  A sharded run acts on the flag as reduced with the last trial's
+    // scalars; before the first trial that is the reduction inside eval_chi2, which changes no state.
+    if (ba->nranks == 1 && ba->stop_requested()) { reason = 1; break; }
     // computeActiveErrors + activeRobustChi2 — equal to the chi2 of the last accepted state, which the
     // previous iteration already evaluated (same state => same value); only iteration 0 needs a pass.
     if (!have_chi) { if ((rc = eval_chi2(ba, &currentChi))) return rc; have_chi = true; st.chi2_initial = currentChi; }
+    if (ba->nranks > 1 && ba->stop_requested()) { reason = 1; break; }
     const double iniChi = currentChi;
     if ((rc = build_system(ba))) return rc;
     if (it == 0) {
@@ -2813,8 +2860,10 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
         lambda *= ni; ni *= 2;               // pop(): the estimate stays
       }
       qmax++; st.lm_trials++;
-    } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+      if (ba->trial_cb) ba->trial_cb(ba->trial_cb_user, it, qmax, tempChi, (rho > 0 && std::isfinite(tempChi)) ? 1 : 0);
+    } while (rho < 0 && qmax < 10 && !ba->stop_requested());
     st.iters_done++;
+    ba->hist_chi2.push_back(currentChi); ba->hist_lambda.push_back(lambda); ba->hist_trials.push_back(qmax);
     if (qmax == 10 || rho == 0) { reason = 2; break; }
     if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
     if (nBad >= 3) { reason = 3; break; }
@@ -2826,6 +2875,23 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   st.ms_total = st.ms_iters + st.ms_setup;
   if (stats) *stats = st;
   pers_dbg_dump(ba);
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_history(const ccm_ba* ba, int cap, double* chi2_per_iter, double* lambda_per_iter, int32_t* trials_per_iter, int* n_iters) {
+  if (!ba || !n_iters) return CCM_E_ARG;
+  *n_iters = (int)ba->hist_chi2.size();
+  for (int i = 0; i < *n_iters && i < cap; i++) {
+    if (chi2_per_iter) chi2_per_iter[i] = ba->hist_chi2[i];
+    if (lambda_per_iter) lambda_per_iter[i] = ba->hist_lambda[i];
+    if (trials_per_iter) trials_per_iter[i] = ba->hist_trials[i];
+  }
+  return CCM_OK;
+}
+
+extern "C" int ccm_ba_set_trial_callback(ccm_ba* ba, ccm_ba_trial_cb cb, void* user) {
+  if (!ba) return CCM_E_ARG;
+  ba->trial_cb = cb; ba->trial_cb_user = user;
   return CCM_OK;
 }
 
@@ -2886,7 +2952,9 @@ extern "C" int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_
                                const volatile unsigned char* stop_flag, double* chi2_per_edge, uint8_t* depth_pos,
                                ccm_ba_stats* stats) {
   ccm_ba* ba = nullptr;
-  int rc = ccm_ba_create(ctx, prob, ctx ? ctx->comm_rank : 0, ctx ? ctx->comm_nranks : 1, &ba);
+  // one rank, always: a one-shot call made by a single agent on a context that carries a multi-rank communicator must not
+  // turn into a collective (sharding is opt-in through ccm_ba_create(rank, nranks), called by ALL ranks)
+  int rc = ccm_ba_create(ctx, prob, 0, 1, &ba);
   if (rc) return rc;
   rc = ccm_ba_run(ba, opt, stop_flag, stats);
   if (rc == CCM_OK) rc = ccm_ba_download(ba, prob->cam_qt, prob->pt_xyz, chi2_per_edge);

@@ -23,6 +23,9 @@ struct ccm_ctx {
   int prof_class = -2;  // -2 none, -1 all
   ccm_prof_slot prof[CCM_K_COUNT];
   std::vector<hipEvent_t> ev_pool;
+  // kernels whose dynamic-LDS limit has been raised for this context's device (bit per kernel, CCM_LDS_ATTR): per
+  // context, not process-wide, so that a second context on another GPU of the same process sets its own
+  uint32_t lds_attr_done = 0;
   // RCCL communicator (opaque; ncclComm_t) for the sharded global BA
   void* comm = nullptr;
   int comm_rank = 0, comm_nranks = 1;
@@ -44,6 +47,15 @@ int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
       return ccm_set_error((ctx), CCM_E_HIP,                                            \
                            std::string(#expr) + ": " + hipGetErrorString(_e) + " (" +   \
                                __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
+  } while (0)
+
+enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT };
+#define CCM_LDS_ATTR(ctx, bit, func, bytes)                                                                              \
+  do {                                                                                                                   \
+    if (!((ctx)->lds_attr_done & (1u << (bit)))) {                                                                       \
+      CCM_HIP_CHECK((ctx), hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      (ctx)->lds_attr_done |= 1u << (bit);                                                                               \
+    }                                                                                                                    \
   } while (0)
 
 // RAII-ish bracket used around a kernel launch when profiling of its class is enabled.

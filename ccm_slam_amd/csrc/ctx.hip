@@ -22,8 +22,11 @@ extern "C" int ccm_device_count(void) {
 
 extern "C" const char* ccm_last_error(const ccm_ctx* ctx) {
   if (ctx) return ctx->err.c_str();
+  // copy under the lock: the returned pointer must stay valid after another thread replaces g_last_err
+  static thread_local std::string tl_copy;
   std::lock_guard<std::mutex> lk(g_err_mu);
-  return g_last_err.c_str();
+  tl_copy = g_last_err;
+  return tl_copy.c_str();
 }
 
 extern "C" int ccm_ctx_create(int device_id, ccm_ctx** out) {

@@ -178,18 +178,24 @@ int frame_reserve(ccm_frame* f, int n) {
   if (n <= f->cap) return CCM_OK;
   ccm_ctx* ctx = f->ctx;
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_desc}) if (p) hipFree(p);   // d_kps lives inside d_desc's block
+  // allocate the new set first and swap only when all of it exists: a failed allocation leaves the frame as it was
   const int cap = std::max(2048, n + n / 2);
-  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_xy, 2 * sizeof(float) * (size_t)cap));
-  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_oct, sizeof(int) * (size_t)cap));
-  CCM_HIP_CHECK(ctx, hipMalloc(&f->d_cell_idx, sizeof(int) * (size_t)cap));
+  const size_t blk_bytes = (32 + sizeof(ccm_keypoint)) * (size_t)cap + 256;
+  float* n_xy = nullptr; int *n_oct = nullptr, *n_cell = nullptr; uint8_t* n_blk = nullptr; void* n_stage = nullptr;
   // descriptors and keypoints in ONE block [desc 32 cap | kps]: ccm_frame_set_keypoints uploads both with one copy
-  uint8_t* blk = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&blk, (32 + sizeof(ccm_keypoint)) * (size_t)cap + 256));
-  f->d_desc = blk;
-  f->d_kps = reinterpret_cast<ccm_keypoint*>(blk + ccm_align256(32 * (size_t)cap));
+  const bool ok = hipMalloc(&n_xy, 2 * sizeof(float) * (size_t)cap) == hipSuccess && hipMalloc(&n_oct, sizeof(int) * (size_t)cap) == hipSuccess &&
+                  hipMalloc(&n_cell, sizeof(int) * (size_t)cap) == hipSuccess && hipMalloc(&n_blk, blk_bytes) == hipSuccess &&
+                  hipHostMalloc(&n_stage, blk_bytes, hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (n_xy) hipFree(n_xy); if (n_oct) hipFree(n_oct); if (n_cell) hipFree(n_cell); if (n_blk) hipFree(n_blk); if (n_stage) hipHostFree(n_stage);
+    return ccm_set_error(ctx, CCM_E_HIP, "ccm_frame: out of memory growing the keypoint buffers");
+  }
+  for (void* p : {(void*)f->d_xy, (void*)f->d_oct, (void*)f->d_cell_idx, (void*)f->d_desc}) if (p) hipFree(p);   // d_kps lives inside d_desc's block
   if (f->h_stage) hipHostFree(f->h_stage);
-  CCM_HIP_CHECK(ctx, hipHostMalloc(&f->h_stage, (32 + sizeof(ccm_keypoint)) * (size_t)cap + 256, hipHostMallocDefault));
+  f->d_xy = n_xy; f->d_oct = n_oct; f->d_cell_idx = n_cell; f->d_desc = n_blk;
+  f->d_kps = reinterpret_cast<ccm_keypoint*>(n_blk + ccm_align256(32 * (size_t)cap));
+  f->h_stage = static_cast<uint8_t*>(n_stage);
   f->cap = cap;
   return CCM_OK;
 }

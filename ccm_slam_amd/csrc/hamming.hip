@@ -380,13 +380,17 @@ extern "C" int ccm_vocab_create(ccm_ctx* ctx, int n_nodes, int L, const int32_t*
   ccm_vocab* v = new ccm_vocab();
   v->ctx = ctx; v->n_nodes = n_nodes; v->L = L;
   v->word_id.assign(word_id, word_id + n_nodes); v->weight.assign(weight, weight + n_nodes);
-  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_child_off, (size_t)(n_nodes + 1) * 4));
-  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_child_id, (size_t)std::max(n_child, 1) * 4));
-  CCM_HIP_CHECK(ctx, hipMalloc(&v->d_node_desc, (size_t)n_nodes * 32));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_child_off, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n_child) CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_child_id, child_id, (size_t)n_child * 4, hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(v->d_node_desc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const bool ok = hipMalloc(&v->d_child_off, (size_t)(n_nodes + 1) * 4) == hipSuccess && hipMalloc(&v->d_child_id, (size_t)std::max(n_child, 1) * 4) == hipSuccess &&
+                  hipMalloc(&v->d_node_desc, (size_t)n_nodes * 32) == hipSuccess &&
+                  hipMemcpyAsync(v->d_child_off, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                  (!n_child || hipMemcpyAsync(v->d_child_id, child_id, (size_t)n_child * 4, hipMemcpyHostToDevice, ctx->stream) == hipSuccess) &&
+                  hipMemcpyAsync(v->d_node_desc, node_desc, (size_t)n_nodes * 32, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                  hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) {   // nothing of a half-built vocabulary survives
+    (void)hipGetLastError();
+    ccm_vocab_destroy(v);
+    return ccm_set_error(ctx, CCM_E_HIP, "ccm_vocab_create: device allocation / upload failed");
+  }
   *out = v;
   return CCM_OK;
 }

@@ -896,8 +896,10 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
         continue;
       }
       if (use_tree) {
-        static bool attr_set = false;
-        if (!attr_set) { if (hipFuncSetAttribute((const void*)pg_precond, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: LDS attribute"); break; } attr_set = true; }
+        if (!(ctx->lds_attr_done & (1u << CCM_LDS_PG_PRECOND))) {
+          if (hipFuncSetAttribute((const void*)pg_precond, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess) { rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: LDS attribute"); break; }
+          ctx->lds_attr_done |= 1u << CCM_LDS_PG_PRECOND;
+        }
         hipLaunchKernelGGL(pg_pcg_start, dim3(ccm_div_up(7 * F, kTPB)), dim3(kTPB), 0, ctx->stream, d, lambda, 1e-10);
         hipLaunchKernelGGL(pg_precond, dim3(1), dim3(1024), lds_pc, ctx->stream, d, 0, 0);
       } else {

@@ -293,8 +293,7 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
     const int use_lds = lds_full <= 150 * 1024;
     const size_t lds_bytes = use_lds ? lds_full : kPoseRed * sizeof(double);
     if (lds_bytes > 64 * 1024) {
-      static bool attr_set = false;
-      if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)poseopt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+      CCM_LDS_ATTR(ctx, CCM_LDS_POSEOPT, poseopt_kernel, 150 * 1024);
     }
     hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kPoseThreads), lds_bytes, ctx->stream, a, use_lds);
   }

@@ -327,8 +327,7 @@ extern "C" int ccm_sim3_optimize(ccm_ctx* ctx, double sim3[8], int n, const doub
     const int use_lds = lds_full <= 150 * 1024;
     const size_t lds_bytes = use_lds ? lds_full : lds_head;
     if (lds_bytes > 64 * 1024) {
-      static bool attr_set = false;
-      if (!attr_set) { CCM_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sim3opt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+      CCM_LDS_ATTR(ctx, CCM_LDS_SIM3OPT, sim3opt_kernel, 150 * 1024);
     }
     hipLaunchKernelGGL(sim3opt_kernel, dim3(1), dim3(kThreads), lds_bytes, ctx->stream, a, use_lds);
   }

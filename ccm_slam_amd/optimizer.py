@@ -15,6 +15,9 @@ import numpy as np
 from ._lib import BAOptions, BAProblem, BAStats, Context, check, lib
 
 
+TRIAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int)
+
+
 def _vp(a):
     return a.ctypes.data_as(C.c_void_p).value if a is not None else None
 
@@ -49,12 +52,39 @@ class BAHandle:
         check(lib().ccm_ba_reset_state(self._h, C.c_void_p(_vp(self._keep["cam_qt"])), C.c_void_p(_vp(self._keep["pt_xyz"]))),
               self.ctx.handle)
 
+    def push_state(self):
+        """SparseOptimizer::push(): keep a device-side copy of the current estimate"""
+        check(lib().ccm_ba_push_state(self._h), self.ctx.handle)
+
+    def pop_state(self):
+        """SparseOptimizer::pop(): the saved estimate becomes current again (device-to-device, stream-ordered)"""
+        check(lib().ccm_ba_pop_state(self._h), self.ctx.handle)
+
     def run(self, max_iters: int, pcg_max_iters: int = 0, pcg_rel_tol: float = 0.0, lambda_init: float = 0.0,
-            verbose: int = 0) -> BAStats:
+            verbose: int = 0, stop_flag=None) -> BAStats:
+        """optimizer.optimize(max_iters).  stop_flag: a 1-element numpy uint8 array playing the reference's bool* pbStopFlag."""
         opt = BAOptions(int(max_iters), int(pcg_max_iters), float(pcg_rel_tol), float(lambda_init), int(verbose))
         st = BAStats()
-        check(lib().ccm_ba_run(self._h, C.byref(opt), None, C.byref(st)), self.ctx.handle)
+        fl = stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None
+        check(lib().ccm_ba_run(self._h, C.byref(opt), fl, C.byref(st)), self.ctx.handle)
         return st
+
+    def history(self):
+        """(chi2 after each LM iteration, lambda after it, trials it took) of the last run"""
+        n = C.c_int(0)
+        chi, lam, tr = np.zeros(256), np.zeros(256), np.zeros(256, np.int32)
+        check(lib().ccm_ba_history(self._h, 256, C.c_void_p(_vp(chi)), C.c_void_p(_vp(lam)), C.c_void_p(_vp(tr)), C.byref(n)), self.ctx.handle)
+        k = min(n.value, 256)
+        return chi[:k].copy(), lam[:k].copy(), tr[:k].copy()
+
+    def set_trial_callback(self, fn):
+        """fn(iteration, trial_in_iteration, chi2_trial, accepted) after every LM trial, on the optimising thread; None removes it"""
+        if fn is None:
+            self._cb = None
+            check(lib().ccm_ba_set_trial_callback(self._h, None, None), self.ctx.handle)
+            return
+        self._cb = TRIAL_CB(lambda user, it, tr, chi, acc: fn(it, tr, chi, acc))
+        check(lib().ccm_ba_set_trial_callback(self._h, self._cb, None), self.ctx.handle)
 
     def download(self, chi2_in=None):
         cam = self._keep["cam_qt"].copy()

@@ -60,7 +60,8 @@ enum {
   CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
   CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
   CCM_K_BA_SCHUR_DIAG, CCM_K_BA_SCHUR_OFF, CCM_K_BA_PCG_SPMV, CCM_K_BA_PCG_UPDATE,
-  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_BA_PCG_PERSIST, CCM_K_COUNT
+  CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_BA_PCG_PERSIST,
+  CCM_K_BA_COARSE /* coarse operator + dense inverse of the two-level preconditioner */, CCM_K_BA_REDUCE /* trial scalars */, CCM_K_COUNT
 };
 int ccm_prof_enable(ccm_ctx* ctx, int kernel_class /* -1: all, -2: none */);
 int ccm_prof_reset(ccm_ctx* ctx);
@@ -234,8 +235,10 @@ typedef struct {
 } ccm_ba_stats;
 
 typedef struct ccm_ba ccm_ba;
+typedef void (*ccm_ba_trial_cb)(void* user, int iteration, int trial_in_iteration, double chi2_trial, int accepted);
 
-/* one-shot: build structure, upload, optimise, write cam_qt/pt_xyz back.
+/* one-shot: build structure, upload, optimise, write cam_qt/pt_xyz back.  Always a single-rank solve, also on a context
+ * that carries a multi-rank communicator (sharding is opt-in through the staged API below, called by all ranks).
  * stop_flag (nullable) is the reference's bool* pbStopFlag, polled between LM trials.
  * chi2_per_edge (nullable, in/out [n_edge]) = e->chi2() as the caller of optimize() sees it: for
  * active (level-0) edges the value of the last evaluated LM trial, inactive edges are left
@@ -247,13 +250,27 @@ int ccm_ba_optimize(ccm_ctx* ctx, ccm_ba_problem* prob, const ccm_ba_options* op
 /* staged API (bench / multi-GPU): create uploads the problem and builds the Schur structure;
  * rank/nranks shard the landmarks (each rank owns a contiguous landmark range balanced by
  * pair count; camera state is replicated).  With nranks > 1 a communicator must be attached
- * before ccm_ba_run.                                                                      */
+ * before ccm_ba_run, and ccm_ba_run / ccm_ba_download are COLLECTIVE calls: every rank makes them with
+ * the same options, and either every rank passes a stop flag or none does (the flag is reduced over
+ * the ranks with each trial's scalars, so a flag raised on one rank stops all of them at the same trial). */
 int  ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* prob, int rank, int nranks, ccm_ba** out);
 void ccm_ba_destroy(ccm_ba* ba);
 int  ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double* pt_xyz); /* re-upload initial state */
+/* SparseOptimizer::push() / pop() for all vertices (sparse_optimizer.cpp:600-613): save the current estimate on the device /
+ * make the saved estimate current again (stream-ordered device copies; one level, a second push overwrites the first) */
+int  ccm_ba_push_state(ccm_ba* ba);
+int  ccm_ba_pop_state(ccm_ba* ba);
 int  ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt, const volatile unsigned char* stop_flag,
                 ccm_ba_stats* stats);
 int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge);
+/* per-iteration record of the last ccm_ba_run: robust chi2 after the iteration, lambda after it, LM trials it took
+ * (what g2o prints with setVerbose(true), sparse_optimizer.cpp:400-410); fills min(*n_iters, cap) entries */
+int  ccm_ba_history(const ccm_ba* ba, int cap, double* chi2_per_iter, double* lambda_per_iter, int32_t* trials_per_iter,
+                    int* n_iters);
+/* called on the optimising thread after every LM trial, before the stop flag is polled (the place where
+ * OptimizationAlgorithmLevenberg::solve tests terminate(), optimization_algorithm_levenberg.cpp:150); a caller can use it
+ * to watch progress or to decide when to raise its stop flag.  cb == NULL removes it. */
+int  ccm_ba_set_trial_callback(ccm_ba* ba, ccm_ba_trial_cb cb, void* user);
 /* e->isDepthPositive() for every edge of the problem at the given state (host arithmetic, O(n_edge)) */
 int  ccm_ba_depth_positive(const ccm_ba_problem* prob, const double* cam_qt, const double* pt_xyz, uint8_t* depth_pos);
 /* host-only: split n landmark weights into nranks contiguous ranges (begin_out has nranks+1 entries) */

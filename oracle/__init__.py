@@ -34,7 +34,9 @@ class BAStats(C.Structure):
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    if force or not os.path.exists(path):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h")) or f == "Makefile"]
+    stale = os.path.exists(path) and any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs)
+    if force or stale or not os.path.exists(path):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return path
 
@@ -175,7 +177,10 @@ def search_by_projection_last(kx, ky, octave, kangle, fdesc, bounds, scale_facto
 
 
 # ---- bundle adjustment -------------------------------------------------------------------------
-def ba_optimize(prob: dict, max_iters: int, linear_solver: int = 0, lambda_init: float = 0.0, chi2_in=None):
+TRIAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int)
+
+
+def ba_optimize(prob: dict, max_iters: int, linear_solver: int = 0, lambda_init: float = 0.0, chi2_in=None, stop_flag=None, trial_hook=None):
     """Runs the oracle LM on a copy of the problem state.  Returns (cam_qt, pt_xyz, chi2_per_edge,
     depth_pos, stats)."""
     cam = np.ascontiguousarray(prob["cam_qt"], np.float64).copy()
@@ -185,15 +190,28 @@ def ba_optimize(prob: dict, max_iters: int, linear_solver: int = 0, lambda_init:
     dpos = np.zeros(ne, np.uint8)
     st = BAStats()
     lvl = prob.get("e_level")
+    cb = None
+    if trial_hook is not None:   # trial_hook(iteration, trial_in_iteration, chi2_trial, accepted) after every LM trial
+        cb = TRIAL_CB(lambda user, it, tr, chi, acc: trial_hook(it, tr, chi, acc))
+        lib().ora_ba_set_trial_hook(cb, None)
+    try:
+        _ba_call(prob, ne, cam, pts, lvl, max_iters, linear_solver, lambda_init, stop_flag, chi2, dpos, st)
+    finally:
+        if cb is not None:
+            lib().ora_ba_set_trial_hook(C.cast(None, TRIAL_CB), None)
+    return cam, pts, chi2, dpos, st
+
+
+def _ba_call(prob, ne, cam, pts, lvl, max_iters, linear_solver, lambda_init, stop_flag, chi2, dpos, st):
     lib().ora_ba_optimize(
         int(prob["n_cam"]), int(prob["n_pt"]), ne, _p(cam, C.c_double), _p(np.ascontiguousarray(prob["cam_fixed"], np.uint8), C.c_uint8),
         _p(np.ascontiguousarray(prob["cam_K"], np.float64), C.c_double), _p(pts, C.c_double),
         _p(np.ascontiguousarray(prob["e_cam"], np.int32), C.c_int32), _p(np.ascontiguousarray(prob["e_pt"], np.int32), C.c_int32),
         _p(np.ascontiguousarray(prob["e_obs"], np.float64), C.c_double), _p(np.ascontiguousarray(prob["e_info"], np.float64), C.c_double),
         _p(np.ascontiguousarray(lvl, np.uint8), C.c_uint8) if lvl is not None else None,
-        C.c_double(prob["huber_delta"]), int(max_iters), int(linear_solver), C.c_double(lambda_init), None,
+        C.c_double(prob["huber_delta"]), int(max_iters), int(linear_solver), C.c_double(lambda_init),
+        stop_flag.ctypes.data_as(C.c_void_p) if stop_flag is not None else None,
         _p(chi2, C.c_double), _p(dpos, C.c_uint8), C.byref(st))
-    return cam, pts, chi2, dpos, st
 
 
 def ba_chi2(prob: dict, cam=None, pts=None) -> float:

@@ -623,6 +623,11 @@ struct BA {
 
 struct LMState { double lambda = 0, ni = 2; int nBad = 0; };
 
+// test hook: called after every LM trial, right before the loop condition polls terminate() (levenberg.cpp:150) — lets a test
+// raise the stop flag from another thread at a known trial on both the oracle and the product
+typedef void (*ora_trial_cb)(void* user, int iteration, int trial_in_iteration, double chi2_trial, int accepted);
+ora_trial_cb g_trial_cb = nullptr; void* g_trial_cb_user = nullptr;
+
 // OptimizationAlgorithmLevenberg::solve (optimization_algorithm_levenberg.cpp:61-164); returns 0 OK, 1 Terminate
 int lm_iteration(BA& ba, int iteration, LMState& st, const volatile unsigned char* stop, int* trials_out,
                  double* chi_out, double lambda_init_user, double* ini_chi_out = nullptr) {
@@ -663,6 +668,7 @@ int lm_iteration(BA& ba, int iteration, LMState& st, const volatile unsigned cha
       ba.cam = cam_backup; ba.pt = pt_backup;      // pop()
     }
     qmax++;
+    if (g_trial_cb) g_trial_cb(g_trial_cb_user, iteration, qmax, tempChi, (rho > 0 && std::isfinite(tempChi)) ? 1 : 0);
   } while (rho < 0 && qmax < 10 && !(stop && *stop));
   if (trials_out) *trials_out = qmax;
   if (chi_out) *chi_out = currentChi;
@@ -695,6 +701,8 @@ void load_problem(BA& ba, int n_cam, int n_pt, int n_edge, const double* cam_qt,
 }  // namespace
 
 extern "C" {
+
+void ora_ba_set_trial_hook(ora_trial_cb cb, void* user) { g_trial_cb = cb; g_trial_cb_user = user; }
 
 struct ora_ba_stats {
   int32_t iters_done, lm_trials, stop_reason;

@@ -39,5 +39,27 @@ def main():
     print("golden fixtures written to", OUT)
 
 
+PT_STRIDE = 37   # every 37th landmark of the final state is kept (the full point sets would be tens of MB)
+
+
+def gba_full(name, iters=20):
+    """One complete optimize(20) of a BASELINE global-BA configuration on the oracle, run to g2o's stop rule: the per-iteration
+    chi2 / lambda / trial-count history, the stop reason and the final estimate.  gba_c4 takes ~70 s, gba_c3 ~35 s, gba_c5 ~10 min
+    on one core of this container; run  python tests/golden/make_golden.py gba_c4 gba_c3 gba_c5  to regenerate."""
+    prob = synth.make_ba_config(name)
+    cam, pts, chi2, dpos, st = oracle.ba_optimize(prob, iters)
+    n = st.iters_done
+    np.savez_compressed(os.path.join(OUT, f"{name}_full.npz"), cam=cam, pts_sub=pts[::PT_STRIDE].copy(), pt_stride=PT_STRIDE,
+                        chi2_hist=np.array([st.chi2_hist[i] for i in range(n)]), lambda_hist=np.array([st.lambda_hist[i] for i in range(n)]),
+                        trials_hist=np.array([st.trials_hist[i] for i in range(n)], np.int32), chi2_initial=st.chi2_initial, chi2_final=st.chi2_final,
+                        iters=n, trials=st.lm_trials, stop_reason=st.stop_reason, max_iters=iters, n_depth_nonpos=int((dpos == 0).sum()),
+                        n_edge=prob["n_edge"])
+    print(name, "iterations", n, "trials", st.lm_trials, "stop", st.stop_reason)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        for nm in sys.argv[1:]:
+            gba_full(nm)
+    else:
+        main()

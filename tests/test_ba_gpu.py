@@ -378,3 +378,99 @@ def test_camera_counts_around_the_cluster_size(ctx, oracle_lib, kfs):
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
     assert np.abs(pts - opts).max() <= 1e-4
+
+
+# ---- full-length parity on the BASELINE global-BA configurations -------------------------------------------------------------
+# The fixtures (tests/golden/gba_*_full.npz, generator tests/golden/make_golden.py gba_c4 gba_c3 gba_c5) hold the ORACLE's complete
+# optimize(20) call: per-iteration chi2 / lambda / trial counts, stop reason and final estimate.  The oracle needs 35 s - 10 min per
+# configuration on one host core, so it is not re-run on the GPU box; tests/test_golden.py re-checks the smallest one on the CPU.
+import os  # noqa: E402
+
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", ["gba_c4", "gba_c3", "gba_c5"])
+def test_full_length_gba_follows_the_oracle_to_the_stop_rule(ctx, name):
+    """optimize(20) run to g2o's own stop rule (gba_c4: 12 iterations / 18 trials with the rejected trials of iterations 8 and 9,
+    chi2 stagnation): same iteration count, same trials in every iteration, same stop reason, the chi2 after every iteration within
+    1e-6 relative, lambda within 1e-3 relative, final poses within the stated tolerance.  optimization_algorithm_levenberg.cpp:102-161."""
+    path = os.path.join(_G, f"{name}_full.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    g = np.load(path)
+    prob = synth.make_ba_config(name)
+    assert prob["n_edge"] == int(g["n_edge"]), "synthetic generator drifted"
+    h = optimizer.BAHandle(ctx, prob)
+    st = h.run(int(g["max_iters"]))
+    chi, lam, tr = h.history()
+    cam, pts, chi2, dpos = h.download()
+    h.close()
+    assert (st.iters_done, st.lm_trials, st.stop_reason) == (int(g["iters"]), int(g["trials"]), int(g["stop_reason"])), \
+        (st.iters_done, st.lm_trials, st.stop_reason, list(tr))
+    assert np.array_equal(tr, g["trials_hist"]), (list(tr), list(g["trials_hist"]))
+    assert abs(st.chi2_initial - float(g["chi2_initial"])) <= 1e-9 * float(g["chi2_initial"])
+    assert np.abs(chi / g["chi2_hist"] - 1).max() <= TOL_CHI, np.abs(chi / g["chi2_hist"] - 1).max()
+    # lambda *= max(1/3, 1 - (2 rho - 1)^3) with rho = (chi2 gain) / (predicted gain): late in the run the gain is ~1e-3 of chi2, so the
+    # 1e-9 relative agreement of chi2 reaches lambda amplified by ~1e4 (measured 4e-5 on gba_c3); the trial pattern above is the sharp check
+    assert np.abs(lam / g["lambda_hist"] - 1).max() <= 1e-3, np.abs(lam / g["lambda_hist"] - 1).max()
+    dt, dr = synth.pose_errors(cam, g["cam"])
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts[::int(g["pt_stride"])] - g["pts_sub"]).max() <= 1e-4
+    assert int((dpos == 0).sum()) == int(g["n_depth_nonpos"])
+
+
+def _run_with_abort(run, raise_at_total_trial):
+    """Drives `run(stop_flag, hook)`; a second thread raises the stop flag (the reference: Communicator.cpp:444-453 writes
+    mbStopGBA from the comm thread) while the optimising thread sits in the trial callback of total trial `raise_at_total_trial`,
+    i.e. exactly before the loop condition polls terminate() — the same instant on both implementations."""
+    import threading
+    flag = np.zeros(1, np.uint8)
+    at_trial, raised = threading.Event(), threading.Event()
+    count = [0]
+
+    def watcher():
+        at_trial.wait()
+        flag[0] = 1
+        raised.set()
+
+    def hook(it, trial, chi, accepted):
+        count[0] += 1
+        if count[0] == raise_at_total_trial:
+            at_trial.set()
+            raised.wait()
+    th = threading.Thread(target=watcher)
+    th.start()
+    out = run(flag, hook)
+    at_trial.set()
+    th.join()
+    return out
+
+
+@pytest.mark.parametrize("k", [3, 7])
+def test_stop_flag_raised_mid_run_by_another_thread(ctx, oracle_lib, k):
+    """k = 3: the flag goes up after an accepted trial (the iteration completes, the next one does not start);
+    k = 7: after a REJECTED trial (on this map the oracle's trial log is 6 accepted first trials, then iteration 6 starts with two
+    rejected ones): the trial loop ends early with rho < 0, the estimate stays popped, the iteration still counts."""
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=60, n_points=5000, seed=21)
+    lam0 = 0.0
+
+    def run_gpu(flag, hook):
+        h = optimizer.BAHandle(ctx, prob)
+        h.set_trial_callback(hook)
+        st = h.run(12, stop_flag=flag, lambda_init=lam0)
+        tr = h.history()[2]
+        cam, pts, _, _ = h.download()
+        h.close()
+        return cam, pts, st, tr
+
+    def run_cpu(flag, hook):
+        cam, pts, _, _, st = oracle_lib.ba_optimize(prob, 12, lambda_init=lam0, stop_flag=flag, trial_hook=hook)
+        return cam, pts, st, np.array([st.trials_hist[i] for i in range(st.iters_done)])
+    ocam, opts, ost, otr = _run_with_abort(run_cpu, k)
+    cam, pts, st, tr = _run_with_abort(run_gpu, k)
+    assert ost.stop_reason == 1 and ost.lm_trials == k, (ost.stop_reason, ost.lm_trials)
+    assert (st.iters_done, st.lm_trials, st.stop_reason) == (ost.iters_done, ost.lm_trials, 1)
+    assert np.array_equal(tr, otr)
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R and np.abs(pts - opts).max() <= 1e-4
