@@ -124,7 +124,9 @@ BA_HD BaPose ba_oplus(const double u[6], const BaPose& T) {
 
 // Huber: rho0 (robustified chi2) and rho1 (weight)
 BA_HD void ba_huber(double e2, double delta, double& rho0, double& rho1) {
-  const double dsqr = delta * delta;
+  // the reference's g2o fork keeps delta^2 in a FLOAT member (robust_kernel_impl.h:84, set in RobustKernelHuber::setDelta, .cpp:65-69):
+  // the f32-rounded square is the inlier threshold and the constant of the outlier branch
+  const double dsqr = (double)(float)(delta * delta);
   if (delta <= 0 || e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
   else { const double s = sqrt(e2); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }

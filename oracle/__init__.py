@@ -280,6 +280,21 @@ class PGStats(C.Structure):
                 ("lambda_final", C.c_double)]
 
 
+def _vec(fn, inp, nout):
+    inp = np.ascontiguousarray(inp, np.float64)
+    out = np.zeros(nout)
+    f = getattr(lib(), fn)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f(inp.ctypes.data, out.ctypes.data)
+    return out
+
+
+def sim3_exp_log(u7): return _vec("ora_sim3_exp_log", u7, 7)
+def sim3_exp(u7): return _vec("ora_sim3_exp", u7, 8)
+def se3_exp(u6): return _vec("ora_se3_exp", u6, 7)
+
+
 def pose_graph_optimize(pg, max_iters=20, lambda_init=1e-16):
     """OptimizeEssentialGraph* numerics restated (ora_pose_graph_optimize).  Returns (sim3[n,8], stats)."""
     sim3 = np.ascontiguousarray(pg["sim3"], np.float64).copy()

@@ -152,8 +152,10 @@ inline Pose pose_mul(const Pose& a, const Pose& b) {
 }
 
 // RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-90)
+// dsqr is a FLOAT member in the reference's g2o fork (robust_kernel_impl.h:84 `float dsqr;`, set by setDelta, .cpp:65-69): delta^2
+// rounded to f32 is both the inlier threshold and the constant subtracted for outliers.  Found by pinning against oracle/_ref.
 inline void huber(double e2, double delta, double rho[3]) {
-  const double dsqr = delta * delta;
+  const double dsqr = (double)(float)(delta * delta);
   if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
   else {
     const double sqrte = std::sqrt(e2);
@@ -1414,5 +1416,14 @@ int ora_pose_graph_system(int n_vert, const double* sim3, const uint8_t* fixed, 
 
 // test hook: out = log(exp(u)) of g2o::Sim3 (sim3.h:72-140, 146-237)
 void ora_sim3_exp_log(const double* u, double* out) { sim3_log(sim3_exp(u), out); }
+// closed forms, for the pinning tests against oracle/_ref (tests/test_ref_g2o.py)
+void ora_sim3_exp(const double* u, double* s8) {
+  const Sim3 S = sim3_exp(u);
+  s8[0] = S.r.x; s8[1] = S.r.y; s8[2] = S.r.z; s8[3] = S.r.w; s8[4] = S.t[0]; s8[5] = S.t[1]; s8[6] = S.t[2]; s8[7] = S.s;
+}
+void ora_se3_exp(const double* u, double* qt7) {
+  const Pose T = se3_exp(u);
+  qt7[0] = T.q.x; qt7[1] = T.q.y; qt7[2] = T.q.z; qt7[3] = T.q.w; qt7[4] = T.t[0]; qt7[5] = T.t[1]; qt7[6] = T.t[2];
+}
 
 }  // extern "C"

@@ -1,0 +1,140 @@
+"""ctypes binding of oracle/_ref/ — binaries built from the REFERENCE'S OWN sources (oracle/Makefile.ref) against look-alike
+third-party headers (oracle/ref_shim/).  TEST INFRASTRUCTURE: the oracle restatement (oracle/*.cpp) is pinned against these in
+tests/test_ref_*.py.  /root/reference exists only in the build container; on the GPU box the prebuilt .so files are used."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_libs = {}
+
+
+def build() -> None:
+    """(re)build oracle/_ref from /root/reference when it is present; a no-op on the GPU box"""
+    subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref", "-s", "-j8"])
+
+
+def available(name: str = "libg2o_ref.so") -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", name))
+
+
+def _lib(name):
+    if name not in _libs:
+        path = os.path.join(_HERE, "_ref", name)
+        if not os.path.exists(path):
+            build()
+        _libs[name] = C.CDLL(path)
+    return _libs[name]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class RefBAStats(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("lm_trials", C.c_int32), ("n_hist", C.c_int32), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double), ("chi2_hist", C.c_double * 64), ("trials_hist", C.c_int32 * 64)]
+
+
+def g2o_ba_optimize(prob: dict, max_iters: int, dense_solver: bool = False, lambda_init: float = 0.0, chi2_in=None):
+    """The reference's g2o on the flat problem, graph built as Optimizer::MapFusionGBA / LocalBundleAdjustmentClient do.
+    Returns (cam_qt, pt_xyz, chi2_per_edge, depth_pos, stats) like oracle.ba_optimize."""
+    cam = np.ascontiguousarray(prob["cam_qt"], np.float64).copy()
+    pts = np.ascontiguousarray(prob["pt_xyz"], np.float64).copy()
+    ne = int(prob["n_edge"])
+    chi2 = np.zeros(ne) if chi2_in is None else np.ascontiguousarray(chi2_in, np.float64).copy()
+    dpos = np.zeros(ne, np.uint8)
+    lvl = prob.get("e_level")
+    lvl = np.ascontiguousarray(lvl, np.uint8) if lvl is not None else None
+    keep = [np.ascontiguousarray(prob[k], t) for k, t in (("cam_fixed", np.uint8), ("cam_K", np.float64), ("e_cam", np.int32), ("e_pt", np.int32),
+                                                          ("e_obs", np.float64), ("e_info", np.float64))]
+    st = RefBAStats()
+    f = _lib("libg2o_ref.so").ref_ba_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.c_int] * 3 + [C.c_void_p] * 9 + [C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(int(prob["n_cam"]), int(prob["n_pt"]), ne, _p(cam), _p(keep[0]), _p(keep[1]), _p(pts), _p(keep[2]), _p(keep[3]), _p(keep[4]), _p(keep[5]), _p(lvl),
+      float(prob["huber_delta"]), int(max_iters), int(bool(dense_solver)), float(lambda_init), None, _p(chi2), _p(dpos), C.byref(st))
+    return cam, pts, chi2, dpos, st
+
+
+def g2o_pose_optimize(cam_qt, Xw, obs, info, K):
+    cam = np.ascontiguousarray(cam_qt, np.float64).copy()
+    Xw, obs, info, K = (np.ascontiguousarray(a, np.float64) for a in (Xw, obs, info, K))
+    n = Xw.shape[0]
+    outl = np.zeros(max(n, 1), np.uint8)
+    f = _lib("libg2o_ref.so").ref_pose_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    ninl = f(_p(cam), n, _p(Xw), _p(obs), _p(info), _p(K), _p(outl))
+    return cam, outl[:n], ninl
+
+
+def g2o_sim3_optimize(sim3, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2=10.0, fix_scale=False):
+    s = np.ascontiguousarray(sim3, np.float64).copy()
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (P1c, P2c, obs1, obs2, info1, info2, K1, K2)]
+    n = arrs[0].shape[0]
+    inl = np.zeros(max(n, 1), np.uint8)
+    f = _lib("libg2o_ref.so").ref_sim3_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_double, C.c_int, C.c_void_p]
+    nin = f(_p(s), n, *[_p(a) for a in arrs], float(th2), int(bool(fix_scale)), _p(inl))
+    return s, inl[:n], nin
+
+
+class RefPGStats(C.Structure):
+    _fields_ = [("iters_done", C.c_int32), ("lm_trials", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
+def g2o_pose_graph_optimize(pg, max_iters=20, lambda_init=1e-16):
+    sim3 = np.ascontiguousarray(pg["sim3"], np.float64).copy()
+    fixed = np.ascontiguousarray(pg["fixed"], np.uint8)
+    e_i, e_j = np.ascontiguousarray(pg["e_i"], np.int32), np.ascontiguousarray(pg["e_j"], np.int32)
+    meas = np.ascontiguousarray(pg["meas"], np.float64)
+    st = RefPGStats()
+    f = _lib("libg2o_ref.so").ref_pose_graph_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+    f(int(sim3.shape[0]), _p(sim3), _p(fixed), int(bool(pg["fix_scale"])), int(e_i.size), _p(e_i), _p(e_j), _p(meas), int(max_iters), float(lambda_init),
+      C.byref(st))
+    return sim3, st
+
+
+def _vec(fn, inp, nout):
+    inp = np.ascontiguousarray(inp, np.float64)
+    out = np.zeros(nout)
+    f = getattr(_lib("libg2o_ref.so"), fn)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    f(_p(inp), _p(out))
+    return out
+
+
+def se3_exp(u6): return _vec("ref_se3_exp", u6, 7)
+def se3_log(qt7): return _vec("ref_se3_log", qt7, 6)
+def sim3_exp(u7): return _vec("ref_sim3_exp", u7, 8)
+def sim3_log(s8): return _vec("ref_sim3_log", s8, 7)
+
+
+def huber(delta, e2):
+    out = np.zeros(3)
+    f = _lib("libg2o_ref.so").ref_huber
+    f.restype = None
+    f.argtypes = [C.c_double, C.c_double, C.c_void_p]
+    f(float(delta), float(e2), _p(out))
+    return out
+
+
+def edge_se3_project(cam_qt, K, X, obs):
+    """EdgeSE3ProjectXYZ at a state: (error[2], J_point[2,3], J_cam[2,6]) from the reference's computeError / linearizeOplus"""
+    a = [np.ascontiguousarray(x, np.float64) for x in (cam_qt, K, X, obs)]
+    err, Jp, Jc = np.zeros(2), np.zeros((2, 3)), np.zeros((2, 6))
+    f = _lib("libg2o_ref.so").ref_edge_se3_project
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 7
+    f(*[_p(x) for x in a], _p(err), _p(Jp), _p(Jc))
+    return err, Jp, Jc

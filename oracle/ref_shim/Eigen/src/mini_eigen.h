@@ -213,6 +213,9 @@ class DenseBase {
   PartialPivLU<PlainObject> partialPivLu() const;
 };
 
+template <class D> using MatrixBase = DenseBase<D>;
+template <class D> using EigenBase = DenseBase<D>;
+
 // ----------------------------------------------------------------------------------------------------------------------
 // storage of Matrix
 // ----------------------------------------------------------------------------------------------------------------------
