@@ -63,6 +63,13 @@ def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
                                              _p(np.ascontiguousarray(b, np.uint8), C.c_uint8)))
 
 
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(3, np.int32)
+    lib().ora_three_maxima(_p(counts, C.c_int32), int(counts.size), _p(out, C.c_int32))
+    return tuple(int(x) for x in out)
+
+
 def hamming_dense_best2(q: np.ndarray, t: np.ndarray):
     q = np.ascontiguousarray(q, np.uint8)
     t = np.ascontiguousarray(t, np.uint8)

@@ -467,6 +467,15 @@ int ora_search_for_initialization(const float* x1, const float* y1, const int32_
   return nmatches;
 }
 
+// ComputeThreeMaxima on a histogram given by its bin sizes (pinning test against oracle/_ref)
+void ora_three_maxima(const int32_t* counts, int L, int32_t* out3) {
+  std::vector<std::vector<int>> histo((size_t)L);
+  for (int i = 0; i < L; i++) histo[(size_t)i].assign((size_t)counts[i], 0);
+  int a = -1, b = -1, c = -1;
+  three_maxima(histo.data(), L, a, b, c);
+  out3[0] = a; out3[1] = b; out3[2] = c;
+}
+
 }  // extern "C"
 
 // ================================================================================================

@@ -138,3 +138,100 @@ def edge_se3_project(cam_qt, K, X, obs):
     f.argtypes = [C.c_void_p] * 7
     f(*[_p(x) for x in a], _p(err), _p(Jp), _p(Jc))
     return err, Jp, Jc
+
+
+# ---- the reference's own ORBextractor (cslam/src/ORBextractor.cpp compiled verbatim) and ORBmatcher statics -----------------------
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32), ("response", np.float32),
+                     ("octave", np.int32)])
+
+
+class RefOrb:
+    """cslam::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) of the reference"""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7):
+        L = _lib("liborb_ref.so")
+        L.ref_orb_create.restype = C.c_void_p
+        L.ref_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        self._h = C.c_void_p(L.ref_orb_create(nfeatures, scale, nlevels, ini_th, min_th))
+        self.nfeatures, self.nlevels, self.scale, self.ini_th, self.min_th = nfeatures, nlevels, scale, ini_th, min_th
+
+    def extract_cli(self, img):
+        """The same extraction in a separate process whose allocator hands out increasing addresses (oracle/ref_orb_cli.cpp): the
+        reference's pointer tie-break in DistributeOctTree becomes node creation order, i.e. deterministic and comparable."""
+        import tempfile
+        img = np.ascontiguousarray(img, np.uint8)
+        exe = os.path.join(_HERE, "_ref", "orb_ref_cli")
+        if not os.path.exists(exe):
+            build()
+        with tempfile.TemporaryDirectory() as d:
+            fin, fout = os.path.join(d, "in.raw"), os.path.join(d, "out.bin")
+            img.tofile(fin)
+            subprocess.check_call([exe, fin, str(img.shape[1]), str(img.shape[0]), str(self.nfeatures), repr(float(self.scale)), str(self.nlevels),
+                                   str(self.ini_th), str(self.min_th), fout])
+            raw = open(fout, "rb").read()
+        n = int(np.frombuffer(raw, np.int32, 1)[0])
+        kps = np.frombuffer(raw, KP_DTYPE, n, 4).copy()
+        desc = np.frombuffer(raw, np.uint8, n * 32, 4 + n * KP_DTYPE.itemsize).reshape(n, 32).copy()
+        return kps, desc
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = 4 * self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        f = _lib("liborb_ref.so").ref_orb_extract
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        n = f(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap)
+        assert n <= cap
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l):
+        f = _lib("liborb_ref.so").ref_orb_get_level
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        w, h = C.c_int(), C.c_int()
+        f(self._h, l, None, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        f(self._h, l, _p(out), C.byref(w), C.byref(h))
+        return out
+
+    def border_pixel(self, l, row, col):
+        f = _lib("liborb_ref.so").ref_orb_border_pixel
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        return f(self._h, l, row, col)
+
+    def tables(self):
+        out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        f = _lib("liborb_ref.so").ref_orb_tables
+        f.restype = None
+        f.argtypes = [C.c_void_p] * 5
+        f(self._h, *[_p(a) for a in out])
+        return out
+
+    def close(self):
+        if self._h:
+            f = _lib("liborb_ref.so").ref_orb_destroy
+            f.restype = None
+            f.argtypes = [C.c_void_p]
+            f(self._h)
+            self._h = None
+
+
+def descriptor_distance(a, b) -> int:
+    a, b = np.ascontiguousarray(a, np.uint8), np.ascontiguousarray(b, np.uint8)
+    f = _lib("liborb_ref.so").ref_descriptor_distance
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    return f(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(3, np.int32)
+    f = _lib("liborb_ref.so").ref_three_maxima
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    f(_p(counts), int(counts.size), _p(out))
+    return tuple(int(x) for x in out)

@@ -1,0 +1,109 @@
+"""Pins the ORB / matcher oracle to the REFERENCE'S OWN sources: oracle/_ref/orb_ref_cli and liborb_ref.so are
+/root/reference/cslam/src/ORBextractor.cpp compiled verbatim (whole file) and lines 1606-1669 of ORBmatcher.cpp, against the look-alike
+cv:: API of oracle/ref_shim/opencv2 whose image primitives are the restated OpenCV 4.2 of oracle/cv_prims.h (the [EXT] part that stays
+restated: resize, FAST-9/16 + score + NMS, 7x7 Gaussian, fastAtan2, cvRound).  Everything else — scale tables, pyramid sizing and borders,
+cell grid, iniTh -> minTh fallback, DistributeOctTree / DivideNode, orientation moments, steered BRIEF taps, output order, scaling — is
+the reference's code, and is reproduced bit for bit by oracle/orb_ref.cpp.
+
+Tie rule: DistributeOctTree orders equally large nodes by heap address (ORBextractor.cpp:852), so the reference binary's own output
+depends on allocator history (visible below: the in-process library and the CLI can disagree with EACH OTHER).  orb_ref_cli runs the
+reference with a monotonic operator new, which makes that order "node creation order" — the rule the oracle and the product define."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from ccm_slam_amd import synth
+from oracle import ref
+
+pytestmark = pytest.mark.skipif(not ref.available("orb_ref_cli") and not os.path.isdir("/root/reference/cslam"),
+                                reason="oracle/_ref not built and /root/reference not present")
+
+
+def _same(img, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7):
+    r = ref.RefOrb(nfeatures, scale, nlevels, ini_th, min_th)
+    o = oracle.OrbOracle(nfeatures, scale, nlevels, ini_th, min_th)
+    rk, rd = r.extract_cli(img)
+    ok, od = o.extract(img)
+    assert len(rk) == len(ok), (len(rk), len(ok))
+    for f in rk.dtype.names:
+        assert np.array_equal(rk[f], ok[f]), f
+    assert np.array_equal(rd, od)
+    # pyramid of the in-process library (content does not depend on the allocator) and the float tables
+    r.extract(img)
+    for l in range(nlevels):
+        assert np.array_equal(r.level(l), o.level(l)), l
+    for a, b in zip(r.tables(), o.tables()[:4]):
+        assert np.array_equal(a, b)
+    r.close(); o.close()
+    return rk
+
+
+def test_reference_extractor_equals_oracle_on_euroc_shaped_frames():
+    for seed, t, nf in ((1000, 0, 1000), (1000, 7, 1000), (1003, 2, 1000), (1001, 3, 2000)):
+        kps = _same(synth.gen_image(seed, t), nf)
+        assert len(kps) >= nf * 0.9
+
+
+def test_reference_extractor_equals_oracle_low_texture_min_threshold_path():
+    # a smooth image with a few faint blobs: most cells are empty at iniThFAST = 20 and are re-run at minThFAST = 7 (:981-985)
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:480, 0:752]
+    img = 110 + 20 * np.sin(xx / 90.0) + 15 * np.cos(yy / 70.0)
+    for _ in range(150):
+        cx, cy, a = rng.uniform(30, 720), rng.uniform(30, 450), rng.uniform(6, 14)
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / 6.0)
+    kps = _same(np.clip(img, 0, 255).astype(np.uint8), 1000)
+    assert 0 < len(kps) < 1000
+
+
+def test_reference_extractor_equals_oracle_other_geometry():
+    img = synth.gen_image(1005, 1)[:360, :640].copy()
+    _same(img, 500, 1.3, 5, 20, 7)
+
+
+def test_reference_border_is_reflect_101_of_the_level():
+    """mvImagePyramid levels live inside a bordered buffer (ComputePyramid :1280-1304); the product does not materialise the border, so check
+    on the reference binary that it is the BORDER_REFLECT_101 of the level itself — i.e. derivable, as DESIGN.md claims."""
+    img = synth.gen_image(1000, 0)
+    r = ref.RefOrb(1000)
+    r.extract(img)
+    for l in (0, 3, 7):
+        L = r.level(l)
+        h, w = L.shape
+        for row, col in ((-1, 5), (-19, -19), (h + 18, w + 18), (7, -3), (h - 1 + 4, 10)):
+            rr = -row if row < 0 else (2 * (h - 1) - row if row >= h else row)
+            cc = -col if col < 0 else (2 * (w - 1) - col if col >= w else col)
+            assert r.border_pixel(l, row, col) == L[rr, cc], (l, row, col)
+    r.close()
+
+
+def test_reference_output_depends_on_allocator_history_only_in_tie_cases():
+    """Documents SURVEY App. D.1 on the real binary: in-process (glibc malloc) and CLI (monotonic allocator) runs of the SAME reference code
+    agree except for a handful of keypoints per frame."""
+    img = synth.gen_image(1000, 0)
+    r = ref.RefOrb(1000)
+    a, _ = r.extract(img)
+    b, _ = r.extract_cli(img)
+    sa = set(zip(a["x"].tolist(), a["y"].tolist(), a["octave"].tolist()))
+    sb = set(zip(b["x"].tolist(), b["y"].tolist(), b["octave"].tolist()))
+    assert len(sa ^ sb) <= 0.03 * len(sb)
+    r.close()
+
+
+def test_reference_descriptor_distance_and_three_maxima():
+    rng = np.random.default_rng(0)
+    d = rng.integers(0, 256, (400, 32), dtype=np.uint8)
+    d[1] = d[0]; d[2] = ~d[0]
+    for i in range(0, 400, 2):
+        ref_d = ref.descriptor_distance(d[i], d[i + 1])
+        assert ref_d == oracle.descriptor_distance(d[i], d[i + 1]) == int(np.unpackbits(d[i] ^ d[i + 1]).sum())
+    assert ref.descriptor_distance(d[0], d[1]) == 0 and ref.descriptor_distance(d[0], d[2]) == 256
+    for _ in range(500):
+        counts = rng.integers(0, rng.integers(1, 40), 30)
+        if rng.random() < 0.3:
+            counts[rng.integers(0, 30, 3)] = counts.max()          # ties between the top bins
+        if rng.random() < 0.2:
+            counts[:] = 0; counts[rng.integers(0, 30)] = 25; counts[rng.integers(0, 30)] = 2   # second below 10 %
+        assert ref.three_maxima(counts) == oracle.three_maxima(counts), counts
