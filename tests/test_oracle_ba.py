@@ -60,7 +60,8 @@ def test_one_lm_step_matches_numpy_derivation():
     om = prob["e_info"]
     chi2 = (r0 ** 2).sum(1) * om
     delta = prob["huber_delta"]
-    w = np.where(chi2 <= delta * delta, 1.0, delta / np.sqrt(np.maximum(chi2, 1e-300)))
+    dsqr = float(np.float32(delta * delta))   # the reference's g2o fork keeps delta^2 in a float (robust_kernel_impl.h:84), see tests/test_ref_g2o.py
+    w = np.where(chi2 <= dsqr, 1.0, delta / np.sqrt(np.maximum(chi2, 1e-300)))
     W = np.repeat(w * om, 2)
     H = J.T @ (W[:, None] * J)
     b = -J.T @ (W * r0.ravel())
@@ -70,7 +71,7 @@ def test_one_lm_step_matches_numpy_derivation():
     # oracle: one iteration, same lambda
     ocam, opts, _, _, st = oracle.ba_optimize(prob, 1, linear_solver=1)
     assert st.iters_done == 1 and st.lm_trials == 1 and st.chi2_final < st.chi2_initial
-    rob0 = np.where(chi2 <= delta * delta, chi2, 2 * np.sqrt(chi2) * delta - delta * delta).sum()
+    rob0 = np.where(chi2 <= dsqr, chi2, 2 * np.sqrt(chi2) * delta - dsqr).sum()
     assert abs(st.chi2_initial - rob0) < 1e-9 * rob0
     assert np.abs(opts - pts1).max() < 2e-6
     for c in range(prob["n_cam"]):
