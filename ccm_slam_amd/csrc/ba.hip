@@ -1956,6 +1956,12 @@ struct ccm_ba {
   // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
   // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
   bool coarse_active = false, coarse_used = false;
+  // The coarse operator Ac = P^T (S + lambda I) P is only a preconditioner: a STALE one (built at an earlier trial's lambda or an
+  // earlier linearisation point) still gives a fixed SPD M^-1 for the whole solve, so PCG converges to the same tolerance, just a few
+  // iterations later.  It is rebuilt when lambda has left [1/4, 4] x the lambda it was built at, or when a solve with the stale
+  // operator needed clearly more iterations than the solve right after the last build (counts are deterministic => so is the policy).
+  bool coarse_valid = false, coarse_fresh = false, coarse_stale_bad = false, coarse_reuse = true;
+  double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
   double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial
   int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
@@ -2351,6 +2357,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return rc2;
     if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)std::max(n_units, 1), &ba->d_cparts)) return rc2;
     ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
+    if (const char* cr = getenv("CCM_BA_COARSE_REUSE")) ba->coarse_reuse = atoi(cr) != 0;
     if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
     return CCM_OK;
   };
@@ -2562,6 +2569,15 @@ int coarse_build(ccm_ba* ba, double lambda) {
   return ccm_dense_chol_inverse_dev(ctx, ba->d_cA, Nc, ba->d_cLinv, ba->d_cX, ba->d_cAinv, ba->d_cinfo);
 }
 
+int coarse_prepare(ccm_ba* ba, double lambda) {
+  const bool need = !ba->coarse_reuse || !ba->coarse_valid || ba->coarse_stale_bad || lambda > 4.0 * ba->coarse_lambda_built || lambda < 0.25 * ba->coarse_lambda_built;
+  ba->coarse_fresh = need;
+  if (!need) return CCM_OK;
+  RC(coarse_build(ba, lambda));
+  ba->coarse_valid = true; ba->coarse_stale_bad = false; ba->coarse_lambda_built = lambda;
+  return CCM_OK;
+}
+
 // one LM trial: solve with lambda, write trial state, return tempChi, scale, ok
 int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_chi, double* scale, bool* ok, int* pcg_iters) {
   ccm_ctx* ctx = ba->ctx;
@@ -2626,11 +2642,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (use_coarse) {
         if (getenv("CCM_BA_COARSE_DBG")) {
           hipStreamSynchronize(ctx->stream); const double tc0 = now_ms();
-          RC(coarse_build(ba, lambda));
+          RC(coarse_prepare(ba, lambda));
           const double tc1 = now_ms(); hipStreamSynchronize(ctx->stream);
           fprintf(stderr, "[ccm_ba] coarse_build: enqueue %.3f ms, complete %.3f ms\n", tc1 - tc0, now_ms() - tc0);
         } else
-        RC(coarse_build(ba, lambda));
+        RC(coarse_prepare(ba, lambda));
         pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.cparts = ba->d_cparts;
       }
       void* kargs[2] = {(void*)&d, (void*)&pa};
@@ -2656,7 +2672,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     if (!persist_ok) {
       d.mk_on = 0;
       if (d.mk_cpart && ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active))) {
-        RC(coarse_build(ba, lambda));
+        RC(coarse_prepare(ba, lambda));
         d.mk_on = 1;
       }
       ba->coarse_used = d.mk_on != 0;
@@ -2720,6 +2736,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
   if (ba->coarse_na && (small_path || d.mk_cpart)) {
+    if (ba->coarse_used) {
+      if (ba->coarse_fresh) ba->coarse_fresh_iters = *pcg_iters;
+      else if (*pcg_iters > ba->coarse_fresh_iters + ba->coarse_fresh_iters / 3 + 8) ba->coarse_stale_bad = true;
+    }
     if (!ba->coarse_used && *pcg_iters >= kCoarseOnIters) ba->coarse_active = true;
     else if (ba->coarse_used && *pcg_iters <= kCoarseOffIters) ba->coarse_active = false;
   }
@@ -2808,6 +2828,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   ccm_ba_options opt{};
   if (opt_in) opt = *opt_in;
   ba->coarse_active = false;   // every run starts from the same preconditioner state
+  ba->coarse_valid = false; ba->coarse_stale_bad = false; ba->coarse_fresh_iters = 0;
   ba->stop_flag = stop_flag; ba->stop_any = false;
   ba->hist_chi2.clear(); ba->hist_lambda.clear(); ba->hist_trials.clear();
   const double t_start = now_ms();

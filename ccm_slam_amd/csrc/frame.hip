@@ -174,6 +174,35 @@ __global__ void frame_frustum_kernel(FrustumFrame fr, int n, const float* P, con
   pu[i] = u; pv[i] = v; lvl[i] = l; pcos[i] = c;
 }
 
+// MapPoint::UpdateNormalAndDepth (MapPoint.cpp:779-823) for a batch of map points, one thread per point.  cv::Mat CV_32F arithmetic
+// restated ([EXT]): `a - b` elementwise in f32; cv::norm accumulates the squares in double and returns sqrt in double; `m / s` is
+// convertTo with alpha = (float)(1.0 / s); `normal + v` is an f32 add.  The observers are summed in the order of the caller's list
+// (the reference iterates a std::map keyed by shared_ptr, i.e. in heap-address order: any order is "the reference's").
+__global__ void frame_normal_depth_kernel(int n, const float* pos, const int* obs_off, const int* obs_kf, const float* kf_center, const int* ref_kf,
+                                          const int* ref_level, const float* scale_factors, int n_levels, float* normal_out, float* dmin, float* dmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int o0 = obs_off[i], o1 = obs_off[i + 1];
+  if (o1 == o0) return;                              // observations.empty(): the point keeps what it has
+  const float p0 = pos[3 * i], p1 = pos[3 * i + 1], p2 = pos[3 * i + 2];
+  float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  for (int o = o0; o < o1; o++) {
+    const float* O = kf_center + 3 * (size_t)obs_kf[o];
+    const float d0 = p0 - O[0], d1 = p1 - O[1], d2 = p2 - O[2];
+    const double nrm = sqrt((double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2);
+    const float a = (float)(1.0 / nrm);
+    n0 = n0 + d0 * a; n1 = n1 + d1 * a; n2 = n2 + d2 * a;
+  }
+  const float* Or = kf_center + 3 * (size_t)ref_kf[i];
+  const float c0 = p0 - Or[0], c1 = p1 - Or[1], c2 = p2 - Or[2];
+  const float dist = (float)sqrt((double)c0 * (double)c0 + (double)c1 * (double)c1 + (double)c2 * (double)c2);
+  const float mx = dist * scale_factors[ref_level[i]];
+  dmax[i] = mx;
+  dmin[i] = mx / scale_factors[n_levels - 1];
+  const float an = (float)(1.0 / (double)(o1 - o0));
+  normal_out[3 * i] = n0 * an; normal_out[3 * i + 1] = n1 * an; normal_out[3 * i + 2] = n2 * an;
+}
+
 int frame_reserve(ccm_frame* f, int n) {
   if (n <= f->cap) return CCM_OK;
   ccm_ctx* ctx = f->ctx;
@@ -376,5 +405,48 @@ extern "C" int ccm_frame_frustum(ccm_ctx* ctx, const ccm_frustum_frame* fr, int 
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(proj_x, h_out, 4 * wn); memcpy(proj_y, h_out + wn, 4 * wn); memcpy(view_cos, h_out + 2 * wn, 4 * wn);
   memcpy(level, h_out + 3 * wn, 4 * wn); memcpy(in_view, h_out + 4 * wn, wn);
+  return CCM_OK;
+}
+
+extern "C" int ccm_update_normal_and_depth(ccm_ctx* ctx, int n_pt, const float* pos, const int32_t* obs_off, const int32_t* obs_kf, int n_kf,
+                                           const float* kf_center, const int32_t* ref_kf, const int32_t* ref_level, const float* scale_factors,
+                                           int n_levels, float* normal, float* min_dist, float* max_dist) {
+  if (!ctx || n_pt < 0 || n_kf < 0 || n_levels <= 0 || (n_pt && (!pos || !obs_off || !kf_center || !ref_kf || !ref_level || !scale_factors || !normal || !min_dist || !max_dist)))
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_update_normal_and_depth: bad args");
+  if (n_pt == 0) return CCM_OK;
+  const int n_obs = obs_off[n_pt];
+  if (n_obs < 0 || (n_obs && !obs_kf)) return ccm_set_error(ctx, CCM_E_ARG, "ccm_update_normal_and_depth: bad observation lists");
+  for (int i = 0; i < n_pt; i++) {
+    if (obs_off[i + 1] < obs_off[i]) return ccm_set_error(ctx, CCM_E_ARG, "ccm_update_normal_and_depth: obs_off must be non-decreasing");
+    if (obs_off[i + 1] > obs_off[i] && (ref_kf[i] < 0 || ref_kf[i] >= n_kf || ref_level[i] < 0 || ref_level[i] >= n_levels))
+      return ccm_set_error(ctx, CCM_E_ARG, "ccm_update_normal_and_depth: reference keyframe / level out of range");
+  }
+  for (int o = 0; o < n_obs; o++) if (obs_kf[o] < 0 || obs_kf[o] >= n_kf) return ccm_set_error(ctx, CCM_E_ARG, "ccm_update_normal_and_depth: keyframe index out of range");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t np = (size_t)n_pt, no = (size_t)n_obs, nk = (size_t)n_kf;
+  // one staging block in, one out: [pos 3np | kf_center 3nk | scale n_levels | obs_off np+1 | obs_kf no | ref_kf np | ref_level np] -> [normal 3np | dmin np | dmax np]
+  const size_t in_words = 3 * np + 3 * nk + (size_t)n_levels + (np + 1) + no + 2 * np, out_words = 5 * np;
+  void* scratch = nullptr; void* pin = nullptr;
+  if (int rc = ccm_io_scratch(ctx, 4 * (in_words + out_words) + 256, &scratch)) return rc;
+  if (int rc = ccm_pin_scratch(ctx, 4 * (in_words + out_words) + 64, &pin)) return rc;
+  float* h = (float*)pin; float* dv = (float*)scratch;
+  size_t w = 0;
+  const size_t o_pos = w; memcpy(h + w, pos, 12 * np); w += 3 * np;
+  const size_t o_kc = w; memcpy(h + w, kf_center, 12 * nk); w += 3 * nk;
+  const size_t o_sf = w; memcpy(h + w, scale_factors, 4 * (size_t)n_levels); w += (size_t)n_levels;
+  const size_t o_off = w; memcpy(h + w, obs_off, 4 * (np + 1)); w += np + 1;
+  const size_t o_okf = w; if (no) memcpy(h + w, obs_kf, 4 * no); w += no;
+  const size_t o_rk = w; memcpy(h + w, ref_kf, 4 * np); w += np;
+  const size_t o_rl = w; memcpy(h + w, ref_level, 4 * np); w += np;
+  float* d_out = dv + in_words; float* h_out = h + in_words;
+  // points without observers keep the caller's values: seed the output block with them
+  memcpy(h_out, normal, 12 * np); memcpy(h_out + 3 * np, min_dist, 4 * np); memcpy(h_out + 4 * np, max_dist, 4 * np);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(dv, h, 4 * (in_words + out_words), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(frame_normal_depth_kernel, dim3(ccm_div_up(n_pt, 256)), dim3(256), 0, ctx->stream, n_pt, dv + o_pos, (const int*)(dv + o_off), (const int*)(dv + o_okf),
+                     dv + o_kc, (const int*)(dv + o_rk), (const int*)(dv + o_rl), dv + o_sf, n_levels, d_out, d_out + 3 * np, d_out + 4 * np);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, 4 * out_words, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(normal, h_out, 12 * np); memcpy(min_dist, h_out + 3 * np, 4 * np); memcpy(max_dist, h_out + 4 * np, 4 * np);
   return CCM_OK;
 }

@@ -81,6 +81,17 @@ class FrustumFrame(C.Structure):
                 ("logScaleFactor", C.c_float), ("nScaleLevels", C.c_int32)]
 
 
+def update_normal_and_depth(ctx: Context, pos, obs_off, obs_kf, kf_center, ref_kf, ref_level, scale_factors, normal, min_dist, max_dist):
+    """MapPoint::UpdateNormalAndDepth for a batch of map points (ccm_update_normal_and_depth).  Returns (normal, min_dist, max_dist)."""
+    f32, i32 = (lambda a: np.ascontiguousarray(a, np.float32)), (lambda a: np.ascontiguousarray(a, np.int32))
+    pos, kf_center, sf = f32(pos).reshape(-1, 3), f32(kf_center).reshape(-1, 3), f32(scale_factors)
+    obs_off, obs_kf, ref_kf, ref_level = i32(obs_off), i32(obs_kf), i32(ref_kf), i32(ref_level)
+    nrm, dmin, dmax = f32(normal).copy().reshape(-1, 3), f32(min_dist).copy(), f32(max_dist).copy()
+    check(lib().ccm_update_normal_and_depth(ctx.handle, int(pos.shape[0]), _p(pos), _p(obs_off), _p(obs_kf), int(kf_center.shape[0]), _p(kf_center),
+                                            _p(ref_kf), _p(ref_level), _p(sf), int(sf.size), _p(nrm), _p(dmin), _p(dmax)), ctx.handle)
+    return nrm, dmin, dmax
+
+
 def is_in_frustum(ctx: Context, frame24, n_levels: int, P, normal, dmin, dmax, cos_limit: float = 0.5):
     """Frame::isInFrustum for a batch of map points (ccm_frame_frustum); frame24 as in oracle.is_in_frustum."""
     f32 = lambda a: np.ascontiguousarray(a, np.float32)

@@ -194,6 +194,18 @@ int  ccm_frame_frustum(ccm_ctx* ctx, const ccm_frustum_frame* fr, int n, const f
                        float viewing_cos_limit, uint8_t* in_view, float* proj_x, float* proj_y, int32_t* level,
                        float* view_cos);
 
+/* MapPoint::UpdateNormalAndDepth (MapPoint.cpp:779-823) for a batch of map points — called after every BA write-back
+ * (Optimizer.cpp:636, 845) and for every new / fused point.  Per point i: world position pos[i] (mWorldPos), the list
+ * obs_kf[obs_off[i] .. obs_off[i+1]) of its NON-BAD observing keyframes in the order the shim iterates mObservations (the
+ * reference's std::map<kfptr, size_t> is ordered by heap address, so any order is a valid reference order; the f32 sum follows the
+ * list), the reference keyframe ref_kf[i] (mpRefKF) and the octave ref_level[i] of its keypoint there; kf_center = GetCameraCenter()
+ * of every keyframe, scale_factors = mvScaleFactors (shared by all keyframes of a map).  Outputs mNormalVector, mfMinDistance,
+ * mfMaxDistance; a point whose list is empty keeps the values passed in (the reference returns early, :796-797). */
+int  ccm_update_normal_and_depth(ccm_ctx* ctx, int n_pt, const float* pos /* n_pt x 3 */, const int32_t* obs_off /* n_pt+1 */,
+                                 const int32_t* obs_kf, int n_kf, const float* kf_center /* n_kf x 3 */, const int32_t* ref_kf,
+                                 const int32_t* ref_level, const float* scale_factors, int n_levels,
+                                 float* normal /* n_pt x 3, in/out */, float* min_dist /* in/out */, float* max_dist /* in/out */);
+
 /* ---- bundle adjustment ----------------------------------------------------------------
  * Replaces the g2o machinery driven by Optimizer::BundleAdjustmentClient /
  * LocalBundleAdjustmentClient / MapFusionGBA (cslam/src/Optimizer.cpp:40-212, 349-644,

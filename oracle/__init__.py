@@ -63,6 +63,20 @@ def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
                                              _p(np.ascontiguousarray(b, np.uint8), C.c_uint8)))
 
 
+def update_normal_and_depth(pos, obs_off, obs_kf, kf_center, ref_kf, ref_level, scale_factors, normal, min_dist, max_dist):
+    """MapPoint::UpdateNormalAndDepth restated (ora_update_normal_and_depth); normal / min_dist / max_dist are copied and returned."""
+    f32, i32 = (lambda a: np.ascontiguousarray(a, np.float32)), (lambda a: np.ascontiguousarray(a, np.int32))
+    pos, kf_center, sf = f32(pos), f32(kf_center), f32(scale_factors)
+    obs_off, obs_kf, ref_kf, ref_level = i32(obs_off), i32(obs_kf), i32(ref_kf), i32(ref_level)
+    nrm, dmin, dmax = f32(normal).copy(), f32(min_dist).copy(), f32(max_dist).copy()
+    f = lib().ora_update_normal_and_depth
+    f.restype = None
+    f.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 3
+    f(int(ref_kf.size), pos.ctypes.data, obs_off.ctypes.data, obs_kf.ctypes.data, kf_center.ctypes.data, ref_kf.ctypes.data, ref_level.ctypes.data,
+      sf.ctypes.data, int(sf.size), nrm.ctypes.data, dmin.ctypes.data, dmax.ctypes.data)
+    return nrm, dmin, dmax
+
+
 def three_maxima(counts):
     counts = np.ascontiguousarray(counts, np.int32)
     out = np.zeros(3, np.int32)

@@ -467,6 +467,36 @@ int ora_search_for_initialization(const float* x1, const float* y1, const int32_
   return nmatches;
 }
 
+// MapPoint::UpdateNormalAndDepth (MapPoint.cpp:779-823), batch form with flat arrays.  cv::Mat CV_32F semantics restated ([EXT] OpenCV):
+// Mat - Mat elementwise in f32; cv::norm(CV_32F) = sqrt of the squares accumulated in double; Mat / s = convertTo(alpha = (float)(1.0 / s));
+// Mat + MatExpr(scaled) = f32 multiply then f32 add (no FMA in an x86-64 baseline build).
+void ora_update_normal_and_depth(int n_pt, const float* pos, const int32_t* obs_off, const int32_t* obs_kf, const float* kf_center,
+                                 const int32_t* ref_kf, const int32_t* ref_level, const float* scale_factors, int n_levels, float* normal,
+                                 float* min_dist, float* max_dist) {
+  for (int i = 0; i < n_pt; i++) {
+    if (obs_off[i + 1] == obs_off[i]) continue;   // observations.empty() -> return (:796-797)
+    const float* P = pos + 3 * (size_t)i;
+    float nrm[3] = {0.f, 0.f, 0.f};               // cv::Mat::zeros(3,1,CV_32F)
+    int n = 0;
+    for (int o = obs_off[i]; o < obs_off[i + 1]; o++) {
+      const float* Owi = kf_center + 3 * (size_t)obs_kf[o];
+      const float ni[3] = {P[0] - Owi[0], P[1] - Owi[1], P[2] - Owi[2]};                               // normali = mWorldPos - Owi
+      const double len = std::sqrt((double)ni[0] * ni[0] + (double)ni[1] * ni[1] + (double)ni[2] * ni[2]);   // cv::norm(normali)
+      const float a = (float)(1.0 / len);
+      for (int c = 0; c < 3; c++) { volatile float t = ni[c] * a; nrm[c] = nrm[c] + t; }             // normal = normal + normali / norm
+      n++;
+    }
+    const float* Or = kf_center + 3 * (size_t)ref_kf[i];
+    const float PC[3] = {P[0] - Or[0], P[1] - Or[1], P[2] - Or[2]};                                     // PC = Pos - pRefKF->GetCameraCenter()
+    const float dist = (float)std::sqrt((double)PC[0] * PC[0] + (double)PC[1] * PC[1] + (double)PC[2] * PC[2]);
+    const float levelScaleFactor = scale_factors[ref_level[i]];
+    max_dist[i] = dist * levelScaleFactor;                                                              // mfMaxDistance
+    min_dist[i] = max_dist[i] / scale_factors[n_levels - 1];                                            // mfMinDistance
+    const float an = (float)(1.0 / (double)n);
+    for (int c = 0; c < 3; c++) normal[3 * (size_t)i + c] = nrm[c] * an;                               // mNormalVector = normal / n
+  }
+}
+
 // ComputeThreeMaxima on a histogram given by its bin sizes (pinning test against oracle/_ref)
 void ora_three_maxima(const int32_t* counts, int L, int32_t* out3) {
   std::vector<std::vector<int>> histo((size_t)L);

@@ -139,3 +139,47 @@ def test_frustum_oracle_on_hand_built_points(oracle_lib):
     assert u[0] == np.float32(367.215) and v[0] == np.float32(248.375) and cs[0] == 1.0
     assert lvl[0] == int(np.ceil(np.log(np.float32(2.0)) / np.log(np.float32(1.2))))   # ceil(3.80) = 4
     assert lvl[6] in (0, 1)                                                               # ratio just below 1
+
+
+def _normal_depth_case(seed, n_pt=5000, n_kf=120):
+    rng = np.random.default_rng(seed)
+    kf_center = (rng.normal(size=(n_kf, 3)) * np.array([8, 5, 1.5])).astype(np.float32)
+    pos = (rng.normal(size=(n_pt, 3)) * np.array([10, 6, 2])).astype(np.float32)
+    k = np.clip(rng.poisson(6, n_pt), 0, 30)
+    k[rng.random(n_pt) < 0.02] = 0                                  # observations.empty(): the point keeps its old values
+    off = np.zeros(n_pt + 1, np.int32); off[1:] = np.cumsum(k)
+    obs = np.concatenate([rng.permutation(n_kf)[:kk] for kk in k] + [np.zeros(0, np.int64)]).astype(np.int32)
+    ref_kf = np.array([obs[off[i]] if k[i] else 0 for i in range(n_pt)], np.int32)      # mpRefKF is one of the observers
+    ref_level = rng.integers(0, 8, n_pt).astype(np.int32)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)   # mvScaleFactor[i] = [i-1] * 1.2f
+    old = (rng.normal(size=(n_pt, 3)).astype(np.float32), rng.uniform(0.1, 1, n_pt).astype(np.float32), rng.uniform(5, 9, n_pt).astype(np.float32))
+    return pos, off, obs, kf_center, ref_kf, ref_level, sf, old
+
+
+def test_update_normal_and_depth_oracle_on_hand_numbers(oracle_lib):
+    """MapPoint::UpdateNormalAndDepth (MapPoint.cpp:779-823): mean unit viewing direction over the observers, max distance = |P - O_ref| * scale[level]
+    of the reference keyframe's keypoint, min distance = max / scale[last]."""
+    pos = np.array([[0, 0, 4]], np.float32)
+    kfc = np.array([[0, 0, 0], [3, 0, 4], [0, -4, 1]], np.float32)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)
+    nrm, dmin, dmax = oracle_lib.update_normal_and_depth(pos, [0, 3], [0, 1, 2], kfc, [2], [3], sf, np.zeros((1, 3)), [0.0], [0.0])
+    exp = (np.array([0, 0, 1.0]) + np.array([-1.0, 0, 0]) + np.array([0, 4, 3]) / 5) / 3
+    assert np.abs(nrm[0] - exp).max() < 1e-6
+    assert abs(dmax[0] - 5 * sf[3]) < 1e-5 and abs(dmin[0] - dmax[0] / sf[7]) < 1e-6
+    # f32 semantics: independent numpy evaluation with the same roundings, on a random map
+    pos, off, obs, kfc, ref_kf, ref_level, sf, old = _normal_depth_case(3, 400, 40)
+    nrm, dmin, dmax = oracle_lib.update_normal_and_depth(pos, off, obs, kfc, ref_kf, ref_level, sf, *old)
+    for i in range(400):
+        if off[i + 1] == off[i]:
+            assert np.array_equal(nrm[i], old[0][i]) and dmin[i] == old[1][i] and dmax[i] == old[2][i]
+            continue
+        acc = np.zeros(3, np.float32)
+        for o in obs[off[i]:off[i + 1]]:
+            d = pos[i] - kfc[o]
+            a = np.float32(1.0 / np.sqrt((d.astype(np.float64) ** 2).sum()))
+            acc = acc + d * a
+        assert np.array_equal(nrm[i], acc * np.float32(1.0 / (off[i + 1] - off[i])))
+        pc = pos[i] - kfc[ref_kf[i]]
+        mx = np.float32(np.sqrt((pc.astype(np.float64) ** 2).sum())) * sf[ref_level[i]]
+        assert dmax[i] == mx and dmin[i] == mx / sf[7]
