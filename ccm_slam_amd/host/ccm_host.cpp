@@ -1008,3 +1008,11 @@ extern "C" int ccmh_bow_transform(int device, int n_nodes, int L, const int32_t*
     return 0;
   } catch (const std::exception&) { return -1000; }
 }
+
+// C entry points of the f32 <-> f64 boundary (ccm_convert.h) for the tests and for non-C++ callers
+#include "ccm_convert.h"
+extern "C" {
+void ccmh_to_se3quat(const float* Tcw16, double* qt7) { ccmh::toSE3Quat(Tcw16, qt7); }
+void ccmh_se3quat_to_cvmat(const double* qt7, float* Tcw16) { ccmh::toCvMat(qt7, Tcw16); }
+void ccmh_sim3_to_cvse3(const double* s8, float* Tcw16) { ccmh::sim3ToCvSE3(s8, Tcw16); }
+}

@@ -528,3 +528,27 @@ def bow_transform(vocab: dict, desc, levelsup=4):
                                 _p(desc, C.c_uint8), N, int(levelsup), _p(word, C.c_int32), _p(w, C.c_double), _p(node, C.c_int32),
                                 _p(bid, C.c_int32), _p(bval, C.c_double))
     return word, w, node, bid[:n], bval[:n]
+
+
+def to_se3quat(Tcw) -> np.ndarray:
+    """Converter::toSE3Quat restated: 4x4 CV_32F pose (or an array of them) -> [qx qy qz qw tx ty tz] f64"""
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(-1, 16)
+    out = np.zeros((T.shape[0], 7))
+    f = lib().ora_to_se3quat
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    for i in range(T.shape[0]):
+        f(T[i].ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def se3quat_to_cvmat(qt) -> np.ndarray:
+    """Converter::toCvMat(SE3Quat) restated: [qx qy qz qw tx ty tz] f64 -> 4x4 CV_32F"""
+    q = np.ascontiguousarray(qt, np.float64).reshape(-1, 7)
+    out = np.zeros((q.shape[0], 16), np.float32)
+    f = lib().ora_se3quat_to_cvmat
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    for i in range(q.shape[0]):
+        f(q[i].ctypes.data, out[i].ctypes.data)
+    return out.reshape(-1, 4, 4)

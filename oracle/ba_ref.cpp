@@ -1416,6 +1416,38 @@ int ora_pose_graph_system(int n_vert, const double* sim3, const uint8_t* fixed, 
 
 // test hook: out = log(exp(u)) of g2o::Sim3 (sim3.h:72-140, 146-237)
 void ora_sim3_exp_log(const double* u, double* out) { sim3_log(sim3_exp(u), out); }
+// Converter::toSE3Quat (Converter.cc:40-50): f32 4x4 (row-major) -> Eigen::Quaterniond(R) [Eigen's trace method] -> SE3Quat(R, t) with
+// normalizeRotation (se3quat.h:58-60, 280-285)
+void ora_to_se3quat(const float* T, double* qt) {
+  double m[3][3];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = (double)T[4 * i + j];
+  double q[4];
+  double t = m[0][0] + m[1][1] + m[2][2];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+    q[0] = (m[2][1] - m[1][2]) * t; q[1] = (m[0][2] - m[2][0]) * t; q[2] = (m[1][0] - m[0][1]) * t;
+  } else {
+    int i = 0;
+    if (m[1][1] > m[0][0]) i = 1;
+    if (m[2][2] > m[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    q[i] = 0.5 * t; t = 0.5 / t;
+    q[3] = (m[k][j] - m[j][k]) * t; q[j] = (m[j][i] + m[i][j]) * t; q[k] = (m[k][i] + m[i][k]) * t;
+  }
+  Quat Q{q[0], q[1], q[2], q[3]};
+  normalize_rotation(Q);
+  qt[0] = Q.x; qt[1] = Q.y; qt[2] = Q.z; qt[3] = Q.w; qt[4] = (double)T[3]; qt[5] = (double)T[7]; qt[6] = (double)T[11];
+}
+// Converter::toCvMat(SE3Quat) (Converter.cc:52-56, 74-82): to_homogeneous_matrix (se3quat.h:271-277) rounded to f32
+void ora_se3quat_to_cvmat(const double* qt, float* T) {
+  const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T[4 * i + j] = (float)R[3 * i + j]; T[4 * i + 3] = (float)qt[4 + i]; }
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
 // closed forms, for the pinning tests against oracle/_ref (tests/test_ref_g2o.py)
 void ora_sim3_exp(const double* u, double* s8) {
   const Sim3 S = sim3_exp(u);

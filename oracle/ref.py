@@ -24,7 +24,7 @@ def available(name: str = "libg2o_ref.so") -> bool:
 
 def _lib(name):
     if name not in _libs:
-        path = os.path.join(_HERE, "_ref", name)
+        path = name if os.path.isabs(name) else os.path.join(_HERE, "_ref", name)
         if not os.path.exists(path):
             build()
         _libs[name] = C.CDLL(path)
@@ -148,8 +148,11 @@ KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32),
 class RefOrb:
     """cslam::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) of the reference"""
 
-    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7):
-        L = _lib("liborb_ref.so")
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, lib_path="liborb_ref.so"):
+        """lib_path: the library that provides cslam::ORBextractor behind oracle/ref_orb_driver.cpp — the reference's own ORBextractor.cpp
+        (default) or shim/liborb_hip_shim.so (OUR drop-in translation unit, on the MI355X)"""
+        self._libname = lib_path
+        L = _lib(lib_path)
         L.ref_orb_create.restype = C.c_void_p
         L.ref_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         self._h = C.c_void_p(L.ref_orb_create(nfeatures, scale, nlevels, ini_th, min_th))
@@ -179,7 +182,7 @@ class RefOrb:
         cap = 4 * self.nfeatures + 64
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
-        f = _lib("liborb_ref.so").ref_orb_extract
+        f = _lib(self._libname).ref_orb_extract
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         n = f(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), cap)
@@ -187,7 +190,7 @@ class RefOrb:
         return kps[:n].copy(), desc[:n].copy()
 
     def level(self, l):
-        f = _lib("liborb_ref.so").ref_orb_get_level
+        f = _lib(self._libname).ref_orb_get_level
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         w, h = C.c_int(), C.c_int()
@@ -197,14 +200,14 @@ class RefOrb:
         return out
 
     def border_pixel(self, l, row, col):
-        f = _lib("liborb_ref.so").ref_orb_border_pixel
+        f = _lib(self._libname).ref_orb_border_pixel
         f.restype = C.c_int
         f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         return f(self._h, l, row, col)
 
     def tables(self):
         out = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
-        f = _lib("liborb_ref.so").ref_orb_tables
+        f = _lib(self._libname).ref_orb_tables
         f.restype = None
         f.argtypes = [C.c_void_p] * 5
         f(self._h, *[_p(a) for a in out])
@@ -212,7 +215,7 @@ class RefOrb:
 
     def close(self):
         if self._h:
-            f = _lib("liborb_ref.so").ref_orb_destroy
+            f = _lib(self._libname).ref_orb_destroy
             f.restype = None
             f.argtypes = [C.c_void_p]
             f(self._h)

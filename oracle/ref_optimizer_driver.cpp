@@ -1,0 +1,202 @@
+// ref_optimizer_driver.cpp — TEST INFRASTRUCTURE.  Builds a synthetic Map / KeyFrame / MapPoint / Frame object graph (the look-alike
+// classes of oracle/ref_shim/cslam_lookalike) from flat arrays, calls the static methods of cslam::Optimizer THROUGH THE REFERENCE'S OWN
+// HEADER (cslam/include/cslam/Optimizer.h) and reads the graph back.  The same file is linked twice:
+//   oracle/_ref/liboptimizer_ref.so        with the reference's cslam/src/Optimizer.cpp + Converter.cc + g2o, all compiled verbatim
+//                                          (oracle/Makefile.ref) — the reference behaviour
+//   shim/liboptimizer_hip_shim.so          with OUR drop-in shim/Optimizer_hip.cpp (-> libccm_hip.so on the MI355X)
+// so that tests/test_ref_optimizer.py / tests/test_shim_gpu.py can hand both the identical map and compare what they leave behind.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include <cslam/Optimizer.h>
+
+namespace cslam { std::mutex MapPoint::mGlobalMutex; }
+
+namespace {
+using cslam::Frame;
+using cslam::KeyFrame;
+using cslam::Map;
+using cslam::MapPoint;
+typedef boost::shared_ptr<KeyFrame> kfptr;
+typedef boost::shared_ptr<MapPoint> mpptr;
+
+struct MapG {
+  // contiguous stores: shared_ptr ordering (std::map<kfptr, ...> iteration, std::set<kfptr>) is ADDRESS order = index order here
+  std::unique_ptr<KeyFrame[]> kf_store;
+  std::unique_ptr<MapPoint[]> mp_store;
+  std::vector<kfptr> kfs;
+  std::vector<mpptr> mps;
+  boost::shared_ptr<Map> map;
+  std::vector<int> obs_mp, obs_kf;
+};
+
+cv::Mat mat44(const float* T) { cv::Mat m(4, 4, CV_32F); std::memcpy(m.data, T, 64); return m; }
+}  // namespace
+
+extern "C" {
+
+// kf_*: per keyframe; keypoints of keyframe k are kp_xy/kp_oct[kp_off[k] .. kp_off[k+1]); observation o: map point obs_mp[o] is seen by
+// keyframe obs_kf[o] at keypoint index obs_kp[o] (AddObservation order = o); covisibility weight = shared map points, connected when >= cov_th
+void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, const int32_t* kf_uid, const float* kf_Tcw, const uint8_t* kf_bad,
+                  const float* K4, const int32_t* kp_off, const float* kp_xy, const int32_t* kp_oct, int n_mp, const int32_t* mp_id,
+                  const int32_t* mp_client, const int32_t* mp_uid, const float* mp_pos, const uint8_t* mp_bad, int n_obs, const int32_t* obs_mp,
+                  const int32_t* obs_kf, const int32_t* obs_kp, int n_levels, float scale_factor, int map_id, int cov_th) {
+  MapG* g = new MapG();
+  g->kf_store.reset(new KeyFrame[n_kf]);
+  g->mp_store.reset(new MapPoint[n_mp]);
+  g->map.reset(new Map());
+  g->map->mMapId = (size_t)map_id;
+  std::vector<float> sf(n_levels), s2(n_levels), is2(n_levels);
+  sf[0] = 1.0f; s2[0] = 1.0f;
+  for (int i = 1; i < n_levels; i++) { sf[i] = sf[i - 1] * scale_factor; s2[i] = sf[i] * sf[i]; }   // ORBextractor.cpp:586-591
+  for (int i = 0; i < n_levels; i++) is2[i] = 1.0f / s2[i];
+  for (int k = 0; k < n_kf; k++) {
+    KeyFrame& kf = g->kf_store[k];
+    kf.mId = std::make_pair((size_t)kf_id[k], (size_t)kf_client[k]);
+    kf.mUniqueId = (size_t)kf_uid[k];
+    kf.mbBad = kf_bad[k] != 0;
+    kf.fx = K4[0]; kf.fy = K4[1]; kf.cx = K4[2]; kf.cy = K4[3];
+    kf.mK = cv::Mat::eye(3, 3, CV_32F);
+    kf.mK.at<float>(0, 0) = K4[0]; kf.mK.at<float>(1, 1) = K4[1]; kf.mK.at<float>(0, 2) = K4[2]; kf.mK.at<float>(1, 2) = K4[3];
+    kf.mnScaleLevels = n_levels; kf.mfScaleFactor = scale_factor; kf.mfLogScaleFactor = std::log(scale_factor);
+    kf.mvScaleFactors = sf; kf.mvLevelSigma2 = s2; kf.mvInvLevelSigma2 = is2;
+    kf.N = kp_off[k + 1] - kp_off[k];
+    kf.mvKeysUn.resize(kf.N);
+    for (int i = 0; i < kf.N; i++) { const int s = kp_off[k] + i; kf.mvKeysUn[i] = cv::KeyPoint(kp_xy[2 * s], kp_xy[2 * s + 1], 31.f * sf[kp_oct[s]], -1, 0, kp_oct[s]); }
+    kf.mvpMapPoints.assign(kf.N, mpptr());
+    kf.SetPose(mat44(kf_Tcw + 16 * (size_t)k), false);
+    g->kfs.push_back(kfptr(&kf, [](KeyFrame*) {}));
+    g->map->msuAssClients.insert((size_t)kf_client[k]);
+  }
+  for (int p = 0; p < n_mp; p++) {
+    MapPoint& mp = g->mp_store[p];
+    mp.mId = std::make_pair((size_t)mp_id[p], (size_t)mp_client[p]);
+    mp.mUniqueId = (size_t)mp_uid[p];
+    mp.mbBad = mp_bad[p] != 0;
+    cv::Mat pos(3, 1, CV_32F);
+    for (int c = 0; c < 3; c++) pos.at<float>(c) = mp_pos[3 * (size_t)p + c];
+    mp.SetWorldPos(pos, false);
+    mp.mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
+    g->mps.push_back(mpptr(&mp, [](MapPoint*) {}));
+  }
+  g->obs_mp.assign(obs_mp, obs_mp + n_obs); g->obs_kf.assign(obs_kf, obs_kf + n_obs);
+  std::vector<std::map<int, int>> shared(n_kf);   // covisibility weights
+  std::vector<std::vector<int>> seen_by(n_mp);
+  for (int o = 0; o < n_obs; o++) {
+    MapPoint& mp = g->mp_store[obs_mp[o]];
+    KeyFrame& kf = g->kf_store[obs_kf[o]];
+    if (!mp.mpRefKF) mp.mpRefKF = g->kfs[obs_kf[o]];                  // the creating keyframe
+    mp.mObservations[g->kfs[obs_kf[o]]] = (size_t)obs_kp[o];        // AddObservation
+    mp.nObs++;
+    kf.mvpMapPoints[obs_kp[o]] = g->mps[obs_mp[o]];                 // AddMapPoint
+    seen_by[obs_mp[o]].push_back(obs_kf[o]);
+  }
+  for (int p = 0; p < n_mp; p++) for (int a : seen_by[p]) for (int b : seen_by[p]) if (a != b) shared[a][b]++;
+  for (int k = 0; k < n_kf; k++) {   // KeyFrame::UpdateConnections: neighbours with >= cov_th shared points, best first
+    std::vector<std::pair<int, int>> v;
+    for (auto& kv : shared[k]) if (kv.second >= cov_th) v.push_back({kv.second, kv.first});
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    KeyFrame& kf = g->kf_store[k];
+    for (auto& e : v) { kf.mvpOrderedConnectedKeyFrames.push_back(g->kfs[e.second]); kf.mvOrderedWeights.push_back(e.first); kf.mConnectedKeyFrameWeights[g->kfs[e.second]] = e.first; }
+    if (k > 0 && kf_client[k] == kf_client[k - 1]) { kf.mpParent = g->kfs[k - 1]; g->kf_store[k - 1].mspChildrens.insert(g->kfs[k]); }
+  }
+  g->map->mvpKeyFrames = g->kfs;
+  g->map->mvpMapPoints = g->mps;
+  if (n_kf) g->map->mvpKeyFrameOrigins.push_back(g->kfs[0]);
+  for (int p = 0; p < n_mp; p++) g->mp_store[p].UpdateNormalAndDepth();   // as after point creation (Mapping.cpp)
+  return g;
+}
+void mapg_destroy(void* h) { delete (MapG*)h; }
+
+// cslam::Optimizer::LocalBundleAdjustmentClient(pKF, pbStopFlag, pMap, ClientId, SysState)   (Optimizer.h:84-86)
+int mapg_local_ba(void* h, int kf_index, int client_id, int server_state, uint8_t* stop_flag) {
+  MapG* g = (MapG*)h;
+  try {
+    cslam::Optimizer::LocalBundleAdjustmentClient(g->kfs[kf_index], (bool*)stop_flag, g->map, (size_t)client_id,
+                                                  server_state ? cslam::eSystemState::SERVER : cslam::eSystemState::CLIENT);
+  } catch (std::exception& e) { return -1; }
+  return 0;
+}
+// cslam::Optimizer::MapFusionGBA(pMap, ClientId, nIterations, pbStopFlag, nLoopKF, bRobust)   (Optimizer.h:93-94)
+int mapg_map_fusion_gba(void* h, int client_id, int n_iterations, uint8_t* stop_flag, int loop_first, int loop_second, int robust) {
+  MapG* g = (MapG*)h;
+  try {
+    cslam::Optimizer::MapFusionGBA(g->map, (size_t)client_id, n_iterations, (bool*)stop_flag, std::make_pair((size_t)loop_first, (size_t)loop_second), robust != 0);
+  } catch (std::exception& e) { return -1; }
+  return 0;
+}
+// cslam::Optimizer::BundleAdjustmentClient(vpKF, vpMP, ClientId, nIterations, pbStopFlag, nLoopKF, bRobust)   (Optimizer.h:79-81)
+int mapg_bundle_adjustment_client(void* h, int client_id, int n_iterations, uint8_t* stop_flag, int robust) {
+  MapG* g = (MapG*)h;
+  try {
+    cslam::Optimizer::BundleAdjustmentClient(g->kfs, g->mps, (size_t)client_id, n_iterations, (bool*)stop_flag, std::make_pair((size_t)0, (size_t)0), robust != 0);
+  } catch (std::exception& e) { return -1; }
+  return 0;
+}
+
+// state after the call.  Any pointer may be NULL.  kf_gba / mp_gba: mTcwGBA / mPosGBA when the call filled them (else zeros), *_flag says so.
+void mapg_get_state(void* h, float* kf_Tcw, float* kf_gba, uint8_t* kf_gba_flag, float* mp_pos, float* mp_gba, uint8_t* mp_gba_flag, uint8_t* mp_bad,
+                    float* mp_normal, float* mp_dmin, float* mp_dmax, uint8_t* obs_alive) {
+  MapG* g = (MapG*)h;
+  for (size_t k = 0; k < g->kfs.size(); k++) {
+    if (kf_Tcw) { cv::Mat T = g->kfs[k]->GetPose(); std::memcpy(kf_Tcw + 16 * k, T.data, 64); }
+    const bool has = !g->kfs[k]->mTcwGBA.empty();
+    if (kf_gba_flag) kf_gba_flag[k] = has;
+    if (kf_gba) { if (has) { cv::Mat T = g->kfs[k]->mTcwGBA.clone(); std::memcpy(kf_gba + 16 * k, T.data, 64); } else std::memset(kf_gba + 16 * k, 0, 64); }
+  }
+  for (size_t p = 0; p < g->mps.size(); p++) {
+    MapPoint& mp = *g->mps[p];
+    if (mp_pos) for (int c = 0; c < 3; c++) mp_pos[3 * p + c] = mp.mWorldPos.at<float>(c);
+    const bool has = !mp.mPosGBA.empty();
+    if (mp_gba_flag) mp_gba_flag[p] = has;
+    if (mp_gba) for (int c = 0; c < 3; c++) mp_gba[3 * p + c] = has ? mp.mPosGBA.at<float>(c) : 0.f;
+    if (mp_bad) mp_bad[p] = mp.mbBad;
+    if (mp_normal) for (int c = 0; c < 3; c++) mp_normal[3 * p + c] = mp.mNormalVector.at<float>(c);
+    if (mp_dmin) mp_dmin[p] = mp.mfMinDistance;
+    if (mp_dmax) mp_dmax[p] = mp.mfMaxDistance;
+  }
+  if (obs_alive) for (size_t o = 0; o < g->obs_mp.size(); o++) obs_alive[o] = g->mps[g->obs_mp[o]]->mObservations.count(g->kfs[g->obs_kf[o]]) ? 1 : 0;
+}
+
+// cslam::Optimizer::PoseOptimizationClient(Frame&)   (Optimizer.h:88): a Frame with n keypoints, each with a map point
+int mapg_pose_optimization(float* Tcw, int n, const float* kp_xy, const int32_t* kp_oct, const float* mp_pos, const float* K4, int n_levels,
+                           float scale_factor, uint8_t* outlier) {
+  Frame F;
+  F.N = n;
+  F.fx = K4[0]; F.fy = K4[1]; F.cx = K4[2]; F.cy = K4[3];
+  F.mvInvLevelSigma2.resize(n_levels);
+  float s = 1.0f;
+  for (int i = 0; i < n_levels; i++) { F.mvInvLevelSigma2[i] = 1.0f / (s * s); s = s * scale_factor; }
+  F.mTcw = mat44(Tcw);
+  std::unique_ptr<MapPoint[]> store(new MapPoint[n > 0 ? n : 1]);
+  F.mvKeysUn.resize(n); F.mvpMapPoints.resize(n); F.mvbOutlier.assign(n, false);
+  for (int i = 0; i < n; i++) {
+    F.mvKeysUn[i] = cv::KeyPoint(kp_xy[2 * i], kp_xy[2 * i + 1], 31.f, -1, 0, kp_oct[i]);
+    cv::Mat pos(3, 1, CV_32F);
+    for (int c = 0; c < 3; c++) pos.at<float>(c) = mp_pos[3 * (size_t)i + c];
+    store[i].SetWorldPos(pos, false);
+    F.mvpMapPoints[i] = mpptr(&store[i], [](MapPoint*) {});
+  }
+  const int nin = cslam::Optimizer::PoseOptimizationClient(F);
+  std::memcpy(Tcw, F.mTcw.data, 64);
+  for (int i = 0; i < n; i++) outlier[i] = F.mvbOutlier[i] ? 1 : 0;
+  return nin;
+}
+
+// cslam::Converter (Converter.cc:40-119) on plain arrays — pins ccm_slam_amd/host/ccm_convert.h and the oracle's converters
+void mapg_to_se3quat(const float* Tcw, double* qt7) {
+  const g2o::SE3Quat T = cslam::Converter::toSE3Quat(mat44(Tcw));
+  qt7[0] = T.rotation().x(); qt7[1] = T.rotation().y(); qt7[2] = T.rotation().z(); qt7[3] = T.rotation().w();
+  for (int i = 0; i < 3; i++) qt7[4 + i] = T.translation()[i];
+}
+void mapg_se3quat_to_cvmat(const double* qt7, float* Tcw) {
+  const g2o::SE3Quat T(Eigen::Quaterniond(qt7[3], qt7[0], qt7[1], qt7[2]), Eigen::Vector3d(qt7[4], qt7[5], qt7[6]));
+  cv::Mat m = cslam::Converter::toCvMat(T);
+  std::memcpy(Tcw, m.data, 64);
+}
+// MapPoint::UpdateNormalAndDepth of the reference (MapPoint.cpp:779-823) on every point of the graph
+void mapg_update_normals(void* h) { MapG* g = (MapG*)h; for (auto& p : g->mps) p->UpdateNormalAndDepth(); }
+
+}  // extern "C"

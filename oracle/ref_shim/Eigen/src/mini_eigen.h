@@ -129,6 +129,12 @@ class DenseBase {
   D& setIdentity() { for (Index j = 0; j < cols(); j++) for (Index i = 0; i < rows(); i++) derived().ref(i, j) = (i == j) ? PlainScalar(1) : PlainScalar(0); return derived(); }
 
   NoAlias<D> noalias() { return NoAlias<D>(derived()); }
+  // m << a, b, c ...  (row-major fill, as Eigen's CommaInitializer)
+  struct CommaInit {
+    D& m; Index i;
+    CommaInit& operator,(PlainScalar v) { m.ref(i / m.cols_(), i % m.cols_()) = v; i++; return *this; }
+  };
+  CommaInit operator<<(PlainScalar v) { derived().ref(0, 0) = v; return CommaInit{derived(), 1}; }
   ArrayWrap<D> array() { return ArrayWrap<D>(derived()); }
 
   // ---- views

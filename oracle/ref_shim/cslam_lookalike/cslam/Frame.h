@@ -1,0 +1,3 @@
+// look-alike of <cslam/Frame.h> (TEST INFRASTRUCTURE): see MapGraph_lookalike.h
+#pragma once
+#include <cslam/MapGraph_lookalike.h>

@@ -1,0 +1,3 @@
+// look-alike of <cslam/MapPoint.h> (TEST INFRASTRUCTURE): see MapGraph_lookalike.h
+#pragma once
+#include <cslam/MapGraph_lookalike.h>

@@ -221,9 +221,15 @@ inline Mat operator*(const Mat& a, const Mat& b) {   // gemm: double accumulator
 inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.type() == CV_32F ? (double)((float)a.get(r, c) + (float)b.get(r, c)) : a.get(r, c) + b.get(r, c)); return m; }
 inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.type() == CV_32F ? (double)((float)a.get(r, c) - (float)b.get(r, c)) : a.get(r, c) - b.get(r, c)); return m; }
 inline Mat operator-(const Mat& a) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, -a.get(r, c)); return m; }
-inline Mat operator*(const Mat& a, double s) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.get(r, c) * s); return m; }
+// Mat * s and Mat / s are MatExprs that OpenCV evaluates with convertTo(alpha = s resp. 1./s) — or folds into scaleAdd when added to another
+// Mat —, and for CV_32F both multiply by the scalar ROUNDED TO FLOAT, in float (cvtScale32f / scaleAdd_32f, baseline build: no FMA)
+inline Mat operator*(const Mat& a, double s) {
+  Mat m(a.rows, a.cols, a.type());
+  for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.type() == CV_32F ? (double)((float)a.get(r, c) * (float)s) : a.get(r, c) * s);
+  return m;
+}
 inline Mat operator*(double s, const Mat& a) { return a * s; }
-inline Mat operator/(const Mat& a, double s) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.get(r, c) / s); return m; }
+inline Mat operator/(const Mat& a, double s) { return a * (1. / s); }
 inline double norm(const Mat& a) { double s = 0; for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) s += a.get(r, c) * a.get(r, c); return std::sqrt(s); }
 inline double norm(const Mat& a, const Mat& b) { return norm(a - b); }
 inline std::ostream& operator<<(std::ostream& os, const Mat& m) {

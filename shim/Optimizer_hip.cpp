@@ -1,0 +1,748 @@
+// Optimizer_hip.cpp — DROP-IN replacement for the translation unit cslam/src/Optimizer.cpp of the reference.
+//
+// It defines the static methods that the reference's own header declares (cslam/include/cslam/Optimizer.h:79-112) — same names, same
+// signatures, compiled against that header — and does what Optimizer.cpp does around g2o: the graph walks that choose vertices and
+// edges, the f32 -> f64 conversions on the way in (Converter.cc:40-119, here ccm_convert.h), the write-back with its side effects
+// (SetPose, SetWorldPos, UpdateNormalAndDepth, EraseObservation, mTcwGBA ...).  The optimisation itself — everything that was g2o —
+// goes through the C ABI of libccm_hip.so (include/ccm_hip.h) to the MI355X: no g2o optimiser, solver, vertex or edge object is created.
+// The only g2o type that appears is the VALUE type g2o::Sim3 (header-only arithmetic), because it is part of the reference's interface
+// (OptimizeSim3's g2oS12, KeyFrameAndPose) and the essential-graph functions compose their edge measurements from it exactly as the
+// reference does.  cslam::Converter (Converter.cc) is a separate translation unit of the reference and stays in the build.
+//
+// Build: shim/Makefile.  In this repository the map classes are the look-alikes of oracle/ref_shim/cslam_lookalike (the real KeyFrame.h /
+// MapPoint.h / Map.h need ROS, PCL, DBoW2 and cereal, none of which is installed); the member names and types used here are those of
+// the real headers, so the same file compiles in a catkin workspace with `Optimizer.cpp` replaced by it in cslam/CMakeLists.txt:122-145.
+// tests/test_shim_gpu.py runs this file and the reference's Optimizer.cpp on identical synthetic maps and compares what they leave
+// behind in the map.
+#include <cslam/Optimizer.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+
+#include "../include/ccm_hip.h"
+#include "../ccm_slam_amd/host/ccm_convert.h"
+
+namespace cslam {
+namespace {
+
+// one device context per calling thread: tracking, local mapping and the server's optimisation threads call concurrently
+ccm_ctx* thread_ctx() {
+  struct Holder {
+    ccm_ctx* c = nullptr;
+    ~Holder() { if (c) ccm_ctx_destroy(c); }
+  };
+  static thread_local Holder h;
+  if (!h.c) {
+    const char* dev = std::getenv("CCM_DEVICE");
+    if (ccm_ctx_create(dev ? std::atoi(dev) : 0, &h.c) != CCM_OK) {
+      cout << COUTFATAL << "no MI355X context: " << ccm_last_error(nullptr) << endl;
+      throw infrastructure_ex();
+    }
+  }
+  return h.c;
+}
+void check(int rc, const char* what) {
+  if (rc != CCM_OK) {
+    cout << COUTFATAL << what << ": " << ccm_last_error(thread_ctx()) << endl;
+    throw infrastructure_ex();
+  }
+}
+
+// a flat bundle-adjustment problem under construction; cameras and points are numbered in g2o VERTEX-ID order, the order in which g2o
+// itself sorts its active vertices (sparse_optimizer.cpp:482-487)
+struct FlatBA {
+  std::vector<std::pair<size_t, Optimizer::kfptr>> cams;   // (vertex id, keyframe)
+  std::vector<char> cam_fixed_by_id;
+  std::unordered_map<size_t, char> fixed;
+  std::vector<std::pair<size_t, Optimizer::mpptr>> pts;
+  struct Edge { size_t cam_id, pt_id; double u, v, info; };
+  std::vector<Edge> edges;
+  // flattened
+  std::vector<double> cam_qt, cam_K, pt_xyz, e_obs, e_info;
+  std::vector<uint8_t> cam_fix, e_level;
+  std::vector<int32_t> e_cam, e_pt;
+  std::unordered_map<size_t, int> cam_index, pt_index;
+
+  void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cams.push_back({id, kf}); fixed[id] = is_fixed; }
+  void addPoint(size_t id, Optimizer::mpptr mp) { pts.push_back({id, mp}); }
+  void addEdge(size_t pt_id, Optimizer::kfptr kf, size_t cam_id, const cv::KeyPoint& kpUn) {
+    const float& invSigma2 = kf->mvInvLevelSigma2[kpUn.octave];
+    edges.push_back({cam_id, pt_id, (double)kpUn.pt.x, (double)kpUn.pt.y, (double)invSigma2});
+  }
+  void removePoint(size_t id) { for (size_t i = 0; i < pts.size(); i++) if (pts[i].first == id) { pts.erase(pts.begin() + i); return; } }
+  // g2o refuses an edge whose camera vertex does not exist (optimizer.vertex(id) == 0 -> addEdge fails): such observations are dropped
+  void flatten(bool drop_edges_without_camera = false) {
+    if (drop_edges_without_camera) {
+      std::unordered_map<size_t, char> have;
+      for (auto& c : cams) have[c.first] = 1;
+      std::vector<Edge> kept;
+      for (auto& e : edges) if (have.count(e.cam_id)) kept.push_back(e);
+      edges.swap(kept);
+    }
+    std::sort(cams.begin(), cams.end(), [](const std::pair<size_t, Optimizer::kfptr>& a, const std::pair<size_t, Optimizer::kfptr>& b) { return a.first < b.first; });
+    std::sort(pts.begin(), pts.end(), [](const std::pair<size_t, Optimizer::mpptr>& a, const std::pair<size_t, Optimizer::mpptr>& b) { return a.first < b.first; });
+    const size_t nc = cams.size(), np = pts.size(), ne = edges.size();
+    cam_qt.resize(7 * nc); cam_K.resize(4 * nc); cam_fix.resize(nc); pt_xyz.resize(3 * np);
+    for (size_t i = 0; i < nc; i++) {
+      cam_index[cams[i].first] = (int)i;
+      const cv::Mat Tcw = cams[i].second->GetPose();                                  // Converter::toSE3Quat(pKF->GetPose())
+      float T[16];
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[4 * r + c] = Tcw.at<float>(r, c);
+      ccmh::toSE3Quat(T, &cam_qt[7 * i]);
+      cam_K[4 * i] = cams[i].second->fx; cam_K[4 * i + 1] = cams[i].second->fy; cam_K[4 * i + 2] = cams[i].second->cx; cam_K[4 * i + 3] = cams[i].second->cy;
+      cam_fix[i] = fixed[cams[i].first] ? 1 : 0;
+    }
+    for (size_t i = 0; i < np; i++) {
+      pt_index[pts[i].first] = (int)i;
+      const cv::Mat P = pts[i].second->GetWorldPos();                                 // Converter::toVector3d(pMP->GetWorldPos())
+      const float p[3] = {P.at<float>(0), P.at<float>(1), P.at<float>(2)};
+      ccmh::toVector3d(p, &pt_xyz[3 * i]);
+    }
+    e_cam.resize(ne); e_pt.resize(ne); e_obs.resize(2 * ne); e_info.resize(ne); e_level.assign(ne, 0);
+    for (size_t k = 0; k < ne; k++) {
+      e_cam[k] = cam_index[edges[k].cam_id]; e_pt[k] = pt_index[edges[k].pt_id];
+      e_obs[2 * k] = edges[k].u; e_obs[2 * k + 1] = edges[k].v; e_info[k] = edges[k].info;
+    }
+  }
+  ccm_ba_problem problem(double huber) {
+    ccm_ba_problem P;
+    P.n_cam = (int32_t)cams.size(); P.n_pt = (int32_t)pts.size(); P.n_edge = (int32_t)edges.size();
+    P.cam_qt = cam_qt.data(); P.cam_fixed = cam_fix.data(); P.cam_K = cam_K.data(); P.pt_xyz = pt_xyz.data();
+    P.e_cam = e_cam.data(); P.e_pt = e_pt.data(); P.e_obs = e_obs.data(); P.e_info = e_info.data(); P.e_level = e_level.data();
+    P.huber_delta = huber;
+    return P;
+  }
+  cv::Mat camPose(size_t id) {                                                       // Converter::toCvMat(vSE3->estimate())
+    float T[16];
+    ccmh::toCvMat(&cam_qt[7 * (size_t)cam_index[id]], T);
+    cv::Mat m(4, 4, CV_32F);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m.at<float>(r, c) = T[4 * r + c];
+    return m.clone();
+  }
+  cv::Mat pointPos(size_t id) {                                                      // Converter::toCvMat(vPoint->estimate())
+    cv::Mat m(3, 1, CV_32F);
+    for (int c = 0; c < 3; c++) m.at<float>(c) = (float)pt_xyz[3 * (size_t)pt_index[id] + c];
+    return m.clone();
+  }
+};
+
+// optimizer.initializeOptimization(0); optimizer.optimize(n) on the device
+void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vector<double>* chi2, std::vector<uint8_t>* depth_pos) {
+  ccm_ba_problem P = f.problem(huber);
+  ccm_ba_options opt;
+  std::memset(&opt, 0, sizeof(opt));
+  opt.max_iters = iterations;
+  if (chi2) chi2->resize(f.edges.size(), 0.0);
+  if (depth_pos) depth_pos->resize(f.edges.size(), 1);
+  check(ccm_ba_optimize(thread_ctx(), &P, &opt, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), chi2 ? chi2->data() : nullptr,
+                        depth_pos ? depth_pos->data() : nullptr, nullptr),
+        "ccm_ba_optimize");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// client side
+// ---------------------------------------------------------------------------------------------------------------------------------
+void Optimizer::GlobalBundleAdjustemntClient(mapptr pMap, size_t ClientId, int nIterations, bool* pbStopFlag, const idpair nLoopKF, const bool bRobust) {
+  vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
+  vector<mpptr> vpMP = pMap->GetAllMapPoints();
+  BundleAdjustmentClient(vpKFs, vpMP, ClientId, nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+
+// Optimizer.cpp:40-212
+void Optimizer::BundleAdjustmentClient(const vector<kfptr>& vpKFs, const vector<mpptr>& vpMP, size_t ClientId, int nIterations, bool* pbStopFlag,
+                                       const idpair nLoopKF, const bool bRobust) {
+  const idpair zeropair = make_pair(0, ClientId);
+  vector<bool> vbNotIncludedMP;
+  vbNotIncludedMP.resize(vpMP.size());
+  FlatBA f;
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    if (pKF->mId.first >= IDRANGE) {
+      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": KF index out of bounds" << endl;
+      throw infrastructure_ex();
+    }
+    f.addCam(Optimizer::GetID(pKF->mId, true), pKF, pKF->mId == zeropair);
+  }
+  const float thHuber2D = sqrt(5.99);
+  for (size_t i = 0; i < vpMP.size(); i++) {
+    mpptr pMP = vpMP[i];
+    if (pMP->isBad()) continue;
+    if (pMP->mId.first >= IDRANGE) {
+      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": MP index out of bounds" << endl;
+      throw infrastructure_ex();
+    }
+    const int id = Optimizer::GetID(pMP->mId, false);
+    f.addPoint(id, pMP);
+    const map<kfptr, size_t> observations = pMP->GetObservations();
+    int nEdges = 0;
+    for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
+      kfptr pKF = mit->first;
+      if (pKF->isBad()) continue;
+      if (pKF->mId.first >= IDRANGE) {
+        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": KF index out of bounds" << endl;
+        throw infrastructure_ex();
+      }
+      nEdges++;
+      f.addEdge(id, pKF, Optimizer::GetID(pKF->mId, true), pKF->mvKeysUn[mit->second]);
+    }
+    if (nEdges == 0) { f.removePoint(id); vbNotIncludedMP[i] = true; }
+    else vbNotIncludedMP[i] = false;
+  }
+  f.flatten(true);
+  run_ba(f, bRobust ? (double)thHuber2D : 0.0, nIterations, pbStopFlag, nullptr, nullptr);
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    cv::Mat pose = f.camPose(Optimizer::GetID(pKF->mId, true));
+    if (nLoopKF == zeropair) pKF->SetPose(pose, false);
+    else {
+      pKF->mTcwGBA.create(4, 4, CV_32F);
+      pose.copyTo(pKF->mTcwGBA);
+      pKF->mBAGlobalForKF = nLoopKF;
+    }
+  }
+  for (size_t i = 0; i < vpMP.size(); i++) {
+    if (vbNotIncludedMP[i]) continue;
+    mpptr pMP = vpMP[i];
+    if (pMP->isBad()) continue;
+    cv::Mat pos = f.pointPos(Optimizer::GetID(pMP->mId, false));
+    if (nLoopKF == zeropair) {
+      pMP->SetWorldPos(pos, false);
+      pMP->UpdateNormalAndDepth();
+    } else {
+      pMP->mPosGBA.create(3, 1, CV_32F);
+      pos.copyTo(pMP->mPosGBA);
+      pMP->mBAGlobalForKF = nLoopKF;
+    }
+  }
+}
+
+// Optimizer.cpp:215-347
+int Optimizer::PoseOptimizationClient(Frame& Frame) {
+  int nInitialCorrespondences = 0;
+  float T0[16];
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T0[4 * r + c] = Frame.mTcw.at<float>(r, c);
+  double cam_qt[7];
+  ccmh::toSE3Quat(T0, cam_qt);                                                        // Converter::toSE3Quat(Frame.mTcw)
+  const int N = Frame.N;
+  std::vector<double> Xw, obs, info;
+  vector<size_t> vnIndexEdgeMono;
+  vnIndexEdgeMono.reserve(N);
+  {
+    unique_lock<mutex> lock(MapPoint::mGlobalMutex);
+    for (int i = 0; i < N; i++) {
+      mpptr pMP = Frame.mvpMapPoints[i];
+      if (pMP) {
+        nInitialCorrespondences++;
+        Frame.mvbOutlier[i] = false;
+        const cv::KeyPoint& kpUn = Frame.mvKeysUn[i];
+        obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y);
+        const float invSigma2 = Frame.mvInvLevelSigma2[kpUn.octave];
+        info.push_back(invSigma2);
+        cv::Mat P = pMP->GetWorldPos();
+        Xw.push_back(P.at<float>(0)); Xw.push_back(P.at<float>(1)); Xw.push_back(P.at<float>(2));
+        vnIndexEdgeMono.push_back(i);
+      }
+    }
+  }
+  if (nInitialCorrespondences < 3) return 0;
+  const double K[4] = {Frame.fx, Frame.fy, Frame.cx, Frame.cy};
+  std::vector<uint8_t> outlier(vnIndexEdgeMono.size(), 0);
+  int nInliers = 0;
+  // the four rounds of 10 iterations with their inlier / outlier reclassification (:299-338) run inside one kernel launch
+  check(ccm_pose_optimize(thread_ctx(), cam_qt, (int)vnIndexEdgeMono.size(), Xw.data(), obs.data(), info.data(), K, outlier.data(), &nInliers), "ccm_pose_optimize");
+  for (size_t i = 0; i < vnIndexEdgeMono.size(); i++) Frame.mvbOutlier[vnIndexEdgeMono[i]] = outlier[i] != 0;
+  float T[16];
+  ccmh::toCvMat(cam_qt, T);                                                           // Converter::toCvMat(SE3quat_recov)
+  cv::Mat pose(4, 4, CV_32F);
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose.at<float>(r, c) = T[4 * r + c];
+  Frame.SetPose(pose);
+  return nInliers;
+}
+
+// Optimizer.cpp:349-644
+void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr pMap, size_t ClientId, eSystemState SysState) {
+  // Local KeyFrames: breadth-first from the current keyframe (:351-366)
+  list<kfptr> lLocalKeyFrames;
+  lLocalKeyFrames.push_back(pKF);
+  pKF->mBALocalForKF = pKF->mId;
+  const vector<kfptr> vNeighKFs = pKF->GetVectorCovisibleKeyFrames();
+  for (int i = 0, iend = vNeighKFs.size(); i < iend; i++) {
+    kfptr pKFi = vNeighKFs[i];
+    pKFi->mBALocalForKF = pKF->mId;
+    if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi);
+  }
+  // Local MapPoints seen in Local KeyFrames (:368-385)
+  list<mpptr> lLocalMapPoints;
+  for (list<kfptr>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
+    vector<mpptr> vpMPs = (*lit)->GetMapPointMatches();
+    for (vector<mpptr>::iterator vit = vpMPs.begin(), vend = vpMPs.end(); vit != vend; vit++) {
+      mpptr pMP = *vit;
+      if (pMP)
+        if (!pMP->isBad())
+          if (pMP->mBALocalForKF != pKF->mId) {
+            lLocalMapPoints.push_back(pMP);
+            pMP->mBALocalForKF = pKF->mId;
+          }
+    }
+  }
+  // Fixed Keyframes: see local points but are not local (:387-404)
+  list<kfptr> lFixedCameras;
+  for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+    map<kfptr, size_t> observations = (*lit)->GetObservations();
+    for (map<kfptr, size_t>::iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+      kfptr pKFi = mit->first;
+      if (pKFi->mBALocalForKF != pKF->mId && pKFi->mBAFixedForKF != pKF->mId) {
+        pKFi->mBAFixedForKF = pKF->mId;
+        if (!pKFi->isBad()) lFixedCameras.push_back(pKFi);
+      }
+    }
+  }
+  FlatBA f;
+  for (list<kfptr>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
+    kfptr pKFi = *lit;
+    if (pKFi->mId.first >= IDRANGE) {
+      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
+      throw infrastructure_ex();
+    }
+    f.addCam(Optimizer::GetID(pKFi->mId, true), pKFi, pKFi->mId.first == 0 && pKFi->mId.second == ClientId);
+  }
+  for (list<kfptr>::iterator lit = lFixedCameras.begin(), lend = lFixedCameras.end(); lit != lend; lit++) {
+    kfptr pKFi = *lit;
+    if (pKFi->mId.first >= IDRANGE) {
+      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
+      throw infrastructure_ex();
+    }
+    f.addCam(Optimizer::GetID(pKFi->mId, true), pKFi, true);
+  }
+  vector<kfptr> vpEdgeKFMono;
+  vector<mpptr> vpMapPointEdgeMono;
+  const float thHuberMono = sqrt(5.991);
+  for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+    mpptr pMP = *lit;
+    if (pMP->mId.first >= IDRANGE) {
+      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": MP index out of bounds" << endl;
+      throw infrastructure_ex();
+    }
+    const int id = Optimizer::GetID(pMP->mId, false);
+    f.addPoint(id, pMP);
+    const map<kfptr, size_t> observations = pMP->GetObservations();
+    for (map<kfptr, size_t>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
+      kfptr pKFi = mit->first;
+      if (pKFi->mId.first >= IDRANGE) {
+        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
+        throw infrastructure_ex();
+      }
+      if (!pKFi->isBad()) {
+        f.addEdge(id, pKFi, Optimizer::GetID(pKFi->mId, true), pKFi->mvKeysUn[mit->second]);
+        vpEdgeKFMono.push_back(pKFi);
+        vpMapPointEdgeMono.push_back(pMP);
+      }
+    }
+  }
+  if (pbStopFlag)
+    if (*pbStopFlag) return;
+  f.flatten();
+  // optimizer.initializeOptimization(); optimizer.optimize(5);  (:536-537)
+  std::vector<double> chi2;
+  std::vector<uint8_t> dpos;
+  run_ba(f, (double)thHuberMono, 5, pbStopFlag, &chi2, &dpos);
+  bool bDoMore = true;
+  if (pbStopFlag)
+    if (*pbStopFlag) bDoMore = false;
+  if (bDoMore) {
+    // outliers to level 1, robust kernel off, optimize(10) (:545-566).  e->chi2() of a level-1 edge keeps the value of the first pass.
+    for (size_t i = 0, iend = f.edges.size(); i < iend; i++) {
+      mpptr pMP = vpMapPointEdgeMono[i];
+      if (pMP->isBad()) continue;
+      if (chi2[i] > 5.991 || !dpos[i]) f.e_level[i] = 1;
+    }
+    run_ba(f, 0.0, 10, pbStopFlag, &chi2, &dpos);
+  }
+  vector<pair<kfptr, mpptr> > vToErase;
+  vToErase.reserve(f.edges.size());
+  for (size_t i = 0, iend = f.edges.size(); i < iend; i++) {
+    mpptr pMP = vpMapPointEdgeMono[i];
+    if (pMP->isBad()) continue;
+    if (chi2[i] > 5.991 || !dpos[i]) vToErase.push_back(make_pair(vpEdgeKFMono[i], pMP));
+  }
+  if (SysState != eSystemState::SERVER)
+    while (!pMap->LockMapUpdate()) { usleep(params::timings::miLockSleep); }
+  if (!vToErase.empty()) {
+    for (size_t i = 0; i < vToErase.size(); i++) {
+      kfptr pKFi = vToErase[i].first;
+      mpptr pMPi = vToErase[i].second;
+      pKFi->EraseMapPointMatch(pMPi);
+      pMPi->EraseObservation(pKFi);
+    }
+  }
+  for (list<kfptr>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
+    kfptr pKFl = *lit;
+    pKFl->SetPose(f.camPose(Optimizer::GetID(pKFl->mId, true)), false);
+    pKFl->mbUpdatedByServer = false;
+  }
+  for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
+    mpptr pMP = *lit;
+    if (pMP->isBad()) {
+      mpptr pMPcheck = pMap->GetMpPtr(pMP->mId);
+      if (pMPcheck) {
+        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << ":" << __LINE__ << " MP bad but not erased from map" << endl;
+        throw estd::infrastructure_ex();
+      }
+    } else {
+      pMP->SetWorldPos(f.pointPos(Optimizer::GetID(pMP->mId, false)), false);
+      pMP->UpdateNormalAndDepth();
+    }
+  }
+  if (SysState != eSystemState::SERVER) pMap->UnLockMapUpdate();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// server side
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Optimizer.cpp:646-859
+void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool* pbStopFlag, idpair nLoopKF, const bool bRobust) {
+  (void)ClientId;
+  vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
+  vector<mpptr> vpMP = pMap->GetAllMapPoints();
+  const idpair zeropair = make_pair(0, pMap->mMapId);
+  if (pMap->mvpKeyFrameOrigins.empty()) {
+    cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << __LINE__ << " pMap->mvpKeyFrameOrigins.empty()" << endl;
+    throw infrastructure_ex();
+  }
+  idpair FixedId = (*(pMap->mvpKeyFrameOrigins.begin()))->mId;
+  vector<bool> vbNotIncludedMP;
+  vbNotIncludedMP.resize(vpMP.size(), false);
+  FlatBA f;
+  size_t maxKFid = 0;
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    f.addCam(pKF->mUniqueId, pKF, pKF->mId == FixedId);
+    if (pKF->mUniqueId > maxKFid) maxKFid = pKF->mUniqueId;
+  }
+  const float thHuber2D = sqrt(5.99);
+  for (size_t i = 0; i < vpMP.size(); i++) {
+    mpptr pMP = vpMP[i];
+    if (pMP->isBad()) continue;
+    const map<kfptr, size_t> observations = pMP->GetObservations();
+    if (observations.size() < 2) { vbNotIncludedMP[i] = true; continue; }
+    int nEdges = 0;
+    const size_t id = pMP->mUniqueId;
+    for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+      kfptr pKF = mit->first;
+      if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
+      nEdges++;
+    }
+    if (nEdges < 2) { vbNotIncludedMP[i] = true; continue; }
+    f.addPoint(id, pMP);
+    for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
+      kfptr pKF = mit->first;
+      if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
+      f.addEdge(id, pKF, pKF->mUniqueId, pKF->mvKeysUn[mit->second]);
+    }
+  }
+  f.flatten(true);
+  run_ba(f, bRobust ? (double)thHuber2D : 0.0, nIterations, pbStopFlag, nullptr, nullptr);
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    cv::Mat pose = f.camPose(pKF->mUniqueId);
+    if (nLoopKF == zeropair) pKF->SetPose(pose, true);
+    else {
+      pKF->mTcwGBA.create(4, 4, CV_32F);
+      pose.copyTo(pKF->mTcwGBA);
+      pKF->mBAGlobalForKF = nLoopKF;
+    }
+  }
+  for (size_t i = 0; i < vpMP.size(); i++) {
+    if (vbNotIncludedMP[i]) continue;
+    mpptr pMP = vpMP[i];
+    if (pMP->isBad()) continue;
+    cv::Mat pos = f.pointPos(pMP->mUniqueId);
+    if (nLoopKF == zeropair) {
+      pMP->SetWorldPos(pos, true);
+      pMP->UpdateNormalAndDepth();
+    } else {
+      pMP->mPosGBA.create(3, 1, CV_32F);
+      pos.copyTo(pMP->mPosGBA);
+      pMP->mBAGlobalForKF = nLoopKF;
+    }
+  }
+}
+
+// Optimizer.cpp:861-1056
+int Optimizer::OptimizeSim3(kfptr pKF1, kfptr pKF2, std::vector<mpptr>& vpMatches1, g2o::Sim3& g2oS12, const float th2, bool bFixScale) {
+  const cv::Mat& K1 = pKF1->mK;
+  const cv::Mat& K2 = pKF2->mK;
+  const cv::Mat R1w = pKF1->GetRotation();
+  const cv::Mat t1w = pKF1->GetTranslation();
+  const cv::Mat R2w = pKF2->GetRotation();
+  const cv::Mat t2w = pKF2->GetTranslation();
+  const double k1[4] = {K1.at<float>(0, 0), K1.at<float>(1, 1), K1.at<float>(0, 2), K1.at<float>(1, 2)};
+  const double k2[4] = {K2.at<float>(0, 0), K2.at<float>(1, 1), K2.at<float>(0, 2), K2.at<float>(1, 2)};
+  const int N = vpMatches1.size();
+  const vector<mpptr> vpMapPoints1 = pKF1->GetMapPointMatches();
+  std::vector<double> P1c, P2c, obs1, obs2, info1, info2;
+  vector<size_t> vnIndexEdge;
+  for (int i = 0; i < N; i++) {
+    if (!vpMatches1[i]) continue;
+    mpptr pMP1 = vpMapPoints1[i];
+    mpptr pMP2 = vpMatches1[i];
+    const int i2 = pMP2->GetIndexInKeyFrame(pKF2);
+    if (pMP1 && pMP2) {
+      if (!pMP1->isBad() && !pMP2->isBad() && i2 >= 0) {
+        cv::Mat P3D1c = R1w * pMP1->GetWorldPos() + t1w;   // the cv::Mat arithmetic stays with the caller's data types (f32)
+        cv::Mat P3D2c = R2w * pMP2->GetWorldPos() + t2w;
+        for (int c = 0; c < 3; c++) { P1c.push_back(P3D1c.at<float>(c)); P2c.push_back(P3D2c.at<float>(c)); }
+      } else continue;
+    } else continue;
+    const cv::KeyPoint& kpUn1 = pKF1->mvKeysUn[i];
+    obs1.push_back(kpUn1.pt.x); obs1.push_back(kpUn1.pt.y);
+    info1.push_back(pKF1->mvInvLevelSigma2[kpUn1.octave]);
+    const cv::KeyPoint& kpUn2 = pKF2->mvKeysUn[i2];
+    obs2.push_back(kpUn2.pt.x); obs2.push_back(kpUn2.pt.y);
+    info2.push_back(pKF2->mvInvLevelSigma2[kpUn2.octave]);
+    vnIndexEdge.push_back(i);
+  }
+  double s8[8] = {g2oS12.rotation().x(), g2oS12.rotation().y(), g2oS12.rotation().z(), g2oS12.rotation().w(),
+                  g2oS12.translation()[0], g2oS12.translation()[1], g2oS12.translation()[2], g2oS12.scale()};
+  std::vector<uint8_t> keep(vnIndexEdge.size(), 1);
+  int nIn = 0;
+  check(ccm_sim3_optimize(thread_ctx(), s8, (int)vnIndexEdge.size(), P1c.data(), P2c.data(), obs1.data(), obs2.data(), info1.data(), info2.data(), k1, k2,
+                          (double)th2, bFixScale ? 1 : 0, keep.data(), &nIn),
+        "ccm_sim3_optimize");
+  for (size_t i = 0; i < vnIndexEdge.size(); i++) if (!keep[i]) vpMatches1[vnIndexEdge[i]] = static_cast<mpptr>(NULL);
+  if (nIn == 0) return 0;   // fewer than 10 survivors after the first pass: g2oS12 stays as it was (:1015-1016)
+  g2oS12 = g2o::Sim3(Eigen::Quaterniond(s8[3], s8[0], s8[1], s8[2]), Eigen::Vector3d(s8[4], s8[5], s8[6]), s8[7]);
+  return nIn;
+}
+
+namespace {
+typedef std::vector<g2o::Sim3, Eigen::aligned_allocator<g2o::Sim3> > Sim3Vec;
+void sim3_to8(const g2o::Sim3& S, double* p) {
+  p[0] = S.rotation().x(); p[1] = S.rotation().y(); p[2] = S.rotation().z(); p[3] = S.rotation().w();
+  p[4] = S.translation()[0]; p[5] = S.translation()[1]; p[6] = S.translation()[2]; p[7] = S.scale();
+}
+// edge list of an essential graph + the device call; vertices are indexed by mUniqueId like the reference's vScw / vpVertices
+struct PoseGraph {
+  std::vector<int32_t> e_i, e_j;
+  std::vector<double> meas;
+  void addEdge(size_t i, size_t j, const g2o::Sim3& Sji) { e_i.push_back((int32_t)i); e_j.push_back((int32_t)j); meas.resize(meas.size() + 8); sim3_to8(Sji, &meas[meas.size() - 8]); }
+  // optimizer.initializeOptimization(); optimizer.optimize(20) with setUserLambdaInit(1e-16): vertices = the keyframes that were added (`present`)
+  void optimize(const Sim3Vec& vScw, const std::vector<char>& present, size_t fixed_uid, bool bFixScale, Sim3Vec& out) {
+    const size_t n = vScw.size();
+    std::vector<int32_t> slot(n, -1);
+    std::vector<double> sim3;
+    std::vector<uint8_t> fixed;
+    int nv = 0;
+    for (size_t u = 0; u < n; u++) if (present[u]) { slot[u] = nv++; sim3.resize(sim3.size() + 8); sim3_to8(vScw[u], &sim3[sim3.size() - 8]); fixed.push_back(u == fixed_uid ? 1 : 0); }
+    std::vector<int32_t> ei(e_i.size()), ej(e_j.size());
+    for (size_t k = 0; k < e_i.size(); k++) { ei[k] = slot[e_i[k]]; ej[k] = slot[e_j[k]]; }
+    check(ccm_pose_graph_optimize(thread_ctx(), nv, sim3.data(), fixed.data(), bFixScale ? 1 : 0, (int)ei.size(), ei.data(), ej.data(), meas.data(), 20, 1e-16, nullptr,
+                                  nullptr),
+          "ccm_pose_graph_optimize");
+    out = vScw;
+    for (size_t u = 0; u < n; u++) if (present[u]) { const double* p = &sim3[8 * (size_t)slot[u]]; out[u] = g2o::Sim3(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]), p[7]); }
+  }
+};
+cv::Mat sim3_pose(const g2o::Sim3& CorrectedSiw) {   // [R t/s; 0 1] (:1272-1281)
+  double s8[8];
+  sim3_to8(CorrectedSiw, s8);
+  float T[16];
+  ccmh::sim3ToCvSE3(s8, T);
+  cv::Mat m(4, 4, CV_32F);
+  for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m.at<float>(r, c) = T[4 * r + c];
+  return m.clone();
+}
+}  // namespace
+
+// Optimizer.cpp:1058-1331
+void Optimizer::OptimizeEssentialGraphLoopClosure(mapptr pMap, kfptr pLoopKF, kfptr pCurKF, const KeyFrameAndPose& NonCorrectedSim3,
+                                                  const KeyFrameAndPose& CorrectedSim3, const map<kfptr, set<kfptr> >& LoopConnections, const bool& bFixScale) {
+  const vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
+  const vector<mpptr> vpMPs = pMap->GetAllMapPoints();
+  const unsigned int nMaxKFid = pMap->GetMaxKFidUnique();
+  Sim3Vec vScw(nMaxKFid + 1), vCorrectedSwc(nMaxKFid + 1);
+  std::vector<char> present(nMaxKFid + 1, 0);
+  const int minFeat = params::opt::miEssGraphMinFeats;
+  for (size_t i = 0, iend = vpKFs.size(); i < iend; i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    const size_t nIDi = pKF->mUniqueId;
+    KeyFrameAndPose::const_iterator it = CorrectedSim3.find(pKF);
+    if (it != CorrectedSim3.end()) vScw[nIDi] = it->second;
+    else {
+      Eigen::Matrix<double, 3, 3> Rcw = Converter::toMatrix3d(pKF->GetRotation());
+      Eigen::Matrix<double, 3, 1> tcw = Converter::toVector3d(pKF->GetTranslation());
+      vScw[nIDi] = g2o::Sim3(Rcw, tcw, 1.0);
+    }
+    present[nIDi] = 1;
+  }
+  PoseGraph pg;
+  set<pair<long unsigned int, long unsigned int> > sInsertedEdges;
+  for (map<kfptr, set<kfptr> >::const_iterator mit = LoopConnections.begin(), mend = LoopConnections.end(); mit != mend; mit++) {
+    kfptr pKF = mit->first;
+    if (pKF->isBad()) continue;
+    const size_t nIDi = pKF->mUniqueId;
+    const set<kfptr>& spConnections = mit->second;
+    const g2o::Sim3 Swi = vScw[nIDi].inverse();
+    for (set<kfptr>::const_iterator sit = spConnections.begin(), send = spConnections.end(); sit != send; sit++) {
+      if ((*sit)->isBad()) continue;
+      const size_t nIDj = (*sit)->mUniqueId;
+      if ((nIDi != pCurKF->mUniqueId || nIDj != pLoopKF->mUniqueId) && pKF->GetWeight(*sit) < minFeat) continue;
+      pg.addEdge(nIDi, nIDj, vScw[nIDj] * Swi);
+      sInsertedEdges.insert(make_pair(min(nIDi, nIDj), max(nIDi, nIDj)));
+    }
+  }
+  for (size_t i = 0, iend = vpKFs.size(); i < iend; i++) {
+    kfptr pKF = vpKFs[i];
+    const size_t nIDi = pKF->mUniqueId;
+    g2o::Sim3 Swi;
+    KeyFrameAndPose::const_iterator iti = NonCorrectedSim3.find(pKF);
+    if (iti != NonCorrectedSim3.end()) Swi = (iti->second).inverse();
+    else Swi = vScw[nIDi].inverse();
+    kfptr pParentKF = pKF->GetParent();
+    if (pParentKF) {   // spanning tree edge
+      const size_t nIDj = pParentKF->mUniqueId;
+      KeyFrameAndPose::const_iterator itj = NonCorrectedSim3.find(pParentKF);
+      const g2o::Sim3 Sjw = itj != NonCorrectedSim3.end() ? itj->second : vScw[nIDj];
+      pg.addEdge(nIDi, nIDj, Sjw * Swi);
+    }
+    const set<kfptr> sLoopEdges = pKF->GetLoopEdges();
+    for (set<kfptr>::const_iterator sit = sLoopEdges.begin(), send = sLoopEdges.end(); sit != send; sit++) {
+      kfptr pLKF = *sit;
+      const size_t nIDj = pLKF->mUniqueId;
+      if (nIDj < nIDi) {
+        KeyFrameAndPose::const_iterator itl = NonCorrectedSim3.find(pLKF);
+        const g2o::Sim3 Slw = itl != NonCorrectedSim3.end() ? itl->second : vScw[nIDj];
+        pg.addEdge(nIDi, nIDj, Slw * Swi);
+      }
+    }
+    const vector<kfptr> vpConnectedKFs = pKF->GetCovisiblesByWeight(minFeat);
+    for (vector<kfptr>::const_iterator vit = vpConnectedKFs.begin(); vit != vpConnectedKFs.end(); vit++) {
+      kfptr pKFn = *vit;
+      if ((*vit)->isBad()) continue;
+      if (pKFn && pKFn != pParentKF && !pKF->hasChild(pKFn) && !sLoopEdges.count(pKFn)) {
+        const size_t nIDj = pKFn->mUniqueId;
+        if (!pKFn->isBad() && nIDj < nIDi) {
+          if (sInsertedEdges.count(make_pair(min(nIDi, nIDj), max(nIDi, nIDj)))) continue;
+          KeyFrameAndPose::const_iterator itn = NonCorrectedSim3.find(pKFn);
+          const g2o::Sim3 Snw = itn != NonCorrectedSim3.end() ? itn->second : vScw[nIDj];
+          pg.addEdge(nIDi, nIDj, Snw * Swi);
+        }
+      }
+    }
+  }
+  Sim3Vec vCorrectedSiw;
+  pg.optimize(vScw, present, pLoopKF->mUniqueId, bFixScale, vCorrectedSiw);
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKFi = vpKFs[i];
+    const size_t nIDi = pKFi->mUniqueId;
+    const g2o::Sim3 CorrectedSiw = vCorrectedSiw[nIDi];
+    vCorrectedSwc[nIDi] = CorrectedSiw.inverse();
+    pKFi->SetPose(sim3_pose(CorrectedSiw), true);
+  }
+  for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+    mpptr pMP = vpMPs[i];
+    if (pMP->isBad()) continue;
+    size_t nIDr;
+    if (pMP->mCorrectedByKF_LC == pCurKF->mId) nIDr = pMP->mCorrectedReference_LC;
+    else nIDr = pMP->GetReferenceKeyFrame()->mUniqueId;
+    const g2o::Sim3 Srw = vScw[nIDr];
+    const g2o::Sim3 correctedSwr = vCorrectedSwc[nIDr];
+    Eigen::Matrix<double, 3, 1> eigP3Dw = Converter::toVector3d(pMP->GetWorldPos());
+    Eigen::Matrix<double, 3, 1> eigCorrectedP3Dw = correctedSwr.map(Srw.map(eigP3Dw));
+    pMP->SetWorldPos(Converter::toCvMat(eigCorrectedP3Dw), true);
+    pMP->UpdateNormalAndDepth();
+  }
+}
+
+// Optimizer.cpp:1333-1566
+void Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap, kfptr pLoopKF, kfptr pCurKF, const map<kfptr, set<kfptr> >& LoopConnections, const bool& bFixScale) {
+  const vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
+  const vector<mpptr> vpMPs = pMap->GetAllMapPoints();
+  const unsigned int nMaxKFid = pMap->GetMaxKFidUnique();
+  Sim3Vec vScw(nMaxKFid + 1), vCorrectedSwc(nMaxKFid + 1);
+  std::vector<char> present(nMaxKFid + 1, 0);
+  const int minFeat = params::opt::miEssGraphMinFeats;
+  for (size_t i = 0, iend = vpKFs.size(); i < iend; i++) {
+    kfptr pKF = vpKFs[i];
+    if (pKF->isBad()) continue;
+    const size_t nIDi = pKF->mUniqueId;
+    Eigen::Matrix<double, 3, 3> Rcw = Converter::toMatrix3d(pKF->GetRotation());
+    Eigen::Matrix<double, 3, 1> tcw = Converter::toVector3d(pKF->GetTranslation());
+    vScw[nIDi] = g2o::Sim3(Rcw, tcw, 1.0);
+    present[nIDi] = 1;
+  }
+  PoseGraph pg;
+  set<pair<long unsigned int, long unsigned int> > sInsertedEdges;
+  for (map<kfptr, set<kfptr> >::const_iterator mit = LoopConnections.begin(), mend = LoopConnections.end(); mit != mend; mit++) {
+    kfptr pKF = mit->first;
+    if (pKF->isBad()) continue;
+    const size_t nIDi = pKF->mUniqueId;
+    const set<kfptr>& spConnections = mit->second;
+    const g2o::Sim3 Swi = vScw[nIDi].inverse();
+    for (set<kfptr>::const_iterator sit = spConnections.begin(), send = spConnections.end(); sit != send; sit++) {
+      if ((*sit)->isBad()) continue;
+      const size_t nIDj = (*sit)->mUniqueId;
+      if ((nIDi != pCurKF->mUniqueId || nIDj != pLoopKF->mUniqueId) && pKF->GetWeight(*sit) < minFeat) continue;
+      pg.addEdge(nIDi, nIDj, vScw[nIDj] * Swi);
+      sInsertedEdges.insert(make_pair(min(nIDi, nIDj), max(nIDi, nIDj)));
+    }
+  }
+  for (size_t i = 0, iend = vpKFs.size(); i < iend; i++) {
+    kfptr pKF = vpKFs[i];
+    const size_t nIDi = pKF->mUniqueId;
+    const g2o::Sim3 Swi = vScw[nIDi].inverse();
+    kfptr pParentKF = pKF->GetParent();
+    if (pParentKF) pg.addEdge(nIDi, pParentKF->mUniqueId, vScw[pParentKF->mUniqueId] * Swi);
+    const set<kfptr> sLoopEdges = pKF->GetLoopEdges();
+    for (set<kfptr>::const_iterator sit = sLoopEdges.begin(), send = sLoopEdges.end(); sit != send; sit++) {
+      const size_t nIDj = (*sit)->mUniqueId;
+      if (nIDj < nIDi) pg.addEdge(nIDi, nIDj, vScw[nIDj] * Swi);
+    }
+    const vector<kfptr> vpConnectedKFs = pKF->GetCovisiblesByWeight(minFeat);
+    for (vector<kfptr>::const_iterator vit = vpConnectedKFs.begin(); vit != vpConnectedKFs.end(); vit++) {
+      kfptr pKFn = *vit;
+      if ((*vit)->isBad()) continue;
+      if (pKFn && pKFn != pParentKF && !pKF->hasChild(pKFn) && !sLoopEdges.count(pKFn)) {
+        const size_t nIDj = pKFn->mUniqueId;
+        if (!pKFn->isBad() && nIDj < nIDi) {
+          if (sInsertedEdges.count(make_pair(min(nIDi, nIDj), max(nIDi, nIDj)))) continue;
+          pg.addEdge(nIDi, nIDj, vScw[nIDj] * Swi);
+        }
+      }
+    }
+  }
+  Sim3Vec vCorrectedSiw;
+  pg.optimize(vScw, present, pLoopKF->mUniqueId, bFixScale, vCorrectedSiw);
+  for (size_t i = 0; i < vpKFs.size(); i++) {
+    kfptr pKFi = vpKFs[i];
+    const size_t nIDi = pKFi->mUniqueId;
+    const g2o::Sim3 CorrectedSiw = vCorrectedSiw[nIDi];
+    vCorrectedSwc[nIDi] = CorrectedSiw.inverse();
+    pKFi->SetPose(sim3_pose(CorrectedSiw), true);
+  }
+  for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+    mpptr pMP = vpMPs[i];
+    if (pMP->isBad()) continue;
+    int nIDr;
+    if (pMP->mCorrectedByKF_MM == pCurKF->mId) nIDr = pMP->mCorrectedReference_MM;
+    else nIDr = pMP->GetReferenceKeyFrame()->mUniqueId;
+    const g2o::Sim3 Srw = vScw[nIDr];
+    const g2o::Sim3 correctedSwr = vCorrectedSwc[nIDr];
+    Eigen::Matrix<double, 3, 1> eigP3Dw = Converter::toVector3d(pMP->GetWorldPos());
+    Eigen::Matrix<double, 3, 1> eigCorrectedP3Dw = correctedSwr.map(Srw.map(eigP3Dw));
+    pMP->SetWorldPos(Converter::toCvMat(eigCorrectedP3Dw), true);
+    pMP->UpdateNormalAndDepth();
+  }
+}
+
+}  // namespace cslam

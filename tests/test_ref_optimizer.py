@@ -1,0 +1,185 @@
+"""The reference's cslam/src/Optimizer.cpp + Converter.cc + MapPoint::UpdateNormalAndDepth, compiled verbatim (oracle/Makefile.ref ->
+oracle/_ref/liboptimizer_ref.so) and called THROUGH THE REFERENCE'S OWN CLASS API (Optimizer.h) on synthetic Map / KeyFrame / MapPoint
+graphs (look-alike classes, oracle/ref_shim/cslam_lookalike), against the flat oracle restatement.  Covers what the flat comparisons of
+tests/test_ref_g2o.py cannot: Optimizer.cpp's own graph construction (which vertices, which edges, ids, robust kernels, levels, the
+5 + 10 iteration protocol of local BA with its erase set), the f32 <-> f64 boundary of row O0 (Converter::toSE3Quat / toCvMat), and the
+write-back side effects.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from ccm_slam_amd import synth
+from oracle import mapgraph as mg
+
+pytestmark = pytest.mark.skipif(not os.path.exists(mg.REF_LIB) and not os.path.isdir("/root/reference/cslam"), reason="oracle/_ref not built")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(mg.REF_LIB):
+        from oracle import ref
+        ref.build()
+
+
+SF = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))])).astype(np.float32)
+IS2 = (np.float32(1) / (SF * SF)).astype(np.float32)
+
+
+def flat_problem_for_oracle(prob, flat, fixed, huber):
+    """what Optimizer.cpp feeds g2o, as a flat problem for the oracle: quaternions from the f32 matrices (Converter::toSE3Quat), f32 points and
+    keypoints widened, information = mvInvLevelSigma2[octave] (f32)"""
+    idx = flat["kp_off"][flat["obs_kf"]] + flat["obs_kp"]
+    p = dict(prob)
+    p["cam_qt"] = oracle.to_se3quat(flat["kf_Tcw"])
+    p["pt_xyz"] = flat["mp_pos"].astype(np.float64)
+    p["e_obs"] = flat["kp_xy"][idx].astype(np.float64)
+    p["e_info"] = IS2[flat["kp_oct"][idx]].astype(np.float64)
+    p["cam_fixed"] = np.asarray(fixed, np.uint8)
+    p["huber_delta"] = float(huber)
+    return p
+
+
+def ulps32(a, b):
+    """difference in units of the f32 spacing at max(1, |value|): poses and points are O(1..10) quantities stored as f32"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) / (np.finfo(np.float32).eps * np.maximum(1.0, np.maximum(np.abs(a), np.abs(b))))
+
+
+def test_converter_boundary_O0_reference_vs_product_vs_oracle():
+    """Converter::toSE3Quat / toCvMat of the reference (Converter.cc:40-93 + se3quat.h) against the product's host code
+    (ccm_slam_amd/host/ccm_convert.h via libccm_host.so) and the oracle's restatement: f32 pose matrices as a map stores them — rotations rounded
+    to f32 (not exactly orthonormal), every branch of the trace method."""
+    to_q, to_T = mg.converter(mg.REF_LIB)
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ccm_slam_amd", "libccm_host.so"))
+    rng = np.random.default_rng(0)
+    worst_q = worst_T = 0.0
+    for k in range(3000):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        if k % 7 == 0:
+            q[3] = abs(q[3]) * 1e-3; q /= np.linalg.norm(q)                  # near-180-degree rotations: the three non-trace branches
+        R = synth.R_from_quat(q[None])[0]
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R.astype(np.float32); T[:3, 3] = rng.normal(size=3).astype(np.float32) * 5
+        ref_q = to_q(T)
+        prod_q = np.zeros(7); host.ccmh_to_se3quat(T.ctypes.data_as(C.c_void_p), prod_q.ctypes.data_as(C.c_void_p))
+        ora_q = oracle.to_se3quat(T)[0]
+        assert ref_q[3] >= 0 and abs(np.linalg.norm(ref_q[:4]) - 1) < 1e-15
+        worst_q = max(worst_q, np.abs(ref_q - prod_q).max(), np.abs(ref_q - ora_q).max())
+        ref_T = to_T(ref_q)
+        prod_T = np.zeros(16, np.float32); host.ccmh_se3quat_to_cvmat(ref_q.ctypes.data_as(C.c_void_p), prod_T.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(ref_T.reshape(-1), prod_T) and np.array_equal(ref_T, oracle.se3quat_to_cvmat(ref_q)[0])   # f32 output: bit-exact
+        worst_T = max(worst_T, np.abs(ref_T - T).max())
+    assert worst_q < 1e-15, worst_q                          # f64 quaternion: identical up to the last bit of sqrt / division ordering
+    assert worst_T < 5e-7                                    # a pose survives the f32 -> SE3Quat -> f32 round trip to f32 precision
+
+
+def test_update_normal_and_depth_of_the_reference_is_the_oracle_bit_for_bit():
+    """MapPoint::UpdateNormalAndDepth (MapPoint.cpp:779-823, compiled from the reference source) is run by the harness on every point at map
+    creation; the flat oracle restatement (and through tests/test_frame_gpu.py the device kernel) must reproduce its f32 results exactly."""
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=25, n_points=3000, seed=9)
+    flat = mg.flat_from_ba_problem(prob, n_agents=2)
+    g = mg.MapGraph(mg.REF_LIB, flat)
+    s = g.state()
+    g.close()
+    n_pt = flat["n_mp"]
+    order = np.lexsort((flat["obs_kf"], flat["obs_mp"]))                # the reference iterates std::map<kfptr, ...>: keyframe (address) order
+    off = np.zeros(n_pt + 1, np.int32); np.add.at(off, flat["obs_mp"] + 1, 1); off = np.cumsum(off).astype(np.int32)
+    obs_kf = flat["obs_kf"][order]
+    first = np.full(n_pt, -1, np.int64)
+    for o in range(flat["obs_mp"].size - 1, -1, -1):
+        first[flat["obs_mp"][o]] = o                                    # mpRefKF = the first keyframe that observed the point
+    ref_kf = flat["obs_kf"][first]
+    ref_level = flat["kp_oct"][flat["kp_off"][ref_kf] + flat["obs_kp"][first]]
+    T = flat["kf_Tcw"]
+    Ow = np.zeros((flat["n_kf"], 3), np.float32)
+    for k in range(flat["n_kf"]):                                        # KeyFrame::SetPose: Ow = -Rwc * tcw (cv::gemm: double accumulation, one rounding)
+        Ow[k] = (-(T[k, :3, :3].T.astype(np.float64)) @ T[k, :3, 3].astype(np.float64)).astype(np.float32)
+    nrm, dmin, dmax = oracle.update_normal_and_depth(flat["mp_pos"], off, obs_kf, Ow, ref_kf, ref_level, SF, np.zeros((n_pt, 3)), np.zeros(n_pt), np.zeros(n_pt))
+    assert np.array_equal(nrm, s["mp_normal"]) and np.array_equal(dmin, s["mp_dmin"]) and np.array_equal(dmax, s["mp_dmax"])
+
+
+def test_map_fusion_gba_of_the_reference_vs_oracle():
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=15, n_points=1500, seed=4, n_fixed=1)
+    flat = mg.flat_from_ba_problem(prob, n_agents=2)
+    fixed = np.zeros(prob["n_cam"], np.uint8); fixed[0] = 1               # mvpKeyFrameOrigins.front()
+    p = flat_problem_for_oracle(prob, flat, fixed, np.float32(np.sqrt(np.float32(5.99))))
+    for iters, tol_ulp in ((1, 4), (4, 64)):
+        g = mg.MapGraph(mg.REF_LIB, flat)
+        assert g.map_fusion_gba(0, iters) == 0
+        s = g.state(); g.close()
+        oc, op, _, _, ost = oracle.ba_optimize(p, iters)
+        assert ulps32(oracle.se3quat_to_cvmat(oc), s["kf_Tcw"]).max() <= tol_ulp
+        assert ulps32(op, s["mp_pos"]).max() <= tol_ulp * 4
+        assert np.array_equal(s["kf_Tcw"][0], flat["kf_Tcw"][0])        # the fixed origin keyframe: toSE3Quat -> toCvMat round trip only
+    # run to the end: the gauge (scale) is free with one fixed keyframe, so compare the gauge-invariant robust chi2 of the two results
+    g = mg.MapGraph(mg.REF_LIB, flat); g.map_fusion_gba(0, 20); s = g.state(); g.close()
+    oc, op, _, _, ost = oracle.ba_optimize(p, 20)
+    chi_ref = oracle.ba_chi2(p, oracle.to_se3quat(s["kf_Tcw"]), s["mp_pos"].astype(np.float64))
+    chi_ora = oracle.ba_chi2(p, oracle.to_se3quat(oracle.se3quat_to_cvmat(oc)), op.astype(np.float32).astype(np.float64))
+    assert abs(chi_ref / chi_ora - 1) < 1e-3, (chi_ref, chi_ora, ost.chi2_final)
+    # with a loop keyframe given, the results go to mTcwGBA / mPosGBA instead (Optimizer.cpp:812-818, 841-852)
+    g = mg.MapGraph(mg.REF_LIB, flat); g.map_fusion_gba(0, 2, loop_kf=(3, 0)); s2 = g.state(); g.close()
+    assert s2["kf_gba_flag"].all() and np.array_equal(s2["kf_Tcw"], flat["kf_Tcw"]) and np.array_equal(s2["mp_pos"], flat["mp_pos"])
+    assert s2["mp_gba_flag"].sum() > 0.9 * flat["n_mp"]
+
+
+def local_window(flat, cur, cov_th):
+    """which keyframes / points / observations LocalBundleAdjustmentClient optimises (Optimizer.cpp:351-404), as sets: local keyframes = the
+    current one and its covisible neighbours, local points = seen by a local keyframe, fixed keyframes = the other observers of those points"""
+    n_kf, n_mp = flat["n_kf"], flat["n_mp"]
+    seen = np.zeros((n_mp, n_kf), bool)
+    seen[flat["obs_mp"], flat["obs_kf"]] = True
+    shared = (seen[:, [cur]] & seen).sum(0)
+    local_kf = shared >= cov_th
+    local_kf[cur] = True
+    local_mp = (seen & local_kf[None, :]).any(1)
+    edge_in = local_mp[flat["obs_mp"]]
+    used_kf = np.zeros(n_kf, bool); used_kf[flat["obs_kf"][edge_in]] = True
+    return local_kf, local_mp, edge_in, used_kf & ~local_kf
+
+
+def test_local_ba_of_the_reference_vs_oracle_protocol():
+    """LocalBundleAdjustmentClient through the class API: local window around the current keyframe, the other observers as fixed cameras,
+    optimize(5) + outlier levels + optimize(10), the erase set, f32 write-back of the local keyframes and points only."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=30, n_points=2500, seed=12, n_fixed=1, mean_track=7)
+    flat = mg.flat_from_ba_problem(prob)
+    flat["cov_th"] = 15
+    cur = 17
+    local_kf, local_mp, edge_in, fixed_kf = local_window(flat, cur, 15)
+    assert 3 <= local_kf.sum() < 30 and fixed_kf.sum() >= 2 and not local_mp.all()     # a real window: local, fixed and untouched parts all exist
+    g = mg.MapGraph(mg.REF_LIB, flat)
+    assert g.local_ba(cur, client_id=0) == 0
+    s = g.state(); g.close()
+    # the same problem for the flat oracle: only the window's observations; cameras outside it never enter
+    fixed = (~local_kf).astype(np.uint8); fixed[0] = 1                                    # mId == (0, ClientId) stays fixed even when local
+    p1 = flat_problem_for_oracle(prob, flat, fixed, np.float32(np.sqrt(np.float32(5.991))))
+    p1["e_level"] = (~edge_in).astype(np.uint8)                                           # observations outside the window: not part of the graph
+    oc, op, chi2, dpos, _ = oracle.ba_optimize(p1, 5)
+    level = p1["e_level"].copy(); level[edge_in & ((chi2 > 5.991) | (dpos == 0))] = 1
+    p2 = dict(p1); p2.update(cam_qt=oc, pt_xyz=op, e_level=level, huber_delta=0.0)
+    oc2, op2, chi2b, dpos2, _ = oracle.ba_optimize(p2, 10, chi2_in=chi2)
+    erase = edge_in & ((chi2b > 5.991) | (dpos2 == 0))
+    assert 0 < erase.sum() < 0.2 * edge_in.sum()
+    flips = (s["obs_alive"] == erase.astype(np.uint8)).sum()             # alive must be the complement of erase
+    assert flips <= 2, flips                                             # an observation with chi2 within rounding of 5.991 may flip
+    T_or = oracle.se3quat_to_cvmat(oc2)
+    assert ulps32(T_or[local_kf], s["kf_Tcw"][local_kf]).max() <= 256
+    assert np.array_equal(s["kf_Tcw"][~local_kf], flat["kf_Tcw"][~local_kf])             # fixed and outside keyframes are not written
+    keep = local_mp & (s["mp_bad"] == 0)
+    assert ulps32(op2[keep], s["mp_pos"][keep]).max() <= 1024
+    assert np.array_equal(s["mp_pos"][~local_mp], flat["mp_pos"][~local_mp])
+
+
+def test_pose_optimization_of_the_reference_vs_oracle():
+    for n, seed, of in ((300, 0, 0.1), (40, 3, 0.3), (1000, 7, 0.2)):
+        pp = synth.make_pose_problem(n, seed, of)
+        R = synth.R_from_quat(pp["cam_qt"][None, :4])[0]
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R.astype(np.float32); T[:3, 3] = pp["cam_qt"][4:].astype(np.float32)
+        octv = np.rint(-np.log(pp["info"]) / (2 * np.log(1.2))).astype(np.int32)
+        Tr, outl, nin = mg.pose_optimization(mg.REF_LIB, T, pp["obs"].astype(np.float32), octv, pp["Xw"].astype(np.float32), np.asarray(pp["K"], np.float32))
+        oc, oo, on = oracle.pose_optimize(oracle.to_se3quat(T)[0], pp["Xw"].astype(np.float32).astype(np.float64), pp["obs"].astype(np.float32).astype(np.float64),
+                                          IS2[octv].astype(np.float64), pp["K"])
+        assert nin == on and np.array_equal(outl, oo)
+        assert ulps32(oracle.se3quat_to_cvmat(oc)[0], Tr).max() <= 2

@@ -1,0 +1,103 @@
+"""OUR drop-in translation units (shim/Optimizer_hip.cpp, shim/ORBextractor_hip.cpp -> libccm_hip.so on the MI355X) against the REFERENCE'S OWN
+translation units (cslam/src/Optimizer.cpp, ORBextractor.cpp compiled verbatim, oracle/_ref), both driven through the reference's class API
+by the same harness on identical synthetic maps / images: what a maintainer gets when the .cpp files are swapped in cslam/CMakeLists.txt.
+Covers the graph walks of the shim, the O0 boundary, the write-back side effects and the erase set end to end."""
+import os
+
+import numpy as np
+import pytest
+
+from ccm_slam_amd import synth
+from oracle import mapgraph as mg
+from oracle import ref
+from tests.test_ref_optimizer import local_window, ulps32
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.path.exists(mg.REF_LIB) and os.path.exists(mg.SHIM_LIB)), reason="oracle/_ref or shim library not built")]
+
+
+def _both(flat, call):
+    out = []
+    for lib in (mg.REF_LIB, mg.SHIM_LIB):
+        g = mg.MapGraph(lib, flat)
+        assert call(g) == 0
+        out.append(g.state())
+        g.close()
+    return out
+
+
+def test_local_bundle_adjustment_client_shim_equals_reference():
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=30, n_points=2500, seed=12, n_fixed=1, mean_track=7)
+    flat = mg.flat_from_ba_problem(prob)
+    for cur in (17, 3):
+        local_kf, local_mp, edge_in, fixed_kf = local_window(flat, cur, 15)
+        r, s = _both(flat, lambda g: g.local_ba(cur, client_id=0))
+        assert (r["obs_alive"] != s["obs_alive"]).sum() <= 2                       # the erase set (chi2 within rounding of 5.991 may flip)
+        assert 0 < (r["obs_alive"] == 0).sum()
+        assert ulps32(r["kf_Tcw"], s["kf_Tcw"]).max() <= 256
+        assert np.array_equal(s["kf_Tcw"][~local_kf], flat["kf_Tcw"][~local_kf])   # only the local keyframes are written
+        keep = (r["mp_bad"] == 0) & (s["mp_bad"] == 0)
+        assert ulps32(r["mp_pos"][keep], s["mp_pos"][keep]).max() <= 1024
+        assert np.array_equal(s["mp_pos"][~local_mp], flat["mp_pos"][~local_mp])
+        assert np.abs(r["mp_normal"][keep] - s["mp_normal"][keep]).max() < 1e-4 and np.abs(r["mp_dmax"][keep] / s["mp_dmax"][keep] - 1).max() < 1e-4
+        assert (r["mp_bad"] != s["mp_bad"]).sum() <= 2
+
+
+def test_local_ba_respects_a_raised_stop_flag_like_the_reference():
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=12, n_points=800, seed=2)
+    flat = mg.flat_from_ba_problem(prob)
+    flag = np.ones(1, np.uint8)
+    r, s = _both(flat, lambda g: g.local_ba(6, client_id=0, stop_flag=flag))
+    for st in (r, s):                                                              # early return at Optimizer.cpp:532-534: nothing is written
+        assert np.array_equal(st["kf_Tcw"], flat["kf_Tcw"]) and np.array_equal(st["mp_pos"], flat["mp_pos"]) and st["obs_alive"].all()
+
+
+def test_map_fusion_gba_and_bundle_adjustment_client_shim_equal_reference():
+    prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=15, n_points=1500, seed=4, n_fixed=1)
+    flat = mg.flat_from_ba_problem(prob, n_agents=2)
+    for call in (lambda g: g.map_fusion_gba(0, 4), lambda g: g.bundle_adjustment_client(0, 4)):
+        r, s = _both(flat, call)
+        assert ulps32(r["kf_Tcw"], s["kf_Tcw"]).max() <= 64
+        assert ulps32(r["mp_pos"], s["mp_pos"]).max() <= 256
+        assert np.array_equal(r["mp_normal"] != 0, s["mp_normal"] != 0)
+    # loop keyframe given: results land in mTcwGBA / mPosGBA, the map itself is untouched (Optimizer.cpp:812-818, 841-852)
+    r, s = _both(flat, lambda g: g.map_fusion_gba(0, 3, loop_kf=(3, 0)))
+    assert np.array_equal(r["kf_gba_flag"], s["kf_gba_flag"]) and np.array_equal(r["mp_gba_flag"], s["mp_gba_flag"])
+    assert np.array_equal(s["kf_Tcw"], flat["kf_Tcw"]) and np.array_equal(s["mp_pos"], flat["mp_pos"])
+    assert ulps32(r["kf_gba"], s["kf_gba"]).max() <= 64 and ulps32(r["mp_gba"], s["mp_gba"]).max() <= 256
+
+
+def test_pose_optimization_client_shim_equals_reference():
+    for n, seed, of in ((300, 0, 0.1), (40, 3, 0.3), (1000, 7, 0.2), (2, 1, 0.0)):
+        pp = synth.make_pose_problem(n, seed, of)
+        R = synth.R_from_quat(pp["cam_qt"][None, :4])[0]
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R.astype(np.float32); T[:3, 3] = pp["cam_qt"][4:].astype(np.float32)
+        octv = np.rint(-np.log(pp["info"]) / (2 * np.log(1.2))).astype(np.int32)
+        args = (T, pp["obs"].astype(np.float32), octv, pp["Xw"].astype(np.float32), np.asarray(pp["K"], np.float32))
+        Tr, outr, nr = mg.pose_optimization(mg.REF_LIB, *args)
+        Ts, outs, ns = mg.pose_optimization(mg.SHIM_LIB, *args)
+        assert nr == ns and np.array_equal(outr, outs)
+        assert ulps32(Tr, Ts).max() <= 2
+
+
+def test_orb_extractor_shim_equals_the_reference_translation_unit():
+    """cslam::ORBextractor::operator() of shim/ORBextractor_hip.cpp (MI355X) against the reference's ORBextractor.cpp (run with the monotonic
+    allocator that makes its pointer tie-break 'creation order'): keypoints, descriptors, mvImagePyramid and the accessor tables, bit for bit."""
+    shim = os.path.join(os.path.dirname(mg.SHIM_LIB), "liborb_hip_shim.so")
+    if not os.path.exists(shim):
+        pytest.skip("shim/liborb_hip_shim.so not built")
+    for seed, t, nf in ((1000, 0, 1000), (1002, 4, 2000)):
+        img = synth.gen_image(seed, t)
+        r = ref.RefOrb(nf)
+        s = ref.RefOrb(nf, lib_path=shim)
+        rk, rd = r.extract_cli(img)
+        sk, sd = s.extract(img)
+        assert len(rk) == len(sk)
+        for f in rk.dtype.names:
+            assert np.array_equal(rk[f], sk[f]), f
+        assert np.array_equal(rd, sd)
+        r.extract(img)
+        for l in range(8):
+            assert np.array_equal(r.level(l), s.level(l)), l
+        for a, b in zip(r.tables(), s.tables()):
+            assert np.array_equal(a, b)
