@@ -122,6 +122,7 @@ struct BaDev {
   const int* row_unit_off;   // [Cp+1] units of block row i
   const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
   int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
+  double* row_part;          // [n_units][kRowSlot] unit partial sums of the two-rows-per-CU shape of the row kernel (nullptr: not allocated)
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]
@@ -461,8 +462,13 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // of the row and every instance costs one 144-byte W_c row read plus LDS.                [CCM_K_BA_SCHUR_OFF]
 constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
 constexpr int kRowSlot = 42;        // doubles per work-unit partial: 6x6 block + 6 (b_schur part of the diagonal units)
-constexpr int kRowTPB = 1024;        // 8 waves walk the row's blocks: the instance stream is latency bound, so more streams win
-__global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
+constexpr int kRowTPB = 1024;        // 16 waves walk the row's blocks: the instance stream is latency bound, so more streams win
+// Two shapes of the same kernel.  <1024, false>: one 16-wave workgroup per CU, unit partial sums in LDS (rows of any length up to
+// kRowMaxEdges).  <512, true>: 8-wave workgroups with the unit partials in a global scratch (d.row_part, L2-resident: written and read back
+// by the same workgroup) so that LDS holds only Y and TWO rows fit a CU: while one row waits on the three dependent load levels of its Y
+// staging or on its final reduction, the other one computes — the kernel is bound by those per-row latencies, not by bytes or flops.
+template <int TPB, bool GPART>
+__global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
   // Workgroup b runs on XCD b % 8.  Every W_c row is read by ~3 block rows, and those are rows of covisible, i.e.
   // neighbouring, keyframes: with row = blockIdx the neighbours sit on 8 different L2s and each fetches its own copy
@@ -473,17 +479,17 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   if (i >= d.Cp) return;
   const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
   // up to 4 (observation, row) items per thread with their three dependent load levels in flight together
-  for (int t0 = threadIdx.x; t0 < ne * 6; t0 += 4 * kRowTPB) {
+  for (int t0 = threadIdx.x; t0 < ne * 6; t0 += 4 * TPB) {
     int e[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int t = t0 + q * kRowTPB; e[q] = (t < ne * 6) ? d.cam_edge[base + t / 6] : -1; }
+    for (int q = 0; q < 4; q++) { const int t = t0 + q * TPB; e[q] = (t < ne * 6) ? d.cam_edge[base + t / 6] : -1; }
     int pt[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) pt[q] = (e[q] >= 0) ? d.ed_pt[e[q]] : 0;
     double a[4][3], D[4][6];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int t = t0 + q * kRowTPB;
+      const int t = t0 + q * TPB;
       const double* Wa = d.W + 18 * (size_t)max(e[q], 0) + 3 * (t % 6);
       const double* Di = d.Dinv + 6 * (size_t)pt[q];
       a[q][0] = Wa[0]; a[q][1] = Wa[1]; a[q][2] = Wa[2];
@@ -492,14 +498,14 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int t = t0 + q * kRowTPB;
+      const int t = t0 + q * TPB;
       if (e[q] < 0) continue;
       Ys[t * 3 + 0] = a[q][0] * D[q][0] + a[q][1] * D[q][1] + a[q][2] * D[q][2];
       Ys[t * 3 + 1] = a[q][0] * D[q][1] + a[q][1] * D[q][3] + a[q][2] * D[q][4];
       Ys[t * 3 + 2] = a[q][0] * D[q][2] + a[q][1] * D[q][4] + a[q][2] * D[q][5];
     }
   }
-  if (threadIdx.x < 18) Ys[d.max_cam_edges * 18 + d.row_units_max * kRowSlot + threadIdx.x] = 0.0;   // a whole zero row of Y
+  if (threadIdx.x < 18) Ys[d.max_cam_edges * 18 + (GPART ? 0 : d.row_units_max * kRowSlot) + threadIdx.x] = 0.0;   // a whole zero row of Y
   __syncthreads();
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   // One wave per block.  S_ij = -[Y_a1 Y_a2 ...] [W_c1 W_c2 ...]^T is a 6 x 6 product with inner dimension 3 per pair
@@ -521,9 +527,9 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   const bool on = jj < 6 && kq < 3;
   const int woff = on ? 3 * jj + kq : 0;
   const unsigned wbyte = 8u * (unsigned)woff;
-  double* part = Ys + (size_t)d.max_cam_edges * 18;
-  const int zslot = d.max_cam_edges * 18 + d.row_units_max * kRowSlot;   // one zero behind the partial sums
   const int u_first = d.row_unit_off[i], u_last = d.row_unit_off[i + 1];
+  double* part = GPART ? d.row_part + kRowSlot * (size_t)u_first : Ys + (size_t)d.max_cam_edges * 18;
+  const int zslot = d.max_cam_edges * 18 + (GPART ? 0 : d.row_units_max * kRowSlot);   // one zero row behind Y (and the partial sums)
   // Software pipeline over the wave's units: the table entry and the two index vectors of the NEXT unit (two dependent
   // load levels) are requested before the W_c rows of the current one, so that a unit exposes one memory latency
   // instead of three (a CU holds one workgroup = 16 waves here: nothing else hides them).
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   };
   if (u < u_last) load_unit(u, n, ic, ia, il, ublk);
   while (u < u_last) {
-    const int un = u + kRowTPB / kWave;
+    const int un = u + TPB / kWave;
     int nn = 0, icn = 0, ian = 0, iln = 0, ublkn = 0;
     if (un < u_last) load_unit(un, nn, icn, ian, iln, ublkn);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(kRowTPB) void ba_schur_row(BaDev d) {
   __syncthreads();
   {
     const int grp = threadIdx.x / 36, el = threadIdx.x % 36;
-    constexpr int kGroups = kRowTPB / 36;
+    constexpr int kGroups = TPB / 36;
     if (grp < kGroups)
       for (int b = d.rowblk_off[i] + grp; b < d.rowblk_off[i + 1]; b += kGroups) {
         double sum = 0;
@@ -2280,6 +2286,13 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
         if (int rc = dev_upload(ba, row_u, &p_r)) return fail(rc);
         if (int rc = dev_upload(ba, blk_u, &p_b)) return fail(rc);
         d.unit_tab = p_t; d.row_unit_off = p_r; d.blk_unit0 = p_b; d.row_units_max = std::max(worst, 1);
+        // two rows per CU when Y of the longest row fits half of the LDS: the partial sums then live in a global scratch
+        d.row_part = nullptr;
+        if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && !getenv("CCM_BA_ROW_V1")) {
+          double* p_part = nullptr;
+          if (int rc = dev_alloc<double>(ba, (size_t)(tab.size() / 3) * 42, &p_part, false)) return fail(rc);
+          d.row_part = p_part;
+        }
       }
     }
     if (Cp) hipLaunchKernelGGL(ba_edge_rank, dim3(Cp), dim3(kTPB), 0, ctx->stream, d, p_rank);
@@ -2600,9 +2613,15 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
-        const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * kRowSlot + 18) * sizeof(double);
-        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row, 158 * 1024);
-        hipLaunchKernelGGL(ba_schur_row, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
+        if (d.row_part) {
+          const size_t lds_row = ((size_t)d.max_cam_edges * 18 + 18) * sizeof(double);
+          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW2, (ba_schur_row_t<512, true>), 80 * 1024);
+          hipLaunchKernelGGL((ba_schur_row_t<512, true>), dim3(8 * ccm_div_up(d.Cp, 8)), dim3(512), lds_row, ctx->stream, d);
+        } else {
+          const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * kRowSlot + 18) * sizeof(double);
+          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, (ba_schur_row_t<1024, false>), 158 * 1024);
+          hipLaunchKernelGGL((ba_schur_row_t<1024, false>), dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
+        }
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
@@ -2822,7 +2841,7 @@ static void pers_dbg_dump(ccm_ba* ba) {
 extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volatile unsigned char* stop_flag, ccm_ba_stats* stats) {
   if (!ba) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
-  if (ba->nranks > 1 && (!ctx->comm || ctx->comm_nranks != ba->nranks || ctx->comm_rank != ba->rank))
+  if (ba->nranks > 1 && ((!ctx->comm && !ctx->loop_group) || ctx->comm_nranks != ba->nranks || ctx->comm_rank != ba->rank))
     return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba_run: sharded problem needs a matching communicator (ccm_comm_init)");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ccm_ba_options opt{};

@@ -5,6 +5,9 @@
 #include <rccl/rccl.h>
 #include <cstring>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
 
 // CCM_FORCE_ALLREDUCE=1 issues the collectives even on a 1-rank communicator (a legal, degenerate all-reduce):
 // lets the single-GPU test box exercise the exact RCCL call sequence of the sharded global BA.
@@ -37,12 +40,80 @@ extern "C" int ccm_comm_init(ccm_ctx* ctx, int nranks, int rank, const uint8_t i
 extern "C" int ccm_comm_destroy(ccm_ctx* ctx) {
   if (!ctx) return CCM_E_ARG;
   if (ctx->comm) { ncclCommDestroy((ncclComm_t)ctx->comm); ctx->comm = nullptr; }
+  ctx->loop_group = nullptr;   // the group object belongs to the test (ccm_comm_loopback_destroy)
   ctx->comm_rank = 0; ctx->comm_nranks = 1;
+  return CCM_OK;
+}
+
+// ---- test-only loop-back communicator ------------------------------------------------------------------------------------------
+// A single-GPU box cannot host two RCCL ranks, so the multi-rank control flow of the sharded global BA (partition, lambda_0 max-reduce,
+// the per-trial all-reduces with their stop / give-up flags, the point gather at download) could never execute with nranks > 1 before the
+// driver's 8-GPU run.  This communicator makes the ranks THREADS of one process that share the device: an all-reduce is a rendezvous of
+// all ranks followed by ONE reduction kernel that adds the ranks' buffers in rank order and writes the identical result back to every
+// rank — the contract RCCL gives (same bits on every rank), minus the wires.  Same entry points, same call sequence in ba.hip.
+namespace {
+struct LoopGroup {
+  int nranks = 0;
+  std::mutex mu; std::condition_variable cv;
+  int arrived = 0; long generation = 0;
+  std::vector<double*> buf; std::vector<size_t> count;
+  int rc = CCM_OK;
+};
+__global__ void loop_reduce_kernel(double* const* bufs, int nranks, size_t n, int is_max) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = bufs[0][i];
+  for (int r = 1; r < nranks; r++) v = is_max ? fmax(v, bufs[r][i]) : v + bufs[r][i];
+  for (int r = 0; r < nranks; r++) bufs[r][i] = v;
+}
+int loop_allreduce(ccm_ctx* ctx, double* d_buf, size_t n, int is_max) {
+  LoopGroup* g = (LoopGroup*)ctx->loop_group;
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // this rank's contribution is complete
+  std::unique_lock<std::mutex> lk(g->mu);
+  const long gen = g->generation;
+  g->buf[ctx->comm_rank] = d_buf; g->count[ctx->comm_rank] = n;
+  if (++g->arrived == g->nranks) {                                 // the last rank to arrive reduces for everybody
+    g->rc = CCM_OK;
+    for (int r = 0; r < g->nranks; r++) if (g->count[r] != n) g->rc = CCM_E_COMM;   // mismatched collective: what would hang RCCL
+    if (g->rc == CCM_OK && n) {
+      double** d_ptrs = nullptr;
+      if (hipMalloc(&d_ptrs, sizeof(double*) * g->nranks) != hipSuccess ||
+          hipMemcpy(d_ptrs, g->buf.data(), sizeof(double*) * g->nranks, hipMemcpyHostToDevice) != hipSuccess) g->rc = CCM_E_HIP;
+      else {
+        hipLaunchKernelGGL(loop_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (double* const*)d_ptrs, g->nranks, n, is_max);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) g->rc = CCM_E_HIP;
+      }
+      if (d_ptrs) hipFree(d_ptrs);
+    }
+    g->arrived = 0; g->generation++;
+    g->cv.notify_all();
+  } else {
+    g->cv.wait(lk, [&] { return g->generation != gen; });
+  }
+  if (g->rc != CCM_OK) return ccm_set_error(ctx, g->rc, "loop-back all-reduce: ranks disagree on the collective (count mismatch) or a HIP call failed");
+  return CCM_OK;
+}
+}  // namespace
+
+extern "C" int ccm_comm_loopback_create(int nranks, void** group) {
+  if (!group || nranks < 1) return CCM_E_ARG;
+  LoopGroup* g = new LoopGroup();
+  g->nranks = nranks; g->buf.assign((size_t)nranks, nullptr); g->count.assign((size_t)nranks, 0);
+  *group = g;
+  return CCM_OK;
+}
+extern "C" void ccm_comm_loopback_destroy(void* group) { delete (LoopGroup*)group; }
+extern "C" int ccm_comm_init_loopback(ccm_ctx* ctx, void* group, int rank) {
+  LoopGroup* g = (LoopGroup*)group;
+  if (!ctx || !g || rank < 0 || rank >= g->nranks) return ccm_set_error(ctx, CCM_E_ARG, "ccm_comm_init_loopback: bad args");
+  if (ctx->comm || ctx->loop_group) return ccm_set_error(ctx, CCM_E_STATE, "ccm_comm_init_loopback: communicator already attached");
+  ctx->loop_group = g; ctx->comm_rank = rank; ctx->comm_nranks = g->nranks;
   return CCM_OK;
 }
 
 // in-place sum all-reduce of n doubles on the ctx stream
 int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
+  if (ctx->loop_group) return loop_allreduce(ctx, d_buf, n, 0);
   if (ctx->comm_nranks <= 1 && !(ctx->comm && force_collectives())) return CCM_OK;
   if (!ctx->comm) return ccm_set_error(ctx, CCM_E_STATE, "all-reduce requested but no communicator attached");
   ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, ctx->stream);
@@ -51,6 +122,7 @@ int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
 }
 
 int ccm_allreduce_max_f64(ccm_ctx* ctx, double* d_buf, size_t n) {
+  if (ctx->loop_group) return loop_allreduce(ctx, d_buf, n, 1);
   if (ctx->comm_nranks <= 1 && !(ctx->comm && force_collectives())) return CCM_OK;
   if (!ctx->comm) return ccm_set_error(ctx, CCM_E_STATE, "all-reduce requested but no communicator attached");
   ncclResult_t r = ncclAllReduce(d_buf, d_buf, n, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream);

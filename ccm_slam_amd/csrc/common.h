@@ -29,6 +29,7 @@ struct ccm_ctx {
   // RCCL communicator (opaque; ncclComm_t) for the sharded global BA
   void* comm = nullptr;
   int comm_rank = 0, comm_nranks = 1;
+  void* loop_group = nullptr;   // test-only in-process communicator (ccm_comm_init_loopback): ranks = threads sharing one GPU
   // reusable staging buffers
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_io = nullptr; size_t d_io_bytes = 0;   // staging for the host-pointer entry points
@@ -49,7 +50,7 @@ int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
                                __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
   } while (0)
 
-enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT };
+enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT };
 #define CCM_LDS_ATTR(ctx, bit, func, bytes)                                                                              \
   do {                                                                                                                   \
     if (!((ctx)->lds_attr_done & (1u << (bit)))) {                                                                       \

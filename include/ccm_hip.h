@@ -304,6 +304,12 @@ int  ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double*
 int ccm_comm_unique_id(uint8_t id_bytes[128]);
 int ccm_comm_init(ccm_ctx* ctx, int nranks, int rank, const uint8_t id_bytes[128]);
 int ccm_comm_destroy(ccm_ctx* ctx);
+/* TEST-ONLY in-process communicator: the ranks are threads of one process sharing one GPU, each with its own ccm_ctx; an all-reduce is
+ * a rendezvous plus one reduction kernel that leaves the same bits in every rank's buffer (RCCL's contract).  Lets a single-GPU box
+ * execute the complete multi-rank control flow of the sharded global BA (tests/test_sharded_loopback_gpu.py). */
+int  ccm_comm_loopback_create(int nranks, void** group);
+void ccm_comm_loopback_destroy(void* group);
+int  ccm_comm_init_loopback(ccm_ctx* ctx, void* group, int rank);
 
 /* motion-only pose optimisation: Optimizer::PoseOptimizationClient (Optimizer.cpp:215-347):
  * 4 rounds x 10 LM iterations on one SE3 vertex with unary EdgeSE3ProjectXYZOnlyPose edges,

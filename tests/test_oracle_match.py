@@ -145,7 +145,7 @@ def _normal_depth_case(seed, n_pt=5000, n_kf=120):
     rng = np.random.default_rng(seed)
     kf_center = (rng.normal(size=(n_kf, 3)) * np.array([8, 5, 1.5])).astype(np.float32)
     pos = (rng.normal(size=(n_pt, 3)) * np.array([10, 6, 2])).astype(np.float32)
-    k = np.clip(rng.poisson(6, n_pt), 0, 30)
+    k = np.clip(rng.poisson(6, n_pt), 0, min(30, n_kf))
     k[rng.random(n_pt) < 0.02] = 0                                  # observations.empty(): the point keeps its old values
     off = np.zeros(n_pt + 1, np.int32); off[1:] = np.cumsum(k)
     obs = np.concatenate([rng.permutation(n_kf)[:kk] for kk in k] + [np.zeros(0, np.int64)]).astype(np.int32)
