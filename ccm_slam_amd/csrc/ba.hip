@@ -2288,7 +2288,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
         d.unit_tab = p_t; d.row_unit_off = p_r; d.blk_unit0 = p_b; d.row_units_max = std::max(worst, 1);
         // two rows per CU when Y of the longest row fits half of the LDS: the partial sums then live in a global scratch
         d.row_part = nullptr;
-        if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && !getenv("CCM_BA_ROW_V1")) {
+        // measured on gba_c4 (r02e): 235 us against 228 us for the one-row shape — no gain: the row is bound by the serial chain of units per wave
+        // (index vectors -> W gathers -> 16 dependent MFMAs), which two resident rows do not shorten.  Kept behind CCM_BA_ROW_V2=1.
+        if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && getenv("CCM_BA_ROW_V2")) {
           double* p_part = nullptr;
           if (int rc = dev_alloc<double>(ba, (size_t)(tab.size() / 3) * 42, &p_part, false)) return fail(rc);
           d.row_part = p_part;
@@ -2626,7 +2628,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
     // ---- PCG ----
-    const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : 1e-8;
+    static const double tol_default = getenv("CCM_BA_PCG_TOL") ? atof(getenv("CCM_BA_PCG_TOL")) : 1e-8;   // experiments only; the parity tests run at 1e-8
+    const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : tol_default;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
     int flags[4] = {0, 0, 0, 0};
     if (d.Cp <= kSmallMaxCp) {
