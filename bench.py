@@ -34,6 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# 6.65 P + 1317 N + 16 N_cand bytes per frame at P = 1 117 367 pyramid pixels, N = 1000 keypoints, N_cand ~ 10 000 candidates
+ORB_BYTES_PER_FRAME = 6.65 * 1117367 + 1317 * 1000 + 16 * 10000
 
 
 def _best_of(fn, reps, batches=3):
@@ -92,6 +94,14 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
         kps, desc = ex(im)
     t_orb = (time.perf_counter() - t0) / n_frames
     T = len(kps)
+    # the batch figure SURVEY 8(d) asks for: 64 frames resident in HBM, results left in HBM, two frames in flight (ccm_orb_extract_batch_dev)
+    from ccm_slam_amd.orb import OrbBatchDev
+    bimgs = np.stack([synth.gen_image(1000, t) for t in range(64)])
+    bat = OrbBatchDev(ctx, ex, bimgs)
+    bat.run()
+    t_batch = _best_of(bat.run, 1, batches=3) / 64
+    n_batch_kps = int(bat.counts().sum())
+    bat.close()
     fg.set_keypoints(kps, desc)
     xy, _, _ = fg.get()
     def _frame():
@@ -134,6 +144,11 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
            "orb_fps_per_agent": round(1.0 / t_orb, 1), "frame_undistort_grid_ms": round(t_frame * 1e3, 4),
            "search_last_frame_ms": round(t_m2 * 1e3, 4), "frustum_cull_ms": round(t_fr * 1e3, 4),
            "search_local_points_ms": round(t_m1 * 1e3, 4), "pose_opt_ms": round(t_pose * 1e3, 4), "features": int(T),
+           "orb_batch64": {"ms_per_frame": round(t_batch * 1e3, 4), "fps": round(1.0 / t_batch, 1), "keypoints": n_batch_kps,
+                           "algorithmic_bytes_per_frame": ORB_BYTES_PER_FRAME, "achieved_GBps": round(ORB_BYTES_PER_FRAME / t_batch / 1e9, 2),
+                           "frac_of_hbm_peak": round(ORB_BYTES_PER_FRAME / t_batch / 1e9 / HBM_PEAK_GBS, 5),
+                           "note": "64 frames resident in HBM, outputs stay in HBM; the 9 MB working set lives in the 256 MB Infinity Cache, so this is "
+                                   "bound by the host's DistributeOctTree (~0.1 ms per frame, overlapped with the next frame's device phase), not by HBM"},
            "window_candidates": int(idx1.size),
            "note": "host-API timings (H2D/D2H included); every stage bit-exact vs the oracle (tests/test_orb_gpu.py, test_frame_gpu.py, "
                    "test_hamming_gpu.py), pose optimisation within 1e-7"}

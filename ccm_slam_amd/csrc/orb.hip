@@ -485,33 +485,45 @@ struct ccm_orb {
   int w = 0, h = 0;
   OrbDev dev{};
   size_t pyr_bytes = 0;
-  uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+  // everything one frame in flight owns.  Two sets: the single-frame entry points use set 0; ccm_orb_extract_batch_dev alternates, so
+  // that frame t+1's device phase 1 runs while the host selects keypoints (DistributeOctTree) for frame t.
+  struct Bufs {
+    uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+    uint32_t* d_cell_slots = nullptr; int* d_cell_counts = nullptr; int* d_cand = nullptr;   // d_cand: [ncells+1 offsets][records]
+    KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr;
+    int* h_cand = nullptr;   // pinned
+    KpIn* h_kin = nullptr;   // pinned
+    int* h_count = nullptr;  // pinned: keypoint count of the frame (batch API)
+    hipEvent_t ev_cand = nullptr;
+  } B[2];
+  int cur = 0;
   int16_t* d_tabs = nullptr; std::vector<int> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // per level offsets into d_tabs
-  uint32_t* d_cell_slots = nullptr; int* d_cell_counts = nullptr; int* d_cand = nullptr;   // d_cand: [ncells+1 offsets][records]
   int cand_cap = 0;
   int* d_tile_level = nullptr; int* d_tile_xy = nullptr; int n_blur_tiles = 0;
-  KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr; int kp_cap = 0;
-  int* h_cand = nullptr;   // pinned
-  KpIn* h_kin = nullptr;   // pinned
+  int kp_cap = 0;
   uint8_t* h_io = nullptr;  // pinned: the input image on the way in, [keypoints | descriptors] on the way out (one DMA each)
   size_t h_io_bytes = 0;
-  hipEvent_t ev_cand = nullptr;
   double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
   Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand;
 };
 
+static void orb_free_bufs(ccm_orb::Bufs& b) {
+  hipFree(b.d_pyr); hipFree(b.d_score); hipFree(b.d_blur); hipFree(b.d_cell_slots); hipFree(b.d_cell_counts); hipFree(b.d_cand);
+  hipFree(b.d_kin); hipFree(b.d_kout);   // d_desc is part of d_kout's block
+  if (b.h_cand) hipHostFree(b.h_cand);
+  if (b.h_kin) hipHostFree(b.h_kin);
+  if (b.h_count) hipHostFree(b.h_count);
+  hipEvent_t ev = b.ev_cand;
+  b = ccm_orb::Bufs();
+  b.ev_cand = ev;   // events do not depend on the geometry
+}
 static void orb_free_geometry(ccm_orb* o) {
-  hipFree(o->d_pyr); hipFree(o->d_score); hipFree(o->d_blur); hipFree(o->d_tabs); hipFree(o->d_cell_slots);
-  hipFree(o->d_cell_counts); hipFree(o->d_cand); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
-  hipFree(o->d_kin); hipFree(o->d_kout);   // d_desc is part of d_kout's block
-  if (o->h_cand) hipHostFree(o->h_cand);
-  if (o->h_kin) hipHostFree(o->h_kin);
+  orb_free_bufs(o->B[0]); orb_free_bufs(o->B[1]);
+  hipFree(o->d_tabs); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
   if (o->h_io) hipHostFree(o->h_io);
-  o->d_pyr = o->d_score = o->d_blur = nullptr; o->d_tabs = nullptr; o->d_cell_slots = nullptr; o->d_cell_counts = nullptr;
-  o->d_cand = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->d_kin = nullptr; o->d_kout = nullptr; o->d_desc = nullptr;
-  o->h_cand = nullptr; o->h_kin = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
+  o->d_tabs = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
 }
 
 extern "C" int ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
@@ -539,7 +551,8 @@ extern "C" int ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, i
   }
   hipSetDevice(ctx->device);
   hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kOrbPattern31, 1024);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev_cand, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&o->B[0].ev_cand, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&o->B[1].ev_cand, hipEventDisableTiming);
   if (e != hipSuccess) { delete o; return ccm_set_error(ctx, CCM_E_HIP, std::string("orb: pattern upload: ") + hipGetErrorString(e)); }
   *out = o;
   return CCM_OK;
@@ -549,7 +562,7 @@ extern "C" void ccm_orb_destroy(ccm_orb* o) {
   if (!o) return;
   if (o->ctx) { hipSetDevice(o->ctx->device); hipStreamSynchronize(o->ctx->stream); }
   orb_free_geometry(o);
-  if (o->ev_cand) hipEventDestroy(o->ev_cand);
+  for (int k = 0; k < 2; k++) if (o->B[k].ev_cand) hipEventDestroy(o->B[k].ev_cand);
   delete o;
 }
 
@@ -572,10 +585,39 @@ extern "C" int ccm_orb_level_size(const ccm_orb* o, int w, int h, int level, int
 }
 extern "C" int ccm_orb_max_keypoints(const ccm_orb* o) { return o ? o->nfeatures + 3 * o->nlevels + 8 : 0; }
 
+// the buffers one frame in flight owns (set k); geometry (pyr_bytes, cand_cap, kp_cap, ncells) must be known
+static int orb_alloc_bufs(ccm_orb* o, int k) {
+  ccm_ctx* ctx = o->ctx;
+  ccm_orb::Bufs& b = o->B[k];
+  if (b.d_pyr) return CCM_OK;
+  const OrbDev& d = o->dev;
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_pyr, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_score, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_blur, o->pyr_bytes));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_pyr, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_score, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_blur, 0, o->pyr_bytes, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_slots, (size_t)o->cand_cap * sizeof(uint32_t)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_counts, (size_t)d.ncells * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
+  {   // keypoints and descriptors in one block [kout | desc] so that the results leave with one copy
+    uint8_t* blk = nullptr;
+    const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
+    CCM_HIP_CHECK(ctx, hipMalloc(&blk, o_d + (size_t)o->kp_cap * 32 + 256));
+    b.d_kout = reinterpret_cast<ccm_keypoint*>(blk);
+    b.d_desc = blk + o_d;
+  }
+  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int), hipHostMallocDefault));
+  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_kin, (size_t)o->kp_cap * sizeof(KpIn), hipHostMallocDefault));
+  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_count, 64, hipHostMallocDefault));
+  return CCM_OK;
+}
+
 // (re)build everything that depends on the image size
 static int orb_prepare(ccm_orb* o, int w, int h) {
   ccm_ctx* ctx = o->ctx;
-  if (o->w == w && o->h == h && o->d_pyr) return CCM_OK;
+  if (o->w == w && o->h == h && o->B[0].d_pyr) return CCM_OK;
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   orb_free_geometry(o);
   OrbDev& d = o->dev;
@@ -634,33 +676,19 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   o->n_blur_tiles = (int)tile_level.size();
   o->cand_cap = d.ncells * kCellCap;
   o->kp_cap = ccm_orb_max_keypoints(o);
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_pyr, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_score, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_blur, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_pyr, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_score, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_blur, 0, o->pyr_bytes, ctx->stream));
+  o->cur = 0;
+  if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cell_slots, (size_t)o->cand_cap * sizeof(uint32_t)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cell_counts, (size_t)d.ncells * sizeof(int)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_level, tile_level.size() * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_xy, tile_xy.size() * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_level, tile_level.data(), tile_level.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_xy, tile_xy.data(), tile_xy.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
-  {   // keypoints and descriptors in one block [kout | desc] so that the results leave with one copy
-    uint8_t* blk = nullptr;
+  {
     const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
-    CCM_HIP_CHECK(ctx, hipMalloc(&blk, o_d + (size_t)o->kp_cap * 32 + 256));
-    o->d_kout = reinterpret_cast<ccm_keypoint*>(blk);
-    o->d_desc = blk + o_d;
     o->h_io_bytes = std::max((size_t)w * h, o_d + (size_t)o->kp_cap * 32) + 256;
     CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_io, o->h_io_bytes, hipHostMallocDefault));
   }
-  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int), hipHostMallocDefault));
-  CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&o->h_kin, (size_t)o->kp_cap * sizeof(KpIn), hipHostMallocDefault));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   o->w = w; o->h = h;
   return CCM_OK;
@@ -673,26 +701,26 @@ static int orb_phase1(ccm_orb* o) {
   for (int l = 1; l < o->nlevels; l++) {
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE);
-    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, ctx->stream, o->d_pyr + P.off, P.w, P.h, P.stride,
-                       o->d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
+    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, ctx->stream, o->B[o->cur].d_pyr + P.off, P.w, P.h, P.stride,
+                       o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
-    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, ctx->stream, d, o->d_pyr, o->d_score);
+    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
-    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d, o->d_score, o->iniTh, o->minTh, o->d_cell_slots, o->d_cell_counts);
-    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d.ncells, o->d_cell_slots, o->d_cell_counts, o->d_cand,
-                       (uint32_t*)(o->d_cand + d.ncells + 1));
+    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
+    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
+                       (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
   }
   const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_cand, o->d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_cand, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand, o->B[o->cur].d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_BLUR);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, ctx->stream, d, o->d_pyr, o->d_blur, o->d_tile_level, o->d_tile_xy);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -705,17 +733,17 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
   // wait for the candidate copy only (the blur kernel queued behind it keeps running)
   {
     const double w0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    CCM_HIP_CHECK(ctx, hipEventSynchronize(o->ev_cand));
+    CCM_HIP_CHECK(ctx, hipEventSynchronize(o->B[o->cur].ev_cand));
     o->t_wait_cand = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - w0;
   }
-  const int* offs = o->h_cand;
+  const int* offs = o->B[o->cur].h_cand;
   const int total = offs[d.ncells];
   if (total > kCandFirstCopy) {
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_cand + d.ncells + 1 + kCandFirstCopy, o->d_cand + d.ncells + 1 + kCandFirstCopy,
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand + d.ncells + 1 + kCandFirstCopy, o->B[o->cur].d_cand + d.ncells + 1 + kCandFirstCopy,
                                       (size_t)(total - kCandFirstCopy) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
-  const uint32_t* rec = (const uint32_t*)(o->h_cand + d.ncells + 1);
+  const uint32_t* rec = (const uint32_t*)(o->B[o->cur].h_cand + d.ncells + 1);
   o->last_cand.resize(o->nlevels);
   int n = 0;
   for (int l = 0; l < o->nlevels; l++) {
@@ -733,7 +761,7 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
     distribute_octree(o->tree_ws, cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
     for (int id : sel) {
       if (n >= o->kp_cap) break;
-      o->h_kin[n++] = KpIn{(int16_t)((int)cand[id].x + minB), (int16_t)((int)cand[id].y + minB), (int16_t)l, (int16_t)cand[id].response};
+      o->B[o->cur].h_kin[n++] = KpIn{(int16_t)((int)cand[id].x + minB), (int16_t)((int)cand[id].y + minB), (int16_t)l, (int16_t)cand[id].response};
     }
   }
   *n_out = n;
@@ -743,10 +771,10 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
 static int orb_phase2(ccm_orb* o, int n) {
   ccm_ctx* ctx = o->ctx;
   if (n == 0) return CCM_OK;
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_kin, o->h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].d_kin, o->B[o->cur].h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->d_pyr, o->d_blur, o->d_kin, n, o->d_kout, o->d_desc);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, o->B[o->cur].d_kout, o->B[o->cur].d_desc);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -764,7 +792,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   const double t0 = now();
   // the image goes through the pinned block (packed rows): a pageable source makes the runtime stage and wait
   for (int y = 0; y < h; y++) memcpy(o->h_io + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
-  CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, o->h_io, w, w, h, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->B[o->cur].d_pyr + L0.off, L0.stride, o->h_io, w, w, h, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = orb_phase1(o))) return rc;
   const double t1 = now();
   int n = 0;
@@ -775,12 +803,12 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   const int nc = std::min(n, cap);
   const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
   // (the image upload from h_io completed before the host octree ran: the candidate read-back waited behind it)
-  if (nc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, o->d_kout, o_d + (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (nc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, o->B[o->cur].d_kout, o_d + (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
   if (pyramid_out)
     for (int l = 0; l < o->nlevels; l++)
       if (pyramid_out[l]) {
         const LevelInfo& L = o->dev.lv[l];
-        CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, o->d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+        CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, o->B[o->cur].d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
       }
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (nc) { memcpy(kps, o->h_io, (size_t)nc * sizeof(ccm_keypoint)); memcpy(desc, o->h_io + o_d, (size_t)nc * 32); }
@@ -803,30 +831,44 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
+  if ((rc = orb_alloc_bufs(o, 1))) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
-  for (int f = 0; f < n_frames; f++) {
-    CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, ctx->stream));
-    if ((rc = orb_phase1(o))) return rc;
-    int n = 0;
-    if ((rc = orb_host_select(o, &n))) return rc;
-    if ((rc = orb_phase2(o, n))) return rc;
-    const int nc = std::min(n, cap);
-    if (nc) {
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_kps + (size_t)f * cap, o->d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToDevice, ctx->stream));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc + (size_t)f * cap * 32, o->d_desc, (size_t)nc * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  // Two frames in flight on ONE in-order stream: iteration f queues the device phase 1 of frame f (into buffer set f & 1), then finishes
+  // frame f - 1: the host waits only for ITS candidate list, selects keypoints (DistributeOctTree, ~0.1 ms) while the GPU is busy with
+  // frame f, and queues phase 2 + the device-to-device copies of the results.  Stream order alone keeps the two sets apart: phase 2 of
+  // frame f - 2 (the last reader of set f & 1) was queued before phase 1 of frame f.
+  for (int f = 0; f <= n_frames; f++) {
+    if (f < n_frames) {
+      o->cur = f & 1;
+      CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->B[o->cur].d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, ctx->stream));
+      if ((rc = orb_phase1(o))) { o->cur = 0; return rc; }
     }
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_counts + f, &nc, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // nc lives on this stack frame
+    if (f >= 1) {
+      const int g = f - 1;
+      o->cur = g & 1;
+      int n = 0;
+      if ((rc = orb_host_select(o, &n))) { o->cur = 0; return rc; }
+      if ((rc = orb_phase2(o, n))) { o->cur = 0; return rc; }
+      const int nc = std::min(n, cap);
+      if (nc) {
+        CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_kps + (size_t)g * cap, o->B[o->cur].d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToDevice, ctx->stream));
+        CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc + (size_t)g * cap * 32, o->B[o->cur].d_desc, (size_t)nc * 32, hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      *o->B[o->cur].h_count = nc;   // pinned; rewritten two frames later, after this copy has long run (the host waits for frame g + 2's candidates first)
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_counts + g, o->B[o->cur].h_count, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
   }
+  o->cur = 0;
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;
 }
 
 extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uint8_t* blur_out) {
-  if (!o || !o->d_pyr || level < 0 || level >= o->nlevels) return CCM_E_ARG;
+  if (!o || !o->B[o->cur].d_pyr || level < 0 || level >= o->nlevels) return CCM_E_ARG;
   ccm_ctx* ctx = o->ctx;
   const LevelInfo& L = o->dev.lv[level];
-  if (score_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
-  if (blur_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(blur_out, L.w, o->d_blur + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  if (score_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->B[o->cur].d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  if (blur_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(blur_out, L.w, o->B[o->cur].d_blur + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;
 }

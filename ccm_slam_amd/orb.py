@@ -119,6 +119,15 @@ class OrbBatchDev:
         self.ctx.d2h(out, self.d_counts)
         return out
 
+    def results(self):
+        """[(keypoints, descriptors)] of every frame, downloaded"""
+        cnt = self.counts()
+        kps = np.zeros(self.n * self.ex.cap, KP_DTYPE)
+        desc = np.zeros((self.n * self.ex.cap, 32), np.uint8)
+        self.ctx.d2h(kps, self.d_kps)
+        self.ctx.d2h(desc, self.d_desc)
+        return [(kps[f * self.ex.cap:f * self.ex.cap + cnt[f]].copy(), desc[f * self.ex.cap:f * self.ex.cap + cnt[f]].copy()) for f in range(self.n)]
+
     def close(self):
         for p in (self.d_imgs, self.d_kps, self.d_desc, self.d_counts):
             self.ctx.free(p)

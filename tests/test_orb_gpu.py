@@ -84,3 +84,26 @@ def test_repeatable(ctx):
     k2, d2 = ex(img)
     assert np.array_equal(d1, d2) and np.array_equal(k1, k2)
     ex.close()
+
+
+def test_batch_of_frames_in_hbm_equals_frame_by_frame_extraction(ctx, oracle_lib):
+    """ccm_orb_extract_batch_dev keeps two frames in flight (frame t+1's device phase 1 overlaps the host keypoint selection of frame t) on two
+    buffer sets; every frame's keypoints and descriptors must be what the single-frame entry point (and therefore the oracle) gives."""
+    from ccm_slam_amd.orb import OrbBatchDev
+    ex = orb.ORBextractor(ctx, 1000)
+    imgs = np.stack([synth.gen_image(1000 + (t % 3), t) for t in range(9)])
+    bat = OrbBatchDev(ctx, ex, imgs)
+    bat.run()
+    res = bat.results()
+    bat.run()                                   # a second pass over the same buffers
+    res2 = bat.results()
+    bat.close()
+    for t in range(9):
+        kps, desc = ex(imgs[t])
+        for got in (res[t], res2[t]):
+            assert len(got[0]) == len(kps) and np.array_equal(got[1], desc)
+            for f in kps.dtype.names:
+                assert np.array_equal(got[0][f], kps[f]), (t, f)
+    ok, od = oracle_lib.OrbOracle(1000).extract(imgs[4])
+    assert np.array_equal(res[4][1], od) and np.array_equal(res[4][0]["x"], ok["x"])
+    ex.close()
