@@ -90,6 +90,34 @@ class MapGraph:
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         return fn(self.h, client_id, iterations, None, int(robust))
 
+    def optimize_sim3(self, kf1: int, kf2: int, match_mp, sim3, th2: float = 10.0, fix_scale: bool = False):
+        """cslam::Optimizer::OptimizeSim3.  Returns (sim3[8], keep flags per keypoint of kf1, nIn)."""
+        match_mp = np.ascontiguousarray(match_mp, np.int32)
+        s8 = np.ascontiguousarray(sim3, np.float64).copy()
+        keep = np.zeros(max(match_mp.size, 1), np.uint8)
+        fn = self.lib.mapg_optimize_sim3
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        nin = fn(self.h, kf1, kf2, _p(match_mp), _p(s8), float(th2), int(fix_scale), _p(keep))
+        return s8, keep[:match_mp.size], nin
+
+    def essential_graph(self, loop_kf: int, cur_kf: int, corrected=(), noncorrected=(), connections=(), loop_edges=(), fix_scale=False, map_fusion=False) -> int:
+        """OptimizeEssentialGraphLoopClosure (map_fusion=False) / OptimizeEssentialGraphMapFusion.  corrected / noncorrected: [(kf index, sim3[8])];
+        connections / loop_edges: [(kf a, kf b)]."""
+        def unpack(lst):
+            idx = np.array([k for k, _ in lst], np.int32)
+            s8 = np.array([s for _, s in lst], np.float64).reshape(-1, 8)
+            return idx, np.ascontiguousarray(s8)
+        ck, cs = unpack(corrected); nk, ns = unpack(noncorrected)
+        ca = np.array([a for a, _ in connections], np.int32); cb = np.array([b for _, b in connections], np.int32)
+        la = np.array([a for a, _ in loop_edges], np.int32); lb = np.array([b for _, b in loop_edges], np.int32)
+        fn = self.lib.mapg_essential_graph
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                       C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        return fn(self.h, int(map_fusion), loop_kf, cur_kf, ck.size, _p(ck), _p(cs), nk.size, _p(nk), _p(ns), ca.size, _p(ca), _p(cb), la.size, _p(la), _p(lb),
+                  int(fix_scale))
+
     def state(self) -> dict:
         f = self.flat
         nk, nm, no = f["n_kf"], f["n_mp"], int(f["obs_mp"].size)

@@ -185,6 +185,49 @@ int mapg_pose_optimization(float* Tcw, int n, const float* kp_xy, const int32_t*
   return nin;
 }
 
+namespace {
+g2o::Sim3 sim3_of(const double* p) { return g2o::Sim3(Eigen::Quaterniond(p[3], p[0], p[1], p[2]), Eigen::Vector3d(p[4], p[5], p[6]), p[7]); }
+void sim3_out(const g2o::Sim3& S, double* p) {
+  p[0] = S.rotation().x(); p[1] = S.rotation().y(); p[2] = S.rotation().z(); p[3] = S.rotation().w();
+  p[4] = S.translation()[0]; p[5] = S.translation()[1]; p[6] = S.translation()[2]; p[7] = S.scale();
+}
+}  // namespace
+
+// cslam::Optimizer::OptimizeSim3(pKF1, pKF2, vpMatches1, g2oS12, th2, bFixScale)   (Optimizer.h:97-98).  match_mp[i] = index of the map point of
+// keyframe 2 matched to keypoint i of keyframe 1 (-1: none); returns nIn, keep[i] = 0 where the call nulled vpMatches1[i]
+int mapg_optimize_sim3(void* h, int kf1, int kf2, const int32_t* match_mp, double* s8, float th2, int fix_scale, uint8_t* keep) {
+  MapG* g = (MapG*)h;
+  std::vector<mpptr> vpMatches1((size_t)g->kfs[kf1]->N);
+  for (int i = 0; i < g->kfs[kf1]->N; i++) vpMatches1[i] = match_mp[i] >= 0 ? g->mps[match_mp[i]] : mpptr();
+  g2o::Sim3 S = sim3_of(s8);
+  int nin = -1;
+  try { nin = cslam::Optimizer::OptimizeSim3(g->kfs[kf1], g->kfs[kf2], vpMatches1, S, th2, fix_scale != 0); } catch (std::exception&) { return -1; }
+  sim3_out(S, s8);
+  for (int i = 0; i < g->kfs[kf1]->N; i++) keep[i] = vpMatches1[i] ? 1 : 0;
+  return nin;
+}
+
+// cslam::Optimizer::OptimizeEssentialGraphLoopClosure / OptimizeEssentialGraphMapFusion   (Optimizer.h:101-110).  corrected / noncorrected: lists
+// of (keyframe index, Sim3 as 8 doubles); loop connections: pairs (keyframe a -> keyframe b); loop edges of the spanning structure are set on the
+// keyframes beforehand (loop_edge pairs, symmetric).  map_fusion != 0 selects the MapFusion variant (which takes no Sim3 maps).
+int mapg_essential_graph(void* h, int map_fusion, int loop_kf, int cur_kf, int n_corr, const int32_t* corr_kf, const double* corr_s8, int n_non,
+                         const int32_t* non_kf, const double* non_s8, int n_conn, const int32_t* conn_a, const int32_t* conn_b, int n_le, const int32_t* le_a,
+                         const int32_t* le_b, int fix_scale) {
+  MapG* g = (MapG*)h;
+  cslam::Optimizer::KeyFrameAndPose Corrected, NonCorrected;
+  for (int i = 0; i < n_corr; i++) Corrected[g->kfs[corr_kf[i]]] = sim3_of(corr_s8 + 8 * (size_t)i);
+  for (int i = 0; i < n_non; i++) NonCorrected[g->kfs[non_kf[i]]] = sim3_of(non_s8 + 8 * (size_t)i);
+  std::map<kfptr, std::set<kfptr> > LoopConnections;
+  for (int i = 0; i < n_conn; i++) LoopConnections[g->kfs[conn_a[i]]].insert(g->kfs[conn_b[i]]);
+  for (int i = 0; i < n_le; i++) { g->kfs[le_a[i]]->mspLoopEdges.insert(g->kfs[le_b[i]]); g->kfs[le_b[i]]->mspLoopEdges.insert(g->kfs[le_a[i]]); }
+  const bool bFixScale = fix_scale != 0;
+  try {
+    if (map_fusion) cslam::Optimizer::OptimizeEssentialGraphMapFusion(g->map, g->kfs[loop_kf], g->kfs[cur_kf], LoopConnections, bFixScale);
+    else cslam::Optimizer::OptimizeEssentialGraphLoopClosure(g->map, g->kfs[loop_kf], g->kfs[cur_kf], NonCorrected, Corrected, LoopConnections, bFixScale);
+  } catch (std::exception&) { return -1; }
+  return 0;
+}
+
 // cslam::Converter (Converter.cc:40-119) on plain arrays — pins ccm_slam_amd/host/ccm_convert.h and the oracle's converters
 void mapg_to_se3quat(const float* Tcw, double* qt7) {
   const g2o::SE3Quat T = cslam::Converter::toSE3Quat(mat44(Tcw));

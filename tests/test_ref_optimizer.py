@@ -183,3 +183,20 @@ def test_pose_optimization_of_the_reference_vs_oracle():
                                           IS2[octv].astype(np.float64), pp["K"])
         assert nin == on and np.array_equal(outl, oo)
         assert ulps32(oracle.se3quat_to_cvmat(oc)[0], Tr).max() <= 2
+
+
+def test_essential_graph_and_sim3_of_the_reference_run_through_the_harness():
+    """OptimizeEssentialGraphLoopClosure and OptimizeSim3 of the reference's Optimizer.cpp through the class API (the comparison with the shim needs
+    the MI355X: tests/test_shim_gpu.py): a loop closure with corrected Sim3s for the last keyframes pulls the trajectory, the fixed loop keyframe
+    keeps its pose up to the Sim3 -> SE3 f32 round trip."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=60, n_points=4000, seed=33, n_fixed=1)
+    flat = mg.flat_from_ba_problem(prob)
+    T = flat["kf_Tcw"]
+    sim3 = lambda k: np.concatenate([oracle.to_se3quat(T[k])[0], [1.0]])
+    corrected = [(k, sim3(k) + np.r_[np.zeros(4), [0.01 * (k - 54), 0, 0], [0.0]]) for k in range(55, 60)]
+    g = mg.MapGraph(mg.REF_LIB, flat)
+    assert g.essential_graph(0, 59, corrected, [(k, sim3(k)) for k in range(55, 60)], [(59, 0)], []) == 0
+    s = g.state(); g.close()
+    moved = np.abs(s["kf_Tcw"] - T).reshape(60, -1).max(1)
+    assert moved[0] < 1e-6 and moved[59] > 1e-3 and moved[30] > 1e-5
+    assert np.isfinite(s["mp_pos"]).all() and np.abs(s["mp_pos"] - flat["mp_pos"]).max() > 1e-4

@@ -101,3 +101,69 @@ def test_orb_extractor_shim_equals_the_reference_translation_unit():
             assert np.array_equal(r.level(l), s.level(l)), l
         for a, b in zip(r.tables(), s.tables()):
             assert np.array_equal(a, b)
+
+
+def _loop_map():
+    """one agent driving a closed loop; the keyframes near the end of the loop see landmarks of the start (loop closure candidates)"""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=60, n_points=4000, seed=33, n_fixed=1)
+    return prob, mg.flat_from_ba_problem(prob)
+
+
+def _sim3_of_pose(T, s=1.0):
+    from oracle import to_se3quat
+    q = to_se3quat(T)[0]
+    return np.concatenate([q, [s]])
+
+
+def test_optimize_sim3_shim_equals_reference():
+    prob, flat = _loop_map()
+    kf1, kf2 = 20, 22
+    seen2 = set(flat["obs_mp"][flat["obs_kf"] == kf2].tolist())
+    n1 = int(flat["kp_off"][kf1 + 1] - flat["kp_off"][kf1])
+    match = np.full(n1, -1, np.int32)
+    sel = np.where(flat["obs_kf"] == kf1)[0]
+    for o in sel:
+        if int(flat["obs_mp"][o]) in seen2:
+            match[flat["obs_kp"][o]] = flat["obs_mp"][o]
+    assert (match >= 0).sum() >= 40
+    T1, T2 = flat["kf_Tcw"][kf1].astype(np.float64), flat["kf_Tcw"][kf2].astype(np.float64)
+    T12 = T1 @ np.linalg.inv(T2)
+    T12[:3, 3] += [0.02, -0.01, 0.015]                                   # a Sim3Solver-grade initial guess
+    s0 = _sim3_of_pose(T12.astype(np.float32), 1.03)
+    for fix in (False, True):
+        out = []
+        for lib in (mg.REF_LIB, mg.SHIM_LIB):
+            g = mg.MapGraph(lib, flat)
+            out.append(g.optimize_sim3(kf1, kf2, match, s0, th2=10.0, fix_scale=fix))
+            g.close()
+        (sr, kr, nr), (ss, ks, ns) = out
+        assert nr == ns and nr >= 10 and np.array_equal(kr, ks)
+        assert np.abs(sr - ss).max() < 1e-5
+        if fix:
+            assert ss[7] == s0[7]
+
+
+@pytest.mark.parametrize("map_fusion", [False, True])
+def test_essential_graph_optimisation_shim_equals_reference(map_fusion):
+    """OptimizeEssentialGraphLoopClosure / MapFusion: the shim builds the same edge set (loop connections, spanning tree, loop edges, covisibility
+    above the threshold), the device solves the pose graph, the write-back moves keyframes and map points like the reference's."""
+    prob, flat = _loop_map()
+    T = flat["kf_Tcw"]
+    cur, loop = 59, 0
+    corrected = [(k, _sim3_of_pose(T[k]) + np.r_[np.zeros(4), [0.01 * (k - 54), -0.004 * (k - 54), 0.002], [0.0]] * np.r_[np.ones(7), [0]] + np.r_[np.zeros(7), [0.01]])
+                 for k in range(55, 60)]
+    noncorrected = [(k, _sim3_of_pose(T[k])) for k in range(55, 60)]
+    connections = [(59, 0), (59, 1), (58, 0), (57, 2)]
+    loop_edges = [(30, 10)]
+    out = []
+    for lib in (mg.REF_LIB, mg.SHIM_LIB):
+        g = mg.MapGraph(lib, flat)
+        assert g.essential_graph(loop, cur, corrected if not map_fusion else (), noncorrected if not map_fusion else (), connections, loop_edges,
+                                 fix_scale=False, map_fusion=map_fusion) == 0
+        out.append(g.state())
+        g.close()
+    r, s = out
+    assert np.abs(r["kf_Tcw"] - flat["kf_Tcw"]).max() > 1e-4 or map_fusion          # the loop-closure variant really moved the keyframes
+    assert np.abs(r["kf_Tcw"] - s["kf_Tcw"]).max() < 2e-4, np.abs(r["kf_Tcw"] - s["kf_Tcw"]).max()
+    assert np.abs(r["mp_pos"] - s["mp_pos"]).max() < 1e-3, np.abs(r["mp_pos"] - s["mp_pos"]).max()
+    assert np.array_equal(r["kf_Tcw"][loop], s["kf_Tcw"][loop])
