@@ -4,8 +4,11 @@
 // stored in this repository.
 #include <cslam/MapPoint.h>
 #include <cslam/KeyFrame.h>
+#include <cslam/Frame.h>
 using namespace std;
 namespace cslam {
 typedef boost::shared_ptr<KeyFrame> kfptr;
+typedef boost::shared_ptr<Frame> frameptr;
 #include "MapPoint_779_823.inc"
+#include "MapPoint_837_869.inc"   // PredictScale(dist, kfptr) and PredictScale(dist, frameptr)
 }  // namespace cslam

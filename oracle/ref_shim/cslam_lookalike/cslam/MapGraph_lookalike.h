@@ -23,6 +23,11 @@
 #include <cslam/config.h>
 #include <cslam/estd.h>
 #include <cslam/Datatypes.h>
+#include <thirdparty/DBoW2/DBoW2/BowVector.h>      // the reference's vendored DBoW2 headers (header-only value types)
+#include <thirdparty/DBoW2/DBoW2/FeatureVector.h>
+
+#define FRAME_GRID_ROWS 48   // Frame.h:51-52
+#define FRAME_GRID_COLS 75
 
 namespace cslam {
 using namespace estd;
@@ -69,6 +74,21 @@ class KeyFrame : public boost::enable_shared_from_this<KeyFrame> {
   std::vector<mpptr> mvpMapPoints;
   std::vector<mpptr> GetMapPointMatches() { return mvpMapPoints; }
   void EraseMapPointMatch(mpptr pMP, bool bLock = false);
+  mpptr GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }                                                   // KeyFrame.cpp:617-621
+  std::set<mpptr> GetMapPoints();                                                                                         // :592-609
+  void AddMapPoint(mpptr pMP, const size_t& idx, bool bLock = false) { (void)bLock; mvpMapPoints[idx] = pMP; }         // :478-498
+  void RemapMapPointMatch(mpptr pMP, const size_t& idx_now, const size_t& idx_new) { mvpMapPoints[idx_now] = nullptr; mvpMapPoints[idx_new] = pMP; }
+  // what the matcher reads besides the above (KeyFrame.h:287-345): descriptors, BoW feature vector, image bounds, the grid
+  std::vector<cv::KeyPoint> mvKeys;
+  cv::Mat mDescriptors;
+  DBoW2::BowVector mBowVec;
+  DBoW2::FeatureVector mFeatVec;
+  int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
+  float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+  std::vector<std::vector<std::vector<size_t> > > mGrid;
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r) const;   // body = KeyFrame.cpp:1162-1201 (ref_frame_excerpt.cpp)
+  bool IsInImage(const float& x, const float& y) const;                                         // body = KeyFrame.cpp:1203-1206
   // covisibility graph / spanning tree / loop edges, as plain containers filled by the harness
   std::vector<kfptr> mvpOrderedConnectedKeyFrames;
   std::vector<int> mvOrderedWeights;
@@ -110,6 +130,22 @@ class MapPoint : public boost::enable_shared_from_this<MapPoint> {
   int GetIndexInKeyFrame(kfptr pKF, bool = false) { auto it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }   // :746-753
   void EraseObservation(kfptr pKF, bool bLock = false, bool bSuppressMapAction = false);   // :442-509 (reduced: no map / communication side effects)
   bool isBad() { return mbBad; }
+  typedef boost::shared_ptr<Frame> frameptr;
+  int Observations() { return nObs; }                                                                                  // MapPoint.cpp:517-521
+  void AddObservation(kfptr pKF, size_t idx, bool bLock = false) { (void)bLock; if (mObservations.count(pKF)) return; mObservations[pKF] = idx; nObs++; }   // :399-440
+  bool IsInKeyFrame(kfptr pKF) { return mObservations.count(pKF) != 0; }                                               // :755-759
+  void Replace(mpptr pMP, bool bLock = false);                                                                         // :560-640, reduced (see below)
+  bool mbDoNotReplace = false;
+  void ComputeDistinctiveDescriptors();                                                                               // :929-994, the reference's own lines (ref_frame_excerpt.cpp)
+  cv::Mat GetDescriptor() { return mDescriptor.clone(); }                                                             // :740-744
+  cv::Mat mDescriptor;
+  int PredictScale(const float& currentDist, kfptr pKF);      // bodies = MapPoint.cpp:836-869 (oracle/ref_mappoint_excerpt.cpp)
+  int PredictScale(const float& currentDist, frameptr pF);
+  // tracking scratch written by Frame::isInFrustum, read by SearchByProjection (MapPoint.h:224-228)
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 0;
+  bool mbTrackInView = false;
+  int mnTrackScaleLevel = 0;
+  mpptr mpReplaced;
   void UpdateNormalAndDepth();   // body = the reference's own lines MapPoint.cpp:779-823 (oracle/ref_mappoint_excerpt.cpp)
   float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
   float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
@@ -124,9 +160,20 @@ class MapPoint : public boost::enable_shared_from_this<MapPoint> {
   static std::mutex mGlobalMutex;   // MapPoint.h:253
 };
 
+inline std::set<KeyFrame::mpptr> KeyFrame::GetMapPoints() { std::set<mpptr> s; for (auto& p : mvpMapPoints) if (p && !p->isBad()) s.insert(p); return s; }
 inline void KeyFrame::EraseMapPointMatch(mpptr pMP, bool) {   // KeyFrame.cpp:518-530
   int idx = pMP->GetIndexInKeyFrame(shared_from_this());
   if (idx >= 0) mvpMapPoints[idx] = nullptr;
+}
+inline void MapPoint::Replace(mpptr pMP, bool) {   // MapPoint.cpp:560-640 without the map / communication side effects: this point's observations move to pMP
+  if (pMP.get() == this) return;
+  std::map<kfptr, size_t> obs = mObservations;
+  mObservations.clear(); mbBad = true; mpReplaced = pMP;
+  for (auto& kv : obs) {
+    kfptr pKF = kv.first;
+    if (!pMP->IsInKeyFrame(pKF)) { pKF->mvpMapPoints[kv.second] = pMP; pMP->AddObservation(pKF, kv.second); }
+    else pKF->mvpMapPoints[kv.second] = nullptr;
+  }
 }
 inline void MapPoint::EraseObservation(kfptr pKF, bool, bool) {   // MapPoint.cpp:442-509: drop the observation; a new reference keyframe if it was this one;
   bool bBad = false;                                              // the point turns bad when two or fewer observers remain
@@ -160,18 +207,35 @@ class Map : public boost::enable_shared_from_this<Map> {
   bool mbLockMapUpdate = false;
 };
 
-class Frame {
+class Frame : public boost::enable_shared_from_this<Frame> {
  public:
   typedef boost::shared_ptr<MapPoint> mpptr;
+  typedef boost::shared_ptr<KeyFrame> kfptr;
   int N = 0;                                  // Frame.h:125-168
-  std::vector<cv::KeyPoint> mvKeysUn;
+  std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+  cv::Mat mDescriptors;
+  DBoW2::BowVector mBowVec;
+  DBoW2::FeatureVector mFeatVec;
+  // grid (Frame.h:100-102, 147-149, 171-174); the three function bodies are the reference's own lines (oracle/ref_frame_excerpt.cpp)
+  static float mfGridElementWidthInv, mfGridElementHeightInv;
+  static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+  std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+  void AssignFeaturesToGrid();                                                                                    // Frame.cpp:103-118
+  bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);                                                  // :254-265
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1, const int maxLevel = -1) const;   // :200-253
+  int mnScaleLevels = 8;
+  float mfScaleFactor = 1.2f, mfLogScaleFactor = 0.f;
+  std::vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2;
   std::vector<mpptr> mvpMapPoints;
   std::vector<bool> mvbOutlier;
   cv::Mat mTcw;
   idpair mId = defpair;
   std::vector<float> mvInvLevelSigma2;
   float fx = 0, fy = 0, cx = 0, cy = 0;
-  void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }   // Frame.cpp:125-129 (UpdatePoseMatrices omitted)
+  cv::Mat mRcw, mRwc, mtcw, mOw;
+  void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); UpdatePoseMatrices(); }   // Frame.cpp:125-129
+  void UpdatePoseMatrices();                                                // :131-137, the reference's own lines (oracle/ref_frame_excerpt.cpp)
+  bool isInFrustum(mpptr pMP, float viewingCosLimit);                       // :139-198, likewise
 };
 
 }  // namespace cslam

@@ -3,8 +3,9 @@
 // compiled by oracle/Makefile.ref) are compiled VERBATIM against these names.  Data structures (Mat with shared, reference-counted
 // storage and ROI views, KeyPoint, Point_, Rect_, InputArray/OutputArray) behave like OpenCV's; the image-processing primitives
 // (resize, FAST, GaussianBlur, fastAtan2, cvRound) are the restatements of OpenCV 4.2.0 in oracle/cv_prims.h — the [EXT] part that
-// stays restated.  Small-matrix arithmetic on CV_32F / CV_64F follows cv::gemm's generic path: products are
-// accumulated in double and rounded once to the element type.
+// stays restated.  Matrix products follow cv::gemm (OpenCV 4.2.0 matmul.simd.hpp, gemmImpl): A*B, A*B+C, -A.t()*B ... are
+// lazy expressions evaluated by ONE gemm call; untransposed products with inner dimension 2..4 (equal to the result's width or height) take the
+// small-matrix path — FLOAT accumulators summed left to right, then (T)(t*alpha + c*beta) in double —, everything else GEMMSingleMul<T, double>.
 // Never used by the product, never shipped.
 #pragma once
 #include <algorithm>
@@ -184,7 +185,8 @@ class Mat {
   static MatInitExpr zeros(Size s, int type) { return MatInitExpr{s.height, s.width, type, 0.0, 0.0}; }
   static MatInitExpr ones(int r, int c, int type) { return MatInitExpr{r, c, type, 1.0, 1.0}; }
   static MatInitExpr eye(int r, int c, int type) { return MatInitExpr{r, c, type, 1.0, 0.0}; }
-  Mat t() const { Mat m(cols, rows, flags_type); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.set(c, r, get(r, c)); return m; }
+  Mat transposed() const { Mat m(cols, rows, flags_type); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.set(c, r, get(r, c)); return m; }
+  inline struct MatTExpr t() const;
   Mat mul(const Mat& o) const { Mat m(rows, cols, flags_type); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) m.set(r, c, get(r, c) * o.get(r, c)); return m; }
   double dot(const Mat& o) const { double s = 0; for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) s += get(r, c) * o.get(r, c); return s; }
   Mat cross(const Mat& o) const {
@@ -212,12 +214,76 @@ class Mat {
   }
 };
 
-inline Mat operator*(const Mat& a, const Mat& b) {   // gemm: double accumulators, one rounding to the element type
-  assert(a.cols == b.rows);
-  Mat m(a.rows, b.cols, a.type());
-  for (int r = 0; r < a.rows; r++) for (int c = 0; c < b.cols; c++) { double s = 0; for (int k = 0; k < a.cols; k++) s += a.get(r, k) * b.get(k, c); m.set(r, c, s); }
+// ---- cv::gemm and the MatExprs that end in it (matop.cpp: MatOp_T, MatOp_GEMM; matmul.simd.hpp: gemmImpl) --------------------------------------
+inline Mat gemm_eval(const Mat& a, bool ta, const Mat& b, bool tb, double alpha, const Mat* c, double beta) {
+  const int arows = ta ? a.cols : a.rows, len = ta ? a.rows : a.cols, bcols = tb ? b.rows : b.cols;
+  assert(len == (tb ? b.cols : b.rows));
+  Mat m(arows, bcols, a.type());
+  auto A = [&](int r, int k) { return ta ? a.get(k, r) : a.get(r, k); };
+  auto B = [&](int k, int col) { return tb ? b.get(col, k) : b.get(k, col); };
+  const bool small = !ta && !tb && 2 <= len && len <= 4 && (len == bcols || len == arows);      // `flags == 0 && 2 <= len && len <= 4 && (len == d_size.width || ...height)`
+  for (int r = 0; r < arows; r++)
+    for (int col = 0; col < bcols; col++) {
+      const double cv = c ? c->get(r, col) * beta : 0.0;
+      if (small && a.type() == CV_32F) {
+        float t = (float)A(r, 0) * (float)B(0, col);
+        for (int k = 1; k < len; k++) t = t + (float)A(r, k) * (float)B(k, col);                 // `float t0 = a[0]*b[0] + a[1]*b[b_step] + a[2]*b[b_step*2]`
+        m.set(r, col, (double)(float)((double)t * alpha + cv));                                  // `d[0] = (float)(t0*alpha + c[0]*beta)` with double alpha, beta
+      } else {
+        double sacc = 0;
+        for (int k = 0; k < len; k++) sacc += A(r, k) * B(k, col);                               // GEMMSingleMul<T, double>
+        m.set(r, col, sacc * alpha + cv);
+      }
+    }
   return m;
 }
+struct MatGemmExpr {
+  Mat a, b; bool ta = false, tb = false; double alpha = 1;
+  Mat eval() const { return gemm_eval(a, ta, b, tb, alpha, nullptr, 0); }
+  operator Mat() const { return eval(); }
+  template <class T> T at(int i) const { return eval().template at<T>(i); }
+  template <class T> T at(int r, int c) const { return eval().template at<T>(r, c); }
+  Mat clone() const { return eval(); }
+  Mat rowRange(int r0, int r1) const { return eval().rowRange(r0, r1); }
+  Mat colRange(int c0, int c1) const { return eval().colRange(c0, c1); }
+  Mat row(int r) const { return eval().row(r); }
+  Mat col(int c) const { return eval().col(c); }
+  double dot(const Mat& o) const { return eval().dot(o); }
+};
+struct MatTExpr {                                     // A.t() * alpha; materialised as transpose + convertTo(alpha) (MatOp_T::assign)
+  Mat a; double alpha = 1;
+  Mat eval() const {
+    Mat m = a.transposed();
+    if (alpha != 1) for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.cols; c++) m.set(r, c, m.type() == CV_32F ? (double)((float)m.get(r, c) * (float)alpha) : m.get(r, c) * alpha);
+    return m;
+  }
+  operator Mat() const { return eval(); }
+  Mat clone() const { return eval(); }
+  Mat rowRange(int r0, int r1) const { return eval().rowRange(r0, r1); }
+  Mat colRange(int c0, int c1) const { return eval().colRange(c0, c1); }
+  Mat row(int r) const { return eval().row(r); }
+  Mat col(int c) const { return eval().col(c); }
+  Mat inv(int method = DECOMP_LU) const { return eval().inv(method); }
+  template <class T> T at(int r, int c) const { return eval().template at<T>(r, c); }
+};
+inline MatTExpr Mat::t() const { MatTExpr e; e.a = *this; return e; }
+inline MatTExpr operator-(MatTExpr e) { e.alpha = -e.alpha; return e; }
+inline MatTExpr operator*(double s, MatTExpr e) { e.alpha *= s; return e; }
+inline MatTExpr operator*(MatTExpr e, double s) { e.alpha *= s; return e; }
+inline MatGemmExpr operator*(const Mat& a, const Mat& b) { MatGemmExpr g; g.a = a; g.b = b; return g; }
+inline MatGemmExpr operator*(const MatTExpr& a, const Mat& b) { MatGemmExpr g; g.a = a.a; g.ta = true; g.alpha = a.alpha; g.b = b; return g; }
+inline MatGemmExpr operator*(const Mat& a, const MatTExpr& b) { MatGemmExpr g; g.a = a; g.b = b.a; g.tb = true; g.alpha = b.alpha; return g; }
+inline MatGemmExpr operator*(const MatTExpr& a, const MatTExpr& b) { MatGemmExpr g; g.a = a.a; g.ta = true; g.b = b.a; g.tb = true; g.alpha = a.alpha * b.alpha; return g; }
+inline MatGemmExpr operator*(const MatGemmExpr& a, const Mat& b) { MatGemmExpr g; g.a = a.eval(); g.b = b; return g; }
+inline MatGemmExpr operator*(const Mat& a, const MatGemmExpr& b) { MatGemmExpr g; g.a = a; g.b = b.eval(); return g; }
+inline MatGemmExpr operator*(const MatGemmExpr& a, const MatTExpr& b) { MatGemmExpr g; g.a = a.eval(); g.b = b.a; g.tb = true; g.alpha = b.alpha; return g; }
+inline MatGemmExpr operator*(MatGemmExpr g, double s) { g.alpha *= s; return g; }
+inline MatGemmExpr operator*(double s, MatGemmExpr g) { g.alpha *= s; return g; }
+inline MatGemmExpr operator-(MatGemmExpr g) { g.alpha = -g.alpha; return g; }
+inline Mat operator+(const MatGemmExpr& g, const Mat& c) { return gemm_eval(g.a, g.ta, g.b, g.tb, g.alpha, &c, 1.0); }          // MatOp_GEMM::add: one gemm with C
+inline Mat operator+(const Mat& c, const MatGemmExpr& g) { return gemm_eval(g.a, g.ta, g.b, g.tb, g.alpha, &c, 1.0); }
+inline Mat operator-(const MatGemmExpr& g, const Mat& c) { return gemm_eval(g.a, g.ta, g.b, g.tb, g.alpha, &c, -1.0); }
+inline Mat operator-(const Mat& c, const MatGemmExpr& g) { return gemm_eval(g.a, g.ta, g.b, g.tb, -g.alpha, &c, 1.0); }
 inline Mat operator+(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.type() == CV_32F ? (double)((float)a.get(r, c) + (float)b.get(r, c)) : a.get(r, c) + b.get(r, c)); return m; }
 inline Mat operator-(const Mat& a, const Mat& b) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, a.type() == CV_32F ? (double)((float)a.get(r, c) - (float)b.get(r, c)) : a.get(r, c) - b.get(r, c)); return m; }
 inline Mat operator-(const Mat& a) { Mat m(a.rows, a.cols, a.type()); for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) m.set(r, c, -a.get(r, c)); return m; }
@@ -358,6 +424,12 @@ class FileNode {
   operator int() const { return (int)v_; }
   operator std::string() const { return s_; }
   bool empty() const { return s_.empty(); }
+  // structured (sequence / map) nodes: DBoW2's YAML vocabulary load/save compiles against these; the pinning harness loads vocabularies through
+  // loadFromTextFile only, so reaching them is an error
+  FileNode operator[](const char*) const { throw std::runtime_error("mini_cv: structured cv::FileNode access is not provided"); }
+  FileNode operator[](const std::string&) const { throw std::runtime_error("mini_cv: structured cv::FileNode access is not provided"); }
+  FileNode operator[](int) const { throw std::runtime_error("mini_cv: structured cv::FileNode access is not provided"); }
+  size_t size() const { return 0; }
 };
 class FileStorage {
   std::map<std::string, std::string> kv_;
@@ -380,6 +452,7 @@ class FileStorage {
   }
   bool isOpened() const { return true; }
   void release() {}
+  template <class T> FileStorage& operator<<(const T&) { throw std::runtime_error("mini_cv: cv::FileStorage writing is not provided"); }
   FileNode operator[](const std::string& k) const {
     auto it = kv_.find(k);
     if (it == kv_.end()) return FileNode();

@@ -94,8 +94,9 @@ def test_update_normal_and_depth_of_the_reference_is_the_oracle_bit_for_bit():
     ref_level = flat["kp_oct"][flat["kp_off"][ref_kf] + flat["obs_kp"][first]]
     T = flat["kf_Tcw"]
     Ow = np.zeros((flat["n_kf"], 3), np.float32)
-    for k in range(flat["n_kf"]):                                        # KeyFrame::SetPose: Ow = -Rwc * tcw (cv::gemm: double accumulation, one rounding)
-        Ow[k] = (-(T[k, :3, :3].T.astype(np.float64)) @ T[k, :3, 3].astype(np.float64)).astype(np.float32)
+    for k in range(flat["n_kf"]):         # KeyFrame::SetPose (KeyFrame.cpp:300-302): Rwc = Rcw.t() is materialised, so -Rwc*tcw is an untransposed 3x3 product:
+        Rwc, tcw = T[k, :3, :3].T, T[k, :3, 3]                                # cv::gemm's small-matrix path, f32 accumulators left to right, alpha = -1
+        Ow[k] = -((Rwc[:, 0] * tcw[0] + Rwc[:, 1] * tcw[1]) + Rwc[:, 2] * tcw[2])
     nrm, dmin, dmax = oracle.update_normal_and_depth(flat["mp_pos"], off, obs_kf, Ow, ref_kf, ref_level, SF, np.zeros((n_pt, 3)), np.zeros(n_pt), np.zeros(n_pt))
     assert np.array_equal(nrm, s["mp_normal"]) and np.array_equal(dmin, s["mp_dmin"]) and np.array_equal(dmax, s["mp_dmax"])
 
