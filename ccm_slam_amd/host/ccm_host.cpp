@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
 
 namespace cslam {
 
@@ -565,14 +567,16 @@ int ORBmatcher::SearchForInitialization(const KeysView& F1, const FrameView& F2,
 int ORBmatcher::ProjectedSearch(const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate,
                                 int distThreshold, int32_t* matched, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) {
   bestIdx.assign(P.n, -1); bestDist.assign(P.n, INT32_MAX);
-  FrameGrid grid(KF);
+  std::unique_ptr<FrameGrid> grid;
+  if (!P.candOff) grid.reset(new FrameGrid(KF));
   std::vector<int32_t> q_of, off(1, 0), idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
   for (int i = 0; i < P.n; i++) {
     if (!P.valid[i]) continue;
     const int lvl = P.level[i];
     const size_t before = idx.size();
     std::vector<int32_t> win;
-    grid.featuresInArea(P.u[i], P.v[i], th * KF.mvScaleFactors[lvl], -1, -1, win);   // KeyFrame::GetFeaturesInArea: no level filter
+    if (P.candOff) win.assign(P.candIdx + P.candOff[i], P.candIdx + P.candOff[i + 1]);
+    else grid->featuresInArea(P.u[i], P.v[i], th * KF.mvScaleFactors[lvl], -1, -1, win);   // KeyFrame::GetFeaturesInArea: no level filter
     for (int k : win) {
       const int kpLevel = KF.mvKeysUn[k].octave;
       if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
@@ -771,14 +775,25 @@ void Optimizer::GlobalBundleAdjustment(HipContext& ctx, BAProblem& p, int nItera
 
 }  // namespace cslam
 
-// ---- C wrappers so the Python test-suite can drive the C++ mirror ---------------------------------------
+// ---- C entry points (ccm_host_c.h): the Python test-suite and the drop-in translation units under shim/ ---------------------------------------
+#include "ccm_host_c.h"
+namespace {
+// one context per (calling thread, device), created on first use and kept for the thread's lifetime: the reference's threads (tracking, mapping, loop
+// finder ...) each call the matcher / optimizer from their own loop, so the per-call cost is a map lookup, not a stream + buffer set-up
+cslam::HipContext& thread_context(int device) {
+  thread_local std::map<int, std::unique_ptr<cslam::HipContext>> ctxs;
+  auto& c = ctxs[device];
+  if (!c) c.reset(new cslam::HipContext(device));
+  return *c;
+}
+}  // namespace
 extern "C" {
 int ccmh_search_by_projection_mp(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* fdesc, int N,
                                  float minX, float minY, float maxX, float maxY, const float* scale_factors, int n_mp,
                                  const uint8_t* in_view, const float* px, const float* py, const int32_t* lvl, const float* vcos,
                                  const uint8_t* mp_desc, float th, float nnratio, int32_t* frame_mp) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     std::vector<cslam::KeyPoint> kps(N);
     for (int i = 0; i < N; i++) kps[i] = cslam::KeyPoint{kx[i], ky[i], 31.f, 0.f, 0.f, oct[i]};
     cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = fdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
@@ -796,7 +811,7 @@ int ccmh_search_by_projection_last(int device, const float* kx, const float* ky,
                                    const int32_t* l_oct, const float* l_angle, const uint8_t* l_desc, float th, int check_ori,
                                    int32_t* cur_mp) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     std::vector<cslam::KeyPoint> kps(N);
     for (int i = 0; i < N; i++) kps[i] = cslam::KeyPoint{kx[i], ky[i], 31.f, kangle[i], 0.f, oct[i]};
     cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = fdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
@@ -810,7 +825,7 @@ int ccmh_search_by_projection_last(int device, const float* kx, const float* ky,
 int ccmh_local_ba(int device, int n_cam, int n_pt, int n_edge, double* cam_qt, const uint8_t* cam_fixed, const double* cam_K,
                   double* pt_xyz, const int32_t* e_cam, const int32_t* e_pt, const double* e_obs, const double* e_info, uint8_t* to_erase) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     cslam::BAProblem p;
     p.cam_qt.assign(cam_qt, cam_qt + 7 * (size_t)n_cam); p.cam_fixed.assign(cam_fixed, cam_fixed + n_cam);
     p.cam_K.assign(cam_K, cam_K + 4 * (size_t)n_cam); p.pt_xyz.assign(pt_xyz, pt_xyz + 3 * (size_t)n_pt);
@@ -831,7 +846,7 @@ int ccmh_search_by_projection_mp_dev(int device, const float* K, const float* di
                                      const int32_t* lvl, const float* vcos, const uint8_t* mp_desc, float th, float nnratio, int32_t* frame_mp,
                                      float* xy_un_out) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     cslam::FrameGridDev grid(ctx, K, dist, n_dist, w, h);
     std::vector<cslam::KeyPoint> keys((const cslam::KeyPoint*)kps_raw, (const cslam::KeyPoint*)kps_raw + N), keysUn;
     grid.SetKeyPoints(keys, fdesc, keysUn);
@@ -853,7 +868,7 @@ int ccmh_search_by_projection_last_dev(int device, const void* kps_un, const uin
                                        const uint8_t* valid, const float* u, const float* v, const int32_t* oct, const float* angle, const uint8_t* mp_desc,
                                        float th, int check_ori, int32_t* frame_mp) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     const float K[4] = {1.f, 1.f, 0.f, 0.f};
     cslam::FrameGridDev grid(ctx, K, nullptr, 0, w, h);
     std::vector<cslam::KeyPoint> keys((const cslam::KeyPoint*)kps_un, (const cslam::KeyPoint*)kps_un + N), keysUn;
@@ -872,7 +887,7 @@ int ccmh_search_by_projection_last_dev(int device, const void* kps_un, const uin
 int ccmh_optimize_sim3(int device, double* sim3, int n, const double* P1c, const double* P2c, const double* obs1, const double* obs2,
                        const double* info1, const double* info2, const double* K1, const double* K2, float th2, int fix_scale, uint8_t* keep) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     std::vector<uint8_t> k;
     const int nin = cslam::Optimizer::OptimizeSim3(ctx, sim3, n, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2, fix_scale != 0, k);
     if (n) std::memcpy(keep, k.data(), k.size());
@@ -882,7 +897,7 @@ int ccmh_optimize_sim3(int device, double* sim3, int n, const double* P1c, const
 
 int ccmh_orb_extract(int device, int nfeatures, const uint8_t* img, int w, int h, void* kps_out, uint8_t* desc_out, int cap) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     cslam::ORBextractor ex(ctx, nfeatures, 1.2f, 8, 20, 7);
     std::vector<cslam::KeyPoint> k; std::vector<uint8_t> d;
     ex(img, w, h, w, k, d);
@@ -910,7 +925,7 @@ int ccmh_search_bow(int device, int mode, const int32_t* n1, const int32_t* o1, 
                     const int32_t* oct2, const float* a2, int N2, const float* F12, float ex, float ey, const float* sigma2_2,
                     const float* sf2, float nnratio, int check_ori, int32_t* out) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     auto k1 = mk_keys(x1, y1, nullptr, a1, N1), k2 = mk_keys(x2, y2, oct2, a2, N2);
     cslam::KeysView A; A.N = N1; A.keys = k1.data(); A.desc = d1; A.hasMapPoint = has1; A.fv = cslam::FeatureVectorView{nn1, n1, o1, i1};
     cslam::KeysView B; B.N = N2; B.keys = k2.data(); B.desc = d2; B.hasMapPoint = has2; B.fv = cslam::FeatureVectorView{nn2, n2, o2, i2};
@@ -929,7 +944,7 @@ int ccmh_search_for_initialization(int device, const float* x1, const float* y1,
                                    float minX, float minY, float maxX, float maxY, float* prev_xy, int window, float nnratio, int check_ori,
                                    int32_t* matches12) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     auto k1 = mk_keys(x1, y1, oct1, a1, N1), k2 = mk_keys(x2, y2, oct2, a2, N2);
     cslam::KeysView A; A.N = N1; A.keys = k1.data(); A.desc = d1;
     std::vector<int32_t> dummy(N2, -1);
@@ -952,7 +967,7 @@ extern "C" int ccmh_projected_window_search(int device, const float* kx, const f
                                             int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim,
                                             int32_t* best_idx, int32_t* best_dist) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     auto kps = mk_keys(kx, ky, oct, nullptr, N);
     std::vector<int32_t> dummy(N, -1);
     cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = kdesc; F.mnMinX = minX; F.mnMinY = minY; F.mnMaxX = maxX; F.mnMaxY = maxY;
@@ -967,6 +982,26 @@ extern "C" int ccmh_projected_window_search(int device, const float* kx, const f
   } catch (const std::exception&) { return -1000; }
 }
 
+// the same search on candidate lists the caller obtained from its own KeyFrame::GetFeaturesInArea (CSR over the n points; th and the bounds are unused)
+extern "C" int ccmh_projected_window_search_cand(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N,
+                                                 const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                                 const uint8_t* pdesc, const int32_t* cand_off, const int32_t* cand_idx, int chi2_gate, int dist_threshold,
+                                                 int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist) {
+  try {
+    cslam::HipContext& ctx = thread_context(device);
+    auto kps = mk_keys(kx, ky, oct, nullptr, N);
+    cslam::FrameView F; F.N = N; F.mvKeysUn = kps.data(); F.mDescriptors = kdesc;
+    cslam::ORBmatcher::ProjectedPoints P; P.n = n_pts; P.valid = valid; P.u = u; P.v = v; P.level = level; P.desc = pdesc; P.noClaim = no_claim;
+    P.candOff = cand_off; P.candIdx = cand_idx;
+    cslam::ORBmatcher m(ctx);
+    std::vector<int32_t> bi, bd;
+    const int n = m.ProjectedSearch(F, inv_sigma2, P, 0.f, chi2_gate != 0, dist_threshold, matched, claim != 0, bi, bd);
+    std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
+    std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+
 // the same search through the device grid (bounds must be the plain image rectangle: 0, 0, maxX, maxY)
 extern "C" int ccmh_projected_window_search_dev(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float maxX,
                                                 float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts, const uint8_t* valid,
@@ -974,7 +1009,7 @@ extern "C" int ccmh_projected_window_search_dev(int device, const float* kx, con
                                                 int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx,
                                                 int32_t* best_dist) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     auto kps = mk_keys(kx, ky, oct, nullptr, N);
     const float K[4] = {1.f, 1.f, 0.f, 0.f};
     cslam::FrameGridDev grid(ctx, K, nullptr, 0, (int)maxX, (int)maxY);
@@ -997,7 +1032,7 @@ extern "C" int ccmh_bow_transform(int device, int n_nodes, int L, const int32_t*
                                   const int32_t* word_id, const double* weight, const uint8_t* desc, int N, int levelsup, int32_t* bow_ids,
                                   double* bow_vals, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_idx, int32_t* sizes /* [n_bow, n_fv_nodes, n_fv_idx] */) {
   try {
-    cslam::HipContext ctx(device);
+    cslam::HipContext& ctx = thread_context(device);
     cslam::ORBVocabulary voc(ctx, n_nodes, L, child_off, child_id, node_desc, word_id, weight);
     cslam::BowVector v; cslam::FeatureVector fv;
     voc.transform(desc, N, v, fv, levelsup);

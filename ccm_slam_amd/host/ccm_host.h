@@ -146,7 +146,11 @@ class ORBmatcher {
   // supplies the outcome of the f32 projection / depth / viewing-angle tests (valid, u, v, predicted level) and applies the
   // map mutations (Replace / AddObservation / RemapMapPointMatch) in order from bestIdx, as the reference does after its loop.
   struct ProjectedPoints { int n = 0; const uint8_t* valid = nullptr; const float* u = nullptr; const float* v = nullptr;
-                           const int32_t* level = nullptr; const uint8_t* desc = nullptr; const uint8_t* noClaim = nullptr; };
+                           const int32_t* level = nullptr; const uint8_t* desc = nullptr; const uint8_t* noClaim = nullptr;
+                           // optional: the window candidates of every point as the caller's KeyFrame::GetFeaturesInArea returned them (CSR over the n points,
+                           // unfiltered, in that order).  A drop-in build has the reference's KeyFrame.cpp, whose grid was filled with the Frame's float
+                           // bounds but is read with the keyframe's int-truncated ones (KeyFrame.cpp:54-61, 1167-1171): only its own lookup has that order.
+                           const int32_t* candOff = nullptr; const int32_t* candIdx = nullptr; };
   int ProjectedSearch(const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate, int distThreshold,
                       int32_t* matched /* nullable in/out [KF.N] */, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
   int ProjectedSearch(FrameGridDev& grid, const FrameView& KF, const float* invLevelSigma2, const ProjectedPoints& P, float th, bool chi2Gate,

@@ -1,0 +1,86 @@
+"""OUR drop-in translation unit shim/ORBmatcher_hip.cpp (-> libccm_host.so -> ccm_hamming_csr on the MI355X) in the place of the reference's
+cslam/src/ORBmatcher.cpp: the SAME harness that pins the oracle to the reference (oracle/ref_matcher_driver.cpp: flat inputs -> the reference's Frame /
+KeyFrame / MapPoint objects -> the method under test through the class API of cslam/include/cslam/ORBmatcher.h -> what it did to the map) is linked with
+our ORBmatcher instead (shim/Makefile: libmatcher_hip_shim.so) and must produce the same tables as the oracle, which tests/test_ref_matcher.py shows
+to be the reference's.  Rows M1-M10 of SURVEY 8a, incl. the map mutations of Fuse and the re-map branch of SearchByProjection(KeyFrame, Scw)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import tests.test_ref_matcher as trm
+from ccm_slam_amd import synth
+
+SHIM = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shim", "libmatcher_hip_shim.so")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(SHIM), reason="shim/libmatcher_hip_shim.so not built")]
+
+
+@pytest.fixture(scope="module")
+def slib():
+    return C.CDLL(SHIM)
+
+
+@pytest.fixture(scope="module")
+def frames():
+    o = oracle.OrbOracle(1000)
+    out = [o.extract(synth.gen_image(1000, t)) for t in (0, 1)]
+    o.close()
+    return out
+
+
+def test_M1_search_by_projection_map_points(slib, frames):
+    trm.test_search_by_projection_map_points_M1(slib, frames)
+
+
+def test_M2_search_by_projection_last_frame(slib, frames):
+    trm.test_search_by_projection_last_frame_M2_with_the_references_own_projection(slib, frames)
+
+
+def test_M3_M4_search_by_bow(slib, frames):
+    trm.test_search_by_bow_M3_M4(slib, frames)
+
+
+def test_M5_search_for_triangulation(slib, frames):
+    trm.test_search_for_triangulation_M5_with_the_references_own_epipole(slib, frames)
+
+
+def test_M6_search_for_initialization(slib, frames):
+    trm.test_search_for_initialization_M6(slib, frames)
+
+
+def test_M7_fuse(slib, frames):
+    trm.test_fuse_M7_chi2_gate(slib, frames)
+
+
+def test_M8_fuse_sim3(slib, frames):
+    trm.test_fuse_sim3_M8(slib, frames)
+
+
+def test_M9_search_by_projection_sim3(slib, frames):
+    trm.test_search_by_projection_sim3_M9_claims(slib, frames)
+
+
+def test_M10_search_by_sim3(slib, frames):
+    trm.test_search_by_sim3_M10(slib, frames)
+
+
+def test_shim_and_reference_libraries_agree_call_by_call(slib, frames):
+    """the two libraries side by side on one Fuse scenario: same return value, same fused features, same projections"""
+    if not os.path.exists(trm.LIB):
+        pytest.skip("oracle/_ref not built")
+    rlib = C.CDLL(trm.LIB)
+    s = trm._projected_case(frames, 21)
+    kps = s["kps"]
+    has = (s["rng"].random(s["N"]) < 0.5).astype(np.uint8)
+    outs = []
+    for lib in (rlib, slib):
+        best = np.zeros(s["n_pts"], np.int32); valid, u, v, lvl = trm._proj_out(s["n_pts"])
+        p = trm._p; c = trm.c
+        n = lib.ref_fuse(p(c(kps["x"])), p(c(kps["y"])), p(c(kps["octave"])), p(s["desc"]), s["N"], *trm.fb, p(s["sf"]), p(s["isig"]), p(s["K4"]), p(s["T"]), p(has),
+                         s["n_pts"], p(s["Xw"]), p(s["normal"]), p(s["dmin"]), p(s["dmax"]), p(s["pdesc"]), C.c_float(3.0), p(best), p(valid), p(u), p(v), p(lvl))
+        outs.append((n, best, valid, u, v, lvl))
+    assert outs[0][0] == outs[1][0] > 500
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
