@@ -1148,13 +1148,10 @@ __device__ __forceinline__ double pers_bcast(double v, int src_lane) {
 // Assemble the damped 96x96 block of one cluster from the block-CSR rows, factor it (Cholesky blocked by camera) and
 // leave W = (block)^-1 in A.  Kept out of line so that its register-hungry 6x6 temporaries do not compete with the
 // register-resident S rows of the PCG loop.
-__device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibuf, const int* cij, const uint32_t* cblk, int c_lo, int c_hi,
-                                                 const double* S, int s0, int s1, double lambda, bool has,
-                                                 long long* tacc, bool timing) {
+__device__ __noinline__ void pers_assemble_cluster(double* A, double* Li, const int* cij, const uint32_t* cblk, int c_lo, int c_hi, const double* S, int m,
+                                                   double lambda, bool has) {
   constexpr int N = kCluN;
   const int t = threadIdx.x;
-  const int nrows = s1 - s0;
-  const int m = 6 * nrows;
   // ---- init 1: assemble the damped dense block of the cluster ----
   for (int i = t; i < N * N; i += kPersTPB) { A[i] = 0; Li[i] = 0; }
   __syncthreads();
@@ -1173,6 +1170,12 @@ __device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibu
   }
   if (m + t < N) A[(m + t) * N + m + t] = 1.0;   // unit diagonal on the padding rows of a short cluster: the factorisation needs no special case
   __syncthreads();
+}
+
+// Factor the dense SPD block in A (lower triangle read; m live rows, unit diagonal beyond) and leave W = A^-1 in A; Li (all zero on entry) is scratch.
+__device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf, int m, long long* tacc, bool timing) {
+  constexpr int N = kCluN;
+  const int t = threadIdx.x;
   PERS_TICK(7)
   // ---- init 2: Cholesky A = L L^T on 16x16 tiles: 6 steps of (diagonal tile | panel | trailing update) instead of 16
   // camera-sized ones.  Diagonal tile: one wave, lane = row with its 16 entries in registers, pivot-row entries by
@@ -1320,6 +1323,179 @@ __device__ __noinline__ void pers_factor_cluster(double* A, double* Li, int* ibu
     }
   }
   __syncthreads();
+}
+
+__device__ __forceinline__ void pers_factor_cluster(double* A, double* Li, int* ibuf, const int* cij, const uint32_t* cblk, int c_lo, int c_hi,
+                                                    const double* S, int s0, int s1, double lambda, bool has, long long* tacc, bool timing) {
+  pers_assemble_cluster(A, Li, cij, cblk, c_lo, c_hi, S, 6 * (s1 - s0), lambda, has);
+  pers_factor_dense(A, Li, ibuf, 6 * (s1 - s0), tacc, timing);
+}
+
+// ---- reduced systems of 17..32 free cameras (a local-BA window): EXACT solve in ONE workgroup -------------------------------------------------------
+// The two 16-camera clusters are eliminated block-wise with the tile factorisation above (f64 matrix cores):
+//   W11 = A11^-1,  T = W11 A12,  S22 = A22 - A12^T T,  W22 = S22^-1,  x2 = W22 (b2 - A12^T W11 b1),  x1 = W11 b1 - T x2.
+// Two 96x96 LDS regions are all a factorisation leaves room for, so T waits in a global scratch (74 KB, L2) while S22 is factored.  This replaces
+// ~19 iterations of the persistent PCG over 4 workgroups (11 us each: two grid exchanges per iteration) by ~6 block products; g2o itself solves
+// these systems directly (LinearSolverDense / Eigen LDLT, Optimizer.cpp:371-375), so the exact solve is also the closer restatement.
+constexpr int kDense2MaxCp = 2 * kClu;
+static inline size_t dense2_lds_bytes() { return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN) * sizeof(double) + 16 + 14 * sizeof(long long) + 64 * sizeof(int); }
+
+__global__ __launch_bounds__(kPersTPB) void ba_solve_dense2(BaDev d, double lambda, const int* coff, const int* cij, const uint32_t* cblk, double* gTt /* [96][96] T transposed */,
+                                                               long long* dbg /* nullable: [9] phase clocks (10 ns ticks) + launches */) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  constexpr int N = kCluN;
+  double* R1 = sm;
+  double* R2 = sm + N * N;
+  double* b1 = R2 + N * N; double* b2 = b1 + N; double* t1 = b2 + N; double* cv = t1 + N; double* x2 = cv + N;
+  double* zpart = x2 + N;                                   // [8][N]
+  int* ibuf = reinterpret_cast<int*>(zpart + 8 * N);        // [4]
+  long long* tacc = reinterpret_cast<long long*>(ibuf + 4);
+  int* roff = reinterpret_cast<int*>(tacc + 14);            // [kDense2MaxCp + 1] row offsets of the block CSR
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(t / kWave);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int Cp = d.Cp, m2 = 6 * (Cp - kClu);
+  long long tprev = (dbg && t == 0) ? wall_clock64() : 0;
+  const bool timing = dbg != nullptr && t == 0;
+  if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
+#define D2_TICK(slot) { if (dbg && t == 0) { const long long tn_ = wall_clock64(); dbg[slot] += tn_ - tprev; tprev = tn_; } }
+  if (t < 4) ibuf[t] = 0;
+  if (t <= Cp) roff[t] = d.row_off[t];
+  if (t < N) { b1[t] = d.bs[t]; b2[t] = (t < m2) ? d.bs[N + t] : 0.0; }
+  // v_out[row] = sum_k M[k][row] * v_in[k] over the 96 x 96 region M (row-major, read down its columns: conflict-free); 8 column parts
+  auto matvec_t = [&](const double* M, const double* vin) {
+    const int row = t % N, prt = t / N;
+    if (prt < 8) {
+      double sv = 0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) sv += M[(12 * prt + k) * N + row] * vin[12 * prt + k];
+      zpart[prt * N + row] = sv;
+    }
+    __syncthreads();
+    double r = 0;
+    if (t < N) {
+      r = zpart[t];
+#pragma unroll
+      for (int q = 1; q < 8; q++) r += zpart[q * N + t];
+    }
+    return r;                                               // valid for t < N
+  };
+  pers_assemble_cluster(R1, R2, cij, cblk, coff[0], coff[1], d.S, N, lambda, true);
+  D2_TICK(0)
+  pers_factor_dense(R1, R2, ibuf, N, tacc, timing);          // R1 = W11 (symmetric)
+  D2_TICK(1)
+  {
+    const double v = matvec_t(R1, b1);
+    if (t < N) t1[t] = v;
+  }
+  // A12 (rows: cluster 0, columns: cluster 1) into R2 from the block-CSR rows of cluster 0
+  for (int e = t; e < N * N; e += kPersTPB) R2[e] = 0.0;
+  __syncthreads();
+  {
+    const int e0 = roff[0], ne = roff[kClu] - e0;
+    for (int idx = t; idx < 6 * ne; idx += kPersTPB) {
+      const int sidx = e0 + idx / 6, r = idx % 6;
+      const int j = d.row_col[sidx];
+      if (j < kClu) continue;
+      int i = 0;
+#pragma unroll
+      for (int step = 8; step > 0; step >>= 1) if (i + step < kClu && roff[i + step] <= sidx) i += step;
+      const uint32_t bt = d.row_blk[sidx];
+      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+#pragma unroll
+      for (int c = 0; c < 6; c++) R2[(6 * i + r) * N + 6 * (j - kClu) + c] = (bt & kTransposeBit) ? B[c * 6 + r] : B[r * 6 + c];
+    }
+  }
+  __syncthreads();
+  D2_TICK(2)
+  // T = W11 A12: 36 tiles of 16 x 16, waves 0..3 own three, the others two
+  v4d acc[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int tile = wave + kPersWaves * q;
+    v4d a4 = {0.0, 0.0, 0.0, 0.0};
+    if (tile < 36) {
+      const int I = tile / 6, J = tile % 6;
+      for (int k0 = 0; k0 < N; k0 += 4)
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(R1[(k0 + kq) * N + 16 * I + i16], R2[(k0 + kq) * N + 16 * J + i16], a4, 0, 0, 0);   // W11 symmetric: read down the column
+    }
+    acc[q] = a4;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int tile = wave + kPersWaves * q;
+    if (tile < 36) {
+      const int I = tile / 6, J = tile % 6;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * I + kq + 4 * r, col = 16 * J + i16;
+        R1[row * N + col] = acc[q][r];
+        gTt[col * N + row] = acc[q][r];
+      }
+    }
+  }
+  __syncthreads();
+  D2_TICK(3)
+  // P = A12^T T (registers) and c = b2 - A12^T t1
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int tile = wave + kPersWaves * q;
+    v4d a4 = {0.0, 0.0, 0.0, 0.0};
+    if (tile < 36) {
+      const int I = tile / 6, J = tile % 6;
+      for (int k0 = 0; k0 < N; k0 += 4)
+        a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(R2[(k0 + kq) * N + 16 * I + i16], R1[(k0 + kq) * N + 16 * J + i16], a4, 0, 0, 0);
+    }
+    acc[q] = a4;
+  }
+  {
+    const double v = matvec_t(R2, t1);
+    if (t < N) cv[t] = b2[t] - v;
+  }
+  __syncthreads();
+  D2_TICK(4)
+  // S22 = A22 - P, factored in place
+  pers_assemble_cluster(R1, R2, cij, cblk, coff[1], coff[2], d.S, m2, lambda, true);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int tile = wave + kPersWaves * q;
+    if (tile < 36) {
+      const int I = tile / 6, J = tile % 6;
+#pragma unroll
+      for (int r = 0; r < 4; r++) R1[(16 * I + kq + 4 * r) * N + 16 * J + i16] -= acc[q][r];
+    }
+  }
+  __syncthreads();
+  D2_TICK(5)
+  pers_factor_dense(R1, R2, ibuf, m2, tacc, timing);         // R1 = W22
+  D2_TICK(6)
+  {
+    const double v = matvec_t(R1, cv);
+    if (t < N) x2[t] = v;
+  }
+  __syncthreads();
+  {   // x1 = t1 - T x2, T^T from the global scratch (coalesced down its columns)
+    const int row = t % N, prt = t / N;
+    if (prt < 8) {
+      double sv = 0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) sv += gTt[(12 * prt + k) * N + row] * x2[12 * prt + k];
+      zpart[prt * N + row] = sv;
+    }
+    __syncthreads();
+    if (t < N) {
+      double r = zpart[t];
+#pragma unroll
+      for (int q = 1; q < 8; q++) r += zpart[q * N + t];
+      d.x[t] = t1[t] - r;
+      if (t < m2) d.x[N + t] = x2[t];
+    }
+  }
+  D2_TICK(7)
+  if (dbg && t == 0) { dbg[8] += 1; dbg[9] += tacc[8]; dbg[10] += tacc[9]; }
+#undef D2_TICK
+  if (t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = 1; d.pcg_flag[2] = ibuf[1]; d.pcg_flag[3] = 0; }
 }
 
 __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) {
@@ -1953,6 +2129,7 @@ struct ccm_ba {
   int cur = 0;
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
   unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
+  double* d_dense_T = nullptr;   // [96][96] scratch of the exact two-cluster solve (17..32 free cameras)
   int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
   uint32_t* d_pers_cblk = nullptr;
   unsigned long long pers_launch = 0;
@@ -2411,6 +2588,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (int rc2 = dev_upload(ba, pers_cij, &ba->d_pers_cij)) return fail(rc2);
     if (int rc2 = dev_upload(ba, pers_cblk, &ba->d_pers_cblk)) return fail(rc2);
   }
+  if (Cp > kSmallMaxCp && Cp <= kDense2MaxCp && ba->d_pers_coff)
+    if (int rc2 = dev_alloc<double>(ba, (size_t)kCluN * kCluN + 16, &ba->d_dense_T)) return fail(rc2);   // + phase clocks (CCM_BA_DENSE2_DBG)
   d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
   if (!ba->pers_grid && Cp > kSmallMaxCp && !ba->coarse_na && !getenv("CCM_BA_NO_COARSE") && kAgg == 2 * kClu) {
     const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
@@ -2632,7 +2811,18 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : tol_default;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
     int flags[4] = {0, 0, 0, 0};
-    if (d.Cp <= kSmallMaxCp) {
+    static const bool dense2_on = !(getenv("CCM_BA_DENSE2") && atoi(getenv("CCM_BA_DENSE2")) == 0);
+    if (d.Cp > kSmallMaxCp && d.Cp <= kDense2MaxCp && ba->d_dense_T && ba->d_pers_coff && dense2_on) {
+      // exact block solve in one workgroup (see ba_solve_dense2): one launch, flags read back with the trial scalars
+      CCM_LDS_ATTR(ctx, CCM_LDS_BA_DENSE2, ba_solve_dense2, dense2_lds_bytes());
+      {
+        ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
+        hipLaunchKernelGGL(ba_solve_dense2, dim3(1), dim3(kPersTPB), dense2_lds_bytes(), ctx->stream, d, lambda, (const int*)ba->d_pers_coff, (const int*)ba->d_pers_cij,
+                           (const uint32_t*)ba->d_pers_cblk, ba->d_dense_T,
+                           getenv("CCM_BA_DENSE2_DBG") ? (long long*)(ba->d_dense_T + kCluN * kCluN) : (long long*)nullptr);
+      }
+      small_path = true;
+    } else if (d.Cp <= kSmallMaxCp) {
       // one launch, no host round trip: the flags are read back after the trial kernels are queued
       size_t lds = (size_t)(5 * 6 * d.Cp + 36 * d.Cp + 18) * sizeof(double);
       const size_t lds_S = 36 * (size_t)(d.Cp + d.nOff) * sizeof(double) + ((size_t)d.Cp + 1 + 2 * (size_t)ba->n_row_entries) * sizeof(int) + 16;
@@ -2831,6 +3021,13 @@ extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* o
 }
 
 static void pers_dbg_dump(ccm_ba* ba) {
+  if (ba->d_dense_T && getenv("CCM_BA_DENSE2_DBG")) {
+    long long h[11];
+    hipMemcpy(h, ba->d_dense_T + kCluN * kCluN, sizeof(h), hipMemcpyDeviceToHost);
+    const double nl = (double)std::max<long long>(h[8], 1);
+    fprintf(stderr, "[ccm_ba] exact two-cluster solve: %lld launches; us/launch: assemble1 %.1f factor1 %.1f t1+A12 %.1f T %.1f P+c %.1f assemble2 %.1f factor2 %.1f x %.1f | both factorisations: cholesky %.1f inverse-factor %.1f\n", h[8],
+            h[0] * 0.01 / nl, h[1] * 0.01 / nl, h[2] * 0.01 / nl, h[3] * 0.01 / nl, h[4] * 0.01 / nl, h[5] * 0.01 / nl, h[6] * 0.01 / nl, h[7] * 0.01 / nl, h[9] * 0.01 / nl, h[10] * 0.01 / nl);
+  }
   if (!ba->pers_grid || !getenv("CCM_BA_PERS_DBG")) return;
   long long h[16];
   hipMemcpy(h, ba->d_pers_bar + 4, sizeof(h), hipMemcpyDeviceToHost);
