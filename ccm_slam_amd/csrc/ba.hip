@@ -1181,7 +1181,10 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
   // camera-sized ones.  Diagonal tile: one wave, lane = row with its 16 entries in registers, pivot-row entries by
   // v_readlane, reciprocal square roots.  Panel: one thread per row below, multiplies by the stored reciprocals.
   // Trailing update: rank-16 on the f64 matrix cores (4 k-steps per 16x16 tile).  104 us (6-column steps, scalar
-  // update) -> 43 us (6-column steps, MFMA update) -> ~20 us.
+  // update) -> 43 us (6-column steps, MFMA update) -> 42 us measured inside the two-cluster solver (diagonal tiles 20, panels 15,
+  // trailing updates 7; then 14 us for L^-1 and 5 us for W).  Tried and dropped (round 2): right-looking diagonal tile with scalar-register
+  // broadcasts + the tile's inverse in the same wave + the panel as one MFMA product per tile: 51 us — the 16 dependent pivots
+  // (rsqrt, broadcast, update: ~300 cycles each) set the time of a tile whichever way the off-path work is arranged.
   double* invd = Li;   // 16 reciprocal pivots of the current step (Li is all zero otherwise and is restored below)
   {
     typedef double v4d __attribute__((ext_vector_type(4)));
@@ -2192,6 +2195,10 @@ int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
   return CCM_OK;
 }
 
+// reduced systems with at most this many off-diagonal blocks use the one-workgroup-per-block Schur kernel; above, the row kernel (which also forms the
+// diagonal blocks and b_schur).  CCM_BA_ROW_MIN_BLOCKS overrides (experiments).
+static inline int row_min_blocks() { static const int v = getenv("CCM_BA_ROW_MIN_BLOCKS") ? atoi(getenv("CCM_BA_ROW_MIN_BLOCKS")) : 256; return v; }
+
 #define RC(x) do { int _rc = (x); if (_rc != CCM_OK) return _rc; } while (0)
 
 // Collectives of a BA handle.  A handle created for ONE rank never enters a collective, even when its context carries a
@@ -2433,7 +2440,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (int rc = dev_alloc<int>(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al, false)) return fail(rc);
     d.inst_al = p_al;
     d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0;
-    if (nOff > 8192 && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
+    if (nOff > row_min_blocks() && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
       std::vector<int> h_off((size_t)nOff + 1);
       if (hipMemcpyAsync(h_off.data(), d_inst_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: instance offsets read-back"));
@@ -2786,13 +2793,13 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   bool small_path = false, pers_trial = false, pers_launch_failed = false;
   int small_flags[4] = {0, 0, 0, 0};
   if (d.Cp) {
-    if (!(d.nOff > 8192 && d.row_units_max)) {   // the row kernel also forms the diagonal blocks and b_schur
+    if (!(d.nOff > row_min_blocks() && d.row_units_max)) {   // the row kernel also forms the diagonal blocks and b_schur
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
       hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
     }
     if (d.nOff) {
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
-      if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
+      if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
         if (d.row_part) {
           const size_t lds_row = ((size_t)d.max_cam_edges * 18 + 18) * sizeof(double);
