@@ -24,10 +24,14 @@
 #include "orb_math.h"
 #include "orb_pattern.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <list>
+#include <memory>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -726,8 +730,64 @@ static int orb_phase1(ccm_orb* o) {
   return CCM_OK;
 }
 
-// host phase: read candidates, run the octree per level, fill h_kin; returns the keypoint count
-static int orb_host_select(ccm_orb* o, int* n_out) {
+// host phase: read candidates, run the octree per level, fill h_kin; returns the keypoint count.
+// The levels are independent (DistributeOctTree is called once per level, ORBextractor.cpp:1027-1040), so a batch call spreads them over a few
+// helper threads that live for the duration of the call (LevelPool); the single-frame path runs them in order on the calling thread.
+static void orb_select_level(ccm_orb* o, const int* offs, const uint32_t* rec, int l, Octree& ws, std::vector<int>& sel) {
+  const LevelInfo& L = o->dev.lv[l];
+  const int c0 = offs[L.cellBase], c1 = offs[L.cellBase + L.nCols * L.nRows];
+  std::vector<Cand>& cand = o->last_cand[l];
+  cand.resize(c1 - c0);
+  for (int k = c0; k < c1; k++) {
+    const uint32_t r = rec[k];
+    cand[k - c0] = Cand{(float)(r & 0xFFF), (float)((r >> 12) & 0xFFF), (float)(r >> 24)};
+  }
+  sel.clear();
+  if (cand.empty()) return;
+  const int minB = kEdge - 3;
+  distribute_octree(ws, cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
+}
+
+// helper threads of one batch call: they spin on a generation counter (a frame's levels arrive every ~0.1 ms; a condition variable's
+// wake-up would cost as much as the work) and take levels from a shared counter, largest level first
+struct LevelPool {
+  ccm_orb* o = nullptr;
+  const int* offs = nullptr; const uint32_t* rec = nullptr;
+  std::vector<std::thread> th;
+  std::vector<Octree> ws; std::vector<std::vector<int>> sel;   // per level
+  std::atomic<int> gen{0}, next{0}, done{0};
+  std::atomic<bool> stop{false};
+  void work() {
+    const int nl = o->nlevels;
+    for (int l; (l = next.fetch_add(1, std::memory_order_acq_rel)) < nl;) {   // acquire: a helper that is late leaving the previous frame may pick up this one's first level
+      orb_select_level(o, offs, rec, l, ws[l], sel[l]);
+      done.fetch_add(1, std::memory_order_release);
+    }
+  }
+  void start(ccm_orb* o_, int helpers) {
+    o = o_; ws.resize(o->nlevels); sel.resize(o->nlevels);
+    for (int i = 0; i < helpers; i++)
+      th.emplace_back([this] {
+        int seen = 0;
+        while (!stop.load(std::memory_order_acquire)) {
+          const int g = gen.load(std::memory_order_acquire);
+          if (g == seen) { __builtin_ia32_pause(); continue; }
+          seen = g;
+          work();
+        }
+      });
+  }
+  void run(const int* offs_, const uint32_t* rec_) {   // the caller takes levels too and returns when all are done
+    offs = offs_; rec = rec_;
+    done.store(0, std::memory_order_relaxed); next.store(0, std::memory_order_release);
+    gen.fetch_add(1, std::memory_order_release);
+    work();
+    while (done.load(std::memory_order_acquire) < o->nlevels) __builtin_ia32_pause();
+  }
+  ~LevelPool() { stop.store(true, std::memory_order_release); for (auto& t : th) t.join(); }
+};
+
+static int orb_host_select(ccm_orb* o, int* n_out, LevelPool* pool = nullptr) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
   // wait for the candidate copy only (the blur kernel queued behind it keeps running)
@@ -745,20 +805,13 @@ static int orb_host_select(ccm_orb* o, int* n_out) {
   }
   const uint32_t* rec = (const uint32_t*)(o->B[o->cur].h_cand + d.ncells + 1);
   o->last_cand.resize(o->nlevels);
+  if (pool) pool->run(offs, rec);
+  const int minB = kEdge - 3;
   int n = 0;
   for (int l = 0; l < o->nlevels; l++) {
-    const LevelInfo& L = d.lv[l];
-    const int c0 = offs[L.cellBase], c1 = offs[L.cellBase + L.nCols * L.nRows];
-    std::vector<Cand>& cand = o->last_cand[l];
-    cand.resize(c1 - c0);
-    for (int k = c0; k < c1; k++) {
-      const uint32_t r = rec[k];
-      cand[k - c0] = Cand{(float)(r & 0xFFF), (float)((r >> 12) & 0xFFF), (float)(r >> 24)};
-    }
-    if (cand.empty()) continue;
-    const int minB = kEdge - 3;
-    std::vector<int>& sel = o->sel_ws;
-    distribute_octree(o->tree_ws, cand.data(), (int)cand.size(), minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
+    if (!pool) orb_select_level(o, offs, rec, l, o->tree_ws, o->sel_ws);
+    const std::vector<int>& sel = pool ? pool->sel[l] : o->sel_ws;
+    const std::vector<Cand>& cand = o->last_cand[l];
     for (int id : sel) {
       if (n >= o->kp_cap) break;
       o->B[o->cur].h_kin[n++] = KpIn{(int16_t)((int)cand[id].x + minB), (int16_t)((int)cand[id].y + minB), (int16_t)l, (int16_t)cand[id].response};
@@ -833,6 +886,10 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   if (rc) return rc;
   if ((rc = orb_alloc_bufs(o, 1))) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
+  // the octrees of a frame's levels run on this thread + a few helpers for the duration of the call (CCM_ORB_BATCH_THREADS, default 3 helpers, 0 = none)
+  static const int n_helpers = getenv("CCM_ORB_BATCH_THREADS") ? std::max(0, std::min(7, atoi(getenv("CCM_ORB_BATCH_THREADS")))) : 3;
+  std::unique_ptr<LevelPool> pool;
+  if (n_helpers > 0 && n_frames > 1) { pool.reset(new LevelPool()); pool->start(o, n_helpers); }
   // Two frames in flight on ONE in-order stream: iteration f queues the device phase 1 of frame f (into buffer set f & 1), then finishes
   // frame f - 1: the host waits only for ITS candidate list, selects keypoints (DistributeOctTree, ~0.1 ms) while the GPU is busy with
   // frame f, and queues phase 2 + the device-to-device copies of the results.  Stream order alone keeps the two sets apart: phase 2 of
@@ -847,7 +904,7 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
       const int g = f - 1;
       o->cur = g & 1;
       int n = 0;
-      if ((rc = orb_host_select(o, &n))) { o->cur = 0; return rc; }
+      if ((rc = orb_host_select(o, &n, pool.get()))) { o->cur = 0; return rc; }
       if ((rc = orb_phase2(o, n))) { o->cur = 0; return rc; }
       const int nc = std::min(n, cap);
       if (nc) {
