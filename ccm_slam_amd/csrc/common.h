@@ -91,6 +91,28 @@ void ccm_tile_plan_symbolic(int T, const std::vector<char>& nz, ccm_tile_plan* p
                             std::vector<int>* row_cols);
 int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info, const ccm_tile_plan* plan = nullptr);
 int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv, double* d_X, double* d_Ainv, int* d_info);
+// Tile-sparse Cholesky with level scheduling (dense_chol.hip): only the non-zero 64 x 64 tiles of L are stored (tid: tile (i, j) -> slot, i >= j),
+// left-looking, all tile columns of one elimination level in one launch.  The caller fills d_tiles (lower triangle; diagonal tiles: lower part)
+// after ccm_tsc_clear and calls ccm_tsc_solve; everything lives in pooled blocks released by ccm_tsc_destroy.
+struct ccm_tsc {
+  int T = 0, n_tiles = 0, n_levels = 0;
+  std::vector<int> tid;                                   // host copy [T * T], -1 = zero tile
+  std::vector<int> lvl_col_off, lvl_gt_off, lvl_pt_off;   // [n_levels + 1]
+  int *d_tid = nullptr, *d_cols = nullptr, *d_gt = nullptr, *d_gk_off = nullptr, *d_gk = nullptr, *d_pt = nullptr;
+  int *d_rc_off = nullptr, *d_rc = nullptr, *d_cr_off = nullptr, *d_cr = nullptr;
+  double *d_tiles = nullptr, *d_linv = nullptr;
+  int* d_info = nullptr;
+  std::vector<std::pair<void*, size_t>> blocks;
+  ccm_ctx* owner = nullptr;                               // set by ccm_tsc_create: the destructor hands the blocks back to its pool
+  ccm_tsc() = default;
+  ccm_tsc(const ccm_tsc&) = delete;
+  ccm_tsc& operator=(const ccm_tsc&) = delete;
+  ~ccm_tsc();
+};
+int ccm_tsc_create(ccm_ctx* ctx, int T, const std::vector<char>& nz, ccm_tsc* out);
+void ccm_tsc_destroy(ccm_ctx* ctx, ccm_tsc* p);
+int ccm_tsc_clear(ccm_ctx* ctx, ccm_tsc* p);
+int ccm_tsc_solve(ccm_ctx* ctx, ccm_tsc* p, double* d_b);
 static inline size_t ccm_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 static inline int ccm_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -60,14 +60,13 @@ __device__ __forceinline__ double bcast64(double v, int lane) {
 }
 // Two waves in a software pipeline: wave 0 factors column c while wave 1 does row c-1 of the forward substitution for
 // L^-1 (it needs row c-1 of L and its reciprocal pivot, both final after step c-1); one block barrier per column.
-__global__ __launch_bounds__(128) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
+// Ajj: the diagonal tile (row stride N doubles), Lg: where its inverse factor goes (64 x 64, contiguous), j: tile index for `info`
+__device__ __forceinline__ void chol_diag_body(double* Ajj, size_t N, int j, double* Lg, int* info) {
   constexpr int LR = NB + 2;   // even row stride: rows stay 16-byte aligned for the paired broadcast reads
   __shared__ __attribute__((aligned(16))) double L[NB * LR];
   __shared__ double rdiag[NB];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* Ajj = A + ((size_t)j * NB) * N + (size_t)j * NB;
-  double* Lg = Linv_all + (size_t)j * NB * NB;
   {   // each wave brings half of the rows, all its loads in flight at once (a rolled loop pays the global latency per row)
     double tmp[NB / 2];
 #pragma unroll
@@ -126,6 +125,93 @@ __global__ __launch_bounds__(128) void chol_diag_wave(double* A, int N, int j, d
 #pragma unroll
     for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
   }
+}
+__global__ __launch_bounds__(128) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
+  chol_diag_body(A + ((size_t)j * NB) * N + (size_t)j * NB, (size_t)N, j, Linv_all + (size_t)j * NB * NB, info);
+}
+
+// ---- tile-sparse, level-scheduled form (ccm_tsc_*): non-zero tiles of L stored compactly (64 x 64, row-major, contiguous), left-looking
+// (every tile GATHERS its updates, no two workgroups write one tile), so all tile columns of one elimination-tree level run in one launch.
+// One level = gather -> diagonal factor -> panel; the pose graph's nested-dissection order gives ~20-40 levels for 2000 keyframes where the
+// right-looking column-by-column form made 3 launches for each of 219 columns and their diagonal tiles (27 us each) formed one chain.
+__global__ __launch_bounds__(kTPB) void tsc_gather(double* tiles, const int* tid, int T, const int* gt, const int* gk_off, const int* gk) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int g = blockIdx.x;
+  const int i = gt[g] >> 16, j = gt[g] & 0xffff;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  for (int q = gk_off[g]; q < gk_off[g + 1]; q++) {
+    const int k = gk[q];
+    load_tile(As, tiles + (size_t)tid[(size_t)i * T + k] * (NB * NB), NB);
+    if (i != j) load_tile(Bs, tiles + (size_t)tid[(size_t)j * T + k] * (NB * NB), NB);
+    __syncthreads();
+    tile_abt(As, i != j ? Bs : As, acc, wave, lane);
+    __syncthreads();
+  }
+  double* Aij = tiles + (size_t)tid[(size_t)i * T + j] * (NB * NB);
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Aij[(size_t)(16 * wave + (lane >> 4) + 4 * r) * NB + 16 * s + (lane & 15)] -= acc[s][r];
+}
+__global__ __launch_bounds__(128) void tsc_diag(double* tiles, const int* tid, int T, const int* cols, double* Linv_all, int* info) {
+  const int j = cols[blockIdx.x];
+  chol_diag_body(tiles + (size_t)tid[(size_t)j * T + j] * (NB * NB), (size_t)NB, j, Linv_all + (size_t)j * NB * NB, info);
+}
+__global__ __launch_bounds__(kTPB) void tsc_panel(double* tiles, const int* tid, int T, const int* pt, const double* Linv_all) {
+  __shared__ double As[NB * LD], Bs[NB * LD];
+  const int i = pt[blockIdx.x] >> 16, j = pt[blockIdx.x] & 0xffff;
+  double* Aij = tiles + (size_t)tid[(size_t)i * T + j] * (NB * NB);
+  load_tile(As, Aij, NB);
+  load_tile(Bs, Linv_all + (size_t)j * NB * NB, NB);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  tile_abt(As, Bs, acc, wave, lane);
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) Aij[(size_t)(16 * wave + (lane >> 4) + 4 * r) * NB + 16 * s + (lane & 15)] = acc[s][r];
+}
+// substitutions, one workgroup per tile column of the level, thread (t, q) = (row or column of the tile, quarter of the inner index):
+//   forward   y_j = Li_j (b_j - sum_{k in row_cols(j)} L_jk y_k)        backward   x_j = Li_j^T (y_j - sum_{i in col_rows(j)} L_ij^T x_i)
+// quarter sums are added in quarter order => deterministic
+__global__ __launch_bounds__(kTPB) void tsc_subst(const double* tiles, const int* tid, int T, const int* cols, const int* l_off, const int* l_idx,
+                                                  const double* Linv_all, double* b, int backward) {
+  __shared__ double part[4][NB];
+  __shared__ double v[NB];
+  const int j = cols[blockIdx.x];
+  const int t = threadIdx.x & 63, q = threadIdx.x >> 6;
+  double s = 0;
+  for (int e = l_off[j]; e < l_off[j + 1]; e++) {
+    const int o = l_idx[e];
+    const double* bo = b + (size_t)o * NB + 16 * q;
+    if (!backward) {
+      const double* Lrow = tiles + (size_t)tid[(size_t)j * T + o] * (NB * NB) + (size_t)t * NB + 16 * q;   // L_jk, row t
+#pragma unroll
+      for (int c = 0; c < 16; c++) s += Lrow[c] * bo[c];
+    } else {
+      const double* Lcol = tiles + (size_t)tid[(size_t)o * T + j] * (NB * NB) + (size_t)(16 * q) * NB + t;   // L_ij, column t
+#pragma unroll
+      for (int r = 0; r < 16; r++) s += Lcol[(size_t)r * NB] * bo[r];
+    }
+  }
+  part[q][t] = s;
+  __syncthreads();
+  if (q == 0) v[t] = b[(size_t)j * NB + t] - (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]);
+  __syncthreads();
+  const double* Li = Linv_all + (size_t)j * NB * NB;
+  double z = 0;
+  if (!backward) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) { const int k = 16 * q + c; if (k <= t) z += Li[t * NB + k] * v[k]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 16; c++) { const int k = 16 * q + c; if (k >= t) z += Li[k * NB + t] * v[k]; }
+  }
+  part[q][t] = z;
+  __syncthreads();
+  if (q == 0) b[(size_t)j * NB + t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
 }
 
 // tile row i = j + 1 + blockIdx.x:  L_ij = A_ij * Li_jj^T   (in place)
@@ -357,6 +443,114 @@ void ccm_tile_plan_symbolic(int T, const std::vector<char>& nz_in, ccm_tile_plan
   }
 }
 
+// ---- tile-sparse Cholesky with level scheduling: plan, storage, solve ----
+template <typename Tv>
+static int tsc_up(ccm_ctx* ctx, ccm_tsc* p, const std::vector<Tv>& v, Tv** out) {
+  void* d = nullptr; size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, std::max<size_t>(v.size(), 1) * sizeof(Tv), &d, &actual)) return rc;
+  p->blocks.push_back({d, actual});
+  if (!v.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, v.data(), v.size() * sizeof(Tv), hipMemcpyHostToDevice, ctx->stream));
+  *out = (Tv*)d;
+  return CCM_OK;
+}
+int ccm_tsc_create(ccm_ctx* ctx, int T, const std::vector<char>& nz, ccm_tsc* p) {
+  if (T <= 0 || T >= 65536) return ccm_set_error(ctx, CCM_E_ARG, "tile cholesky: bad tile count");
+  ccm_tile_plan sym;
+  std::vector<int> col_rows, upd_pairs, row_cols;
+  ccm_tile_plan_symbolic(T, nz, &sym, &col_rows, &upd_pairs, &row_cols);   // fill pattern: col_rows(j) = rows below, row_cols(j) = columns left
+  p->T = T; p->owner = ctx;
+  // elimination levels: a column can be eliminated when every column it has a tile in is done
+  std::vector<int> level(T, 0);
+  int nl = 0;
+  for (int j = 0; j < T; j++) {
+    int l = 0;
+    for (int e = sym.h_row_off[j]; e < sym.h_row_off[j + 1]; e++) l = std::max(l, level[row_cols[e]] + 1);
+    level[j] = l; nl = std::max(nl, l + 1);
+  }
+  p->n_levels = nl;
+  p->tid.assign((size_t)T * T, -1);
+  int nt = 0;
+  for (int j = 0; j < T; j++) {
+    p->tid[(size_t)j * T + j] = nt++;
+    for (int e = sym.h_col_off[j]; e < sym.h_col_off[j + 1]; e++) p->tid[(size_t)col_rows[e] * T + j] = nt++;
+  }
+  p->n_tiles = nt;
+  std::vector<int> cols, gt, gk_off(1, 0), gk, pt;
+  p->lvl_col_off.assign(1, 0); p->lvl_gt_off.assign(1, 0); p->lvl_pt_off.assign(1, 0);
+  for (int l = 0; l < nl; l++) {
+    for (int j = 0; j < T; j++) {
+      if (level[j] != l) continue;
+      cols.push_back(j);
+      const int* rj = row_cols.data() + sym.h_row_off[j]; const int nj = sym.h_row_off[j + 1] - sym.h_row_off[j];
+      if (nj) { gt.push_back((j << 16) | j); for (int a = 0; a < nj; a++) gk.push_back(rj[a]); gk_off.push_back((int)gk.size()); }
+      for (int e = sym.h_col_off[j]; e < sym.h_col_off[j + 1]; e++) {
+        const int i = col_rows[e];
+        pt.push_back((i << 16) | j);
+        const int* ri = row_cols.data() + sym.h_row_off[i]; const int ni = sym.h_row_off[i + 1] - sym.h_row_off[i];
+        const size_t before = gk.size();
+        for (int a = 0, b = 0; a < ni && b < nj;) {   // columns k < j where both L_ik and L_jk are non-zero
+          if (ri[a] == rj[b]) { gk.push_back(ri[a]); a++; b++; } else if (ri[a] < rj[b]) a++; else b++;
+        }
+        if (gk.size() > before) { gt.push_back((i << 16) | j); gk_off.push_back((int)gk.size()); }
+      }
+    }
+    p->lvl_col_off.push_back((int)cols.size()); p->lvl_gt_off.push_back((int)gt.size()); p->lvl_pt_off.push_back((int)pt.size());
+  }
+  if (int rc = tsc_up(ctx, p, p->tid, &p->d_tid)) return rc;
+  if (int rc = tsc_up(ctx, p, cols, &p->d_cols)) return rc;
+  if (int rc = tsc_up(ctx, p, gt, &p->d_gt)) return rc;
+  if (int rc = tsc_up(ctx, p, gk_off, &p->d_gk_off)) return rc;
+  if (int rc = tsc_up(ctx, p, gk, &p->d_gk)) return rc;
+  if (int rc = tsc_up(ctx, p, pt, &p->d_pt)) return rc;
+  if (int rc = tsc_up(ctx, p, sym.h_row_off, &p->d_rc_off)) return rc;
+  if (int rc = tsc_up(ctx, p, row_cols, &p->d_rc)) return rc;
+  if (int rc = tsc_up(ctx, p, sym.h_col_off, &p->d_cr_off)) return rc;
+  if (int rc = tsc_up(ctx, p, col_rows, &p->d_cr)) return rc;
+  std::vector<double> none;
+  void* d = nullptr; size_t actual = 0;
+  if (int rc = ccm_pool_get(ctx, (size_t)nt * NB * NB * sizeof(double), &d, &actual)) return rc;
+  p->blocks.push_back({d, actual}); p->d_tiles = (double*)d;
+  if (int rc = ccm_pool_get(ctx, (size_t)T * NB * NB * sizeof(double), &d, &actual)) return rc;
+  p->blocks.push_back({d, actual}); p->d_linv = (double*)d;
+  if (int rc = ccm_pool_get(ctx, 256, &d, &actual)) return rc;
+  p->blocks.push_back({d, actual}); p->d_info = (int*)d;
+  return CCM_OK;
+}
+void ccm_tsc_destroy(ccm_ctx* ctx, ccm_tsc* p) {
+  for (auto& b : p->blocks) ccm_pool_put(ctx, b.first, b.second);
+  p->blocks.clear();
+}
+ccm_tsc::~ccm_tsc() { if (owner) ccm_tsc_destroy(owner, this); }
+int ccm_tsc_clear(ccm_ctx* ctx, ccm_tsc* p) {
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(p->d_tiles, 0, (size_t)p->n_tiles * NB * NB * sizeof(double), ctx->stream));
+  return CCM_OK;
+}
+// factorises the tiles in place and solves for d_b ([64 T], in: rhs, out: x); *d_info = first non-positive pivot + 1 or 0
+int ccm_tsc_solve(ccm_ctx* ctx, ccm_tsc* p, double* d_b) {
+  const int T = p->T;
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(p->d_info, 0, sizeof(int), ctx->stream));
+  for (int l = 0; l < p->n_levels; l++) {
+    const int c0 = p->lvl_col_off[l], nc = p->lvl_col_off[l + 1] - c0;
+    const int g0 = p->lvl_gt_off[l], ng = p->lvl_gt_off[l + 1] - g0;
+    const int p0 = p->lvl_pt_off[l], np = p->lvl_pt_off[l + 1] - p0;
+    if (ng) hipLaunchKernelGGL(tsc_gather, dim3(ng), dim3(kTPB), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_gt + g0, (const int*)p->d_gk_off + g0, (const int*)p->d_gk);
+    hipLaunchKernelGGL(tsc_diag, dim3(nc), dim3(128), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0, p->d_linv, p->d_info);
+    if (np) hipLaunchKernelGGL(tsc_panel, dim3(np), dim3(kTPB), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_pt + p0, (const double*)p->d_linv);
+  }
+  for (int l = 0; l < p->n_levels; l++) {
+    const int c0 = p->lvl_col_off[l], nc = p->lvl_col_off[l + 1] - c0;
+    hipLaunchKernelGGL(tsc_subst, dim3(nc), dim3(kTPB), 0, ctx->stream, (const double*)p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0,
+                       (const int*)p->d_rc_off, (const int*)p->d_rc, (const double*)p->d_linv, d_b, 0);
+  }
+  for (int l = p->n_levels - 1; l >= 0; l--) {
+    const int c0 = p->lvl_col_off[l], nc = p->lvl_col_off[l + 1] - c0;
+    hipLaunchKernelGGL(tsc_subst, dim3(nc), dim3(kTPB), 0, ctx->stream, (const double*)p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0,
+                       (const int*)p->d_cr_off, (const int*)p->d_cr, (const double*)p->d_linv, d_b, 1);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
 // Test hook: host matrix (n x n row-major, symmetric positive definite) and rhs in, solution out.
 extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info) {
   if (!ctx || !A || !b || !x || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_dense_solve: bad args");
@@ -382,6 +576,44 @@ extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double
     for (int i = 0; i < n; i++) x[i] = bp[i];
   }
   hipFree(dA); hipFree(db); hipFree(dl); hipFree(di);
+  return rc;
+}
+
+// Test hook for the tile-sparse, level-scheduled form: the tile pattern is taken from the non-zeros of the host matrix (its fill is added
+// symbolically), the matrix is scattered into the compact tile storage, factored and solved.  *levels / *tiles report the plan.
+extern "C" int ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles) {
+  if (!ctx || !A || !b || !x || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_tile_solve: bad args");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int N = ((n + NB - 1) / NB) * NB, T = N / NB;
+  std::vector<char> nz((size_t)T * T, 0);
+  for (int i = 0; i < n; i++) for (int c = 0; c <= i; c++) if (A[(size_t)i * n + c] != 0.0) nz[(size_t)(i / NB) * T + c / NB] = 1;
+  for (int t = 0; t < T; t++) nz[(size_t)t * T + t] = 1;
+  ccm_tsc p;
+  if (int rc = ccm_tsc_create(ctx, T, nz, &p)) return rc;
+  std::vector<double> ht((size_t)p.n_tiles * NB * NB, 0.0), hb(N, 0.0);
+  for (int i = 0; i < N; i++) {
+    if (i >= n) { ht[(size_t)p.tid[(size_t)(i / NB) * T + i / NB] * NB * NB + (size_t)(i % NB) * (NB + 1)] = 1.0; continue; }
+    hb[i] = b[i];
+    for (int c = 0; c <= i; c++) {
+      const double v = A[(size_t)i * n + c];
+      if (v != 0.0) ht[(size_t)p.tid[(size_t)(i / NB) * T + c / NB] * NB * NB + (size_t)(i % NB) * NB + c % NB] = v;
+    }
+  }
+  double* db = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&db, N * sizeof(double)));
+  hipMemcpyAsync(p.d_tiles, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(db, hb.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  int rc = ccm_tsc_solve(ctx, &p, db);
+  if (rc == CCM_OK) {
+    hipMemcpyAsync(hb.data(), db, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(info, p.d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_debug_tile_solve: sync");
+    for (int i = 0; i < n; i++) x[i] = hb[i];
+  }
+  if (levels) *levels = p.n_levels;
+  if (tiles) *tiles = p.n_tiles;
+  hipStreamSynchronize(ctx->stream);
+  hipFree(db);
   return rc;
 }
 

@@ -623,6 +623,88 @@ __global__ __launch_bounds__(kTPB) void pg_dense_fill(PgDev d, const int* blk_a,
   if (i < N) { rhs[i] = (i < n) ? d.b[i] : 0.0; if (i >= n) A[(size_t)i * N + i] = 1.0; }
 }
 
+// tile-sparse form (ccm_tsc): vertex a sits at dense offset dpos[a] (nested-dissection order, pieces padded to whole tiles); only tiles of the
+// lower triangle exist; padding unknowns (dsrc < 0) get a unit diagonal
+__global__ __launch_bounds__(kTPB) void pg_tile_fill(PgDev d, const int* blk_a, const int* blk_b, const int* dpos, const int* dsrc, const int* tid, int T, double* tiles,
+                                                     double* rhs, double lambda, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.nBlk * 49) {
+    const int k = i / 49, el = i % 49, p = el / 7, q = el % 7;
+    const int a = blk_a[k], b = blk_b[k];
+    double v = d.H[i];
+    if (a == b && p == q) v += lambda;
+    const int ra = dpos[a] + p, rb = dpos[b] + q;
+    const int ta = ra >> 6, tb = rb >> 6;
+    if (ta >= tb) tiles[(size_t)tid[(size_t)ta * T + tb] * 4096 + (size_t)(ra & 63) * 64 + (rb & 63)] = v;
+    if (a != b && tb >= ta) tiles[(size_t)tid[(size_t)tb * T + ta] * 4096 + (size_t)(rb & 63) * 64 + (ra & 63)] = v;
+  }
+  if (i < N) {
+    const int src = dsrc[i];
+    rhs[i] = src >= 0 ? d.b[src] : 0.0;
+    if (src < 0) tiles[(size_t)tid[(size_t)(i >> 6) * T + (i >> 6)] * 4096 + (size_t)(i & 63) * 65] = 1.0;
+  }
+}
+__global__ __launch_bounds__(kTPB) void pg_tile_extract(const double* rhs, const int* dsrc, int N, double* x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N && dsrc[i] >= 0) x[dsrc[i]] = rhs[i];
+}
+
+// Nested-dissection order of the free vertices for the tile-sparse factorisation: recursive bisection by the middle level of a BFS from a
+// pseudo-peripheral vertex (essential graphs are chains with short covisibility links and a few loop edges: a BFS level is a handful of
+// keyframes); pieces = leaves (<= leaf vertices, BFS order: banded inside) and separators, emitted children first, separator after them.
+// Every piece starts on a tile boundary (64 unknowns) so that sibling subtrees share no tile and eliminate in parallel.
+static void pg_nd_order(int F, const std::vector<std::vector<int>>& adj, int leaf, std::vector<std::vector<int>>* pieces) {
+  std::vector<int> mark(F, -1), dist(F, 0), queue;
+  int stamp = 0;
+  // BFS inside the vertex set tagged `tag` in `mark`; returns the visit order, dist[] filled
+  auto bfs = [&](int start, int tag, std::vector<int>& order) {
+    order.clear(); order.push_back(start); dist[start] = 0; mark[start] = tag + 1;   // tag + 1 = visited in this pass
+    for (size_t h = 0; h < order.size(); h++) {
+      const int u = order[h];
+      for (int v : adj[u]) if (mark[v] == tag) { mark[v] = tag + 1; dist[v] = dist[u] + 1; order.push_back(v); }
+    }
+  };
+  std::vector<std::vector<int>> stack;
+  {
+    std::vector<int> all(F);
+    for (int a = 0; a < F; a++) all[a] = a;
+    stack.push_back(all);
+  }
+  // explicit recursion: entries are either vertex sets to dissect or (flagged by a leading -1) finished pieces to emit in order
+  std::vector<int> order, order2;
+  while (!stack.empty()) {
+    std::vector<int> S = std::move(stack.back()); stack.pop_back();
+    if (!S.empty() && S[0] == -1) { pieces->emplace_back(S.begin() + 1, S.end()); continue; }
+    if (S.empty()) continue;
+    const int tag = (stamp += 2);
+    for (int v : S) mark[v] = tag;
+    bfs(S[0], tag, order);
+    if (order.size() < S.size()) {   // disconnected: this component now, the rest later (no separator between them)
+      std::vector<int> rest;
+      for (int v : S) if (mark[v] == tag) rest.push_back(v);
+      stack.push_back(rest);
+      stack.push_back(order);
+      continue;
+    }
+    // pseudo-peripheral start: restart from the last vertex reached
+    for (int v : S) mark[v] = tag;
+    bfs(order.back(), tag, order2);
+    if ((int)S.size() <= leaf) { order2.insert(order2.begin(), -1); stack.push_back(order2); continue; }
+    const int depth = dist[order2.back()];
+    if (depth < 2) { order2.insert(order2.begin(), -1); stack.push_back(order2); continue; }   // a clique-like blob: no useful separator
+    // middle level by vertex count
+    std::vector<int> cnt(depth + 1, 0);
+    for (int v : order2) cnt[dist[v]]++;
+    int m = 1, acc = cnt[0];
+    while (m < depth - 1 && acc + cnt[m] < (int)S.size() / 2) { acc += cnt[m]; m++; }
+    std::vector<int> A, B, sep(1, -1);
+    for (int v : order2) { if (dist[v] < m) A.push_back(v); else if (dist[v] == m) sep.push_back(v); else B.push_back(v); }
+    stack.push_back(sep);   // popped last: after both halves
+    stack.push_back(B);
+    stack.push_back(A);
+  }
+}
+
 typedef std::vector<std::pair<void*, size_t>> PgAllocs;   // pooled blocks (ccm_pool_get / ccm_pool_put)
 template <typename T>
 int up(ccm_ctx* ctx, PgAllocs& allocs, const std::vector<T>& v, T** out) {
@@ -776,9 +858,40 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   const size_t n_dense = 7 * (size_t)F;
   const int N_dense = (int)((n_dense + 63) / 64) * 64;
   const bool use_dense = !(solver_env && !strcmp(solver_env, "pcg")) && n_dense <= 24000;
+  // exact solver, default form: tile-sparse, level-scheduled Cholesky over a nested-dissection order (ccm_tsc); CCM_PG_SOLVER=dense keeps the
+  // round-1 form (dense array, natural order, one tile column after the other) for comparison
+  const bool use_tiles = use_dense && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL");
   double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
   ccm_tile_plan plan;
-  if (use_dense) {
+  ccm_tsc tsc;
+  int *d_dpos = nullptr, *d_dsrc = nullptr;
+  int N_tiles = 0;
+  if (use_tiles) {
+    std::vector<int> ka(nBlk), kb(nBlk);
+    for (int k = 0; k < nBlk; k++) { ka[k] = keys[k].first; kb[k] = keys[k].second; }
+    PG_RC(up(ctx, allocs, ka, &d_blk_a)); PG_RC(up(ctx, allocs, kb, &d_blk_b));
+    std::vector<std::vector<int>> adj(F);
+    for (int k = 0; k < nBlk; k++) if (ka[k] != kb[k]) { adj[ka[k]].push_back(kb[k]); adj[kb[k]].push_back(ka[k]); }
+    std::vector<std::vector<int>> pieces;
+    static const int nd_leaf = getenv("CCM_PG_ND_LEAF") ? atoi(getenv("CCM_PG_ND_LEAF")) : 31;   // 31 vertices = 217 unknowns = 4 tiles (2000 keyframes: leaf 31: 17.2 ms / 11 levels, 63: 18.9 / 13, 127: 23.4 / 19)
+    pg_nd_order(F, adj, std::max(nd_leaf, 9), &pieces);
+    std::vector<int> dpos(F, 0), dsrc;
+    for (auto& pc : pieces) {
+      for (int v : pc) { dpos[v] = (int)dsrc.size(); for (int c = 0; c < 7; c++) dsrc.push_back(7 * v + c); }
+      while (dsrc.size() % 64) dsrc.push_back(-1);
+    }
+    N_tiles = (int)dsrc.size();
+    const int T = N_tiles / 64;
+    std::vector<char> nz((size_t)T * T, 0);
+    for (int t = 0; t < T; t++) nz[(size_t)t * T + t] = 1;
+    for (int k = 0; k < nBlk; k++) {
+      const int a0 = dpos[ka[k]] / 64, a1 = (dpos[ka[k]] + 6) / 64, b0 = dpos[kb[k]] / 64, b1 = (dpos[kb[k]] + 6) / 64;
+      for (int ta = a0; ta <= a1; ta++) for (int tb = b0; tb <= b1; tb++) nz[(size_t)std::max(ta, tb) * T + std::min(ta, tb)] = 1;
+    }
+    PG_RC(ccm_tsc_create(ctx, T, nz, &tsc));
+    PG_RC(up(ctx, allocs, dpos, &d_dpos)); PG_RC(up(ctx, allocs, dsrc, &d_dsrc)); PG_RC(al(ctx, allocs, (size_t)N_tiles, &d_rhs));
+    if (getenv("CCM_PG_DBG")) fprintf(stderr, "[ccm_pg] tile-sparse cholesky: %d unknowns in %d pieces -> %d tiles columns, %d non-zero tiles, %d levels\n", (int)n_dense, (int)pieces.size(), T, tsc.n_tiles, tsc.n_levels);
+  } else if (use_dense) {
     std::vector<int> ka(nBlk), kb(nBlk);
     for (int k = 0; k < nBlk; k++) { ka[k] = keys[k].first; kb[k] = keys[k].second; }
     PG_RC(up(ctx, allocs, ka, &d_blk_a)); PG_RC(up(ctx, allocs, kb, &d_blk_b));
@@ -822,7 +935,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[0])); PG_RC(al(ctx, allocs, (size_t)std::max(d.n_wg_upd, n_wg_init), &d.prz[1]));
   PG_RC(al(ctx, allocs, 8, &d.scal)); PG_RC(al(ctx, allocs, 4, &d.flag));
   PG_RC(al(ctx, allocs, (size_t)std::max({d.n_wg_edge, n_wg_v, 1}), &d.part));
-  auto cleanup = [&]() { hipStreamSynchronize(ctx->stream); for (auto& p : allocs) ccm_pool_put(ctx, p.first, p.second); };
+  auto cleanup = [&]() { hipStreamSynchronize(ctx->stream); for (auto& p : allocs) ccm_pool_put(ctx, p.first, p.second); if (use_tiles) ccm_tsc_destroy(ctx, &tsc); };
   auto read_scal = [&](int idx, double* out) -> int {
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, d.scal + idx, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -863,6 +976,16 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
       const size_t lds_pc = (7 * (size_t)F + 1024 + 16) * sizeof(double);
       if (use_dense) {
         int info = 0;
+        if (use_tiles) {
+          if ((rc = ccm_tsc_clear(ctx, &tsc))) break;
+          hipLaunchKernelGGL(pg_tile_fill, dim3(ccm_div_up(std::max(nBlk * 49, N_tiles), kTPB)), dim3(kTPB), 0, ctx->stream, d, d_blk_a, d_blk_b, (const int*)d_dpos,
+                             (const int*)d_dsrc, (const int*)tsc.d_tid, tsc.T, tsc.d_tiles, d_rhs, lambda, N_tiles);
+          if ((rc = ccm_tsc_solve(ctx, &tsc, d_rhs))) break;
+          hipLaunchKernelGGL(pg_tile_extract, dim3(ccm_div_up(N_tiles, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)d_rhs, (const int*)d_dsrc, N_tiles, d.x);
+          if (hipMemcpyAsync(&info, tsc.d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: tile solve readback"); break;
+          }
+        } else {
         hipMemsetAsync(d_A, 0, (size_t)N_dense * N_dense * sizeof(double), ctx->stream);
         hipLaunchKernelGGL(pg_dense_fill, dim3(ccm_div_up(std::max(nBlk * 49, N_dense), kTPB)), dim3(kTPB), 0, ctx->stream, d, d_blk_a, d_blk_b, d_A, d_rhs,
                            lambda, N_dense);
@@ -870,6 +993,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
         if (hipMemcpyAsync(d.x, d_rhs, n_dense * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
           rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: dense solve readback"); break;
+        }
         }
         const bool ok_d = info == 0;     // > 0: leading minor not positive definite -> solver failure, LM rejects the step
         if (!ok_d) hipMemsetAsync(d.x, 0, 7 * (size_t)F * sizeof(double), ctx->stream);

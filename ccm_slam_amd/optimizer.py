@@ -230,6 +230,15 @@ def debug_dense_solve(ctx: Context, A, b):
     return x, info.value
 
 
+def debug_tile_solve(ctx: Context, A, b):
+    """Test hook: SPD solve through the tile-sparse, level-scheduled Cholesky (ccm_debug_tile_solve); returns (x, info, levels, tiles)."""
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b); info = C.c_int(0); levels = C.c_int(0); tiles = C.c_int(0)
+    check(lib().ccm_debug_tile_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info),
+                                     C.byref(levels), C.byref(tiles)), ctx.handle)
+    return x, info.value, levels.value, tiles.value
+
+
 def debug_dense_inverse(ctx: Context, A):
     """Test hook: explicit SPD inverse through the tile kernels of dense_chol.hip (ccm_debug_dense_inverse)."""
     A = np.ascontiguousarray(A, np.float64)

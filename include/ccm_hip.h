@@ -353,6 +353,10 @@ int  ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3 /* n_vert x 
 /* test hook for the dense f64 Cholesky (MFMA tiles) behind ccm_pose_graph_optimize: solves A x = b for a host matrix
  * (n x n row-major, symmetric positive definite); *info = 0 or (first non-positive pivot + 1). */
 int  ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info);
+/* test hook for the tile-sparse, level-scheduled form of the same factorisation (what ccm_pose_graph_optimize uses by default): only the
+ * non-zero 64 x 64 tiles of the factor are stored, tile columns of one elimination level run in one launch; the tile pattern is taken from
+ * the non-zeros of A.  levels / tiles (nullable) receive the plan's level and tile counts. */
+int  ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles);
 /* same machinery, explicit inverse (used for the coarse level of the BA preconditioner) */
 int  ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info);
 

@@ -1,8 +1,8 @@
 """Essential-graph optimisation on the device (ccm_pose_graph_optimize) vs the oracle restatement of what
 Optimizer::OptimizeEssentialGraph{LoopClosure,MapFusion} hand to g2o (oracle/ba_ref.cpp: ora_pose_graph_optimize).
 
-Tolerance: f64 LM with numerically differentiated 7x7 Jacobians (delta 1e-9 amplifies rounding by 5e8) and an inexact
-reduced solve (block-Jacobi PCG, relative tolerance 1e-10, vs the oracle's block Cholesky).  Near convergence the
+Tolerance: f64 LM with numerically differentiated 7x7 Jacobians (delta 1e-9 amplifies rounding by 5e8); the linear solve is exact on both
+sides (device: tile-sparse Cholesky over a nested-dissection order; oracle: block Cholesky in natural order), so only rounding differs.  Near convergence the
 accept / reject decision of a trial can depend on differences of that size, so the trial COUNT is not compared; the
 optimised Sim3s must agree to 1e-5 (rotation / scale) and 1e-5 m, the final chi2 to 1e-6 of the initial chi2."""
 import numpy as np
@@ -69,6 +69,54 @@ def test_dense_mfma_cholesky_solves_spd_systems(ctx, n):
     assert info == 0
     ref = np.linalg.solve(A, b)
     assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()) * n
+
+
+def _spd_with_pattern(n, mask, seed):
+    rng = np.random.default_rng(seed)
+    M = rng.normal(size=(n, n)) * mask
+    A = M + M.T
+    A += np.diag(np.abs(A).sum(axis=1) + 1.0)      # diagonally dominant => SPD
+    return A, rng.normal(size=n)
+
+
+@pytest.mark.parametrize("kind,n", [("dense", 200), ("banded", 1000), ("bordered", 900), ("one_tile", 40)])
+def test_tile_sparse_level_scheduled_cholesky(ctx, kind, n):
+    """ccm_tsc (what ccm_pose_graph_optimize factors with): compact non-zero tiles, left-looking gathers, all tile columns of an elimination
+    level per launch.  Dense: one column per level; banded: a chain; bordered block-diagonal (nested-dissection shape): the diagonal blocks
+    share levels, i.e. FEWER levels than tile columns."""
+    idx = np.arange(n)
+    if kind in ("dense", "one_tile"): mask = np.ones((n, n))
+    elif kind == "banded": mask = (np.abs(idx[:, None] - idx[None, :]) <= 90).astype(float)
+    else:
+        blk = np.minimum(idx // 192, 3)                # four diagonal blocks of three tiles, then a border
+        border = idx >= 768
+        mask = ((blk[:, None] == blk[None, :]) | border[:, None] | border[None, :]).astype(float)
+    A, b = _spd_with_pattern(n, mask, n)
+    x, info, levels, tiles = optimizer.debug_tile_solve(ctx, A, b)
+    assert info == 0
+    ref = np.linalg.solve(A, b)
+    assert np.abs(x - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max()) * n
+    T = (n + 63) // 64
+    if kind == "dense": assert levels == T and tiles == T * (T + 1) // 2
+    if kind == "banded": assert levels == T and tiles < T * (T + 1) // 2
+    if kind == "bordered": assert levels == 3 + (T - 12) and tiles == 4 * 6 + (T - 12) * 12 + (T - 12) * (T - 11) // 2
+
+
+def test_tile_cholesky_reports_a_non_positive_pivot(ctx):
+    A = np.eye(200); A[140, 140] = -1.0
+    x, info, _, _ = optimizer.debug_tile_solve(ctx, A, np.ones(200))
+    assert info == 141
+
+
+def test_pose_graph_nested_dissection_matches_the_natural_order_solver(ctx, monkeypatch):
+    """500 keyframes: the default exact solver (nested-dissection order, tile-sparse level-scheduled Cholesky) against the round-1 form
+    (natural order, dense array, column after column): same LM iterations and trials, Sim3s within 1e-7."""
+    pg = synth.make_pose_graph(500, 2, covis=6)
+    s1, st1 = optimizer.pose_graph_optimization(ctx, pg)
+    monkeypatch.setenv("CCM_PG_SOLVER", "dense")
+    s0, st0 = optimizer.pose_graph_optimization(ctx, pg)
+    assert (st1.iters_done, st1.lm_trials) == (st0.iters_done, st0.lm_trials)
+    assert np.abs(s1 - s0).max() < 1e-7, np.abs(s1 - s0).max()
 
 
 def test_dense_cholesky_reports_a_non_positive_pivot(ctx):
