@@ -74,6 +74,27 @@ def local_ba_leg(ctx, with_cpu, reps=5):
     return out
 
 
+def pose_graph_leg(ctx, with_cpu, reps=3):
+    """Essential-graph optimisation as loop closing / map fusion call it (Optimizer::OptimizeEssentialGraph*, Optimizer.cpp:1122-1480): one
+    ccm_pose_graph_optimize call (structure build, LM to g2o's stop rule, download) on a 2000-keyframe graph with loop edges, best of `reps`."""
+    from ccm_slam_amd import optimizer, synth
+    pg = synth.make_pose_graph(2000, 0, covis=6)
+    best = None
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        s, st = optimizer.pose_graph_optimization(ctx, pg)
+        dt = time.perf_counter() - t0
+        if r > 0: best = dt if best is None else min(best, dt)
+    out = {"pose_graph_ms": round(best * 1e3, 2),
+           "pose_graph_workload": f"2000 keyframes / {pg['n_edge']} Sim3 edges, {st.iters_done} LM iterations / {st.lm_trials} trials, exact tile-sparse Cholesky (nested dissection)"}
+    if with_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        oracle.pose_graph_optimize(pg)
+        out["pose_graph_cpu_port_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    return out
+
+
 def tracking_leg(ctx, with_cpu, n_frames=32):
     """Per-frame cost of the agent-side hot path on one GPU, synthetic EuRoC-shaped stream (752x480, 1000 ORB features),
     through the host API (PCIe included), in the order Tracking runs it: ORB extraction; Frame construction (undistort +
@@ -394,6 +415,7 @@ def main():
         extra = tracking_leg(ctx, with_cpu=(world == 1 and not args.no_cpu_baseline))
         if world == 1:   # per-agent figure, independent of N; a single-rank solve has no business inside a sharded job's timing run
             extra.update(local_ba_leg(ctx, with_cpu=not args.no_cpu_baseline))
+            extra.update(pose_graph_leg(ctx, with_cpu=not args.no_cpu_baseline))
 
     if rank == 0:
         out = {
