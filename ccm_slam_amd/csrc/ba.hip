@@ -72,12 +72,33 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= kTPB/kWa
   return s;
 }
 
-// sum of an array of partials, identical result in every lane of every wave (fixed order)
-__device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n) {
-  const int lane = threadIdx.x & (kWave - 1);
-  double s = 0;
-  for (int i = lane; i < n; i += kWave) s += p[i];
-  return wave_sum(s);
+// Sums of NS arrays of per-workgroup partials, identical result in every thread of every workgroup (fixed order: thread-strided partial
+// sums with four loads in flight, wave tree, waves in order).  The whole workgroup shares the work: with every WAVE summing all partials on its
+// own (one load in flight per lane) the 10 000-keyframe map spent ~45 us of each ba_pcg_update and ~20 us of each ba_pcg_spmv on 6 000 /
+// 2 500 serial L2 round trips before touching its rows.  red: LDS scratch [NS][kTPB / kWave]; contains a block barrier.
+template <int NS, int TPB = kTPB>
+__device__ __forceinline__ void block_sum_partials(const double* const (&p)[NS], const int (&n)[NS], double (&out)[NS], double* red) {
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int i = t;
+    for (; i + 3 * TPB < n[q]; i += 4 * TPB) {
+      const double v0 = p[q][i], v1 = p[q][i + TPB], v2 = p[q][i + 2 * TPB], v3 = p[q][i + 3 * TPB];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; i < n[q]; i += TPB) a0 += p[q][i];
+    const double w = wave_sum((a0 + a1) + (a2 + a3));
+    if (lane == 0) red[q * (TPB / kWave) + wv] = w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NS; q++) {
+    double tot = red[q * (TPB / kWave)];
+#pragma unroll
+    for (int w = 1; w < TPB / kWave; w++) tot += red[q * (TPB / kWave) + w];
+    out[q] = tot;
+  }
 }
 
 struct BaDev {
@@ -711,31 +732,43 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // (the start kernel of this path, ba_pcg_init_tiles, is defined after the cluster factorisation it shares with the persistent kernel)
 
 // iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
-// Workgroup = 4 waves = 2 block rows, TWO waves per row: the row product is a chain of dependent loads
-// (index -> block -> vector), so splitting a row's blocks over two waves halves that chain; each wave keeps 8
-// blocks in flight (lane = g*8 + r: group g takes every 16th block starting at its own offset, r is the block row).
-constexpr int kRowsPerWG = 2;
-__global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
+// TWO waves per block row: the row product is a chain of dependent loads (index -> block -> vector), so splitting a row's blocks over two
+// waves halves that chain; each wave keeps 8 blocks in flight (lane = g*8 + r: group g takes every 16th block starting at its own offset,
+// r is the block row).  Workgroup = 16 waves = 8 rows: measured on the 10 000-keyframe map (rocprofv3), a launch costs ~10 us of dependent
+// round trips plus ~10 ns per WORKGROUP dispatched, whatever the workgroups do (a pass that only adds six numbers per row: 20 us for 2 500
+// workgroups), so 5 000 two-row workgroups spent most of the kernel being dispatched.  (Also measured and dropped: a two-pass symmetric
+// form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
+constexpr int kSpmvTPB = 1024;
+constexpr int kRowsPerWG = kSpmvTPB / (2 * kWave);
+__global__ __launch_bounds__(kSpmvTPB) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
+  __shared__ double redp[4 * (kSpmvTPB / kWave)];
   if (d.pcg_flag[0]) return;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int rl = wv >> 1, h = wv & 1;            // local row, half
   // XCD-aware row assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give
   // XCD x the CONTIGUOUS row chunk x: covisible cameras are close in index, hence a block S_ij and its mirror use
-  // (row i and, transposed, row j) are read by the same XCD and the second read hits that XCD's 4 MiB L2.
+  // (row i and, transposed, row j) are read by the same XCD and the second read can hit that XCD's 4 MiB L2.
   const int per_xcd = gridDim.x >> 3;            // grid is padded to a multiple of 8 workgroups
   const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const int i = wg * kRowsPerWG + rl;
-  double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
-  if (d.mk_on) rz_k += sum_partials(d.mk_cry[k & 1], d.n_wg_upd);
-  double beta = 0;
-  if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
-  else {
-    double rz_prev = sum_partials(d.prz[(k + 1) & 1], d.n_wg_upd);
-    if (d.mk_on) rz_prev += sum_partials(d.mk_cry[(k + 1) & 1], d.n_wg_upd);
-    beta = rz_k / rz_prev;
+  double rz_k, beta = 0;
+  {
+    const int nco = d.mk_on ? d.n_wg_upd : 0, npr = k ? d.n_wg_upd : 0;
+    const double* const ps[4] = {d.prz[k & 1], d.mk_cry[k & 1], d.prz[(k + 1) & 1], d.mk_cry[(k + 1) & 1]};
+    const int ns[4] = {d.n_wg_upd, nco, npr, k ? nco : 0};
+    double sm[4];
+    block_sum_partials<4, kSpmvTPB>(ps, ns, sm, redp);
+    rz_k = sm[0];
+    if (d.mk_on) rz_k += sm[1];
+    if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
+    else {
+      double rz_prev = sm[2];
+      if (d.mk_on) rz_prev += sm[3];
+      beta = rz_k / rz_prev;
+    }
   }
   const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
   // convergence test (identical in every workgroup): sqrt(rz_k / rz_0) <= rel_tol, or exact zero residual
@@ -787,14 +820,19 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_spmv(BaDev d, int k) {
     if (lane == 0) lds[rl] = pq;
   } else if (h == 0 && lane == 0) lds[rl] = 0.0;
   __syncthreads();
-  if (threadIdx.x == 0) d.ppq[wg] = lds[0] + lds[1];
+  if (threadIdx.x == 0) {
+    double tot = lds[0];
+#pragma unroll
+    for (int q = 1; q < kRowsPerWG; q++) tot += lds[q];
+    d.ppq[wg] = tot;
+  }
 }
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
 // one workgroup per cluster
 __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   __shared__ double rc[kCluN];
-  __shared__ double zpart[2][kCluN];
+  __shared__ double zpart[4][kCluN];
   __shared__ double red[kTPB / kWave];
   const int t = threadIdx.x, c = blockIdx.x;
   const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
@@ -805,9 +843,17 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   const size_t g = 6 * (size_t)s0 + t;
   double xv = 0, rv = 0, qv = 0, pv = 0;
   if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g]; }
-  double rz_k = sum_partials(d.prz[k & 1], d.n_wg_upd);
-  if (d.mk_on) rz_k += sum_partials(d.mk_cry[k & 1], d.n_wg_upd);
-  const double pq = sum_partials(d.ppq, d.n_wg_spmv);
+  __shared__ double redp[3 * (kTPB / kWave)];
+  double rz_k, pq;
+  {
+    const double* const ps[3] = {d.prz[k & 1], d.mk_cry[k & 1], d.ppq};
+    const int ns[3] = {d.n_wg_upd, d.mk_on ? d.n_wg_upd : 0, d.n_wg_spmv};
+    double sm[3];
+    block_sum_partials<3>(ps, ns, sm, redp);
+    rz_k = sm[0];
+    if (d.mk_on) rz_k += sm[1];
+    pq = sm[2];
+  }
   if (done) return;
   if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = 1; }
@@ -819,30 +865,29 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
     rv -= alpha * qv;
     d.r[g] = rv;
     rc[t] = rv;
-  }
+  } else if (t < kCluN) rc[t] = 0.0;
   __syncthreads();
-  // z = W r_c : two threads per output row (halves of the column range); W is symmetric, so reading W[col][row]
-  // makes consecutive threads touch consecutive addresses
+  // z = W r_c: thread (rp, seg) = (t % 48, t / 48) takes rows 2 rp, 2 rp + 1 and the columns [24 seg, 24 seg + 24); W is symmetric, so W[col][row]
+  // puts consecutive threads on consecutive addresses, and the 24 16-byte loads of a thread are all in flight at once: the whole 74 KB block
+  // of the cluster arrives in ONE memory round trip (two threads per row with 8 loads in flight took six; rocprofv3: 13.5 us per launch on the
+  // 10 000-keyframe map).  Rows / columns beyond a short last cluster: W is the identity there and r is zero.
   const double* W = d.Wc + (size_t)c * kCluN * kCluN;
-  if (t < 2 * m) {
-    const int row = t % m, half = t / m;
-    const int c0 = half ? m / 2 : 0, c1 = half ? m : m / 2;
-    // 8 independent loads in flight per thread: the mat-vec is latency bound otherwise (W comes from L2 / MALL)
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int col = c0;
-    for (; col + 8 <= c1; col += 8) {
-      const double w0 = W[(col + 0) * kCluN + row], w1 = W[(col + 1) * kCluN + row], w2 = W[(col + 2) * kCluN + row], w3 = W[(col + 3) * kCluN + row];
-      const double w4 = W[(col + 4) * kCluN + row], w5 = W[(col + 5) * kCluN + row], w6 = W[(col + 6) * kCluN + row], w7 = W[(col + 7) * kCluN + row];
-      s0 += w0 * rc[col] + w4 * rc[col + 4]; s1 += w1 * rc[col + 1] + w5 * rc[col + 5];
-      s2 += w2 * rc[col + 2] + w6 * rc[col + 6]; s3 += w3 * rc[col + 3] + w7 * rc[col + 7];
-    }
-    for (; col < c1; col++) s0 += W[col * kCluN + row] * rc[col];
-    zpart[half][row] = (s0 + s1) + (s2 + s3);
+  if (t < 192) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int rp = t % 48, seg = t / 48;
+    const v2d* Wp = reinterpret_cast<const v2d*>(W + (size_t)(24 * seg) * kCluN + 2 * rp);
+    v2d w[24];
+#pragma unroll
+    for (int q = 0; q < 24; q++) w[q] = Wp[(size_t)q * (kCluN / 2)];
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int q = 0; q < 24; q++) { const double rq = rc[24 * seg + q]; s0 += w[q][0] * rq; s1 += w[q][1] * rq; }
+    zpart[seg][2 * rp] = s0; zpart[seg][2 * rp + 1] = s1;
   }
   __syncthreads();
   double rz = 0;
   if (t < m) {
-    const double z = zpart[0][t] + zpart[1][t];
+    const double z = ((zpart[0][t] + zpart[1][t]) + zpart[2][t]) + zpart[3][t];
     d.z[g] = z;
     rz = rc[t] * z;
   }
@@ -878,12 +923,22 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
   }
   __syncthreads();
   const int agg = c >> 1;
-  for (int rr = wv; rr < 6; rr += kTPB / kWave) {
-    const double* ar = d.mk_Ainv + (size_t)(6 * agg + rr) * d.mk_Nc;
-    double acc = 0;
-    for (int jj = lane; jj < nca; jj += kWave) acc += ar[jj] * rcs[jj];
-    acc = wave_sum(acc);
-    if (lane == 0) ys[rr] = acc;
+  {
+    // y = Ac^-1[6 rows of the aggregate] rc: every thread takes a strided slice of all six rows with its loads in flight together, then wave
+    // trees and the four wave sums in order.  (One wave per row with one load in flight per lane: 30 serial L2 round trips per row, 22 us per
+    // launch on the 10 000-keyframe map, 1 878 coarse unknowns.)
+    __shared__ double yred[6][kTPB / kWave];
+    double a6[6] = {0, 0, 0, 0, 0, 0};
+    const double* ar = d.mk_Ainv + (size_t)(6 * agg) * d.mk_Nc;
+    for (int jj = t; jj < nca; jj += kTPB) {
+      const double rv = rcs[jj];
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) a6[rr] += ar[(size_t)rr * d.mk_Nc + jj] * rv;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++) { const double w = wave_sum(a6[rr]); if (lane == 0) yred[rr][wv] = w; }
+    __syncthreads();
+    if (t < 6) ys[t] = ((yred[t][0] + yred[t][1]) + yred[t][2]) + yred[t][3];
   }
   __syncthreads();
   const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
@@ -2924,7 +2979,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         for (; k < kend; k++) {
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-            hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kTPB), 0, ctx->stream, d, k);
+            hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kSpmvTPB), 0, ctx->stream, d, k);
           }
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
