@@ -679,11 +679,16 @@ static void pg_nd_order(int F, const std::vector<std::vector<int>>& adj, int lea
     const int tag = (stamp += 2);
     for (int v : S) mark[v] = tag;
     bfs(S[0], tag, order);
-    if (order.size() < S.size()) {   // disconnected: this component now, the rest later (no separator between them)
-      std::vector<int> rest;
-      for (int v : S) if (mark[v] == tag) rest.push_back(v);
-      stack.push_back(rest);
-      stack.push_back(order);
+    if (order.size() < S.size()) {   // disconnected: no separator between components; small ones share pieces (a piece costs at least one tile)
+      std::vector<std::vector<int>> comps(1, order);
+      for (int v : S) if (mark[v] == tag) { bfs(v, tag, order); comps.push_back(order); }
+      std::vector<int> bin(1, -1);
+      for (auto& cc : comps) {
+        if ((int)cc.size() > leaf / 2) { stack.push_back(cc); continue; }
+        if ((int)bin.size() - 1 + (int)cc.size() > leaf) { stack.push_back(bin); bin.assign(1, -1); }
+        bin.insert(bin.end(), cc.begin(), cc.end());
+      }
+      if (bin.size() > 1) stack.push_back(bin);
       continue;
     }
     // pseudo-peripheral start: restart from the last vertex reached

@@ -119,6 +119,39 @@ def test_pose_graph_nested_dissection_matches_the_natural_order_solver(ctx, monk
     assert np.abs(s1 - s0).max() < 1e-7, np.abs(s1 - s0).max()
 
 
+def _concat_graphs(parts):
+    off = 0
+    out = dict(sim3=[], fixed=[], e_i=[], e_j=[], meas=[])
+    for g in parts:
+        out["sim3"].append(g["sim3"]); out["fixed"].append(g["fixed"]); out["meas"].append(g["meas"])
+        out["e_i"].append(g["e_i"] + off); out["e_j"].append(g["e_j"] + off)
+        off += g["n_vert"]
+    r = {k: np.concatenate(v) for k, v in out.items()}
+    r.update(fix_scale=False, n_vert=off, n_edge=int(r["e_i"].size))
+    return r
+
+
+def test_disconnected_components_and_a_hub(ctx, oracle_lib):
+    """Shapes the nested-dissection order must not choke on: 25 independent 12-keyframe loops (each with its own fixed keyframe: small
+    components share pieces), plus a 150-keyframe loop whose vertex 5 also has an edge to every 7th keyframe (a hub: wide BFS levels)."""
+    parts = [synth.make_pose_graph(12, 100 + k, n_loop=1, covis=2) for k in range(25)]
+    big = synth.make_pose_graph(150, 7)
+    hub_i, hub_j, hub_m = [], [], []
+    for k in range(12, 150, 7):   # consistent extra edges (measured from the drifted estimate): zero error, but they shape the graph
+        hub_i.append(k); hub_j.append(5)
+        a, b = big["sim3"][5], big["sim3"][k]
+        Ra, Rb = synth.R_from_quat(a[None, :4])[0], synth.R_from_quat(b[None, :4])[0]
+        Rji = Ra @ Rb.T
+        sji = a[7] / b[7]
+        tji = a[4:7] - sji * (Rji @ b[4:7])
+        hub_m.append(np.concatenate([synth.quat_from_R(Rji[None])[0], tji, [sji]]))
+    big = dict(big, e_i=np.concatenate([big["e_i"], np.array(hub_i, np.int32)]), e_j=np.concatenate([big["e_j"], np.array(hub_j, np.int32)]),
+               meas=np.concatenate([big["meas"], np.stack(hub_m)]))
+    big["n_edge"] = int(big["e_i"].size)
+    pg = _concat_graphs(parts + [big])
+    _check(ctx, oracle_lib, pg)
+
+
 def test_dense_cholesky_reports_a_non_positive_pivot(ctx):
     A = np.eye(70); A[40, 40] = -1.0
     x, info = optimizer.debug_dense_solve(ctx, A, np.ones(70))
