@@ -862,10 +862,12 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   const char* solver_env = getenv("CCM_PG_SOLVER");
   const size_t n_dense = 7 * (size_t)F;
   const int N_dense = (int)((n_dense + 63) / 64) * 64;
-  const bool use_dense = !(solver_env && !strcmp(solver_env, "pcg")) && n_dense <= 24000;
-  // exact solver, default form: tile-sparse, level-scheduled Cholesky over a nested-dissection order (ccm_tsc); CCM_PG_SOLVER=dense keeps the
-  // round-1 form (dense array, natural order, one tile column after the other) for comparison
-  const bool use_tiles = use_dense && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL");
+  // exact solver, default form: tile-sparse, level-scheduled Cholesky over a nested-dissection order (ccm_tsc: only the non-zero tiles are
+  // stored, so the size limit is the tile-pattern table, not a dense array); CCM_PG_SOLVER=dense keeps the round-1 form (dense array of
+  // <= 24 000 unknowns, natural order, one tile column after the other) for comparison
+  const bool want_exact = !(solver_env && !strcmp(solver_env, "pcg"));
+  const bool use_tiles = want_exact && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL") && n_dense <= 800000;
+  const bool use_dense = want_exact && (use_tiles || n_dense <= 24000);
   double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
   ccm_tile_plan plan;
   ccm_tsc tsc;
