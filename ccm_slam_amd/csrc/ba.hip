@@ -140,7 +140,7 @@ struct BaDev {
   const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
   int max_cam_edges;         // longest per-camera edge list on this rank
   // row-centric Schur kernel: work units = (block, chunk of <= row_chunk consecutive pair instances), dealt to the waves
-  const int* unit_tab;       // [n_units][3]: block, first instance, end instance
+  const int4* unit_tab;      // [n_units]: block (-1: the camera's own observations), first instance, end instance, slot of the partial sum inside the row; per row longest unit first
   const int* row_unit_off;   // [Cp+1] units of block row i
   const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
   int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
@@ -573,12 +573,17 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
   // b_schur_i = b_p,i - sum_e Y_e b_l(e) are the same product with c = a = e and the landmark's b_l as a seventh column of
   // the B operand (lanes j = 6 / 14).  The separate one-wave-per-camera kernel for the diagonal re-read W, D^-1 and the
   // index chains that this workgroup has just loaded and took 56 us.
+  // The table lists a row's units LONGEST FIRST (slot = the unit's index in block order, where its partial sum goes), so that the 16 waves of
+  // a row, dealt round-robin, carry near-equal instance counts; one 16-byte entry per unit.  (Measured on gba_c4: 223 us either way — the
+  // waves of a row were not waiting for a slowest one.)
   int u = u_first + wv;
-  int n = 0, ic = 0, ia = 0, il = 0, ublk = 0;
-  auto load_unit = [&](int uu, int& n_, int& ic_, int& ia_, int& il_, int& blk_) {
-    blk_ = d.unit_tab[3 * uu];
-    const int s0 = d.unit_tab[3 * uu + 1];
-    n_ = d.unit_tab[3 * uu + 2] - s0;
+  int n = 0, ic = 0, ia = 0, il = 0, ublk = 0, uslot = 0;
+  auto load_unit = [&](int uu, int& n_, int& ic_, int& ia_, int& il_, int& blk_, int& slot_) {
+    const int4 te = d.unit_tab[uu];
+    blk_ = te.x;
+    const int s0 = te.y;
+    n_ = te.z - s0;
+    slot_ = te.w;
     if (blk_ >= 0) {
       ic_ = (lane < n_) ? 144 * d.inst_c[s0 + lane] : 0;
       ia_ = (lane < n_) ? 144 * d.inst_al[s0 + lane] : 8 * zslot;   // padding instances multiply the zero row
@@ -590,11 +595,11 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
       il_ = (lane < n_) ? 24 * d.ed_pt[e] : 0;
     }
   };
-  if (u < u_last) load_unit(u, n, ic, ia, il, ublk);
+  if (u < u_last) load_unit(u, n, ic, ia, il, ublk, uslot);
   while (u < u_last) {
     const int un = u + TPB / kWave;
-    int nn = 0, icn = 0, ian = 0, iln = 0, ublkn = 0;
-    if (un < u_last) load_unit(un, nn, icn, ian, iln, ublkn);
+    int nn = 0, icn = 0, ian = 0, iln = 0, ublkn = 0, uslotn = 0;
+    if (un < u_last) load_unit(un, nn, icn, ian, iln, ublkn, uslotn);
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     int q0 = 0;
     if (ublk < 0) {   // diagonal unit: lanes j = 6 / 14 feed b_l as the seventh column
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
     // D register r of lane (j, kq) is D[kq + 4 r][j]: even instances in D[0..5][0..5] (r = 0, 1; j < 6), odd ones in
     // D[8..13][8..13] (r = 2, 3; j = 8..13) -> added to the even sum of lane j - 8
     const double b0 = __shfl_down(acc[2], 8, kWave), b1 = __shfl_down(acc[3], 8, kWave);
-    double* pu = part + kRowSlot * (size_t)(u - u_first);
+    double* pu = part + kRowSlot * (size_t)uslot;
     if (j < 6) {
       pu[kq * 6 + j] = acc[0] + b0;
       if (kq < 2) pu[(kq + 4) * 6 + j] = acc[1] + b1;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
       pu[36 + kq] = acc[0] + b0;
       if (kq < 2) pu[40 + kq] = acc[1] + b1;
     }
-    u = un; n = nn; ic = icn; ia = ian; il = iln; ublk = ublkn;
+    u = un; n = nn; ic = icn; ia = ian; il = iln; ublk = ublkn; uslot = uslotn;
   }
   __syncthreads();
   {
@@ -2518,18 +2523,22 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
           worst = std::max(worst, nu);
         }
         if (worst > units_cap) continue;
-        std::vector<int> tab, row_u(Cp + 1, 0), blk_u((size_t)nOff + 1, 0);
+        std::vector<int4> tab;
+        std::vector<int> row_u(Cp + 1, 0), blk_u((size_t)nOff + 1, 0);
         for (int i = 0; i < Cp; i++) {
+          const size_t r0 = tab.size();
           for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) {
-            blk_u[b] = (int)tab.size() / 3;
+            blk_u[b] = (int)tab.size();
             int s0 = h_off[b];
-            do { const int s1 = std::min(h_off[b + 1], s0 + chunk); tab.push_back(b); tab.push_back(s0); tab.push_back(s1); s0 = s1; } while (s0 < h_off[b + 1]);
+            do { const int s1 = std::min(h_off[b + 1], s0 + chunk); tab.push_back(make_int4(b, s0, s1, (int)(tab.size() - r0))); s0 = s1; } while (s0 < h_off[b + 1]);
           }
-          for (int s0 = 0, ne_i = cam_off[i + 1] - cam_off[i]; s0 < ne_i; s0 += chunk) { tab.push_back(-1); tab.push_back(s0); tab.push_back(std::min(ne_i, s0 + chunk)); }
-          row_u[i + 1] = (int)tab.size() / 3;
+          for (int s0 = 0, ne_i = cam_off[i + 1] - cam_off[i]; s0 < ne_i; s0 += chunk) tab.push_back(make_int4(-1, s0, std::min(ne_i, s0 + chunk), (int)(tab.size() - r0)));
+          row_u[i + 1] = (int)tab.size();
+          // processing order: longest unit first (stable); the slots keep the block order the final sums rely on
+          std::stable_sort(tab.begin() + r0, tab.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
         }
-        blk_u[nOff] = (int)tab.size() / 3;
-        int *p_t = nullptr, *p_r = nullptr, *p_b = nullptr;
+        blk_u[nOff] = (int)tab.size();
+        int4* p_t = nullptr; int *p_r = nullptr, *p_b = nullptr;
         if (int rc = dev_upload(ba, tab, &p_t)) return fail(rc);
         if (int rc = dev_upload(ba, row_u, &p_r)) return fail(rc);
         if (int rc = dev_upload(ba, blk_u, &p_b)) return fail(rc);
@@ -2540,7 +2549,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
         // (index vectors -> W gathers -> 16 dependent MFMAs), which two resident rows do not shorten.  Kept behind CCM_BA_ROW_V2=1.
         if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && getenv("CCM_BA_ROW_V2")) {
           double* p_part = nullptr;
-          if (int rc = dev_alloc<double>(ba, (size_t)(tab.size() / 3) * 42, &p_part, false)) return fail(rc);
+          if (int rc = dev_alloc<double>(ba, (size_t)tab.size() * 42, &p_part, false)) return fail(rc);
           d.row_part = p_part;
         }
       }
