@@ -267,11 +267,285 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbDev d, const uint8_t* 
 // ---- orientation + descriptor: one wave per keypoint -----------------------------------------------
 struct KpIn { int16_t x, y; int16_t level; int16_t response; };
 
+// ---- DistributeOctTree on the device (ORBextractor.cpp:707-931): one workgroup per pyramid level, everything in LDS ----------------------------
+// The reference walks a std::list and splits nodes one by one; the order of that list decides ties and the output order.  The walk is
+// restated in ROUNDS that a workgroup can execute in parallel (validated against the oracle's sequential restatement before it was written
+// as a kernel):
+//  * keys never move: every stable partition keeps the keys of a node in ascending candidate index, so a key only needs the slot of its
+//    current node, and "first maximum of the response" at the end is max(response, then smallest index);
+//  * one split pass: the nodes to split carry a processing rank (main loop: list order of the expandable nodes; final phase: descending
+//    (size, creation index) with the cut where the list reaches N — prefix sums of children-1 in rank order); children are created in rank
+//    order x quadrant order, and because every child is pushed to the FRONT the new list is reverse(creation order) followed by the old
+//    list without the split nodes;
+//  * node ids of the reference (creation order) are only ever compared inside one pass, so the creation index of the pass is enough.
+// A level needs 12 B per candidate and 52 B per list slot (<= 4 N + 16 slots) of LDS; levels that do not fit raise a flag and the frame is
+// redone through the host octree.
+constexpr int kOctTPB = 1024;
+struct OctNode { int16_t ulx, uly, urx, bry; uint16_t size; uint16_t nomore; };
+struct OctArgs {
+  const int* cand;        // [ncells + 1 offsets][records]
+  int ncells, nlevels;
+  int nfeat[kMaxLevels];
+  int lcap[kMaxLevels];   // list slots per level
+  int kcap;               // candidates per level that fit
+  KpIn* stage;            // [nlevels][stage_stride]
+  int stage_stride;
+  int* counts;            // [nlevels] list sizes, [nlevels] = arrival counter
+  KpIn* kin; int* n_out; int kp_cap;   // n_out: [keypoint count, overflow flag]
+};
+
+// exclusive scan of two consecutive items per thread over the workgroup (items 2t, 2t+1); returns the total.  wsum: LDS [kOctTPB / 64 + 1]
+__device__ __forceinline__ int oct_scan2(int v0, int v1, int& e0, int& e1, int* wsum) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int a = v0 + v1;
+  int inc = a;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+  __syncthreads();                       // wsum may still be read by the previous call
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kOctTPB / 64; w++) { const int x = wsum[w]; if (w < wv) base += x; tot += x; }
+  e0 = base + inc - a;
+  e1 = e0 + v0;
+  return tot;
+}
+
+__global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char oct_lds[];
+  __shared__ int wsum[kOctTPB / 64 + 1];
+  __shared__ int sh[16];                 // [0] list size  [1] cur buffer  [2] created  [3] new candidates  [4] finish  [5] cut rank  [6] overflow
+  __shared__ int rootcnt[16], rootslot[16];
+  const int t = threadIdx.x;
+  const int l = blockIdx.x;
+  const LevelInfo Lv = d.lv[l];
+  const int N = a.nfeat[l], Lcap = a.lcap[l];
+  const int c0 = a.cand[Lv.cellBase], c1 = a.cand[Lv.cellBase + Lv.nCols * Lv.nRows];
+  const int n = c1 - c0;
+  const uint32_t* grec = reinterpret_cast<const uint32_t*>(a.cand + a.ncells + 1) + c0;
+  // LDS carve-up
+  uint32_t* rec = reinterpret_cast<uint32_t*>(oct_lds);                       // [kcap]
+  uint16_t* knode = reinterpret_cast<uint16_t*>(rec + a.kcap);                // [kcap]
+  uint8_t* kq = reinterpret_cast<uint8_t*>(knode + a.kcap);                   // [kcap]
+  size_t o = ((size_t)a.kcap * 7 + 15) & ~(size_t)15;
+  OctNode* nodes0 = reinterpret_cast<OctNode*>(oct_lds + o); o += (size_t)Lcap * sizeof(OctNode);
+  OctNode* nodes1 = reinterpret_cast<OctNode*>(oct_lds + o); o += (size_t)Lcap * sizeof(OctNode);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(oct_lds + o); o += (size_t)Lcap * 16;     // [Lcap][4] quadrant counts, then child slots / new slot
+  int16_t* prank = reinterpret_cast<int16_t*>(oct_lds + o); o += (size_t)Lcap * 2;      // processing rank of a slot, -1 = not split
+  int16_t* byrank = reinterpret_cast<int16_t*>(oct_lds + o); o += (size_t)Lcap * 2;     // rank -> children (then creation base)
+  uint16_t* cslot = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    // expandable children of the last pass: slot,
+  uint16_t* csize = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    //   size,
+  uint16_t* cci = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;      //   creation index
+  uint8_t* mark = reinterpret_cast<uint8_t*>(oct_lds + o);                                  // [Lcap] node takes part in the counting
+  int* g_over = a.n_out + 1;                                                                  // [count, overflow flag]
+  if (t < 16) { sh[t] = 0; rootcnt[t] = 0; }
+  __syncthreads();
+  const int W = (Lv.w - kEdge + 3) - (kEdge - 3), H = (Lv.h - kEdge + 3) - (kEdge - 3);
+  const int nIni = (int)roundf(static_cast<float>(W) / static_cast<float>(H));
+  bool overflow = n > a.kcap || nIni > 15 || nIni < 1;
+  if (!overflow && n > 0) {
+    const float hX = static_cast<float>(W) / nIni;
+    // roots: bin the candidates (order inside a node never matters, see above)
+    for (int k = t; k < n; k += kOctTPB) {
+      const uint32_t r = grec[k];
+      rec[k] = r;
+      const int root = (int)(static_cast<float>(r & 0xFFF) / hX);
+      kq[k] = (uint8_t)root;
+      atomicAdd(&rootcnt[root < 15 ? root : 15], 1);
+    }
+    __syncthreads();
+    if (t == 0) {
+      int ls = 0;
+      for (int i = 0; i < nIni; i++) {
+        rootslot[i] = -1;
+        if (rootcnt[i] == 0) continue;   // empty root: erased (:754-757)
+        OctNode nd;
+        nd.ulx = (int16_t)(int)(hX * static_cast<float>(i)); nd.urx = (int16_t)(int)(hX * static_cast<float>(i + 1)); nd.uly = 0; nd.bry = (int16_t)H;
+        nd.size = (uint16_t)rootcnt[i]; nd.nomore = rootcnt[i] == 1;
+        nodes0[ls] = nd; rootslot[i] = ls++;
+      }
+      sh[0] = ls; sh[1] = 0;
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += kOctTPB) knode[k] = (uint16_t)rootslot[kq[k]];
+    __syncthreads();
+    // ---- rounds ----
+    bool final_phase = false;
+    for (int guard = 0; guard < 64; guard++) {
+      const int Ls = sh[0];
+      OctNode* cur = sh[1] ? nodes1 : nodes0;
+      OctNode* nxt = sh[1] ? nodes0 : nodes1;
+      const int m = sh[3];                                   // expandable children of the previous pass (final phase input)
+      // 1. which nodes take part
+      const int i0 = 2 * t, i1 = 2 * t + 1;
+      int f0 = 0, f1 = 0;
+      if (!final_phase) {
+        if (i0 < Ls) f0 = cur[i0].nomore ? 0 : 1;
+        if (i1 < Ls) f1 = cur[i1].nomore ? 0 : 1;
+        int e0, e1;
+        const int P = oct_scan2(f0, f1, e0, e1, wsum);
+        if (i0 < Ls) { prank[i0] = f0 ? (int16_t)e0 : (int16_t)-1; mark[i0] = (uint8_t)f0; }
+        if (i1 < Ls) { prank[i1] = f1 ? (int16_t)e1 : (int16_t)-1; mark[i1] = (uint8_t)f1; }
+        if (t == 0) sh[5] = P;                               // all of them are split
+      } else {
+        if (i0 < Ls) { prank[i0] = -1; mark[i0] = 0; }
+        if (i1 < Ls) { prank[i1] = -1; mark[i1] = 0; }
+        __syncthreads();
+        for (int c = t; c < m; c += kOctTPB) mark[cslot[c]] = 1;
+      }
+      for (int e = t; e < 4 * Ls; e += kOctTPB) cnt[e] = 0;
+      __syncthreads();
+      // 2. quadrant of every key of a participating node (DivideNode :650-705), counts per (node, quadrant)
+      for (int k = t; k < n; k += kOctTPB) {
+        const int nd = knode[k];
+        if (!mark[nd]) continue;
+        const OctNode Pn = cur[nd];
+        const int midx = Pn.ulx + ((Pn.urx - Pn.ulx + 1) >> 1), midy = Pn.uly + ((Pn.bry - Pn.uly + 1) >> 1);   // (int)ceil((float)extent / 2)
+        const uint32_t r = rec[k];
+        const int x = r & 0xFFF, y = (r >> 12) & 0xFFF;
+        const int q = (x < midx) ? ((y < midy) ? 0 : 2) : ((y < midy) ? 1 : 3);
+        kq[k] = (uint8_t)q;
+        atomicAdd(&cnt[4 * nd + q], 1u);
+      }
+      __syncthreads();
+      if (final_phase) {
+        // 3. processing order of the final phase: descending (size, creation index); the list reaches N at rank sh[5]
+        for (int c = t; c < m; c += kOctTPB) {
+          const int sz = csize[c], ci = cci[c];
+          int r = 0;
+          for (int o2 = 0; o2 < m; o2++) { const int s2 = csize[o2], c2 = cci[o2]; r += (s2 > sz || (s2 == sz && c2 > ci)) ? 1 : 0; }
+          const int nd = cslot[c];
+          const int nch = (cnt[4 * nd] ? 1 : 0) + (cnt[4 * nd + 1] ? 1 : 0) + (cnt[4 * nd + 2] ? 1 : 0) + (cnt[4 * nd + 3] ? 1 : 0);
+          prank[nd] = (int16_t)r;
+          byrank[r] = (int16_t)(nch - 1);
+        }
+        __syncthreads();
+        int e0, e1;
+        const int v0 = i0 < m ? byrank[i0] : 0, v1 = i1 < m ? byrank[i1] : 0;
+        oct_scan2(v0, v1, e0, e1, wsum);
+        if (t == 0) sh[5] = m;                                // no cut: every candidate is split
+        __syncthreads();
+        // first rank whose inclusive count reaches N
+        if (i0 < m && Ls + e0 + v0 >= N && (i0 == 0 || Ls + e0 < N)) sh[5] = i0 + 1;
+        if (i1 < m && Ls + e1 + v1 >= N && Ls + e1 < N) sh[5] = i1 + 1;
+        __syncthreads();
+        const int R = sh[5];
+        for (int c = t; c < m; c += kOctTPB) { const int nd = cslot[c]; if (prank[nd] >= R) prank[nd] = -1; }
+        __syncthreads();
+      }
+      const int P = sh[5];                                   // nodes split in this pass (ranks 0 .. P-1)
+      // 4. children per rank -> creation base; kept nodes -> position behind the children
+      if (i0 < Ls && prank[i0] >= 0) byrank[prank[i0]] = (int16_t)((cnt[4 * i0] ? 1 : 0) + (cnt[4 * i0 + 1] ? 1 : 0) + (cnt[4 * i0 + 2] ? 1 : 0) + (cnt[4 * i0 + 3] ? 1 : 0));
+      if (i1 < Ls && prank[i1] >= 0) byrank[prank[i1]] = (int16_t)((cnt[4 * i1] ? 1 : 0) + (cnt[4 * i1 + 1] ? 1 : 0) + (cnt[4 * i1 + 2] ? 1 : 0) + (cnt[4 * i1 + 3] ? 1 : 0));
+      __syncthreads();
+      int cb0, cb1;
+      const int C = oct_scan2(i0 < P ? byrank[i0] : 0, i1 < P ? byrank[i1] : 0, cb0, cb1, wsum);
+      __syncthreads();
+      if (i0 < P) byrank[i0] = (int16_t)cb0;
+      if (i1 < P) byrank[i1] = (int16_t)cb1;
+      int kp0, kp1;
+      const int K = oct_scan2((i0 < Ls && prank[i0] < 0) ? 1 : 0, (i1 < Ls && prank[i1] < 0) ? 1 : 0, kp0, kp1, wsum);
+      if (t == 0) { sh[2] = C; sh[3] = 0; }
+      __syncthreads();
+      if (C + K > Lcap) overflow = true;                      // (cannot happen: a pass at most quadruples a list shorter than N)
+      // 5. the new list
+      if (!overflow) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          const int i = w ? i1 : i0;
+          if (i >= Ls) continue;
+          const OctNode Pn = cur[i];
+          if (prank[i] < 0) {
+            const int ns = C + (w ? kp1 : kp0);
+            nxt[ns] = Pn;
+            cnt[4 * i] = (uint32_t)ns;
+            continue;
+          }
+          const int midx = Pn.ulx + ((Pn.urx - Pn.ulx + 1) >> 1), midy = Pn.uly + ((Pn.bry - Pn.uly + 1) >> 1);
+          int ci = byrank[prank[i]];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int sz = (int)cnt[4 * i + q];
+            if (sz == 0) continue;
+            OctNode ch;
+            ch.ulx = (q & 1) ? (int16_t)midx : Pn.ulx; ch.urx = (q & 1) ? Pn.urx : (int16_t)midx;
+            ch.uly = (q & 2) ? (int16_t)midy : Pn.uly; ch.bry = (q & 2) ? Pn.bry : (int16_t)midy;
+            ch.size = (uint16_t)sz; ch.nomore = sz == 1;
+            const int ns = C - 1 - ci;                        // pushed to the front: reverse creation order
+            nxt[ns] = ch;
+            cnt[4 * i + q] = (uint32_t)ns;
+            if (sz > 1) { const int e = atomicAdd(&sh[3], 1); cslot[e] = (uint16_t)ns; csize[e] = (uint16_t)sz; cci[e] = (uint16_t)ci; }
+            ci++;
+          }
+        }
+      }
+      __syncthreads();
+      // 6. keys follow their nodes
+      if (!overflow)
+        for (int k = t; k < n; k += kOctTPB) {
+          const int nd = knode[k];
+          knode[k] = (uint16_t)cnt[4 * nd + (prank[nd] >= 0 ? kq[k] : 0)];
+        }
+      __syncthreads();
+      // 7. the reference's loop conditions (:835-845, :901-905)
+      const int newLs = C + K, nExp = sh[3];
+      bool done;
+      if (!final_phase) {
+        done = newLs >= N || newLs == Ls;
+        if (!done && newLs + 3 * nExp > N) final_phase = true;
+      } else done = newLs >= N || newLs == Ls;
+      __syncthreads();
+      if (t == 0) { sh[0] = newLs; sh[1] ^= 1; }
+      __syncthreads();
+      if (done || overflow) break;
+    }
+  }
+  // ---- best response per node, in list order ----
+  const int Ls = (overflow || n == 0) ? 0 : sh[0];
+  if (Ls > 0) {
+    OctNode* cur = sh[1] ? nodes1 : nodes0;
+    (void)cur;
+    for (int e = t; e < Ls; e += kOctTPB) cnt[e] = 0;
+    __syncthreads();
+    for (int k = t; k < n; k += kOctTPB) atomicMax(&cnt[knode[k]], ((rec[k] >> 24) << 16) | (uint32_t)(0xFFFF - k));   // first maximum = smallest index
+    __syncthreads();
+    const int minB = kEdge - 3;
+    for (int e = t; e < Ls && e < a.stage_stride; e += kOctTPB) {
+      const uint32_t r = rec[0xFFFF - (cnt[e] & 0xFFFF)];
+      a.stage[(size_t)l * a.stage_stride + e] = KpIn{(int16_t)((int)(r & 0xFFF) + minB), (int16_t)((int)((r >> 12) & 0xFFF) + minB), (int16_t)l, (int16_t)(r >> 24)};
+    }
+    if (Ls > a.stage_stride) overflow = true;
+  }
+  // ---- the last level to finish concatenates the levels ----
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (t == 0) {
+    a.counts[l] = Ls;
+    if (overflow) atomicExch(g_over, 1);
+    __threadfence();
+    last = atomicAdd(a.counts + a.nlevels, 1) == a.nlevels - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  int off = 0;
+  for (int q = 0; q < a.nlevels; q++) {
+    const int c = __hip_atomic_load(a.counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = t; e < c && off + e < a.kp_cap; e += kOctTPB) a.kin[off + e] = a.stage[(size_t)q * a.stage_stride + e];
+    off += c;
+  }
+  if (t == 0) { *a.n_out = off < a.kp_cap ? off : a.kp_cap; a.counts[a.nlevels] = 0; }
+}
+
+
 __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                              const KpIn* __restrict__ kin, int n, ccm_keypoint* __restrict__ kout,
-                                                              uint8_t* __restrict__ desc) {
+                                                              const KpIn* __restrict__ kin, int n, const int* __restrict__ n_dev /* nullable: count on the device */,
+                                                              ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc) {
   const int lane = threadIdx.x & (kWave - 1);
   const int i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+  if (n_dev) n = *n_dev;
   if (i >= n) return;
   const KpIn kp = kin[i];
   const LevelInfo L = d.lv[kp.level];
@@ -497,7 +771,8 @@ struct ccm_orb {
     KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr;
     int* h_cand = nullptr;   // pinned
     KpIn* h_kin = nullptr;   // pinned
-    int* h_count = nullptr;  // pinned: keypoint count of the frame (batch API)
+    int* h_count = nullptr;  // pinned: keypoint count of the frame (batch API); device octree: [0] count, [1] overflow flag
+    KpIn* d_oct_stage = nullptr; int* d_oct_counts = nullptr; int* d_n = nullptr;   // device octree: per-level results, [levels | arrival | overflow], keypoint count
     hipEvent_t ev_cand = nullptr;
   } B[2];
   int cur = 0;
@@ -509,13 +784,18 @@ struct ccm_orb {
   size_t h_io_bytes = 0;
   double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
   Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
+  // device octree (orb_octree_kernel): LDS plan of this geometry; oct_ok = false -> host octree
+  bool oct_ok = false; int oct_kcap = 0, oct_stride = 0; size_t oct_lds = 0; int oct_lcap[kMaxLevels] = {0};
+  hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
+  hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
   // last-frame debug
-  std::vector<std::vector<Cand>> last_cand;
+  std::vector<std::vector<Cand>> last_cand; bool last_cand_valid = false;
 };
 
 static void orb_free_bufs(ccm_orb::Bufs& b) {
   hipFree(b.d_pyr); hipFree(b.d_score); hipFree(b.d_blur); hipFree(b.d_cell_slots); hipFree(b.d_cell_counts); hipFree(b.d_cand);
   hipFree(b.d_kin); hipFree(b.d_kout);   // d_desc is part of d_kout's block
+  hipFree(b.d_oct_stage); hipFree(b.d_oct_counts); hipFree(b.d_n);
   if (b.h_cand) hipHostFree(b.h_cand);
   if (b.h_kin) hipHostFree(b.h_kin);
   if (b.h_count) hipHostFree(b.h_count);
@@ -567,6 +847,9 @@ extern "C" void ccm_orb_destroy(ccm_orb* o) {
   if (o->ctx) { hipSetDevice(o->ctx->device); hipStreamSynchronize(o->ctx->stream); }
   orb_free_geometry(o);
   for (int k = 0; k < 2; k++) if (o->B[k].ev_cand) hipEventDestroy(o->B[k].ev_cand);
+  if (o->stream2) { hipStreamSynchronize(o->stream2); hipStreamDestroy(o->stream2); }
+  if (o->ev_a) hipEventDestroy(o->ev_a);
+  if (o->ev_b) hipEventDestroy(o->ev_b);
   delete o;
 }
 
@@ -605,6 +888,13 @@ static int orb_alloc_bufs(ccm_orb* o, int k) {
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_counts, (size_t)d.ncells * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
+  if (o->oct_ok) {
+    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_oct_stage, (size_t)o->nlevels * o->oct_stride * sizeof(KpIn)));
+    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_oct_counts, (size_t)(o->nlevels + 2) * sizeof(int)));
+    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_n, 2 * sizeof(int)));
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_oct_counts, 0, (size_t)(o->nlevels + 2) * sizeof(int), ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_n, 0, 2 * sizeof(int), ctx->stream));
+  }
   {   // keypoints and descriptors in one block [kout | desc] so that the results leave with one copy
     uint8_t* blk = nullptr;
     const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
@@ -681,6 +971,17 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   o->cand_cap = d.ncells * kCellCap;
   o->kp_cap = ccm_orb_max_keypoints(o);
   o->cur = 0;
+  {   // LDS plan of the device octree: 52 B per list slot (4 N + 16 slots of the level with most features), the rest for candidates at 7 B each
+    static const bool host_oct = getenv("CCM_ORB_HOST_OCTREE") && atoi(getenv("CCM_ORB_HOST_OCTREE")) != 0;
+    int nmax = 0;
+    for (int l = 0; l < o->nlevels; l++) { o->oct_lcap[l] = 4 * o->nfeat[l] + 16; nmax = std::max(nmax, o->nfeat[l]); }
+    const size_t slots = (size_t)(4 * nmax + 16) * (2 * sizeof(OctNode) + 16 + 5 * 2 + 1) + 64;
+    const size_t budget = 150 * 1024;
+    o->oct_stride = nmax + 8;
+    o->oct_kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
+    o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
+    o->oct_ok = !host_oct && o->oct_kcap >= 2048 && 4 * nmax + 16 <= 2 * kOctTPB;
+  }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
@@ -699,32 +1000,34 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
 }
 
 // device phase 1: pyramid, scores, cells, compaction; blur is queued too (it does not depend on the octree)
-static int orb_phase1(ccm_orb* o) {
+static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
   for (int l = 1; l < o->nlevels; l++) {
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE);
-    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, ctx->stream, o->B[o->cur].d_pyr + P.off, P.w, P.h, P.stride,
+    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.off, P.w, P.h, P.stride,
                        o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
-    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
+    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
-    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
-    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, ctx->stream, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
+    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
+    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
                        (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
   }
-  const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand, o->B[o->cur].d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, ctx->stream));
+  if (copy_cand) {
+    const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand, o->B[o->cur].d_cand, first, hipMemcpyDeviceToHost, o->st));
+    CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, o->st));
+  }
   {
     ccm_prof_scope ps(ctx, CCM_K_BLUR);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, ctx->stream, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -804,7 +1107,7 @@ static int orb_host_select(ccm_orb* o, int* n_out, LevelPool* pool = nullptr) {
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   const uint32_t* rec = (const uint32_t*)(o->B[o->cur].h_cand + d.ncells + 1);
-  o->last_cand.resize(o->nlevels);
+  o->last_cand.resize(o->nlevels); o->last_cand_valid = true;
   if (pool) pool->run(offs, rec);
   const int minB = kEdge - 3;
   int n = 0;
@@ -827,7 +1130,30 @@ static int orb_phase2(ccm_orb* o, int n) {
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].d_kin, o->B[o->cur].h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, o->B[o->cur].d_kout, o->B[o->cur].d_desc);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (const int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
+// keypoint selection and phase 2 without the host: octree kernel (one workgroup per level), then orientation + descriptors for the count the
+// device wrote (the grid covers the capacity, surplus waves leave at once)
+static int orb_phase2_dev(ccm_orb* o, int out_cap) {
+  ccm_ctx* ctx = o->ctx;
+  ccm_orb::Bufs& b = o->B[o->cur];
+  OctArgs a;
+  a.cand = b.d_cand; a.ncells = o->dev.ncells; a.nlevels = o->nlevels;
+  for (int l = 0; l < o->nlevels; l++) { a.nfeat[l] = o->nfeat[l]; a.lcap[l] = o->oct_lcap[l]; }
+  a.kcap = o->oct_kcap; a.stage = b.d_oct_stage; a.stage_stride = o->oct_stride; a.counts = b.d_oct_counts;
+  a.kin = b.d_kin; a.n_out = b.d_n; a.kp_cap = std::min(o->kp_cap, out_cap);
+  CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel, 152 * 1024);
+  {
+    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
+    hipLaunchKernelGGL(orb_octree_kernel, dim3(o->nlevels), dim3(kOctTPB), o->oct_lds, o->st, o->dev, a);
+  }
+  {
+    ccm_prof_scope ps(ctx, CCM_K_BRIEF);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, (const int*)b.d_n, b.d_kout, b.d_desc);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -838,6 +1164,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   if (!o || !img || w <= 0 || h <= 0 || stride < w || !kps || !desc || !n_out) return ccm_set_error(o ? o->ctx : nullptr, CCM_E_ARG, "ccm_orb_extract: bad args");
   ccm_ctx* ctx = o->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  o->st = ctx->stream;
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
@@ -846,7 +1173,37 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   // the image goes through the pinned block (packed rows): a pageable source makes the runtime stage and wait
   for (int y = 0; y < h; y++) memcpy(o->h_io + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
   CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(o->B[o->cur].d_pyr + L0.off, L0.stride, o->h_io, w, w, h, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = orb_phase1(o))) return rc;
+  const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
+  o->last_cand_valid = false;
+  if (o->oct_ok) {
+    // no host in the middle: pyramid, FAST, octree, orientation and descriptors are queued back to back; ONE wait at the end
+    ccm_orb::Bufs& b = o->B[o->cur];
+    if ((rc = orb_phase1(o, false))) return rc;
+    if ((rc = orb_phase2_dev(o, cap))) return rc;
+    const double t1 = now();
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, b.d_kout, o_d + (size_t)std::min(cap, o->kp_cap) * 32, hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(b.h_count, b.d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (pyramid_out)
+      for (int l = 0; l < o->nlevels; l++)
+        if (pyramid_out[l]) {
+          const LevelInfo& L = o->dev.lv[l];
+          CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(pyramid_out[l], L.w, b.d_pyr + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.h_count[1] == 0) {
+      const int nc = std::min(b.h_count[0], cap);
+      if (nc) { memcpy(kps, o->h_io, (size_t)nc * sizeof(ccm_keypoint)); memcpy(desc, o->h_io + o_d, (size_t)nc * 32); }
+      const double t5 = now();
+      o->t_phase[0] = t1 - t0; o->t_phase[1] = 0; o->t_phase[2] = 0; o->t_phase[3] = 0; o->t_phase[4] = t5 - t1; o->t_phase[5] = t5 - t0;
+      *n_out = nc;
+      return CCM_OK;
+    }
+    // a level did not fit the kernel's LDS plan: clear the flag and select on the host from the candidates that are still on the device
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_n + 1, 0, sizeof(int), ctx->stream));
+    const size_t first = ((size_t)o->dev.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(b.h_cand, b.d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipEventRecord(b.ev_cand, ctx->stream));
+  } else if ((rc = orb_phase1(o))) return rc;
   const double t1 = now();
   int n = 0;
   if ((rc = orb_host_select(o, &n))) return rc;
@@ -854,7 +1211,6 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   if ((rc = orb_phase2(o, n))) return rc;
   const double t4 = now();
   const int nc = std::min(n, cap);
-  const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
   // (the image upload from h_io completed before the host octree ran: the candidate read-back waited behind it)
   if (nc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, o->B[o->cur].d_kout, o_d + (size_t)nc * 32, hipMemcpyDeviceToHost, ctx->stream));
   if (pyramid_out)
@@ -882,10 +1238,47 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   if (!o || !d_imgs || n_frames < 0 || !d_kps || !d_desc || !d_counts) return ccm_set_error(o ? o->ctx : nullptr, CCM_E_ARG, "ccm_orb_extract_batch_dev: bad args");
   ccm_ctx* ctx = o->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  o->st = ctx->stream;
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
   if ((rc = orb_alloc_bufs(o, 1))) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
+  if (o->oct_ok && cap > 0) {
+    // device octree: the whole batch is queued without a single host wait.  Even frames run on the context's stream with buffer set 0, odd
+    // frames on a second stream with set 1: the octree kernel is eight workgroups of serial rounds (~55 us), the other frame's pyramid /
+    // FAST / descriptor kernels fill the rest of the GPU meanwhile.
+    if (!o->stream2) {
+      CCM_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking));
+      CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_a, hipEventDisableTiming));
+      CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_b, hipEventDisableTiming));
+    }
+    CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_a, ctx->stream));            // whatever produced the images on the context's stream comes first
+    CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->stream2, o->ev_a, 0));
+    const int nc = std::min(cap, o->kp_cap);
+    for (int f = 0; f < n_frames; f++) {
+      o->cur = f & 1;
+      o->st = (f & 1) ? o->stream2 : ctx->stream;
+      ccm_orb::Bufs& b = o->B[o->cur];
+      CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
+      if ((rc = orb_phase1(o, false))) { o->cur = 0; o->st = ctx->stream; return rc; }
+      if ((rc = orb_phase2_dev(o, cap))) { o->cur = 0; o->st = ctx->stream; return rc; }
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_kps + (size_t)f * cap, b.d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToDevice, o->st));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc + (size_t)f * cap * 32, b.d_desc, (size_t)nc * 32, hipMemcpyDeviceToDevice, o->st));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_counts + f, b.d_n, sizeof(int), hipMemcpyDeviceToDevice, o->st));
+    }
+    o->cur = 0; o->st = ctx->stream;
+    // the overflow flags are sticky over the batch
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[1].h_count, o->B[1].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, o->stream2));
+    CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_b, o->stream2));
+    CCM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_b, 0));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[0].h_count, o->B[0].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    o->last_cand_valid = false;
+    if (n_frames == 0 || (o->B[0].h_count[1] == 0 && (n_frames < 2 || o->B[1].h_count[1] == 0))) return CCM_OK;
+    // some level of some frame did not fit the kernel's LDS plan: redo the batch with the host octree
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[0].d_n + 1, 0, sizeof(int), ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[1].d_n + 1, 0, sizeof(int), ctx->stream));
+  }
   // the octrees of a frame's levels run on this thread + a few helpers for the duration of the call (CCM_ORB_BATCH_THREADS, default 3 helpers, 0 = none)
   static const int n_helpers = getenv("CCM_ORB_BATCH_THREADS") ? std::max(0, std::min(7, atoi(getenv("CCM_ORB_BATCH_THREADS")))) : 3;
   std::unique_ptr<LevelPool> pool;
@@ -931,7 +1324,25 @@ extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, ui
 }
 
 extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) {
-  if (!o || level < 0 || level >= o->nlevels || !n_out || (int)o->last_cand.size() != o->nlevels) return CCM_E_ARG;
+  if (!o || level < 0 || level >= o->nlevels || !n_out) return CCM_E_ARG;
+  if (!o->last_cand_valid) {   // the device octree never brings the candidates to the host: fetch them for this call
+    ccm_ctx* ctx = o->ctx;
+    ccm_orb::Bufs& b = o->B[o->cur];
+    if (!b.d_cand) return CCM_E_ARG;
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(b.h_cand, b.d_cand, ((size_t)o->dev.ncells + 1 + o->cand_cap) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int* offs = b.h_cand;
+    const uint32_t* rec = (const uint32_t*)(b.h_cand + o->dev.ncells + 1);
+    o->last_cand.resize(o->nlevels);
+    for (int l = 0; l < o->nlevels; l++) {
+      const LevelInfo& L = o->dev.lv[l];
+      const int c0 = offs[L.cellBase], c1 = offs[L.cellBase + L.nCols * L.nRows];
+      o->last_cand[l].resize(c1 - c0);
+      for (int k = c0; k < c1; k++) { const uint32_t r = rec[k]; o->last_cand[l][k - c0] = Cand{(float)(r & 0xFFF), (float)((r >> 12) & 0xFFF), (float)(r >> 24)}; }
+    }
+    o->last_cand_valid = true;
+  }
+  if ((int)o->last_cand.size() != o->nlevels) return CCM_E_ARG;
   const std::vector<Cand>& c = o->last_cand[level];
   *n_out = (int)c.size();
   for (int i = 0; i < (int)c.size() && i < cap && out; i++) out[i] = ccm_keypoint{c[i].x, c[i].y, 7.f, -1.f, c[i].response, 0};
