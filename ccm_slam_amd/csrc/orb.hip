@@ -979,8 +979,9 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     const size_t budget = 150 * 1024;
     o->oct_stride = nmax + 8;
     o->oct_kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
-    o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
     o->oct_ok = !host_oct && o->oct_kcap >= 2048 && 4 * nmax + 16 <= 2 * kOctTPB;
+    if (getenv("CCM_ORB_OCT_KCAP")) o->oct_kcap = std::min(o->oct_kcap, std::max(256, atoi(getenv("CCM_ORB_OCT_KCAP"))) & ~15);   // tests: force the host fallback
+    o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
   }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
@@ -1346,6 +1347,67 @@ extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out
   const std::vector<Cand>& c = o->last_cand[level];
   *n_out = (int)c.size();
   for (int i = 0; i < (int)c.size() && i < cap && out; i++) out[i] = ccm_keypoint{c[i].x, c[i].y, 7.f, -1.f, c[i].response, 0};
+  return CCM_OK;
+}
+
+// Test hook: the device octree kernel alone on a caller-supplied candidate set of ONE level (integer positions relative to the level's border
+// box of W x H, responses 1..255); sel_out receives the indices of the kept candidates in output order.  *overflow = 1 when the set does not
+// fit the kernel's LDS plan for N features.
+extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N,
+                                        int32_t* sel_out, int cap, int* n_out, int* overflow) {
+  if (!ctx || n < 0 || !n_out || !overflow || (n && (!x || !y || !response)) || W <= 0 || H <= 0 || N <= 0 || W > 4000 || H > 4000)
+    return ccm_set_error(ctx, CCM_E_ARG, "ccm_orb_debug_octree_dev: bad args");
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  OrbDev d{};
+  d.nlevels = 1; d.ncells = 1;
+  d.lv[0].w = W + 2 * kEdge - 6; d.lv[0].h = H + 2 * kEdge - 6; d.lv[0].nCols = 1; d.lv[0].nRows = 1; d.lv[0].cellBase = 0;
+  std::vector<int> cand(2 + (size_t)n);
+  cand[0] = 0; cand[1] = n;
+  for (int k = 0; k < n; k++) {
+    if (x[k] < 0 || x[k] > 0xFFF || y[k] < 0 || y[k] > 0xFFF || response[k] < 1 || response[k] > 255) return ccm_set_error(ctx, CCM_E_ARG, "ccm_orb_debug_octree_dev: candidate out of range");
+    cand[2 + k] = (int)((uint32_t)x[k] | ((uint32_t)y[k] << 12) | ((uint32_t)response[k] << 24));
+  }
+  const int lcap = 4 * N + 16, stride = 4 * N + 16;
+  const size_t slots = (size_t)lcap * (2 * sizeof(OctNode) + 16 + 5 * 2 + 1) + 64;
+  const size_t budget = 150 * 1024;
+  const int kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
+  if (kcap < 16 || lcap > 2 * kOctTPB) { *overflow = 1; *n_out = 0; return CCM_OK; }
+  int *d_cand = nullptr, *d_counts = nullptr, *d_nout = nullptr; KpIn *d_stage = nullptr, *d_kin = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_cand, cand.size() * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_counts, 4 * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_nout, 2 * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_stage, (size_t)stride * sizeof(KpIn)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d_kin, (size_t)stride * sizeof(KpIn)));
+  hipMemcpyAsync(d_cand, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  hipMemsetAsync(d_counts, 0, 4 * sizeof(int), ctx->stream);
+  hipMemsetAsync(d_nout, 0, 2 * sizeof(int), ctx->stream);
+  OctArgs a{};
+  a.cand = d_cand; a.ncells = 1; a.nlevels = 1; a.nfeat[0] = N; a.lcap[0] = lcap; a.kcap = kcap; a.stage = d_stage; a.stage_stride = stride;
+  a.counts = d_counts; a.kin = d_kin; a.n_out = d_nout; a.kp_cap = stride;
+  const size_t lds = ((size_t)kcap * 7 + 15) / 16 * 16 + slots;
+  int rc = CCM_OK;
+  if (hipFuncSetAttribute((const void*)orb_octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "octree: LDS attribute");
+  std::vector<KpIn> out(stride);
+  int hn[2] = {0, 0};
+  if (rc == CCM_OK) {
+    hipLaunchKernelGGL(orb_octree_kernel, dim3(1), dim3(kOctTPB), lds, ctx->stream, d, a);
+    hipMemcpyAsync(out.data(), d_kin, out.size() * sizeof(KpIn), hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(hn, d_nout, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_orb_debug_octree_dev: kernel");
+  }
+  hipFree(d_cand); hipFree(d_counts); hipFree(d_nout); hipFree(d_stage); hipFree(d_kin);
+  if (rc) return rc;
+  *overflow = hn[1]; *n_out = hn[1] ? 0 : hn[0];
+  if (!hn[1] && sel_out) {
+    // the kernel returns positions; positions are unique in a candidate set, so they identify the candidate
+    const int minB = kEdge - 3;
+    for (int e = 0; e < hn[0] && e < cap; e++) {
+      const int px = out[e].x - minB, py = out[e].y - minB;
+      int found = -1;
+      for (int k = 0; k < n; k++) if (x[k] == px && y[k] == py) { found = k; break; }
+      sel_out[e] = found;
+    }
+  }
   return CCM_OK;
 }
 

@@ -143,6 +143,16 @@ def distribute_octree(x, y, response, minX, maxX, minY, maxY, N):
     return sel[:n.value]
 
 
+def debug_octree_dev(ctx: Context, x, y, response, W, H, N):
+    """Test hook: the device octree kernel on one level's candidates; returns (selected indices in output order, overflow flag)."""
+    x, y, r = (np.ascontiguousarray(a, np.int32) for a in (x, y, response))
+    sel = np.zeros(4 * N + 16, np.int32)
+    n = C.c_int(0); over = C.c_int(0)
+    check(lib().ccm_orb_debug_octree_dev(ctx.handle, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                                         int(x.size), int(W), int(H), int(N), sel.ctypes.data_as(C.c_void_p), int(sel.size), C.byref(n), C.byref(over)), ctx.handle)
+    return sel[:n.value], over.value
+
+
 def smoke_check(ctx: Context, oracle):
     from . import synth
     img = synth.gen_image(1234, 0)

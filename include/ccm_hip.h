@@ -142,6 +142,11 @@ int  ccm_orb_max_keypoints(const ccm_orb* orb);
  * (minX,minY); sel_out receives the indices of the kept candidates in the reference's output order. */
 int  ccm_orb_distribute_octree(const float* x, const float* y, const float* response, int n, int minX, int maxX,
                                int minY, int maxY, int N, int32_t* sel_out, int cap, int* n_out);
+/* test hook: DistributeOctTree as the DEVICE runs it (orb_octree_kernel, one workgroup) on one level's candidates: integer positions inside the
+ * level's W x H border box, responses 1..255, positions unique; sel_out: indices of the kept candidates in output order.  *overflow = 1 when
+ * the set does not fit the kernel's LDS plan (the extractor then selects on the host). */
+int  ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N,
+                              int32_t* sel_out, int cap, int* n_out, int* overflow);
 /* batch of frames already resident in HBM (d_imgs: n_frames images, tightly packed w*h each);
  * outputs stay on the device: d_kps [n_frames][cap], d_desc [n_frames][cap][32],
  * d_counts [n_frames].  Host octree selection (DistributeOctTree) runs between the two device

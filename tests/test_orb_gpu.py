@@ -107,3 +107,34 @@ def test_batch_of_frames_in_hbm_equals_frame_by_frame_extraction(ctx, oracle_lib
     ok, od = oracle_lib.OrbOracle(1000).extract(imgs[4])
     assert np.array_equal(res[4][1], od) and np.array_equal(res[4][0]["x"], ok["x"])
     ex.close()
+
+
+def test_device_octree_matches_the_sequential_list_walk(ctx, oracle_lib):
+    """orb_octree_kernel (round-based restatement of DistributeOctTree, one workgroup per level) against the oracle's sequential walk on random
+    candidate sets: one / two / three root nodes, N from 1 to 434, few and many candidates, heavy ties in size and response."""
+    rng = np.random.default_rng(5)
+    from oracle import KP_DTYPE
+    n_checked = 0
+    for trial in range(60):
+        W = int(rng.integers(120, 760)); H = int(rng.integers(60, 470))
+        if W < H: W, H = H, W
+        if trial % 7 == 0: W = min(3 * H + int(rng.integers(0, 40)), 4000)
+        n = int(rng.integers(1, 6000)); N = int(rng.choice([1, 2, 5, 17, 60, 105, 217, 434]))
+        x = rng.integers(0, W, n); y = rng.integers(0, H, n)
+        _, ui = np.unique(np.stack([x, y], 1), axis=0, return_index=True); ui.sort()
+        x, y = x[ui], y[ui]
+        resp = rng.integers(7, 7 + (3 if trial % 3 == 0 else 120), x.size)
+        sel, over = orb.debug_octree_dev(ctx, x, y, resp, W, H, N)
+        if over: continue
+        kps = np.zeros(x.size, KP_DTYPE); kps["x"] = x; kps["y"] = y; kps["response"] = resp
+        ref = oracle_lib.distribute_octree(kps, 0, W, 0, H, N)
+        assert len(sel) == len(ref), (trial, W, H, x.size, N, len(sel), len(ref))
+        assert np.array_equal(x[sel].astype(np.float32), ref["x"]) and np.array_equal(y[sel].astype(np.float32), ref["y"]), (trial, W, H, x.size, N)
+        n_checked += 1
+    assert n_checked >= 50
+
+
+def test_levels_that_do_not_fit_the_octree_kernel_fall_back_to_the_host(ctx, oracle_lib, monkeypatch):
+    """CCM_ORB_OCT_KCAP shrinks the kernel's candidate capacity: level 0 overflows, the frame is redone through the host octree, same result."""
+    monkeypatch.setenv("CCM_ORB_OCT_KCAP", "1024")
+    _compare(ctx, oracle_lib, synth.gen_image(1000, 3), 1000)
