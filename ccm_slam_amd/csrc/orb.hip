@@ -292,9 +292,11 @@ struct OctArgs {
   int stage_stride;
   int* counts;            // [nlevels] list sizes, [nlevels] = arrival counter
   KpIn* kin; int* n_out; int kp_cap;   // n_out: [keypoint count, overflow flag]
+  unsigned long long* dbg;   // nullable: phase clocks of level 0 (timing experiments)
 };
 
-// exclusive scan of two consecutive items per thread over the workgroup (items 2t, 2t+1); returns the total.  wsum: LDS [kOctTPB / 64 + 1]
+// exclusive scan of two consecutive items per thread over the workgroup (items 2t, 2t+1); returns the total.  wsum: LDS [TPB / 64 + 1]
+template <int TPB>
 __device__ __forceinline__ int oct_scan2(int v0, int v1, int& e0, int& e1, int* wsum) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int a = v0 + v1;
@@ -306,15 +308,16 @@ __device__ __forceinline__ int oct_scan2(int v0, int v1, int& e0, int& e1, int* 
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kOctTPB / 64; w++) { const int x = wsum[w]; if (w < wv) base += x; tot += x; }
+  for (int w = 0; w < TPB / 64; w++) { const int x = wsum[w]; if (w < wv) base += x; tot += x; }
   e0 = base + inc - a;
   e1 = e0 + v0;
   return tot;
 }
 
-__global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
+template <int TPB>
+__global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_lds[];
-  __shared__ int wsum[kOctTPB / 64 + 1];
+  __shared__ int wsum[TPB / 64 + 1];
   __shared__ int sh[16];                 // [0] list size  [1] cur buffer  [2] created  [3] new candidates  [4] finish  [5] cut rank  [6] overflow
   __shared__ int rootcnt[16], rootslot[16];
   const int t = threadIdx.x;
@@ -334,11 +337,13 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
   uint32_t* cnt = reinterpret_cast<uint32_t*>(oct_lds + o); o += (size_t)Lcap * 16;     // [Lcap][4] quadrant counts, then child slots / new slot
   int16_t* prank = reinterpret_cast<int16_t*>(oct_lds + o); o += (size_t)Lcap * 2;      // processing rank of a slot, -1 = not split
   int16_t* byrank = reinterpret_cast<int16_t*>(oct_lds + o); o += (size_t)Lcap * 2;     // rank -> children (then creation base)
-  uint16_t* cslot = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    // expandable children of the last pass: slot,
-  uint16_t* csize = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    //   size,
-  uint16_t* cci = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;      //   creation index
+  o = (o + 15) & ~(size_t)15;
+  uint32_t* ckey = reinterpret_cast<uint32_t*>(oct_lds + o); o += (size_t)Lcap * 4;     // expandable children of the last pass: size << 16 | creation index
+  uint16_t* cslot = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    //   and their list slot
   uint8_t* mark = reinterpret_cast<uint8_t*>(oct_lds + o);                                  // [Lcap] node takes part in the counting
   int* g_over = a.n_out + 1;                                                                  // [count, overflow flag]
+  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define OCT_T(slot) do { if (a.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tq[slot] += t_ - tl; tl = t_; } } while (0)
   if (t < 16) { sh[t] = 0; rootcnt[t] = 0; }
   __syncthreads();
   const int W = (Lv.w - kEdge + 3) - (kEdge - 3), H = (Lv.h - kEdge + 3) - (kEdge - 3);
@@ -347,12 +352,22 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
   if (!overflow && n > 0) {
     const float hX = static_cast<float>(W) / nIni;
     // roots: bin the candidates (order inside a node never matters, see above)
-    for (int k = t; k < n; k += kOctTPB) {
-      const uint32_t r = grec[k];
-      rec[k] = r;
-      const int root = (int)(static_cast<float>(r & 0xFFF) / hX);
-      kq[k] = (uint8_t)root;
-      atomicAdd(&rootcnt[root < 15 ? root : 15], 1);
+    for (int k0 = t; k0 < n; k0 += 4 * TPB) {   // four global loads in flight per thread
+      uint32_t r4[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) r4[q] = (k0 + q * TPB < n) ? grec[k0 + q * TPB] : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; q++) if (k0 + q * TPB < n) rec[k0 + q * TPB] = r4[q];
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += TPB) {   // every wave adds its count per root once (thousands of atomics on one or two counters serialise)
+      const int k = k0 + t;
+      int root = -1;
+      if (k < n) { root = (int)(static_cast<float>(rec[k] & 0xFFF) / hX); root = root < 15 ? root : 15; kq[k] = (uint8_t)root; }
+      for (int i = 0; i <= nIni && i < 16; i++) {
+        const int c = __popcll(__ballot(root == i));
+        if ((t & 63) == 0 && c) atomicAdd(&rootcnt[i], c);
+      }
     }
     __syncthreads();
     if (t == 0) {
@@ -368,8 +383,9 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
       sh[0] = ls; sh[1] = 0;
     }
     __syncthreads();
-    for (int k = t; k < n; k += kOctTPB) knode[k] = (uint16_t)rootslot[kq[k]];
+    for (int k = t; k < n; k += TPB) knode[k] = (uint16_t)rootslot[kq[k]];
     __syncthreads();
+    OCT_T(0);
     // ---- rounds ----
     bool final_phase = false;
     for (int guard = 0; guard < 64; guard++) {
@@ -377,27 +393,22 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
       OctNode* cur = sh[1] ? nodes1 : nodes0;
       OctNode* nxt = sh[1] ? nodes0 : nodes1;
       const int m = sh[3];                                   // expandable children of the previous pass (final phase input)
-      // 1. which nodes take part
       const int i0 = 2 * t, i1 = 2 * t + 1;
-      int f0 = 0, f1 = 0;
+      // 1. which nodes take part in the counting: every expandable node (main loop) / the candidates of the previous pass (final phase)
       if (!final_phase) {
-        if (i0 < Ls) f0 = cur[i0].nomore ? 0 : 1;
-        if (i1 < Ls) f1 = cur[i1].nomore ? 0 : 1;
-        int e0, e1;
-        const int P = oct_scan2(f0, f1, e0, e1, wsum);
-        if (i0 < Ls) { prank[i0] = f0 ? (int16_t)e0 : (int16_t)-1; mark[i0] = (uint8_t)f0; }
-        if (i1 < Ls) { prank[i1] = f1 ? (int16_t)e1 : (int16_t)-1; mark[i1] = (uint8_t)f1; }
-        if (t == 0) sh[5] = P;                               // all of them are split
+        if (i0 < Ls) mark[i0] = cur[i0].nomore ? 0 : 1;
+        if (i1 < Ls) mark[i1] = cur[i1].nomore ? 0 : 1;
       } else {
-        if (i0 < Ls) { prank[i0] = -1; mark[i0] = 0; }
-        if (i1 < Ls) { prank[i1] = -1; mark[i1] = 0; }
+        if (i0 < Ls) mark[i0] = 0;
+        if (i1 < Ls) mark[i1] = 0;
         __syncthreads();
-        for (int c = t; c < m; c += kOctTPB) mark[cslot[c]] = 1;
+        for (int c = t; c < m; c += TPB) mark[cslot[c]] = 1;
       }
-      for (int e = t; e < 4 * Ls; e += kOctTPB) cnt[e] = 0;
+      for (int e = t; e < 4 * Ls; e += TPB) cnt[e] = 0;
+      if (t == 0) sh[3] = 0;
       __syncthreads();
       // 2. quadrant of every key of a participating node (DivideNode :650-705), counts per (node, quadrant)
-      for (int k = t; k < n; k += kOctTPB) {
+      for (int k = t; k < n; k += TPB) {
         const int nd = knode[k];
         if (!mark[nd]) continue;
         const OctNode Pn = cur[nd];
@@ -409,45 +420,70 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
         atomicAdd(&cnt[4 * nd + q], 1u);
       }
       __syncthreads();
-      if (final_phase) {
-        // 3. processing order of the final phase: descending (size, creation index); the list reaches N at rank sh[5]
-        for (int c = t; c < m; c += kOctTPB) {
-          const int sz = csize[c], ci = cci[c];
-          int r = 0;
-          for (int o2 = 0; o2 < m; o2++) { const int s2 = csize[o2], c2 = cci[o2]; r += (s2 > sz || (s2 == sz && c2 > ci)) ? 1 : 0; }
-          const int nd = cslot[c];
-          const int nch = (cnt[4 * nd] ? 1 : 0) + (cnt[4 * nd + 1] ? 1 : 0) + (cnt[4 * nd + 2] ? 1 : 0) + (cnt[4 * nd + 3] ? 1 : 0);
-          prank[nd] = (int16_t)r;
-          byrank[r] = (int16_t)(nch - 1);
-        }
-        __syncthreads();
+      OCT_T(1);
+      auto nchild = [&](int i) { return (cnt[4 * i] ? 1 : 0) + (cnt[4 * i + 1] ? 1 : 0) + (cnt[4 * i + 2] ? 1 : 0) + (cnt[4 * i + 3] ? 1 : 0); };
+      int P, C;                                              // nodes split in this pass, children created
+      int kp0 = 0, kp1 = 0;                                  // kept nodes before slot i0 / i1
+      if (!final_phase) {
+        // 3a. main loop: every expandable node is split, in list order.  One scan of (split flag | children << 12) gives the processing
+        // rank, the creation base of the node's children and — slot minus rank — the position of a kept node behind them
+        const int f0 = i0 < Ls ? mark[i0] : 0, f1 = i1 < Ls ? mark[i1] : 0;
+        const int v0 = f0 ? (1 | (nchild(i0) << 12)) : 0, v1 = f1 ? (1 | (nchild(i1) << 12)) : 0;
         int e0, e1;
-        const int v0 = i0 < m ? byrank[i0] : 0, v1 = i1 < m ? byrank[i1] : 0;
-        oct_scan2(v0, v1, e0, e1, wsum);
+        const int tot = oct_scan2<TPB>(v0, v1, e0, e1, wsum);
+        P = tot & 0xFFF; C = tot >> 12;
+        if (i0 < Ls) { prank[i0] = f0 ? (int16_t)(e0 & 0xFFF) : (int16_t)-1; if (f0) byrank[e0 & 0xFFF] = (int16_t)(e0 >> 12); }
+        if (i1 < Ls) { prank[i1] = f1 ? (int16_t)(e1 & 0xFFF) : (int16_t)-1; if (f1) byrank[e1 & 0xFFF] = (int16_t)(e1 >> 12); }
+        kp0 = i0 - (e0 & 0xFFF); kp1 = i1 - (e1 & 0xFFF);
+        __syncthreads();
+      } else {
+        // 3b. final phase: processing order = descending (size, creation index); the pass stops with the node that takes the list to N
+        if (i0 < Ls) prank[i0] = -1;
+        if (i1 < Ls) prank[i1] = -1;
+        __syncthreads();
+        for (int e = m + t; e < ((m + 3) & ~3); e += TPB) ckey[e] = 0;   // pad to whole 16-byte reads (0 is below every key)
+        __syncthreads();
+        for (int c = t; c < m; c += TPB) {
+          const uint32_t key = ckey[c];
+          int r = 0;
+          for (int o2 = 0; o2 < m; o2 += 4) {   // (size, creation index) compare as one word; four candidates per LDS read
+            const uint4 k4 = *reinterpret_cast<const uint4*>(ckey + o2);
+            r += (k4.x > key ? 1 : 0) + (k4.y > key ? 1 : 0) + (k4.z > key ? 1 : 0) + (k4.w > key ? 1 : 0);
+          }
+          const int nd = cslot[c];
+          prank[nd] = (int16_t)r;
+          byrank[r] = (int16_t)nchild(nd);
+        }
         if (t == 0) sh[5] = m;                                // no cut: every candidate is split
         __syncthreads();
-        // first rank whose inclusive count reaches N
-        if (i0 < m && Ls + e0 + v0 >= N && (i0 == 0 || Ls + e0 < N)) sh[5] = i0 + 1;
-        if (i1 < m && Ls + e1 + v1 >= N && Ls + e1 < N) sh[5] = i1 + 1;
+        const int n0 = i0 < m ? byrank[i0] : 0, n1 = i1 < m ? byrank[i1] : 0;   // children by rank
+        int e0, e1;
+        oct_scan2<TPB>(n0, n1, e0, e1, wsum);                        // children created before this rank
+        // list size after splitting ranks 0..r = Ls + children - (r + 1); first rank that reaches N
+        const int a0 = Ls + e0 + n0 - (i0 + 1), b0 = Ls + e0 - i0;
+        const int a1 = Ls + e1 + n1 - (i1 + 1), b1 = Ls + e1 - i1;
+        if (i0 < m && a0 >= N && b0 < N) sh[5] = i0 + 1;
+        if (i1 < m && a1 >= N && b1 < N) sh[5] = i1 + 1;
         __syncthreads();
-        const int R = sh[5];
-        for (int c = t; c < m; c += kOctTPB) { const int nd = cslot[c]; if (prank[nd] >= R) prank[nd] = -1; }
+        P = sh[5];
+        if (i0 < P) byrank[i0] = (int16_t)e0;                 // creation base of the rank's children
+        if (i1 < P) byrank[i1] = (int16_t)e1;
+        for (int c = t; c < m; c += TPB) { const int nd = cslot[c]; if (prank[nd] >= P) prank[nd] = -1; }
+        if (t == 0) sh[2] = 0;
         __syncthreads();
+        // children created by the ranks below the cut, and the kept nodes in list order
+        int k0, k1;
+        const int K = oct_scan2<TPB>((i0 < Ls && prank[i0] < 0) ? 1 : 0, (i1 < Ls && prank[i1] < 0) ? 1 : 0, k0, k1, wsum);
+        kp0 = k0; kp1 = k1;
+        // C = children of ranks 0..P-1 = base of rank P-1 + its children
+        if (P > 0 && i0 == P - 1) sh[2] = e0 + n0;
+        if (P > 0 && i1 == P - 1) sh[2] = e1 + n1;
+        __syncthreads();
+        C = sh[2];
+        (void)K;
       }
-      const int P = sh[5];                                   // nodes split in this pass (ranks 0 .. P-1)
-      // 4. children per rank -> creation base; kept nodes -> position behind the children
-      if (i0 < Ls && prank[i0] >= 0) byrank[prank[i0]] = (int16_t)((cnt[4 * i0] ? 1 : 0) + (cnt[4 * i0 + 1] ? 1 : 0) + (cnt[4 * i0 + 2] ? 1 : 0) + (cnt[4 * i0 + 3] ? 1 : 0));
-      if (i1 < Ls && prank[i1] >= 0) byrank[prank[i1]] = (int16_t)((cnt[4 * i1] ? 1 : 0) + (cnt[4 * i1 + 1] ? 1 : 0) + (cnt[4 * i1 + 2] ? 1 : 0) + (cnt[4 * i1 + 3] ? 1 : 0));
-      __syncthreads();
-      int cb0, cb1;
-      const int C = oct_scan2(i0 < P ? byrank[i0] : 0, i1 < P ? byrank[i1] : 0, cb0, cb1, wsum);
-      __syncthreads();
-      if (i0 < P) byrank[i0] = (int16_t)cb0;
-      if (i1 < P) byrank[i1] = (int16_t)cb1;
-      int kp0, kp1;
-      const int K = oct_scan2((i0 < Ls && prank[i0] < 0) ? 1 : 0, (i1 < Ls && prank[i1] < 0) ? 1 : 0, kp0, kp1, wsum);
-      if (t == 0) { sh[2] = C; sh[3] = 0; }
-      __syncthreads();
+      OCT_T(final_phase ? 3 : 2);
+      const int K = Ls - P;
       if (C + K > Lcap) overflow = true;                      // (cannot happen: a pass at most quadruples a list shorter than N)
       // 5. the new list
       if (!overflow) {
@@ -475,29 +511,27 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
             const int ns = C - 1 - ci;                        // pushed to the front: reverse creation order
             nxt[ns] = ch;
             cnt[4 * i + q] = (uint32_t)ns;
-            if (sz > 1) { const int e = atomicAdd(&sh[3], 1); cslot[e] = (uint16_t)ns; csize[e] = (uint16_t)sz; cci[e] = (uint16_t)ci; }
+            if (sz > 1) { const int e = atomicAdd(&sh[3], 1); cslot[e] = (uint16_t)ns; ckey[e] = ((uint32_t)sz << 16) | (uint32_t)ci; }
             ci++;
           }
         }
       }
       __syncthreads();
+      OCT_T(4);
       // 6. keys follow their nodes
       if (!overflow)
-        for (int k = t; k < n; k += kOctTPB) {
+        for (int k = t; k < n; k += TPB) {
           const int nd = knode[k];
           knode[k] = (uint16_t)cnt[4 * nd + (prank[nd] >= 0 ? kq[k] : 0)];
         }
-      __syncthreads();
       // 7. the reference's loop conditions (:835-845, :901-905)
       const int newLs = C + K, nExp = sh[3];
-      bool done;
-      if (!final_phase) {
-        done = newLs >= N || newLs == Ls;
-        if (!done && newLs + 3 * nExp > N) final_phase = true;
-      } else done = newLs >= N || newLs == Ls;
+      const bool done = newLs >= N || newLs == Ls;
+      if (!final_phase && !done && newLs + 3 * nExp > N) final_phase = true;
       __syncthreads();
       if (t == 0) { sh[0] = newLs; sh[1] ^= 1; }
       __syncthreads();
+      OCT_T(5); tq[7]++;
       if (done || overflow) break;
     }
   }
@@ -506,18 +540,21 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
   if (Ls > 0) {
     OctNode* cur = sh[1] ? nodes1 : nodes0;
     (void)cur;
-    for (int e = t; e < Ls; e += kOctTPB) cnt[e] = 0;
+    for (int e = t; e < Ls; e += TPB) cnt[e] = 0;
     __syncthreads();
-    for (int k = t; k < n; k += kOctTPB) atomicMax(&cnt[knode[k]], ((rec[k] >> 24) << 16) | (uint32_t)(0xFFFF - k));   // first maximum = smallest index
+    for (int k = t; k < n; k += TPB) atomicMax(&cnt[knode[k]], ((rec[k] >> 24) << 16) | (uint32_t)(0xFFFF - k));   // first maximum = smallest index
     __syncthreads();
     const int minB = kEdge - 3;
-    for (int e = t; e < Ls && e < a.stage_stride; e += kOctTPB) {
+    for (int e = t; e < Ls && e < a.stage_stride; e += TPB) {
       const uint32_t r = rec[0xFFFF - (cnt[e] & 0xFFFF)];
       a.stage[(size_t)l * a.stage_stride + e] = KpIn{(int16_t)((int)(r & 0xFFF) + minB), (int16_t)((int)((r >> 12) & 0xFFF) + minB), (int16_t)l, (int16_t)(r >> 24)};
     }
     if (Ls > a.stage_stride) overflow = true;
   }
   // ---- the last level to finish concatenates the levels ----
+  OCT_T(6);
+  if (a.dbg && l == 0 && t == 0) for (int q = 0; q < 8; q++) a.dbg[q] += tq[q];
+#undef OCT_T
   __shared__ int last;
   __threadfence();
   __syncthreads();
@@ -533,7 +570,7 @@ __global__ __launch_bounds__(kOctTPB) void orb_octree_kernel(OrbDev d, OctArgs a
   int off = 0;
   for (int q = 0; q < a.nlevels; q++) {
     const int c = __hip_atomic_load(a.counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int e = t; e < c && off + e < a.kp_cap; e += kOctTPB) a.kin[off + e] = a.stage[(size_t)q * a.stage_stride + e];
+    for (int e = t; e < c && off + e < a.kp_cap; e += TPB) a.kin[off + e] = a.stage[(size_t)q * a.stage_stride + e];
     off += c;
   }
   if (t == 0) { *a.n_out = off < a.kp_cap ? off : a.kp_cap; a.counts[a.nlevels] = 0; }
@@ -785,9 +822,10 @@ struct ccm_orb {
   double t_phase[6] = {0, 0, 0, 0, 0, 0}; double t_wait_cand = 0;   // host wall clock of the last frame, ms: upload+queue, wait cand, octree, queue2, wait+D2H, total
   Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
   // device octree (orb_octree_kernel): LDS plan of this geometry; oct_ok = false -> host octree
-  bool oct_ok = false; int oct_kcap = 0, oct_stride = 0; size_t oct_lds = 0; int oct_lcap[kMaxLevels] = {0};
+  bool oct_ok = false; int oct_tpb = 1024; int oct_kcap = 0, oct_stride = 0; size_t oct_lds = 0; int oct_lcap[kMaxLevels] = {0};
   hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
   hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  unsigned long long* d_oct_dbg = nullptr;   // CCM_ORB_OCT_DBG: phase clocks of the octree kernel, printed by ccm_orb_destroy
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand; bool last_cand_valid = false;
 };
@@ -845,6 +883,14 @@ extern "C" int ccm_orb_create(ccm_ctx* ctx, int nfeatures, float scale_factor, i
 extern "C" void ccm_orb_destroy(ccm_orb* o) {
   if (!o) return;
   if (o->ctx) { hipSetDevice(o->ctx->device); hipStreamSynchronize(o->ctx->stream); }
+  if (o->d_oct_dbg) {
+    unsigned long long h[8];
+    hipMemcpy(h, o->d_oct_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const double nl = (double)std::max<unsigned long long>(h[7], 1);
+    fprintf(stderr, "[ccm_orb] octree kernel, level 0, clock ticks: load+roots %llu | per pass (%llu passes): count %.0f scan(main) %.0f rank+scan(final) %.0f new list %.0f remap+loop %.0f | final select %llu\n",
+            h[0], h[7], h[1] / nl, h[2] / nl, h[3] / nl, h[4] / nl, h[5] / nl, h[6]);
+    hipFree(o->d_oct_dbg);
+  }
   orb_free_geometry(o);
   for (int k = 0; k < 2; k++) if (o->B[k].ev_cand) hipEventDestroy(o->B[k].ev_cand);
   if (o->stream2) { hipStreamSynchronize(o->stream2); hipStreamDestroy(o->stream2); }
@@ -980,9 +1026,11 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     o->oct_stride = nmax + 8;
     o->oct_kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
     o->oct_ok = !host_oct && o->oct_kcap >= 2048 && 4 * nmax + 16 <= 2 * kOctTPB;
+    o->oct_tpb = (4 * nmax + 16 <= 1024 && !getenv("CCM_ORB_OCT_1024")) ? 512 : 1024;
     if (getenv("CCM_ORB_OCT_KCAP")) o->oct_kcap = std::min(o->oct_kcap, std::max(256, atoi(getenv("CCM_ORB_OCT_KCAP"))) & ~15);   // tests: force the host fallback
     o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
   }
+  if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 64)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 64)); }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1147,10 +1195,16 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap) {
   for (int l = 0; l < o->nlevels; l++) { a.nfeat[l] = o->nfeat[l]; a.lcap[l] = o->oct_lcap[l]; }
   a.kcap = o->oct_kcap; a.stage = b.d_oct_stage; a.stage_stride = o->oct_stride; a.counts = b.d_oct_counts;
   a.kin = b.d_kin; a.n_out = b.d_n; a.kp_cap = std::min(o->kp_cap, out_cap);
-  CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel, 152 * 1024);
+  a.dbg = o->d_oct_dbg;
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
-    hipLaunchKernelGGL(orb_octree_kernel, dim3(o->nlevels), dim3(kOctTPB), o->oct_lds, o->st, o->dev, a);
+    if (o->oct_tpb == 512) {   // two list slots per thread: 512 threads hold up to 4 N + 16 = 1024 slots, and a barrier of 8 waves is cheaper than one of 16
+      CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel<512>, 152 * 1024);
+      hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(o->nlevels), dim3(512), o->oct_lds, o->st, o->dev, a);
+    } else {
+      CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT2, orb_octree_kernel<1024>, 152 * 1024);
+      hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(o->nlevels), dim3(1024), o->oct_lds, o->st, o->dev, a);
+    }
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
@@ -1386,11 +1440,12 @@ extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const in
   a.counts = d_counts; a.kin = d_kin; a.n_out = d_nout; a.kp_cap = stride;
   const size_t lds = ((size_t)kcap * 7 + 15) / 16 * 16 + slots;
   int rc = CCM_OK;
-  if (hipFuncSetAttribute((const void*)orb_octree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "octree: LDS attribute");
+  if (hipFuncSetAttribute((const void*)orb_octree_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess || hipFuncSetAttribute((const void*)orb_octree_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "octree: LDS attribute");
   std::vector<KpIn> out(stride);
   int hn[2] = {0, 0};
   if (rc == CCM_OK) {
-    hipLaunchKernelGGL(orb_octree_kernel, dim3(1), dim3(kOctTPB), lds, ctx->stream, d, a);
+    if (lcap <= 1024) hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(1), dim3(512), lds, ctx->stream, d, a);
+    else hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, a);
     hipMemcpyAsync(out.data(), d_kin, out.size() * sizeof(KpIn), hipMemcpyDeviceToHost, ctx->stream);
     hipMemcpyAsync(hn, d_nout, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_orb_debug_octree_dev: kernel");
