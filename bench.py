@@ -168,10 +168,9 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
            "orb_batch64": {"ms_per_frame": round(t_batch * 1e3, 4), "fps": round(1.0 / t_batch, 1), "keypoints": n_batch_kps,
                            "algorithmic_bytes_per_frame": ORB_BYTES_PER_FRAME, "achieved_GBps": round(ORB_BYTES_PER_FRAME / t_batch / 1e9, 2),
                            "frac_of_hbm_peak": round(ORB_BYTES_PER_FRAME / t_batch / 1e9 / HBM_PEAK_GBS, 5),
-                           "note": "64 frames resident in HBM, outputs stay in HBM; two frames in flight, the per-level DistributeOctTree calls of a frame "
-                                   "(independent, ~0.09 ms on one thread) run on the calling thread + 3 helper threads that live for the call "
-                                   "(CCM_ORB_BATCH_THREADS); the 9 MB working set lives in the 256 MB Infinity Cache, so the pipeline is bound by its "
-                                   "~12 short dependent launches per frame, not by HBM"},
+                           "note": "64 frames resident in HBM, outputs stay in HBM; DistributeOctTree runs on the device (one workgroup per level), "
+                                   "the whole batch is queued on two streams (even / odd frames) without host work; the 9 MB working set lives in the "
+                                   "256 MB Infinity Cache, so the pipeline is bound by its ~13 short dependent launches per frame, not by HBM"},
            "window_candidates": int(idx1.size),
            "note": "host-API timings (H2D/D2H included); every stage bit-exact vs the oracle (tests/test_orb_gpu.py, test_frame_gpu.py, "
                    "test_hamming_gpu.py), pose optimisation within 1e-7"}
