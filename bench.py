@@ -360,7 +360,8 @@ def main():
             continue
         avg_us = ms * 1e3 / n
         ach = kb[name] / (avg_us * 1e-6) / 1e9
-        ent = pmc.get(KERNEL_OF_CLASS[name].split("+")[0])
+        kname = KERNEL_OF_CLASS[name].split("+")[0]
+        ent = pmc.get(kname) or pmc.get(kname + "_t")   # templated kernels appear as name_t in the rocprofv3 tables
         kernels.append({"class": name.lower(), "kernel": KERNEL_OF_CLASS[name], "launches_per_call": n, "avg_us": round(avg_us, 2),
                         "ms_per_call": round(ms, 4), "algorithmic_bytes_per_launch": kb[name], "achieved_GBps": round(ach, 1),
                         "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5), "limiter": LIMITER.get(name, "hbm"),
