@@ -1,6 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_orb_gpu.py -x -q -m gpu 2>&1 | tail -5
-echo "== single"; timeout 120 python scripts/orb_phases.py 2>&1 | tail -2
-echo "== batch"; timeout 120 python scripts/orb_batch_time.py 2>&1 | tail -1
-bash scripts/kstats.sh python scripts/orb_batch_time.py 2>&1 | head -3
+for w in 2 3 4 5 6 8; do
+  echo "== waves $w"
+  CCM_POSE_WAVES=$w timeout 60 python scripts/poseopt_profile.py 300 2>&1 | tail -1
+  CCM_POSE_WAVES=$w timeout 60 python scripts/poseopt_profile.py 1000 2>&1 | tail -1
+done
+timeout 300 python -m pytest tests/test_poseopt_gpu.py -x -q -m gpu 2>&1 | tail -2
