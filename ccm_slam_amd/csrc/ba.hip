@@ -26,6 +26,7 @@
 //  * LM control (lambda schedule, rho test, stop rules) runs on the host exactly as
 //    optimization_algorithm_levenberg.cpp:61-164 does; one 48-byte pinned D2H read per trial.
 #include "common.h"
+#include "ba_types.h"
 #include "ba_math.h"
 #include <algorithm>
 #include <chrono>
@@ -35,16 +36,10 @@
 #include <numeric>
 
 int ccm_allreduce_f64(ccm_ctx* ctx, double* d_buf, size_t n);   // comm.hip
-int ccm_ba_build_pairs(ccm_ctx* ctx, const std::vector<int>& g_pt_off, const std::vector<int>& cslot_g, int Cp, int lb, int le, int eb,
-                       std::vector<uint64_t>& all_keys, int** d_inst_off, int** d_inst_a, int** d_inst_c, int64_t* n_inst,
-                       std::vector<std::pair<void*, size_t>>& keep);   // ba_structure.hip
 int ccm_allreduce_max_f64(ccm_ctx* ctx, double* d_buf, size_t n);
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kTPB = 256;
-constexpr uint32_t kTransposeBit = 0x80000000u;
 
 inline double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -101,80 +96,6 @@ __device__ __forceinline__ void block_sum_partials(const double* const (&p)[NS],
   }
 }
 
-struct BaDev {
-  // sizes
-  int n_cam, Cp, Lloc, Eloc, nOff;
-  double huber;
-  // camera state (all cameras replicated), [2][n_cam*7]
-  double* cam[2];
-  const double* K;           // [n_cam*4]
-  const int* slot_cam;       // [Cp] pose slot -> camera index
-  // landmark state (own landmarks), [2][Lloc*3]
-  double* pt[2];
-  // edges of own landmarks, sorted by landmark
-  const int* pt_off;         // [Lloc+1]
-  const int* ed_cam;         // [Eloc] camera index
-  const int* ed_cslot;       // [Eloc] pose slot or -1 (fixed camera)
-  const int* ed_pt;          // [Eloc] local landmark
-  const double* obs;         // [Eloc*2]
-  const double* info;        // [Eloc]
-  // per camera slot: list of local edges
-  const int* cam_off;        // [Cp+1]
-  const int* cam_edge;       // [..]
-  const int* cam_pt;         // [..] landmark of every camera-list slot (ed_pt[cam_edge[s]])
-  // linear system pieces
-  double* W;                 // [Eloc*18]  Hpl block of each edge (pose rows x landmark cols)
-  double* Hll;               // [Lloc*6]   symmetric 3x3
-  double* bl;                // [Lloc*3]
-  double* Dinv;              // [Lloc*6]
-  double* dl;                // [Lloc*3]   D^-1 b_l
-  double* Hpp;               // [Cp*36]    partial (own edges)
-  double* bp;                // [Cp*6]     partial
-  // reduced system (contiguous: all-reduced in one call)
-  double* S;                 // [(Cp+nOff)*36] diagonal blocks first
-  double* bs;                // [Cp*6]
-  const int* inst_off;       // [nOff+1]
-  const int* inst_a;         // edge with the block-row camera
-  const int* inst_c;         // edge with the block-col camera
-  const int* inst_al;        // rank of inst_a's edge inside its camera's edge list (row-centric Schur kernel)
-  const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
-  int max_cam_edges;         // longest per-camera edge list on this rank
-  // row-centric Schur kernel: work units = (block, chunk of <= row_chunk consecutive pair instances), dealt to the waves
-  const int4* unit_tab;      // [n_units]: block (-1: the camera's own observations), first instance, end instance, slot of the partial sum inside the row; per row longest unit first
-  const int* row_unit_off;   // [Cp+1] units of block row i
-  const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
-  int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
-  double* row_part;          // [n_units][kRowSlot] unit partial sums of the two-rows-per-CU shape of the row kernel (nullptr: not allocated)
-  // block CSR for SpMV (full rows, diag included)
-  const int* row_off;        // [Cp+1]
-  const int* row_col;        // [..]
-  const uint32_t* row_blk;   // [..] block id | transpose bit
-  // PCG
-  double *x, *r, *z, *q, *p[2];
-  double* Wc;                // [n_clusters][96*96] explicit inverses of the damped cluster blocks
-  double *ppq, *prz[2];      // partials
-  double* pcg_scal;          // [0]=rz0 [1]=thresh^2  [2]=lambda
-  int* pcg_flag;             // [0]=done [1]=iters [2]=fail
-  int n_wg_spmv, n_wg_upd, n_wg_wave4;   // wave4: one wave per camera, 4 per workgroup
-  // trial outputs
-  double* edge_chi2;         // [Eloc]
-  uint8_t* edge_depth;       // [Eloc]
-  double* part_pt;           // [n_wg_pt*2]  (robust chi2, scale) partials
-  double* part_cam;          // [n_wg_cam]   scale partials (pose part)
-  double* scal;              // [0] chi2 [1] scale [2] stop requested on any rank [3] persistent PCG gave up on any rank (0..3 are summed over
-                             // ranks in ONE all-reduce per trial) [4] maxdiag [5] - [6..7] = pcg_flag (4 ints)
-  int n_wg_pt, n_wg_cam;
-  // edge-parallel landmark kernels: chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
-  const int* chunk_off;      // [n_chunk+1] landmark ranges; nullptr: a landmark has more than kTPB observations -> thread-per-landmark kernels
-  int n_chunk;
-  int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
-  // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
-  double* mk_cpart;          // [n_clusters][6] restriction parts P^T r of every cluster
-  double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
-  const double* mk_P;        // [Cp][36] prolongation blocks
-  const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse
-  int mk_on, mk_Nc, mk_na;   // mk_on: this trial's solve uses the coarse level
-};
 
 // ---------------------------------------------------------------------------------------------
 // linearisation: landmark side (one thread per own landmark)          [CCM_K_BA_LINEARIZE]
@@ -482,9 +403,6 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // camera i is formed once into LDS (the per-block kernel above re-reads W_a and Dinv and redoes the 6x3x3 product for
 // every pair instance: 336 B and 27 flops per instance instead of 152 B and 9), then the waves walk the blocks (i, j > i)
 // of the row and every instance costs one 144-byte W_c row read plus LDS.                [CCM_K_BA_SCHUR_OFF]
-constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
-constexpr int kRowSlot = 42;        // doubles per work-unit partial: 6x6 block + 6 (b_schur part of the diagonal units)
-constexpr int kRowTPB = 1024;        // 16 waves walk the row's blocks: the instance stream is latency bound, so more streams win
 // Two shapes of the same kernel.  <1024, false>: one 16-wave workgroup per CU, unit partial sums in LDS (rows of any length up to
 // kRowMaxEdges).  <512, true>: 8-wave workgroups with the unit partials in a global scratch (d.row_part, L2-resident: written and read back
 // by the same workgroup) so that LDS holds only Y and TWO rows fit a CU: while one row waits on the three dependent load levels of its Y
@@ -696,16 +614,6 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
   }
 }
 
-// rank of every observation inside its camera's list, then per pair instance the rank of its row-side observation
-__global__ void ba_edge_rank(BaDev d, int* rank) {
-  const int i = blockIdx.x;
-  for (int s = d.cam_off[i] + threadIdx.x; s < d.cam_off[i + 1]; s += blockDim.x) rank[d.cam_edge[s]] = s - d.cam_off[i];
-}
-__global__ void ba_inst_rank(const int* inst_a, const int* rank, int n, int* inst_al) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n) inst_al[s] = rank[inst_a[s]];
-}
-
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
 // Preconditioner: block-Jacobi over CLUSTERS of kClu consecutive camera slots (dense 96x96 blocks).  Keyframes of
 // one agent are consecutive and covisibility is mostly local in time, so a cluster captures the strong
@@ -713,8 +621,6 @@ __global__ void ba_inst_rank(const int* inst_a, const int* rank, int n, int* ins
 // (336 -> 178 at lambda = 0.3).  Per LM trial one workgroup per cluster assembles its dense block from the
 // block-CSR rows, factors it (Cholesky in LDS), forms the explicit inverse W = L^-T L^-1 and stores it; per
 // PCG iteration the same workgroup applies z_c = W r_c (dense 96x96 mat-vec).
-constexpr int kClu = 16;            // cameras per cluster
-constexpr int kCluN = 6 * kClu;     // 96 unknowns
 
 // cluster part of the coarse restriction P^T r (6 values): the 6 products of every (camera, component) go through LDS
 // and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
@@ -743,8 +649,6 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // round trips plus ~10 ns per WORKGROUP dispatched, whatever the workgroups do (a pass that only adds six numbers per row: 20 us for 2 500
 // workgroups), so 5 000 two-row workgroups spent most of the kernel being dispatched.  (Also measured and dropped: a two-pass symmetric
 // form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
-constexpr int kSpmvTPB = 1024;
-constexpr int kRowsPerWG = kSpmvTPB / (2 * kWave);
 __global__ __launch_bounds__(kSpmvTPB) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
@@ -971,11 +875,6 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
 // 4-agent map); its explicit inverse is formed once per LM trial by the tile kernels of dense_chol.hip and the persistent
 // PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Offline study on 600-keyframe systems (same matrices): 296 -> 75 CG
 // iterations at lambda 0.3, 69 -> 38 at lambda 30, independent of the map size.
-#ifndef CCM_KAGG
-#define CCM_KAGG 32
-#endif
-constexpr int kAgg = CCM_KAGG;   // cameras per aggregate (32 = 2 clusters = 4 persistent units)
-constexpr int kAggUnits = kAgg / 8;
 constexpr int kCoarseOnIters = 80, kCoarseOffIters = 35;   // a coarse build (0.38 ms) is worth ~35 CG iterations
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
@@ -1100,11 +999,7 @@ __global__ void ba_coarse_pad(double* Ac, int nc, int Nc) {
 // A barrier gives up after a bounded spin (abort flag -> solver failure -> LM rejects the step) so a scheduling
 // accident can never hang the device.  Cooperative launch guarantees co-residency; the host uses this path when
 // the cluster count fits (<= 4096 free cameras on 256 CUs), the multi-kernel path otherwise.
-constexpr int kPersTPB = 1024;
-constexpr int kPersWaves = kPersTPB / kWave;
 constexpr long kPersMaxSpins = 3000000;    // x ~60 ns sleep: ~0.2 s per barrier worst case
-constexpr int kPersIdxCap = 3072;          // CSR entries of one cluster's rows (staged in LDS)
-constexpr int kPersColCap = 640;           // distinct neighbour columns of one cluster
 
 struct PersArgs {
   double lambda, rel_tol;
@@ -1404,7 +1299,6 @@ __device__ __forceinline__ void pers_factor_cluster(double* A, double* Li, int* 
 // Two 96x96 LDS regions are all a factorisation leaves room for, so T waits in a global scratch (74 KB, L2) while S22 is factored.  This replaces
 // ~19 iterations of the persistent PCG over 4 workgroups (11 us each: two grid exchanges per iteration) by ~6 block products; g2o itself solves
 // these systems directly (LinearSolverDense / Eigen LDLT, Optimizer.cpp:371-375), so the exact solve is also the closer restatement.
-constexpr int kDense2MaxCp = 2 * kClu;
 static inline size_t dense2_lds_bytes() { return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN) * sizeof(double) + 16 + 14 * sizeof(long long) + 64 * sizeof(int); }
 
 __global__ __launch_bounds__(kPersTPB) void ba_solve_dense2(BaDev d, double lambda, const int* coff, const int* cij, const uint32_t* cblk, double* gTt /* [96][96] T transposed */,
@@ -1904,7 +1798,6 @@ static inline size_t pers_lds_bytes() {
 // Vectors and the 6x6 block-Jacobi preconditioner live in LDS and an iteration is a few block barriers (~2 us).  Typical
 // local-BA sizes (tens of cameras) go through the persistent kernel instead: its 16-camera cluster preconditioner needs
 // a third of the iterations (lba_c2: 59 -> 19 per solve).
-constexpr int kSmallMaxCp = 16;   // one cluster: the single-workgroup kernel; above, the persistent kernel with its 16-camera cluster preconditioner
 
 template <int TPB>
 __device__ __forceinline__ double block_dot_small(double v, double* red /* [16] */) {
@@ -2170,10 +2063,10 @@ __global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_loca
   }
 }
 
-__global__ void ba_scatter_points(double* full, const double* own, const int* own_slot /*local -> global landmark slot*/, int Lloc) {
+__global__ void ba_scatter_points(double* full, const double* own, int lb /* first own landmark slot */, int Lloc) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= Lloc) return;
-  const int g = own_slot[l];
+  const int g = lb + l;
   full[3 * (size_t)g] = own[3 * (size_t)l]; full[3 * (size_t)g + 1] = own[3 * (size_t)l + 1]; full[3 * (size_t)g + 2] = own[3 * (size_t)l + 2];
 }
 
@@ -2182,55 +2075,6 @@ __global__ void ba_scatter_points(double* full, const double* own, const int* ow
 // =================================================================================================
 // host side
 // =================================================================================================
-struct ccm_ba {
-  ccm_ctx* ctx = nullptr;
-  int rank = 0, nranks = 1;
-  int n_cam = 0, n_pt = 0, n_edge = 0;
-  int Cp = 0, Lp = 0, Lloc = 0, Eloc = 0, nOff = 0;
-  int64_t n_inst = 0, n_act_edges = 0, n_row_entries = 0;
-  int lp_begin = 0, lp_end = 0;
-  std::vector<int> slot_cam, cam_slot, slot_pt, pt_slot;
-  std::vector<int> loc_edge_orig;       // local edge -> original edge index
-  std::vector<std::pair<void*, size_t>> allocs;   // pooled blocks (ccm_pool_get)
-  BaDev d{};
-  int cur = 0;
-  double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
-  unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
-  double* d_dense_T = nullptr;   // [96][96] scratch of the exact two-cluster solve (17..32 free cameras)
-  int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
-  uint32_t* d_pers_cblk = nullptr;
-  unsigned long long pers_launch = 0;
-  // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
-  int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
-  // The coarse level costs a dense inverse per trial (~0.5 ms) and ~25% per CG iteration; it pays only when the
-  // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
-  // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
-  bool coarse_active = false, coarse_used = false;
-  // The coarse operator Ac = P^T (S + lambda I) P is only a preconditioner: a STALE one (built at an earlier trial's lambda or an
-  // earlier linearisation point) still gives a fixed SPD M^-1 for the whole solve, so PCG converges to the same tolerance, just a few
-  // iterations later.  It is rebuilt when lambda has left [1/4, 4] x the lambda it was built at, or when a solve with the stale
-  // operator needed clearly more iterations than the solve right after the last build (counts are deterministic => so is the policy).
-  bool coarse_valid = false, coarse_fresh = false, coarse_stale_bad = false, coarse_reuse = true;
-  double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
-  double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial
-  int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
-  double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
-  double* d_cparts = nullptr;
-  int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
-  double* d_pt_full = nullptr; int* d_own_slot = nullptr;
-  double* d_hpp_full = nullptr;
-  double *d_saved_cam = nullptr, *d_saved_pt = nullptr;   // ccm_ba_push_state
-  double ms_setup = 0;
-  // stop flag of the running ccm_ba_run (the reference's bool* pbStopFlag).  One rank: read where g2o calls terminate().
-  // Sharded: the local value rides in the per-trial all-reduce and only the reduced value (stop_any) is acted on.
-  const volatile unsigned char* stop_flag = nullptr;
-  bool stop_any = false;
-  bool stop_requested() const { return nranks > 1 ? stop_any : (stop_flag && *stop_flag); }
-  int stop_local() const { return (stop_flag && *stop_flag) ? 1 : 0; }
-  // per-iteration record of the last run (chi2 after the iteration, lambda, trials) and the optional per-trial callback
-  std::vector<double> hist_chi2, hist_lambda; std::vector<int32_t> hist_trials;
-  ccm_ba_trial_cb trial_cb = nullptr; void* trial_cb_user = nullptr;
-};
 
 namespace {
 
@@ -2298,397 +2142,16 @@ extern "C" int ccm_ba_partition(const int64_t* weight, int n, int nranks, int32_
   return CCM_OK;
 }
 
-extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, int nranks, ccm_ba** out) {
-  if (!ctx || !P || !out || nranks < 1 || rank < 0 || rank >= nranks) return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: bad args");
-  if (P->n_cam <= 0 || P->n_pt < 0 || P->n_edge < 0 || !P->cam_qt || !P->cam_fixed || !P->cam_K ||
-      (P->n_pt && !P->pt_xyz) || (P->n_edge && (!P->e_cam || !P->e_pt || !P->e_obs || !P->e_info)))
-    return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: incomplete problem");
-  for (int e = 0; e < P->n_edge; e++)
-    if (P->e_cam[e] < 0 || P->e_cam[e] >= P->n_cam || P->e_pt[e] < 0 || P->e_pt[e] >= P->n_pt)
-      return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: edge index out of range");
-  const double t0 = now_ms();
-  const bool setup_dbg = getenv("CCM_BA_SETUP_DBG") != nullptr;
-  double t_last = t0;
-  auto lap = [&](const char* what) { if (setup_dbg) { const double t = now_ms(); fprintf(stderr, "[ccm_ba] setup %-22s %7.2f ms\n", what, t - t_last); t_last = t; } };
-  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  ccm_ba* ba = new ccm_ba();
-  ba->ctx = ctx; ba->rank = rank; ba->nranks = nranks;
-  ba->n_cam = P->n_cam; ba->n_pt = P->n_pt; ba->n_edge = P->n_edge;
-  auto fail = [&](int rc) { ccm_ba_destroy(ba); return rc; };
-
-  // ---- active set (initializeOptimization(0), sparse_optimizer.cpp:199-267) ----
-  std::vector<int> act;
-  act.reserve(P->n_edge);
-  std::vector<char> cam_has(P->n_cam, 0), pt_has(P->n_pt, 0);
-  for (int e = 0; e < P->n_edge; e++) {
-    if (P->e_level && P->e_level[e] != 0) continue;
-    act.push_back(e);
-    cam_has[P->e_cam[e]] = 1; pt_has[P->e_pt[e]] = 1;
-  }
-  ba->n_act_edges = (int64_t)act.size();
-  ba->cam_slot.assign(P->n_cam, -1); ba->pt_slot.assign(P->n_pt, -1);
-  for (int c = 0; c < P->n_cam; c++) if (cam_has[c] && !P->cam_fixed[c]) { ba->cam_slot[c] = (int)ba->slot_cam.size(); ba->slot_cam.push_back(c); }
-  for (int p = 0; p < P->n_pt; p++) if (pt_has[p]) { ba->pt_slot[p] = (int)ba->slot_pt.size(); ba->slot_pt.push_back(p); }
-  const int Cp = ba->Cp = (int)ba->slot_cam.size();
-  const int Lp = ba->Lp = (int)ba->slot_pt.size();
-
-  lap("active set");
-  // ---- edges sorted by (landmark slot, pose slot) — fixed cameras (slot -1) first ----
-  std::vector<int> order(act.size());
-  std::vector<int> g_pt_off;                    // [Lp+1] edge ranges of the landmark slots in `order`
-  {
-    std::vector<int> cnt(Lp + 1, 0);
-    for (int e : act) cnt[ba->pt_slot[P->e_pt[e]] + 1]++;
-    for (int l = 0; l < Lp; l++) cnt[l + 1] += cnt[l];
-    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-    for (int e : act) order[pos[ba->pt_slot[P->e_pt[e]]]++] = e;
-    // per-landmark order by pose slot: the lists are short (~6), so a stable insertion sort on precomputed keys instead of
-    // 150 000 std::stable_sort calls with their temporary buffers (6.5 -> ~2 ms of the set-up)
-    std::vector<int> key(order.size());
-    for (size_t k = 0; k < order.size(); k++) key[k] = ba->cam_slot[P->e_cam[order[k]]];
-    for (int l = 0; l < Lp; l++) {
-      const int b0 = cnt[l], b1 = cnt[l + 1];
-      if (b1 - b0 > 64) {
-        std::vector<std::pair<int, int>> tmp(b1 - b0);
-        for (int k = b0; k < b1; k++) tmp[k - b0] = {key[k], order[k]};
-        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
-        for (int k = b0; k < b1; k++) order[k] = tmp[k - b0].second;
-        continue;
-      }
-      for (int k = b0 + 1; k < b1; k++) {
-        const int kk = key[k], ee = order[k];
-        int q = k - 1;
-        while (q >= b0 && key[q] > kk) { key[q + 1] = key[q]; order[q + 1] = order[q]; q--; }
-        key[q + 1] = kk; order[q + 1] = ee;
-      }
-    }
-    g_pt_off.swap(cnt);                          // the prefix sums of the counting sort are the landmark edge ranges
-  }
-
-  lap("edge sort");
-  // ---- shard the landmarks: weight = pair instances + edges ----
-  std::vector<int32_t> shard(nranks + 1);
-  if (nranks == 1) { shard[0] = 0; shard[1] = Lp; }   // nothing to balance: skip the weight pass over all edges
-  else {
-    std::vector<int64_t> weight(Lp);
-    for (int l = 0; l < Lp; l++) {
-      int kf = 0;
-      for (int k = g_pt_off[l]; k < g_pt_off[l + 1]; k++) kf += ba->cam_slot[P->e_cam[order[k]]] >= 0;
-      weight[l] = (int64_t)kf * (kf + 1) / 2 + (g_pt_off[l + 1] - g_pt_off[l]);
-    }
-    ccm_ba_partition(weight.data(), Lp, nranks, shard.data());
-  }
-  const int lb = ba->lp_begin = shard[rank], le = ba->lp_end = shard[rank + 1];
-  const int Lloc = ba->Lloc = le - lb;
-  const int eb = g_pt_off[lb], ee = g_pt_off[le];
-  const int Eloc = ba->Eloc = ee - eb;
-
-  lap("shard");
-  // ---- global off-diagonal block structure + own pair instances: built on the device (ba_structure.hip) ----
-  std::vector<uint64_t> all_keys;
-  int *d_inst_off = nullptr, *d_inst_a = nullptr, *d_inst_c = nullptr;
-  {
-    std::vector<int> cslot_g(order.size());
-    for (size_t k = 0; k < order.size(); k++) cslot_g[k] = ba->cam_slot[P->e_cam[order[k]]];
-    int64_t n_inst = 0;
-    if (int rc = ccm_ba_build_pairs(ctx, g_pt_off, cslot_g, Cp, lb, le, eb, all_keys, &d_inst_off, &d_inst_a, &d_inst_c, &n_inst, ba->allocs)) return fail(rc);
-    ba->n_inst = n_inst;
-  }
-  lap("pair structure (device)");
-  const int nOff = ba->nOff = (int)all_keys.size();
-  // ---- block CSR rows (full symmetric pattern) ----
-  std::vector<int> row_cnt(Cp + 1, 0);
-  for (int i = 0; i < Cp; i++) row_cnt[i + 1] = 1;
-  for (int b = 0; b < nOff; b++) { row_cnt[(int)(all_keys[b] >> 32) + 1]++; row_cnt[(int)(uint32_t)all_keys[b] + 1]++; }
-  for (int i = 0; i < Cp; i++) row_cnt[i + 1] += row_cnt[i];
-  std::vector<int> row_col(row_cnt[Cp]); std::vector<uint32_t> row_blk(row_cnt[Cp]);
-  {
-    // column-ascending per row: lower part (transposed blocks, ascending j because keys are sorted by (i,j)
-    // and we visit b in order -> for row j the i's arrive ascending), then diagonal, then upper part.
-    std::vector<int> lower_cnt(Cp, 0);
-    for (int b = 0; b < nOff; b++) lower_cnt[(int)(uint32_t)all_keys[b]]++;
-    std::vector<int> pos_low(Cp), pos_up(Cp);
-    for (int i = 0; i < Cp; i++) {
-      pos_low[i] = row_cnt[i];
-      const int dpos = row_cnt[i] + lower_cnt[i];
-      row_col[dpos] = i; row_blk[dpos] = (uint32_t)i;
-      pos_up[i] = dpos + 1;
-    }
-    for (int b = 0; b < nOff; b++) {
-      const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
-      row_col[pos_up[i]] = j; row_blk[pos_up[i]++] = (uint32_t)(Cp + b);
-      row_col[pos_low[j]] = i; row_blk[pos_low[j]++] = (uint32_t)(Cp + b) | kTransposeBit;
-    }
-  }
-  ba->n_row_entries = row_cnt[Cp];
-  // persistent PCG: per cluster the ascending list of distinct columns its rows touch + every entry's position in it
-  std::vector<int> pers_uoff, pers_ucol, pers_loc, pers_coff, pers_cij;
-  std::vector<uint32_t> pers_cblk;
-  bool pers_fits = Cp > kSmallMaxCp;
-  if (pers_fits) {
-    const int n_clu = 2 * ccm_div_up(Cp, kClu);   // units of kClu/2 rows (two workgroups per cluster)
-    pers_uoff.assign(n_clu + 1, 0);
-    pers_loc.resize(row_cnt[Cp]);
-    std::vector<int> mark(Cp, -1), cols;
-    for (int c = 0; c < n_clu && pers_fits; c++) {
-      const int r0 = std::min(Cp, (c >> 1) * kClu + (c & 1) * (kClu / 2)), r1 = std::min({Cp, r0 + kClu / 2, ((c >> 1) + 1) * kClu});
-      cols.clear();
-      for (int s2 = row_cnt[r0]; s2 < row_cnt[r1]; s2++) if (mark[row_col[s2]] != c) { mark[row_col[s2]] = c; cols.push_back(row_col[s2]); }
-      std::sort(cols.begin(), cols.end());
-      if ((int)cols.size() > kPersColCap || row_cnt[r1] - row_cnt[r0] > kPersIdxCap) { pers_fits = false; break; }
-      // reuse mark as column -> local index for this cluster (values >= n_clu never collide with cluster ids < n_clu)
-      for (size_t q = 0; q < cols.size(); q++) mark[cols[q]] = n_clu + (int)q;
-      for (int s2 = row_cnt[r0]; s2 < row_cnt[r1]; s2++) pers_loc[s2] = mark[row_col[s2]] - n_clu;
-      for (size_t q = 0; q < cols.size(); q++) mark[cols[q]] = -1;
-      pers_ucol.insert(pers_ucol.end(), cols.begin(), cols.end());
-      pers_uoff[c + 1] = (int)pers_ucol.size();
-    }
-    // block-CSR entries that fall inside each cluster's own 16x16 block (what the cluster factorisation assembles):
-    // local row << 4 | local column, and the entry's S block (with its transpose bit)
-    const int n_cl = ccm_div_up(Cp, kClu);
-    pers_coff.assign(n_cl + 1, 0);
-    for (int c = 0; c < n_cl; c++) {
-      const int r0 = c * kClu, r1 = std::min(Cp, r0 + kClu);
-      for (int i = r0; i < r1; i++)
-        for (int s2 = row_cnt[i]; s2 < row_cnt[i + 1]; s2++)
-          if (row_col[s2] >= r0 && row_col[s2] < r1) { pers_cij.push_back(((i - r0) << 4) | (row_col[s2] - r0)); pers_cblk.push_back(row_blk[s2]); }
-      pers_coff[c + 1] = (int)pers_cij.size();
-    }
-  }
-
-  lap("rows + persist lists");
-  // ---- local edge arrays ----
-  std::vector<int> pt_off(Lloc + 1), ed_cam(Eloc), ed_cslot(Eloc), ed_pt(Eloc);
-  std::vector<double> obs(2 * (size_t)Eloc), info(Eloc);
-  ba->loc_edge_orig.resize(Eloc);
-  for (int l = 0; l <= Lloc; l++) pt_off[l] = g_pt_off[lb + l] - eb;
-  for (int k = 0; k < Eloc; k++) {
-    const int e = order[eb + k];
-    ba->loc_edge_orig[k] = e;
-    ed_cam[k] = P->e_cam[e]; ed_cslot[k] = ba->cam_slot[P->e_cam[e]]; ed_pt[k] = ba->pt_slot[P->e_pt[e]] - lb;
-    obs[2 * (size_t)k] = P->e_obs[2 * (size_t)e]; obs[2 * (size_t)k + 1] = P->e_obs[2 * (size_t)e + 1];
-    info[k] = P->e_info[e];
-  }
-  std::vector<int> cam_off(Cp + 1, 0), cam_edge;
-  for (int k = 0; k < Eloc; k++) if (ed_cslot[k] >= 0) cam_off[ed_cslot[k] + 1]++;
-  for (int i = 0; i < Cp; i++) cam_off[i + 1] += cam_off[i];
-  cam_edge.resize(cam_off[Cp]);
-  {
-    std::vector<int> pos(cam_off.begin(), cam_off.end() - 1);
-    for (int k = 0; k < Eloc; k++) if (ed_cslot[k] >= 0) cam_edge[pos[ed_cslot[k]]++] = k;
-  }
-  std::vector<int> own_slot(Lloc);
-  for (int l = 0; l < Lloc; l++) own_slot[l] = lb + l;
-
-  lap("local arrays");
-  // ---- upload ----
-  BaDev& d = ba->d;
-  d.n_cam = P->n_cam; d.Cp = Cp; d.Lloc = Lloc; d.Eloc = Eloc; d.nOff = nOff; d.huber = P->huber_delta;
-  {
-    std::vector<double> K(P->cam_K, P->cam_K + 4 * (size_t)P->n_cam);
-    double* dk = nullptr; if (int rc = dev_upload(ba, K, &dk)) return fail(rc); d.K = dk;
-  }
-#define UP(vec, field, T) { T* _p = nullptr; if (int rc = dev_upload(ba, vec, &_p)) return fail(rc); d.field = _p; }
-  UP(ba->slot_cam, slot_cam, int) UP(pt_off, pt_off, int) UP(ed_cam, ed_cam, int) UP(ed_cslot, ed_cslot, int)
-  UP(ed_pt, ed_pt, int) UP(obs, obs, double) UP(info, info, double) UP(cam_off, cam_off, int) UP(cam_edge, cam_edge, int)
-  {
-    std::vector<int> cam_pt(cam_edge.size());
-    for (size_t q = 0; q < cam_edge.size(); q++) cam_pt[q] = ed_pt[cam_edge[q]];
-    UP(cam_pt, cam_pt, int)
-  }
-  d.inst_off = d_inst_off; d.inst_a = d_inst_a; d.inst_c = d_inst_c;
-  {
-    std::vector<int> rowblk_off(Cp + 1, 0);
-    for (int b = 0; b < nOff; b++) rowblk_off[(int)(all_keys[b] >> 32) + 1]++;
-    for (int i = 0; i < Cp; i++) rowblk_off[i + 1] += rowblk_off[i];
-    int* p_rb = nullptr; if (int rc = dev_upload(ba, rowblk_off, &p_rb)) return fail(rc); d.rowblk_off = p_rb;
-    d.max_cam_edges = 0;
-    for (int i = 0; i < Cp; i++) d.max_cam_edges = std::max(d.max_cam_edges, cam_off[i + 1] - cam_off[i]);
-    int *p_rank = nullptr, *p_al = nullptr;
-    if (int rc = dev_alloc<int>(ba, (size_t)std::max(Eloc, 1), &p_rank, false)) return fail(rc);
-    if (int rc = dev_alloc<int>(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al, false)) return fail(rc);
-    d.inst_al = p_al;
-    d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0;
-    if (nOff > row_min_blocks() && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
-      std::vector<int> h_off((size_t)nOff + 1);
-      if (hipMemcpyAsync(h_off.data(), d_inst_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: instance offsets read-back"));
-      const size_t lds_free = 158 * 1024 - 18 * sizeof(double) - (size_t)d.max_cam_edges * 18 * sizeof(double);
-      const int units_cap = (int)(lds_free / (kRowSlot * sizeof(double)));
-      for (int chunk = kWave; chunk <= kWave && !d.row_units_max; chunk *= 2) {   // a unit = one 64-instance index vector
-        int worst = 0;
-        for (int i = 0; i < Cp; i++) {
-          int nu = ccm_div_up(cam_off[i + 1] - cam_off[i], chunk);   // diagonal units: the camera's own observations
-          for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) nu += std::max(1, ccm_div_up(h_off[b + 1] - h_off[b], chunk));
-          worst = std::max(worst, nu);
-        }
-        if (worst > units_cap) continue;
-        std::vector<int4> tab;
-        std::vector<int> row_u(Cp + 1, 0), blk_u((size_t)nOff + 1, 0);
-        for (int i = 0; i < Cp; i++) {
-          const size_t r0 = tab.size();
-          for (int b = rowblk_off[i]; b < rowblk_off[i + 1]; b++) {
-            blk_u[b] = (int)tab.size();
-            int s0 = h_off[b];
-            do { const int s1 = std::min(h_off[b + 1], s0 + chunk); tab.push_back(make_int4(b, s0, s1, (int)(tab.size() - r0))); s0 = s1; } while (s0 < h_off[b + 1]);
-          }
-          for (int s0 = 0, ne_i = cam_off[i + 1] - cam_off[i]; s0 < ne_i; s0 += chunk) tab.push_back(make_int4(-1, s0, std::min(ne_i, s0 + chunk), (int)(tab.size() - r0)));
-          row_u[i + 1] = (int)tab.size();
-          // processing order: longest unit first (stable); the slots keep the block order the final sums rely on
-          std::stable_sort(tab.begin() + r0, tab.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
-        }
-        blk_u[nOff] = (int)tab.size();
-        int4* p_t = nullptr; int *p_r = nullptr, *p_b = nullptr;
-        if (int rc = dev_upload(ba, tab, &p_t)) return fail(rc);
-        if (int rc = dev_upload(ba, row_u, &p_r)) return fail(rc);
-        if (int rc = dev_upload(ba, blk_u, &p_b)) return fail(rc);
-        d.unit_tab = p_t; d.row_unit_off = p_r; d.blk_unit0 = p_b; d.row_units_max = std::max(worst, 1);
-        // two rows per CU when Y of the longest row fits half of the LDS: the partial sums then live in a global scratch
-        d.row_part = nullptr;
-        // measured on gba_c4 (r02e): 235 us against 228 us for the one-row shape — no gain: the row is bound by the serial chain of units per wave
-        // (index vectors -> W gathers -> 16 dependent MFMAs), which two resident rows do not shorten.  Kept behind CCM_BA_ROW_V2=1.
-        if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && getenv("CCM_BA_ROW_V2")) {
-          double* p_part = nullptr;
-          if (int rc = dev_alloc<double>(ba, (size_t)tab.size() * 42, &p_part, false)) return fail(rc);
-          d.row_part = p_part;
-        }
-      }
-    }
-    if (Cp) hipLaunchKernelGGL(ba_edge_rank, dim3(Cp), dim3(kTPB), 0, ctx->stream, d, p_rank);
-    if (ba->n_inst) hipLaunchKernelGGL(ba_inst_rank, dim3(ccm_div_up(ba->n_inst, kTPB)), dim3(kTPB), 0, ctx->stream, d.inst_a, (const int*)p_rank, (int)ba->n_inst, p_al);
-  }
-  UP(row_cnt, row_off, int) UP(row_col, row_col, int) UP(row_blk, row_blk, uint32_t)
-#undef UP
-  if (int rc = dev_upload(ba, own_slot, &ba->d_own_slot)) return fail(rc);
-#define AL(field, n, T) { T* _p = nullptr; if (int rc = dev_alloc<T>(ba, (n), &_p)) return fail(rc); d.field = _p; }
-  AL(cam[0], 7 * (size_t)P->n_cam, double) AL(cam[1], 7 * (size_t)P->n_cam, double)
-  AL(pt[0], 3 * (size_t)Lloc, double) AL(pt[1], 3 * (size_t)Lloc, double)
-  AL(W, 18 * (size_t)Eloc, double) AL(Hll, 6 * (size_t)Lloc, double) AL(bl, 3 * (size_t)Lloc, double)
-  AL(Dinv, 6 * (size_t)Lloc, double) AL(dl, 3 * (size_t)Lloc, double) AL(Hpp, 36 * (size_t)Cp, double) AL(bp, 6 * (size_t)Cp, double)
-  AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
-  AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double)
-  AL(Wc, (size_t)ccm_div_up(std::max(Cp, 1), kClu) * kCluN * kCluN, double)
-  d.n_wg_spmv = ((ccm_div_up(std::max(Cp, 1), kRowsPerWG) + 7) / 8) * 8;   // padded to 8 (one chunk per XCD)
-  d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave);
-  d.n_wg_upd = ccm_div_up(std::max(Cp, 1), kClu);   // one workgroup per preconditioner cluster
-  d.n_wg_pt = ccm_div_up(std::max(Lloc, 1), kTPB); d.n_wg_cam = ccm_div_up(std::max(Cp, 1), kTPB);
-  d.chunk_off = nullptr; d.n_chunk = 0;
-  {
-    std::vector<int> chunk(1, 0);
-    bool fits = true;
-    for (int l = 0; l < Lloc && fits; l++) {
-      if (pt_off[l + 1] - pt_off[l] > kTPB) fits = false;
-      else if (pt_off[l + 1] - pt_off[chunk.back()] > kTPB || l + 1 - chunk.back() > kTPB) chunk.push_back(l);
-    }
-    if (fits && Lloc) {
-      chunk.push_back(Lloc);
-      int* p_ch = nullptr;
-      if (int rc = dev_upload(ba, chunk, &p_ch)) return fail(rc);
-      d.chunk_off = p_ch; d.n_chunk = (int)chunk.size() - 1;
-    }
-  }
-  d.n_part = d.chunk_off ? d.n_chunk : d.n_wg_pt;
-  AL(ppq, d.n_wg_spmv, double) AL(prz[0], d.n_wg_upd, double) AL(prz[1], d.n_wg_upd, double)
-  AL(pcg_scal, 4, double)
-  AL(edge_chi2, Eloc, double) AL(edge_depth, Eloc, uint8_t)
-  AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 8, double)
-#undef AL
-  d.pcg_flag = reinterpret_cast<int*>(d.scal + 6);   // [scalars | PCG flags]: one 64-byte read-back per LM trial
-  if (hipHostMalloc(&ba->h_rb, 64, hipHostMallocDefault) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer"));
-  ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
-  if (int rc = dev_alloc<double>(ba, ba->red_count, &ba->d_red)) return fail(rc);
-  d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);
-  if (int rc = dev_alloc<double>(ba, 3 * (size_t)std::max(Lp, 1), &ba->d_pt_full)) return fail(rc);
-  if (int rc = dev_alloc<double>(ba, 36 * (size_t)std::max(Cp, 1), &ba->d_hpp_full)) return fail(rc);
-  // coarse-level structures (SURVEY-free addition, see the comment at kAgg): block lists of Ac = P^T S P by aggregate pair,
-  // buffers for P, Ac, its inverse.  Used by the persistent kernel (cparts: one slot row per unit) and, for maps above
-  // 2048 free cameras, by the multi-kernel PCG (mk_*: per-cluster restriction parts and coarse scalar parts).
-  auto make_coarse = [&](int na, int Nc, int n_units) -> int {
-    std::map<std::pair<int, int>, std::vector<int>> cb;
-    for (int i = 0; i < Cp; i++) cb[{i / kAgg, i / kAgg}].push_back(i * 2);
-    std::vector<int> bi(Cp + nOff), bj(Cp + nOff);
-    for (int i = 0; i < Cp; i++) { bi[i] = i; bj[i] = i; }
-    for (int b = 0; b < nOff; b++) {
-      const int i = (int)(all_keys[b] >> 32), j = (int)(uint32_t)all_keys[b];
-      bi[Cp + b] = i; bj[Cp + b] = j;
-      const int a = i / kAgg, a2 = j / kAgg;   // i < j => a <= a2
-      cb[{a, a2}].push_back((Cp + b) * 2 + (a == a2 ? 1 : 0));
-    }
-    std::vector<int> cb_off(1, 0), cb_ent, cb_ab;
-    for (auto& kv : cb) { cb_ab.push_back(kv.first.first); cb_ab.push_back(kv.first.second); cb_ent.insert(cb_ent.end(), kv.second.begin(), kv.second.end()); cb_off.push_back((int)cb_ent.size()); }
-    if (int rc2 = dev_upload(ba, cb_off, &ba->d_cb_off)) return rc2;
-    if (int rc2 = dev_upload(ba, cb_ent, &ba->d_cb_ent)) return rc2;
-    if (int rc2 = dev_upload(ba, cb_ab, &ba->d_cb_ab)) return rc2;
-    if (int rc2 = dev_upload(ba, bi, &ba->d_blk_i)) return rc2;
-    if (int rc2 = dev_upload(ba, bj, &ba->d_blk_j)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, 36 * (size_t)Cp, &ba->d_cP)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cA)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cX)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * Nc, &ba->d_cAinv)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, (size_t)Nc * 64, &ba->d_cLinv)) return rc2;
-    if (int rc2 = dev_alloc<int>(ba, 4, &ba->d_cinfo)) return rc2;
-    if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)std::max(n_units, 1), &ba->d_cparts)) return rc2;
-    ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = (int)cb_ab.size() / 2;
-    if (const char* cr = getenv("CCM_BA_COARSE_REUSE")) ba->coarse_reuse = atoi(cr) != 0;
-    if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
-    return CCM_OK;
-  };
-  // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device
-  ba->pers_grid = 0;
-  if (pers_fits && !getenv("CCM_BA_NO_PERSIST")) {
-    const int n_clu = ccm_div_up(Cp, kClu);
-    const int grid = ((2 * n_clu + 7) / 8) * 8;   // two workgroups per cluster
-    const size_t lds = pers_lds_bytes();
-    int per_cu = 0, n_cu = 0;
-    if (hipFuncSetAttribute((const void*)ba_pcg_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_pcg_persist, kPersTPB, lds) == hipSuccess &&
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid && grid <= 4 * kWave) {
-      if (int rc2 = dev_alloc<unsigned>(ba, 4 + 2 * 16, &ba->d_pers_bar)) return fail(rc2);   // + debug clocks
-      if (hipMemsetAsync(ba->d_pers_bar, 0, (4 + 2 * 16) * sizeof(unsigned), ctx->stream) != hipSuccess) return fail(ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: memset"));
-      if (int rc2 = dev_alloc<double>(ba, 4 * (size_t)grid, &ba->d_pers_part)) return fail(rc2);   // [2][2][grid] slot words
-      if (int rc2 = dev_upload(ba, pers_uoff, &ba->d_pers_uoff)) return fail(rc2);
-      if (int rc2 = dev_upload(ba, pers_ucol, &ba->d_pers_ucol)) return fail(rc2);
-      if (int rc2 = dev_upload(ba, pers_loc, &ba->d_pers_loc)) return fail(rc2);
-      if (int rc2 = dev_upload(ba, pers_coff, &ba->d_pers_coff)) return fail(rc2);
-      if (int rc2 = dev_upload(ba, pers_cij, &ba->d_pers_cij)) return fail(rc2);
-      if (int rc2 = dev_upload(ba, pers_cblk, &ba->d_pers_cblk)) return fail(rc2);
-      ba->pers_grid = grid;
-      // coarse level: aggregates of kAgg cameras; block lists of Ac = P^T S P
-      if (!getenv("CCM_BA_NO_COARSE")) {
-        const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
-        if (7 * (size_t)Nc + 6 * (size_t)grid + 320 <= (size_t)kCluN * kCluN / 2 && kAggUnits * na <= grid + kAggUnits - 1)
-          if (int rc2 = make_coarse(na, Nc, grid)) return fail(rc2);
-      }
-    }
-    (void)hipGetLastError();
-  }
-  // maps too large for the persistent kernel: the same coarse level inside the multi-kernel PCG (kAgg = 2 clusters)
-  if (!ba->d_pers_coff && !pers_coff.empty()) {   // the cluster entry lists also serve the multi-kernel PCG's start kernel
-    if (int rc2 = dev_upload(ba, pers_coff, &ba->d_pers_coff)) return fail(rc2);
-    if (int rc2 = dev_upload(ba, pers_cij, &ba->d_pers_cij)) return fail(rc2);
-    if (int rc2 = dev_upload(ba, pers_cblk, &ba->d_pers_cblk)) return fail(rc2);
-  }
-  if (Cp > kSmallMaxCp && Cp <= kDense2MaxCp && ba->d_pers_coff)
-    if (int rc2 = dev_alloc<double>(ba, (size_t)kCluN * kCluN + 16, &ba->d_dense_T)) return fail(rc2);   // + phase clocks (CCM_BA_DENSE2_DBG)
-  d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
-  if (!ba->pers_grid && Cp > kSmallMaxCp && !ba->coarse_na && !getenv("CCM_BA_NO_COARSE") && kAgg == 2 * kClu) {
-    const int na = ccm_div_up(Cp, kAgg), nc = 6 * na, Nc = ((nc + 63) / 64) * 64;
-    if (Nc <= 6144) {   // three Nc^2 f64 buffers: <= 0.9 GB
-      if (int rc2 = make_coarse(na, Nc, 0)) return fail(rc2);
-      const int n_clu = ccm_div_up(Cp, kClu);
-      if (int rc2 = dev_alloc<double>(ba, 6 * (size_t)n_clu, &d.mk_cpart)) return fail(rc2);
-      if (int rc2 = dev_alloc<double>(ba, (size_t)n_clu, &d.mk_cry[0])) return fail(rc2);
-      if (int rc2 = dev_alloc<double>(ba, (size_t)n_clu, &d.mk_cry[1])) return fail(rc2);
-      d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
-    }
-  }
-  int rc = ccm_ba_reset_state(ba, P->cam_qt, P->pt_xyz);
-  if (rc) return fail(rc);
-  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  lap("alloc + upload");
-  ba->ms_setup = now_ms() - t0;
-  *out = ba;
-  return CCM_OK;
+// ccm_ba_create lives in ba_build.hip (structure build on the device).  Occupancy question it asks about the persistent PCG kernel: can `grid`
+// workgroups be co-resident on this device?
+int ccm_ba_pers_grid_fits(ccm_ctx* ctx, int grid) {
+  const size_t lds = pers_lds_bytes();
+  int per_cu = 0, n_cu = 0;
+  const bool ok = hipFuncSetAttribute((const void*)ba_pcg_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_pcg_persist, kPersTPB, lds) == hipSuccess &&
+                  hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu * n_cu >= grid;
+  (void)hipGetLastError();
+  return ok ? 1 : 0;
 }
 
 extern "C" void ccm_ba_destroy(ccm_ba* ba) {
@@ -2699,26 +2162,16 @@ extern "C" void ccm_ba_destroy(ccm_ba* ba) {
   delete ba;
 }
 
+int ccm_ba_state_from_raw(ccm_ba* ba);                                       // ba_build.hip
+int ccm_ba_points_to_raw_order(ccm_ba* ba, const double* d_pt_slots);         // ba_build.hip
+
 extern "C" int ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double* pt_xyz) {
   if (!ba || !cam_qt || (ba->n_pt && !pt_xyz)) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  std::vector<double> cam(7 * (size_t)ba->n_cam);
-  for (int c = 0; c < ba->n_cam; c++) {
-    BaPose T = ba_load_pose(cam_qt + 7 * (size_t)c);
-    ba_normalize_rotation(T);   // SE3Quat(q,t) ctor normalises (se3quat.h:61-63)
-    ba_store_pose(&cam[7 * (size_t)c], T);
-  }
-  std::vector<double> pts(3 * (size_t)std::max(ba->Lloc, 1), 0.0);
-  for (int l = 0; l < ba->Lloc; l++) {
-    const int p = ba->slot_pt[ba->lp_begin + l];
-    pts[3 * (size_t)l] = pt_xyz[3 * (size_t)p]; pts[3 * (size_t)l + 1] = pt_xyz[3 * (size_t)p + 1]; pts[3 * (size_t)l + 2] = pt_xyz[3 * (size_t)p + 2];
-  }
-  ba->cur = 0;
-  for (int k = 0; k < 2; k++) {
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.cam[k], cam.data(), cam.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (ba->Lloc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.pt[k], pts.data(), 3 * (size_t)ba->Lloc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  }
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_cam, cam_qt, 7 * (size_t)ba->n_cam * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (ba->n_pt) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_pt, pt_xyz, 3 * (size_t)ba->n_pt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  RC(ccm_ba_state_from_raw(ba));   // SE3Quat(q, t) normalises the rotation (se3quat.h:61-63); landmarks gathered into slot order
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;
 }
@@ -2730,7 +2183,8 @@ extern "C" int ccm_ba_push_state(ccm_ba* ba) {
   ccm_ctx* ctx = ba->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nc = 7 * (size_t)ba->n_cam, np = 3 * (size_t)std::max(ba->Lloc, 1);
-  if (!ba->d_saved_cam) { RC(dev_alloc<double>(ba, nc, &ba->d_saved_cam, false)); RC(dev_alloc<double>(ba, np, &ba->d_saved_pt, false)); }
+  if (!ba->d_saved_cam) RC(dev_alloc<double>(ba, nc, &ba->d_saved_cam, false));
+  if (!ba->d_saved_pt) RC(dev_alloc<double>(ba, np, &ba->d_saved_pt, false));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_saved_cam, ba->d.cam[ba->cur], nc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   if (ba->Lloc) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_saved_pt, ba->d.pt[ba->cur], 3 * (size_t)ba->Lloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return CCM_OK;
@@ -2738,7 +2192,7 @@ extern "C" int ccm_ba_push_state(ccm_ba* ba) {
 extern "C" int ccm_ba_pop_state(ccm_ba* ba) {
   if (!ba) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
-  if (!ba->d_saved_cam) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba_pop_state: nothing pushed");
+  if (!ba->d_saved_cam || !ba->d_saved_pt) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba_pop_state: nothing pushed");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   ba->cur = 0;
   for (int k = 0; k < 2; k++) {
@@ -3233,17 +2687,18 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
     for (int i = 0; i < ba->Cp; i++) std::memcpy(cam_qt + 7 * (size_t)ba->slot_cam[i], &cam[7 * (size_t)ba->slot_cam[i]], 7 * sizeof(double));
   }
   if (pt_xyz && ba->Lp) {
-    std::vector<double> pts(3 * (size_t)ba->Lp);
+    // optimised landmarks into the caller's numbering on the device (landmarks without an active edge keep the values uploaded at create / reset),
+    // then ONE copy straight into the caller's array
+    const double* src = d.pt[ba->cur];
     if (ba->nranks > 1) {
-      CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pt_full, 0, pts.size() * sizeof(double), ctx->stream));
-      if (ba->Lloc) hipLaunchKernelGGL(ba_scatter_points, dim3(ccm_div_up(ba->Lloc, kTPB)), dim3(kTPB), 0, ctx->stream, ba->d_pt_full, d.pt[ba->cur], ba->d_own_slot, ba->Lloc);
-      RC(ba_allreduce_sum(ba, ba->d_pt_full, pts.size()));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), ba->d_pt_full, pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    } else {
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(pts.data(), d.pt[ba->cur], pts.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pt_full, 0, 3 * (size_t)ba->Lp * sizeof(double), ctx->stream));
+      if (ba->Lloc) hipLaunchKernelGGL(ba_scatter_points, dim3(ccm_div_up(ba->Lloc, kTPB)), dim3(kTPB), 0, ctx->stream, ba->d_pt_full, d.pt[ba->cur], ba->lp_begin, ba->Lloc);
+      RC(ba_allreduce_sum(ba, ba->d_pt_full, 3 * (size_t)ba->Lp));
+      src = ba->d_pt_full;
     }
+    RC(ccm_ba_points_to_raw_order(ba, src));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(pt_xyz, ba->d_raw_pt, 3 * (size_t)ba->n_pt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int l = 0; l < ba->Lp; l++) std::memcpy(pt_xyz + 3 * (size_t)ba->slot_pt[l], &pts[3 * (size_t)l], 3 * sizeof(double));
   }
   if (chi2_per_edge && ba->Eloc) {
     // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors,
@@ -3251,6 +2706,10 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
     // (level != 0) edges keep whatever the caller passed in, as g2o leaves their _error untouched.
     std::vector<double> c2(ba->Eloc);
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(c2.data(), d.edge_chi2, c2.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ba->loc_edge_orig.empty()) {   // local edge -> the caller's edge index (built on the device, fetched on first use)
+      ba->loc_edge_orig.resize(ba->Eloc);
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->loc_edge_orig.data(), ba->d_loc_edge_orig, (size_t)ba->Eloc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < ba->Eloc; k++) chi2_per_edge[ba->loc_edge_orig[k]] = c2[k];
   }

@@ -104,26 +104,20 @@ int emit_pairs(ccm_ctx* ctx, Tmp& tmp, const int* d_pt_off, const int* d_cslot, 
 
 }  // namespace
 
-// g_pt_off [Lp+1] / cslot_g [E]: landmark-sorted edge ranges and the pose slot (-1 = fixed) of every edge position.
-// Own landmarks [lb, le), eb = first own edge position.  Outputs: all_keys (host, (ia << 32) | ic ascending), device
-// inst_off [nOff+1] / inst_a / inst_c [n_inst] (blocks appended to `keep`, owned by the caller).
-int ccm_ba_build_pairs(ccm_ctx* ctx, const std::vector<int>& g_pt_off, const std::vector<int>& cslot_g, int Cp, int lb, int le, int eb,
-                       std::vector<uint64_t>& all_keys, int** d_inst_off, int** d_inst_a, int** d_inst_c, int64_t* n_inst,
+// d_pt_off [Lp+1] / d_cslot [E] (device): landmark-sorted edge ranges and the pose slot (-1 = fixed) of every edge position.
+// Own landmarks [lb, le), eb = first own edge position.  Outputs (device, blocks appended to `keep`, owned by the caller): the global block
+// list d_U [nOff] (key = ia * Cp + ic, ascending), inst_off [nOff+1] / inst_a / inst_c [n_inst].  Two host syncs (pair count, block count).
+int ccm_ba_build_pairs(ccm_ctx* ctx, const int* d_pt_off, const int* d_cslot, int Lp, int Cp, int lb, int le, int eb,
+                       uint32_t** d_U_out, int* nOff_out, int** d_inst_off, int** d_inst_a, int** d_inst_c, int64_t* n_inst,
                        std::vector<std::pair<void*, size_t>>& keep) {
-  const int Lp = (int)g_pt_off.size() - 1;
   if (Cp > 65535) return ccm_set_error(ctx, CCM_E_ARG, "bundle adjustment: more than 65535 free cameras (32-bit block keys)");
-  all_keys.clear();
-  *n_inst = 0;
+  *n_inst = 0; *nOff_out = 0; *d_U_out = nullptr;
   auto keep_get = [&](size_t n, int** out) -> int {
     void* p = nullptr; size_t actual = 0;
     if (int rc = ccm_pool_get(ctx, std::max<size_t>(n, 1) * sizeof(int), &p, &actual)) return rc;
     keep.push_back({p, actual}); *out = (int*)p; return CCM_OK;
   };
   Tmp tmp{ctx, {}};
-  int *d_pt_off = nullptr, *d_cslot = nullptr;
-  ST_RC(tmp.get(g_pt_off.size(), &d_pt_off)); ST_RC(tmp.get(cslot_g.size(), &d_cslot));
-  ST_HIP(hipMemcpyAsync(d_pt_off, g_pt_off.data(), g_pt_off.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (!cslot_g.empty()) ST_HIP(hipMemcpyAsync(d_cslot, cslot_g.data(), cslot_g.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   unsigned bits = 1;
   while (bits < 32 && ((uint64_t)1 << bits) < (uint64_t)Cp * (uint64_t)Cp) bits++;
   const bool whole = (lb == 0 && le == Lp);
@@ -173,16 +167,16 @@ int ccm_ba_build_pairs(ccm_ctx* ctx, const std::vector<int>& g_pt_off, const std
     ST_HIP(hipMemcpyAsync(&nOff, runs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     ST_HIP(hipStreamSynchronize(ctx->stream));
   }
+  int* U_keep = nullptr;
+  ST_RC(keep_get((size_t)nOff, &U_keep));
+  if (nOff) ST_HIP(hipMemcpyAsync(U_keep, U, (size_t)nOff * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
   ST_RC(keep_get((size_t)nOff + 1, d_inst_off)); ST_RC(keep_get((size_t)n_own, d_inst_a)); ST_RC(keep_get((size_t)n_own, d_inst_c));
   hipLaunchKernelGGL(ranges_kernel, dim3(ccm_div_up(nOff + 1, kTPB)), dim3(kTPB), 0, ctx->stream, (const uint32_t*)U, nOff, (const uint32_t*)ok_sorted, n_own,
                      *d_inst_off);
   if (n_own) hipLaunchKernelGGL(split_kernel, dim3(ccm_div_up(n_own, kTPB)), dim3(kTPB), 0, ctx->stream, (const unsigned long long*)ov_sorted, n_own, eb, *d_inst_a, *d_inst_c);
   ST_HIP(hipGetLastError());
-  std::vector<uint32_t> Uh(nOff);
-  if (nOff) ST_HIP(hipMemcpyAsync(Uh.data(), U, (size_t)nOff * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  ST_HIP(hipStreamSynchronize(ctx->stream));
-  all_keys.resize(nOff);
-  for (int b = 0; b < nOff; b++) all_keys[b] = ((uint64_t)(Uh[b] / (uint32_t)Cp) << 32) | (uint64_t)(Uh[b] % (uint32_t)Cp);
+  *d_U_out = (uint32_t*)U_keep;
+  *nOff_out = nOff;
   *n_inst = n_own;
-  return CCM_OK;
+  return CCM_OK;   // ~Tmp waits for the stream before the temporaries go back to the pool
 }

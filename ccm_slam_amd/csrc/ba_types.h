@@ -1,0 +1,153 @@
+// ba_types.h — device-side problem description (BaDev), the BA handle (ccm_ba) and the size constants shared by ba.hip (kernels, LM loop) and
+// ba_build.hip (structure build on the device).
+#pragma once
+#include "common.h"
+
+constexpr int kWave = 64;
+constexpr int kTPB = 256;
+constexpr uint32_t kTransposeBit = 0x80000000u;
+constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
+constexpr int kRowSlot = 42;         // doubles per work-unit partial: 6x6 block + 6 (b_schur part of the diagonal units)
+constexpr int kRowTPB = 1024;        // 16 waves walk the row's blocks: the instance stream is latency bound, so more streams win
+constexpr int kClu = 16;             // cameras per preconditioner cluster
+constexpr int kCluN = 6 * kClu;      // 96 unknowns
+constexpr int kSpmvTPB = 1024;
+constexpr int kRowsPerWG = kSpmvTPB / (2 * kWave);
+#ifndef CCM_KAGG
+#define CCM_KAGG 32
+#endif
+constexpr int kAgg = CCM_KAGG;       // cameras per coarse aggregate (32 = 2 clusters = 4 persistent units)
+constexpr int kAggUnits = kAgg / 8;
+constexpr int kPersTPB = 1024;
+constexpr int kPersWaves = kPersTPB / kWave;
+constexpr int kPersIdxCap = 3072;    // CSR entries of one persistent unit's rows (staged in LDS)
+constexpr int kPersColCap = 640;     // distinct neighbour columns of one persistent unit
+constexpr int kSmallMaxCp = 16;      // one cluster: the single-workgroup kernel; above, the persistent kernel with its 16-camera cluster preconditioner
+constexpr int kDense2MaxCp = 2 * kClu;
+
+struct BaDev {
+  // sizes
+  int n_cam, Cp, Lloc, Eloc, nOff;
+  double huber;
+  // camera state (all cameras replicated), [2][n_cam*7]
+  double* cam[2];
+  const double* K;           // [n_cam*4]
+  const int* slot_cam;       // [Cp] pose slot -> camera index
+  // landmark state (own landmarks), [2][Lloc*3]
+  double* pt[2];
+  // edges of own landmarks, sorted by landmark
+  const int* pt_off;         // [Lloc+1]
+  const int* ed_cam;         // [Eloc] camera index
+  const int* ed_cslot;       // [Eloc] pose slot or -1 (fixed camera)
+  const int* ed_pt;          // [Eloc] local landmark
+  const double* obs;         // [Eloc*2]
+  const double* info;        // [Eloc]
+  // per camera slot: list of local edges
+  const int* cam_off;        // [Cp+1]
+  const int* cam_edge;       // [..]
+  const int* cam_pt;         // [..] landmark of every camera-list slot (ed_pt[cam_edge[s]])
+  // linear system pieces
+  double* W;                 // [Eloc*18]  Hpl block of each edge (pose rows x landmark cols)
+  double* Hll;               // [Lloc*6]   symmetric 3x3
+  double* bl;                // [Lloc*3]
+  double* Dinv;              // [Lloc*6]
+  double* dl;                // [Lloc*3]   D^-1 b_l
+  double* Hpp;               // [Cp*36]    partial (own edges)
+  double* bp;                // [Cp*6]     partial
+  // reduced system (contiguous: all-reduced in one call)
+  double* S;                 // [(Cp+nOff)*36] diagonal blocks first
+  double* bs;                // [Cp*6]
+  const int* inst_off;       // [nOff+1]
+  const int* inst_a;         // edge with the block-row camera
+  const int* inst_c;         // edge with the block-col camera
+  const int* inst_al;        // rank of inst_a's edge inside its camera's edge list (row-centric Schur kernel)
+  const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
+  int max_cam_edges;         // longest per-camera edge list on this rank
+  // row-centric Schur kernel: work units = (block, chunk of <= row_chunk consecutive pair instances), dealt to the waves
+  const int4* unit_tab;      // [n_units]: block (-1: the camera's own observations), first instance, end instance, slot of the partial sum inside the row; per row longest unit first
+  const int* row_unit_off;   // [Cp+1] units of block row i
+  const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
+  int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
+  double* row_part;          // [n_units][kRowSlot] unit partial sums of the two-rows-per-CU shape of the row kernel (nullptr: not allocated)
+  // block CSR for SpMV (full rows, diag included)
+  const int* row_off;        // [Cp+1]
+  const int* row_col;        // [..]
+  const uint32_t* row_blk;   // [..] block id | transpose bit
+  // PCG
+  double *x, *r, *z, *q, *p[2];
+  double* Wc;                // [n_clusters][96*96] explicit inverses of the damped cluster blocks
+  double *ppq, *prz[2];      // partials
+  double* pcg_scal;          // [0]=rz0 [1]=thresh^2  [2]=lambda
+  int* pcg_flag;             // [0]=done [1]=iters [2]=fail
+  int n_wg_spmv, n_wg_upd, n_wg_wave4;   // wave4: one wave per camera, 4 per workgroup
+  // trial outputs
+  double* edge_chi2;         // [Eloc]
+  uint8_t* edge_depth;       // [Eloc]
+  double* part_pt;           // [n_wg_pt*2]  (robust chi2, scale) partials
+  double* part_cam;          // [n_wg_cam]   scale partials (pose part)
+  double* scal;              // [0] chi2 [1] scale [2] stop requested on any rank [3] persistent PCG gave up on any rank (0..3 are summed over
+                             // ranks in ONE all-reduce per trial) [4] maxdiag [5] - [6..7] = pcg_flag (4 ints)
+  int n_wg_pt, n_wg_cam;
+  // edge-parallel landmark kernels: chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
+  const int* chunk_off;      // [n_chunk+1] landmark ranges; nullptr: a landmark has more than kTPB observations -> thread-per-landmark kernels
+  int n_chunk;
+  int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
+  // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
+  double* mk_cpart;          // [n_clusters][6] restriction parts P^T r of every cluster
+  double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
+  const double* mk_P;        // [Cp][36] prolongation blocks
+  const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse
+  int mk_on, mk_Nc, mk_na;   // mk_on: this trial's solve uses the coarse level
+};
+
+struct ccm_ba {
+  ccm_ctx* ctx = nullptr;
+  int rank = 0, nranks = 1;
+  int n_cam = 0, n_pt = 0, n_edge = 0;
+  int Cp = 0, Lp = 0, Lloc = 0, Eloc = 0, nOff = 0;
+  int64_t n_inst = 0, n_act_edges = 0, n_row_entries = 0;
+  int lp_begin = 0, lp_end = 0;
+  std::vector<int> slot_cam;            // [Cp] pose slot -> camera index (host copy for ccm_ba_download)
+  std::vector<int> loc_edge_orig;       // local edge -> the caller's edge index (host copy, fetched on first use)
+  double *d_raw_cam = nullptr, *d_raw_pt = nullptr;   // the caller's cameras [n_cam][7] / landmarks [n_pt][3] as uploaded (create / reset); d_raw_pt also stages the download
+  int *d_slot_pt = nullptr, *d_loc_edge_orig = nullptr;   // [Lp] landmark slot -> landmark index; [Eloc]
+  std::vector<std::pair<void*, size_t>> allocs;   // pooled blocks (ccm_pool_get)
+  BaDev d{};
+  int cur = 0;
+  double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
+  unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
+  double* d_dense_T = nullptr;   // [96][96] scratch of the exact two-cluster solve (17..32 free cameras)
+  int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
+  uint32_t* d_pers_cblk = nullptr;
+  unsigned long long pers_launch = 0;
+  // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
+  int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
+  // The coarse level costs a dense inverse per trial (~0.5 ms) and ~25% per CG iteration; it pays only when the
+  // cluster-Jacobi solve is long (small lambda).  Switch with hysteresis on the iteration count of the previous solve
+  // (deterministic: the counts are): on after a solve of >= kCoarseOnIters iterations, off after one of <= kCoarseOffIters.
+  bool coarse_active = false, coarse_used = false;
+  // The coarse operator Ac = P^T (S + lambda I) P is only a preconditioner: a STALE one (built at an earlier trial's lambda or an
+  // earlier linearisation point) still gives a fixed SPD M^-1 for the whole solve, so PCG converges to the same tolerance, just a few
+  // iterations later.  It is rebuilt when lambda has left [1/4, 4] x the lambda it was built at, or when a solve with the stale
+  // operator needed clearly more iterations than the solve right after the last build (counts are deterministic => so is the policy).
+  bool coarse_valid = false, coarse_fresh = false, coarse_stale_bad = false, coarse_reuse = true;
+  double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
+  double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial
+  int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
+  double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
+  double* d_cparts = nullptr;
+  int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
+  double* d_pt_full = nullptr;
+  double* d_hpp_full = nullptr;
+  double *d_saved_cam = nullptr, *d_saved_pt = nullptr;   // ccm_ba_push_state
+  double ms_setup = 0;
+  // stop flag of the running ccm_ba_run (the reference's bool* pbStopFlag).  One rank: read where g2o calls terminate().
+  // Sharded: the local value rides in the per-trial all-reduce and only the reduced value (stop_any) is acted on.
+  const volatile unsigned char* stop_flag = nullptr;
+  bool stop_any = false;
+  bool stop_requested() const { return nranks > 1 ? stop_any : (stop_flag && *stop_flag); }
+  int stop_local() const { return (stop_flag && *stop_flag) ? 1 : 0; }
+  // per-iteration record of the last run (chi2 after the iteration, lambda, trials) and the optional per-trial callback
+  std::vector<double> hist_chi2, hist_lambda; std::vector<int32_t> hist_trials;
+  ccm_ba_trial_cb trial_cb = nullptr; void* trial_cb_user = nullptr;
+};

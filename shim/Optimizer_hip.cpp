@@ -16,6 +16,7 @@
 // behind in the map.
 #include <cslam/Optimizer.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -50,6 +51,18 @@ void check(int rc, const char* what) {
     throw infrastructure_ex();
   }
 }
+
+// wall-clock phases of the last bundle-adjustment call made by this thread (ms): [0] graph walk (vertices + edges gathered), [1] flatten (ids -> indices,
+// f32 -> f64), [2] ccm_ba_create (structure build: g2o's initializeOptimization + buildStructure), [3] ccm_ba_run (optimize(n)), [4] download (+ depth
+// test), [5] keyframe write-back, [6] map-point write-back (SetWorldPos + UpdateNormalAndDepth), [7] whole call.  Read with ccm_shim_last_phases().
+thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct PhaseClock {
+  double t0, t;
+  PhaseClock() : t0(now_ms()), t(t0) { for (double& v : g_phase) v = 0; }
+  void lap(int i) { const double n = now_ms(); g_phase[i] += n - t; t = n; }
+  ~PhaseClock() { g_phase[7] = now_ms() - t0; }
+};
 
 // a flat bundle-adjustment problem under construction; cameras and points are numbered in g2o VERTEX-ID order, the order in which g2o
 // itself sorts its active vertices (sparse_optimizer.cpp:482-487)
@@ -137,9 +150,19 @@ void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vect
   opt.max_iters = iterations;
   if (chi2) chi2->resize(f.edges.size(), 0.0);
   if (depth_pos) depth_pos->resize(f.edges.size(), 1);
-  check(ccm_ba_optimize(thread_ctx(), &P, &opt, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), chi2 ? chi2->data() : nullptr,
-                        depth_pos ? depth_pos->data() : nullptr, nullptr),
-        "ccm_ba_optimize");
+  // = ccm_ba_optimize (one rank: a one-shot call never turns into a collective), split so that the phases can be read
+  ccm_ctx* ctx = thread_ctx();
+  ccm_ba* ba = nullptr;
+  double t = now_ms();
+  check(ccm_ba_create(ctx, &P, 0, 1, &ba), "ccm_ba_create");
+  double n = now_ms(); g_phase[2] += n - t; t = n;
+  int rc = ccm_ba_run(ba, &opt, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr);
+  n = now_ms(); g_phase[3] += n - t; t = n;
+  if (rc == CCM_OK) rc = ccm_ba_download(ba, P.cam_qt, P.pt_xyz, chi2 ? chi2->data() : nullptr);
+  if (rc == CCM_OK && depth_pos) rc = ccm_ba_depth_positive(&P, P.cam_qt, P.pt_xyz, depth_pos->data());
+  ccm_ba_destroy(ba);
+  g_phase[4] += now_ms() - t;
+  check(rc, "ccm_ba_run");
 }
 
 }  // namespace
@@ -268,6 +291,7 @@ int Optimizer::PoseOptimizationClient(Frame& Frame) {
 
 // Optimizer.cpp:349-644
 void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr pMap, size_t ClientId, eSystemState SysState) {
+  PhaseClock pc;
   // Local KeyFrames: breadth-first from the current keyframe (:351-366)
   list<kfptr> lLocalKeyFrames;
   lLocalKeyFrames.push_back(pKF);
@@ -348,7 +372,9 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   }
   if (pbStopFlag)
     if (*pbStopFlag) return;
+  pc.lap(0);
   f.flatten();
+  pc.lap(1);
   // optimizer.initializeOptimization(); optimizer.optimize(5);  (:536-537)
   std::vector<double> chi2;
   std::vector<uint8_t> dpos;
@@ -365,6 +391,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     }
     run_ba(f, 0.0, 10, pbStopFlag, &chi2, &dpos);
   }
+  pc.t = now_ms();
   vector<pair<kfptr, mpptr> > vToErase;
   vToErase.reserve(f.edges.size());
   for (size_t i = 0, iend = f.edges.size(); i < iend; i++) {
@@ -387,6 +414,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     pKFl->SetPose(f.camPose(Optimizer::GetID(pKFl->mId, true)), false);
     pKFl->mbUpdatedByServer = false;
   }
+  pc.lap(5);
   for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
     mpptr pMP = *lit;
     if (pMP->isBad()) {
@@ -400,6 +428,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
       pMP->UpdateNormalAndDepth();
     }
   }
+  pc.lap(6);
   if (SysState != eSystemState::SERVER) pMap->UnLockMapUpdate();
 }
 
@@ -409,6 +438,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
 // Optimizer.cpp:646-859
 void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool* pbStopFlag, idpair nLoopKF, const bool bRobust) {
   (void)ClientId;
+  PhaseClock pc;
   vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
   vector<mpptr> vpMP = pMap->GetAllMapPoints();
   const idpair zeropair = make_pair(0, pMap->mMapId);
@@ -448,8 +478,11 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
       f.addEdge(id, pKF, pKF->mUniqueId, pKF->mvKeysUn[mit->second]);
     }
   }
+  pc.lap(0);
   f.flatten(true);
+  pc.lap(1);
   run_ba(f, bRobust ? (double)thHuber2D : 0.0, nIterations, pbStopFlag, nullptr, nullptr);
+  pc.t = now_ms();
   for (size_t i = 0; i < vpKFs.size(); i++) {
     kfptr pKF = vpKFs[i];
     if (pKF->isBad()) continue;
@@ -461,6 +494,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
       pKF->mBAGlobalForKF = nLoopKF;
     }
   }
+  pc.lap(5);
   for (size_t i = 0; i < vpMP.size(); i++) {
     if (vbNotIncludedMP[i]) continue;
     mpptr pMP = vpMP[i];
@@ -475,6 +509,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
       pMP->mBAGlobalForKF = nLoopKF;
     }
   }
+  pc.lap(6);
 }
 
 // Optimizer.cpp:861-1056
@@ -746,3 +781,6 @@ void Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap, kfptr pLoopKF, kfpt
 }
 
 }  // namespace cslam
+
+// phases (ms) of the last LocalBundleAdjustmentClient / MapFusionGBA call of the calling thread, see g_phase above
+extern "C" void ccm_shim_last_phases(double* out8) { for (int i = 0; i < 8; i++) out8[i] = cslam::g_phase[i]; }
