@@ -653,7 +653,12 @@ __global__ __launch_bounds__(kSpmvTPB) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
   __shared__ double redp[4 * (kSpmvTPB / kWave)];
-  if (d.pcg_flag[0]) return;
+  // the "done" flag is read ONCE per workgroup: workgroup 0 sets it further down in this very launch, and waves of another workgroup that read it at
+  // different times would leave the block-wide sums below with missing members
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = d.pcg_flag[0];
+  __syncthreads();
+  if (s_done) return;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int rl = wv >> 1, h = wv & 1;            // local row, half
@@ -2169,8 +2174,8 @@ extern "C" int ccm_ba_reset_state(ccm_ba* ba, const double* cam_qt, const double
   if (!ba || !cam_qt || (ba->n_pt && !pt_xyz)) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_cam, cam_qt, 7 * (size_t)ba->n_cam * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (ba->n_pt) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_pt, pt_xyz, 3 * (size_t)ba->n_pt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_cam, cam_qt, 7 * (size_t)ba->n_cam * sizeof(double), hipMemcpyDefault, ctx->stream));
+  if (ba->n_pt) CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_raw_pt, pt_xyz, 3 * (size_t)ba->n_pt * sizeof(double), hipMemcpyDefault, ctx->stream));
   RC(ccm_ba_state_from_raw(ba));   // SE3Quat(q, t) normalises the rotation (se3quat.h:61-63); landmarks gathered into slot order
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;
@@ -2480,7 +2485,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   RC(read_scalars(ba, s, small_flags));
   CCM_HIP_CHECK(ctx, hipGetLastError());
   ba->stop_any = s[2] > 0.0;
-  if (s[3] > 0.0 && (pers_trial || pers_launch_failed)) {   // the persistent kernel could not hold its grid exchange: never again on this handle
+  // s[3] is summed over the ranks: the persistent kernel gave up (or could not be launched) SOMEWHERE.  Every rank repeats the trial on the multi-kernel
+  // path, whatever its own solver did — the repeat issues the Schur and scalar all-reduces again, so a rank that skipped it would fall out of step with
+  // its peers, and all ranks must keep bit-identical camera states.  The repeat runs with pers_grid = 0 and contributes 0: it cannot recurse.
+  if (s[3] > 0.0) {
     ba->pers_grid = 0;
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }
@@ -2590,6 +2598,19 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   ba->coarse_valid = false; ba->coarse_stale_bad = false; ba->coarse_fresh_iters = 0;
   ba->stop_flag = stop_flag; ba->stop_any = false;
   ba->hist_chi2.clear(); ba->hist_lambda.clear(); ba->hist_trials.clear();
+  if (ba->nranks > 1 && !ba->pers_agreed) {
+    // the ranks of a sharded run must take the same PCG path from the first trial (bit-identical replicated solves): the persistent kernel is used only
+    // when EVERY rank can run it (occupancy, CU count and CCM_BA_NO_PERSIST may differ between ranks)
+    const double mine = ba->pers_grid ? 0.0 : 1.0;
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d.scal + 5, &mine, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    RC(ba_allreduce_max(ba, ba->d.scal + 5, 1));
+    double any = 0;
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(&any, ba->d.scal + 5, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (any > 0.0) ba->pers_grid = 0;
+    ba->pers_agreed = true;
+  }
   const double t_start = now_ms();
   ccm_ba_stats st{};
   st.ms_setup = ba->ms_setup;

@@ -471,7 +471,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   Tmp tmp{ctx, {}};
   auto body = [&]() -> int {
     BaDev& d = ba->d;
-    // ---- the caller's flat arrays -> HBM.  Index arrays first: the structure kernels queue behind them while the host stages the big ones ----
+    // ---- the caller's flat arrays -> HBM (hipMemcpyDefault: the arrays of ccm_ba_problem may live in host OR device memory).  Index arrays first: the
+    // structure kernels queue behind them while the host stages the big ones ----
     int *r_ecam = nullptr, *r_ept = nullptr; uint8_t *r_lvl = nullptr, *r_fixed = nullptr;
     double *r_obs = nullptr, *r_info = nullptr, *dK = nullptr;
     BB_RC(tmp.get((size_t)n_edge, &r_ecam)); BB_RC(tmp.get((size_t)n_edge, &r_ept));
@@ -481,11 +482,11 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     BB_RC(keep_get(ba, 4 * (size_t)n_cam, &dK));
     BB_RC(keep_get(ba, 7 * (size_t)n_cam, &ba->d_raw_cam)); BB_RC(keep_get(ba, 3 * (size_t)std::max(n_pt, 1), &ba->d_raw_pt));
     if (n_edge) {
-      BB_HIP(hipMemcpyAsync(r_ecam, P->e_cam, (size_t)n_edge * sizeof(int), hipMemcpyHostToDevice, st));
-      BB_HIP(hipMemcpyAsync(r_ept, P->e_pt, (size_t)n_edge * sizeof(int), hipMemcpyHostToDevice, st));
-      if (r_lvl) BB_HIP(hipMemcpyAsync(r_lvl, P->e_level, (size_t)n_edge, hipMemcpyHostToDevice, st));
+      BB_HIP(hipMemcpyAsync(r_ecam, P->e_cam, (size_t)n_edge * sizeof(int), hipMemcpyDefault, st));
+      BB_HIP(hipMemcpyAsync(r_ept, P->e_pt, (size_t)n_edge * sizeof(int), hipMemcpyDefault, st));
+      if (r_lvl) BB_HIP(hipMemcpyAsync(r_lvl, P->e_level, (size_t)n_edge, hipMemcpyDefault, st));
     }
-    BB_HIP(hipMemcpyAsync(r_fixed, P->cam_fixed, (size_t)n_cam, hipMemcpyHostToDevice, st));
+    BB_HIP(hipMemcpyAsync(r_fixed, P->cam_fixed, (size_t)n_cam, hipMemcpyDefault, st));
     lap("H2D index arrays");
     // ---- active set (initializeOptimization(0), sparse_optimizer.cpp:199-267) and vertex slots ----
     BuildSizes* sz = nullptr;
@@ -524,12 +525,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     BB_HIP(hipGetLastError());
     // ---- the big arrays (the host stages them while the kernels above run) ----
     if (n_edge) {
-      BB_HIP(hipMemcpyAsync(r_obs, P->e_obs, 2 * (size_t)n_edge * sizeof(double), hipMemcpyHostToDevice, st));
-      BB_HIP(hipMemcpyAsync(r_info, P->e_info, (size_t)n_edge * sizeof(double), hipMemcpyHostToDevice, st));
+      BB_HIP(hipMemcpyAsync(r_obs, P->e_obs, 2 * (size_t)n_edge * sizeof(double), hipMemcpyDefault, st));
+      BB_HIP(hipMemcpyAsync(r_info, P->e_info, (size_t)n_edge * sizeof(double), hipMemcpyDefault, st));
     }
-    BB_HIP(hipMemcpyAsync(dK, P->cam_K, 4 * (size_t)n_cam * sizeof(double), hipMemcpyHostToDevice, st));
-    BB_HIP(hipMemcpyAsync(ba->d_raw_cam, P->cam_qt, 7 * (size_t)n_cam * sizeof(double), hipMemcpyHostToDevice, st));
-    if (n_pt) BB_HIP(hipMemcpyAsync(ba->d_raw_pt, P->pt_xyz, 3 * (size_t)n_pt * sizeof(double), hipMemcpyHostToDevice, st));
+    BB_HIP(hipMemcpyAsync(dK, P->cam_K, 4 * (size_t)n_cam * sizeof(double), hipMemcpyDefault, st));
+    BB_HIP(hipMemcpyAsync(ba->d_raw_cam, P->cam_qt, 7 * (size_t)n_cam * sizeof(double), hipMemcpyDefault, st));
+    if (n_pt) BB_HIP(hipMemcpyAsync(ba->d_raw_pt, P->pt_xyz, 3 * (size_t)n_pt * sizeof(double), hipMemcpyDefault, st));
     d.K = dK;
     // ---- sizes (first read-back) ----
     BuildSizes hs;

@@ -120,6 +120,7 @@ struct ccm_ba {
   int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
   uint32_t* d_pers_cblk = nullptr;
   unsigned long long pers_launch = 0;
+  bool pers_agreed = false;   // sharded handle: the ranks have agreed on whether the persistent kernel is used (first ccm_ba_run)
   // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
   int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;
   // The coarse level costs a dense inverse per trial (~0.5 ms) and ~25% per CG iteration; it pays only when the

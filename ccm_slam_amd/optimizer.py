@@ -25,9 +25,17 @@ def _vp(a):
 class BAHandle:
     """Staged BA (ccm_ba_create / run / download).  Keeps the flattened arrays alive."""
 
-    def __init__(self, ctx: Context, prob: dict, rank: int = 0, nranks: int = 1):
+    def __init__(self, ctx: Context, prob: dict, rank: int = 0, nranks: int = 1, resident: "ResidentProblem | None" = None):
+        """resident: the flat problem already uploaded to HBM (ResidentProblem): ccm_ba_create then reads device memory only."""
         self.ctx = ctx
         self.prob = prob
+        if resident is not None:
+            self._keep = resident.keep
+            self.cprob = resident.host_cprob
+            self._h = C.c_void_p()
+            check(lib().ccm_ba_create(ctx.handle, C.byref(resident.dev_cprob), int(rank), int(nranks), C.byref(self._h)), ctx.handle)
+            ctx.adopt(self)
+            return
         self._keep = {
             "cam_qt": np.ascontiguousarray(prob["cam_qt"], np.float64).copy(),
             "cam_fixed": np.ascontiguousarray(prob["cam_fixed"], np.uint8),
@@ -134,6 +142,32 @@ class BAHandle:
             self.close()
         except Exception:
             pass
+
+
+class ResidentProblem:
+    """The flat arrays of a BA problem uploaded once to HBM; `dev_cprob` is a ccm_ba_problem whose pointers address device memory
+    (ccm_ba_create accepts either, include/ccm_hip.h)."""
+
+    def __init__(self, ctx: Context, prob: dict):
+        self.ctx = ctx
+        k = self.keep = {
+            "cam_qt": np.ascontiguousarray(prob["cam_qt"], np.float64).copy(), "cam_fixed": np.ascontiguousarray(prob["cam_fixed"], np.uint8),
+            "cam_K": np.ascontiguousarray(prob["cam_K"], np.float64), "pt_xyz": np.ascontiguousarray(prob["pt_xyz"], np.float64).copy(),
+            "e_cam": np.ascontiguousarray(prob["e_cam"], np.int32), "e_pt": np.ascontiguousarray(prob["e_pt"], np.int32),
+            "e_obs": np.ascontiguousarray(prob["e_obs"], np.float64), "e_info": np.ascontiguousarray(prob["e_info"], np.float64),
+            "e_level": np.ascontiguousarray(prob["e_level"], np.uint8) if prob.get("e_level") is not None else None}
+        order = ("cam_qt", "cam_fixed", "cam_K", "pt_xyz", "e_cam", "e_pt", "e_obs", "e_info", "e_level")
+        self.dptr = {n: (ctx.upload(k[n]) if k[n] is not None else None) for n in order}
+        dims = (int(prob["n_cam"]), int(prob["n_pt"]), int(prob["n_edge"]))
+        self.host_cprob = BAProblem(*dims, *[_vp(k[n]) for n in order], float(prob["huber_delta"]))
+        self.dev_cprob = BAProblem(*dims, *[self.dptr[n] for n in order], float(prob["huber_delta"]))
+        self.bytes = sum(k[n].nbytes for n in order if k[n] is not None)
+
+    def close(self):
+        for p in self.dptr.values():
+            if p:
+                self.ctx.free(p)
+        self.dptr = {}
 
 
 def bundle_adjustment(ctx: Context, prob: dict, max_iters: int, chi2_in=None, **kw):

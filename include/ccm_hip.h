@@ -217,7 +217,10 @@ int  ccm_update_normal_and_depth(ccm_ctx* ctx, int n_pt, const float* pos /* n_p
  * 646-859): BlockSolver_6_3 + OptimizationAlgorithmLevenberg + EdgeSE3ProjectXYZ + Huber
  * (thirdparty/g2o/g2o/core/block_solver.hpp, optimization_algorithm_levenberg.cpp,
  * types/types_six_dof_expmap.{h,cpp}, core/robust_kernel_impl.cpp).
- * All state is f64.  cam_qt rows: qx qy qz qw tx ty tz (world -> camera, as g2o::SE3Quat). */
+ * All state is f64.  cam_qt rows: qx qy qz qw tx ty tz (world -> camera, as g2o::SE3Quat).
+ * ccm_ba_create / ccm_ba_reset_state only COPY these arrays to their device-side staging buffers (the structure is built on the device), so every
+ * pointer may address host memory (pageable or pinned) or memory of the context's device; the one-shot ccm_ba_optimize, ccm_ba_download and
+ * ccm_ba_depth_positive write / read host memory. */
 typedef struct {
   int32_t n_cam, n_pt, n_edge;
   double*        cam_qt;     /* [n_cam*7]  in/out                                        */

@@ -11,11 +11,11 @@ import numpy as np
 from ccm_slam_amd import synth
 from oracle import mapgraph as mg
 
-PH = ("walk", "flatten", "create", "run", "download", "kf_writeback", "mp_writeback", "total")
+PH = ("walk", "flatten", "create", "run", "download", "kf_writeback", "mp_writeback", "total", "vertices", "release")
 
 
 def phases(lib):
-    out = (C.c_double * 8)()
+    out = (C.c_double * 10)()
     lib.ccm_shim_last_phases(out)
     return {k: round(v, 3) for k, v in zip(PH, out)}
 

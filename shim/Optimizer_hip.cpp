@@ -20,8 +20,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
-#include <unordered_map>
+#include <thread>
 
 #include "../include/ccm_hip.h"
 #include "../ccm_slam_amd/host/ccm_convert.h"
@@ -55,7 +56,7 @@ void check(int rc, const char* what) {
 // wall-clock phases of the last bundle-adjustment call made by this thread (ms): [0] graph walk (vertices + edges gathered), [1] flatten (ids -> indices,
 // f32 -> f64), [2] ccm_ba_create (structure build: g2o's initializeOptimization + buildStructure), [3] ccm_ba_run (optimize(n)), [4] download (+ depth
 // test), [5] keyframe write-back, [6] map-point write-back (SetWorldPos + UpdateNormalAndDepth), [7] whole call.  Read with ccm_shim_last_phases().
-thread_local double g_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_phase[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct PhaseClock {
   double t0, t;
@@ -64,65 +65,131 @@ struct PhaseClock {
   ~PhaseClock() { g_phase[7] = now_ms() - t0; }
 };
 
+// host threads for the per-map-point work of a global bundle adjustment (graph walk, write-back): every map point is independent and the
+// reference's accessors take the point's own mutexes, so contiguous chunks of vpMP are handled by a few threads and merged in order.
+// Measured on the 4-agent map (150 000 points, 256-core host): walk 87 ms on one thread, 36 on 8, 34 on 32 (shared_ptr reference counts of
+// the 2000 keyframes bounce between the cores); write-back 230 / 46 / 17 ms.  CCM_SHIM_THREADS overrides (1 = the calling thread only).
+int shim_threads(size_t n_items, unsigned cap = 8) {
+  static const int env = std::getenv("CCM_SHIM_THREADS") ? std::atoi(std::getenv("CCM_SHIM_THREADS")) : 0;
+  int t = env > 0 ? env : (int)std::min<unsigned>(std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1u, cap);
+  if (n_items < 20000) t = 1;
+  return std::max(1, t);
+}
+template <typename F>
+void parallel_chunks(size_t n, int n_thr, F fn /* (chunk index, begin, end) */) {
+  if (n_thr <= 1) { fn(0, (size_t)0, n); return; }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err((size_t)n_thr);
+  for (int t = 0; t < n_thr; t++)
+    th.emplace_back([&, t]() {
+      try { fn(t, n * (size_t)t / (size_t)n_thr, n * (size_t)(t + 1) / (size_t)n_thr); } catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
+  for (auto& x : th) x.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+
+// vertex id -> index: a direct table when the ids are compact (mUniqueId, GetID of a few clients), a sorted list otherwise
+struct IdIndex {
+  std::vector<int32_t> table;
+  std::vector<std::pair<size_t, int32_t>> sorted;
+  void build(const std::vector<size_t>& ids) {
+    table.clear(); sorted.clear();
+    size_t mx = 0;
+    for (size_t v : ids) mx = std::max(mx, v);
+    if (mx <= 8 * ids.size() + 4096) {
+      table.assign(mx + 1, -1);
+      for (size_t i = 0; i < ids.size(); i++) table[ids[i]] = (int32_t)i;
+    } else {
+      sorted.reserve(ids.size());
+      for (size_t i = 0; i < ids.size(); i++) sorted.push_back({ids[i], (int32_t)i});
+      std::sort(sorted.begin(), sorted.end());
+    }
+  }
+  int32_t find(size_t id) const {
+    if (!table.empty()) return id < table.size() ? table[id] : -1;
+    auto it = std::lower_bound(sorted.begin(), sorted.end(), std::make_pair(id, (int32_t)INT32_MIN));
+    return (it != sorted.end() && it->first == id) ? it->second : -1;
+  }
+};
+
 // a flat bundle-adjustment problem under construction; cameras and points are numbered in g2o VERTEX-ID order, the order in which g2o
-// itself sorts its active vertices (sparse_optimizer.cpp:482-487)
+// itself sorts its active vertices (sparse_optimizer.cpp:482-487).  Edges keep their insertion order (the callers index per-edge results by it).
 struct FlatBA {
-  std::vector<std::pair<size_t, Optimizer::kfptr>> cams;   // (vertex id, keyframe)
-  std::vector<char> cam_fixed_by_id;
-  std::unordered_map<size_t, char> fixed;
-  std::vector<std::pair<size_t, Optimizer::mpptr>> pts;
-  struct Edge { size_t cam_id, pt_id; double u, v, info; };
-  std::vector<Edge> edges;
+  std::vector<size_t> cam_id, pt_id;                 // insertion order until flatten() sorts them by id
+  std::vector<Optimizer::kfptr> cam_kf;
+  std::vector<char> cam_is_fixed;
+  std::vector<MapPoint*> pt_mp;                      // raw: the caller's containers keep the points alive, and 150 000 shared_ptr copies cost ~15 ms of cache-missing atomics each way
+  std::vector<size_t> e_cam_id, e_pt_id;             // per edge: vertex ids
   // flattened
   std::vector<double> cam_qt, cam_K, pt_xyz, e_obs, e_info;
   std::vector<uint8_t> cam_fix, e_level;
   std::vector<int32_t> e_cam, e_pt;
-  std::unordered_map<size_t, int> cam_index, pt_index;
+  IdIndex cam_index, pt_index;
 
-  void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cams.push_back({id, kf}); fixed[id] = is_fixed; }
-  void addPoint(size_t id, Optimizer::mpptr mp) { pts.push_back({id, mp}); }
-  void addEdge(size_t pt_id, Optimizer::kfptr kf, size_t cam_id, const cv::KeyPoint& kpUn) {
+  size_t nEdges() const { return e_cam_id.size(); }
+  void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cam_id.push_back(id); cam_kf.push_back(kf); cam_is_fixed.push_back(is_fixed ? 1 : 0); }
+  void addPoint(size_t id, const Optimizer::mpptr& mp) { pt_id.push_back(id); pt_mp.push_back(mp.get()); }
+  void addEdge(size_t p_id, const Optimizer::kfptr& kf, size_t c_id, const cv::KeyPoint& kpUn) {
     const float& invSigma2 = kf->mvInvLevelSigma2[kpUn.octave];
-    edges.push_back({cam_id, pt_id, (double)kpUn.pt.x, (double)kpUn.pt.y, (double)invSigma2});
+    e_cam_id.push_back(c_id); e_pt_id.push_back(p_id);
+    e_obs.push_back((double)kpUn.pt.x); e_obs.push_back((double)kpUn.pt.y); e_info.push_back((double)invSigma2);
   }
-  void removePoint(size_t id) { for (size_t i = 0; i < pts.size(); i++) if (pts[i].first == id) { pts.erase(pts.begin() + i); return; } }
+  void removePoint(size_t id) {   // the callers remove the point they added last (a point without edges)
+    for (size_t i = pt_id.size(); i-- > 0;) if (pt_id[i] == id) { pt_id.erase(pt_id.begin() + i); pt_mp.erase(pt_mp.begin() + i); return; }
+  }
+  void append(FlatBA& o) {        // merge of a thread's part (points and edges of a later chunk of vpMP)
+    pt_id.insert(pt_id.end(), o.pt_id.begin(), o.pt_id.end()); pt_mp.insert(pt_mp.end(), o.pt_mp.begin(), o.pt_mp.end());
+    e_cam_id.insert(e_cam_id.end(), o.e_cam_id.begin(), o.e_cam_id.end()); e_pt_id.insert(e_pt_id.end(), o.e_pt_id.begin(), o.e_pt_id.end());
+    e_obs.insert(e_obs.end(), o.e_obs.begin(), o.e_obs.end()); e_info.insert(e_info.end(), o.e_info.begin(), o.e_info.end());
+  }
+  template <typename P>
+  static void sort_by_id(std::vector<size_t>& ids, std::vector<P>& ptrs, std::vector<char>* flags) {
+    if (std::is_sorted(ids.begin(), ids.end())) return;
+    std::vector<size_t> perm(ids.size());
+    for (size_t i = 0; i < perm.size(); i++) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return ids[a] < ids[b]; });
+    std::vector<size_t> ids2(ids.size()); std::vector<P> p2(ids.size()); std::vector<char> f2(flags ? ids.size() : 0);
+    for (size_t i = 0; i < perm.size(); i++) { ids2[i] = ids[perm[i]]; p2[i] = ptrs[perm[i]]; if (flags) f2[i] = (*flags)[perm[i]]; }
+    ids.swap(ids2); ptrs.swap(p2); if (flags) flags->swap(f2);
+  }
   // g2o refuses an edge whose camera vertex does not exist (optimizer.vertex(id) == 0 -> addEdge fails): such observations are dropped
   void flatten(bool drop_edges_without_camera = false) {
-    if (drop_edges_without_camera) {
-      std::unordered_map<size_t, char> have;
-      for (auto& c : cams) have[c.first] = 1;
-      std::vector<Edge> kept;
-      for (auto& e : edges) if (have.count(e.cam_id)) kept.push_back(e);
-      edges.swap(kept);
-    }
-    std::sort(cams.begin(), cams.end(), [](const std::pair<size_t, Optimizer::kfptr>& a, const std::pair<size_t, Optimizer::kfptr>& b) { return a.first < b.first; });
-    std::sort(pts.begin(), pts.end(), [](const std::pair<size_t, Optimizer::mpptr>& a, const std::pair<size_t, Optimizer::mpptr>& b) { return a.first < b.first; });
-    const size_t nc = cams.size(), np = pts.size(), ne = edges.size();
+    sort_by_id(cam_id, cam_kf, &cam_is_fixed);
+    sort_by_id<MapPoint*>(pt_id, pt_mp, nullptr);
+    cam_index.build(cam_id); pt_index.build(pt_id);
+    const size_t nc = cam_id.size(), np = pt_id.size();
     cam_qt.resize(7 * nc); cam_K.resize(4 * nc); cam_fix.resize(nc); pt_xyz.resize(3 * np);
     for (size_t i = 0; i < nc; i++) {
-      cam_index[cams[i].first] = (int)i;
-      const cv::Mat Tcw = cams[i].second->GetPose();                                  // Converter::toSE3Quat(pKF->GetPose())
+      const cv::Mat Tcw = cam_kf[i]->GetPose();                                      // Converter::toSE3Quat(pKF->GetPose())
       float T[16];
       for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) T[4 * r + c] = Tcw.at<float>(r, c);
       ccmh::toSE3Quat(T, &cam_qt[7 * i]);
-      cam_K[4 * i] = cams[i].second->fx; cam_K[4 * i + 1] = cams[i].second->fy; cam_K[4 * i + 2] = cams[i].second->cx; cam_K[4 * i + 3] = cams[i].second->cy;
-      cam_fix[i] = fixed[cams[i].first] ? 1 : 0;
+      cam_K[4 * i] = cam_kf[i]->fx; cam_K[4 * i + 1] = cam_kf[i]->fy; cam_K[4 * i + 2] = cam_kf[i]->cx; cam_K[4 * i + 3] = cam_kf[i]->cy;
+      cam_fix[i] = cam_is_fixed[i] ? 1 : 0;
     }
-    for (size_t i = 0; i < np; i++) {
-      pt_index[pts[i].first] = (int)i;
-      const cv::Mat P = pts[i].second->GetWorldPos();                                 // Converter::toVector3d(pMP->GetWorldPos())
-      const float p[3] = {P.at<float>(0), P.at<float>(1), P.at<float>(2)};
-      ccmh::toVector3d(p, &pt_xyz[3 * i]);
-    }
-    e_cam.resize(ne); e_pt.resize(ne); e_obs.resize(2 * ne); e_info.resize(ne); e_level.assign(ne, 0);
+    parallel_chunks(np, shim_threads(np), [&](int, size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) {
+        const cv::Mat P = pt_mp[i]->GetWorldPos();                                   // Converter::toVector3d(pMP->GetWorldPos())
+        const float p[3] = {P.at<float>(0), P.at<float>(1), P.at<float>(2)};
+        ccmh::toVector3d(p, &pt_xyz[3 * i]);
+      }
+    });
+    const size_t ne = e_cam_id.size();
+    e_cam.resize(ne); e_pt.resize(ne);
+    size_t w = 0;
     for (size_t k = 0; k < ne; k++) {
-      e_cam[k] = cam_index[edges[k].cam_id]; e_pt[k] = pt_index[edges[k].pt_id];
-      e_obs[2 * k] = edges[k].u; e_obs[2 * k + 1] = edges[k].v; e_info[k] = edges[k].info;
+      const int32_t ci = cam_index.find(e_cam_id[k]);
+      if (ci < 0 && drop_edges_without_camera) continue;
+      e_cam[w] = ci; e_pt[w] = pt_index.find(e_pt_id[k]);
+      if (w != k) { e_cam_id[w] = e_cam_id[k]; e_pt_id[w] = e_pt_id[k]; e_obs[2 * w] = e_obs[2 * k]; e_obs[2 * w + 1] = e_obs[2 * k + 1]; e_info[w] = e_info[k]; }
+      w++;
     }
+    e_cam.resize(w); e_pt.resize(w); e_cam_id.resize(w); e_pt_id.resize(w); e_obs.resize(2 * w); e_info.resize(w);
+    e_level.assign(w, 0);
   }
   ccm_ba_problem problem(double huber) {
     ccm_ba_problem P;
-    P.n_cam = (int32_t)cams.size(); P.n_pt = (int32_t)pts.size(); P.n_edge = (int32_t)edges.size();
+    P.n_cam = (int32_t)cam_id.size(); P.n_pt = (int32_t)pt_id.size(); P.n_edge = (int32_t)e_cam.size();
     P.cam_qt = cam_qt.data(); P.cam_fixed = cam_fix.data(); P.cam_K = cam_K.data(); P.pt_xyz = pt_xyz.data();
     P.e_cam = e_cam.data(); P.e_pt = e_pt.data(); P.e_obs = e_obs.data(); P.e_info = e_info.data(); P.e_level = e_level.data();
     P.huber_delta = huber;
@@ -130,15 +197,16 @@ struct FlatBA {
   }
   cv::Mat camPose(size_t id) {                                                       // Converter::toCvMat(vSE3->estimate())
     float T[16];
-    ccmh::toCvMat(&cam_qt[7 * (size_t)cam_index[id]], T);
+    ccmh::toCvMat(&cam_qt[7 * (size_t)cam_index.find(id)], T);
     cv::Mat m(4, 4, CV_32F);
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m.at<float>(r, c) = T[4 * r + c];
-    return m.clone();
+    return m;
   }
   cv::Mat pointPos(size_t id) {                                                      // Converter::toCvMat(vPoint->estimate())
     cv::Mat m(3, 1, CV_32F);
-    for (int c = 0; c < 3; c++) m.at<float>(c) = (float)pt_xyz[3 * (size_t)pt_index[id] + c];
-    return m.clone();
+    const size_t i = (size_t)pt_index.find(id);
+    for (int c = 0; c < 3; c++) m.at<float>(c) = (float)pt_xyz[3 * i + c];
+    return m;
   }
 };
 
@@ -148,8 +216,8 @@ void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vect
   ccm_ba_options opt;
   std::memset(&opt, 0, sizeof(opt));
   opt.max_iters = iterations;
-  if (chi2) chi2->resize(f.edges.size(), 0.0);
-  if (depth_pos) depth_pos->resize(f.edges.size(), 1);
+  if (chi2) chi2->resize(f.nEdges(), 0.0);
+  if (depth_pos) depth_pos->resize(f.nEdges(), 1);
   // = ccm_ba_optimize (one rank: a one-shot call never turns into a collective), split so that the phases can be read
   ccm_ctx* ctx = thread_ctx();
   ccm_ba* ba = nullptr;
@@ -384,7 +452,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     if (*pbStopFlag) bDoMore = false;
   if (bDoMore) {
     // outliers to level 1, robust kernel off, optimize(10) (:545-566).  e->chi2() of a level-1 edge keeps the value of the first pass.
-    for (size_t i = 0, iend = f.edges.size(); i < iend; i++) {
+    for (size_t i = 0, iend = f.nEdges(); i < iend; i++) {
       mpptr pMP = vpMapPointEdgeMono[i];
       if (pMP->isBad()) continue;
       if (chi2[i] > 5.991 || !dpos[i]) f.e_level[i] = 1;
@@ -393,8 +461,8 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   }
   pc.t = now_ms();
   vector<pair<kfptr, mpptr> > vToErase;
-  vToErase.reserve(f.edges.size());
-  for (size_t i = 0, iend = f.edges.size(); i < iend; i++) {
+  vToErase.reserve(f.nEdges());
+  for (size_t i = 0, iend = f.nEdges(); i < iend; i++) {
     mpptr pMP = vpMapPointEdgeMono[i];
     if (pMP->isBad()) continue;
     if (chi2[i] > 5.991 || !dpos[i]) vToErase.push_back(make_pair(vpEdgeKFMono[i], pMP));
@@ -447,8 +515,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
     throw infrastructure_ex();
   }
   idpair FixedId = (*(pMap->mvpKeyFrameOrigins.begin()))->mId;
-  vector<bool> vbNotIncludedMP;
-  vbNotIncludedMP.resize(vpMP.size(), false);
+  std::vector<char> vbNotIncludedMP(vpMP.size(), 0);   // one byte per point: chunks of vpMP are walked by different threads
   FlatBA f;
   size_t maxKFid = 0;
   for (size_t i = 0; i < vpKFs.size(); i++) {
@@ -458,25 +525,36 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
     if (pKF->mUniqueId > maxKFid) maxKFid = pKF->mUniqueId;
   }
   const float thHuber2D = sqrt(5.99);
-  for (size_t i = 0; i < vpMP.size(); i++) {
-    mpptr pMP = vpMP[i];
-    if (pMP->isBad()) continue;
-    const map<kfptr, size_t> observations = pMP->GetObservations();
-    if (observations.size() < 2) { vbNotIncludedMP[i] = true; continue; }
-    int nEdges = 0;
-    const size_t id = pMP->mUniqueId;
-    for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
-      kfptr pKF = mit->first;
-      if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
-      nEdges++;
-    }
-    if (nEdges < 2) { vbNotIncludedMP[i] = true; continue; }
-    f.addPoint(id, pMP);
-    for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
-      kfptr pKF = mit->first;
-      if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
-      f.addEdge(id, pKF, pKF->mUniqueId, pKF->mvKeysUn[mit->second]);
-    }
+  pc.lap(8);
+  {
+    // the map points in contiguous chunks of vpMP, one chunk per host thread (every point is independent; GetObservations() copies under the point's
+    // own mutex exactly as in the reference); the chunks are appended in order, so vertices and edges keep the order of the sequential walk
+    const int n_thr = shim_threads(vpMP.size());
+    std::vector<FlatBA> part((size_t)n_thr);
+    parallel_chunks(vpMP.size(), n_thr, [&](int t, size_t i0, size_t i1) {
+      FlatBA& g = t == 0 ? f : part[(size_t)t];
+      for (size_t i = i0; i < i1; i++) {
+        const mpptr& pMP = vpMP[i];
+        if (pMP->isBad()) continue;
+        const map<kfptr, size_t> observations = pMP->GetObservations();
+        if (observations.size() < 2) { vbNotIncludedMP[i] = true; continue; }
+        int nEdges = 0;
+        const size_t id = pMP->mUniqueId;
+        for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) {
+          const kfptr& pKF = mit->first;
+          if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
+          nEdges++;
+        }
+        if (nEdges < 2) { vbNotIncludedMP[i] = true; continue; }
+        g.addPoint(id, pMP);
+        for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
+          const kfptr& pKF = mit->first;
+          if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
+          g.addEdge(id, pKF, pKF->mUniqueId, pKF->mvKeysUn[mit->second]);
+        }
+      }
+    });
+    for (int t = 1; t < n_thr; t++) f.append(part[(size_t)t]);
   }
   pc.lap(0);
   f.flatten(true);
@@ -495,21 +573,27 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
     }
   }
   pc.lap(5);
-  for (size_t i = 0; i < vpMP.size(); i++) {
-    if (vbNotIncludedMP[i]) continue;
-    mpptr pMP = vpMP[i];
-    if (pMP->isBad()) continue;
-    cv::Mat pos = f.pointPos(pMP->mUniqueId);
-    if (nLoopKF == zeropair) {
-      pMP->SetWorldPos(pos, true);
-      pMP->UpdateNormalAndDepth();
-    } else {
-      pMP->mPosGBA.create(3, 1, CV_32F);
-      pos.copyTo(pMP->mPosGBA);
-      pMP->mBAGlobalForKF = nLoopKF;
+  // every keyframe has its new pose: the per-point write-back (SetWorldPos + UpdateNormalAndDepth, 150 000 mutex-taking calls after a merge of four
+  // agents) is independent from point to point
+  parallel_chunks(vpMP.size(), shim_threads(vpMP.size(), 32), [&](int, size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) {
+      if (vbNotIncludedMP[i]) continue;
+      const mpptr& pMP = vpMP[i];
+      if (pMP->isBad()) continue;
+      cv::Mat pos = f.pointPos(pMP->mUniqueId);
+      if (nLoopKF == zeropair) {
+        pMP->SetWorldPos(pos, true);
+        pMP->UpdateNormalAndDepth();
+      } else {
+        pMP->mPosGBA.create(3, 1, CV_32F);
+        pos.copyTo(pMP->mPosGBA);
+        pMP->mBAGlobalForKF = nLoopKF;
+      }
     }
-  }
+  });
   pc.lap(6);
+  { FlatBA released; std::swap(f, released); }
+  pc.lap(9);
 }
 
 // Optimizer.cpp:861-1056
@@ -783,4 +867,4 @@ void Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap, kfptr pLoopKF, kfpt
 }  // namespace cslam
 
 // phases (ms) of the last LocalBundleAdjustmentClient / MapFusionGBA call of the calling thread, see g_phase above
-extern "C" void ccm_shim_last_phases(double* out8) { for (int i = 0; i < 8; i++) out8[i] = cslam::g_phase[i]; }
+extern "C" void ccm_shim_last_phases(double* out10) { for (int i = 0; i < 10; i++) out10[i] = cslam::g_phase[i]; }

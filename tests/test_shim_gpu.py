@@ -167,3 +167,47 @@ def test_essential_graph_optimisation_shim_equals_reference(map_fusion):
     assert np.abs(r["kf_Tcw"] - s["kf_Tcw"]).max() < 2e-4, np.abs(r["kf_Tcw"] - s["kf_Tcw"]).max()
     assert np.abs(r["mp_pos"] - s["mp_pos"]).max() < 1e-3, np.abs(r["mp_pos"] - s["mp_pos"]).max()
     assert np.array_equal(r["kf_Tcw"][loop], s["kf_Tcw"][loop])
+
+
+def test_map_fusion_gba_through_the_shim_at_baseline_scale_is_lossless():
+    """BASELINE config 4 (2000 keyframes, 150 000 map points, 0.95 M observations) as a Map / KeyFrame / MapPoint graph, Optimizer::MapFusionGBA(…, 20)
+    through shim/Optimizer_hip.cpp: what the call leaves in the map must be EXACTLY the f32 image (Converter::toCvMat) of what the flat C ABI computes
+    on the flat problem that the reference's accessors describe (f32 poses through Converter::toSE3Quat, f32 points widened, mvInvLevelSigma2 of the
+    observation's octave) — i.e. the threaded graph walk, the flatten and the threaded write-back lose nothing and reorder nothing that matters.
+    The reference's own Optimizer.cpp needs ~25 s per LM iteration on this map (bench.py's cpu_baseline), so it is compared at 30 keyframes above."""
+    import ctypes as C
+    from ccm_slam_amd import optimizer
+    from ccm_slam_amd._lib import Context
+    prob = synth.make_ba_config("gba_c4")
+    flat = mg.flat_from_ba_problem(prob, n_agents=4)
+    g = mg.MapGraph(mg.SHIM_LIB, flat)
+    assert g.map_fusion_gba(0, 20) == 0
+    ph = (C.c_double * 10)()
+    g.lib.ccm_shim_last_phases(ph)
+    st = g.state()
+    g.close()
+    assert 0 < ph[2] and 0 < ph[3] and ph[7] >= ph[2] + ph[3]                     # create and run were clocked inside the call
+    to_q, to_T = mg.converter(mg.SHIM_LIB)
+    n_kf, n_mp = flat["n_kf"], flat["n_mp"]
+    cam_qt = np.stack([to_q(flat["kf_Tcw"][k]) for k in range(n_kf)])
+    sf = np.ones(mg.N_LEVELS, np.float32)
+    for i in range(1, mg.N_LEVELS):
+        sf[i] = sf[i - 1] * mg.SCALE
+    inv_sigma2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)                  # ORBextractor.cpp:586-597 in f32
+    o_kf, o_mp, o_kp = flat["obs_kf"], flat["obs_mp"], flat["obs_kp"]
+    slot = flat["kp_off"][o_kf] + o_kp
+    keep = np.bincount(o_mp, minlength=n_mp)[o_mp] >= 2                           # Optimizer.cpp:738-741: points with fewer than two observations stay out
+    K = np.tile(flat["K4"].astype(np.float64), (n_kf, 1))
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1                                # mvpKeyFrameOrigins[0]
+    prob2 = dict(n_cam=n_kf, n_pt=n_mp, n_edge=int(keep.sum()), cam_qt=cam_qt, cam_fixed=fixed, cam_K=K, pt_xyz=flat["mp_pos"].astype(np.float64),
+                 e_cam=o_kf[keep].astype(np.int32), e_pt=o_mp[keep].astype(np.int32), e_obs=flat["kp_xy"][slot[keep]].astype(np.float64),
+                 e_info=inv_sigma2[flat["kp_oct"][slot[keep]]].astype(np.float64), e_level=None, huber_delta=float(np.float32(np.sqrt(5.99))))   # const float thHuber2D = sqrt(5.99)
+    ctx = Context(0)
+    cam, pts, _, _, stats = optimizer.bundle_adjustment(ctx, prob2, 20)
+    ctx.close()
+    assert stats.iters_done >= 8 and stats.stop_reason == 3                       # ended by chi2 stagnation like the run of tests/golden/gba_c4_full.npz
+    T = np.stack([to_T(cam[k]) for k in range(n_kf)])
+    assert np.array_equal(T, st["kf_Tcw"])
+    seen = np.bincount(o_mp[keep], minlength=n_mp) > 0
+    assert np.array_equal(pts[seen].astype(np.float32), st["mp_pos"][seen])
+    assert np.array_equal(st["mp_pos"][~seen], flat["mp_pos"][~seen])
