@@ -622,8 +622,12 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
 // block-CSR rows, factors it (Cholesky in LDS), forms the explicit inverse W = L^-T L^-1 and stores it; per
 // PCG iteration the same workgroup applies z_c = W r_c (dense 96x96 mat-vec).
 
-// cluster part of the coarse restriction P^T r (6 values): the 6 products of every (camera, component) go through LDS
-// and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
+// weight of camera slot k towards the SECOND node of its interval (the first one gets 1 - t): the coarse space interpolates the rigid-body twists of
+// nodes placed every kAgg cameras linearly in the camera index (hat functions)
+__device__ __forceinline__ double coarse_hat_t(int k) { return ((double)(k % kAgg) + 0.5) * (1.0 / (double)kAgg); }
+
+// cluster part of the coarse restriction P^T r: 6 values for the first node of the cluster's interval, 6 for the second.  The 6 products of every
+// (camera, component) go through LDS and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
 __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m, const double* rc, double* prod) {
   const int t = threadIdx.x;
   if (t < m) {
@@ -633,10 +637,11 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
     for (int cc = 0; cc < 6; cc++) prod[t * 6 + cc] = P[cc] * rv;
   }
   __syncthreads();
-  if (t < 6) {
+  if (t < 12) {
+    const int cc = t % 6, second = t / 6;
     double sv = 0;
-    for (int q = 0; q < m; q++) sv += prod[q * 6 + t];
-    d.mk_cpart[6 * (size_t)c + t] = sv;
+    for (int q = 0; q < m; q++) { const double w1 = coarse_hat_t(s0 + q / 6); sv += (second ? w1 : 1.0 - w1) * prod[q * 6 + cc]; }
+    d.mk_cpart[12 * (size_t)c + t] = sv;
   }
 }
 
@@ -819,67 +824,80 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 }
 
 // Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per cluster after ba_pcg_init_tiles / ba_pcg_update:
-// rc = P^T r summed per aggregate (two clusters), y = Ac^-1[aggregate rows] rc (each cluster recomputes the 6 values of its
-// aggregate: 6 x Nc multiply-adds, cheaper than another grid-wide step), z += P y for the cluster's cameras, and the
-// coarse part of r.z = rc_agg . y_agg, counted by the first cluster of every aggregate.
+// rc = P^T r per coarse node (the second-node parts of the previous interval's two clusters + the first-node parts of this interval's),
+// y = Ac^-1[rows of the two nodes of the cluster's interval] rc (each cluster recomputes these 12 values: 12 x Nc multiply-adds, cheaper than another
+// grid-wide step), z += P (w0 y_a + w1 y_a+1) for the cluster's cameras, and the coarse part of r.z = rc . y, every node counted once (by the first
+// cluster of its interval; the last node by the first cluster of the last interval).
 __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
-  extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * na]
-  __shared__ double ys[8];
+  extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * (na + 1)]
+  __shared__ double ys[12];
   if (d.pcg_flag[0]) return;
   const int t = threadIdx.x, c = blockIdx.x;
   const int lane = t & (kWave - 1), wv = t / kWave;
-  const int nca = 6 * d.mk_na, n_clu = d.n_wg_upd;
+  const int nca = 6 * (d.mk_na + 1), n_clu = d.n_wg_upd;
   for (int e = t; e < nca; e += kTPB) {
-    const int a = e / 6, cc = e % 6;
-    double v = d.mk_cpart[6 * (size_t)(2 * a) + cc];
-    if (2 * a + 1 < n_clu) v += d.mk_cpart[6 * (size_t)(2 * a + 1) + cc];
+    const int n = e / 6, cc = e % 6;
+    double v = 0;
+    if (n < d.mk_na) {
+      v += d.mk_cpart[12 * (size_t)(2 * n) + cc];
+      if (2 * n + 1 < n_clu) v += d.mk_cpart[12 * (size_t)(2 * n + 1) + cc];
+    }
+    if (n >= 1) {
+      v += d.mk_cpart[12 * (size_t)(2 * n - 2) + 6 + cc];
+      if (2 * n - 1 < n_clu) v += d.mk_cpart[12 * (size_t)(2 * n - 1) + 6 + cc];
+    }
     rcs[e] = v;
   }
   __syncthreads();
   const int agg = c >> 1;
   {
-    // y = Ac^-1[6 rows of the aggregate] rc: every thread takes a strided slice of all six rows with its loads in flight together, then wave
-    // trees and the four wave sums in order.  (One wave per row with one load in flight per lane: 30 serial L2 round trips per row, 22 us per
-    // launch on the 10 000-keyframe map, 1 878 coarse unknowns.)
-    __shared__ double yred[6][kTPB / kWave];
-    double a6[6] = {0, 0, 0, 0, 0, 0};
+    // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows with its loads in flight together, then wave
+    // trees and the four wave sums in order.
+    __shared__ double yred[12][kTPB / kWave];
+    double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double* ar = d.mk_Ainv + (size_t)(6 * agg) * d.mk_Nc;
     for (int jj = t; jj < nca; jj += kTPB) {
       const double rv = rcs[jj];
 #pragma unroll
-      for (int rr = 0; rr < 6; rr++) a6[rr] += ar[(size_t)rr * d.mk_Nc + jj] * rv;
+      for (int rr = 0; rr < 12; rr++) a12[rr] += ar[(size_t)rr * d.mk_Nc + jj] * rv;
     }
 #pragma unroll
-    for (int rr = 0; rr < 6; rr++) { const double w = wave_sum(a6[rr]); if (lane == 0) yred[rr][wv] = w; }
+    for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
     __syncthreads();
-    if (t < 6) ys[t] = ((yred[t][0] + yred[t][1]) + yred[t][2]) + yred[t][3];
+    if (t < 12) ys[t] = ((yred[t][0] + yred[t][1]) + yred[t][2]) + yred[t][3];
   }
   __syncthreads();
   const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
   const int m = 6 * (s1 - s0);
   if (t < m) {
     const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
+    const double w1 = coarse_hat_t(s0 + t / 6), w0 = 1.0 - w1;
     double zc = 0;
 #pragma unroll
-    for (int cc = 0; cc < 6; cc++) zc += P[cc] * ys[cc];
+    for (int cc = 0; cc < 6; cc++) zc += P[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
     d.z[6 * (size_t)s0 + t] += zc;
   }
   if (t == 0) {
     double sv = 0;
-    if ((c & 1) == 0)
+    if ((c & 1) == 0) {
       for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
+      if (agg == d.mk_na - 1) for (int rr = 0; rr < 6; rr++) sv += rcs[6 * (agg + 1) + rr] * ys[6 + rr];
+    }
     d.mk_cry[par][c] = sv;
   }
 }
 
 // ---- coarse level of the two-level preconditioner ------------------------------------------------------------------
 // Cluster block-Jacobi cannot see the smooth error modes of a long trajectory (rigid drifts of whole map sections), so the
-// CG iteration count grows with the map.  Coarse space: one rigid-body twist (6 unknowns) per aggregate of kAgg
-// consecutive cameras, prolongated to camera k by the adjoint P_k = Ad(T_cw,k) (a world-frame twist xi moves camera k by
-// the left perturbation Ad(T_cw) xi).  Ac = P^T (S + lambda I) P is dense and small (6 * Cp / kAgg unknowns, 375 for the
-// 4-agent map); its explicit inverse is formed once per LM trial by the tile kernels of dense_chol.hip and the persistent
-// PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Offline study on 600-keyframe systems (same matrices): 296 -> 75 CG
-// iterations at lambda 0.3, 69 -> 38 at lambda 30, independent of the map size.
+// CG iteration count grows with the map.  Coarse space: one rigid-body twist (6 unknowns) per NODE, nodes placed every kAgg
+// consecutive cameras, interpolated LINEARLY in the camera index between the two nodes of a camera's interval (hat functions:
+// camera k of interval a takes (1 - t) xi_a + t xi_a+1, t = (k % kAgg + 1/2) / kAgg) and prolongated to camera k by the adjoint
+// P_k = Ad(T_cw,k) (a world-frame twist xi moves camera k by the left perturbation Ad(T_cw) xi).  Ac = P^T (S + lambda I) P is dense and
+// small (6 (Cp / kAgg + 1) unknowns, 384 for the 4-agent map); its explicit inverse is formed by the tile kernels of dense_chol.hip and the
+// persistent PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Round 2 used piecewise-CONSTANT twists per aggregate (same size of Ac); offline
+// on a 1000-keyframe 4-agent system (same matrices, CG to 1e-8): cluster-Jacobi alone 357 iterations at lambda 0.3, + constant aggregates 136,
+// + hats 82 (lambda 3: 346 / 116 / 74; lambda 30: 269 / 83 / 59) — a continuous interpolant represents the smooth drift modes that a
+// step function can only follow with its jumps.
 constexpr int kCoarseOnIters = 80, kCoarseOffIters = 35;   // a coarse build (0.38 ms) is worth ~35 CG iterations
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
@@ -907,25 +925,25 @@ __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
     }
 }
 
-// one workgroup (16 waves) per coarse block (a <= a'): Ac_aa' = sum over the S blocks (i in a, j in a') of
-// P_i^T (S_ij [+ lambda I]) P_j; an off-diagonal S block inside one aggregate also contributes its transpose.  The work is
-// pure latency (entry -> block index -> cameras -> three 6x6 matrices), so every wave takes kCoarseBatch consecutive
-// entries at a time, stages their matrices in its own LDS slice with coalesced loads (all chains of a batch in flight
-// together) and multiplies out of LDS.  The 16 partial sums are added in a fixed order => deterministic.
+// one workgroup (16 waves) per pair of camera intervals (a <= b) that share S blocks: the four weighted sums
+//   F^pq_ab = sum over the S blocks (i in a, j in b) of w^p_i w^q_j P_i^T (S_ij [+ lambda I]) P_j,   w^0 = 1 - t, w^1 = t,
+// (an off-diagonal S block inside one interval also contributes its transpose, w^q_i w^p_j (...)^T) go to stage[pair][2 p + q]; ba_coarse_sum then
+// adds the up to four F that meet in every pair of coarse NODES (n, n') = (a + p, b + q).  The work is pure latency (entry -> block index -> cameras ->
+// three 6x6 matrices), so every wave takes kCoarseBatch consecutive entries at a time, stages their matrices in its own LDS slice with coalesced loads
+// (all chains of a batch in flight together) and multiplies out of LDS.  The 16 partial sums are added in a fixed order => deterministic.
 constexpr int kCoarseTPB = 1024;
 constexpr int kCoarseBatch = 4;
-__global__ __launch_bounds__(kCoarseTPB) void ba_coarse_assemble(BaDev d, const double* Pm, const int* cb_off, const int* cb_ent, const int* cb_ab, int n_cb,
-                                                                 const int* blk_i, const int* blk_j, double lambda, double* Ac, int Nc) {
+__global__ __launch_bounds__(kCoarseTPB) void ba_coarse_assemble(BaDev d, const double* Pm, const int* cb_off, const int* cb_ent, int n_cb,
+                                                                 const int* blk_i, const int* blk_j, double lambda, double* stage_out /* [n_cb][4][36] */) {
   constexpr int kNW = kCoarseTPB / kWave;
   __shared__ double stage[kNW][kCoarseBatch][3][36];   // [S block | P_i | P_j]
-  __shared__ double part[kNW][36];
+  __shared__ double part[kNW][4][36];
   const int w = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-  const int a = cb_ab[2 * w], b = cb_ab[2 * w + 1];
   const bool el = lane < 36;
   const int r = el ? lane / 6 : 0, c = el ? lane % 6 : 0;
   const int end = cb_off[w + 1];
-  double acc = 0;
+  double acc[4] = {0, 0, 0, 0};
   for (int s0 = cb_off[w] + wv * kCoarseBatch; s0 < end; s0 += kNW * kCoarseBatch) {
     int code[kCoarseBatch], ci[kCoarseBatch], cj[kCoarseBatch];
 #pragma unroll
@@ -964,23 +982,56 @@ __global__ __launch_bounds__(kCoarseTPB) void ba_coarse_assemble(BaDev d, const 
         m += tq * Pj[q * 6 + c];
       }
       const double mt = __shfl(m, c * 6 + r, kWave);
-      acc += (code[u] & 1) ? (m + mt) : m;
+      const double ti = coarse_hat_t(ci[u]), tj = coarse_hat_t(cj[u]);
+      const double wi[2] = {1.0 - ti, ti}, wj[2] = {1.0 - tj, tj};
+      const bool both = (code[u] & 1) != 0;   // off-diagonal S block inside one interval: its mirror image belongs to the same pair
+#pragma unroll
+      for (int pq = 0; pq < 4; pq++) {
+        const int p = pq >> 1, q = pq & 1;
+        double v = (wi[p] * wj[q]) * m;
+        if (both) v += (wi[q] * wj[p]) * mt;
+        acc[pq] += v;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (el) part[wv][lane] = acc;
+  if (el) {
+#pragma unroll
+    for (int pq = 0; pq < 4; pq++) part[wv][pq][lane] = acc[pq];
+  }
   __syncthreads();
-  if (wv == 0 && el) {
+  if (threadIdx.x < 4 * 36) {
+    const int pq = threadIdx.x / 36, e = threadIdx.x % 36;
     double tot = 0;
 #pragma unroll
-    for (int k = 0; k < kNW; k++) tot += part[k][lane];
-    Ac[(size_t)(6 * a + r) * Nc + 6 * b + c] = tot;
-    if (a != b) Ac[(size_t)(6 * b + c) * Nc + 6 * a + r] = tot;
+    for (int k = 0; k < kNW; k++) tot += part[k][pq][e];
+    stage_out[((size_t)w * 4 + pq) * 36 + e] = tot;
   }
 }
-__global__ void ba_coarse_pad(double* Ac, int nc, int Nc) {
-  const int i = nc + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < Nc) Ac[(size_t)i * Nc + i] = 1.0;
+
+// Ac[n][n'] (6x6, all node pairs; identity on the padding up to Nc) = sum over p, q of F^pq of the interval pair (n - p, n' - q); a pair stored as
+// (b, a) with b < a is read transposed with p and q exchanged.  cb_key: the sorted keys a * na + b of the interval pairs that exist.
+__global__ void ba_coarse_sum(const double* stage, const unsigned* cb_key, int n_cb, int na, int nn, double* Ac, int Nc) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Nc * Nc) return;
+  const int row = (int)(idx / Nc), col = (int)(idx % Nc);
+  if (row >= 6 * nn || col >= 6 * nn) { Ac[idx] = (row == col) ? 1.0 : 0.0; return; }
+  int n = row / 6, r = row % 6, n2 = col / 6, c = col % 6;
+  if (row > col) { int tmp = n; n = n2; n2 = tmp; tmp = r; r = c; c = tmp; }   // the mirror element runs the SAME additions in the same order: Ac is bit-symmetric
+  double sum = 0;
+#pragma unroll
+  for (int pq = 0; pq < 4; pq++) {
+    const int p = pq >> 1, q = pq & 1;
+    int a = n - p, b = n2 - q;
+    if (a < 0 || b < 0 || a >= na || b >= na) continue;
+    int sel = 2 * p + q, e = r * 6 + c;
+    if (a > b) { const int tmp = a; a = b; b = tmp; sel = 2 * q + p; e = c * 6 + r; }
+    const unsigned key = (unsigned)a * (unsigned)na + (unsigned)b;
+    int lo = 0, hi = n_cb;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cb_key[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < n_cb && cb_key[lo] == key) sum += stage[((size_t)lo * 4 + sel) * 36 + e];
+  }
+  Ac[idx] = sum;
 }
 
 // ---- persistent PCG: the WHOLE solve of one LM trial in one launch of co-resident workgroups -------------------
@@ -1019,8 +1070,8 @@ struct PersArgs {
   const int* loc;       // [n_row_entries] position of the entry's column in its cluster's ucol list
   long long* dbg;       // optional [16] phase clocks of workgroup 0 (wall_clock64 ticks, 10 ns), accumulated over iterations
   // coarse level (nullptr = cluster-Jacobi only): explicit inverse [Nc x Nc], prolongation blocks [Cp][36], aggregates
-  const double* Ainv; const double* Pm; int na, Nc;
-  double* cparts;              // [6][grid]: the units' parts of the coarse restriction P^T q, component-major; exchanged like p, q and z
+  const double* Ainv; const double* Pm; int na, Nc;   // na camera intervals, na + 1 coarse nodes
+  double* cparts;              // [12][grid]: the units' parts of the coarse restriction P^T q (6 for the first node of the unit's interval, 6 for the second), component-major; exchanged like p, q and z
 };
 
 // a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double in the PCG loop)
@@ -1506,7 +1557,8 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
   pers_factor_cluster(A, Li, ibuf, a.cij, a.cblk, has ? a.coff[c] : 0, has ? a.coff[c + 1] : 0, d.S, s0, s1, lambda, has, tacc, timing);
   // keep only the unit's own 48 rows of W, transposed (WT[col][row]: conflict-free for the mat-vec); the other half of the
-  // A region then holds the coarse level: Ac^-1 rows of the unit's aggregate | coarse residual | gathered unit parts | own P_k
+  // A region then holds the coarse level: Ac^-1 rows of the two nodes of the unit's interval (as f32: it is only a preconditioner, and 12 rows in f64
+  // would not fit) | coarse residual | own P_k | y of the two nodes
   {
     double wreg[5];
     int nw = 0;
@@ -1516,14 +1568,14 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) A[e] = wreg[nw];
   }
   const bool coarse = a.Ainv != nullptr;
-  const int Nc = a.Nc, nca = 6 * a.na;
-  double* ainv_l = A + N * (N / 2);          // [6][Nc]
-  double* rco = ainv_l + 6 * Nc;             // [Nc]
+  const int Nc = a.Nc, nca = 6 * (a.na + 1);
+  float* ainv_l = reinterpret_cast<float*>(A + N * (N / 2));   // [12][Nc] f32
+  double* rco = A + N * (N / 2) + 6 * Nc;    // [Nc]
   double* pown = rco + Nc;                   // [8][36]
-  double* ypart = pown + 8 * 36;             // [6]
-  const int agg = u / kAggUnits;             // aggregate of the unit's cameras (kAgg is a multiple of the 8 cameras of a unit)
+  double* ypart = pown + 8 * 36;             // [12]
+  const int agg = u / kAggUnits;             // interval of the unit's cameras (kAgg is a multiple of the 8 cameras of a unit): nodes agg and agg + 1
   if (coarse) {
-    for (int e = t; e < 6 * Nc; e += kPersTPB) ainv_l[e] = has ? a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0;
+    for (int e = t; e < 12 * Nc; e += kPersTPB) ainv_l[e] = has ? (float)a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0f;
     for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;
     for (int e = t; e < 8 * 36; e += kPersTPB) pown[e] = (e / 36 < nown) ? a.Pm[36 * (size_t)o0 + e] : 0.0;
   }
@@ -1534,7 +1586,8 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   // optimiser, refreshed at the top of every iteration: the indices are recomputed (a few integer ops) instead.
   int tq = t, lq = lane;
   // unit part of the coarse restriction P^T v for the own rows: wave 0, lane = (component c, camera k); the 8 camera
-  // terms of a component sit in 8 neighbouring lanes.  Published component-major for the other units.
+  // terms of a component sit in 8 neighbouring lanes; every camera's term goes with weight 1 - t to the first node of the unit's interval and with t
+  // to the second.  Published component-major for the other units.
   auto coarse_restrict = [&](const double* vec /* LDS, own 48 entries */) {
     if (wv == 0) {
       const int cc = lq >> 3, kk = lq & 7;
@@ -1543,19 +1596,27 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 #pragma unroll
         for (int rr = 0; rr < 6; rr++) sv += pown[kk * 36 + rr * 6 + cc] * vec[6 * kk + rr];
       }
-      sv += __shfl_xor(sv, 1, kWave);
-      sv += __shfl_xor(sv, 2, kWave);
-      sv += __shfl_xor(sv, 4, kWave);
-      if (cc < 6 && kk == 0) coh_store(a.cparts + (size_t)cc * nwg + u, sv);
+      const double w1 = coarse_hat_t(8 * u + kk);
+      double s0v = (1.0 - w1) * sv, s1v = w1 * sv;
+      s0v += __shfl_xor(s0v, 1, kWave); s1v += __shfl_xor(s1v, 1, kWave);
+      s0v += __shfl_xor(s0v, 2, kWave); s1v += __shfl_xor(s1v, 2, kWave);
+      s0v += __shfl_xor(s0v, 4, kWave); s1v += __shfl_xor(s1v, 4, kWave);
+      if (cc < 6 && kk == 0) { coh_store(a.cparts + (size_t)cc * nwg + u, s0v); coh_store(a.cparts + (size_t)(6 + cc) * nwg + u, s1v); }
     }
   };
-  // sum of the 4 units' parts of aggregate tq / 6, component tq % 6 (valid after the exchange that follows coarse_restrict)
+  // component tq % 6 of node tq / 6: the first-node parts of the 4 units of interval n plus the second-node parts of the 4 units of interval n - 1
+  // (valid after the exchange that follows coarse_restrict)
   auto coarse_gather = [&]() {
     double sgm = 0;
     if (coarse && tq < nca) {
-      const double* cp = a.cparts + (size_t)(tq % 6) * nwg + kAggUnits * (tq / 6);
+      const int n = tq / 6, cc = tq % 6;
+      const double* c0 = a.cparts + (size_t)cc * nwg + kAggUnits * n;
+      const double* c1 = a.cparts + (size_t)(6 + cc) * nwg + kAggUnits * (n - 1);
 #pragma unroll
-      for (int mm = 0; mm < kAggUnits; mm++) if (kAggUnits * (tq / 6) + mm < nwg) sgm += coh_load(cp + mm);
+      for (int mm = 0; mm < kAggUnits; mm++) {
+        if (n < a.na && kAggUnits * n + mm < nwg) sgm += coh_load(c0 + mm);
+        if (n >= 1 && kAggUnits * (n - 1) + mm < nwg) sgm += coh_load(c1 + mm);
+      }
     }
     return sgm;
   };
@@ -1617,12 +1678,13 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
           for (int col = 0; col < 12; col++) sv += A[(c0 + col) * (N / 2) + row] * rc[c0 + col];
         }
         zpart[prt * (N / 2) + row] = sv;
-      } else if (coarse && wv < 12) {                       // waves 6..11: y[wv - 6] = Ac^-1[aggregate row] . coarse residual
-        const double* ar = ainv_l + (wv - 6) * Nc;
-        double acc = 0;
-        for (int j = lq; j < nca; j += kWave) acc += ar[j] * rco[j];
-        acc = wave_sum(acc);
-        if (lq == 0) ypart[wv - 6] = acc;
+      } else if (coarse && wv < 12) {                       // waves 6..11: y of component wv - 6 of both nodes = Ac^-1[row] . coarse residual
+        const float* ar0 = ainv_l + (wv - 6) * Nc;
+        const float* ar1 = ainv_l + (wv - 6 + 6) * Nc;
+        double acc0 = 0, acc1 = 0;
+        for (int j = lq; j < nca; j += kWave) { const double rv = rco[j]; acc0 += (double)ar0[j] * rv; acc1 += (double)ar1[j] * rv; }
+        acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
+        if (lq == 0) { ypart[wv - 6] = acc0; ypart[wv - 6 + 6] = acc1; }
       }
     }
     __syncthreads();
@@ -1633,8 +1695,9 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       for (int q = 1; q < 8; q++) z += zpart[q * (N / 2) + tq];
       if (coarse) {
         const int kk = tq / 6, rr = tq % 6;
+        const double w1 = coarse_hat_t(8 * u + kk), w0 = 1.0 - w1;
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * ypart[cc];
+        for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * (w0 * ypart[cc] + w1 * ypart[6 + cc]);
       }
       zs[tq] = z;
       coh_store(d.z + 6 * (size_t)o0 + tq, z);
@@ -2291,13 +2354,12 @@ int coarse_build(ccm_ba* ba, double lambda) {
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   ccm_prof_scope ps(ctx, CCM_K_BA_COARSE);
-  const int Nc = ba->coarse_Nc, nc = 6 * ba->coarse_na;
+  const int Nc = ba->coarse_Nc, na = ba->coarse_na, nn = na + 1;
   hipLaunchKernelGGL(ba_coarse_P, dim3(ccm_div_up(d.Cp, kTPB)), dim3(kTPB), 0, ctx->stream, d, ba->cur, ba->d_cP);
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, (size_t)Nc * Nc * sizeof(double), ctx->stream));
   hipLaunchKernelGGL(ba_coarse_assemble, dim3(ba->coarse_ncb), dim3(kCoarseTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
-                     (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
-                     lambda, ba->d_cA, Nc);
-  if (Nc > nc) hipLaunchKernelGGL(ba_coarse_pad, dim3(1), dim3(64), 0, ctx->stream, ba->d_cA, nc, Nc);
+                     (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j, lambda, ba->d_cstage);
+  hipLaunchKernelGGL(ba_coarse_sum, dim3(ccm_div_up((int64_t)Nc * Nc, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)ba->d_cstage, (const unsigned*)ba->d_cb_key,
+                     ba->coarse_ncb, na, nn, ba->d_cA, Nc);
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return ccm_dense_chol_inverse_dev(ctx, ba->d_cA, Nc, ba->d_cLinv, ba->d_cX, ba->d_cAinv, ba->d_cinfo);
 }
@@ -2438,7 +2500,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (!ba->d_pers_coff) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba: cluster entry lists missing");
         hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
                            (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
-        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)d.mk_na * sizeof(double), ctx->stream, d, 0);
+        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, 0);
       }
       const int chunk = 24;
       int k = 0;
@@ -2452,7 +2514,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
             hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)d.mk_na * sizeof(double), ctx->stream, d, (k + 1) & 1);
+            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
@@ -2519,9 +2581,9 @@ extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* A
   if (!ba || !na) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
-  *na = ba->coarse_na;
+  *na = ba->coarse_na;   // camera intervals; the coarse system has na + 1 nodes of 6 unknowns
   if (!ba->coarse_na || !Ac) return CCM_OK;
-  const size_t nc = 6 * (size_t)ba->coarse_na, Nc = (size_t)ba->coarse_Nc;
+  const size_t nc = 6 * ((size_t)ba->coarse_na + 1), Nc = (size_t)ba->coarse_Nc;
   if (cap < nc * nc) return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_debug_coarse: buffer too small");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   RC(build_system(ba));
@@ -2534,10 +2596,8 @@ extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* A
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(buf.data(), ba->d_cAinv, buf.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (Ainv) for (size_t r = 0; r < nc; r++) for (size_t c = 0; c < nc; c++) Ainv[r * nc + c] = buf[r * Nc + c];
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_cA, 0, Nc * Nc * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(ba_coarse_assemble, dim3(ba->coarse_ncb), dim3(kCoarseTPB), 0, ctx->stream, d, (const double*)ba->d_cP,
-                     (const int*)ba->d_cb_off, (const int*)ba->d_cb_ent, (const int*)ba->d_cb_ab, ba->coarse_ncb, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j,
-                     lambda, ba->d_cA, (int)Nc);
+  hipLaunchKernelGGL(ba_coarse_sum, dim3(ccm_div_up((int64_t)Nc * Nc, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)ba->d_cstage, (const unsigned*)ba->d_cb_key,
+                     ba->coarse_ncb, ba->coarse_na, ba->coarse_na + 1, ba->d_cA, (int)Nc);
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(buf.data(), ba->d_cA, buf.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (size_t r = 0; r < nc; r++) for (size_t c = 0; c < nc; c++) Ac[r * nc + c] = buf[r * Nc + c];

@@ -664,7 +664,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (ba->n_inst) hipLaunchKernelGGL(bb_inst_rank, dim3(grid_for(ba->n_inst)), dim3(kB), 0, st, (const int*)d_inst_a, (const int*)p_rank, (int)ba->n_inst, p_al);
     d.inst_al = p_al;
     // ---- coarse level: block lists of Ac = P^T S P by aggregate pair ----
-    const int na = ccm_div_up(std::max(Cp, 1), kAgg), ncoarse = 6 * na, Nc = ((ncoarse + 63) / 64) * 64;
+    const int na = ccm_div_up(std::max(Cp, 1), kAgg), ncoarse = 6 * (na + 1), Nc = ((ncoarse + 63) / 64) * 64;   // na camera intervals, na + 1 coarse nodes
     const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && 7 * (size_t)Nc + 6 * (size_t)pers_grid_want + 320 <= (size_t)kCluN * kCluN / 2 &&
                              kAggUnits * na <= pers_grid_want + kAggUnits - 1;
     const bool coarse_mk = pers_wanted && !getenv("CCM_BA_NO_COARSE") && kAgg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
@@ -685,6 +685,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       BB_HIP(rocprim::run_length_encode(scratch, bytes, ck_s, (unsigned)nk, uq, cnts, n_runs, st));
       const size_t max_runs = std::min<size_t>(nk, (size_t)na * (na + 1) / 2);
       BB_RC(keep_get(ba, max_runs + 1, &ba->d_cb_off)); BB_RC(keep_get(ba, 2 * max_runs, &ba->d_cb_ab));
+      BB_RC(keep_get(ba, max_runs, &ba->d_cb_key)); BB_RC(keep_get(ba, max_runs * 4 * 36, &ba->d_cstage));
+      BB_HIP(hipMemcpyAsync(ba->d_cb_key, uq, max_runs * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
       hipLaunchKernelGGL(bb_counts_tail, dim3(1), dim3(1), 0, st, cnts, (const int*)n_runs);
       BB_RC(scan_excl(ctx, tmp, (const int*)cnts, ba->d_cb_off, max_runs + 1));
       hipLaunchKernelGGL(bb_coarse_ab, dim3(grid_for((int64_t)max_runs)), dim3(kB), 0, st, (const unsigned*)uq, (const int*)n_runs, na, ba->d_cb_ab, sz);
@@ -763,7 +765,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cA, true)); BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cX, true));
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv, true)); BB_RC(keep_get(ba, (size_t)Nc * 64, &ba->d_cLinv, true));
       BB_RC(keep_get(ba, 4, &ba->d_cinfo, true));
-      BB_RC(keep_get(ba, 6 * (size_t)std::max(n_units, 1), &ba->d_cparts, true));
+      BB_RC(keep_get(ba, 12 * (size_t)std::max(n_units, 1), &ba->d_cparts, true));
       ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = hs.ncb;
       if (const char* cr = getenv("CCM_BA_COARSE_REUSE")) ba->coarse_reuse = atoi(cr) != 0;
       if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
@@ -784,7 +786,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (!ba->pers_grid && coarse_mk) {
       BB_RC(coarse_buffers(0));
       double *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
-      BB_RC(keep_get(ba, 6 * (size_t)n_cl, &p1, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p2, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p3, true));
+      BB_RC(keep_get(ba, 12 * (size_t)n_cl, &p1, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p2, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p3, true));
       d.mk_cpart = p1; d.mk_cry[0] = p2; d.mk_cry[1] = p3;
       d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
     }

@@ -137,6 +137,8 @@ struct ccm_ba {
   int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
   double* d_cparts = nullptr;
+  unsigned* d_cb_key = nullptr;   // [ncb] sorted keys a * na + b of the interval pairs that share S blocks
+  double* d_cstage = nullptr;     // [ncb][4][36] weighted sums of every interval pair (ba_coarse_assemble -> ba_coarse_sum)
   int *d_cb_off = nullptr, *d_cb_ent = nullptr, *d_cb_ab = nullptr, *d_blk_i = nullptr, *d_blk_j = nullptr, *d_cinfo = nullptr;
   double* d_pt_full = nullptr;
   double* d_hpp_full = nullptr;

@@ -121,12 +121,12 @@ class BAHandle:
         return out
 
     def coarse_level(self, lam: float):
-        """Test hook (ccm_ba_debug_coarse): (na, Ac, Ainv, P) of the two-level preconditioner, or (0, None, None, None)."""
+        """Test hook (ccm_ba_debug_coarse): (na camera intervals, Ac, Ainv over the na + 1 coarse nodes, P) of the two-level preconditioner, or (0, None, None, None)."""
         na = C.c_int(0)
         check(lib().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), None, None, None, C.c_size_t(0)), self.ctx.handle)
         if na.value == 0:
             return 0, None, None, None
-        nc = 6 * na.value
+        nc = 6 * (na.value + 1)
         Ac = np.zeros((nc, nc)); Ai = np.zeros((nc, nc)); P = np.zeros((self.counts()["free_cams"], 6, 6))
         check(lib().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), C.c_void_p(_vp(Ac)), C.c_void_p(_vp(Ai)), C.c_void_p(_vp(P)),
                                         C.c_size_t(Ac.size)), self.ctx.handle)
