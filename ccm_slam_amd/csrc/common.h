@@ -61,8 +61,8 @@ enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TIL
 
 // RAII-ish bracket used around a kernel launch when profiling of its class is enabled.
 struct ccm_prof_scope {
-  ccm_ctx* ctx; int cls; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
-  ccm_prof_scope(ccm_ctx* c, int k);
+  ccm_ctx* ctx; int cls; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool on = false;
+  ccm_prof_scope(ccm_ctx* c, int k, hipStream_t launch_stream = nullptr);   // nullptr: the context's stream
   ~ccm_prof_scope();
 };
 

@@ -135,15 +135,15 @@ static hipEvent_t take_event(ccm_ctx* ctx) {
   return e;
 }
 
-ccm_prof_scope::ccm_prof_scope(ccm_ctx* c, int k) : ctx(c), cls(k) {
+ccm_prof_scope::ccm_prof_scope(ccm_ctx* c, int k, hipStream_t launch_stream) : ctx(c), cls(k), st(launch_stream ? launch_stream : (c ? c->stream : nullptr)) {
   on = c && (c->prof_class == -1 || c->prof_class == k);
   if (!on) return;
   e0 = take_event(ctx); e1 = take_event(ctx);
-  hipEventRecord(e0, ctx->stream);
+  hipEventRecord(e0, st);   // on the stream the bracketed kernels are launched on (the ORB batch path alternates between two)
 }
 ccm_prof_scope::~ccm_prof_scope() {
   if (!on) return;
-  hipEventRecord(e1, ctx->stream);
+  hipEventRecord(e1, st);
   ctx->prof[cls].pending.emplace_back(e0, e1);
 }
 

@@ -437,7 +437,11 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
         kp0 = i0 - (e0 & 0xFFF); kp1 = i1 - (e1 & 0xFFF);
         __syncthreads();
       } else {
-        // 3b. final phase: processing order = descending (size, creation index); the pass stops with the node that takes the list to N
+        // 3b. final phase: processing order = descending (size, creation index); the pass stops with the node that takes the list to N.
+        // ASSUMPTION behind the tie-break: the reference sorts pair<int, ExtractorNode*> (ORBextractor.cpp:852), i.e. nodes with equally many keypoints
+        // by HEAP ADDRESS, which equals creation order only while list nodes are allocated at growing addresses (true under the monotonic
+        // operator new of oracle/_ref/orb_ref_cli, not guaranteed by glibc malloc: DESIGN 2, "The reference is not deterministic").  The oracle and
+        // this kernel DEFINE the tie as creation order.
         if (i0 < Ls) prank[i0] = -1;
         if (i1 < Ls) prank[i1] = -1;
         __syncthreads();
@@ -1054,17 +1058,17 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
   const OrbDev& d = o->dev;
   for (int l = 1; l < o->nlevels; l++) {
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
-    ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE);
+    ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
     hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.off, P.w, P.h, P.stride,
                        o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
   {
-    ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
+    ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE, o->st);
     hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
   }
   {
-    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
+    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
     hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
     hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
                        (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
@@ -1075,7 +1079,7 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
     CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, o->st));
   }
   {
-    ccm_prof_scope ps(ctx, CCM_K_BLUR);
+    ccm_prof_scope ps(ctx, CCM_K_BLUR, o->st);
     hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
@@ -1197,7 +1201,7 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap) {
   a.kin = b.d_kin; a.n_out = b.d_n; a.kp_cap = std::min(o->kp_cap, out_cap);
   a.dbg = o->d_oct_dbg;
   {
-    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS);
+    ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
     if (o->oct_tpb == 512) {   // two list slots per thread: 512 threads hold up to 4 N + 16 = 1024 slots, and a barrier of 8 waves is cheaper than one of 16
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel<512>, 152 * 1024);
       hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(o->nlevels), dim3(512), o->oct_lds, o->st, o->dev, a);
@@ -1207,7 +1211,7 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap) {
     }
   }
   {
-    ccm_prof_scope ps(ctx, CCM_K_BRIEF);
+    ccm_prof_scope ps(ctx, CCM_K_BRIEF, o->st);
     hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, (const int*)b.d_n, b.d_kout, b.d_desc);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());

@@ -2,9 +2,10 @@
 Optimizer::OptimizeEssentialGraph{LoopClosure,MapFusion} hand to g2o (oracle/ba_ref.cpp: ora_pose_graph_optimize).
 
 Tolerance: f64 LM with numerically differentiated 7x7 Jacobians (delta 1e-9 amplifies rounding by 5e8); the linear solve is exact on both
-sides (device: tile-sparse Cholesky over a nested-dissection order; oracle: block Cholesky in natural order), so only rounding differs.  Near convergence the
-accept / reject decision of a trial can depend on differences of that size, so the trial COUNT is not compared; the
-optimised Sim3s must agree to 1e-5 (rotation / scale) and 1e-5 m, the final chi2 to 1e-6 of the initial chi2."""
+sides (device: tile-sparse Cholesky over a nested-dissection order; oracle: block Cholesky in natural order), so only rounding differs.  The LM iteration
+and trial COUNTS are compared up to 2000 keyframes (they agree there); near convergence the accept / reject decision of a trial can depend on differences
+of rounding size, which is what happens at 10 000 keyframes — no count is asserted at that size.  The optimised Sim3s must agree to 1e-5
+(rotation / scale) and 1e-5 m, the final chi2 to 1e-6 of the initial chi2."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,7 @@ def _check(ctx, oracle_lib, pg):
     assert st.chi2_final < 0.2 * st.chi2_initial                       # the loop error was distributed
     assert np.abs(s - so).max() < 1e-5, np.abs(s - so).max()
     assert np.array_equal(s[pg["fixed"] == 1], pg["sim3"][pg["fixed"] == 1])   # fixed vertices untouched, bit for bit
+    assert (st.iters_done, st.lm_trials) == (sto.iters_done, sto.lm_trials)      # same LM path: iterations and trials (sizes up to 2000 keyframes)
     return s, st
 
 
@@ -31,6 +33,14 @@ def test_pose_graph_matches_oracle(ctx, oracle_lib, n_kf, seed, fix_scale):
     s, st = _check(ctx, oracle_lib, pg)
     if fix_scale:
         assert np.array_equal(s[:, 7], pg["sim3"][:, 7])               # update[6] is zeroed: scales never move
+
+
+def test_pose_graph_of_the_bench_workload_matches_oracle(ctx, oracle_lib):
+    """bench.py's essential-graph leg: 2000 keyframes / ~10 000 Sim3 edges (covisibility 6), the map size of BASELINE config 4.  Same LM iterations and
+    trials as the oracle (2 / 11), Sim3s within 1e-5 (measured 4e-6)."""
+    pg = synth.make_pose_graph(2000, 0, covis=6)
+    s, st = _check(ctx, oracle_lib, pg)
+    assert st.iters_done >= 2
 
 
 def test_consistent_graph_is_a_fixed_point(ctx):

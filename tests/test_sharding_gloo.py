@@ -65,3 +65,26 @@ def test_two_rank_partial_systems_allreduce_to_full_system():
         assert err < 1e-10, (rank, err)
         assert same
         assert bounds[0] == 0 and bounds[-1] == 500 and 100 < bounds[1] < 400
+
+
+def test_bench_n_rank_launch_path_up_to_the_first_device_call():
+    """The driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: everything bench.py does BEFORE its first device call
+    (env parsing, gloo rendezvous on 127.0.0.1, broadcast of the 128-byte communicator id from rank 0, barrier, MAX-reduce of the ranks' clocks) runs here
+    with two ranks and no GPU (`--plumbing-only`), so that the driver's scaling run is not the first execution of that branch."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--plumbing-only"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import re
+    lines = [json.loads(m) for m in re.findall(r'\{"plumbing".*?\}', out.stdout)]   # the two ranks share one stdout: their lines may run together
+    assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["world"] == 2 for l in lines)
+    assert lines[0]["id_sha"] == lines[1]["id_sha"] and all(l["max"] == 2.0 for l in lines)
