@@ -399,42 +399,85 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
   if (wv == 0 && lane < 36) d.S[36 * (size_t)(d.Cp + b) + lane] = -(((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]);
 }
 
-// off-diagonal Schur blocks, row-centric: one workgroup per free camera i.  Y_e = W_e Dinv_l (6x3) of ALL observations of
-// camera i is formed once into LDS (the per-block kernel above re-reads W_a and Dinv and redoes the 6x3x3 product for
-// every pair instance: 336 B and 27 flops per instance instead of 152 B and 9), then the waves walk the blocks (i, j > i)
-// of the row and every instance costs one 144-byte W_c row read plus LDS.                [CCM_K_BA_SCHUR_OFF]
-// Two shapes of the same kernel.  <1024, false>: one 16-wave workgroup per CU, unit partial sums in LDS (rows of any length up to
-// kRowMaxEdges).  <512, true>: 8-wave workgroups with the unit partials in a global scratch (d.row_part, L2-resident: written and read back
-// by the same workgroup) so that LDS holds only Y and TWO rows fit a CU: while one row waits on the three dependent load levels of its Y
-// staging or on its final reduction, the other one computes — the kernel is bound by those per-row latencies, not by bytes or flops.
-template <int TPB, bool GPART>
-__global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
+// ---- row Schur kernel: off-diagonal AND diagonal blocks of one camera row per workgroup ------------------------------------------------------------
+// One workgroup (16 waves) per free camera i.  Y_e = W_e D^-1 (6x3) of ALL observations of camera i is formed once into LDS, then every pair instance
+// (observation a of camera i, observation c of camera j > i, same landmark) contributes Y_a W_c^T to S_ij.                  [CCM_K_BA_SCHUR_OFF]
+// Round 2 fed pairs of instances to v_mfma_f64_16x16x4 (14 % of the tile used, 64 cycles of the matrix pipe per pair, two 8-byte gathers per lane and
+// instruction): 223 us on the 4-agent map.  This form gives an instance to a LANE: the lane fetches the whole W_c row (144 B, nine 16-byte loads), reads
+// the Y_a row out of LDS and multiplies on the vector ALUs (108 f64 FMAs).  The sum over the instances of a block is made cheap by giving every work
+// unit (<= kRow2Chunk consecutive instances of one block) only kRow2Group = 16 lanes, each accumulating its instances serially, and by reducing the 36
+// sums of the FOUR units of a wave pass together with one halving butterfly (xor 8, 4, 2, 1: every step exchanges half of the values a lane still
+// holds: 18 + 9 + 5 + 3 exchanges instead of 4 x 36), after which each lane holds <= 3 finished elements.  Summation order: lane-serial, then the fixed
+// tree — deterministic, identical on every rank.
+// The diagonal block needs no pass of its own: the thread that stages Y_e still holds W_e, so it forms Y_e W_e^T (symmetric: 21 entries) and Y_e b_l
+// (6) on the spot; the same butterfly leaves one partial per 16 observations in LDS.
+// Phase clocks (CCM_BA_ROW_DBG, 4-agent map, us per row, 7.8 rows per CU): the kernel is a chain of dependent memory round trips, not of flops or
+// bytes — staging 4.9 (index -> W, D^-1), block passes 6.6 (table entry -> index vectors -> W_c rows), final sums 2.9; a first version with separate
+// own-observation passes spent 10.7 us per row on their four-deep chain (table -> cam_edge -> ed_pt -> b_l).
+template <int N>
+__device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[(N + 1) / 2], bool hi, int mask) {
+  constexpr int H = (N + 1) / 2;   // the lower lanes keep elements [0, H), the upper ones [H, N) (N - H <= H of them, padded with zeros)
+#pragma unroll
+  for (int k = 0; k < H; k++) {
+    const double up = (H + k < N) ? in[H + k] : 0.0;
+    const double keep = hi ? up : in[k];
+    const double send = hi ? in[k] : up;
+    out[k] = keep + __shfl_xor(send, mask, kWave);
+  }
+}
+// element range [*e0, *e0 + *cnt) that a lane holds after the four steps (lane bits q3..q0 of its position inside the group)
+__device__ __forceinline__ void row2_range(int N, int q, int* e0, int* cnt) {
+  int off = 0, cap = N, n = N;   // cap: the (compile-time) array length of the step, n: how many of its entries are real sums (the rest is zero padding)
+#pragma unroll
+  for (int bit = 8; bit >= 1; bit >>= 1) {
+    const int H = (cap + 1) / 2;
+    if (q & bit) { off += H; n = max(0, n - H); } else n = min(n, H);
+    cap = H;
+  }
+  *e0 = off; *cnt = n;
+}
+
+__global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
-  // Workgroup b runs on XCD b % 8.  Every W_c row is read by ~3 block rows, and those are rows of covisible, i.e.
-  // neighbouring, keyframes: with row = blockIdx the neighbours sit on 8 different L2s and each fetches its own copy
-  // (PMC: 0.55-1.1 GB per launch for 137 MB of W — the kernel ran at the fabric's bandwidth, not on latency); here XCD x
-  // walks the contiguous row range [x * per, (x + 1) * per), so rows in flight on one L2 share their W_c rows.
-  const int per_xcd = gridDim.x >> 3;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  constexpr int G = kRow2Group, UPW = kWave / G, NW = kRow2TPB / kWave;
+  const int per_xcd = gridDim.x >> 3;      // workgroup b runs on XCD b % 8: XCD x walks the contiguous row range [x * per, (x + 1) * per) (rows in flight share W_c rows)
   const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (i >= d.Cp) return;
-  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
-  // Y_e = W_e D^-1: one thread per observation, 16-byte loads (9 for W_e, 3 for D^-1: 12 wave-wide loads per 64 observations instead of 54
-  // with one thread per (observation, row)), landmark index per camera slot precomputed (two dependent load levels instead of three).
-  // Measured by switching phases off (gba_c4): this phase 40 -> 23 us of the kernel.  Same expressions, same Y bits.
+  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;   // ne <= kRowMaxEdges < kRow2TPB: one observation per thread
+  long long tk0 = 0;
+  if (d.row_dbg && threadIdx.x == 0) tk0 = wall_clock64();
+#define ROW2_TICK(slot) { if (d.row_dbg && threadIdx.x == 0) { const long long tn_ = wall_clock64(); atomicAdd((unsigned long long*)(d.row_dbg + slot), (unsigned long long)(tn_ - tk0)); tk0 = tn_; } }
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int grp = lane / G, q = lane % G;
+  const int zrow = d.max_cam_edges;        // a zero row of Y behind the real ones: what the idle lanes of a unit multiply
+  const int n_dgrp = (ne + G - 1) / G;     // 16-observation groups of the diagonal partials
+  double* dpart = Ys + 18 * (size_t)(zrow + 1);                           // [ceil(max_cam_edges / 16)][27]
+  double* part = dpart + 27 * (size_t)((d.max_cam_edges + G - 1) / G);    // [row_units_max][36]
+  // the table entry and the index vectors of this wave's first block pass are requested before anything else: their round trips overlap the staging
+  const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
+  int4 te_next = make_int4(0, 0, 0, 0);
+  if (wv * UPW + grp < n_units) te_next = d.unit_tab[u_first + wv * UPW + grp];
+  // ---- Y_e = W_e D^-1 of the camera's observations, one thread per observation; the same thread adds the observation's part of the diagonal block
+  //      (Y_e W_e^T, symmetric: entries r <= c) and of b_schur (Y_e b_l) ----
   {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    for (int t = threadIdx.x; t < ne; t += TPB) {
+    const int t = threadIdx.x;
+    double dacc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) dacc[k] = 0.0;
+    if (t < ne) {
       const int e = d.cam_edge[base + t], pt = d.cam_pt[base + t];
       const v2d* Wp = reinterpret_cast<const v2d*>(d.W + 18 * (size_t)e);
       const v2d* Dp = reinterpret_cast<const v2d*>(d.Dinv + 6 * (size_t)pt);
       v2d w2[9], d2[3];
 #pragma unroll
-      for (int q = 0; q < 9; q++) w2[q] = Wp[q];
+      for (int k = 0; k < 9; k++) w2[k] = Wp[k];
 #pragma unroll
-      for (int q = 0; q < 3; q++) d2[q] = Dp[q];
+      for (int k = 0; k < 3; k++) d2[k] = Dp[k];
+      const double bl0 = d.bl[3 * (size_t)pt], bl1 = d.bl[3 * (size_t)pt + 1], bl2 = d.bl[3 * (size_t)pt + 2];
       double wf[18], yf[18];
 #pragma unroll
-      for (int q = 0; q < 9; q++) { wf[2 * q] = w2[q][0]; wf[2 * q + 1] = w2[q][1]; }
+      for (int k = 0; k < 9; k++) { wf[2 * k] = w2[k][0]; wf[2 * k + 1] = w2[k][1]; }
       const double D0 = d2[0][0], D1 = d2[0][1], D2 = d2[1][0], D3 = d2[1][1], D4 = d2[2][0], D5 = d2[2][1];
 #pragma unroll
       for (int r = 0; r < 6; r++) {
@@ -445,173 +488,110 @@ __global__ __launch_bounds__(TPB, 4) void ba_schur_row_t(BaDev d) {
       }
       v2d* Yp = reinterpret_cast<v2d*>(Ys + 18 * (size_t)t);
 #pragma unroll
-      for (int q = 0; q < 9; q++) { v2d v; v[0] = yf[2 * q]; v[1] = yf[2 * q + 1]; Yp[q] = v; }
+      for (int k = 0; k < 9; k++) { v2d v; v[0] = yf[2 * k]; v[1] = yf[2 * k + 1]; Yp[k] = v; }
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};   // compact index of (r, c), r <= c: kTri[r] + c
+#pragma unroll
+        for (int c = r; c < 6; c++)
+          dacc[kTri[r] + c] = __builtin_fma(yf[3 * r + 2], wf[3 * c + 2], __builtin_fma(yf[3 * r + 1], wf[3 * c + 1], yf[3 * r] * wf[3 * c]));
+        dacc[21 + r] = __builtin_fma(yf[3 * r + 2], bl2, __builtin_fma(yf[3 * r + 1], bl1, yf[3 * r] * bl0));
+      }
+    }
+    if (wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
+      double t1[14], t2[7], t3[4], t4[2];
+      row2_halve<27>(dacc, t1, (q & 8) != 0, 8);
+      row2_halve<14>(t1, t2, (q & 4) != 0, 4);
+      row2_halve<7>(t2, t3, (q & 2) != 0, 2);
+      row2_halve<4>(t3, t4, (q & 1) != 0, 1);
+      int e0, cnt;
+      row2_range(27, q, &e0, &cnt);
+      const int g = threadIdx.x / G;
+      if (g < n_dgrp) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * (size_t)g + e0 + k] = t4[k];
+      }
     }
   }
-  if (threadIdx.x < 18) Ys[d.max_cam_edges * 18 + (GPART ? 0 : d.row_units_max * kRowSlot) + threadIdx.x] = 0.0;   // a whole zero row of Y
+  if (threadIdx.x < 18) Ys[18 * (size_t)zrow + threadIdx.x] = 0.0;
   __syncthreads();
-  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  // One wave per block.  S_ij = -[Y_a1 Y_a2 ...] [W_c1 W_c2 ...]^T is a 6 x 6 product with inner dimension 3 per pair
-  // instance: it goes through v_mfma_f64_16x16x4 with ONE instance per instruction (k = 0..2 the landmark axes, k = 3
-  // zero): A operand = Y (lane (i, k) = (lane & 15, lane >> 4) supplies Y[i][k]), B operand = W_c (lane (j, k) supplies
-  // W_c[j][k]).  Not for the flops — 14% of the tile is used — but for the LOAD count: with lane = output element every
-  // instance cost three 8-byte loads per lane from global and three from LDS, each operand fetched six times over, and
-  // the kernel sat on the CU's address path (330 us; deeper prefetch changed nothing); here every operand element is
-  // fetched once (18 lanes x 8 bytes per instance from each side).  The two index arrays are read 64 instances at a
-  // time, one per lane, and handed out by v_readlane; 8 instances are in flight.  Instance order is kept.
-  typedef double v4d __attribute__((ext_vector_type(4)));
-  // TWO instances per MFMA: the even one in tile rows / columns 0..5, the odd one in 8..13 (they share only the k axis, so
-  // their products land in different 6x6 corners of D and the cross terms are ignored).  Measured: the f64 MFMA costs
-  // 64 cycles of its SIMD and a wave-wide load ~16 cycles of the CU's address path whatever it fetches, so per-instance
-  // instruction count, not bytes or latency, set the kernel's time (286 us with one instance per instruction, 203 us
-  // of it without the MFMA; forcing every W_c read into a 147 KB window changed nothing).
-  const int j = lane & 15, kq = lane >> 4;
-  const int odd = (j >> 3) & 1, jj = j & 7;
-  const bool on = jj < 6 && kq < 3;
-  const int woff = on ? 3 * jj + kq : 0;
-  const unsigned wbyte = 8u * (unsigned)woff;
-  const int u_first = d.row_unit_off[i], u_last = d.row_unit_off[i + 1];
-  double* part = GPART ? d.row_part + kRowSlot * (size_t)u_first : Ys + (size_t)d.max_cam_edges * 18;
-  const int zslot = d.max_cam_edges * 18 + (GPART ? 0 : d.row_units_max * kRowSlot);   // one zero row behind Y (and the partial sums)
-  // Software pipeline over the wave's units: the table entry and the two index vectors of the NEXT unit (two dependent
-  // load levels) are requested before the W_c rows of the current one, so that a unit exposes one memory latency
-  // instead of three (a CU holds one workgroup = 16 waves here: nothing else hides them).
-  // PMC (rocprofv3, scripts/kpmc.sh): 21 VALU + 7 SALU instructions per MFMA (v_readlane pairs, 64-bit selects, two
-  // quarter-rate v_mul_lo_u32 for the x144 / x18 address scaling), VALU 35% and MFMA 23% busy, waves waiting 38% of
-  // their cycles.  So: the index vectors hold BYTE offsets (scaled once per 64 instances), each lane picks the entry of
-  // its own instance (even / odd) with one ds_bpermute per vector (the LDS pipe is idle), and the "switched off" lanes
-  // are handled by an and-mask on the Y offset: ~4 VALU instructions per MFMA.
-  const int pick = odd;                                   // lane's instance inside a pair
-  const unsigned ymask = on ? ~0u : 0u;
-  const unsigned ybyte = on ? 8u * (unsigned)woff : 8u * (unsigned)zslot;
-  const char* Wb = reinterpret_cast<const char*>(d.W);
-  const char* Yb = reinterpret_cast<const char*>(Ys);
-  // A unit is either <= 64 pair instances of an off-diagonal block (table entry: block, first, end) or <= 64 of the
-  // camera's OWN observations (entry: -1, first, end) for the diagonal block: S_ii = Hpp_i - sum_e Y_e W_e^T and
-  // b_schur_i = b_p,i - sum_e Y_e b_l(e) are the same product with c = a = e and the landmark's b_l as a seventh column of
-  // the B operand (lanes j = 6 / 14).  The separate one-wave-per-camera kernel for the diagonal re-read W, D^-1 and the
-  // index chains that this workgroup has just loaded and took 56 us.
-  // The table lists a row's units LONGEST FIRST (slot = the unit's index in block order, where its partial sum goes), so that the 16 waves of
-  // a row, dealt round-robin, carry near-equal instance counts; one 16-byte entry per unit.  (Measured on gba_c4: 223 us either way — the
-  // waves of a row were not waiting for a slowest one.)
-  int u = u_first + wv;
-  int n = 0, ic = 0, ia = 0, il = 0, ublk = 0, uslot = 0;
-  auto load_unit = [&](int uu, int& n_, int& ic_, int& ia_, int& il_, int& blk_, int& slot_) {
-    const int4 te = d.unit_tab[uu];
-    blk_ = te.x;
-    const int s0 = te.y;
-    n_ = te.z - s0;
-    slot_ = te.w;
-    if (blk_ >= 0) {
-      ic_ = (lane < n_) ? 144 * d.inst_c[s0 + lane] : 0;
-      ia_ = (lane < n_) ? 144 * d.inst_al[s0 + lane] : 8 * zslot;   // padding instances multiply the zero row
-      il_ = 0;
-    } else {
-      const int e = (lane < n_) ? d.cam_edge[base + s0 + lane] : 0;
-      ic_ = 144 * e;
-      ia_ = (lane < n_) ? 144 * (s0 + lane) : 8 * zslot;
-      il_ = (lane < n_) ? 24 * d.ed_pt[e] : 0;
-    }
-  };
-  if (u < u_last) load_unit(u, n, ic, ia, il, ublk, uslot);
-  while (u < u_last) {
-    const int un = u + TPB / kWave;
-    int nn = 0, icn = 0, ian = 0, iln = 0, ublkn = 0, uslotn = 0;
-    if (un < u_last) load_unit(un, nn, icn, ian, iln, ublkn, uslotn);
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    int q0 = 0;
-    if (ublk < 0) {   // diagonal unit: lanes j = 6 / 14 feed b_l as the seventh column
-      const char* Lb = reinterpret_cast<const char*>(d.bl);
-      const bool c6 = jj == 6 && kq < 3;
-      const unsigned lbyte = 8u * (unsigned)kq;
-      for (; q0 + 32 <= n; q0 += 32) {
-        double wv8[16], yv8[16];
+  ROW2_TICK(0)
+  // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
+  for (int p = wv; p * UPW < n_units; p += NW) {
+    const int uu = p * UPW + grp;
+    const int4 te = te_next;
+    const int s0 = te.y, s1 = te.z, slot = te.w;
+    if ((p + NW) * UPW + grp < n_units) te_next = d.unit_tab[u_first + (p + NW) * UPW + grp]; else te_next = make_int4(0, 0, 0, 0);
+    double acc[36];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
-          const unsigned lb = (unsigned)__shfl(il, q0 + 2 * q + pick, kWave);
-          const char* src = c6 ? Lb + (lb + lbyte) : Wb + (cb + wbyte);
-          wv8[q] = *reinterpret_cast<const double*>(src);
-          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
-        }
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    // the table lists the units longest first, so group 0 of the pass sets the trip count of the wave
+    const int nit = __builtin_amdgcn_readfirstlane((s1 - s0 + G - 1) / G);
+    int ce_n = (s0 + q < s1) ? d.inst_c[s0 + q] : 0;          // index vectors one iteration ahead of the W_c rows they address
+    int ar_n = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow;
+    for (int it = 0; it < nit; it++) {
+      const int ce = ce_n, ar = ar_n;
+      const int sn = s0 + (it + 1) * G + q;
+      ce_n = (sn < s1) ? d.inst_c[sn] : 0;
+      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
+      const v2d* Wp = reinterpret_cast<const v2d*>(d.W + 18 * (size_t)ce);
+      const double* Yp = Ys + 18 * (size_t)ar;
+      v2d w2[9];
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
-      }
-      for (; q0 < n; q0 += 16) {   // remainder in batches of 8 pairs; instances beyond n read the zero row of Y
-        double wv8[8], yv8[8];
+      for (int k = 0; k < 9; k++) w2[k] = Wp[k];
+      double wf[18];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
-          const unsigned lb = (unsigned)__shfl(il, q0 + 2 * q + pick, kWave);
-          const char* src = c6 ? Lb + (lb + lbyte) : Wb + (cb + wbyte);
-          wv8[q] = *reinterpret_cast<const double*>(src);
-          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
-        }
+      for (int k = 0; k < 9; k++) { wf[2 * k] = w2[k][0]; wf[2 * k + 1] = w2[k][1]; }
 #pragma unroll
-        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
+      for (int r = 0; r < 6; r++) {   // the Y row comes out of LDS three values at a time: 16 waves leave 128 registers per lane
+        const double y0 = Yp[3 * r], y1 = Yp[3 * r + 1], y2 = Yp[3 * r + 2];
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[6 * r + c] = __builtin_fma(y2, wf[3 * c + 2], __builtin_fma(y1, wf[3 * c + 1], __builtin_fma(y0, wf[3 * c], acc[6 * r + c])));   // explicit: the library is built -ffp-contract=off
       }
     }
-    if (ublk >= 0)
-    for (; q0 + 32 <= n; q0 += 32) {
-      double wv8[16], yv8[16];
+    double t1[18], t2[9], t3[5], t4[3];
+    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
+    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
+    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
+    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
+    int e0, cnt;
+    row2_range(36, q, &e0, &cnt);
+    if (uu < n_units) {
+      double* pu = part + 36 * (size_t)slot;
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
-        wv8[q] = *reinterpret_cast<const double*>(Wb + (cb + wbyte));        // switched-off lanes: any finite W times an LDS zero
-        yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
-      }
-#pragma unroll
-      for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
+      for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
     }
-    if (ublk >= 0)
-      for (; q0 < n; q0 += 16) {   // remainder in batches of 8 pairs; instances beyond n read the zero row of Y
-        double wv8[8], yv8[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const unsigned cb = (unsigned)__shfl(ic, q0 + 2 * q + pick, kWave), ab = (unsigned)__shfl(ia, q0 + 2 * q + pick, kWave);
-          wv8[q] = *reinterpret_cast<const double*>(Wb + (cb + wbyte));
-          yv8[q] = *reinterpret_cast<const double*>(Yb + ((ab & ymask) + ybyte));
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yv8[q], wv8[q], acc, 0, 0, 0);
-      }
-    // D register r of lane (j, kq) is D[kq + 4 r][j]: even instances in D[0..5][0..5] (r = 0, 1; j < 6), odd ones in
-    // D[8..13][8..13] (r = 2, 3; j = 8..13) -> added to the even sum of lane j - 8
-    const double b0 = __shfl_down(acc[2], 8, kWave), b1 = __shfl_down(acc[3], 8, kWave);
-    double* pu = part + kRowSlot * (size_t)uslot;
-    if (j < 6) {
-      pu[kq * 6 + j] = acc[0] + b0;
-      if (kq < 2) pu[(kq + 4) * 6 + j] = acc[1] + b1;
-    } else if (j == 6 && ublk < 0) {   // seventh column: the b_schur part
-      pu[36 + kq] = acc[0] + b0;
-      if (kq < 2) pu[40 + kq] = acc[1] + b1;
-    }
-    u = un; n = nn; ic = icn; ia = ian; il = iln; ublk = ublkn; uslot = uslotn;
   }
+  ROW2_TICK(1)   // (wave 0's share of the block passes)
   __syncthreads();
+  ROW2_TICK(2)   // (waiting for the slowest wave)
+  // ---- final sums: per block over its units (slot = creation order: a block's units are consecutive); diagonal block + b_schur over the 16-observation groups ----
   {
-    const int grp = threadIdx.x / 36, el = threadIdx.x % 36;
-    constexpr int kGroups = TPB / 36;
-    if (grp < kGroups)
-      for (int b = d.rowblk_off[i] + grp; b < d.rowblk_off[i + 1]; b += kGroups) {
+    const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
+    constexpr int kGroups = kRow2TPB / 36;
+    if (grp36 < kGroups)
+      for (int b = d.rowblk_off[i] + grp36; b < d.rowblk_off[i + 1]; b += kGroups) {
         double sum = 0;
-        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + kWave - 1) / kWave);
-        for (int u = ub; u < ue; u++) sum += part[kRowSlot * (size_t)(u - u_first) + el];
+        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + d.unit_chunk - 1) / d.unit_chunk);
+        for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
         d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
       }
-    // diagonal block and b_schur from the camera's own-observation units (the last ceil(ne / 64) units of the row); the
-    // upper triangle is mirrored so that S_ii is exactly symmetric
-    if (threadIdx.x < kRowSlot) {
-      const int el = threadIdx.x;
-      const int nd = (ne + kWave - 1) / kWave;
+    if (threadIdx.x >= kRow2TPB - 64 && threadIdx.x - (kRow2TPB - 64) < 27) {   // the last wave (it has no block of the loop above when the row is short)
+      const int e = threadIdx.x - (kRow2TPB - 64);
       double sum = 0;
-      for (int u = u_last - nd; u < u_last; u++) sum += part[kRowSlot * (size_t)(u - u_first) + el];
-      if (el < 36) {
-        const int a = el / 6, b = el % 6;
-        if (a <= b) { const double v = d.Hpp[36 * (size_t)i + el] - sum; d.S[36 * (size_t)i + a * 6 + b] = v; d.S[36 * (size_t)i + b * 6 + a] = v; }
-      } else d.bs[6 * (size_t)i + el - 36] = d.bp[6 * (size_t)i + el - 36] - sum;
+      for (int g = 0; g < n_dgrp; g++) sum += dpart[27 * (size_t)g + e];
+      if (e < 21) {
+        const int r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+        const int tri = r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15;
+        const int c = e - tri;
+        const double v = d.Hpp[36 * (size_t)i + 6 * r + c] - sum;
+        d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;   // the upper triangle is mirrored: S_ii is exactly symmetric
+      } else d.bs[6 * (size_t)i + e - 21] = d.bp[6 * (size_t)i + e - 21] - sum;
     }
   }
+  ROW2_TICK(3)
+  if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
+#undef ROW2_TICK
 }
 
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
@@ -2399,15 +2379,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
       if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
-        if (d.row_part) {
-          const size_t lds_row = ((size_t)d.max_cam_edges * 18 + 18) * sizeof(double);
-          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW2, (ba_schur_row_t<512, true>), 80 * 1024);
-          hipLaunchKernelGGL((ba_schur_row_t<512, true>), dim3(8 * ccm_div_up(d.Cp, 8)), dim3(512), lds_row, ctx->stream, d);
-        } else {
-          const size_t lds_row = ((size_t)d.max_cam_edges * 18 + (size_t)d.row_units_max * kRowSlot + 18) * sizeof(double);
-          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, (ba_schur_row_t<1024, false>), 158 * 1024);
-          hipLaunchKernelGGL((ba_schur_row_t<1024, false>), dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRowTPB), lds_row, ctx->stream, d);
-        }
+        const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
@@ -2629,6 +2603,13 @@ extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* o
 }
 
 static void pers_dbg_dump(ccm_ba* ba) {
+  if (ba->d.row_dbg) {
+    long long h[8];
+    hipMemcpy(h, ba->d.row_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const double nw = (double)std::max<long long>(h[5], 1);
+    fprintf(stderr, "[ccm_ba] row Schur kernel, thread 0 of every workgroup (%lld workgroups): us per row: staging + diagonal %.2f block passes %.2f wait %.2f final sums %.2f\n",
+            h[5], h[0] * 0.01 / nw, h[1] * 0.01 / nw, h[2] * 0.01 / nw, h[3] * 0.01 / nw);
+  }
   if (ba->d_dense_T && getenv("CCM_BA_DENSE2_DBG")) {
     long long h[11];
     hipMemcpy(h, ba->d_dense_T + kCluN * kCluN, sizeof(h), hipMemcpyDeviceToHost);

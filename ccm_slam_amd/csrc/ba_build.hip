@@ -334,25 +334,22 @@ __global__ __launch_bounds__(kB) void bb_cluster_entries(int Cp, const int* row_
   if (!FILL && t == 0) ccnt[c] = s_run;
 }
 
-// row Schur kernel: work units = (block, chunk of <= 64 consecutive pair instances) + chunks of the camera's own observations
-__global__ void bb_unit_counts(int nOff, int Cp, const int* inst_off, const int* cam_off, int* nub, int* nud) {
+// row Schur kernel: work units = (block, chunk of <= `chunk` consecutive pair instances), at least one per block; a block's units are consecutive
+__global__ void bb_unit_counts(int nOff, int chunk, const int* inst_off, int* nub) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t <= nOff) nub[t] = (t < nOff) ? max(1, (inst_off[t + 1] - inst_off[t] + kWave - 1) / kWave) : 0;
-  if (t <= Cp) nud[t] = (t < Cp) ? (cam_off[t + 1] - cam_off[t] + kWave - 1) / kWave : 0;
+  if (t <= nOff) nub[t] = (t < nOff) ? max(1, (inst_off[t + 1] - inst_off[t] + chunk - 1) / chunk) : 0;
 }
-__global__ void bb_unit_offsets(int nOff, int Cp, const int* blk_pref, const int* dpre, const int* rowblk_off, const int* bi, int* row_unit_off, int* blk_unit0,
-                                BuildSizes* sz) {
+__global__ void bb_unit_offsets(int nOff, int Cp, const int* blk_pref, const int* rowblk_off, int* row_unit_off, int* blk_unit0, BuildSizes* sz) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t <= Cp) row_unit_off[t] = blk_pref[rowblk_off[t]] + dpre[t];
-  if (t < Cp) atomicMax(&sz->worst_units, (blk_pref[rowblk_off[t + 1]] + dpre[t + 1]) - (blk_pref[rowblk_off[t]] + dpre[t]));
-  if (t == 0) sz->n_units = blk_pref[nOff] + dpre[Cp];
-  if (t < nOff) blk_unit0[t] = blk_pref[t] + dpre[bi[Cp + t]];
-  if (t == nOff) blk_unit0[t] = blk_pref[nOff] + dpre[Cp];
+  if (t <= Cp) row_unit_off[t] = blk_pref[rowblk_off[t]];
+  if (t < Cp) atomicMax(&sz->worst_units, blk_pref[rowblk_off[t + 1]] - blk_pref[rowblk_off[t]]);
+  if (t == 0) sz->n_units = blk_pref[nOff];
+  if (t <= nOff) blk_unit0[t] = blk_pref[t];
 }
-// one workgroup per camera row: the row's units in creation order (blocks of the row, then the own-observation chunks), then ranked LONGEST FIRST
-// (stable) — the order the 16 waves of the row kernel are dealt their units in; the slot keeps the creation index (where the partial sum goes)
-__global__ __launch_bounds__(kB) void bb_unit_fill(int Cp, const int* rowblk_off, const int* inst_off, const int* cam_off, const int* row_unit_off, const int* blk_unit0,
-                                                 int4* tab) {
+// one workgroup per camera row: the row's units in creation order (block after block), then ranked LONGEST FIRST (stable) — the order the waves of the row
+// kernel are dealt their units in, four per pass, so that the units of a pass have similar lengths; the slot keeps the creation index (where the partial
+// sum goes and where the final per-block sums find it)
+__global__ __launch_bounds__(kB) void bb_unit_fill(int Cp, int chunk, const int* rowblk_off, const int* inst_off, const int* row_unit_off, const int* blk_unit0, int4* tab) {
   extern __shared__ int su[];   // [n][3]: block, first, end
   const int i = blockIdx.x, t = threadIdx.x;
   const int base = row_unit_off[i], n = row_unit_off[i + 1] - base;
@@ -360,10 +357,8 @@ __global__ __launch_bounds__(kB) void bb_unit_fill(int Cp, const int* rowblk_off
   for (int b = rowblk_off[i] + t; b < rowblk_off[i + 1]; b += kB) {
     int c = blk_unit0[b] - base, s0 = inst_off[b];
     const int end = inst_off[b + 1];
-    do { const int s1 = min(end, s0 + kWave); blk[c] = b; s0a[c] = s0; s1a[c] = s1; c++; s0 = s1; } while (s0 < end);
+    do { const int s1 = min(end, s0 + chunk); blk[c] = b; s0a[c] = s0; s1a[c] = s1; c++; s0 = s1; } while (s0 < end);
   }
-  const int ne = cam_off[i + 1] - cam_off[i], nd = (ne + kWave - 1) / kWave;
-  for (int q = t; q < nd; q += kB) { const int c = n - nd + q; blk[c] = -1; s0a[c] = q * kWave; s1a[c] = min(ne, (q + 1) * kWave); }
   __syncthreads();
   for (int c = t; c < n; c += kB) {
     const int len = s1a[c] - s0a[c];
@@ -649,14 +644,14 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     }
     BB_HIP(hipGetLastError());
     // ---- row Schur kernel: unit offsets (the table itself needs the sizes read back below) ----
-    int *nub = nullptr, *nud = nullptr, *blk_pref = nullptr, *dpre = nullptr, *p_row_u = nullptr, *p_blk_u = nullptr;
-    BB_RC(tmp.get((size_t)nOff + 1, &nub)); BB_RC(tmp.get((size_t)Cp + 1, &nud)); BB_RC(tmp.get((size_t)nOff + 1, &blk_pref)); BB_RC(tmp.get((size_t)Cp + 1, &dpre));
+    int *nub = nullptr, *blk_pref = nullptr, *p_row_u = nullptr, *p_blk_u = nullptr;
+    BB_RC(tmp.get((size_t)nOff + 1, &nub)); BB_RC(tmp.get((size_t)nOff + 1, &blk_pref));
     BB_RC(keep_get(ba, (size_t)Cp + 1, &p_row_u)); BB_RC(keep_get(ba, (size_t)nOff + 1, &p_blk_u));
-    hipLaunchKernelGGL(bb_unit_counts, dim3(grid_for(std::max(nOff, Cp) + 1)), dim3(kB), 0, st, nOff, Cp, (const int*)d_inst_off, (const int*)p_cam_off, nub, nud);
+    static const int chunk_env = getenv("CCM_BA_ROW_CHUNK") ? atoi(getenv("CCM_BA_ROW_CHUNK")) : 0;   // experiments: 16 / 32 / 64 / 128
+    const int unit_chunk = d.unit_chunk = chunk_env >= kRow2Group ? chunk_env : kRow2Chunk;
+    hipLaunchKernelGGL(bb_unit_counts, dim3(grid_for(nOff + 1)), dim3(kB), 0, st, nOff, unit_chunk, (const int*)d_inst_off, nub);
     BB_RC(scan_excl(ctx, tmp, nub, blk_pref, (size_t)nOff + 1));
-    BB_RC(scan_excl(ctx, tmp, nud, dpre, (size_t)Cp + 1));
-    hipLaunchKernelGGL(bb_unit_offsets, dim3(grid_for(std::max(nOff, Cp) + 1)), dim3(kB), 0, st, nOff, Cp, (const int*)blk_pref, (const int*)dpre, (const int*)p_rowblk,
-                       (const int*)ba->d_blk_i, p_row_u, p_blk_u, sz);
+    hipLaunchKernelGGL(bb_unit_offsets, dim3(grid_for(std::max(nOff, Cp) + 1)), dim3(kB), 0, st, nOff, Cp, (const int*)blk_pref, (const int*)p_rowblk, p_row_u, p_blk_u, sz);
     // ---- rank of every observation inside its camera's list / of every pair instance's row-side observation ----
     int *p_rank = nullptr, *p_al = nullptr;
     BB_RC(tmp.get((size_t)Eloc, &p_rank)); BB_RC(keep_get(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_al));
@@ -714,24 +709,19 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     }
     d.max_cam_edges = hs.max_cam_edges;
     // ---- row Schur kernel: the unit table, when every row's partial sums fit the LDS beside its Y ----
-    d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0; d.row_part = nullptr;
+    d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0; d.row_dbg = nullptr;
+    if (getenv("CCM_BA_ROW_DBG")) { long long* p_dbg = nullptr; BB_RC(keep_get(ba, 8, &p_dbg, true)); d.row_dbg = p_dbg; }
     if (nOff > row_min_blocks() && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
-      const size_t lds_free = 158 * 1024 - 18 * sizeof(double) - (size_t)d.max_cam_edges * 18 * sizeof(double);
-      const int units_cap = (int)(lds_free / (kRowSlot * sizeof(double)));
+      // LDS of a row: Y of its observations + a zero row, the diagonal partials (27 per 16 observations), 36 doubles per unit
+      const size_t lds_free = 158 * 1024 - ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group)) * sizeof(double);
+      const int units_cap = (int)(lds_free / (36 * sizeof(double)));
       if (hs.worst_units <= units_cap) {
         int4* p_tab = nullptr;
         BB_RC(keep_get(ba, (size_t)hs.n_units, &p_tab));
-        hipLaunchKernelGGL(bb_unit_fill, dim3(Cp), dim3(kB), 3 * (size_t)std::max(hs.worst_units, 1) * sizeof(int), st, Cp, (const int*)p_rowblk, (const int*)d_inst_off,
-                           (const int*)p_cam_off, (const int*)p_row_u, (const int*)p_blk_u, p_tab);
+        hipLaunchKernelGGL(bb_unit_fill, dim3(Cp), dim3(kB), 3 * (size_t)std::max(hs.worst_units, 1) * sizeof(int), st, Cp, unit_chunk, (const int*)p_rowblk,
+                           (const int*)d_inst_off, (const int*)p_row_u, (const int*)p_blk_u, p_tab);
         BB_HIP(hipGetLastError());
         d.unit_tab = p_tab; d.row_unit_off = p_row_u; d.blk_unit0 = p_blk_u; d.row_units_max = std::max(hs.worst_units, 1);
-        // two rows per CU when Y of the longest row fits half of the LDS: measured on gba_c4 (r02e) 235 us against 228 us for the one-row shape — no
-        // gain; kept behind CCM_BA_ROW_V2=1
-        if (((size_t)d.max_cam_edges * 18 + 18) * sizeof(double) <= 79 * 1024 && getenv("CCM_BA_ROW_V2")) {
-          double* p_part = nullptr;
-          BB_RC(keep_get(ba, (size_t)hs.n_units * 42, &p_part));
-          d.row_part = p_part;
-        }
       }
     }
     // ---- solver buffers ----

@@ -7,8 +7,9 @@ constexpr int kWave = 64;
 constexpr int kTPB = 256;
 constexpr uint32_t kTransposeBit = 0x80000000u;
 constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
-constexpr int kRowSlot = 42;         // doubles per work-unit partial: 6x6 block + 6 (b_schur part of the diagonal units)
-constexpr int kRowTPB = 1024;        // 16 waves walk the row's blocks: the instance stream is latency bound, so more streams win
+constexpr int kRow2TPB = 1024;       // lane-per-instance row kernel: 16 waves, i.e. 128 VGPRs per lane (36-42 accumulators + the W_c row; the Y row is read three values at a time)
+constexpr int kRow2Group = 16;       // lanes that share one work unit (block chunk); 4 units per wave pass
+constexpr int kRow2Chunk = 32;       // pair instances per work unit: <= 2 per lane (measured on the 4-agent map: 32: 211 us, 64: 219, 128: 271 — the passes are latency chains, so short ones win)
 constexpr int kClu = 16;             // cameras per preconditioner cluster
 constexpr int kCluN = 6 * kClu;      // 96 unknowns
 constexpr int kSpmvTPB = 1024;
@@ -64,11 +65,12 @@ struct BaDev {
   const int* rowblk_off;     // [Cp+1] off-diagonal blocks (i, j > i) of block row i = [rowblk_off[i], rowblk_off[i+1])
   int max_cam_edges;         // longest per-camera edge list on this rank
   // row-centric Schur kernel: work units = (block, chunk of <= row_chunk consecutive pair instances), dealt to the waves
-  const int4* unit_tab;      // [n_units]: block (-1: the camera's own observations), first instance, end instance, slot of the partial sum inside the row; per row longest unit first
+  const int4* unit_tab;      // [n_units]: block, first instance, end instance, slot of the partial sum inside the row (creation index); per row longest unit first
   const int* row_unit_off;   // [Cp+1] units of block row i
   const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
   int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
-  double* row_part;          // [n_units][kRowSlot] unit partial sums of the two-rows-per-CU shape of the row kernel (nullptr: not allocated)
+  int unit_chunk;            // pair instances per work unit (kRow2Chunk)
+  long long* row_dbg;        // nullable (CCM_BA_ROW_DBG): [8] phase clocks of the row kernel summed over its workgroups (10 ns ticks) + launches
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]

@@ -66,11 +66,21 @@ __global__ __launch_bounds__(256) void hamming_dense_merge(
   const int qi = blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= Q) return;
   int b = 256, s = 256, bi = -1;
-  for (int sp = 0; sp < n_split; ++sp) {   // ascending target ranges: strict '<' keeps the first minimum
-    const size_t o = (size_t)sp * Q + qi;
-    const int pb = p_best[o], ps = p_second[o];
-    if (pb < b) { s = min(b, ps); b = pb; bi = p_best_idx[o]; }
-    else        { s = min(s, pb); }
+  // eight splits' partial results are requested together (one memory round trip per batch instead of one per split: 13.7 -> ~4 us at 2000 x 2000,
+  // where the 32 splits were 32 dependent round trips), then combined in ascending target order: strict '<' keeps the first minimum
+  for (int sp0 = 0; sp0 < n_split; sp0 += 8) {
+    int pb[8], ps[8], pi[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const bool v = sp0 + u < n_split;
+      const size_t o = (size_t)(v ? sp0 + u : 0) * Q + qi;
+      pb[u] = v ? p_best[o] : 256; ps[u] = v ? p_second[o] : 256; pi[u] = v ? p_best_idx[o] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (pb[u] < b) { s = min(b, ps[u]); b = pb[u]; bi = pi[u]; }
+      else           { s = min(s, pb[u]); }
+    }
   }
   best_idx[qi] = bi; best[qi] = b; second[qi] = s;
 }

@@ -14,7 +14,7 @@ from ccm_slam_amd._lib import lib
 
 pytestmark = pytest.mark.gpu
 
-KCLU, KAGG, WAVE, TPB = 16, 32, 64, 256
+KCLU, KAGG, CHUNK, TPB = 16, 32, 32, 256
 TBIT = np.uint32(0x80000000)
 _HOOKS = None
 
@@ -133,8 +133,8 @@ def host_structure(prob, rank=0, nranks=1):
                         cij.append(((i - r0) << 4) | (col - r0)); cblk.append(S["row_blk"][s])
             coff.append(len(cij))
         S["pers_coff"], S["pers_cij"], S["pers_cblk"] = np.array(coff), np.array(cij, np.int64), np.array(cblk, np.uint32)
-    # row-kernel unit table: per row the units of its blocks (<= 64 pair instances each, at least one per block), then of the camera's own observations,
-    # listed longest first (stable), slot = creation index
+    # row-kernel unit table: per row the units of its blocks (<= CHUNK pair instances each, at least one per block; slot = creation index), listed longest
+    # first (stable).  (The diagonal block needs no units: the thread that stages an observation's Y adds its part.)
     tab, row_u, blk_u = [], [0], []
     for i in range(Cp):
         units = []
@@ -142,12 +142,9 @@ def host_structure(prob, rank=0, nranks=1):
             blk_u.append(len(tab) + len(units))
             s0, end = int(S["inst_off"][b]), int(S["inst_off"][b + 1])
             while True:
-                s1 = min(end, s0 + WAVE); units.append([b, s0, s1, len(units)]); s0 = s1
+                s1 = min(end, s0 + CHUNK); units.append([b, s0, s1, len(units)]); s0 = s1
                 if s0 >= end:
                     break
-        ne = int(S["cam_off"][i + 1] - S["cam_off"][i])
-        for s0 in range(0, ne, WAVE):
-            units.append([-1, s0, min(ne, s0 + WAVE), len(units)])
         units.sort(key=lambda u: -(u[2] - u[1]))               # list.sort is stable
         tab.extend(units); row_u.append(len(tab))
     blk_u.append(len(tab))
