@@ -414,6 +414,11 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // Phase clocks (CCM_BA_ROW_DBG, 4-agent map, us per row, 7.8 rows per CU): the kernel is a chain of dependent memory round trips, not of flops or
 // bytes — staging 4.9 (index -> W, D^-1), block passes 6.6 (table entry -> index vectors -> W_c rows), final sums 2.9; a first version with separate
 // own-observation passes spent 10.7 us per row on their four-deep chain (table -> cam_edge -> ed_pt -> b_l).
+// Measured and dropped (round 3): an LDS-free "flat" form — a 16-lane group per S block recomputing Y_a = W_a D^-1 from global memory (21 sixteen-byte
+// gathers per instance and lane), any number of waves per CU — 393 us against 197 us: a wave-wide 16-byte gather whose lanes address 64 different rows
+// costs one L1 line look-up per LANE (~64 cycles per instruction), so the gathers alone were ~140 us; the same holds for the nine W_c gathers per
+// instance here (~60 us of this kernel).  What would lift it: nine consecutive lanes fetching one 144-byte row (2.25 line look-ups) and handing it to the
+// computing lane through LDS — for which the 70-100 KB of Y leave no room.
 template <int N>
 __device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[(N + 1) / 2], bool hi, int mask) {
   constexpr int H = (N + 1) / 2;   // the lower lanes keep elements [0, H), the upper ones [H, N) (N - H <= H of them, padded with zeros)
