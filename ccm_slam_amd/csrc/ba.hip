@@ -461,8 +461,8 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
   double* part = dpart + 27 * (size_t)((d.max_cam_edges + G - 1) / G);    // [row_units_max][36]
   // the table entry and the index vectors of this wave's first block pass are requested before anything else: their round trips overlap the staging
   const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
-  int4 te_next = make_int4(0, 0, 0, 0);
-  if (wv * UPW + grp < n_units) te_next = d.unit_tab[u_first + wv * UPW + grp];
+  int n_s0 = 0, n_s1 = 0, n_slot = 0;
+  if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; }
   // ---- Y_e = W_e D^-1 of the camera's observations, one thread per observation; the same thread adds the observation's part of the diagonal block
   //      (Y_e W_e^T, symmetric: entries r <= c) and of b_schur (Y_e b_l) ----
   {
@@ -494,13 +494,16 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
       v2d* Yp = reinterpret_cast<v2d*>(Ys + 18 * (size_t)t);
 #pragma unroll
       for (int k = 0; k < 9; k++) { v2d v; v[0] = yf[2 * k]; v[1] = yf[2 * k + 1]; Yp[k] = v; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is read back three values at a time below (same thread): Y, W_e and the 27 sums do not fit 128 registers together
+      const double* Yr = Ys + 18 * (size_t)t;
 #pragma unroll
       for (int r = 0; r < 6; r++) {
         constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};   // compact index of (r, c), r <= c: kTri[r] + c
+        const double y0 = Yr[3 * r], y1 = Yr[3 * r + 1], y2 = Yr[3 * r + 2];
 #pragma unroll
         for (int c = r; c < 6; c++)
-          dacc[kTri[r] + c] = __builtin_fma(yf[3 * r + 2], wf[3 * c + 2], __builtin_fma(yf[3 * r + 1], wf[3 * c + 1], yf[3 * r] * wf[3 * c]));
-        dacc[21 + r] = __builtin_fma(yf[3 * r + 2], bl2, __builtin_fma(yf[3 * r + 1], bl1, yf[3 * r] * bl0));
+          dacc[kTri[r] + c] = __builtin_fma(y2, wf[3 * c + 2], __builtin_fma(y1, wf[3 * c + 1], y0 * wf[3 * c]));
+        dacc[21 + r] = __builtin_fma(y2, bl2, __builtin_fma(y1, bl1, y0 * bl0));
       }
     }
     if (wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
@@ -524,9 +527,9 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
   // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
   for (int p = wv; p * UPW < n_units; p += NW) {
     const int uu = p * UPW + grp;
-    const int4 te = te_next;
-    const int s0 = te.y, s1 = te.z, slot = te.w;
-    if ((p + NW) * UPW + grp < n_units) te_next = d.unit_tab[u_first + (p + NW) * UPW + grp]; else te_next = make_int4(0, 0, 0, 0);
+    const int s0 = n_s0, s1 = n_s1, slot = n_slot;
+    n_s0 = n_s1 = n_slot = 0;
+    if ((p + NW) * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + (p + NW) * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; }
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;

@@ -127,6 +127,11 @@ struct FlatBA {
   IdIndex cam_index, pt_index;
 
   size_t nEdges() const { return e_cam_id.size(); }
+  void reset() {   // keeps every vector's capacity: the global BA of a 4-agent map builds ~60 MB of flat arrays, and allocating (first-touch page faults) and
+                   // releasing (munmap) them cost ~50 ms per call — the server thread keeps one FlatBA for its lifetime instead
+    cam_id.clear(); pt_id.clear(); cam_kf.clear(); cam_is_fixed.clear(); pt_mp.clear(); e_cam_id.clear(); e_pt_id.clear();
+    cam_qt.clear(); cam_K.clear(); pt_xyz.clear(); e_obs.clear(); e_info.clear(); cam_fix.clear(); e_level.clear(); e_cam.clear(); e_pt.clear();
+  }
   void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cam_id.push_back(id); cam_kf.push_back(kf); cam_is_fixed.push_back(is_fixed ? 1 : 0); }
   void addPoint(size_t id, const Optimizer::mpptr& mp) { pt_id.push_back(id); pt_mp.push_back(mp.get()); }
   void addEdge(size_t p_id, const Optimizer::kfptr& kf, size_t c_id, const cv::KeyPoint& kpUn) {
@@ -516,7 +521,10 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   }
   idpair FixedId = (*(pMap->mvpKeyFrameOrigins.begin()))->mId;
   std::vector<char> vbNotIncludedMP(vpMP.size(), 0);   // one byte per point: chunks of vpMP are walked by different threads
-  FlatBA f;
+  static thread_local FlatBA f_keep;
+  static thread_local std::vector<FlatBA> part_keep;
+  FlatBA& f = f_keep;
+  f.reset();
   size_t maxKFid = 0;
   for (size_t i = 0; i < vpKFs.size(); i++) {
     kfptr pKF = vpKFs[i];
@@ -530,7 +538,9 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
     // the map points in contiguous chunks of vpMP, one chunk per host thread (every point is independent; GetObservations() copies under the point's
     // own mutex exactly as in the reference); the chunks are appended in order, so vertices and edges keep the order of the sequential walk
     const int n_thr = shim_threads(vpMP.size());
-    std::vector<FlatBA> part((size_t)n_thr);
+    std::vector<FlatBA>& part = part_keep;
+    if (part.size() < (size_t)n_thr) part.resize((size_t)n_thr);
+    for (auto& g : part) g.reset();
     parallel_chunks(vpMP.size(), n_thr, [&](int t, size_t i0, size_t i1) {
       FlatBA& g = t == 0 ? f : part[(size_t)t];
       for (size_t i = i0; i < i1; i++) {
@@ -592,7 +602,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
     }
   });
   pc.lap(6);
-  { FlatBA released; std::swap(f, released); }
+  f.cam_kf.clear(); f.pt_mp.clear();   // no keyframe / map point is kept alive between calls; the flat arrays stay allocated
   pc.lap(9);
 }
 
