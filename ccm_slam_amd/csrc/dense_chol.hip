@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kTPB) void chol_xtx(const double* X, int N, double*
 int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, double* d_linv, int* d_info, const ccm_tile_plan* plan) {
   if (N % NB) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: N must be a multiple of 64");
   const int T = N / NB;
-  if (plan && (plan->T != T || T >= 65536)) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: tile plan does not match");
+  if (plan && (plan->T != T || T >= 32768)) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: tile plan does not match");
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
     hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
@@ -454,7 +454,7 @@ static int tsc_up(ccm_ctx* ctx, ccm_tsc* p, const std::vector<Tv>& v, Tv** out) 
   return CCM_OK;
 }
 int ccm_tsc_create(ccm_ctx* ctx, int T, const std::vector<char>& nz, ccm_tsc* p) {
-  if (T <= 0 || T >= 65536) return ccm_set_error(ctx, CCM_E_ARG, "tile cholesky: bad tile count");
+  if (T <= 0 || T >= 32768) return ccm_set_error(ctx, CCM_E_ARG, "tile cholesky: bad tile count (tile coordinates are packed as (i << 16) | j in a signed int)");
   ccm_tile_plan sym;
   std::vector<int> col_rows, upd_pairs, row_cols;
   ccm_tile_plan_symbolic(T, nz, &sym, &col_rows, &upd_pairs, &row_cols);   // fill pattern: col_rows(j) = rows below, row_cols(j) = columns left

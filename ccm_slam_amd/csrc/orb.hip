@@ -583,10 +583,11 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
 
 __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                               const KpIn* __restrict__ kin, int n, const int* __restrict__ n_dev /* nullable: count on the device */,
-                                                              ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc) {
+                                                              ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc, int* __restrict__ count_out /* nullable */) {
   const int lane = threadIdx.x & (kWave - 1);
   const int i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   if (n_dev) n = *n_dev;
+  if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;   // batch API: the frame's keypoint count lands next to its results, no copy launch
   if (i >= n) return;
   const KpIn kp = kin[i];
   const LevelInfo L = d.lv[kp.level];
@@ -793,6 +794,7 @@ static void distribute_octree(Octree& T, const Cand* c, int n, int minX, int max
 }  // namespace
 
 // =================================================================================================
+constexpr int kOrbSets = 4;   // frames in flight of the batch API with the device octree (sets 0 / 1 also serve the single-frame and host-octree paths)
 struct ccm_orb {
   ccm_ctx* ctx = nullptr;
   int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
@@ -815,7 +817,7 @@ struct ccm_orb {
     int* h_count = nullptr;  // pinned: keypoint count of the frame (batch API); device octree: [0] count, [1] overflow flag
     KpIn* d_oct_stage = nullptr; int* d_oct_counts = nullptr; int* d_n = nullptr;   // device octree: per-level results, [levels | arrival | overflow], keypoint count
     hipEvent_t ev_cand = nullptr;
-  } B[2];
+  } B[kOrbSets];
   int cur = 0;
   int16_t* d_tabs = nullptr; std::vector<int> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // per level offsets into d_tabs
   int cand_cap = 0;
@@ -828,7 +830,8 @@ struct ccm_orb {
   // device octree (orb_octree_kernel): LDS plan of this geometry; oct_ok = false -> host octree
   bool oct_ok = false; int oct_tpb = 1024; int oct_kcap = 0, oct_stride = 0; size_t oct_lds = 0; int oct_lcap[kMaxLevels] = {0};
   hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
-  hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;   // host-octree batch path
+  hipStream_t bstream[kOrbSets] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t bev[kOrbSets] = {nullptr, nullptr, nullptr, nullptr};   // device-octree batch path: stream / "done" event of sets 1..3
   unsigned long long* d_oct_dbg = nullptr;   // CCM_ORB_OCT_DBG: phase clocks of the octree kernel, printed by ccm_orb_destroy
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand; bool last_cand_valid = false;
@@ -846,7 +849,7 @@ static void orb_free_bufs(ccm_orb::Bufs& b) {
   b.ev_cand = ev;   // events do not depend on the geometry
 }
 static void orb_free_geometry(ccm_orb* o) {
-  orb_free_bufs(o->B[0]); orb_free_bufs(o->B[1]);
+  for (int k = 0; k < kOrbSets; k++) orb_free_bufs(o->B[k]);
   hipFree(o->d_tabs); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
   if (o->h_io) hipHostFree(o->h_io);
   o->d_tabs = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
@@ -898,6 +901,7 @@ extern "C" void ccm_orb_destroy(ccm_orb* o) {
   orb_free_geometry(o);
   for (int k = 0; k < 2; k++) if (o->B[k].ev_cand) hipEventDestroy(o->B[k].ev_cand);
   if (o->stream2) { hipStreamSynchronize(o->stream2); hipStreamDestroy(o->stream2); }
+  for (int k = 1; k < kOrbSets; k++) { if (o->bstream[k]) { hipStreamSynchronize(o->bstream[k]); hipStreamDestroy(o->bstream[k]); } if (o->bev[k]) hipEventDestroy(o->bev[k]); }
   if (o->ev_a) hipEventDestroy(o->ev_a);
   if (o->ev_b) hipEventDestroy(o->ev_b);
   delete o;
@@ -1183,7 +1187,7 @@ static int orb_phase2(ccm_orb* o, int n) {
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].d_kin, o->B[o->cur].h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (const int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (const int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc, (int*)nullptr);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1191,7 +1195,7 @@ static int orb_phase2(ccm_orb* o, int n) {
 
 // keypoint selection and phase 2 without the host: octree kernel (one workgroup per level), then orientation + descriptors for the count the
 // device wrote (the grid covers the capacity, surplus waves leave at once)
-static int orb_phase2_dev(ccm_orb* o, int out_cap) {
+static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr, uint8_t* dout = nullptr, int* count_out = nullptr) {
   ccm_ctx* ctx = o->ctx;
   ccm_orb::Bufs& b = o->B[o->cur];
   OctArgs a;
@@ -1212,7 +1216,7 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap) {
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF, o->st);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, (const int*)b.d_n, b.d_kout, b.d_desc);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, (const int*)b.d_n, kout ? kout : b.d_kout, dout ? dout : b.d_desc, count_out);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1303,40 +1307,46 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   if ((rc = orb_alloc_bufs(o, 1))) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
   if (o->oct_ok && cap > 0) {
-    // device octree: the whole batch is queued without a single host wait.  Even frames run on the context's stream with buffer set 0, odd
-    // frames on a second stream with set 1: the octree kernel is eight workgroups of serial rounds (~55 us), the other frame's pyramid /
-    // FAST / descriptor kernels fill the rest of the GPU meanwhile.
-    if (!o->stream2) {
-      CCM_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->stream2, hipStreamNonBlocking));
-      CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_a, hipEventDisableTiming));
-      CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_b, hipEventDisableTiming));
+    // device octree: the whole batch is queued without a single host wait, kOrbSets frames in flight: frame f runs on stream f % kOrbSets with its own
+    // buffer set (the octree kernel is eight workgroups of serial rounds, ~40 us: the other frames' pyramid / FAST / descriptor kernels fill the
+    // GPU meanwhile), and the orientation + descriptor kernel writes keypoints, descriptors and the count straight into the caller's arrays
+    // (round 2: two frames in flight and three device-to-device copies per frame, 15 us of a stream's time: 0.069 ms per frame).
+    for (int k = 1; k < kOrbSets; k++) {
+      if ((rc = orb_alloc_bufs(o, k))) return rc;
+      if (!o->bstream[k]) {
+        CCM_HIP_CHECK(ctx, hipStreamCreateWithFlags(&o->bstream[k], hipStreamNonBlocking));
+        CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->bev[k], hipEventDisableTiming));
+      }
     }
+    if (!o->ev_a) CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_a, hipEventDisableTiming));
     CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_a, ctx->stream));            // whatever produced the images on the context's stream comes first
-    CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->stream2, o->ev_a, 0));
+    for (int k = 1; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->bstream[k], o->ev_a, 0));
     const int nc = std::min(cap, o->kp_cap);
+    (void)nc;
     for (int f = 0; f < n_frames; f++) {
-      o->cur = f & 1;
-      o->st = (f & 1) ? o->stream2 : ctx->stream;
+      o->cur = f % kOrbSets;
+      o->st = o->cur ? o->bstream[o->cur] : ctx->stream;
       ccm_orb::Bufs& b = o->B[o->cur];
       CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
       if ((rc = orb_phase1(o, false))) { o->cur = 0; o->st = ctx->stream; return rc; }
-      if ((rc = orb_phase2_dev(o, cap))) { o->cur = 0; o->st = ctx->stream; return rc; }
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_kps + (size_t)f * cap, b.d_kout, (size_t)nc * sizeof(ccm_keypoint), hipMemcpyDeviceToDevice, o->st));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_desc + (size_t)f * cap * 32, b.d_desc, (size_t)nc * 32, hipMemcpyDeviceToDevice, o->st));
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_counts + f, b.d_n, sizeof(int), hipMemcpyDeviceToDevice, o->st));
+      if ((rc = orb_phase2_dev(o, cap, d_kps + (size_t)f * cap, d_desc + (size_t)f * cap * 32, d_counts + f))) { o->cur = 0; o->st = ctx->stream; return rc; }
     }
     o->cur = 0; o->st = ctx->stream;
     // the overflow flags are sticky over the batch
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[1].h_count, o->B[1].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, o->stream2));
-    CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_b, o->stream2));
-    CCM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->ev_b, 0));
+    for (int k = 1; k < kOrbSets; k++) {
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[k].h_count, o->B[k].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, o->bstream[k]));
+      CCM_HIP_CHECK(ctx, hipEventRecord(o->bev[k], o->bstream[k]));
+      CCM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->bev[k], 0));
+    }
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[0].h_count, o->B[0].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     o->last_cand_valid = false;
-    if (n_frames == 0 || (o->B[0].h_count[1] == 0 && (n_frames < 2 || o->B[1].h_count[1] == 0))) return CCM_OK;
+    bool overflow = false;
+    for (int k = 0; k < kOrbSets && k < n_frames; k++) overflow = overflow || o->B[k].h_count[1] != 0;
+    if (!overflow) return CCM_OK;
     // some level of some frame did not fit the kernel's LDS plan: redo the batch with the host octree
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[0].d_n + 1, 0, sizeof(int), ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[1].d_n + 1, 0, sizeof(int), ctx->stream));
+    for (int k = 0; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[k].d_n + 1, 0, sizeof(int), ctx->stream));
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
   // the octrees of a frame's levels run on this thread + a few helpers for the duration of the call (CCM_ORB_BATCH_THREADS, default 3 helpers, 0 = none)
   static const int n_helpers = getenv("CCM_ORB_BATCH_THREADS") ? std::max(0, std::min(7, atoi(getenv("CCM_ORB_BATCH_THREADS")))) : 3;

@@ -866,7 +866,9 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   // stored, so the size limit is the tile-pattern table, not a dense array); CCM_PG_SOLVER=dense keeps the round-1 form (dense array of
   // <= 24 000 unknowns, natural order, one tile column after the other) for comparison
   const bool want_exact = !(solver_env && !strcmp(solver_env, "pcg"));
-  const bool use_tiles = want_exact && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL") && n_dense <= 800000;
+  // (<= 20 000 keyframes: the symbolic step keeps dense T x T tile-pattern tables on host and device, T ~ 4000 tiles at that size, and packs tile
+  // coordinates as (i << 16) | j in a signed int, i.e. T < 32768; larger graphs take the tree-preconditioned PCG path)
+  const bool use_tiles = want_exact && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL") && n_dense <= 140000;
   const bool use_dense = want_exact && (use_tiles || n_dense <= 24000);
   double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
   ccm_tile_plan plan;
