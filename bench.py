@@ -55,25 +55,20 @@ def _best_of(fn, reps, batches=3):
 
 
 def local_ba_leg(ctx, with_cpu, reps=5):
-    """Local bundle adjustment as LocalMapping calls it (Optimizer::LocalBundleAdjustmentClient, Optimizer.cpp:349-859): handle
-    creation from host arrays, 5 + 10 LM iterations, download, tear-down — end to end through the host API, best of `reps`.
-    Workload lba_c2: 30 free + 40 fixed keyframes, 4000 map points, ~23 000 observations."""
+    """Local bundle adjustment as LocalMapping calls it (Optimizer::LocalBundleAdjustmentClient, Optimizer.cpp:349-644): handle creation from host arrays,
+    optimize(5) with Huber, outlier edges to level 1 (ccm_ba_set_edge_levels on the same handle), optimize(10) without the kernel, downloads, tear-down —
+    end to end through the host API, best of `reps`.  Workload lba_c2: 30 free + 40 fixed keyframes, 4000 map points, ~23 000 observations."""
     from ccm_slam_amd import optimizer, synth
+    from ccm_slam_amd._lib import K as KCLS
     prob = synth.make_ba_config("lba_c2")
     best = None
     for _ in range(reps + 1):          # first repetition warms the allocation pool
         t0 = time.perf_counter()
-        h = optimizer.BAHandle(ctx, prob)
-        st = h.run(15)
-        h.download()
-        h.close()
+        _, _, erase, st1, st2 = optimizer.local_bundle_adjustment(ctx, prob)
         dt = time.perf_counter() - t0
         if _ > 0: best = dt if best is None else min(best, dt)
-    from ccm_slam_amd._lib import K as KCLS
     ctx.prof_enable(-1); ctx.prof_reset()
-    h = optimizer.BAHandle(ctx, prob)
-    h.run(15)
-    h.close()
+    optimizer.local_bundle_adjustment(ctx, prob)
     ctx.sync()
     lba_kernels = []
     for name, k in KCLS.items():
@@ -83,12 +78,19 @@ def local_ba_leg(ctx, with_cpu, reps=5):
                 lba_kernels.append({"class": name.lower(), "launches_per_call": n, "avg_us": round(ms * 1e3 / n, 2), "ms_per_call": round(ms, 4)})
     lba_kernels.sort(key=lambda e: -e["ms_per_call"])
     ctx.prof_enable(-2)
-    out = {"local_ba_kernels": lba_kernels, "local_ba_ms": round(best * 1e3, 3), "local_ba_workload": f"lba_c2: {prob['n_cam']} KFs ({int((prob['cam_fixed'] == 0).sum())} free), "
-                                                                     f"{prob['n_pt']} points, {prob['n_edge']} observations, {st.iters_done} LM iterations / {st.lm_trials} trials"}
+    out = {"local_ba_kernels": lba_kernels, "local_ba_ms": round(best * 1e3, 3),
+           "local_ba_workload": f"lba_c2: {prob['n_cam']} KFs ({int((prob['cam_fixed'] == 0).sum())} free), {prob['n_pt']} points, {prob['n_edge']} observations; "
+                                f"optimize(5) + optimize(10) on one handle: {st1.iters_done} + {st2.iters_done} LM iterations / {st1.lm_trials} + {st2.lm_trials} trials, "
+                                f"{int(erase.sum())} observations to erase"}
     if with_cpu:
+        import numpy as np
         import oracle
         t0 = time.perf_counter()
-        oracle.ba_optimize(prob, 15)
+        p1 = dict(prob); p1["huber_delta"] = float(np.float32(np.sqrt(np.float32(5.991))))
+        ocam, opts, ochi2, odpos, _ = oracle.ba_optimize(p1, 5)
+        level = np.zeros(prob["n_edge"], np.uint8); level[(ochi2 > 5.991) | (odpos == 0)] = 1
+        p2 = dict(prob); p2.update(cam_qt=ocam, pt_xyz=opts, e_level=level, huber_delta=0.0)
+        oracle.ba_optimize(p2, 10, chi2_in=ochi2)
         out["local_ba_cpu_port_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
     return out
 

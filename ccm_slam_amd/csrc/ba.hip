@@ -2029,7 +2029,7 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2(BaDev d, int cur, double
       double rho0, w;
       ba_huber(c2, d.huber, rho0, w);
       chi += rho0;
-      d.edge_chi2[e] = c2;
+      if (d.info[e] != 0.0) d.edge_chi2[e] = c2;   // an edge moved to level 1 (ccm_ba_set_edge_levels) keeps the chi2 of the pass before, like g2o's _error
       d.edge_depth[e] = zc > 0.0;
     }
   }
@@ -2093,7 +2093,7 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, doub
     double rho0, w;
     ba_huber(c2, d.huber, rho0, w);
     chi = rho0;
-    d.edge_chi2[e] = c2;
+    if (d.info[e] != 0.0) d.edge_chi2[e] = c2;     // (see ba_backsub_chi2)
     d.edge_depth[e] = zc > 0.0;
   }
   const double s0 = block_sum(chi, lds);
@@ -2725,6 +2725,34 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   st.ms_total = st.ms_iters + st.ms_setup;
   if (stats) *stats = st;
   pers_dbg_dump(ba);
+  return CCM_OK;
+}
+
+// edges whose level is not 0 leave the optimisation: their information becomes 0, so every sum they enter gets an exact zero
+__global__ void ba_deactivate_edges(double* info, const int* loc_edge_orig, const uint8_t* level, int Eloc) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < Eloc && level[loc_edge_orig[k]] != 0) info[k] = 0.0;
+}
+
+// The second stage of Optimizer::LocalBundleAdjustmentClient (Optimizer.cpp:545-566: outlier edges -> setLevel(1), robust kernel off,
+// initializeOptimization(0), optimize(10)) on the SAME handle: edges with e_level != 0 are taken out by zeroing their information (exact zeros in every
+// sum: the same normal equations as a rebuilt structure, whose rows / blocks they would merely not have), the Huber delta is replaced, the estimate stays.
+// Edges that were inactive at ccm_ba_create are not part of the handle and cannot come back.  ccm_ba_download keeps returning, for a deactivated edge,
+// the chi2 of the last pass it took part in (g2o leaves the _error of a level-1 edge alone).
+extern "C" int ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double huber_delta) {
+  if (!ba || !e_level) return CCM_E_ARG;
+  ccm_ctx* ctx = ba->ctx;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (ba->n_edge) {
+    void* d_lvl = nullptr;
+    RC(ccm_scratch(ctx, (size_t)ba->n_edge, &d_lvl));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_lvl, e_level, (size_t)ba->n_edge, hipMemcpyDefault, ctx->stream));
+    if (ba->Eloc) hipLaunchKernelGGL(ba_deactivate_edges, dim3(ccm_div_up(ba->Eloc, kTPB)), dim3(kTPB), 0, ctx->stream, const_cast<double*>(ba->d.info), (const int*)ba->d_loc_edge_orig,
+                                     (const uint8_t*)d_lvl, ba->Eloc);
+    CCM_HIP_CHECK(ctx, hipGetLastError());
+    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // e_level may be a pageable host array
+  }
+  ba->d.huber = huber_delta;
   return CCM_OK;
 }
 

@@ -77,6 +77,11 @@ class BAHandle:
         check(lib().ccm_ba_run(self._h, C.byref(opt), fl, C.byref(st)), self.ctx.handle)
         return st
 
+    def set_edge_levels(self, e_level, huber_delta: float):
+        """second stage of the local BA on the same handle (ccm_ba_set_edge_levels): edges with level != 0 leave, new Huber delta"""
+        lvl = np.ascontiguousarray(e_level, np.uint8)
+        check(lib().ccm_ba_set_edge_levels(self._h, C.c_void_p(_vp(lvl)), C.c_double(huber_delta)), self.ctx.handle)
+
     def history(self):
         """(chi2 after each LM iteration, lambda after it, trials it took) of the last run"""
         n = C.c_int(0)
@@ -196,9 +201,23 @@ def local_bundle_adjustment(ctx: Context, prob: dict, **kw):
     Returns (cam_qt, pt_xyz, to_erase mask, stats1, stats2)."""
     p1 = dict(prob)
     p1["huber_delta"] = float(np.float32(np.sqrt(np.float32(5.991))))
-    cam, pts, chi2, dpos, st1 = bundle_adjustment(ctx, p1, 5, **kw)
-    level = np.ascontiguousarray(prob.get("e_level", np.zeros(prob["n_edge"], np.uint8)), np.uint8).copy()
+    level = np.ascontiguousarray(prob.get("e_level") if prob.get("e_level") is not None else np.zeros(prob["n_edge"], np.uint8), np.uint8).copy()
     active = level == 0
+    if kw.pop("one_handle", True):
+        # both stages on ONE handle (what shim/Optimizer_hip.cpp does): the outliers of the first pass leave through ccm_ba_set_edge_levels
+        h = BAHandle(ctx, p1)
+        try:
+            st1 = h.run(5, **kw)
+            _, _, chi2, dpos = h.download()
+            level[active & ((chi2 > 5.991) | (dpos == 0))] = 1
+            h.set_edge_levels(level, 0.0)
+            st2 = h.run(10, **kw)
+            cam2, pts2, chi2b, dpos2 = h.download(chi2)
+        finally:
+            h.close()
+        erase = active & ((chi2b > 5.991) | (dpos2 == 0))
+        return cam2, pts2, erase, st1, st2
+    cam, pts, chi2, dpos, st1 = bundle_adjustment(ctx, p1, 5, **kw)
     out = active & ((chi2 > 5.991) | (dpos == 0))
     level[out] = 1
     p2 = dict(prob)

@@ -283,6 +283,11 @@ int  ccm_ba_pop_state(ccm_ba* ba);
 int  ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt, const volatile unsigned char* stop_flag,
                 ccm_ba_stats* stats);
 int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge);
+/* Second stage of Optimizer::LocalBundleAdjustmentClient on the SAME handle (Optimizer.cpp:545-566: outlier edges -> setLevel(1), robust kernel off,
+ * optimize(10)): edges with e_level[e] != 0 ([n_edge], the caller's numbering) leave the optimisation, the Huber delta is replaced (<= 0: none), the
+ * estimate stays; the next ccm_ba_run is the reference's initializeOptimization(0) + optimize(n) on the reduced edge set.  Edges inactive at
+ * ccm_ba_create cannot be re-activated.  A deactivated edge keeps reporting the chi2 of the last pass it took part in. */
+int  ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double huber_delta);
 /* per-iteration record of the last ccm_ba_run: robust chi2 after the iteration, lambda after it, LM trials it took
  * (what g2o prints with setVerbose(true), sparse_optimizer.cpp:400-410); fills min(*n_iters, cap) entries */
 int  ccm_ba_history(const ccm_ba* ba, int cap, double* chi2_per_iter, double* lambda_per_iter, int32_t* trials_per_iter,

@@ -215,8 +215,10 @@ struct FlatBA {
   }
 };
 
-// optimizer.initializeOptimization(0); optimizer.optimize(n) on the device
-void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vector<double>* chi2, std::vector<uint8_t>* depth_pos) {
+// optimizer.initializeOptimization(0); optimizer.optimize(n) on the device.  keep != nullptr: the handle outlives the call (*keep == nullptr: it is
+// created here; otherwise the problem of the earlier call is reused: the edges whose e_level became non-zero leave, the estimate stays — the second
+// stage of the local BA, Optimizer.cpp:545-566); the caller releases it with ccm_ba_destroy.
+void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vector<double>* chi2, std::vector<uint8_t>* depth_pos, ccm_ba** keep = nullptr) {
   ccm_ba_problem P = f.problem(huber);
   ccm_ba_options opt;
   std::memset(&opt, 0, sizeof(opt));
@@ -225,15 +227,16 @@ void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vect
   if (depth_pos) depth_pos->resize(f.nEdges(), 1);
   // = ccm_ba_optimize (one rank: a one-shot call never turns into a collective), split so that the phases can be read
   ccm_ctx* ctx = thread_ctx();
-  ccm_ba* ba = nullptr;
+  ccm_ba* ba = keep ? *keep : nullptr;
   double t = now_ms();
-  check(ccm_ba_create(ctx, &P, 0, 1, &ba), "ccm_ba_create");
+  if (!ba) check(ccm_ba_create(ctx, &P, 0, 1, &ba), "ccm_ba_create");
+  else check(ccm_ba_set_edge_levels(ba, f.e_level.data(), huber), "ccm_ba_set_edge_levels");
   double n = now_ms(); g_phase[2] += n - t; t = n;
   int rc = ccm_ba_run(ba, &opt, reinterpret_cast<const volatile unsigned char*>(pbStopFlag), nullptr);
   n = now_ms(); g_phase[3] += n - t; t = n;
   if (rc == CCM_OK) rc = ccm_ba_download(ba, P.cam_qt, P.pt_xyz, chi2 ? chi2->data() : nullptr);
   if (rc == CCM_OK && depth_pos) rc = ccm_ba_depth_positive(&P, P.cam_qt, P.pt_xyz, depth_pos->data());
-  ccm_ba_destroy(ba);
+  if (keep) *keep = ba; else ccm_ba_destroy(ba);
   g_phase[4] += now_ms() - t;
   check(rc, "ccm_ba_run");
 }
@@ -451,7 +454,8 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   // optimizer.initializeOptimization(); optimizer.optimize(5);  (:536-537)
   std::vector<double> chi2;
   std::vector<uint8_t> dpos;
-  run_ba(f, (double)thHuberMono, 5, pbStopFlag, &chi2, &dpos);
+  struct Handle { ccm_ba* h = nullptr; ~Handle() { if (h) ccm_ba_destroy(h); } } session;   // both optimisations run on one device-side problem
+  run_ba(f, (double)thHuberMono, 5, pbStopFlag, &chi2, &dpos, &session.h);
   bool bDoMore = true;
   if (pbStopFlag)
     if (*pbStopFlag) bDoMore = false;
@@ -462,7 +466,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
       if (pMP->isBad()) continue;
       if (chi2[i] > 5.991 || !dpos[i]) f.e_level[i] = 1;
     }
-    run_ba(f, 0.0, 10, pbStopFlag, &chi2, &dpos);
+    run_ba(f, 0.0, 10, pbStopFlag, &chi2, &dpos, &session.h);
   }
   pc.t = now_ms();
   vector<pair<kfptr, mpptr> > vToErase;

@@ -64,9 +64,13 @@ def test_noise_free_converges_to_truth(ctx):
     assert np.abs(pts - prob["gt_pt_xyz"]).max() < 5e-3
 
 
-def test_local_ba_two_stage(ctx, oracle_lib):
+@pytest.mark.parametrize("one_handle", [True, False])
+def test_local_ba_two_stage(ctx, oracle_lib, one_handle):
+    """one_handle: both optimisations on ONE handle, the outliers of the first leaving through ccm_ba_set_edge_levels (what the drop-in translation unit
+    does); False: the second stage as a freshly built problem with e_level set.  Same window, same erase set either way."""
     prob = synth.make_ba_config("lba_c2")
-    cam, pts, erase, st1, st2 = optimizer.local_bundle_adjustment(ctx, prob)
+    cam, pts, erase, st1, st2 = optimizer.local_bundle_adjustment(ctx, prob, one_handle=one_handle)
+    assert (st1.iters_done, st2.iters_done) == (5, 10)
     # oracle: same two-stage protocol (Optimizer.cpp:536-602)
     p1 = dict(prob)
     p1["huber_delta"] = float(np.float32(np.sqrt(np.float32(5.991))))
