@@ -1204,6 +1204,8 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
 #pragma unroll
         for (int c = 0; c < 16; c++) {
           double sv = row[c];
+          // (measured and dropped, round 3: the pivot-row entries through __shfl — all c of them requested at once, two partial sums — instead of
+          // v_readlane broadcasts: 170 us against 158 us for the two-cluster solve)
 #pragma unroll
           for (int k = 0; k < c; k++) sv -= row[k] * pers_bcast(row[k], c);
           double dd = pers_bcast(sv, c);
