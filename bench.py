@@ -62,11 +62,11 @@ def local_ba_leg(ctx, with_cpu, reps=5):
     from ccm_slam_amd._lib import K as KCLS
     prob = synth.make_ba_config("lba_c2")
     best = None
-    for _ in range(reps + 1):          # first repetition warms the allocation pool
+    for rep in range(reps + 1):        # first repetition warms the allocation pool
         t0 = time.perf_counter()
-        _, _, erase, st1, st2 = optimizer.local_bundle_adjustment(ctx, prob)
+        _cam, _pts, erase, st1, st2 = optimizer.local_bundle_adjustment(ctx, prob)
         dt = time.perf_counter() - t0
-        if _ > 0: best = dt if best is None else min(best, dt)
+        if rep > 0: best = dt if best is None else min(best, dt)
     ctx.prof_enable(-1); ctx.prof_reset()
     optimizer.local_bundle_adjustment(ctx, prob)
     ctx.sync()
