@@ -316,7 +316,7 @@ def ba_kernel_bytes(counts):
 
 KERNEL_OF_CLASS = {   # device kernel(s) behind every profiling class on the gba-sized path (names as rocprofv3 prints them)
     "BA_LINEARIZE": "ba_linearize_pts_e", "BA_CAM": "ba_linearize_cams", "BA_DINV": "ba_dinv", "BA_SCHUR_DIAG": "ba_schur_diag",
-    "BA_SCHUR_OFF": "ba_schur_row2", "BA_PCG_SPMV": "ba_pcg_spmv", "BA_PCG_UPDATE": "ba_pcg_update", "BA_BACKSUB": "ba_backsub_chi2_e",
+    "BA_SCHUR_OFF": "ba_schur_row3", "BA_PCG_SPMV": "ba_pcg_spmv", "BA_PCG_UPDATE": "ba_pcg_update", "BA_BACKSUB": "ba_backsub_chi2_e",
     "BA_UPDATE": "ba_update_cams", "BA_CHI2": "ba_backsub_chi2_e", "BA_PCG_PERSIST": "ba_pcg_persist",
     "BA_COARSE": "ba_coarse_assemble+chol_*", "BA_REDUCE": "ba_reduce_scalars"}
 LIMITER = {"BA_PCG_PERSIST": "latency (grid exchange): two grid-wide exchanges of ~3.3 us per CG iteration, S stays in registers",

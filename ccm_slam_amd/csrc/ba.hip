@@ -156,8 +156,11 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
     const double K4[4] = {Kc[0], Kc[1], Kc[2], Kc[3]};
     double r0, r1;
     ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
-    double Ji[6], Jj[12];
-    ba_jacobians(T, K4, X, Ji, Jj);
+    double Ji[6], Jj[12], Xc[3], Rm[9];
+    ba_map(T, X, Xc);
+    const double iz = 1.0 / Xc[2];
+    ba_q_to_R(T, Rm);
+    ba_jac_from_xc(Xc[0], Xc[1], iz, K4[0], K4[1], Rm, Ji, Jj);   // = ba_jacobians(T, K4, X, Ji, Jj)
     const double om = d.info[e];
     double rho0, w;
     ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
@@ -221,6 +224,14 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
   const int c = d.slot_cam[i];
   const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
   const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
+  if (d.camRK && lane < 12) {   // rotation matrix + focal lengths of the camera by pose slot: what ba_schur_row3 combines an observation's compact record with
+    double Rm[9];
+    ba_q_to_R(T, Rm);
+    double v = lane == 9 ? K4[0] : lane == 10 ? K4[1] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) v = lane == k ? Rm[k] : v;
+    d.camRK[12 * (size_t)i + lane] = v;
+  }
   double acc[32];   // 27 sums + padding for the halving butterfly
 #pragma unroll
   for (int k = 0; k < 32; k++) acc[k] = 0;
@@ -233,8 +244,9 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
     double Xc[3];
     ba_map(T, X, Xc);
     double Jj[12];
+    const double iz = 1.0 / Xc[2];
     {
-      const double x = Xc[0], y = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz, fx = K4[0], fy = K4[1];
+      const double x = Xc[0], y = Xc[1], iz2 = iz * iz, fx = K4[0], fy = K4[1];
       Jj[0] = x * y * iz2 * fx; Jj[1] = -(1 + (x * x * iz2)) * fx; Jj[2] = y * iz * fx; Jj[3] = -iz * fx; Jj[4] = 0; Jj[5] = x * iz2 * fx;
       Jj[6] = (1 + y * y * iz2) * fy; Jj[7] = -x * y * iz2 * fy; Jj[8] = -x * iz * fy; Jj[9] = 0; Jj[10] = -iz * fy; Jj[11] = y * iz2 * fy;
     }
@@ -242,6 +254,12 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
     double rho0, w;
     ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
     const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    if (d.E4) {   // what ba_schur_row3 re-derives this observation's Hpl block from (the values the landmark-side kernel computes for the same observation)
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v2d* E = reinterpret_cast<v2d*>(d.E4 + 4 * (size_t)s);
+      v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = iz; eb[1] = wom;
+      E[0] = ea; E[1] = eb;
+    }
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -600,6 +618,209 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
   ROW2_TICK(3)
   if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
 #undef ROW2_TICK
+}
+
+// The same row kernel on COMPACT observation records: an observation's Hpl block W = Jj^T (w Omega) Ji is a function of the landmark in the camera frame
+// (x, y, 1 / z), the weight and the camera's rotation and focal lengths, so a pair instance fetches 32 bytes (E4, camera-major) + the column camera's
+// 96 bytes (camRK, shared by the unit's 16 lanes) instead of 144 divergent bytes of the stored block.  ba_schur_row2 was bound by the address
+// processing of those nine divergent 16-byte loads per lane (one line look-up per lane and load: 3.8 us per 1024-lane pass on a CU); here it is two.  The
+// camera's own observations are read in camera-major order (contiguous) and re-derive exactly the stored block for Y and the diagonal block.
+__global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
+  extern __shared__ __attribute__((aligned(16))) double Ys[];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  constexpr int G = kRow2Group, UPW = kWave / G, NW = kRow2TPB / kWave;
+  const int per_xcd = gridDim.x >> 3;      // workgroup b runs on XCD b % 8: XCD x walks the contiguous row range [x * per, (x + 1) * per) (rows in flight share W_c rows)
+  const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (i >= d.Cp) return;
+  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;   // ne <= kRowMaxEdges < kRow2TPB: one observation per thread
+  long long tk0 = 0;
+  if (d.row_dbg && threadIdx.x == 0) tk0 = wall_clock64();
+#define ROW3_TICK(slot) { if (d.row_dbg && threadIdx.x == 0) { const long long tn_ = wall_clock64(); atomicAdd((unsigned long long*)(d.row_dbg + slot), (unsigned long long)(tn_ - tk0)); tk0 = tn_; } }
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int grp = lane / G, q = lane % G;
+  const int zrow = d.max_cam_edges;        // a zero row of Y behind the real ones: what the idle lanes of a unit multiply
+  const int n_dgrp = (ne + G - 1) / G;     // 16-observation groups of the diagonal partials
+  double* dpart = Ys + 18 * (size_t)(zrow + 1);                           // [ceil(max_cam_edges / 16)][27]
+  double* part = dpart + 27 * (size_t)((d.max_cam_edges + G - 1) / G);    // [row_units_max][36]
+  // the table entry and the index vectors of this wave's first block pass are requested before anything else: their round trips overlap the staging.
+  // (Measured and dropped: requesting the observation records first and the table entry behind them, with the loads made unconditional so that no
+  // branch end waits for them, and [D^-1 | b_l] as one 80-byte record per landmark: 5.8-6.0 us of staging per row instead of 4.9.)
+  const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
+  int n_s0 = 0, n_s1 = 0, n_slot = 0, n_j = 0;
+  if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
+  // ---- Y_e = W_e D^-1 of the camera's observations, one thread per observation; the same thread adds the observation's part of the diagonal block
+  //      (Y_e W_e^T, symmetric: entries r <= c) and of b_schur (Y_e b_l) ----
+  {
+    const int t = threadIdx.x;
+    double dacc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) dacc[k] = 0.0;
+    if (t < ne) {
+      const int pt = d.cam_pt[base + t];
+      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)(base + t));   // camera-major: the workgroup reads one contiguous range
+      const v2d* Dp = reinterpret_cast<const v2d*>(d.Dinv + 6 * (size_t)pt);
+      const v2d ea = Ep[0], eb = Ep[1];
+      v2d d2[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) d2[k] = Dp[k];
+      const double bl0 = d.bl[3 * (size_t)pt], bl1 = d.bl[3 * (size_t)pt + 1], bl2 = d.bl[3 * (size_t)pt + 2];
+      double wf[18], yf[18];
+      {   // W_e as the linearisation formed it (same expressions, no contraction: bit-identical to the stored block)
+        const double* rk = d.camRK + 12 * (size_t)i;
+        double Rm[9], Ji[6], Jj[12];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rm[k] = rk[k];
+        ba_jac_from_xc(ea[0], ea[1], eb[0], rk[9], rk[10], Rm, Ji, Jj);
+        const double wom = eb[1];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b = 0; b < 3; b++) wf[a * 3 + b] = (Jj[a] * Ji[b] + Jj[6 + a] * Ji[3 + b]) * wom;
+      }
+      const double D0 = d2[0][0], D1 = d2[0][1], D2 = d2[1][0], D3 = d2[1][1], D4 = d2[2][0], D5 = d2[2][1];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double a0 = wf[3 * r], a1 = wf[3 * r + 1], a2 = wf[3 * r + 2];
+        yf[3 * r + 0] = a0 * D0 + a1 * D1 + a2 * D2;
+        yf[3 * r + 1] = a0 * D1 + a1 * D3 + a2 * D4;
+        yf[3 * r + 2] = a0 * D2 + a1 * D4 + a2 * D5;
+      }
+      v2d* Yp = reinterpret_cast<v2d*>(Ys + 18 * (size_t)t);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { v2d v; v[0] = yf[2 * k]; v[1] = yf[2 * k + 1]; Yp[k] = v; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is read back three values at a time below (same thread): Y, W_e and the 27 sums do not fit 128 registers together
+      const double* Yr = Ys + 18 * (size_t)t;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};   // compact index of (r, c), r <= c: kTri[r] + c
+        const double y0 = Yr[3 * r], y1 = Yr[3 * r + 1], y2 = Yr[3 * r + 2];
+#pragma unroll
+        for (int c = r; c < 6; c++)
+          dacc[kTri[r] + c] = __builtin_fma(y2, wf[3 * c + 2], __builtin_fma(y1, wf[3 * c + 1], y0 * wf[3 * c]));
+        dacc[21 + r] = __builtin_fma(y2, bl2, __builtin_fma(y1, bl1, y0 * bl0));
+      }
+    }
+    if (wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
+      double t1[14], t2[7], t3[4], t4[2];
+      row2_halve<27>(dacc, t1, (q & 8) != 0, 8);
+      row2_halve<14>(t1, t2, (q & 4) != 0, 4);
+      row2_halve<7>(t2, t3, (q & 2) != 0, 2);
+      row2_halve<4>(t3, t4, (q & 1) != 0, 1);
+      int e0, cnt;
+      row2_range(27, q, &e0, &cnt);
+      const int g = threadIdx.x / G;
+      if (g < n_dgrp) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * (size_t)g + e0 + k] = t4[k];
+      }
+    }
+  }
+  if (threadIdx.x < 18) Ys[18 * (size_t)zrow + threadIdx.x] = 0.0;
+  __syncthreads();
+  ROW3_TICK(0)
+  // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
+  for (int p = wv; p * UPW < n_units; p += NW) {
+    const int uu = p * UPW + grp;
+    const int s0 = n_s0, s1 = n_s1, slot = n_slot, jc = n_j;
+    n_s0 = n_s1 = n_slot = n_j = 0;
+    if ((p + NW) * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + (p + NW) * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    // the table lists the units longest first, so group 0 of the pass sets the trip count of the wave
+    const int nit = __builtin_amdgcn_readfirstlane((s1 - s0 + G - 1) / G);
+    int ce_n = (s0 + q < s1) ? d.inst_cp[s0 + q] : 0;         // index vectors one iteration ahead of the records they address
+    int ar_n = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow;
+    int jq = jc;
+    for (int it = 0; it < nit; it++) {
+      const int ce = ce_n, ar = ar_n;
+      // the block's column camera: the same 96 bytes for the 16 lanes of the unit.  Requested every iteration, first (the index is laundered: left alone,
+      // the compiler hoists these loop-invariant loads out of the loop, has no registers for their 24 values and reloads them from scratch memory — extra
+      // dependent L2 round trips in every iteration)
+      asm volatile("" : "+v"(jq));
+      const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jq);
+      v2d r2[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) r2[k] = rk[k];
+      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce);
+      const v2d ea = Ep[0], eb = Ep[1];
+      const int sn = s0 + (it + 1) * G + q;
+      ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
+      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
+      const double* Yp = Ys + 18 * (size_t)ar;
+      // Y_a W_c^T with W_c = Jj^T (wom Ji) never formed: V = Y_a (wom Ji)^T is 6 x 2, then V Jj (two structural zeros).  With a = x / z, b = y / z:
+      //   wom Ji = -(wom / z) [fx (R_0 - a R_2) ; fy (R_1 - b R_2)]   (R_k: rows of the rotation matrix)
+      //   Jj     = [fx (a b, -(1 + a^2), b, -1/z, 0, a / z) ; fy (1 + b^2, -a b, -a, 0, -1/z, b / z)]
+      // (types_six_dof_expmap.cpp:196-226 regrouped: the products differ from the stored block's in the last bits only)
+      double wj0[3], wj1[3], pj[5], qj[5];
+      {
+        const double iz = eb[0], fx = r2[4][1], fy = r2[5][0];
+        const double a = ea[0] * iz, b = ea[1] * iz;
+        const double gx = -(iz * fx) * eb[1], gy = -(iz * fy) * eb[1];
+        const double R0[3] = {r2[0][0], r2[0][1], r2[1][0]}, R1[3] = {r2[1][1], r2[2][0], r2[2][1]}, R2[3] = {r2[3][0], r2[3][1], r2[4][0]};
+#pragma unroll
+        for (int c = 0; c < 3; c++) { wj0[c] = gx * __builtin_fma(-a, R2[c], R0[c]); wj1[c] = gy * __builtin_fma(-b, R2[c], R1[c]); }
+        const double fxa = fx * a, fyb = fy * b;
+        pj[0] = fxa * b; pj[1] = -__builtin_fma(fxa, a, fx); pj[2] = fx * b; pj[3] = -(fx * iz); pj[4] = fxa * iz;
+        qj[0] = __builtin_fma(fyb, b, fy); qj[1] = -(fyb * a); qj[2] = -(fy * a); qj[3] = -(fy * iz); qj[4] = fyb * iz;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; r++) {   // the Y row comes out of LDS three values at a time: 16 waves leave 128 registers per lane
+        const double y0 = Yp[3 * r], y1 = Yp[3 * r + 1], y2 = Yp[3 * r + 2];
+        const double v0 = __builtin_fma(y2, wj0[2], __builtin_fma(y1, wj0[1], y0 * wj0[0]));
+        const double v1 = __builtin_fma(y2, wj1[2], __builtin_fma(y1, wj1[1], y0 * wj1[0]));
+        acc[6 * r + 0] = __builtin_fma(v1, qj[0], __builtin_fma(v0, pj[0], acc[6 * r + 0]));
+        acc[6 * r + 1] = __builtin_fma(v1, qj[1], __builtin_fma(v0, pj[1], acc[6 * r + 1]));
+        acc[6 * r + 2] = __builtin_fma(v1, qj[2], __builtin_fma(v0, pj[2], acc[6 * r + 2]));
+        acc[6 * r + 3] = __builtin_fma(v0, pj[3], acc[6 * r + 3]);
+        acc[6 * r + 4] = __builtin_fma(v1, qj[3], acc[6 * r + 4]);
+        acc[6 * r + 5] = __builtin_fma(v1, qj[4], __builtin_fma(v0, pj[4], acc[6 * r + 5]));
+      }
+    }
+    double t1[18], t2[9], t3[5], t4[3];
+    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
+    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
+    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
+    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
+    int e0, cnt;
+    row2_range(36, q, &e0, &cnt);
+    if (uu < n_units) {
+      double* pu = part + 36 * (size_t)slot;
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
+    }
+  }
+  ROW3_TICK(1)   // (wave 0's share of the block passes)
+  __syncthreads();
+  ROW3_TICK(2)   // (waiting for the slowest wave)
+  // ---- final sums: per block over its units (slot = creation order: a block's units are consecutive); diagonal block + b_schur over the 16-observation groups ----
+  {
+    const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
+    constexpr int kGroups = kRow2TPB / 36;
+    if (grp36 < kGroups)
+      for (int b = d.rowblk_off[i] + grp36; b < d.rowblk_off[i + 1]; b += kGroups) {
+        double sum = 0;
+        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + d.unit_chunk - 1) / d.unit_chunk);
+        for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
+        d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
+      }
+    if (threadIdx.x >= kRow2TPB - 64 && threadIdx.x - (kRow2TPB - 64) < 27) {   // the last wave (it has no block of the loop above when the row is short)
+      // (measured and dropped: lane = 16-observation group and the 27 sums by the halving butterfly instead of this serial loop: 146 us against 143)
+      const int e = threadIdx.x - (kRow2TPB - 64);
+      double sum = 0;
+      for (int g = 0; g < n_dgrp; g++) sum += dpart[27 * (size_t)g + e];
+      if (e < 21) {
+        const int r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+        const int tri = r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15;
+        const int c = e - tri;
+        const double v = d.Hpp[36 * (size_t)i + 6 * r + c] - sum;
+        d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;   // the upper triangle is mirrored: S_ii is exactly symmetric
+      } else d.bs[6 * (size_t)i + e - 21] = d.bp[6 * (size_t)i + e - 21] - sum;
+    }
+  }
+  ROW3_TICK(3)
+  if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
+#undef ROW3_TICK
 }
 
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
@@ -2390,8 +2611,13 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
       else if (d.row_units_max) {
         const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
-        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
-        hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+        if (d.E4) {
+          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
+          hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+        } else {
+          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
+          hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+        }
       } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
     }
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
@@ -2780,15 +3006,18 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (cam_qt) {
-    std::vector<double> cam(7 * (size_t)ba->n_cam);
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(cam.data(), d.cam[ba->cur], cam.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < ba->Cp; i++) std::memcpy(cam_qt + 7 * (size_t)ba->slot_cam[i], &cam[7 * (size_t)ba->slot_cam[i]], 7 * sizeof(double));
-  }
-  if (pt_xyz && ba->Lp) {
-    // optimised landmarks into the caller's numbering on the device (landmarks without an active edge keep the values uploaded at create / reset),
-    // then ONE copy straight into the caller's array
+  const bool want_pt = pt_xyz && ba->Lp, want_chi2 = chi2_per_edge && ba->Eloc, want_map = want_chi2 && ba->loc_edge_orig.empty();
+  // everything is copied into the context's pinned block behind the device work (one synchronisation), then placed into the caller's arrays
+  const size_t b_cam = cam_qt ? 7 * (size_t)ba->n_cam * sizeof(double) : 0, b_pt = want_pt ? 3 * (size_t)ba->n_pt * sizeof(double) : 0,
+               b_c2 = want_chi2 ? (size_t)ba->Eloc * sizeof(double) : 0;
+  void* pin = nullptr;
+  RC(ccm_pin_scratch(ctx, b_cam + b_pt + b_c2 + 1024, &pin));
+  double* h_cam = (double*)pin;
+  double* h_pt = (double*)((char*)pin + ((b_cam + 255) & ~(size_t)255));
+  double* h_c2 = (double*)((char*)h_pt + ((b_pt + 255) & ~(size_t)255));
+  if (cam_qt) CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_cam, d.cam[ba->cur], b_cam, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_pt) {
+    // optimised landmarks into the caller's numbering on the device (landmarks without an active edge keep the values uploaded at create / reset)
     const double* src = d.pt[ba->cur];
     if (ba->nranks > 1) {
       CCM_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pt_full, 0, 3 * (size_t)ba->Lp * sizeof(double), ctx->stream));
@@ -2797,22 +3026,23 @@ extern "C" int ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, doubl
       src = ba->d_pt_full;
     }
     RC(ccm_ba_points_to_raw_order(ba, src));
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(pt_xyz, ba->d_raw_pt, 3 * (size_t)ba->n_pt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_pt, ba->d_raw_pt, b_pt, hipMemcpyDeviceToHost, ctx->stream));
   }
-  if (chi2_per_edge && ba->Eloc) {
-    // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors,
-    // even when that trial was rejected).  Only the own (shard-local) active edges are written; inactive
-    // (level != 0) edges keep whatever the caller passed in, as g2o leaves their _error untouched.
-    std::vector<double> c2(ba->Eloc);
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(c2.data(), d.edge_chi2, c2.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (ba->loc_edge_orig.empty()) {   // local edge -> the caller's edge index (built on the device, fetched on first use)
+  if (want_chi2) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_c2, d.edge_chi2, b_c2, hipMemcpyDeviceToHost, ctx->stream));
+    if (want_map) {   // local edge -> the caller's edge index (built on the device, fetched on first use)
       ba->loc_edge_orig.resize(ba->Eloc);
       CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->loc_edge_orig.data(), ba->d_loc_edge_orig, (size_t)ba->Eloc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
-    CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int k = 0; k < ba->Eloc; k++) chi2_per_edge[ba->loc_edge_orig[k]] = c2[k];
   }
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (cam_qt)   // only the poses that were vertices of the problem
+    for (int i = 0; i < ba->Cp; i++) std::memcpy(cam_qt + 7 * (size_t)ba->slot_cam[i], h_cam + 7 * (size_t)ba->slot_cam[i], 7 * sizeof(double));
+  if (want_pt) std::memcpy(pt_xyz, h_pt, b_pt);
+  if (want_chi2)
+    // e->chi2(): value of the last evaluated LM trial (g2o keeps _error of the last computeActiveErrors, even when that trial was rejected).  Only the
+    // own (shard-local) active edges are written; inactive (level != 0) edges keep whatever the caller passed in, as g2o leaves their _error untouched.
+    for (int k = 0; k < ba->Eloc; k++) chi2_per_edge[ba->loc_edge_orig[k]] = h_c2[k];
   return CCM_OK;
 }
 

@@ -377,6 +377,16 @@ __global__ void bb_inst_rank(const int* inst_a, const int* rank, int n, int* ins
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < n) inst_al[s] = rank[inst_a[s]];
 }
+// position of every observation in camera-major order (the order of cam_edge; the caller presets -1: observations of fixed cameras stay there), then per
+// pair instance the position of its column-side observation
+__global__ void bb_edge_cpos(const int* cam_off, const int* cam_edge, int* cpos) {
+  const int i = blockIdx.x;
+  for (int s = cam_off[i] + threadIdx.x; s < cam_off[i + 1]; s += blockDim.x) cpos[cam_edge[s]] = s;
+}
+__global__ void bb_inst_cpos(const int* inst_c, const int* cpos, int n, int* inst_cp) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) inst_cp[s] = cpos[inst_c[s]];
+}
 
 // coarse level: every S block (diagonal first, then the off-diagonal ones in block order) with the key of its aggregate pair
 __global__ void bb_coarse_keys(int Cp, int nOff, const int* bi, const int* bj, int na, unsigned* keys, int* vals) {
@@ -466,8 +476,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   Tmp tmp{ctx, {}};
   auto body = [&]() -> int {
     BaDev& d = ba->d;
-    // ---- the caller's flat arrays -> HBM (hipMemcpyDefault: the arrays of ccm_ba_problem may live in host OR device memory).  Index arrays first: the
-    // structure kernels queue behind them while the host stages the big ones ----
+    // ---- the caller's flat arrays -> HBM (hipMemcpyDefault: the arrays of ccm_ba_problem may live in host OR device memory; staging plain host arrays
+    // through a pinned block first was measured and is slower than the runtime's own pageable path: 3.1 vs 2.5 ms on the 4-agent map).  Index arrays first:
+    // the structure kernels queue behind them while the host stages the big ones ----
     int *r_ecam = nullptr, *r_ept = nullptr; uint8_t *r_lvl = nullptr, *r_fixed = nullptr;
     double *r_obs = nullptr, *r_info = nullptr, *dK = nullptr;
     BB_RC(tmp.get((size_t)n_edge, &r_ecam)); BB_RC(tmp.get((size_t)n_edge, &r_ept));
@@ -658,6 +669,18 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (Cp) hipLaunchKernelGGL(bb_edge_rank, dim3(Cp), dim3(kB), 0, st, (const int*)p_cam_off, (const int*)p_cam_edge, p_rank);
     if (ba->n_inst) hipLaunchKernelGGL(bb_inst_rank, dim3(grid_for(ba->n_inst)), dim3(kB), 0, st, (const int*)d_inst_a, (const int*)p_rank, (int)ba->n_inst, p_al);
     d.inst_al = p_al;
+    // ---- compact observation records of the row kernel (ba_schur_row3): camera-major positions ----
+    d.E4 = nullptr; d.camRK = nullptr; d.inst_cp = nullptr; d.blk_j = ba->d_blk_j + Cp;
+    static const bool row3_on = !(getenv("CCM_BA_ROW") && atoi(getenv("CCM_BA_ROW")) == 2);
+    if (row3_on && Cp && Eloc) {
+      int *p_cpos = nullptr, *p_icp = nullptr; double *p_e4 = nullptr, *p_rk = nullptr;
+      BB_RC(tmp.get((size_t)Eloc, &p_cpos)); BB_RC(keep_get(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_icp));
+      BB_RC(keep_get(ba, 4 * (size_t)Eloc, &p_e4, true)); BB_RC(keep_get(ba, 12 * (size_t)Cp, &p_rk, true));
+      BB_HIP(hipMemsetAsync(p_cpos, 0xFF, (size_t)Eloc * sizeof(int), st));
+      hipLaunchKernelGGL(bb_edge_cpos, dim3(Cp), dim3(kB), 0, st, (const int*)p_cam_off, (const int*)p_cam_edge, p_cpos);
+      if (ba->n_inst) hipLaunchKernelGGL(bb_inst_cpos, dim3(grid_for(ba->n_inst)), dim3(kB), 0, st, (const int*)d_inst_c, (const int*)p_cpos, (int)ba->n_inst, p_icp);
+      d.E4 = p_e4; d.camRK = p_rk; d.inst_cp = p_icp;
+    }
     // ---- coarse level: block lists of Ac = P^T S P by aggregate pair ----
     const int na = ccm_div_up(std::max(Cp, 1), kAgg), ncoarse = 6 * (na + 1), Nc = ((ncoarse + 63) / 64) * 64;   // na camera intervals, na + 1 coarse nodes
     const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && 7 * (size_t)Nc + 6 * (size_t)pers_grid_want + 320 <= (size_t)kCluN * kCluN / 2 &&

@@ -141,14 +141,11 @@ BA_HD double ba_residual(const BaPose& T, const double K[4], const double X[3], 
   return Xc[2];
 }
 
-// Jacobians: Ji (2x3, d e/d point) and Jj (2x6, d e/d pose [rot, trans])
-BA_HD void ba_jacobians(const BaPose& T, const double K[4], const double X[3], double Ji[6], double Jj[12]) {
-  double Xc[3];
-  ba_map(T, X, Xc);
-  const double x = Xc[0], y = Xc[1], fx = K[0], fy = K[1];
-  const double iz = 1.0 / Xc[2], iz2 = iz * iz;   // one reciprocal for the ~12 divisions by z / z^2 of the reference formulas
-  double R[9];
-  ba_q_to_R(T, R);
+// Jacobians: Ji (2x3, d e/d point) and Jj (2x6, d e/d pose [rot, trans]) from the camera-frame point (x, y, 1 / z), the focal lengths and the rotation
+// matrix.  The row Schur kernel re-derives the Hpl block of a PARTNER observation from these four numbers + the partner camera's 11 instead of reading
+// its 18 stored values (ba.hip: ba_schur_row3), with the very expressions ba_jacobians evaluates.
+BA_HD void ba_jac_from_xc(double x, double y, double iz, double fx, double fy, const double R[9], double Ji[6], double Jj[12]) {
+  const double iz2 = iz * iz;
   const double tmp[6] = {fx, 0, -x * iz * fx, 0, fy, -y * iz * fy};
   for (int r = 0; r < 2; r++)
     for (int c = 0; c < 3; c++) {
@@ -158,6 +155,14 @@ BA_HD void ba_jacobians(const BaPose& T, const double K[4], const double X[3], d
     }
   Jj[0] = x * y * iz2 * fx; Jj[1] = -(1 + (x * x * iz2)) * fx; Jj[2] = y * iz * fx; Jj[3] = -iz * fx; Jj[4] = 0; Jj[5] = x * iz2 * fx;
   Jj[6] = (1 + y * y * iz2) * fy; Jj[7] = -x * y * iz2 * fy; Jj[8] = -x * iz * fy; Jj[9] = 0; Jj[10] = -iz * fy; Jj[11] = y * iz2 * fy;
+}
+BA_HD void ba_jacobians(const BaPose& T, const double K[4], const double X[3], double Ji[6], double Jj[12]) {
+  double Xc[3];
+  ba_map(T, X, Xc);
+  const double iz = 1.0 / Xc[2];   // one reciprocal for the ~12 divisions by z / z^2 of the reference formulas
+  double R[9];
+  ba_q_to_R(T, R);
+  ba_jac_from_xc(Xc[0], Xc[1], iz, K[0], K[1], R, Ji, Jj);
 }
 
 // pose-only Jacobian (EdgeSE3ProjectXYZOnlyPose::linearizeOplus, types_six_dof_expmap.cpp:266-288)

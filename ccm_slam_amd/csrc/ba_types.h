@@ -9,7 +9,8 @@ constexpr uint32_t kTransposeBit = 0x80000000u;
 constexpr int kRowMaxEdges = 1000;   // 144 B of LDS per observation of the camera
 constexpr int kRow2TPB = 1024;       // lane-per-instance row kernel: 16 waves, i.e. 128 VGPRs per lane (36-42 accumulators + the W_c row; the Y row is read three values at a time)
 constexpr int kRow2Group = 16;       // lanes that share one work unit (block chunk); 4 units per wave pass
-constexpr int kRow2Chunk = 32;       // pair instances per work unit: <= 2 per lane (measured on the 4-agent map: 32: 211 us, 64: 219, 128: 271 — the passes are latency chains, so short ones win)
+constexpr int kRow2Chunk = 64;       // pair instances per work unit: <= 4 per lane (measured on the 4-agent map with ba_schur_row3: 16: 164 us, 32: 143, 48: 139, 64: 137, 96: 139;
+                                     // with ba_schur_row2, whose passes were bound by their divergent loads: 32: 211 us, 64: 219, 128: 271)
 constexpr int kClu = 16;             // cameras per preconditioner cluster
 constexpr int kCluN = 6 * kClu;      // 96 unknowns
 constexpr int kSpmvTPB = 1024;
@@ -70,6 +71,11 @@ struct BaDev {
   const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
   int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
   int unit_chunk;            // pair instances per work unit (kRow2Chunk)
+  // compact form of the Hpl blocks for the row kernel (ba_schur_row3; E4 == nullptr: ba_schur_row2 reads the stored blocks instead)
+  double* E4;                // [cam_off[Cp]][4] per observation of a free camera, CAMERA-MAJOR (the order of cam_edge): x, y, 1 / z of the landmark in the camera frame, w * information
+  double* camRK;             // [Cp][12] per pose slot: rotation matrix (row-major), fx, fy, 0
+  const int* inst_cp;        // [n_inst] ed_cpos of the pair instance's block-col observation
+  const int* blk_j;          // [nOff] column pose slot of every off-diagonal block
   long long* row_dbg;        // nullable (CCM_BA_ROW_DBG): [8] phase clocks of the row kernel summed over its workgroups (10 ns ticks) + launches
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <cstring>
 #include <string>
 #include <vector>
 #include <mutex>

@@ -14,7 +14,7 @@ from ccm_slam_amd._lib import lib
 
 pytestmark = pytest.mark.gpu
 
-KCLU, KAGG, CHUNK, TPB = 16, 32, 32, 256
+KCLU, KAGG, CHUNK, TPB = 16, 32, 64, 256
 TBIT = np.uint32(0x80000000)
 _HOOKS = None
 
