@@ -165,11 +165,17 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
     double rho0, w;
     ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
     const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    if (d.E4L && d.ed_cslot[e] >= 0) {   // the compact record in landmark-major order (ba_backsub_chi2_e): coalesced, 32 bytes instead of the 144 of the block
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v2d* E = reinterpret_cast<v2d*>(d.E4L + 4 * (size_t)e);
+      v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = iz; eb[1] = wom;
+      E[0] = ea; E[1] = eb;
+    }
     hb[t][0] = Ji[0] * o0 + Ji[3] * o1; hb[t][1] = Ji[1] * o0 + Ji[4] * o1; hb[t][2] = Ji[2] * o0 + Ji[5] * o1;
     hb[t][3] = (Ji[0] * Ji[0] + Ji[3] * Ji[3]) * wom; hb[t][4] = (Ji[0] * Ji[1] + Ji[3] * Ji[4]) * wom;
     hb[t][5] = (Ji[0] * Ji[2] + Ji[3] * Ji[5]) * wom; hb[t][6] = (Ji[1] * Ji[1] + Ji[4] * Ji[4]) * wom;
     hb[t][7] = (Ji[1] * Ji[2] + Ji[4] * Ji[5]) * wom; hb[t][8] = (Ji[2] * Ji[2] + Ji[5] * Ji[5]) * wom;
-    if (d.ed_cslot[e] >= 0) {
+    if (!d.w_free && d.ed_cslot[e] >= 0) {
       double* W = d.W + 18 * (size_t)e;
 #pragma unroll
       for (int i = 0; i < 6; i++)
@@ -620,6 +626,24 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
 #undef ROW2_TICK
 }
 
+// Factors of an observation's Hpl block W = Jj^T (wom Ji) from its compact record (x, y, 1 / z | wom) and its camera's record (rotation matrix rows
+// R_0 R_1 R_2, fx, fy), W itself never formed.  With a = x / z, b = y / z:
+//   wom Ji = -(wom / z) [fx (R_0 - a R_2) ; fy (R_1 - b R_2)]                                                  -> wj0[3], wj1[3]
+//   Jj     = [fx (a b, -(1 + a^2), b, -1/z, 0, a / z) ; fy (1 + b^2, -a b, -a, 0, -1/z, b / z)]                 -> pj[5] (column 4 is zero), qj[5] (column 3 is zero)
+// (types_six_dof_expmap.cpp:196-226 regrouped: products formed from these differ from those of the stored block in the last bits only)
+typedef double ba_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ba_compact_factors(ba_v2d ea, ba_v2d eb, const ba_v2d (&r2)[6], double (&wj0)[3], double (&wj1)[3], double (&pj)[5], double (&qj)[5]) {
+  const double iz = eb[0], fx = r2[4][1], fy = r2[5][0];
+  const double a = ea[0] * iz, b = ea[1] * iz;
+  const double gx = -(iz * fx) * eb[1], gy = -(iz * fy) * eb[1];
+  const double R0[3] = {r2[0][0], r2[0][1], r2[1][0]}, R1[3] = {r2[1][1], r2[2][0], r2[2][1]}, R2[3] = {r2[3][0], r2[3][1], r2[4][0]};
+#pragma unroll
+  for (int c = 0; c < 3; c++) { wj0[c] = gx * __builtin_fma(-a, R2[c], R0[c]); wj1[c] = gy * __builtin_fma(-b, R2[c], R1[c]); }
+  const double fxa = fx * a, fyb = fy * b;
+  pj[0] = fxa * b; pj[1] = -__builtin_fma(fxa, a, fx); pj[2] = fx * b; pj[3] = -(fx * iz); pj[4] = fxa * iz;
+  qj[0] = __builtin_fma(fyb, b, fy); qj[1] = -(fyb * a); qj[2] = -(fy * a); qj[3] = -(fy * iz); qj[4] = fyb * iz;
+}
+
 // The same row kernel on COMPACT observation records: an observation's Hpl block W = Jj^T (w Omega) Ji is a function of the landmark in the camera frame
 // (x, y, 1 / z), the weight and the camera's rotation and focal lengths, so a pair instance fetches 32 bytes (E4, camera-major) + the column camera's
 // 96 bytes (camRK, shared by the unit's 16 lanes) instead of 144 divergent bytes of the stored block.  ba_schur_row2 was bound by the address
@@ -748,22 +772,9 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
       ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
       ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
       const double* Yp = Ys + 18 * (size_t)ar;
-      // Y_a W_c^T with W_c = Jj^T (wom Ji) never formed: V = Y_a (wom Ji)^T is 6 x 2, then V Jj (two structural zeros).  With a = x / z, b = y / z:
-      //   wom Ji = -(wom / z) [fx (R_0 - a R_2) ; fy (R_1 - b R_2)]   (R_k: rows of the rotation matrix)
-      //   Jj     = [fx (a b, -(1 + a^2), b, -1/z, 0, a / z) ; fy (1 + b^2, -a b, -a, 0, -1/z, b / z)]
-      // (types_six_dof_expmap.cpp:196-226 regrouped: the products differ from the stored block's in the last bits only)
+      // Y_a W_c^T with W_c = Jj^T (wom Ji) never formed: V = Y_a (wom Ji)^T is 6 x 2, then V Jj (two structural zeros): 36 + 60 multiply-adds
       double wj0[3], wj1[3], pj[5], qj[5];
-      {
-        const double iz = eb[0], fx = r2[4][1], fy = r2[5][0];
-        const double a = ea[0] * iz, b = ea[1] * iz;
-        const double gx = -(iz * fx) * eb[1], gy = -(iz * fy) * eb[1];
-        const double R0[3] = {r2[0][0], r2[0][1], r2[1][0]}, R1[3] = {r2[1][1], r2[2][0], r2[2][1]}, R2[3] = {r2[3][0], r2[3][1], r2[4][0]};
-#pragma unroll
-        for (int c = 0; c < 3; c++) { wj0[c] = gx * __builtin_fma(-a, R2[c], R0[c]); wj1[c] = gy * __builtin_fma(-b, R2[c], R1[c]); }
-        const double fxa = fx * a, fyb = fy * b;
-        pj[0] = fxa * b; pj[1] = -__builtin_fma(fxa, a, fx); pj[2] = fx * b; pj[3] = -(fx * iz); pj[4] = fxa * iz;
-        qj[0] = __builtin_fma(fyb, b, fy); qj[1] = -(fyb * a); qj[2] = -(fy * a); qj[3] = -(fy * iz); qj[4] = fyb * iz;
-      }
+      ba_compact_factors(ea, eb, r2, wj0, wj1, pj, qj);
 #pragma unroll
       for (int r = 0; r < 6; r++) {   // the Y row comes out of LDS three values at a time: 16 waves leave 128 registers per lane
         const double y0 = Yp[3 * r], y1 = Yp[3 * r + 1], y2 = Yp[3 * r + 2];
@@ -2276,7 +2287,22 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, doub
     if (t < ne) {
       const int e = e0 + t, cs = d.ed_cslot[e];
       double a0 = 0, a1 = 0, a2 = 0;
-      if (cs >= 0) {
+      if (cs >= 0 && d.w_free) {
+        // W^T dx = (wom Ji)^T (Jj dx) from the compact record and the camera's record: 32 coalesced bytes + 96 bytes of a 192 KB table instead of 144
+        const ba_v2d* Ep = reinterpret_cast<const ba_v2d*>(d.E4L + 4 * (size_t)e);
+        const ba_v2d* rk = reinterpret_cast<const ba_v2d*>(d.camRK + 12 * (size_t)cs);
+        const double* xp = d.x + 6 * (size_t)cs;
+        const ba_v2d ea = Ep[0], eb = Ep[1];
+        ba_v2d r2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) r2[k] = rk[k];
+        double wj0[3], wj1[3], pj[5], qj[5];
+        ba_compact_factors(ea, eb, r2, wj0, wj1, pj, qj);
+        const double x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3], x4 = xp[4], x5 = xp[5];
+        const double u0 = __builtin_fma(pj[4], x5, __builtin_fma(pj[3], x3, __builtin_fma(pj[2], x2, __builtin_fma(pj[1], x1, pj[0] * x0))));
+        const double u1 = __builtin_fma(qj[4], x5, __builtin_fma(qj[3], x4, __builtin_fma(qj[2], x2, __builtin_fma(qj[1], x1, qj[0] * x0))));
+        a0 = __builtin_fma(wj1[0], u1, wj0[0] * u0); a1 = __builtin_fma(wj1[1], u1, wj0[1] * u0); a2 = __builtin_fma(wj1[2], u1, wj0[2] * u0);
+      } else if (cs >= 0) {
         const double* W = d.W + 18 * (size_t)e;
         const double* xp = d.x + 6 * (size_t)cs;
 #pragma unroll
@@ -2385,6 +2411,34 @@ int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
 // reduced systems with at most this many off-diagonal blocks use the one-workgroup-per-block Schur kernel; above, the row kernel (which also forms the
 // diagonal blocks and b_schur).  CCM_BA_ROW_MIN_BLOCKS overrides (experiments).
 static inline int row_min_blocks() { static const int v = getenv("CCM_BA_ROW_MIN_BLOCKS") ? atoi(getenv("CCM_BA_ROW_MIN_BLOCKS")) : 256; return v; }
+
+// S and b_schur of the current linearisation and D^-1 (one rank's part): the row kernel on large maps (it also forms the diagonal blocks and b_schur), the
+// per-block kernels otherwise.  Also what the test hooks below call, so that they see the kernels the LM loop runs.
+static int launch_schur(ccm_ba* ba) {
+  ccm_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  if (!d.Cp) return CCM_OK;
+  if (!(d.nOff > row_min_blocks() && d.row_units_max)) {   // the row kernel also forms the diagonal blocks and b_schur
+    ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
+    hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
+  }
+  if (d.nOff) {
+    ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
+    if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
+    else if (d.row_units_max) {
+      const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
+      if (d.E4) {
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+      } else {
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+      }
+    } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
 
 #define RC(x) do { int _rc = (x); if (_rc != CCM_OK) return _rc; } while (0)
 
@@ -2602,24 +2656,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   bool small_path = false, pers_trial = false, pers_launch_failed = false;
   int small_flags[4] = {0, 0, 0, 0};
   if (d.Cp) {
-    if (!(d.nOff > row_min_blocks() && d.row_units_max)) {   // the row kernel also forms the diagonal blocks and b_schur
-      ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_DIAG);
-      hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
-    }
-    if (d.nOff) {
-      ccm_prof_scope ps(ctx, CCM_K_BA_SCHUR_OFF);
-      if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
-      else if (d.row_units_max) {
-        const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
-        if (d.E4) {
-          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
-          hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
-        } else {
-          CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
-          hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
-        }
-      } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
-    }
+    RC(launch_schur(ba));
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
     // ---- PCG ----
     static const double tol_default = getenv("CCM_BA_PCG_TOL") ? atof(getenv("CCM_BA_PCG_TOL")) : 1e-8;   // experiments only; the parity tests run at 1e-8
@@ -2798,8 +2835,7 @@ extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* A
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   RC(build_system(ba));
   if (d.Lloc) hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
-  hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
-  if (d.nOff) hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
+  RC(launch_schur(ba));
   // the inverse destroys d_cA: assemble twice
   RC(coarse_build(ba, lambda));
   std::vector<double> buf(Nc * Nc);
@@ -2825,14 +2861,7 @@ extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* o
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   RC(build_system(ba));
   if (d.Lloc) hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
-  if (d.Cp) {
-    hipLaunchKernelGGL(ba_schur_diag, dim3(d.n_wg_wave4), dim3(kTPB), 0, ctx->stream, d);
-    if (d.nOff) {
-      if (d.nOff <= 8192) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
-      else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
-    }
-  }
-  CCM_HIP_CHECK(ctx, hipGetLastError());
+  RC(launch_schur(ba));
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(out, ba->d_red, ba->red_count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;

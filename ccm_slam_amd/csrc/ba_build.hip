@@ -751,7 +751,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
 #define AL(field, n, T) { T* _p = nullptr; BB_RC(keep_get<T>(ba, (n), &_p, true)); d.field = _p; }
     AL(cam[0], 7 * (size_t)n_cam, double) AL(cam[1], 7 * (size_t)n_cam, double)
     AL(pt[0], 3 * (size_t)Lloc, double) AL(pt[1], 3 * (size_t)Lloc, double)
-    AL(W, 18 * (size_t)Eloc, double) AL(Hll, 6 * (size_t)Lloc, double) AL(bl, 3 * (size_t)Lloc, double)
+    // the Hpl blocks (144 bytes per observation) exist only where a kernel reads them: with the row kernel on compact records and the edge-parallel
+    // landmark kernels every consumer re-derives them (32 bytes per observation in landmark-major order for the back-substitution)
+    d.E4L = nullptr;
+    d.w_free = (d.E4 && d.chunk_off && d.unit_tab && nOff > row_min_blocks() && !getenv("CCM_BA_KEEP_W")) ? 1 : 0;
+    if (d.w_free) { double* p_l = nullptr; BB_RC(keep_get(ba, 4 * (size_t)Eloc, &p_l, true)); d.E4L = p_l; }
+    AL(W, d.w_free ? 1 : 18 * (size_t)Eloc, double) AL(Hll, 6 * (size_t)Lloc, double) AL(bl, 3 * (size_t)Lloc, double)
     AL(Dinv, 6 * (size_t)Lloc, double) AL(dl, 3 * (size_t)Lloc, double) AL(Hpp, 36 * (size_t)Cp, double) AL(bp, 6 * (size_t)Cp, double)
     AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
     AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double)

@@ -73,6 +73,10 @@ struct BaDev {
   int unit_chunk;            // pair instances per work unit (kRow2Chunk)
   // compact form of the Hpl blocks for the row kernel (ba_schur_row3; E4 == nullptr: ba_schur_row2 reads the stored blocks instead)
   double* E4;                // [cam_off[Cp]][4] per observation of a free camera, CAMERA-MAJOR (the order of cam_edge): x, y, 1 / z of the landmark in the camera frame, w * information
+  double* E4L;               // [Eloc][4] the same four numbers in LANDMARK-major order (the order of the edge arrays), written by the landmark-side linearisation;
+                             // nullptr unless w_free
+  int w_free;                // the Hpl blocks are never stored: every kernel of the handle's path derives them from E4 / E4L + camRK (large maps: row kernel +
+                             // edge-parallel landmark kernels); 0: W is written and the fallback Schur kernels read it
   double* camRK;             // [Cp][12] per pose slot: rotation matrix (row-major), fx, fy, 0
   const int* inst_cp;        // [n_inst] ed_cpos of the pair instance's block-col observation
   const int* blk_j;          // [nOff] column pose slot of every off-diagonal block
