@@ -843,8 +843,8 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
 // PCG iteration the same workgroup applies z_c = W r_c (dense 96x96 mat-vec).
 
 // weight of camera slot k towards the SECOND node of its interval (the first one gets 1 - t): the coarse space interpolates the rigid-body twists of
-// nodes placed every kAgg cameras linearly in the camera index (hat functions)
-__device__ __forceinline__ double coarse_hat_t(int k) { return ((double)(k % kAgg) + 0.5) * (1.0 / (double)kAgg); }
+// nodes placed every `agg` cameras linearly in the camera index (hat functions)
+__device__ __forceinline__ double coarse_hat_t(int k, int agg) { return ((double)(k % agg) + 0.5) * (1.0 / (double)agg); }
 
 // cluster part of the coarse restriction P^T r: 6 values for the first node of the cluster's interval, 6 for the second.  The 6 products of every
 // (camera, component) go through LDS and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
@@ -860,7 +860,7 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
   if (t < 12) {
     const int cc = t % 6, second = t / 6;
     double sv = 0;
-    for (int q = 0; q < m; q++) { const double w1 = coarse_hat_t(s0 + q / 6); sv += (second ? w1 : 1.0 - w1) * prod[q * 6 + cc]; }
+    for (int q = 0; q < m; q++) { const double w1 = coarse_hat_t(s0 + q / 6, d.agg); sv += (second ? w1 : 1.0 - w1) * prod[q * 6 + cc]; }
     d.mk_cpart[12 * (size_t)c + t] = sv;
   }
 }
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
   const int m = 6 * (s1 - s0);
   if (t < m) {
     const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
-    const double w1 = coarse_hat_t(s0 + t / 6), w0 = 1.0 - w1;
+    const double w1 = coarse_hat_t(s0 + t / 6, d.agg), w0 = 1.0 - w1;
     double zc = 0;
 #pragma unroll
     for (int cc = 0; cc < 6; cc++) zc += P[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
@@ -1109,16 +1109,19 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
 
 // ---- coarse level of the two-level preconditioner ------------------------------------------------------------------
 // Cluster block-Jacobi cannot see the smooth error modes of a long trajectory (rigid drifts of whole map sections), so the
-// CG iteration count grows with the map.  Coarse space: one rigid-body twist (6 unknowns) per NODE, nodes placed every kAgg
+// CG iteration count grows with the map.  Coarse space: one rigid-body twist (6 unknowns) per NODE, nodes placed every `agg` (BaDev::agg: 16 or 32)
 // consecutive cameras, interpolated LINEARLY in the camera index between the two nodes of a camera's interval (hat functions:
-// camera k of interval a takes (1 - t) xi_a + t xi_a+1, t = (k % kAgg + 1/2) / kAgg) and prolongated to camera k by the adjoint
+// camera k of interval a takes (1 - t) xi_a + t xi_a+1, t = (k % agg + 1/2) / agg) and prolongated to camera k by the adjoint
 // P_k = Ad(T_cw,k) (a world-frame twist xi moves camera k by the left perturbation Ad(T_cw) xi).  Ac = P^T (S + lambda I) P is dense and
-// small (6 (Cp / kAgg + 1) unknowns, 384 for the 4-agent map); its explicit inverse is formed by the tile kernels of dense_chol.hip and the
+// small (6 (Cp / agg + 1) unknowns, 756 for the 4-agent map with intervals of 16); its explicit inverse is formed by the tile kernels of dense_chol.hip and the
 // persistent PCG adds P Ac^-1 P^T r to the cluster-Jacobi term.  Round 2 used piecewise-CONSTANT twists per aggregate (same size of Ac); offline
 // on a 1000-keyframe 4-agent system (same matrices, CG to 1e-8): cluster-Jacobi alone 357 iterations at lambda 0.3, + constant aggregates 136,
 // + hats 82 (lambda 3: 346 / 116 / 74; lambda 30: 269 / 83 / 59) — a continuous interpolant represents the smooth drift modes that a
 // step function can only follow with its jumps.
-constexpr int kCoarseOnIters = 80, kCoarseOffIters = 35;   // a coarse build (0.38 ms) is worth ~35 CG iterations
+// hysteresis of the adaptive switch (iterations of the previous solve): intervals of 32 cameras: a coarse build (0.38 ms) is worth ~35 CG iterations; the
+// finer spaces converge in fewer iterations with the level ON, so their thresholds sit lower (with 80 / 35 a 16-camera space switches itself off after every
+// good solve: 2391 instead of 779 CG iterations per call on the 3-agent map; swept on the 3- and 4-agent maps: 40 / 15)
+constexpr int kCoarseOnIters = 80, kCoarseOffIters = 35, kCoarseOnItersFine = 40, kCoarseOffItersFine = 15;
 
 __global__ void ba_coarse_P(BaDev d, int cur, double* Pm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1202,7 +1205,7 @@ __global__ __launch_bounds__(kCoarseTPB) void ba_coarse_assemble(BaDev d, const 
         m += tq * Pj[q * 6 + c];
       }
       const double mt = __shfl(m, c * 6 + r, kWave);
-      const double ti = coarse_hat_t(ci[u]), tj = coarse_hat_t(cj[u]);
+      const double ti = coarse_hat_t(ci[u], d.agg), tj = coarse_hat_t(cj[u], d.agg);
       const double wi[2] = {1.0 - ti, ti}, wj[2] = {1.0 - tj, tj};
       const bool both = (code[u] & 1) != 0;   // off-diagonal S block inside one interval: its mirror image belongs to the same pair
 #pragma unroll
@@ -1791,11 +1794,16 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   }
   const bool coarse = a.Ainv != nullptr;
   const int Nc = a.Nc, nca = 6 * (a.na + 1);
-  float* ainv_l = reinterpret_cast<float*>(A + N * (N / 2));   // [12][Nc] f32
-  double* rco = A + N * (N / 2) + 6 * Nc;    // [Nc]
+  float* ainv_l = reinterpret_cast<float*>(A + N * (N / 2));   // [12][Nc] f32: up to the whole half (Nc <= 768: intervals of 16 cameras on the 4-agent map)
+  // coarse residual | own P_k | y of the two nodes: behind the staged structure in the Li region (dead once W is formed; the structure lists that move in
+  // below end at pl + 6 kPersColCap + 256)
+  double* rco = Li + (32 + 2 * kPersIdxCap + kPersColCap) / 2 + 6 * kPersColCap + 256;   // [Nc]
   double* pown = rco + Nc;                   // [8][36]
   double* ypart = pown + 8 * 36;             // [12]
-  const int agg = u / kAggUnits;             // interval of the unit's cameras (kAgg is a multiple of the 8 cameras of a unit): nodes agg and agg + 1
+  static_assert((32 + 2 * kPersIdxCap + kPersColCap) % 2 == 0 && (32 + 2 * kPersIdxCap + kPersColCap) / 2 + 6 * kPersColCap + 256 + 768 + 8 * 36 + 12 <= kCluN * kCluN,
+                "coarse vectors do not fit behind the staged structure");
+  const int aggu = d.agg >> 3;               // units per interval (an interval is a multiple of the 8 cameras of a unit)
+  const int agg = u / aggu;                  // interval of the unit's cameras: nodes agg and agg + 1
   if (coarse) {
     for (int e = t; e < 12 * Nc; e += kPersTPB) ainv_l[e] = has ? (float)a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0f;
     for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;
@@ -1818,7 +1826,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
 #pragma unroll
         for (int rr = 0; rr < 6; rr++) sv += pown[kk * 36 + rr * 6 + cc] * vec[6 * kk + rr];
       }
-      const double w1 = coarse_hat_t(8 * u + kk);
+      const double w1 = coarse_hat_t(8 * u + kk, d.agg);
       double s0v = (1.0 - w1) * sv, s1v = w1 * sv;
       s0v += __shfl_xor(s0v, 1, kWave); s1v += __shfl_xor(s1v, 1, kWave);
       s0v += __shfl_xor(s0v, 2, kWave); s1v += __shfl_xor(s1v, 2, kWave);
@@ -1832,12 +1840,11 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     double sgm = 0;
     if (coarse && tq < nca) {
       const int n = tq / 6, cc = tq % 6;
-      const double* c0 = a.cparts + (size_t)cc * nwg + kAggUnits * n;
-      const double* c1 = a.cparts + (size_t)(6 + cc) * nwg + kAggUnits * (n - 1);
-#pragma unroll
-      for (int mm = 0; mm < kAggUnits; mm++) {
-        if (n < a.na && kAggUnits * n + mm < nwg) sgm += coh_load(c0 + mm);
-        if (n >= 1 && kAggUnits * (n - 1) + mm < nwg) sgm += coh_load(c1 + mm);
+      const double* c0 = a.cparts + (size_t)cc * nwg + aggu * n;
+      const double* c1 = a.cparts + (size_t)(6 + cc) * nwg + aggu * (n - 1);
+      for (int mm = 0; mm < aggu; mm++) {
+        if (n < a.na && aggu * n + mm < nwg) sgm += coh_load(c0 + mm);
+        if (n >= 1 && aggu * (n - 1) + mm < nwg) sgm += coh_load(c1 + mm);
       }
     }
     return sgm;
@@ -1917,7 +1924,7 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       for (int q = 1; q < 8; q++) z += zpart[q * (N / 2) + tq];
       if (coarse) {
         const int kk = tq / 6, rr = tq % 6;
-        const double w1 = coarse_hat_t(8 * u + kk), w0 = 1.0 - w1;
+        const double w1 = coarse_hat_t(8 * u + kk, d.agg), w0 = 1.0 - w1;
 #pragma unroll
         for (int cc = 0; cc < 6; cc++) z += pown[kk * 36 + rr * 6 + cc] * (w0 * ypart[cc] + w1 * ypart[6 + cc]);
       }
@@ -2807,8 +2814,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (ba->coarse_fresh) ba->coarse_fresh_iters = *pcg_iters;
       else if (*pcg_iters > ba->coarse_fresh_iters + ba->coarse_fresh_iters / 3 + 8) ba->coarse_stale_bad = true;
     }
-    static const int on_it = getenv("CCM_BA_COARSE_ON") ? atoi(getenv("CCM_BA_COARSE_ON")) : kCoarseOnIters;
-    static const int off_it = getenv("CCM_BA_COARSE_OFF") ? atoi(getenv("CCM_BA_COARSE_OFF")) : kCoarseOffIters;
+    static const int on_env = getenv("CCM_BA_COARSE_ON") ? atoi(getenv("CCM_BA_COARSE_ON")) : 0;
+    static const int off_env = getenv("CCM_BA_COARSE_OFF") ? atoi(getenv("CCM_BA_COARSE_OFF")) : 0;
+    const int on_it = on_env ? on_env : (d.agg < kAggWide ? kCoarseOnItersFine : kCoarseOnIters);
+    const int off_it = off_env ? off_env : (d.agg < kAggWide ? kCoarseOffItersFine : kCoarseOffIters);
     if (!ba->coarse_used && *pcg_iters >= on_it) ba->coarse_active = true;
     else if (ba->coarse_used && *pcg_iters <= off_it) ba->coarse_active = false;
   }

@@ -389,10 +389,10 @@ __global__ void bb_inst_cpos(const int* inst_c, const int* cpos, int n, int* ins
 }
 
 // coarse level: every S block (diagonal first, then the off-diagonal ones in block order) with the key of its aggregate pair
-__global__ void bb_coarse_keys(int Cp, int nOff, const int* bi, const int* bj, int na, unsigned* keys, int* vals) {
+__global__ void bb_coarse_keys(int Cp, int nOff, const int* bi, const int* bj, int na, int agg, unsigned* keys, int* vals) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Cp + nOff) return;
-  const int a = bi[k] / kAgg, a2 = bj[k] / kAgg;   // i < j => a <= a2
+  const int a = bi[k] / agg, a2 = bj[k] / agg;   // i < j => a <= a2
   keys[k] = (unsigned)a * (unsigned)na + (unsigned)a2;
   vals[k] = (k < Cp) ? 2 * k : 2 * k + (a == a2 ? 1 : 0);
 }
@@ -682,16 +682,30 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       d.E4 = p_e4; d.camRK = p_rk; d.inst_cp = p_icp;
     }
     // ---- coarse level: block lists of Ac = P^T S P by aggregate pair ----
-    const int na = ccm_div_up(std::max(Cp, 1), kAgg), ncoarse = 6 * (na + 1), Nc = ((ncoarse + 63) / 64) * 64;   // na camera intervals, na + 1 coarse nodes
-    const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && 7 * (size_t)Nc + 6 * (size_t)pers_grid_want + 320 <= (size_t)kCluN * kCluN / 2 &&
-                             kAggUnits * na <= pers_grid_want + kAggUnits - 1;
-    const bool coarse_mk = pers_wanted && !getenv("CCM_BA_NO_COARSE") && kAgg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
+    // intervals of 16 cameras wherever a unit of the persistent solver can keep its 12 rows of Ac^-1 (f32) in the free half of the LDS region of W
+    // (12 Nc floats <= 96 * 48 doubles: Nc <= 768, i.e. up to 2032 free cameras) — measured on a 1000-keyframe map with the coarse level always on:
+    // 1351 CG iterations per call with intervals of 32, 901 with 16 — and 32 otherwise and on the multi-kernel path (whose kernels pair two clusters)
+    auto coarse_size = [&](int agg, int* na_out, int* Nc_out) { *na_out = ccm_div_up(std::max(Cp, 1), agg); *Nc_out = ((6 * (*na_out + 1) + 63) / 64) * 64; };
+    auto pers_fits = [&](int agg, int na_, int Nc_) { return 6 * (size_t)Nc_ <= (size_t)kCluN * kCluN / 2 && (agg / 8) * na_ <= pers_grid_want + agg / 8 - 1; };
+    int agg = kAggWide, na = 0, Nc = 0;
+    static const int agg_env = getenv("CCM_BA_COARSE_AGG") ? atoi(getenv("CCM_BA_COARSE_AGG")) : 0;        // experiments: 16 / 24 / 32
+    static const int nc_cap = getenv("CCM_BA_COARSE_NC") ? atoi(getenv("CCM_BA_COARSE_NC")) : kCoarseNcCap;
+    if (pers_try)
+      for (int cand : {kAggFine, kAggMid}) {
+        if (agg_env ? cand != agg_env : false) continue;
+        coarse_size(cand, &na, &Nc);
+        if ((agg_env || Nc <= nc_cap) && pers_fits(cand, na, Nc)) { agg = cand; break; }
+      }
+    coarse_size(agg, &na, &Nc);
+    d.agg = agg;
+    const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && pers_fits(agg, na, Nc);
+    const bool coarse_mk = pers_wanted && !getenv("CCM_BA_NO_COARSE") && agg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
     unsigned* uq = nullptr; unsigned* cnts = nullptr; int* n_runs = nullptr;
     if (coarse_pers || coarse_mk) {
       const size_t nk = (size_t)Cp + nOff;
       unsigned* ck = nullptr; int* cv = nullptr;
       BB_RC(tmp.get(nk, &ck)); BB_RC(tmp.get(nk, &cv)); BB_RC(tmp.get(nk, &uq)); BB_RC(tmp.get(nk + 1, &cnts)); BB_RC(tmp.get(1, &n_runs));
-      hipLaunchKernelGGL(bb_coarse_keys, dim3(grid_for((int64_t)nk)), dim3(kB), 0, st, Cp, nOff, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j, na, ck, cv);
+      hipLaunchKernelGGL(bb_coarse_keys, dim3(grid_for((int64_t)nk)), dim3(kB), 0, st, Cp, nOff, (const int*)ba->d_blk_i, (const int*)ba->d_blk_j, na, agg, ck, cv);
       unsigned* ck_s = ck; int* cv_s = cv;
       BB_RC(sort_pairs(ctx, tmp, ck, cv, nk, bits_for((uint64_t)na * na), &ck_s, &cv_s));
       BB_RC(keep_get(ba, nk, &ba->d_cb_ent));

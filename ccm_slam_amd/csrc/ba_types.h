@@ -15,11 +15,9 @@ constexpr int kClu = 16;             // cameras per preconditioner cluster
 constexpr int kCluN = 6 * kClu;      // 96 unknowns
 constexpr int kSpmvTPB = 1024;
 constexpr int kRowsPerWG = kSpmvTPB / (2 * kWave);
-#ifndef CCM_KAGG
-#define CCM_KAGG 32
-#endif
-constexpr int kAgg = CCM_KAGG;       // cameras per coarse aggregate (32 = 2 clusters = 4 persistent units)
-constexpr int kAggUnits = kAgg / 8;
+constexpr int kCoarseNcCap = 768;              // (see ba_build.hip: the interval is the smallest of 16 / 24 / 32 cameras whose coarse system stays within this size)
+constexpr int kAggFine = 16, kAggMid = 24, kAggWide = 32;   // cameras per interval of the coarse space (BaDev::agg): 16 wherever the persistent solver's LDS holds the 12 rows of
+                                             // Ac^-1 a unit needs (maps up to 2032 free cameras), 32 otherwise and on the multi-kernel path (= 2 clusters there)
 constexpr int kPersTPB = 1024;
 constexpr int kPersWaves = kPersTPB / kWave;
 constexpr int kPersIdxCap = 3072;    // CSR entries of one persistent unit's rows (staged in LDS)
@@ -110,6 +108,7 @@ struct BaDev {
   const double* mk_P;        // [Cp][36] prolongation blocks
   const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse
   int mk_on, mk_Nc, mk_na;   // mk_on: this trial's solve uses the coarse level
+  int agg;                   // cameras per interval of the coarse space (kAggFine / kAggWide); a multiple of the 8 cameras of a persistent unit
 };
 
 struct ccm_ba {

@@ -177,14 +177,14 @@ def test_sharded_partial_systems_sum_to_the_single_rank_system(ctx, nranks):
 
 def test_coarse_level_matches_its_definition(ctx, oracle_lib):
     """Two-level preconditioner: Ac = P^T (S + lambda I) P, P = the adjoints P_k = Ad(T_cw,k) interpolated linearly in the camera index between coarse nodes
-    placed every 32 cameras (hat functions), assembled by gather on the device (four weighted sums per pair of camera intervals, then summed per pair of
+    placed every 16 cameras (hat functions), assembled by gather on the device (four weighted sums per pair of camera intervals, then summed per pair of
     nodes) and inverted by the tile kernels — against numpy on the oracle's dense reduced system."""
     prob = synth.make_ba_problem(n_agents=2, kfs_per_agent=60, n_points=3000, seed=5)
     lam = 2.5
     h = optimizer.BAHandle(ctx, prob)
     na, Ac, Ai, P = h.coarse_level(lam)
     h.close()
-    assert na == 4                                    # 119 free cameras / 32 -> 4 intervals, 5 nodes
+    assert na == 8                                    # 119 free cameras / 16 -> 8 intervals, 9 nodes (intervals of 16 on the persistent solver's path)
     nn = na + 1
     H, b, _ = oracle_lib.ba_partial_system(prob, lam, 0, prob["n_pt"], True)
     n = H.shape[0]; Cp = n // 6
@@ -196,7 +196,7 @@ def test_coarse_level_matches_its_definition(ctx, oracle_lib):
         tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
         Pi = np.zeros((6, 6)); Pi[:3, :3] = R; Pi[3:, :3] = tx @ R; Pi[3:, 3:] = R
         assert np.abs(P[i] - Pi).max() < 1e-12
-        a, w1 = i // 32, ((i % 32) + 0.5) / 32
+        a, w1 = i // 16, ((i % 16) + 0.5) / 16
         Pd[6 * i:6 * i + 6, 6 * a:6 * a + 6] = (1 - w1) * Pi
         Pd[6 * i:6 * i + 6, 6 * (a + 1):6 * (a + 1) + 6] = w1 * Pi
     ref = Pd.T @ H @ Pd

@@ -14,7 +14,7 @@ from ccm_slam_amd._lib import lib
 
 pytestmark = pytest.mark.gpu
 
-KCLU, KAGG, CHUNK, TPB = 16, 32, 64, 256
+KCLU, CHUNK, TPB = 16, 64, 256
 TBIT = np.uint32(0x80000000)
 _HOOKS = None
 
@@ -43,7 +43,7 @@ def partition(weight, nranks):
     return begin
 
 
-def host_structure(prob, rank=0, nranks=1):
+def host_structure(prob, rank=0, nranks=1, agg=32):
     e_cam, e_pt = prob["e_cam"].astype(np.int64), prob["e_pt"].astype(np.int64)
     lvl = prob.get("e_level")
     lvl = np.zeros(e_cam.size, np.uint8) if lvl is None else np.asarray(lvl)
@@ -160,9 +160,9 @@ def host_structure(prob, rank=0, nranks=1):
     S["chunk_off"] = np.array(chunk + [le - lb]) if fits and le > lb else np.zeros(0, np.int64)
     cb = {}
     for i in range(Cp):
-        cb.setdefault((i // KAGG, i // KAGG), []).append(2 * i)
+        cb.setdefault((i // agg, i // agg), []).append(2 * i)
     for b in range(nOff):
-        a, a2 = bi[b] // KAGG, bj[b] // KAGG
+        a, a2 = bi[b] // agg, bj[b] // agg
         cb.setdefault((a, a2), []).append(2 * (Cp + b) + (1 if a == a2 else 0))
     keys = sorted(cb)
     S["cb_ab"] = np.array(keys, np.int64).reshape(-1); S["cb_ent"] = np.array([e for k in keys for e in cb[k]], np.int64)
@@ -172,9 +172,14 @@ def host_structure(prob, rank=0, nranks=1):
 
 def check(ctx, prob, rank=0, nranks=1):
     h = optimizer.BAHandle(ctx, prob, rank=rank, nranks=nranks)
-    S = host_structure(prob, rank, nranks)
     sz = dev_array(h, "sizes", np.int32)
     Cp, Lp, Lloc, Eloc, nOff, max_ce, units_max, pers_grid, c_na, c_ncb, n_chunk, lb = (int(v) for v in sz)
+    # intervals of the coarse space: 16 cameras where the persistent solver runs and 12 rows of Ac^-1 (6 (Cp / 16 + 1) floats each, padded to 64) fit its LDS
+    # (<= 768), 32 otherwise (ba_build.hip)
+    nc16 = -(-6 * (-(-Cp // 16) + 1) // 64) * 64
+    agg = 16 if pers_grid and nc16 <= 768 else 32
+    if c_na: assert c_na == -(-Cp // agg)
+    S = host_structure(prob, rank, nranks, agg)
     assert (Cp, Lp, Lloc, Eloc, nOff, max_ce, lb) == (S["Cp"], S["Lp"], S["Lloc"], S["Eloc"], S["nOff"], S["max_cam_edges"], S["lb"])
     names = ["slot_cam", "slot_pt", "loc_edge_orig", "pt_off", "ed_cam", "ed_cslot", "ed_pt", "cam_off", "cam_edge", "cam_pt", "rowblk_off", "row_off", "row_col",
              "inst_off", "inst_a", "inst_c", "inst_al", "blk_i", "blk_j", "chunk_off"]
