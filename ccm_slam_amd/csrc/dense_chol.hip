@@ -9,6 +9,8 @@
 // then tile-wise forward / backward substitution.  MFMA operand layout (guide, "f64 MFMA does NOT use these maps"):
 // A: lane l holds A[l & 15][l >> 4], B: lane l holds B[l >> 4][l & 15], D: reg r of lane l is D[(l >> 4) + 4 r][l & 15].
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -126,8 +128,96 @@ __device__ __forceinline__ void chol_diag_body(double* Ajj, size_t N, int j, dou
     for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
   }
 }
+// The same tile, BLOCKED by 16 columns (round 3).  The unblocked form above pays, for every one of its 64 columns, a chain of up to 16 dependent
+// multiply-adds on operands fetched from LDS, a pivot broadcast, a store and a block barrier (~460 ns per column).  Here wave 0 takes 16 columns at a time:
+//   (a) the block's 16 entries of every row are brought up to date with all EARLIER columns in one pass of independent chains (16 accumulators per lane,
+//       the multipliers L_ck of the block's 16 pivot rows read from LDS at uniform addresses, two per read) — off the pivot chain;
+//   (b) the 16 pivots of the block then run on registers alone: lane i keeps its row, a pivot row's entries travel by v_readlane, rows below the block
+//       form their panel entries in the same instruction stream (the 16 x 16 tile factorisation of the BA cluster solver, 64 rows tall): ~200 ns per pivot;
+//   (c) the block's columns go to LDS for the later blocks and for wave 1, which forms L^-1 one BLOCK behind (four barriers per tile instead of 64).
+__device__ __forceinline__ void chol_diag_body_blk(double* Ajj, size_t N, int j, double* Lg, int* info) {
+  constexpr int LR = NB + 2, KB = 16;
+  __shared__ __attribute__((aligned(16))) double L[NB * LR];
+  __shared__ double rdiag[NB];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {
+    double tmp[NB / 2];
+#pragma unroll
+    for (int r = 0; r < NB / 2; r++) tmp[r] = Ajj[(size_t)(wv * (NB / 2) + r) * N + lane];
+#pragma unroll
+    for (int r = 0; r < NB / 2; r++) L[(wv * (NB / 2) + r) * LR + lane] = tmp[r];
+  }
+  __syncthreads();
+  // The two waves run DIFFERENT loops with the same number of block barriers (wave 0 arrives at barrier b after block b is in LDS, wave 1 before it reads
+  // it): in one shared loop the register allocator keeps wave 1's 64 values of x alive through wave 0's code as well, and both spill.
+  if (wv == 0) {
+    int bad_col = 0;
+#pragma unroll
+    for (int b = 0; b < NB / KB; b++) {
+      const int c0 = KB * b;
+      double row[KB];   // lane i's entries of the block's 16 columns (its earlier columns stay in LDS)
+#pragma unroll
+      for (int c = 0; c < KB; c += 2) { const double2 v = *reinterpret_cast<const double2*>(&L[lane * LR + c0 + c]); row[c] = v.x; row[c + 1] = v.y; }
+      // (a) row[c] -= sum_{k < c0} L_ik L_{c0 + c, k}: both operands from LDS (the lane's own earlier entries; the pivot rows at uniform addresses)
+#pragma unroll 2
+      for (int k = 0; k < c0; k += 2) {
+        const double2 a2 = *reinterpret_cast<const double2*>(&L[lane * LR + k]);
+#pragma unroll
+        for (int c = 0; c < KB; c++) {
+          const double2 l2 = *reinterpret_cast<const double2*>(&L[(c0 + c) * LR + k]);
+          row[c] = __builtin_fma(-a2.y, l2.y, __builtin_fma(-a2.x, l2.x, row[c]));
+        }
+      }
+      // (b) the block's 16 pivots on registers
+#pragma unroll
+      for (int c = 0; c < KB; c++) {
+        double s0 = row[c], s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < c; k++) {
+          const double m = bcast64(row[k], c0 + c);
+          if (k & 1) s1 = __builtin_fma(-row[k], m, s1); else s0 = __builtin_fma(-row[k], m, s0);
+        }
+        const double sv = s0 + s1;
+        double dd = bcast64(sv, c0 + c);
+        if (!(dd > 0.0)) { if (!bad_col) bad_col = c0 + c + 1; dd = 1.0; }
+        const double inv = rsqrt(dd);
+        row[c] = (lane == c0 + c) ? dd * inv : sv * inv;   // lanes above the diagonal hold unused values
+        if (lane == c0 + c) rdiag[c0 + c] = inv;
+      }
+      // (c) the block's columns for the later blocks and for wave 1
+#pragma unroll
+      for (int c = 0; c < KB; c += 2) { double2 v; v.x = row[c]; v.y = row[c + 1]; *reinterpret_cast<double2*>(&L[lane * LR + c0 + c]) = v; }
+      __syncthreads();
+    }
+    if (bad_col && lane == 0 && *info == 0) *info = j * NB + bad_col;
+#pragma unroll
+    for (int r = 0; r < NB; r++) Ajj[(size_t)r * N + lane] = (lane <= r) ? L[r * LR + lane] : 0.0;
+  } else {
+    double x[NB];     // lane t's column of L^-1
+#pragma unroll
+    for (int b = 0; b < NB / KB; b++) {
+      __syncthreads();
+      // X = L^-1, lane = column t, rows of block b: x_r = (delta_rt - sum_{k<r} L_rk x_k) / L_rr  (x_k = 0 for k < t, so the bounds are uniform)
+#pragma unroll
+      for (int rr = 0; rr < KB; rr++) {
+        const int r = KB * b + rr;
+        const double* Lrow = L + r * LR;
+        double acc[4] = {(r == lane) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < r; k++) acc[k & 3] = __builtin_fma(-Lrow[k], x[k], acc[k & 3]);
+        x[r] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) * rdiag[r];
+        Lg[r * NB + lane] = x[r];
+        asm volatile("" ::: "memory");   // keeps the next row's LDS reads behind this row
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(128) void chol_diag_wave(double* A, int N, int j, double* Linv_all, int* info) {
   chol_diag_body(A + ((size_t)j * NB) * N + (size_t)j * NB, (size_t)N, j, Linv_all + (size_t)j * NB * NB, info);
+}
+__global__ __launch_bounds__(128) void chol_diag_wave_blk(double* A, int N, int j, double* Linv_all, int* info) {
+  chol_diag_body_blk(A + ((size_t)j * NB) * N + (size_t)j * NB, (size_t)N, j, Linv_all + (size_t)j * NB * NB, info);
 }
 
 // ---- tile-sparse, level-scheduled form (ccm_tsc_*): non-zero tiles of L stored compactly (64 x 64, row-major, contiguous), left-looking
@@ -154,9 +244,13 @@ __global__ __launch_bounds__(kTPB) void tsc_gather(double* tiles, const int* tid
 #pragma unroll
     for (int r = 0; r < 4; r++) Aij[(size_t)(16 * wave + (lane >> 4) + 4 * r) * NB + 16 * s + (lane & 15)] -= acc[s][r];
 }
+static inline bool diag_blocked() { static const bool v = !(getenv("CCM_CHOL_DIAG") && !strcmp(getenv("CCM_CHOL_DIAG"), "columns")); return v; }
+
+template <bool kBlocked>
 __global__ __launch_bounds__(128) void tsc_diag(double* tiles, const int* tid, int T, const int* cols, double* Linv_all, int* info) {
   const int j = cols[blockIdx.x];
-  chol_diag_body(tiles + (size_t)tid[(size_t)j * T + j] * (NB * NB), (size_t)NB, j, Linv_all + (size_t)j * NB * NB, info);
+  if (kBlocked) chol_diag_body_blk(tiles + (size_t)tid[(size_t)j * T + j] * (NB * NB), (size_t)NB, j, Linv_all + (size_t)j * NB * NB, info);
+  else chol_diag_body(tiles + (size_t)tid[(size_t)j * T + j] * (NB * NB), (size_t)NB, j, Linv_all + (size_t)j * NB * NB, info);
 }
 __global__ __launch_bounds__(kTPB) void tsc_panel(double* tiles, const int* tid, int T, const int* pt, const double* Linv_all) {
   __shared__ double As[NB * LD], Bs[NB * LD];
@@ -389,7 +483,8 @@ int ccm_dense_chol_solve_dev(ccm_ctx* ctx, double* d_A, int N, double* d_b, doub
   if (plan && (plan->T != T || T >= 32768)) return ccm_set_error(ctx, CCM_E_ARG, "dense cholesky: tile plan does not match");
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    if (diag_blocked()) hipLaunchKernelGGL(chol_diag_wave_blk, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    else hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     if (plan) {
       const int nr = plan->h_col_off[j + 1] - plan->h_col_off[j], np = plan->h_upd_off[j + 1] - plan->h_upd_off[j];
       if (nr) hipLaunchKernelGGL(chol_panel, dim3(nr), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, plan->d_col_rows + plan->h_col_off[j]);
@@ -534,7 +629,8 @@ int ccm_tsc_solve(ccm_ctx* ctx, ccm_tsc* p, double* d_b) {
     const int g0 = p->lvl_gt_off[l], ng = p->lvl_gt_off[l + 1] - g0;
     const int p0 = p->lvl_pt_off[l], np = p->lvl_pt_off[l + 1] - p0;
     if (ng) hipLaunchKernelGGL(tsc_gather, dim3(ng), dim3(kTPB), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_gt + g0, (const int*)p->d_gk_off + g0, (const int*)p->d_gk);
-    hipLaunchKernelGGL(tsc_diag, dim3(nc), dim3(128), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0, p->d_linv, p->d_info);
+    if (diag_blocked()) hipLaunchKernelGGL(tsc_diag<true>, dim3(nc), dim3(128), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0, p->d_linv, p->d_info);
+    else hipLaunchKernelGGL(tsc_diag<false>, dim3(nc), dim3(128), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_cols + c0, p->d_linv, p->d_info);
     if (np) hipLaunchKernelGGL(tsc_panel, dim3(np), dim3(kTPB), 0, ctx->stream, p->d_tiles, (const int*)p->d_tid, T, (const int*)p->d_pt + p0, (const double*)p->d_linv);
   }
   for (int l = 0; l < p->n_levels; l++) {
@@ -624,7 +720,8 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
   const int T = N / NB;
   CCM_HIP_CHECK(ctx, hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
   for (int j = 0; j < T; j++) {
-    hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    if (diag_blocked()) hipLaunchKernelGGL(chol_diag_wave_blk, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
+    else hipLaunchKernelGGL(chol_diag_wave, dim3(1), dim3(128), 0, ctx->stream, d_A, N, j, d_linv, d_info);
     const int rem = T - j - 1;
     if (rem > 0) {
       hipLaunchKernelGGL(chol_panel, dim3(rem), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const double*)d_linv, (const int*)nullptr);
