@@ -1430,45 +1430,41 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
     const int i16 = lane & 15, kq = lane >> 4;
     for (int T = 0; T < 6 && 16 * T < m; T++) {
       const int b0 = 16 * T;
-      if (wave == 0) {
-        const int rl = lane & 15;                       // lanes 16..63 shadow lanes 0..15 (uniform control flow for v_readlane)
+      // Diagonal tile AND panel in one instruction stream (round 3): lanes 0..15 of waves 0 and 1 each factor the 16 rows of the diagonal tile (the same
+      // arithmetic, so both hold the same pivot rows), lanes 16..63 carry rows BELOW the tile (wave 0: the first 48, wave 1: the next 32) and form their panel
+      // entries L_ic = (A_ic - sum_{k<c} L_ik L_ck) / L_cc with the multipliers arriving by v_readlane from lanes 0..15 of their own wave — the column step a
+      // row below the diagonal takes anyway.  The separate panel pass (one thread per row, 16 dependent steps on LDS operands, a barrier) cost 15 of the 42 us.
+      const int r0 = b0 + 16;
+      if (wave < 2) {
+        const int rl = lane & 15;
+        const int prow = r0 + 48 * wave + (lane - 16);   // panel row of lanes 16..63
+        const bool is_panel = lane >= 16;
+        const int rowi = is_panel ? min(prow, N - 1) : b0 + rl;
         double row[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) row[k] = A[(b0 + rl) * N + b0 + k];
+        for (int k = 0; k < 16; k++) row[k] = A[rowi * N + b0 + k];
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < 16; c++) {
           double sv = row[c];
-          // (measured and dropped, round 3: the pivot-row entries through __shfl — all c of them requested at once, two partial sums — instead of
-          // v_readlane broadcasts: 170 us against 158 us for the two-cluster solve)
 #pragma unroll
           for (int k = 0; k < c; k++) sv -= row[k] * pers_bcast(row[k], c);
           double dd = pers_bcast(sv, c);
           if (!(dd > 0.0)) { bad = true; dd = 1.0; }      // (padding rows of a short cluster carry a unit diagonal)
           const double inv = rsqrt(dd);
-          row[c] = (rl == c) ? dd * inv : sv * inv;     // lanes above the diagonal hold unused values
-          if (lane == c) invd[c] = inv;
+          row[c] = (!is_panel && rl == c) ? dd * inv : sv * inv;     // lanes above the diagonal hold unused values
+          if (wave == 0 && lane == c) invd[c] = inv;
         }
-        if (bad && lane == 0) ibuf[1] = 1;
-        if (lane < 16) {
+        if (wave == 0 && bad && lane == 0) ibuf[1] = 1;
+        if (!is_panel) {
+          if (wave == 0) {
 #pragma unroll
-          for (int k = 0; k < 16; k++) if (k <= lane) A[(b0 + lane) * N + b0 + k] = row[k];
+            for (int k = 0; k < 16; k++) if (k <= lane) A[(b0 + lane) * N + b0 + k] = row[k];
+          }
+        } else if (prow < m) {
+#pragma unroll
+          for (int k = 0; k < 16; k++) A[prow * N + b0 + k] = row[k];
         }
-      }
-      __syncthreads();
-      const int r0 = b0 + 16;
-      if (r0 + t < m) {   // panel: one thread per row below the diagonal tile, X L_TT^T = A_iT
-        const int i = r0 + t;
-        double x[16];
-#pragma unroll
-        for (int cc = 0; cc < 16; cc++) {
-          double sv = A[i * N + b0 + cc];
-#pragma unroll
-          for (int k = 0; k < cc; k++) sv -= x[k] * A[(b0 + cc) * N + b0 + k];
-          x[cc] = sv * invd[cc];
-        }
-#pragma unroll
-        for (int cc = 0; cc < 16; cc++) A[i * N + b0 + cc] = x[cc];
       }
       __syncthreads();
       {   // trailing update A_IJ -= X_I X_J^T over the lower tiles I >= J > T
