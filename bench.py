@@ -294,19 +294,24 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
 def ba_kernel_bytes(counts):
     E, L, C, B, P = (float(counts[k]) for k in ("edges", "points", "free_cams", "blocks", "pairs"))
     n_off = B - C
+    # Large maps (more than 256 off-diagonal blocks: the row kernel's path, ba_build.hip `w_free`) never store the 144-byte Hpl block of an observation:
+    # the landmark- and camera-side linearisations write a 32-byte record each (landmark-major / camera-major), the row kernel and the back-substitution
+    # re-derive the block from it and the camera's 96-byte record.  The figures below are what each kernel must move ONCE (gathered tables counted once).
+    compact = n_off > 256
+    w_e = 32.0 if compact else 144.0
     return {
         # what the persistent solve must move once per launch: S, b in; x out (S is held in registers, vectors in LDS, for
         # the whole solve: every further byte is on-chip)
         "BA_PCG_PERSIST": 288.0 * B + 2 * 48.0 * C,
         "BA_PCG_SPMV": 288.0 * B + 4 * 48.0 * C,          # per CG iteration: S once + z, p in, q, p out
         "BA_PCG_UPDATE": (36 + 6 * 6) * 8.0 * C,
-        # row kernel: every observation's W and D^-1 once, every off-diagonal and diagonal block written once
-        "BA_SCHUR_OFF": 144.0 * E + 48.0 * L + 288.0 * B,
+        # row kernel: every observation's record (or W) and [D^-1 | b_l] once, every off-diagonal and diagonal block written once
+        "BA_SCHUR_OFF": w_e * E + (48.0 + 24.0) * L + 288.0 * B + (96.0 * C if compact else 0.0),
         "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
-        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + 144.0) * E + (24.0 + 72.0) * L,
-        "BA_CAM": (24.0 + 24.0 + 8.0) * E + (56.0 + 288.0 + 48.0) * C,
+        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + w_e) * E + (24.0 + 72.0) * L,
+        "BA_CAM": (24.0 + 24.0 + 8.0 + (32.0 if compact else 0.0)) * E + (56.0 + 288.0 + 48.0 + (96.0 if compact else 0.0)) * C,
         "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
-        "BA_BACKSUB": (144.0 + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L,
+        "BA_BACKSUB": (w_e + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L + (96.0 * C if compact else 0.0),
         "BA_UPDATE": (56.0 * 2 + 48.0 * 2) * C,
         "BA_CHI2": (56.0 + 24.0 + 9.0 + 8.0) * E + 24.0 * L,
         "BA_COARSE": 288.0 * B + 288.0 * C,               # S and the prolongation blocks once
@@ -320,7 +325,7 @@ KERNEL_OF_CLASS = {   # device kernel(s) behind every profiling class on the gba
     "BA_UPDATE": "ba_update_cams", "BA_CHI2": "ba_backsub_chi2_e", "BA_PCG_PERSIST": "ba_pcg_persist",
     "BA_COARSE": "ba_coarse_assemble+chol_*", "BA_REDUCE": "ba_reduce_scalars"}
 LIMITER = {"BA_PCG_PERSIST": "latency (grid exchange): two grid-wide exchanges of ~3.3 us per CG iteration, S stays in registers",
-           "BA_COARSE": "latency (dependent tile launches of the dense inverse)", "BA_REDUCE": "latency (single workgroup)",
+           "BA_COARSE": "latency (dependent tile launches of the dense inverse: the 64-wide diagonal tiles form one chain of pivots)", "BA_REDUCE": "latency (single workgroup)",
            "BA_UPDATE": "latency (launch)", "BA_DINV": "hbm"}
 
 
