@@ -1801,7 +1801,14 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   const int aggu = d.agg >> 3;               // units per interval (an interval is a multiple of the 8 cameras of a unit)
   const int agg = u / aggu;                  // interval of the unit's cameras: nodes agg and agg + 1
   if (coarse) {
-    for (int e = t; e < 12 * Nc; e += kPersTPB) ainv_l[e] = has ? (float)a.Ainv[(size_t)(6 * agg + e / Nc) * Nc + e % Nc] : 0.0f;
+    {   // the 12 rows are one contiguous range of Ac^-1; all of a thread's loads in flight at once (as a rolled loop: nine dependent round trips per launch)
+      const double* src = a.Ainv + (size_t)(6 * agg) * Nc;
+      double tmpa[9];
+#pragma unroll
+      for (int q = 0; q < 9; q++) { const int e = t + q * kPersTPB; tmpa[q] = (has && e < 12 * Nc) ? src[e] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < 9; q++) { const int e = t + q * kPersTPB; if (e < 12 * Nc) ainv_l[e] = (float)tmpa[q]; }
+    }
     for (int e = t; e < Nc; e += kPersTPB) rco[e] = 0.0;
     for (int e = t; e < 8 * 36; e += kPersTPB) pown[e] = (e / 36 < nown) ? a.Pm[36 * (size_t)o0 + e] : 0.0;
   }
