@@ -802,16 +802,22 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
     }
   }
   ROW3_TICK(1)   // (wave 0's share of the block passes)
+  // the unit range of the thread's first block of the final sums is requested BEFORE the barrier: its round trip runs while the slower waves finish
+  const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
+  constexpr int kGroups = kRow2TPB / 36;
+  const int fb0 = d.rowblk_off[i] + grp36, fb_end = d.rowblk_off[i + 1];
+  int f_ub = 0, f_n = 0;
+  if (grp36 < kGroups && fb0 < fb_end) { f_ub = d.blk_unit0[fb0]; f_n = d.inst_off[fb0 + 1] - d.inst_off[fb0]; }
   __syncthreads();
   ROW3_TICK(2)   // (waiting for the slowest wave)
   // ---- final sums: per block over its units (slot = creation order: a block's units are consecutive); diagonal block + b_schur over the 16-observation groups ----
   {
-    const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
-    constexpr int kGroups = kRow2TPB / 36;
     if (grp36 < kGroups)
-      for (int b = d.rowblk_off[i] + grp36; b < d.rowblk_off[i + 1]; b += kGroups) {
+      for (int b = fb0; b < fb_end; b += kGroups) {
         double sum = 0;
-        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + d.unit_chunk - 1) / d.unit_chunk);
+        const int ub = (b == fb0) ? f_ub : d.blk_unit0[b];
+        const int ni = (b == fb0) ? f_n : d.inst_off[b + 1] - d.inst_off[b];
+        const int ue = ub + max(1, (ni + d.unit_chunk - 1) / d.unit_chunk);
         for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
         d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
       }
