@@ -507,3 +507,30 @@ def test_stop_flag_raised_mid_run_by_another_thread(ctx, oracle_lib, k):
     assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R and np.abs(pts - opts).max() <= 1e-4
+
+
+def _variant(env):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ba_variant_run.py"), "3", "120", "18000", "77"], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_formulations_of_the_large_map_path_agree():
+    """The large-map path in its default form (observations as 32-byte compact records, Hpl blocks never stored; coarse space with nodes every 16 cameras;
+    blocked Cholesky tiles) against its alternatives, each in its own process (the switches are read once): the row kernel on STORED blocks
+    (CCM_BA_ROW=2), stored blocks next to the compact row kernel (CCM_BA_KEEP_W=1), coarse nodes every 32 cameras, column-wise diagonal tiles.  All of
+    them must take the same LM path (iterations, trials per iteration) and end in the same poses to 1e-9 (they differ in summation order and in the
+    preconditioner only; the CG tolerance is 1e-8 of the initial residual)."""
+    base = _variant({})
+    assert base["counts"]["blocks"] - base["counts"]["free_cams"] > 256          # the row kernel's path
+    cam0 = np.array(base["cam"])
+    for env in ({"CCM_BA_ROW": "2"}, {"CCM_BA_KEEP_W": "1"}, {"CCM_BA_COARSE_AGG": "32"}, {"CCM_CHOL_DIAG": "columns"}):
+        v = _variant(env)
+        assert (v["iters"], v["trials"]) == (base["iters"], base["trials"]), (env, v["trials"], base["trials"])
+        assert np.abs(np.array(v["chi2"]) / np.array(base["chi2"]) - 1).max() < 1e-9, env
+        assert np.abs(np.array(v["cam"]) - cam0).max() < 1e-9, (env, np.abs(np.array(v["cam"]) - cam0).max())
+        assert abs(v["pts_sum"] / base["pts_sum"] - 1) < 1e-9
+    assert _variant({"CCM_BA_COARSE_AGG": "32"})["pcg_iters"] > base["pcg_iters"]   # the finer coarse space is what saves CG iterations
