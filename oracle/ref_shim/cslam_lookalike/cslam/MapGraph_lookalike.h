@@ -147,6 +147,11 @@ class MapPoint : public boost::enable_shared_from_this<MapPoint> {
   int mnTrackScaleLevel = 0;
   mpptr mpReplaced;
   void UpdateNormalAndDepth();   // body = the reference's own lines MapPoint.cpp:779-823 (oracle/ref_mappoint_excerpt.cpp)
+#ifdef CCM_LOOKALIKE_MAPPOINT_SETTER
+  // the OPTIONAL three-line patch of INTEGRATION.md (not in the reference): with it shim/Optimizer_hip.cpp replaces the per-point UpdateNormalAndDepth()
+  // calls of a global BA's write-back by one batched device call
+  void SetNormalAndDepth(const cv::Mat& normal, float minDist, float maxDist) { std::unique_lock<std::mutex> l(mMutexPos); normal.copyTo(mNormalVector); mfMinDistance = minDist; mfMaxDistance = maxDist; }
+#endif
   float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }
   float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }
   // state read by the excerpt above (names as in MapPoint.h:268-300)

@@ -23,6 +23,8 @@
 #include <exception>
 #include <string>
 #include <thread>
+#include <type_traits>
+#include <utility>
 
 #include "../include/ccm_hip.h"
 #include "../ccm_slam_amd/host/ccm_convert.h"
@@ -120,6 +122,12 @@ struct FlatBA {
   std::vector<char> cam_is_fixed;
   std::vector<MapPoint*> pt_mp;                      // raw: the caller's containers keep the points alive, and 150 000 shared_ptr copies cost ~15 ms of cache-missing atomics each way
   std::vector<size_t> e_cam_id, e_pt_id;             // per edge: vertex ids
+  // per point, only filled when MapPoint offers SetNormalAndDepth (batched UpdateNormalAndDepth of the write-back): id of the reference keyframe, octave of the
+  // point's keypoint there, and whether EVERY non-bad observation became an edge (else the point takes the reference's own method)
+  std::vector<size_t> pt_ref_cam_id;
+  std::vector<int32_t> pt_ref_level;
+  std::vector<char> pt_regular;
+  bool aux_ok = true;                                // false once flatten() had to reorder the points (the per-point arrays above are in insertion order)
   // flattened
   std::vector<double> cam_qt, cam_K, pt_xyz, e_obs, e_info;
   std::vector<uint8_t> cam_fix, e_level;
@@ -130,10 +138,12 @@ struct FlatBA {
   void reset() {   // keeps every vector's capacity: the global BA of a 4-agent map builds ~60 MB of flat arrays, and allocating (first-touch page faults) and
                    // releasing (munmap) them cost ~50 ms per call — the server thread keeps one FlatBA for its lifetime instead
     cam_id.clear(); pt_id.clear(); cam_kf.clear(); cam_is_fixed.clear(); pt_mp.clear(); e_cam_id.clear(); e_pt_id.clear();
+    pt_ref_cam_id.clear(); pt_ref_level.clear(); pt_regular.clear(); aux_ok = true;
     cam_qt.clear(); cam_K.clear(); pt_xyz.clear(); e_obs.clear(); e_info.clear(); cam_fix.clear(); e_level.clear(); e_cam.clear(); e_pt.clear();
   }
   void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cam_id.push_back(id); cam_kf.push_back(kf); cam_is_fixed.push_back(is_fixed ? 1 : 0); }
   void addPoint(size_t id, const Optimizer::mpptr& mp) { pt_id.push_back(id); pt_mp.push_back(mp.get()); }
+  void addPointAux(size_t ref_cam_id, int level, bool regular) { pt_ref_cam_id.push_back(ref_cam_id); pt_ref_level.push_back(level); pt_regular.push_back(regular ? 1 : 0); }
   void addEdge(size_t p_id, const Optimizer::kfptr& kf, size_t c_id, const cv::KeyPoint& kpUn) {
     const float& invSigma2 = kf->mvInvLevelSigma2[kpUn.octave];
     e_cam_id.push_back(c_id); e_pt_id.push_back(p_id);
@@ -146,6 +156,8 @@ struct FlatBA {
     pt_id.insert(pt_id.end(), o.pt_id.begin(), o.pt_id.end()); pt_mp.insert(pt_mp.end(), o.pt_mp.begin(), o.pt_mp.end());
     e_cam_id.insert(e_cam_id.end(), o.e_cam_id.begin(), o.e_cam_id.end()); e_pt_id.insert(e_pt_id.end(), o.e_pt_id.begin(), o.e_pt_id.end());
     e_obs.insert(e_obs.end(), o.e_obs.begin(), o.e_obs.end()); e_info.insert(e_info.end(), o.e_info.begin(), o.e_info.end());
+    pt_ref_cam_id.insert(pt_ref_cam_id.end(), o.pt_ref_cam_id.begin(), o.pt_ref_cam_id.end());
+    pt_ref_level.insert(pt_ref_level.end(), o.pt_ref_level.begin(), o.pt_ref_level.end()); pt_regular.insert(pt_regular.end(), o.pt_regular.begin(), o.pt_regular.end());
   }
   template <typename P>
   static void sort_by_id(std::vector<size_t>& ids, std::vector<P>& ptrs, std::vector<char>* flags) {
@@ -160,6 +172,7 @@ struct FlatBA {
   // g2o refuses an edge whose camera vertex does not exist (optimizer.vertex(id) == 0 -> addEdge fails): such observations are dropped
   void flatten(bool drop_edges_without_camera = false) {
     sort_by_id(cam_id, cam_kf, &cam_is_fixed);
+    if (!std::is_sorted(pt_id.begin(), pt_id.end())) aux_ok = false;
     sort_by_id<MapPoint*>(pt_id, pt_mp, nullptr);
     cam_index.build(cam_id); pt_index.build(pt_id);
     const size_t nc = cam_id.size(), np = pt_id.size();
@@ -510,6 +523,65 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// batched MapPoint::UpdateNormalAndDepth for the write-back of a global BA — only when MapPoint offers SetNormalAndDepth (the optional patch of
+// INTEGRATION.md; the reference keeps mNormalVector / mfMinDistance / mfMaxDistance protected without a setter, MapPoint.h:286-305).  Detected at compile
+// time, so this translation unit builds against the unpatched header too and then calls the reference's method per point.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T, typename = void> struct has_normal_depth_setter : std::false_type {};
+template <typename T>
+struct has_normal_depth_setter<T, decltype(std::declval<T&>().SetNormalAndDepth(std::declval<const cv::Mat&>(), 0.0f, 0.0f), void())> : std::true_type {};
+constexpr bool kBatchedNormals = has_normal_depth_setter<MapPoint>::value;
+
+template <typename MP> void store_normal_depth(MP* p, const float* n3, float mn, float mx, std::true_type) {
+  cv::Mat n(3, 1, CV_32F);
+  n.at<float>(0) = n3[0]; n.at<float>(1) = n3[1]; n.at<float>(2) = n3[2];
+  p->SetNormalAndDepth(n, mn, mx);
+}
+template <typename MP> void store_normal_depth(MP*, const float*, float, float, std::false_type) {}
+
+// SetWorldPos + UpdateNormalAndDepth (Optimizer.cpp:843-845) of every point of the flattened problem: positions by SetWorldPos as before; normal / depth
+// range of the REGULAR points (every non-bad observation is an edge of the problem, reference keyframe among its cameras) by ONE call of
+// ccm_update_normal_and_depth (MapPoint.cpp:779-823 on the device, bit-exact: tests/test_frame_gpu.py) over the problem's own edge lists — a point's edges
+// are in the order the walk iterated its mObservations, which is the order the reference sums in; the other points take the reference's method.
+void batched_point_writeback(FlatBA& f) {
+  const size_t np = f.pt_id.size(), nc = f.cam_id.size(), ne = f.e_pt.size();
+  std::vector<float> pos(3 * np), center(3 * nc), normal(3 * np, 0.0f), dmin(np, 0.0f), dmax(np, 0.0f);
+  std::vector<int32_t> off(np + 1, 0), kf(ne), ref(np, 0), lvl(np, 0);
+  for (size_t i = 0; i < np; i++) for (int c = 0; c < 3; c++) pos[3 * i + c] = (float)f.pt_xyz[3 * i + c];   // what pointPos() hands to SetWorldPos
+  for (size_t i = 0; i < nc; i++) {
+    const cv::Mat Ow = f.cam_kf[i]->GetCameraCenter();                                                      // after the keyframe write-back
+    for (int c = 0; c < 3; c++) center[3 * i + c] = Ow.at<float>(c);
+  }
+  for (size_t k = 0; k < ne; k++) off[(size_t)f.e_pt[k] + 1]++;
+  for (size_t i = 0; i < np; i++) off[i + 1] += off[i];
+  {
+    std::vector<int32_t> fill(off.begin(), off.end() - 1);
+    for (size_t k = 0; k < ne; k++) kf[(size_t)fill[(size_t)f.e_pt[k]]++] = f.e_cam[k];                     // stable: the walk's order inside a point
+  }
+  std::vector<char> regular(np, 0);
+  for (size_t i = 0; i < np; i++) {
+    const int32_t r = f.pt_regular[i] ? f.cam_index.find(f.pt_ref_cam_id[i]) : -1;
+    regular[i] = r >= 0;
+    ref[i] = r >= 0 ? r : 0; lvl[i] = f.pt_ref_level[i];
+    if (!regular[i]) off[i + 1] = off[i + 1];                                                               // (its result is ignored below)
+  }
+  const std::vector<float>& sf = f.cam_kf[0]->mvScaleFactors;                                                // one table per map (ORBextractor parameters)
+  check(ccm_update_normal_and_depth(thread_ctx(), (int)np, pos.data(), off.data(), kf.data(), (int)nc, center.data(), ref.data(), lvl.data(), sf.data(),
+                                    (int)f.cam_kf[0]->mnScaleLevels, normal.data(), dmin.data(), dmax.data()), "ccm_update_normal_and_depth");
+  parallel_chunks(np, shim_threads(np, 32), [&](int, size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) {
+      MapPoint* pMP = f.pt_mp[i];
+      if (pMP->isBad()) continue;
+      cv::Mat p(3, 1, CV_32F);
+      for (int c = 0; c < 3; c++) p.at<float>(c) = pos[3 * i + c];
+      pMP->SetWorldPos(p, true);
+      if (regular[i]) store_normal_depth(pMP, &normal[3 * i], dmin[i], dmax[i], has_normal_depth_setter<MapPoint>());
+      else pMP->UpdateNormalAndDepth();
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // server side
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Optimizer.cpp:646-859
@@ -561,6 +633,14 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
         }
         if (nEdges < 2) { vbNotIncludedMP[i] = true; continue; }
         g.addPoint(id, pMP);
+        if (kBatchedNormals) {   // what the batched UpdateNormalAndDepth of the write-back needs beside the edges
+          int nLive = 0;         // observations the reference's method would use (non-bad keyframes): all of them must be edges
+          for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) if (mit->first && !mit->first->isBad()) nLive++;
+          const kfptr pRef = pMP->GetReferenceKeyFrame();
+          map<kfptr, size_t>::const_iterator rit = pRef ? observations.find(pRef) : observations.end();
+          const bool regular = nLive == nEdges && pRef && !pRef->isBad() && pRef->mUniqueId <= maxKFid && rit != observations.end();
+          g.addPointAux(regular ? pRef->mUniqueId : 0, regular ? pRef->mvKeysUn[rit->second].octave : 0, regular);
+        }
         for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); mit++) {
           const kfptr& pKF = mit->first;
           if (!pKF || pKF->isBad() || pKF->mUniqueId > maxKFid) continue;
@@ -589,6 +669,9 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   pc.lap(5);
   // every keyframe has its new pose: the per-point write-back (SetWorldPos + UpdateNormalAndDepth, 150 000 mutex-taking calls after a merge of four
   // agents) is independent from point to point
+  static const bool batched_off = std::getenv("CCM_SHIM_NO_BATCHED_NORMALS") != nullptr;
+  if (kBatchedNormals && !batched_off && nLoopKF == zeropair && f.aux_ok && f.pt_regular.size() == f.pt_id.size() && !f.cam_kf.empty()) batched_point_writeback(f);
+  else
   parallel_chunks(vpMP.size(), shim_threads(vpMP.size(), 32), [&](int, size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; i++) {
       if (vbNotIncludedMP[i]) continue;

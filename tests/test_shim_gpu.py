@@ -211,3 +211,27 @@ def test_map_fusion_gba_through_the_shim_at_baseline_scale_is_lossless():
     seen = np.bincount(o_mp[keep], minlength=n_mp) > 0
     assert np.array_equal(pts[seen].astype(np.float32), st["mp_pos"][seen])
     assert np.array_equal(st["mp_pos"][~seen], flat["mp_pos"][~seen])
+
+
+def test_batched_normal_and_depth_of_the_patched_shim_equals_the_per_point_method():
+    """shim/Optimizer_hip.cpp built against a MapPoint that carries the OPTIONAL setter of INTEGRATION.md (`SetNormalAndDepth`, three lines a maintainer may
+    add; the look-alike has it under -DCCM_LOOKALIKE_MAPPOINT_SETTER): the write-back of MapFusionGBA then hands every point's normal and scale-invariance
+    distances to ONE ccm_update_normal_and_depth call instead of calling the reference's UpdateNormalAndDepth() per point.  Everything the call leaves in
+    the map — poses, positions, normals, distance ranges — must equal, bit for bit, what the unpatched shim leaves (whose per-point calls run the
+    reference's own lines MapPoint.cpp:779-823), on a 3-agent map with fixed and free keyframes."""
+    import os
+    patched = os.path.join(os.path.dirname(mg.SHIM_LIB), "liboptimizer_hip_shim_patched.so")
+    if not os.path.exists(patched):
+        pytest.skip("patched shim not built")
+    prob = synth.make_ba_problem(n_agents=3, kfs_per_agent=60, n_points=25000, seed=31)
+    flat = mg.flat_from_ba_problem(prob, n_agents=3)
+    out = []
+    for lib in (mg.SHIM_LIB, patched):
+        g = mg.MapGraph(lib, flat)
+        assert g.map_fusion_gba(0, 20) == 0
+        out.append(g.state())
+        g.close()
+    a, b = out
+    assert np.abs(a["mp_normal"]).max() > 0.5 and (a["mp_dmax"] > a["mp_dmin"]).sum() > 20000     # the per-point method ran
+    for k in ("kf_Tcw", "mp_pos", "mp_normal", "mp_dmin", "mp_dmax"):
+        assert np.array_equal(a[k], b[k]), k
