@@ -257,6 +257,74 @@ void run_ba(FlatBA& f, double huber, int iterations, bool* pbStopFlag, std::vect
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// batched MapPoint::UpdateNormalAndDepth for the write-back of a global BA — only when MapPoint offers SetNormalAndDepth (the optional patch of
+// INTEGRATION.md; the reference keeps mNormalVector / mfMinDistance / mfMaxDistance protected without a setter, MapPoint.h:286-305).  Detected at compile
+// time, so this translation unit builds against the unpatched header too and then calls the reference's method per point.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <typename T, typename = void> struct has_normal_depth_setter : std::false_type {};
+template <typename T>
+struct has_normal_depth_setter<T, decltype(std::declval<T&>().SetNormalAndDepth(std::declval<const cv::Mat&>(), 0.0f, 0.0f), void())> : std::true_type {};
+constexpr bool kBatchedNormals = has_normal_depth_setter<MapPoint>::value;
+
+template <typename MP> void store_normal_depth(MP* p, const float* n3, float mn, float mx, std::true_type) {
+  cv::Mat n(3, 1, CV_32F);
+  n.at<float>(0) = n3[0]; n.at<float>(1) = n3[1]; n.at<float>(2) = n3[2];
+  p->SetNormalAndDepth(n, mn, mx);
+}
+template <typename MP> void store_normal_depth(MP*, const float*, float, float, std::false_type) {}
+
+// SetWorldPos + UpdateNormalAndDepth (Optimizer.cpp:843-845) of every point of the flattened problem: positions by SetWorldPos as before; normal / depth
+// range of the REGULAR points (every non-bad observation is an edge of the problem, reference keyframe among its cameras) by ONE call of
+// ccm_update_normal_and_depth (MapPoint.cpp:779-823 on the device, bit-exact: tests/test_frame_gpu.py) over the problem's own edge lists — a point's edges
+// are in the order the walk iterated its mObservations, which is the order the reference sums in; the other points take the reference's method.
+// edge_skip (local BA): observations erased after the optimisation (they are no longer in mObservations); ref_from_walk: the reference keyframe and octave
+// were recorded by the graph walk (global BA: no second GetObservations()), else they are asked of the point now (local BA: EraseObservation may have moved
+// mpRefKF, MapPoint.cpp:474-476); pos_lock: SetWorldPos's bLock as the reference call site passes it.
+void batched_point_writeback(FlatBA& f, const std::vector<char>* edge_skip, bool ref_from_walk, bool pos_lock, bool ids_are_unique_ids) {
+  const size_t np = f.pt_id.size(), nc = f.cam_id.size(), ne = f.e_pt.size();
+  std::vector<float> pos(3 * np), center(3 * nc), normal(3 * np, 0.0f), dmin(np, 0.0f), dmax(np, 0.0f);
+  std::vector<int32_t> off(np + 1, 0), kf(ne), ref(np, 0), lvl(np, 0);
+  for (size_t i = 0; i < np; i++) for (int c = 0; c < 3; c++) pos[3 * i + c] = (float)f.pt_xyz[3 * i + c];   // what pointPos() hands to SetWorldPos
+  for (size_t i = 0; i < nc; i++) {
+    const cv::Mat Ow = f.cam_kf[i]->GetCameraCenter();                                                      // after the keyframe write-back
+    for (int c = 0; c < 3; c++) center[3 * i + c] = Ow.at<float>(c);
+  }
+  for (size_t k = 0; k < ne; k++) if (!edge_skip || !(*edge_skip)[k]) off[(size_t)f.e_pt[k] + 1]++;
+  for (size_t i = 0; i < np; i++) off[i + 1] += off[i];
+  {
+    std::vector<int32_t> fill(off.begin(), off.end() - 1);
+    for (size_t k = 0; k < ne; k++) if (!edge_skip || !(*edge_skip)[k]) kf[(size_t)fill[(size_t)f.e_pt[k]]++] = f.e_cam[k];   // stable: the walk's order inside a point
+  }
+  std::vector<char> regular(np, 0);
+  for (size_t i = 0; i < np; i++) {
+    int32_t r = -1;
+    if (ref_from_walk) { r = f.pt_regular[i] ? f.cam_index.find(f.pt_ref_cam_id[i]) : -1; lvl[i] = f.pt_ref_level[i]; }
+    else if (!f.pt_mp[i]->isBad()) {
+      const Optimizer::kfptr pRef = f.pt_mp[i]->GetReferenceKeyFrame();
+      const int idx = pRef ? f.pt_mp[i]->GetIndexInKeyFrame(pRef) : -1;
+      if (pRef && idx >= 0) { r = f.cam_index.find(ids_are_unique_ids ? pRef->mUniqueId : (size_t)Optimizer::GetID(pRef->mId, true)); lvl[i] = pRef->mvKeysUn[idx].octave; }
+    }
+    regular[i] = r >= 0 && off[i + 1] > off[i];
+    ref[i] = r >= 0 ? r : 0;
+  }
+  const std::vector<float>& sf = f.cam_kf[0]->mvScaleFactors;                                                // one table per map (ORBextractor parameters)
+  check(ccm_update_normal_and_depth(thread_ctx(), (int)np, pos.data(), off.data(), kf.data(), (int)nc, center.data(), ref.data(), lvl.data(), sf.data(),
+                                    (int)f.cam_kf[0]->mnScaleLevels, normal.data(), dmin.data(), dmax.data()), "ccm_update_normal_and_depth");
+  parallel_chunks(np, shim_threads(np, 32), [&](int, size_t b, size_t e) {
+    for (size_t i = b; i < e; i++) {
+      MapPoint* pMP = f.pt_mp[i];
+      if (pMP->isBad()) continue;
+      cv::Mat p(3, 1, CV_32F);
+      for (int c = 0; c < 3; c++) p.at<float>(c) = pos[3 * i + c];
+      pMP->SetWorldPos(p, pos_lock);
+      if (regular[i]) store_normal_depth(pMP, &normal[3 * i], dmin[i], dmax[i], has_normal_depth_setter<MapPoint>());
+      else pMP->UpdateNormalAndDepth();
+    }
+  });
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // client side
 // ---------------------------------------------------------------------------------------------------------------------------------
 void Optimizer::GlobalBundleAdjustemntClient(mapptr pMap, size_t ClientId, int nIterations, bool* pbStopFlag, const idpair nLoopKF, const bool bRobust) {
@@ -505,6 +573,21 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     pKFl->mbUpdatedByServer = false;
   }
   pc.lap(5);
+  static const bool batched_off = std::getenv("CCM_SHIM_NO_BATCHED_NORMALS") != nullptr;
+  if (kBatchedNormals && !batched_off && !f.cam_kf.empty() && !f.pt_id.empty()) {
+    // (with the optional MapPoint::SetNormalAndDepth) positions as below, normals and distance ranges of all local points by one device call over the
+    // problem's edges minus the erased observations
+    for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++)
+      if ((*lit)->isBad() && pMap->GetMpPtr((*lit)->mId)) {
+        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << ":" << __LINE__ << " MP bad but not erased from map" << endl;
+        throw estd::infrastructure_ex();
+      }
+    std::vector<char> erased(f.nEdges(), 0);
+    for (size_t i = 0, iend = f.nEdges(); i < iend; i++) erased[i] = !vpMapPointEdgeMono[i]->isBad() && (chi2[i] > 5.991 || !dpos[i]);
+    // (an observation erased above whose point turned bad with it belongs to a point the helper skips)
+    for (size_t i = 0, iend = f.nEdges(); i < iend; i++) if (vpMapPointEdgeMono[i]->isBad()) erased[i] = 1;
+    batched_point_writeback(f, &erased, false, false, false);
+  } else
   for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
     mpptr pMP = *lit;
     if (pMP->isBad()) {
@@ -520,65 +603,6 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   }
   pc.lap(6);
   if (SysState != eSystemState::SERVER) pMap->UnLockMapUpdate();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// batched MapPoint::UpdateNormalAndDepth for the write-back of a global BA — only when MapPoint offers SetNormalAndDepth (the optional patch of
-// INTEGRATION.md; the reference keeps mNormalVector / mfMinDistance / mfMaxDistance protected without a setter, MapPoint.h:286-305).  Detected at compile
-// time, so this translation unit builds against the unpatched header too and then calls the reference's method per point.
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <typename T, typename = void> struct has_normal_depth_setter : std::false_type {};
-template <typename T>
-struct has_normal_depth_setter<T, decltype(std::declval<T&>().SetNormalAndDepth(std::declval<const cv::Mat&>(), 0.0f, 0.0f), void())> : std::true_type {};
-constexpr bool kBatchedNormals = has_normal_depth_setter<MapPoint>::value;
-
-template <typename MP> void store_normal_depth(MP* p, const float* n3, float mn, float mx, std::true_type) {
-  cv::Mat n(3, 1, CV_32F);
-  n.at<float>(0) = n3[0]; n.at<float>(1) = n3[1]; n.at<float>(2) = n3[2];
-  p->SetNormalAndDepth(n, mn, mx);
-}
-template <typename MP> void store_normal_depth(MP*, const float*, float, float, std::false_type) {}
-
-// SetWorldPos + UpdateNormalAndDepth (Optimizer.cpp:843-845) of every point of the flattened problem: positions by SetWorldPos as before; normal / depth
-// range of the REGULAR points (every non-bad observation is an edge of the problem, reference keyframe among its cameras) by ONE call of
-// ccm_update_normal_and_depth (MapPoint.cpp:779-823 on the device, bit-exact: tests/test_frame_gpu.py) over the problem's own edge lists — a point's edges
-// are in the order the walk iterated its mObservations, which is the order the reference sums in; the other points take the reference's method.
-void batched_point_writeback(FlatBA& f) {
-  const size_t np = f.pt_id.size(), nc = f.cam_id.size(), ne = f.e_pt.size();
-  std::vector<float> pos(3 * np), center(3 * nc), normal(3 * np, 0.0f), dmin(np, 0.0f), dmax(np, 0.0f);
-  std::vector<int32_t> off(np + 1, 0), kf(ne), ref(np, 0), lvl(np, 0);
-  for (size_t i = 0; i < np; i++) for (int c = 0; c < 3; c++) pos[3 * i + c] = (float)f.pt_xyz[3 * i + c];   // what pointPos() hands to SetWorldPos
-  for (size_t i = 0; i < nc; i++) {
-    const cv::Mat Ow = f.cam_kf[i]->GetCameraCenter();                                                      // after the keyframe write-back
-    for (int c = 0; c < 3; c++) center[3 * i + c] = Ow.at<float>(c);
-  }
-  for (size_t k = 0; k < ne; k++) off[(size_t)f.e_pt[k] + 1]++;
-  for (size_t i = 0; i < np; i++) off[i + 1] += off[i];
-  {
-    std::vector<int32_t> fill(off.begin(), off.end() - 1);
-    for (size_t k = 0; k < ne; k++) kf[(size_t)fill[(size_t)f.e_pt[k]]++] = f.e_cam[k];                     // stable: the walk's order inside a point
-  }
-  std::vector<char> regular(np, 0);
-  for (size_t i = 0; i < np; i++) {
-    const int32_t r = f.pt_regular[i] ? f.cam_index.find(f.pt_ref_cam_id[i]) : -1;
-    regular[i] = r >= 0;
-    ref[i] = r >= 0 ? r : 0; lvl[i] = f.pt_ref_level[i];
-    if (!regular[i]) off[i + 1] = off[i + 1];                                                               // (its result is ignored below)
-  }
-  const std::vector<float>& sf = f.cam_kf[0]->mvScaleFactors;                                                // one table per map (ORBextractor parameters)
-  check(ccm_update_normal_and_depth(thread_ctx(), (int)np, pos.data(), off.data(), kf.data(), (int)nc, center.data(), ref.data(), lvl.data(), sf.data(),
-                                    (int)f.cam_kf[0]->mnScaleLevels, normal.data(), dmin.data(), dmax.data()), "ccm_update_normal_and_depth");
-  parallel_chunks(np, shim_threads(np, 32), [&](int, size_t b, size_t e) {
-    for (size_t i = b; i < e; i++) {
-      MapPoint* pMP = f.pt_mp[i];
-      if (pMP->isBad()) continue;
-      cv::Mat p(3, 1, CV_32F);
-      for (int c = 0; c < 3; c++) p.at<float>(c) = pos[3 * i + c];
-      pMP->SetWorldPos(p, true);
-      if (regular[i]) store_normal_depth(pMP, &normal[3 * i], dmin[i], dmax[i], has_normal_depth_setter<MapPoint>());
-      else pMP->UpdateNormalAndDepth();
-    }
-  });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -670,7 +694,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   // every keyframe has its new pose: the per-point write-back (SetWorldPos + UpdateNormalAndDepth, 150 000 mutex-taking calls after a merge of four
   // agents) is independent from point to point
   static const bool batched_off = std::getenv("CCM_SHIM_NO_BATCHED_NORMALS") != nullptr;
-  if (kBatchedNormals && !batched_off && nLoopKF == zeropair && f.aux_ok && f.pt_regular.size() == f.pt_id.size() && !f.cam_kf.empty()) batched_point_writeback(f);
+  if (kBatchedNormals && !batched_off && nLoopKF == zeropair && f.aux_ok && f.pt_regular.size() == f.pt_id.size() && !f.cam_kf.empty()) batched_point_writeback(f, nullptr, true, true, true);
   else
   parallel_chunks(vpMP.size(), shim_threads(vpMP.size(), 32), [&](int, size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; i++) {

@@ -235,3 +235,16 @@ def test_batched_normal_and_depth_of_the_patched_shim_equals_the_per_point_metho
     assert np.abs(a["mp_normal"]).max() > 0.5 and (a["mp_dmax"] > a["mp_dmin"]).sum() > 20000     # the per-point method ran
     for k in ("kf_Tcw", "mp_pos", "mp_normal", "mp_dmin", "mp_dmax"):
         assert np.array_equal(a[k], b[k]), k
+    # the local bundle adjustment's write-back the same way (observations erased as outliers leave the lists; EraseObservation may move a point's
+    # reference keyframe, so it is asked of the point after the erasures)
+    lflat = mg.flat_from_ba_problem(synth.make_ba_config("lba_c2"))
+    out = []
+    for lib in (mg.SHIM_LIB, patched):
+        g = mg.MapGraph(lib, lflat)
+        assert g.local_ba(15, client_id=0) == 0
+        out.append(g.state())
+        g.close()
+    a, b = out
+    assert (a["obs_alive"] == 0).sum() > 100                                                       # outlier observations were erased
+    for k in ("kf_Tcw", "mp_pos", "mp_normal", "mp_dmin", "mp_dmax", "mp_bad", "obs_alive"):
+        assert np.array_equal(a[k], b[k]), k
