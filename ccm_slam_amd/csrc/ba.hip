@@ -1352,6 +1352,8 @@ __device__ __forceinline__ bool pers_exchange(int t /* threadIdx.x */, unsigned 
 #pragma unroll
     for (int j = 0; j < kPer; j++) { val[j] = 0; if (t + j * kWave >= nwg) done |= 1u << j; }
     bool ok_w = true;
+    // (measured and dropped, round 3: a second poll request ~0.25 us behind the first so that an incomplete first answer does not cost a whole further round
+    // trip: the per-unit time inside an exchange went from 3.4 to 4.1-4.4 us — twice the polling traffic on the slot lines slows every answer down)
     for (long spins = 0;; spins++) {
 #pragma unroll
       for (int j = 0; j < kPer; j++) {
@@ -2024,7 +2026,10 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     if (coarse) { __syncthreads(); coarse_restrict(qs + ob); }
     PERS_TICK(1)
     double pq = 0;
+    long long tw0 = 0;
+    if (a.dbg && t == 0) tw0 = wall_clock64();
     alive = pers_exchange(tq, slots_pq, nwg, u, pq_t, false, ++epoch, a.bar + 1, red, &pq, ibuf + 2);
+    if (a.dbg && t == 0) a.dbg[32 + 2 * u] += wall_clock64() - tw0;   // per unit: time inside exchange 1 (its own wait for the slowest unit + the exchange latency)
     PERS_TICK(2)
     if (!alive) { fail = 1; break; }
     const double q_partner = (tq < m && !(tq >= ob && tq < ob + mo)) ? coh_load(d.q + 6 * (size_t)s0 + tq) : 0.0;
@@ -2039,7 +2044,9 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
     const double rz_t2 = apply_W();
     PERS_TICK(4)
     rz_prev = rz;
+    if (a.dbg && t == 0) tw0 = wall_clock64();
     alive = pers_exchange(tq, slots_rz, nwg, u, rz_t2, false, ++epoch, a.bar + 1, red, &rz, ibuf + 2);
+    if (a.dbg && t == 0) a.dbg[33 + 2 * u] += wall_clock64() - tw0;
     PERS_TICK(5)
     if (!alive) { fail = 1; break; }
     PERS_TICK(6)
@@ -2903,6 +2910,18 @@ static void pers_dbg_dump(ccm_ba* ba) {
   if (!ba->pers_grid || !getenv("CCM_BA_PERS_DBG")) return;
   long long h[16];
   hipMemcpy(h, ba->d_pers_bar + 4, sizeof(h), hipMemcpyDeviceToHost);
+  {
+    std::vector<long long> w(2 * (size_t)ba->pers_grid);
+    hipMemcpy(w.data(), (long long*)(ba->d_pers_bar + 4) + 32, w.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    const double itn = (double)std::max<long long>(h[12], 1);
+    for (int x = 0; x < 2; x++) {
+      std::vector<double> v;
+      for (int g = 0; g < ba->pers_grid; g++) if (w[2 * g + x] > 0) v.push_back(w[2 * g + x] * 0.01 / itn);
+      std::sort(v.begin(), v.end());
+      if (!v.empty()) fprintf(stderr, "[ccm_ba] persistent PCG, time inside exchange %d per unit and iteration (us): min %.2f  p10 %.2f  median %.2f  p90 %.2f  max %.2f  (%zu units)\n",
+                              x + 1, v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+    }
+  }
   const double it = (double)std::max<long long>(h[12], 1), nl = (double)std::max<long long>(h[13], 1);
   fprintf(stderr, "[ccm_ba] persistent PCG, workgroup 0: %lld iterations in %lld launches; us/iteration: stage_p %.2f spmv+dot %.2f barrier1 %.2f "
           "sum_pq %.2f update+W %.2f barrier2 %.2f sum_rz %.2f | us/launch: assemble %.1f cholesky %.1f inverse %.1f W %.1f start %.1f\n",

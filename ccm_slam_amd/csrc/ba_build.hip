@@ -807,7 +807,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     ba->pers_grid = 0;
     d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
     if (pers_try && !hs.pers_bad) {
-      BB_RC(keep_get(ba, 4 + 2 * 16, &ba->d_pers_bar, true));   // abort flag + debug clocks
+      BB_RC(keep_get(ba, 4 + 2 * 16 + 4 * 512, &ba->d_pers_bar, true));   // abort flag + debug clocks (workgroup 0's phases; then per workgroup the time spent in the two exchanges)
       BB_RC(keep_get(ba, 4 * (size_t)pers_grid_want, &ba->d_pers_part, true));   // [2][2][grid] slot words
       ba->pers_grid = pers_grid_want;
       if (coarse_pers) BB_RC(coarse_buffers(pers_grid_want));
