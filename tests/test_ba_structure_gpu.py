@@ -176,8 +176,8 @@ def check(ctx, prob, rank=0, nranks=1):
     Cp, Lp, Lloc, Eloc, nOff, max_ce, units_max, pers_grid, c_na, c_ncb, n_chunk, lb = (int(v) for v in sz)
     # intervals of the coarse space: 16 cameras where the persistent solver runs and 12 rows of Ac^-1 (6 (Cp / 16 + 1) floats each, padded to 64) fit its LDS
     # (<= 768), 32 otherwise (ba_build.hip)
-    nc16 = -(-6 * (-(-Cp // 16) + 1) // 64) * 64
-    agg = 16 if pers_grid and nc16 <= 768 else 32
+    nc = lambda a: -(-6 * (-(-Cp // a) + 1) // 64) * 64
+    agg = 32 if not pers_grid else 16 if nc(16) <= 768 else 24 if nc(24) <= 768 else 32
     if c_na: assert c_na == -(-Cp // agg)
     S = host_structure(prob, rank, nranks, agg)
     assert (Cp, Lp, Lloc, Eloc, nOff, max_ce, lb) == (S["Cp"], S["Lp"], S["Lloc"], S["Eloc"], S["nOff"], S["max_cam_edges"], S["lb"])
