@@ -123,6 +123,7 @@ struct ccm_ba {
   double *d_raw_cam = nullptr, *d_raw_pt = nullptr;   // the caller's cameras [n_cam][7] / landmarks [n_pt][3] as uploaded (create / reset); d_raw_pt also stages the download
   int *d_slot_pt = nullptr, *d_loc_edge_orig = nullptr;   // [Lp] landmark slot -> landmark index; [Eloc]
   std::vector<std::pair<void*, size_t>> allocs;   // pooled blocks (ccm_pool_get)
+  std::vector<std::pair<void*, size_t>> zero_list; // blocks to clear before first use (ccm_ba_create: one launch for all of them)
   BaDev d{};
   int cur = 0;
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
