@@ -734,7 +734,10 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       }
     coarse_size(agg, &na, &Nc);
     d.agg = agg;
-    const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && pers_fits(agg, na, Nc);
+    // (windows of up to 32 free cameras are solved exactly by ba_solve_dense2 and never see a coarse level: its block lists — a sort, a run-length encode and
+    // half a dozen short kernels of a launch-bound 0.7 ms build — are skipped there unless that solver is switched off)
+    static const bool dense2_off = getenv("CCM_BA_DENSE2") && atoi(getenv("CCM_BA_DENSE2")) == 0;
+    const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && pers_fits(agg, na, Nc) && (Cp > kDense2MaxCp || dense2_off);
     const bool coarse_mk = pers_wanted && !getenv("CCM_BA_NO_COARSE") && agg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
     unsigned* uq = nullptr; unsigned* cnts = nullptr; int* n_runs = nullptr;
     if (coarse_pers || coarse_mk) {
