@@ -23,8 +23,9 @@ the total problem is fixed => "scaling": "strong".
 
 The timed region is exactly K steps bracketed by barrier + device synchronise, MAX over ranks.  `roofline` = the dominant kernel,
 `roofline_trial` = the whole LM trial against SURVEY §8(d)'s byte formula, `kernels` = every kernel class of the call (HIP events on
-the launching stream, taken in a second, untimed pass).  `cpu_baseline` = the reference's own Optimizer.cpp + g2o compiled verbatim
-(oracle/_ref/liboptimizer_ref.so, look-alike Eigen) on ONE LM iteration of the same map through the class API, the CPU port beside it.
+the launching stream, taken in a second, untimed pass).  `cpu_baseline` = the reference's own g2o compiled verbatim (oracle/_ref/libg2o_ref.so,
+thirdparty/g2o built -O2 -g as its CMake default does, look-alike Eigen; the graph built as Optimizer::MapFusionGBA builds it by
+oracle/ref_g2o_driver.cpp — NOT through the class API) on optimize(1) and optimize(4) of the same map, the CPU port beside it.
 """
 from __future__ import annotations
 
@@ -310,12 +311,19 @@ def ba_kernel_bytes(counts):
         # row kernel: every observation's record (or W) and [D^-1 | b_l] once, every off-diagonal and diagonal block written once
         "BA_SCHUR_OFF": w_e * E + (48.0 + 24.0) * L + 288.0 * B + (96.0 * C if compact else 0.0),
         "BA_SCHUR_DIAG": (144.0 + 48.0 + 24.0 + 4.0) * E + (288.0 * 2 + 96.0) * C,
-        "BA_LINEARIZE": (56.0 + 32.0 + 24.0 + 12.0 + w_e) * E + (24.0 + 72.0) * L,
-        "BA_CAM": (24.0 + 24.0 + 8.0 + (32.0 if compact else 0.0)) * E + (56.0 + 288.0 + 48.0 + (96.0 if compact else 0.0)) * C,
+        # per observation: landmark / camera / slot indices 12, observation 16, information 8, record (or block) out; per landmark: range 8, position 24 in,
+        # Hll 48 + b_l 24 out; per camera (a 56 + 32-byte table that the observations gather from and that stays in L2): pose + intrinsics, counted ONCE
+        "BA_LINEARIZE": (36.0 + w_e) * E + 104.0 * L + 88.0 * C,
+        # camera-major pass: edge / landmark indices 8, observation 16, information 8, record out; the landmark positions it gathers are a 24 L table (once);
+        # per camera pose + intrinsics 88 in, Hpp 288 + b_p 48 (+ rotation / focal record 96) out
+        "BA_CAM": (32.0 + (32.0 if compact else 0.0)) * E + 24.0 * L + (88.0 + 288.0 + 48.0 + (96.0 if compact else 0.0)) * C,
         "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
-        "BA_BACKSUB": (w_e + 48.0 + 56.0 + 24.0 + 9.0 + 8.0) * E + (24.0 * 3 + 48.0) * L + (96.0 * C if compact else 0.0),
+        # per observation: indices 12, record (or block) in, observation 16 + information 8 in, chi2 8 + depth flag 1 out; per landmark: range 4, position 24 +
+        # b_l 24 + D^-1 48 in, trial position 24 out; per camera, gathered tables counted ONCE (round 3 counted them per observation, which put this kernel
+        # and the linearisation above the achievable bandwidth): step 48, trial pose 56, intrinsics 32 (+ rotation / focal record 96)
+        "BA_BACKSUB": (45.0 + w_e) * E + 124.0 * L + (136.0 + (96.0 if compact else 0.0)) * C,
         "BA_UPDATE": (56.0 * 2 + 48.0 * 2) * C,
-        "BA_CHI2": (56.0 + 24.0 + 9.0 + 8.0) * E + 24.0 * L,
+        "BA_CHI2": (8.0 + 24.0 + 9.0) * E + 28.0 * L + 88.0 * C,
         "BA_COARSE": 288.0 * B + 288.0 * C,               # S and the prolongation blocks once
         "BA_REDUCE": 16.0 * (E / 256.0),
     }
@@ -613,6 +621,8 @@ def main():
         # over its measured duration against the HBM peak whatever the limiter, so the number stays comparable across rounds.
         roofline = {"kernel": dom["kernel"], "bound": "hbm" if dom["limiter"] == "hbm" else dom["limiter"], "achieved": dom["achieved_GBps"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_of_hbm_peak"], "traffic": dom["pmc_hbm_bytes_per_launch"],
+                    "traffic_source": "profiles/pmc_latest.json — the last COMMITTED rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload (2 x FETCH + WRITE per "
+                                      "launch, scripts/profile.sh); counters cannot be collected inside this process, so this is NOT measured in this run",
                     "launches": dom["launches_per_call"], "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                     "share_of_call": round(dom["ms_per_call"] / max(sum(k["ms_per_call"] for k in kernels), 1e-9), 3)}
     # whole LM trial against the HBM roofline, SURVEY §8(d): bytes(trial) = 656 E + 312 L + 700 C + 576 S
@@ -625,8 +635,8 @@ def main():
                       "frac_of_achievable_6300": round(trial_gbs / 6300.0, 5),
                       "kernel_ms_per_call": round(sum(k["ms_per_call"] for k in kernels), 3), "profiled_call_ms": round(prof_call_ms, 3)}
 
-    # ---- CPU baseline on this box's host cores (rank 0, N = 1): the REFERENCE's own Optimizer.cpp + g2o compiled verbatim, one LM iteration of the same
-    # map through the class API (bounded sample: ~25 s); the CPU port (oracle/ba_ref.cpp) beside it
+    # ---- CPU baseline on this box's host cores (rank 0, N = 1): the REFERENCE's own g2o compiled verbatim (libg2o_ref.so), optimize(1) and optimize(4) of the same
+    # map (graph built by oracle/ref_g2o_driver.cpp the way MapFusionGBA builds it; bounded sample: ~25 s); the CPU port (oracle/ba_ref.cpp) beside it
     cpu = None
     n_agents = int(synth.BA_CONFIGS.get(args.workload, {}).get("n_agents", 1))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -656,7 +666,7 @@ def main():
         if ref and ref["ms_per_iter"] > 0:
             cpu = {"value": round(1e3 / ref["ms_per_iter"], 5), "unit": "LM iter/s", "cores": 1, "kind": "reference",
                    "ms_per_iter": ref["ms_per_iter"], "first_iteration_s": ref["first_iteration_s"], "four_iterations_s": ref["four_iterations_s"],
-                   "sample": f"the reference's own g2o (thirdparty/g2o compiled verbatim, oracle/_ref/libg2o_ref.so, -O3, 1 thread as in the reference build; graph built as "
+                   "sample": f"the reference's own g2o (thirdparty/g2o compiled verbatim, oracle/_ref/libg2o_ref.so, -O2 -g = g2o's CMake default, oracle/Makefile.ref:17; 1 thread as in the reference build; graph built as "
                              f"Optimizer::MapFusionGBA builds it) on {args.workload} ({prob['n_cam']} KFs, {prob['n_pt']} landmarks, {prob['n_edge']} observations): optimize(1) and "
                              "optimize(4) from the same initial estimate; value = 3 iterations / (t4 - t1), i.e. WITHOUT the one-off structure build and symbolic ordering "
                              "(first_iteration_s), which the LOOK-ALIKE Eigen of oracle/ref_shim (minimum-degree SimplicialLDLT, no supernodes) does far slower than real "

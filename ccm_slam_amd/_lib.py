@@ -75,6 +75,22 @@ def lib():
     return _lib
 
 
+_hooks = None
+
+
+def hooks():
+    """libccm_testhooks.so: the TEST-ONLY entry points (include/ccm_testhooks.h).  A separate library on top of the product; tests/ and scripts/ only."""
+    global _hooks
+    if _hooks is None:
+        lib()   # the product library first: the hooks link against it
+        path = os.path.join(_HERE, "libccm_testhooks.so")
+        if not os.path.exists(path):
+            raise CcmError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _hooks = C.CDLL(path)
+        _hooks.ccm_comm_loopback_destroy.restype = None
+    return _hooks
+
+
 def check(rc: int, ctx=None):
     if rc != 0:
         msg = lib().ccm_last_error(ctx)

@@ -26,6 +26,7 @@
 //  * LM control (lambda schedule, rho test, stop rules) runs on the host exactly as
 //    optimization_algorithm_levenberg.cpp:61-164 does; one 48-byte pinned D2H read per trial.
 #include "common.h"
+#include "test_internal.h"
 #include "ba_types.h"
 #include "ba_math.h"
 #include <algorithm>
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts(BaDev d, int cur) {
     double Ji[6], Jj[12];
     ba_jacobians(T, K4, X, Ji, Jj);
     const double om = d.info[e];
+    if (om == 0.0) {   // an edge that left through ccm_ba_set_edge_levels: exact zeros, whatever its residual is (g2o never evaluates a level-1 edge; inf * 0 would poison the sums)
+      if (d.ed_cslot[e] >= 0) { double* W = d.W + 18 * (size_t)e; for (int k = 0; k < 18; k++) W[k] = 0.0; }
+      continue;
+    }
     double rho0, w;
     ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
     const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
@@ -162,13 +167,20 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
     ba_q_to_R(T, Rm);
     ba_jac_from_xc(Xc[0], Xc[1], iz, K4[0], K4[1], Rm, Ji, Jj);   // = ba_jacobians(T, K4, X, Ji, Jj)
     const double om = d.info[e];
+    const bool off = om == 0.0;   // an edge that left through ccm_ba_set_edge_levels contributes exact zeros whatever its residual is (g2o never evaluates a level-1 edge; inf * 0 would poison the sums)
     double rho0, w;
-    ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
-    const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    ba_huber(off ? 0.0 : (r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
+    const double o0 = off ? 0.0 : -om * r0 * w, o1 = off ? 0.0 : -om * r1 * w, wom = off ? 0.0 : w * om;
+    if (off) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) Ji[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) Jj[k] = 0.0;
+    }
     if (d.E4L && d.ed_cslot[e] >= 0) {   // the compact record in landmark-major order (ba_backsub_chi2_e): coalesced, 32 bytes instead of the 144 of the block
       typedef double v2d __attribute__((ext_vector_type(2)));
       v2d* E = reinterpret_cast<v2d*>(d.E4L + 4 * (size_t)e);
-      v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = iz; eb[1] = wom;
+      v2d ea, eb; ea[0] = off ? 0.0 : Xc[0]; ea[1] = off ? 0.0 : Xc[1]; eb[0] = off ? 0.0 : iz; eb[1] = wom;
       E[0] = ea; E[1] = eb;
     }
     hb[t][0] = Ji[0] * o0 + Ji[3] * o1; hb[t][1] = Ji[1] * o0 + Ji[4] * o1; hb[t][2] = Ji[2] * o0 + Ji[5] * o1;
@@ -257,13 +269,19 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
       Jj[6] = (1 + y * y * iz2) * fy; Jj[7] = -x * y * iz2 * fy; Jj[8] = -x * iz * fy; Jj[9] = 0; Jj[10] = -iz * fy; Jj[11] = y * iz2 * fy;
     }
     const double om = d.info[e];
+    const bool off = om == 0.0;   // (see ba_linearize_pts_e)
     double rho0, w;
-    ba_huber((r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
-    const double o0 = -om * r0 * w, o1 = -om * r1 * w, wom = w * om;
+    ba_huber(off ? 0.0 : (r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
+    const double o0 = off ? 0.0 : -om * r0 * w, o1 = off ? 0.0 : -om * r1 * w, wom = off ? 0.0 : w * om;
+    if (off) {
+      Xc[0] = Xc[1] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 12; k++) Jj[k] = 0.0;
+    }
     if (d.E4) {   // what ba_schur_row3 re-derives this observation's Hpl block from (the values the landmark-side kernel computes for the same observation)
       typedef double v2d __attribute__((ext_vector_type(2)));
       v2d* E = reinterpret_cast<v2d*>(d.E4 + 4 * (size_t)s);
-      v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = iz; eb[1] = wom;
+      v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = off ? 0.0 : iz; eb[1] = wom;
       E[0] = ea; E[1] = eb;
     }
     int k = 0;
@@ -2282,7 +2300,7 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2(BaDev d, int cur, double
       const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
       double r0, r1;
       const double zc = ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
-      const double c2 = (r0 * r0 + r1 * r1) * d.info[e];
+      const double c2 = d.info[e] != 0.0 ? (r0 * r0 + r1 * r1) * d.info[e] : 0.0;   // a deactivated edge adds an exact zero whatever its residual is
       double rho0, w;
       ba_huber(c2, d.huber, rho0, w);
       chi += rho0;
@@ -2361,7 +2379,7 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, doub
     const double K4[4] = {d.K[4 * c], d.K[4 * c + 1], d.K[4 * c + 2], d.K[4 * c + 3]};
     double r0, r1;
     const double zc = ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
-    const double c2 = (r0 * r0 + r1 * r1) * d.info[e];
+    const double c2 = d.info[e] != 0.0 ? (r0 * r0 + r1 * r1) * d.info[e] : 0.0;   // (see ba_backsub_chi2)
     double rho0, w;
     ba_huber(c2, d.huber, rho0, w);
     chi = rho0;
@@ -2849,7 +2867,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
 // Summing the downloads of all ranks' handles must reproduce the single-rank system (tests/test_ba_gpu.py).
 // Test hook: coarse operator Ac = P^T (S + lambda I) P of the current state and its inverse ([6 na]^2 each, row-major), plus
 // the prolongation blocks P_k ([Cp][36]).  *na = 0 when the coarse level is not in use for this problem.
-extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap) {
+int ccm_internal::ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap) {
   if (!ba || !na) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
@@ -2876,7 +2894,7 @@ extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* A
   return CCM_OK;
 }
 
-extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count) {
+int ccm_internal::ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count) {
   if (!ba || !count) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
@@ -3022,17 +3040,20 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   return CCM_OK;
 }
 
-// edges whose level is not 0 leave the optimisation: their information becomes 0, so every sum they enter gets an exact zero
-__global__ void ba_deactivate_edges(double* info, const int* loc_edge_orig, const uint8_t* level, int Eloc) {
+// edges whose level is not 0 leave the optimisation: their information becomes 0, so every sum they enter gets an exact zero; an edge whose level is 0
+// (again) gets the information it was created with
+__global__ void ba_deactivate_edges(double* info, const double* info_orig, const int* loc_edge_orig, const uint8_t* level, int Eloc) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < Eloc && level[loc_edge_orig[k]] != 0) info[k] = 0.0;
+  if (k < Eloc) info[k] = level[loc_edge_orig[k]] != 0 ? 0.0 : info_orig[k];
 }
 
 // The second stage of Optimizer::LocalBundleAdjustmentClient (Optimizer.cpp:545-566: outlier edges -> setLevel(1), robust kernel off,
 // initializeOptimization(0), optimize(10)) on the SAME handle: edges with e_level != 0 are taken out by zeroing their information (exact zeros in every
 // sum: the same normal equations as a rebuilt structure, whose rows / blocks they would merely not have), the Huber delta is replaced, the estimate stays.
-// Edges that were inactive at ccm_ba_create are not part of the handle and cannot come back.  ccm_ba_download keeps returning, for a deactivated edge,
-// the chi2 of the last pass it took part in (g2o leaves the _error of a level-1 edge alone).
+// Edges that were inactive at ccm_ba_create are not part of the handle and cannot come back; every other edge can: the call is a pure function of
+// (e_level, huber_delta) and the information stored at create time (d_info_orig), so a handle that is re-run (push / pop state) passes its first-stage
+// levels and delta again and gets the first-stage problem back.  ccm_ba_download keeps returning, for a deactivated edge, the chi2 of the last pass it
+// took part in (g2o leaves the _error of a level-1 edge alone).
 extern "C" int ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double huber_delta) {
   if (!ba || !e_level) return CCM_E_ARG;
   ccm_ctx* ctx = ba->ctx;
@@ -3041,8 +3062,12 @@ extern "C" int ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double
     void* d_lvl = nullptr;
     RC(ccm_scratch(ctx, (size_t)ba->n_edge, &d_lvl));
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_lvl, e_level, (size_t)ba->n_edge, hipMemcpyDefault, ctx->stream));
-    if (ba->Eloc) hipLaunchKernelGGL(ba_deactivate_edges, dim3(ccm_div_up(ba->Eloc, kTPB)), dim3(kTPB), 0, ctx->stream, const_cast<double*>(ba->d.info), (const int*)ba->d_loc_edge_orig,
-                                     (const uint8_t*)d_lvl, ba->Eloc);
+    if (ba->Eloc && !ba->d_info_orig) {   // first call: keep what ccm_ba_create stored
+      RC(dev_alloc<double>(ba, (size_t)ba->Eloc, &ba->d_info_orig, false));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_info_orig, ba->d.info, (size_t)ba->Eloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (ba->Eloc) hipLaunchKernelGGL(ba_deactivate_edges, dim3(ccm_div_up(ba->Eloc, kTPB)), dim3(kTPB), 0, ctx->stream, const_cast<double*>(ba->d.info), (const double*)ba->d_info_orig,
+                                     (const int*)ba->d_loc_edge_orig, (const uint8_t*)d_lvl, ba->Eloc);
     CCM_HIP_CHECK(ctx, hipGetLastError());
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // e_level may be a pageable host array
   }

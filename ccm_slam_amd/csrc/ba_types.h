@@ -155,6 +155,7 @@ struct ccm_ba {
   double* d_pt_full = nullptr;
   double* d_hpp_full = nullptr;
   double *d_saved_cam = nullptr, *d_saved_pt = nullptr;   // ccm_ba_push_state
+  double* d_info_orig = nullptr;   // the edges' information as ccm_ba_create stored it: ccm_ba_set_edge_levels derives the current one from it, so levels can go back to 0
   double ms_setup = 0;
   // stop flag of the running ccm_ba_run (the reference's bool* pbStopFlag).  One rank: read where g2o calls terminate().
   // Sharded: the local value rides in the per-trial all-reduce and only the reduced value (stop_any) is acted on.

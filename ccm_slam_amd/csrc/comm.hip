@@ -2,6 +2,7 @@
 // global BA (one all-reduce of the reduced camera system per LM trial).  The
 // reference has no collective at all; this is new MI355X-side machinery.
 #include "common.h"
+#include "test_internal.h"
 #include <rccl/rccl.h>
 #include <cstring>
 #include <cstdlib>
@@ -95,15 +96,15 @@ int loop_allreduce(ccm_ctx* ctx, double* d_buf, size_t n, int is_max) {
 }
 }  // namespace
 
-extern "C" int ccm_comm_loopback_create(int nranks, void** group) {
+int ccm_internal::comm_loopback_create(int nranks, void** group) {
   if (!group || nranks < 1) return CCM_E_ARG;
   LoopGroup* g = new LoopGroup();
   g->nranks = nranks; g->buf.assign((size_t)nranks, nullptr); g->count.assign((size_t)nranks, 0);
   *group = g;
   return CCM_OK;
 }
-extern "C" void ccm_comm_loopback_destroy(void* group) { delete (LoopGroup*)group; }
-extern "C" int ccm_comm_init_loopback(ccm_ctx* ctx, void* group, int rank) {
+void ccm_internal::comm_loopback_destroy(void* group) { delete (LoopGroup*)group; }
+int ccm_internal::comm_init_loopback(ccm_ctx* ctx, void* group, int rank) {
   LoopGroup* g = (LoopGroup*)group;
   if (!ctx || !g || rank < 0 || rank >= g->nranks) return ccm_set_error(ctx, CCM_E_ARG, "ccm_comm_init_loopback: bad args");
   if (ctx->comm || ctx->loop_group) return ccm_set_error(ctx, CCM_E_STATE, "ccm_comm_init_loopback: communicator already attached");

@@ -9,6 +9,7 @@
 // then tile-wise forward / backward substitution.  MFMA operand layout (guide, "f64 MFMA does NOT use these maps"):
 // A: lane l holds A[l & 15][l >> 4], B: lane l holds B[l >> 4][l & 15], D: reg r of lane l is D[(l >> 4) + 4 r][l & 15].
 #include "common.h"
+#include "test_internal.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -151,10 +152,16 @@ __device__ __forceinline__ void chol_diag_body_blk(double* Ajj, size_t N, int j,
   __syncthreads();
   // The two waves run DIFFERENT loops with the same number of block barriers (wave 0 arrives at barrier b after block b is in LDS, wave 1 before it reads
   // it): in one shared loop the register allocator keeps wave 1's 64 values of x alive through wave 0's code as well, and both spill.
+  // INVARIANT: each branch executes EXACTLY kBlocks barriers, one per trip of its `b` loop and none elsewhere (s_barrier counts arrivals per wave, not
+  // call sites; the HIP model does not promise that, so this relies on the gfx950 barrier and on both trip counts being the one constant below).
+  // The column-by-column form chol_diag_body (one shared barrier site per column) stays in the build behind CCM_CHOL_DIAG=columns and is compared with
+  // this one by tests/test_ba_gpu.py::test_formulations_of_the_large_map_path_agree.
+  constexpr int kBlocks = NB / KB;
+  static_assert(NB % KB == 0 && kBlocks >= 1, "both waves must run the same whole number of 16-column blocks");
   if (wv == 0) {
     int bad_col = 0;
 #pragma unroll
-    for (int b = 0; b < NB / KB; b++) {
+    for (int b = 0; b < kBlocks; b++) {
       const int c0 = KB * b;
       double row[KB];   // lane i's entries of the block's 16 columns (its earlier columns stay in LDS)
 #pragma unroll
@@ -196,7 +203,7 @@ __device__ __forceinline__ void chol_diag_body_blk(double* Ajj, size_t N, int j,
   } else {
     double x[NB];     // lane t's column of L^-1
 #pragma unroll
-    for (int b = 0; b < NB / KB; b++) {
+    for (int b = 0; b < kBlocks; b++) {   // (kBlocks barriers, see the invariant above)
       __syncthreads();
       // X = L^-1, lane = column t, rows of block b: x_r = (delta_rt - sum_{k<r} L_rk x_k) / L_rr  (x_k = 0 for k < t, so the bounds are uniform)
 #pragma unroll
@@ -648,7 +655,7 @@ int ccm_tsc_solve(ccm_ctx* ctx, ccm_tsc* p, double* d_b) {
 }
 
 // Test hook: host matrix (n x n row-major, symmetric positive definite) and rhs in, solution out.
-extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info) {
+int ccm_internal::debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info) {
   if (!ctx || !A || !b || !x || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_dense_solve: bad args");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int N = ((n + NB - 1) / NB) * NB;
@@ -677,7 +684,7 @@ extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double
 
 // Test hook for the tile-sparse, level-scheduled form: the tile pattern is taken from the non-zeros of the host matrix (its fill is added
 // symbolically), the matrix is scattered into the compact tile storage, factored and solved.  *levels / *tiles report the plan.
-extern "C" int ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles) {
+int ccm_internal::debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles) {
   if (!ctx || !A || !b || !x || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_tile_solve: bad args");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int N = ((n + NB - 1) / NB) * NB, T = N / NB;
@@ -735,7 +742,7 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
 }
 
 // Test hook: inverse of a host SPD matrix (n x n row-major) through the tile kernels above.
-extern "C" int ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info) {
+int ccm_internal::debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info) {
   if (!ctx || !A || !Ainv || !info || n <= 0) return ccm_set_error(ctx, CCM_E_ARG, "ccm_debug_dense_inverse: bad args");
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int N = ((n + NB - 1) / NB) * NB;

@@ -21,6 +21,7 @@
 // count down.  The batch entry point pipelines frames over several streams so the host octree of frame
 // i overlaps the device phases of frame i+1.
 #include "common.h"
+#include "test_internal.h"
 #include "orb_math.h"
 #include "orb_pattern.h"
 #include <algorithm>
@@ -39,8 +40,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxLevels = 16;
 constexpr int kEdge = 19, kHalfPatch = 15, kPatch = 31;
-constexpr int kCellMax = 50;       // largest cell edge supported by the LDS tile
-constexpr int kCellCap = 640;      // >= ceil(50/2)^2: strict 3x3 NMS keeps no two adjacent pixels
+constexpr int kCellMax = 60;       // largest cell edge supported by the LDS tile: a level with ONE column of cells has cells of up to 59 px (:949-955)
+constexpr int kCellCap = 900;      // >= ceil(60/2)^2: strict 3x3 NMS keeps no two adjacent pixels
 constexpr int kCandFirstCopy = 16384;
 
 struct LevelInfo {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   __syncthreads();
   const int W = (Lv.w - kEdge + 3) - (kEdge - 3), H = (Lv.h - kEdge + 3) - (kEdge - 3);
   const int nIni = (int)roundf(static_cast<float>(W) / static_cast<float>(H));
-  bool overflow = n > a.kcap || nIni > 15 || nIni < 1;
+  bool overflow = n > 0 && (n > a.kcap || nIni > 15 || nIni < 1);   // (a level without cells has n = 0 and a meaningless box)
   if (!overflow && n > 0) {
     const float hX = static_cast<float>(W) / nIni;
     // roots: bin the candidates (order inside a node never matters, see above)
@@ -924,7 +925,10 @@ extern "C" int ccm_orb_level_size(const ccm_orb* o, int w, int h, int level, int
   *lh = (int)lrintf((float)h * o->isf[level]);
   return CCM_OK;
 }
-extern "C" int ccm_orb_max_keypoints(const ccm_orb* o) { return o ? o->nfeatures + 3 * o->nlevels + 8 : 0; }
+// Upper bound of a frame's keypoint count.  Per level DistributeOctTree returns at most max(N_l + 3, 4 nIni) nodes: the first pass splits every root
+// (nIni = round(W / H) of them) before any count is checked (:759-843), later passes stop within 3 of N_l (:901-905).  nIni <= 16 is assumed here
+// (levels up to 16.5 times as wide as high); wider levels are truncated at this capacity.
+extern "C" int ccm_orb_max_keypoints(const ccm_orb* o) { return o ? o->nfeatures + 67 * o->nlevels : 0; }
 
 // the buffers one frame in flight owns (set k); geometry (pyr_bytes, cand_cap, kp_cap, ncells) must be known
 static int orb_alloc_bufs(ccm_orb* o, int k) {
@@ -938,8 +942,8 @@ static int orb_alloc_bufs(ccm_orb* o, int k) {
   CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_pyr, 0, o->pyr_bytes, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_score, 0, o->pyr_bytes, ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_blur, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_slots, (size_t)o->cand_cap * sizeof(uint32_t)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_counts, (size_t)d.ncells * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_slots, std::max<size_t>(o->cand_cap, 1) * sizeof(uint32_t)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_counts, std::max<size_t>(d.ncells, 1) * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
   if (o->oct_ok) {
@@ -978,7 +982,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   for (int l = 0; l < o->nlevels; l++) {
     LevelInfo& L = d.lv[l];
     ccm_orb_level_size(o, w, h, l, &L.w, &L.h);
-    if (L.w < 2 * kEdge + 8 || L.h < 2 * kEdge + 8) return ccm_set_error(ctx, CCM_E_ARG, "orb: image too small for the requested pyramid");
+    if (L.w < 1 || L.h < 1) return ccm_set_error(ctx, CCM_E_ARG, "orb: a pyramid level is empty (cv::resize rejects an empty size, ORBextractor.cpp:1293)");
     if (L.w > 4000 || L.h > 4000) return ccm_set_error(ctx, CCM_E_ARG, "orb: image too large (packed candidate coordinates are 12 bit)");
     L.stride = (L.w + 63) & ~63;
     L.off = off; off += L.stride * L.h;
@@ -988,9 +992,16 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     // cell grid (:949-955), f32 arithmetic as in the reference
     const float width = (float)((L.w - kEdge + 3) - (kEdge - 3)), height = (float)((L.h - kEdge + 3) - (kEdge - 3));
     L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);
-    if (L.nCols <= 0 || L.nRows <= 0) return ccm_set_error(ctx, CCM_E_ARG, "orb: pyramid level smaller than one cell");
-    L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
-    if (L.wCell > kCellMax || L.hCell > kCellMax) return ccm_set_error(ctx, CCM_E_STATE, "orb: cell larger than the LDS tile");
+    // A level smaller than one cell: the reference's cell loops (`for i < nRows`, `for j < nCols`, :957-998) do not run, so the level contributes no
+    // keypoint; its image is still part of mvImagePyramid.  Level sizes only shrink, so such levels are a suffix of the pyramid.
+    const bool live = L.nCols > 0 && L.nRows > 0;
+    if (!live) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 0; }
+    else {
+      L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+      if (L.wCell > kCellMax || L.hCell > kCellMax) return ccm_set_error(ctx, CCM_E_STATE, "orb: cell larger than the LDS tile");
+      // DistributeOctTree (:711-716): nIni = round(W / H) roots; 0 roots (H > 2 W) is a division by zero in the reference
+      if ((int)std::round(width / height) < 1) return ccm_set_error(ctx, CCM_E_ARG, "orb: a level is more than twice as high as wide (the reference's DistributeOctTree divides by nIni = 0)");
+    }
     L.cellBase = cellBase; cellBase += L.nCols * L.nRows;
     // resize tables for level l (from level l-1)
     if (l > 0) {
@@ -1016,8 +1027,9 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
       }
       if (tabs.size() & 1) tabs.push_back(0);
     }
-    for (int by = 0; by < L.h; by += kBlurTH)
-      for (int bx = 0; bx < L.w; bx += kBlurTW) { tile_level.push_back(l); tile_xy.push_back(bx); tile_xy.push_back(by); }
+    if (live)   // the blurred level is only read around keypoints
+      for (int by = 0; by < L.h; by += kBlurTH)
+        for (int bx = 0; bx < L.w; bx += kBlurTW) { tile_level.push_back(l); tile_xy.push_back(bx); tile_xy.push_back(by); }
   }
   d.ncells = cellBase; d.totalRows = rowBase; d.maxW = maxW;
   o->pyr_bytes = (size_t)off + 4096;
@@ -1028,10 +1040,10 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   {   // LDS plan of the device octree: 52 B per list slot (4 N + 16 slots of the level with most features), the rest for candidates at 7 B each
     static const bool host_oct = getenv("CCM_ORB_HOST_OCTREE") && atoi(getenv("CCM_ORB_HOST_OCTREE")) != 0;
     int nmax = 0;
-    for (int l = 0; l < o->nlevels; l++) { o->oct_lcap[l] = 4 * o->nfeat[l] + 16; nmax = std::max(nmax, o->nfeat[l]); }
-    const size_t slots = (size_t)(4 * nmax + 16) * (2 * sizeof(OctNode) + 16 + 5 * 2 + 1) + 64;
+    for (int l = 0; l < o->nlevels; l++) { o->oct_lcap[l] = std::max(4 * o->nfeat[l] + 16, 64); nmax = std::max(nmax, o->nfeat[l]); }   // 64: the first pass turns up to 15 roots into 60 nodes whatever N is
+    const size_t slots = (size_t)std::max(4 * nmax + 16, 64) * (2 * sizeof(OctNode) + 16 + 5 * 2 + 1) + 64;
     const size_t budget = 150 * 1024;
-    o->oct_stride = nmax + 8;
+    o->oct_stride = nmax + 64;
     o->oct_kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
     o->oct_ok = !host_oct && o->oct_kcap >= 2048 && 4 * nmax + 16 <= 2 * kOctTPB;
     o->oct_tpb = (4 * nmax + 16 <= 1024 && !getenv("CCM_ORB_OCT_1024")) ? 512 : 1024;
@@ -1042,10 +1054,12 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_level, tile_level.size() * sizeof(int)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_xy, tile_xy.size() * sizeof(int)));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_level, tile_level.data(), tile_level.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_xy, tile_xy.data(), tile_xy.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_level, std::max<size_t>(tile_level.size(), 1) * sizeof(int)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tile_xy, std::max<size_t>(tile_xy.size(), 2) * sizeof(int)));
+  if (!tile_level.empty()) {
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_level, tile_level.data(), tile_level.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tile_xy, tile_xy.data(), tile_xy.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  }
   {
     const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
     o->h_io_bytes = std::max((size_t)w * h, o_d + (size_t)o->kp_cap * 32) + 256;
@@ -1071,7 +1085,9 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
     ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE, o->st);
     hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
   }
-  {
+  if (d.ncells == 0) {   // no level holds a cell (image below 62 px): the candidate list is empty, the pyramid above is the whole result
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[o->cur].d_cand, 0, sizeof(int), o->st));
+  } else {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
     hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
     hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
@@ -1082,7 +1098,7 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand, o->B[o->cur].d_cand, first, hipMemcpyDeviceToHost, o->st));
     CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, o->st));
   }
-  {
+  if (o->n_blur_tiles > 0) {
     ccm_prof_scope ps(ctx, CCM_K_BLUR, o->st);
     hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
   }
@@ -1290,7 +1306,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   return CCM_OK;
 }
 
-extern "C" int ccm_orb_debug_timing(const ccm_orb* o, double out_ms[6]) {
+int ccm_internal::orb_debug_timing(const ccm_orb* o, double out_ms[6]) {
   if (!o || !out_ms) return CCM_E_ARG;
   for (int i = 0; i < 6; i++) out_ms[i] = o->t_phase[i];
   return CCM_OK;
@@ -1382,7 +1398,7 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   return CCM_OK;
 }
 
-extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uint8_t* blur_out) {
+int ccm_internal::orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uint8_t* blur_out) {
   if (!o || !o->B[o->cur].d_pyr || level < 0 || level >= o->nlevels) return CCM_E_ARG;
   ccm_ctx* ctx = o->ctx;
   const LevelInfo& L = o->dev.lv[level];
@@ -1392,7 +1408,7 @@ extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, ui
   return CCM_OK;
 }
 
-extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) {
+int ccm_internal::orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) {
   if (!o || level < 0 || level >= o->nlevels || !n_out) return CCM_E_ARG;
   if (!o->last_cand_valid) {   // the device octree never brings the candidates to the host: fetch them for this call
     ccm_ctx* ctx = o->ctx;
@@ -1421,7 +1437,7 @@ extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out
 // Test hook: the device octree kernel alone on a caller-supplied candidate set of ONE level (integer positions relative to the level's border
 // box of W x H, responses 1..255); sel_out receives the indices of the kept candidates in output order.  *overflow = 1 when the set does not
 // fit the kernel's LDS plan for N features.
-extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N,
+int ccm_internal::orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N,
                                         int32_t* sel_out, int cap, int* n_out, int* overflow) {
   if (!ctx || n < 0 || !n_out || !overflow || (n && (!x || !y || !response)) || W <= 0 || H <= 0 || N <= 0 || W > 4000 || H > 4000)
     return ccm_set_error(ctx, CCM_E_ARG, "ccm_orb_debug_octree_dev: bad args");
@@ -1435,7 +1451,7 @@ extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const in
     if (x[k] < 0 || x[k] > 0xFFF || y[k] < 0 || y[k] > 0xFFF || response[k] < 1 || response[k] > 255) return ccm_set_error(ctx, CCM_E_ARG, "ccm_orb_debug_octree_dev: candidate out of range");
     cand[2 + k] = (int)((uint32_t)x[k] | ((uint32_t)y[k] << 12) | ((uint32_t)response[k] << 24));
   }
-  const int lcap = 4 * N + 16, stride = 4 * N + 16;
+  const int lcap = std::max(4 * N + 16, 64), stride = lcap;
   const size_t slots = (size_t)lcap * (2 * sizeof(OctNode) + 16 + 5 * 2 + 1) + 64;
   const size_t budget = 150 * 1024;
   const int kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;

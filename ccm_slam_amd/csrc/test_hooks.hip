@@ -2,6 +2,8 @@
 // They reach into handles through the internal headers; nothing in the product's timed paths knows about them.
 #include "common.h"
 #include "ba_types.h"
+#include "test_internal.h"
+#include "../../include/ccm_testhooks.h"
 #include <cstring>
 #include <string>
 
@@ -68,4 +70,20 @@ extern "C" int ccm_ba_debug_array(ccm_ba* ba, const char* name, void* out, size_
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemcpy(out, src, sz, hipMemcpyDeviceToHost));
   return CCM_OK;
+}
+
+// ---- C wrappers of the C++-linkage test entry points that live next to the file-local kernels they exercise (test_internal.h) ----
+extern "C" int ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count) { return ccm_internal::ba_debug_partial_reduced(ba, lambda, out, cap, count); }
+extern "C" int ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap) { return ccm_internal::ba_debug_coarse(ba, lambda, na, Ac, Ainv, Pm, cap); }
+extern "C" int ccm_comm_loopback_create(int nranks, void** group) { return ccm_internal::comm_loopback_create(nranks, group); }
+extern "C" void ccm_comm_loopback_destroy(void* group) { ccm_internal::comm_loopback_destroy(group); }
+extern "C" int ccm_comm_init_loopback(ccm_ctx* ctx, void* group, int rank) { return ccm_internal::comm_init_loopback(ctx, group, rank); }
+extern "C" int ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info) { return ccm_internal::debug_dense_solve(ctx, A, b, n, x, info); }
+extern "C" int ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles) { return ccm_internal::debug_tile_solve(ctx, A, b, n, x, info, levels, tiles); }
+extern "C" int ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info) { return ccm_internal::debug_dense_inverse(ctx, A, n, Ainv, info); }
+extern "C" int ccm_orb_debug_timing(const ccm_orb* o, double out_ms[6]) { return ccm_internal::orb_debug_timing(o, out_ms); }
+extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uint8_t* blur_out) { return ccm_internal::orb_debug_level(o, level, score_out, blur_out); }
+extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) { return ccm_internal::orb_debug_candidates(o, level, out, cap, n_out); }
+extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N, int32_t* sel_out, int cap, int* n_out, int* overflow) {
+  return ccm_internal::orb_debug_octree_dev(ctx, x, y, response, n, W, H, N, sel_out, cap, n_out, overflow);
 }

@@ -12,7 +12,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import BAOptions, BAProblem, BAStats, Context, check, lib
+from ._lib import BAOptions, BAProblem, BAStats, Context, check, hooks, lib
 
 
 TRIAL_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int)
@@ -119,21 +119,21 @@ class BAHandle:
     def partial_reduced(self, lam: float) -> np.ndarray:
         """Test hook: this rank's partial [S | b_schur] at the current state (ccm_ba_debug_partial_reduced)."""
         n = C.c_size_t()
-        check(lib().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), None, C.c_size_t(0), C.byref(n)), self.ctx.handle)
+        check(hooks().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), None, C.c_size_t(0), C.byref(n)), self.ctx.handle)
         out = np.zeros(n.value, np.float64)
-        check(lib().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), C.c_void_p(_vp(out)), C.c_size_t(out.size), C.byref(n)),
+        check(hooks().ccm_ba_debug_partial_reduced(self._h, C.c_double(lam), C.c_void_p(_vp(out)), C.c_size_t(out.size), C.byref(n)),
               self.ctx.handle)
         return out
 
     def coarse_level(self, lam: float):
         """Test hook (ccm_ba_debug_coarse): (na camera intervals, Ac, Ainv over the na + 1 coarse nodes, P) of the two-level preconditioner, or (0, None, None, None)."""
         na = C.c_int(0)
-        check(lib().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), None, None, None, C.c_size_t(0)), self.ctx.handle)
+        check(hooks().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), None, None, None, C.c_size_t(0)), self.ctx.handle)
         if na.value == 0:
             return 0, None, None, None
         nc = 6 * (na.value + 1)
         Ac = np.zeros((nc, nc)); Ai = np.zeros((nc, nc)); P = np.zeros((self.counts()["free_cams"], 6, 6))
-        check(lib().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), C.c_void_p(_vp(Ac)), C.c_void_p(_vp(Ai)), C.c_void_p(_vp(P)),
+        check(hooks().ccm_ba_debug_coarse(self._h, C.c_double(lam), C.byref(na), C.c_void_p(_vp(Ac)), C.c_void_p(_vp(Ai)), C.c_void_p(_vp(P)),
                                         C.c_size_t(Ac.size)), self.ctx.handle)
         return na.value, Ac, Ai, P
 
@@ -279,7 +279,7 @@ def debug_dense_solve(ctx: Context, A, b):
     """Test hook: SPD solve through the device's blocked MFMA-f64 Cholesky (ccm_debug_dense_solve)."""
     A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64)
     x = np.zeros_like(b); info = C.c_int(0)
-    check(lib().ccm_debug_dense_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info)), ctx.handle)
+    check(hooks().ccm_debug_dense_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info)), ctx.handle)
     return x, info.value
 
 
@@ -287,7 +287,7 @@ def debug_tile_solve(ctx: Context, A, b):
     """Test hook: SPD solve through the tile-sparse, level-scheduled Cholesky (ccm_debug_tile_solve); returns (x, info, levels, tiles)."""
     A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64)
     x = np.zeros_like(b); info = C.c_int(0); levels = C.c_int(0); tiles = C.c_int(0)
-    check(lib().ccm_debug_tile_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info),
+    check(hooks().ccm_debug_tile_solve(ctx.handle, C.c_void_p(_vp(A)), C.c_void_p(_vp(b)), int(b.size), C.c_void_p(_vp(x)), C.byref(info),
                                      C.byref(levels), C.byref(tiles)), ctx.handle)
     return x, info.value, levels.value, tiles.value
 
@@ -296,5 +296,5 @@ def debug_dense_inverse(ctx: Context, A):
     """Test hook: explicit SPD inverse through the tile kernels of dense_chol.hip (ccm_debug_dense_inverse)."""
     A = np.ascontiguousarray(A, np.float64)
     out = np.zeros_like(A); info = C.c_int(0)
-    check(lib().ccm_debug_dense_inverse(ctx.handle, C.c_void_p(_vp(A)), int(A.shape[0]), C.c_void_p(_vp(out)), C.byref(info)), ctx.handle)
+    check(hooks().ccm_debug_dense_inverse(ctx.handle, C.c_void_p(_vp(A)), int(A.shape[0]), C.c_void_p(_vp(out)), C.byref(info)), ctx.handle)
     return out, info.value

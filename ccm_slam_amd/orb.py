@@ -6,7 +6,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import Context, Keypoint, check, lib
+from ._lib import Context, Keypoint, check, hooks, lib
 
 KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
                      ("response", np.float32), ("octave", np.int32)])
@@ -87,14 +87,14 @@ class ORBextractor:
         lw, lh = self.level_size(*self._wh, level)
         score = np.zeros((lh, lw), np.uint8)
         blur = np.zeros((lh, lw), np.uint8)
-        check(lib().ccm_orb_debug_level(self._h, level, score.ctypes.data_as(C.c_void_p), blur.ctypes.data_as(C.c_void_p)), self.ctx.handle)
+        check(hooks().ccm_orb_debug_level(self._h, level, score.ctypes.data_as(C.c_void_p), blur.ctypes.data_as(C.c_void_p)), self.ctx.handle)
         return score, blur
 
     def debug_candidates(self, level):
         n = C.c_int(0)
-        check(lib().ccm_orb_debug_candidates(self._h, level, None, 0, C.byref(n)), self.ctx.handle)
+        check(hooks().ccm_orb_debug_candidates(self._h, level, None, 0, C.byref(n)), self.ctx.handle)
         out = np.zeros(max(n.value, 1), KP_DTYPE)
-        check(lib().ccm_orb_debug_candidates(self._h, level, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), self.ctx.handle)
+        check(hooks().ccm_orb_debug_candidates(self._h, level, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), self.ctx.handle)
         return out[:n.value]
 
 
@@ -148,7 +148,7 @@ def debug_octree_dev(ctx: Context, x, y, response, W, H, N):
     x, y, r = (np.ascontiguousarray(a, np.int32) for a in (x, y, response))
     sel = np.zeros(4 * N + 16, np.int32)
     n = C.c_int(0); over = C.c_int(0)
-    check(lib().ccm_orb_debug_octree_dev(ctx.handle, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+    check(hooks().ccm_orb_debug_octree_dev(ctx.handle, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
                                          int(x.size), int(W), int(H), int(N), sel.ctypes.data_as(C.c_void_p), int(sel.size), C.byref(n), C.byref(over)), ctx.handle)
     return sel[:n.value], over.value
 

@@ -342,6 +342,68 @@ def gen_image(seed: int, t: int = 0, w: int = IMG_W, h: int = IMG_H) -> np.ndarr
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+# Sweep cases on which the REFERENCE ITSELF throws: a level whose border box has W > 0 and H <= 0 (or the reverse) makes DistributeOctTree compute
+# nIni = round(W / H) <= 0 and `vpIniNodes.resize(nIni)` raises std::length_error (ORBextractor.cpp:711-716; observed on oracle/_ref/orb_ref_cli).  The
+# oracle and the product define the natural continuation — such a level holds no cell, hence no keypoint — and are compared with each other there.
+ORB_SWEEP_REFERENCE_THROWS = {"small_64x48", "small_100x70", "small_96x96", "small_91x62", "small_62x91", "small_123x77", "small_200x63", "small_80x80"}
+
+
+def orb_sweep_cases():
+    """(name, image, nfeatures, kwargs) for the wide ORB parity sweep (tests/test_orb_gpu.py: HIP vs oracle; tests/test_ref_orb.py: oracle vs the
+    reference's own ORBextractor.cpp).  Everything ORBextractor.cpp:933-998 / :1280-1304 branches on: widths and heights of every residue mod 4 (row
+    strides, resize tables), levels smaller than one 30-px cell (they contribute no keypoints: `nCols` or `nRows` is 0 and the cell loops do not
+    run), images where EVERY level is, single-cell levels whose cell is up to 59 px wide, dense checkerboards (the most NMS survivors a cell can
+    hold, tens of thousands of octree candidates per level), saturated / noise / step images, nlevels 1 and 12, other scale factors, tiny and huge
+    feature budgets, iniThFAST == minThFAST.  kwargs use the oracle's names (scale, nlevels, ini_th, min_th)."""
+    cases = []
+    # 1. sizes around the EuRoC frame with every residue of width and height mod 4 (28 images)
+    k = 0
+    for dw in range(-3, 4):
+        for dh in (-2, -1, 1, 3):
+            cases.append((f"size_{IMG_W + dw}x{IMG_H + dh}", gen_image(2000 + k, k, IMG_W + dw, IMG_H + dh), 1000, {}))
+            k += 1
+    # 2. small images: vanishing levels (64x48: no level holds a cell; 40x40: none either and levels shrink to 11 px; 100x70 / 96x96: some do)
+    for w, h, s in ((64, 48, 1), (40, 40, 2), (100, 70, 3), (96, 96, 4), (91, 62, 5), (62, 91, 6), (123, 77, 7), (160, 120, 8), (200, 63, 9), (64, 64, 10),
+                    (80, 80, 11), (75, 75, 12)):
+        cases.append((f"small_{w}x{h}", gen_image(3000 + s, s, w, h), 300, {}))
+    rng = np.random.default_rng(77)
+    cases.append(("small_noise_91x91", rng.integers(0, 256, (91, 91), dtype=np.uint8), 200, {}))
+    # 3. checkerboards: squares of 2 / 3 / 5 px, a corner at every crossing
+    yy, xx = np.mgrid[0:IMG_H, 0:IMG_W]
+    for sq in (2, 3, 5):
+        cases.append((f"checker_{sq}px", (((xx // sq + yy // sq) & 1) * 215 + 20).astype(np.uint8), 1000, {}))
+    cases.append(("checker_3px_2000", (((xx // 3 + yy // 3) & 1) * 255).astype(np.uint8), 2000, {}))
+    # 4. pixel statistics
+    cases.append(("noise_u8", rng.integers(0, 256, (IMG_H, IMG_W), dtype=np.uint8), 1000, {}))
+    cases.append(("noise_binary", (rng.integers(0, 2, (IMG_H, IMG_W)) * 255).astype(np.uint8), 1000, {}))
+    cases.append(("all_zero", np.zeros((IMG_H, IMG_W), np.uint8), 1000, {}))
+    cases.append(("all_255", np.full((IMG_H, IMG_W), 255, np.uint8), 1000, {}))
+    cases.append(("vertical_step", np.where(xx < IMG_W // 2, 40, 200).astype(np.uint8), 1000, {}))
+    sparse = np.full((IMG_H, IMG_W), 128, np.uint8)
+    for _ in range(40):
+        x, y = int(rng.integers(25, IMG_W - 25)), int(rng.integers(25, IMG_H - 25))
+        sparse[y - 1:y + 2, x - 1:x + 2] = int(rng.integers(0, 2)) * 255
+    cases.append(("forty_blobs", sparse, 1000, {}))
+    # 5. extractor parameters
+    base = gen_image(4000, 3)
+    cases.append(("nlevels_1", base, 1000, {"nlevels": 1}))
+    cases.append(("nlevels_12", base, 1000, {"nlevels": 12}))
+    cases.append(("nlevels_12_2000", gen_image(4001, 5), 2000, {"nlevels": 12}))
+    cases.append(("scale_1.1", base, 1000, {"scale": 1.1}))
+    cases.append(("scale_1.5_6", base, 800, {"scale": 1.5, "nlevels": 6}))
+    cases.append(("scale_2.0_4", base, 500, {"scale": 2.0, "nlevels": 4}))
+    cases.append(("nfeatures_7", base, 7, {}))
+    cases.append(("nfeatures_50", base, 50, {}))
+    cases.append(("nfeatures_5000", gen_image(4002, 9), 5000, {}))
+    cases.append(("th_40_20", base, 1000, {"ini_th": 40, "min_th": 20}))
+    cases.append(("th_equal_12", base, 1000, {"ini_th": 12, "min_th": 12}))
+    cases.append(("th_1_1", gen_image(4003, 1, 320, 240), 600, {"ini_th": 1, "min_th": 1}))
+    cases.append(("vga", gen_image(4004, 2, 640, 480), 1200, {}))
+    cases.append(("hd_1280x720", gen_image(4005, 4, 1280, 720), 1500, {}))
+    cases.append(("wide_1000x130", gen_image(4006, 6, 1000, 130), 500, {"nlevels": 4}))
+    return cases
+
+
 def make_pose_problem(n: int = 300, seed: int = 0, outlier_frac: float = 0.1, pose_sigma_t: float = 0.05,
                       pose_sigma_r_deg: float = 1.0):
     """One tracked frame for Optimizer::PoseOptimizationClient (Optimizer.cpp:215-347): n map points seen by

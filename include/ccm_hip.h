@@ -142,25 +142,12 @@ int  ccm_orb_max_keypoints(const ccm_orb* orb);
  * (minX,minY); sel_out receives the indices of the kept candidates in the reference's output order. */
 int  ccm_orb_distribute_octree(const float* x, const float* y, const float* response, int n, int minX, int maxX,
                                int minY, int maxY, int N, int32_t* sel_out, int cap, int* n_out);
-/* test hook: DistributeOctTree as the DEVICE runs it (orb_octree_kernel, one workgroup) on one level's candidates: integer positions inside the
- * level's W x H border box, responses 1..255, positions unique; sel_out: indices of the kept candidates in output order.  *overflow = 1 when
- * the set does not fit the kernel's LDS plan (the extractor then selects on the host). */
-int  ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N,
-                              int32_t* sel_out, int cap, int* n_out, int* overflow);
 /* batch of frames already resident in HBM (d_imgs: n_frames images, tightly packed w*h each);
  * outputs stay on the device: d_kps [n_frames][cap], d_desc [n_frames][cap][32],
  * d_counts [n_frames].  Host octree selection (DistributeOctTree) runs between the two device
  * phases exactly as in ccm_orb_extract.                                                   */
 int  ccm_orb_extract_batch_dev(ccm_orb* orb, const uint8_t* d_imgs, int n_frames, int w, int h,
                                ccm_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
-/* intermediate products for parity tests (host copies; any pointer may be NULL):
- * FAST score map and blurred image of one level of the LAST extracted frame.              */
-int  ccm_orb_debug_level(ccm_orb* orb, int level, uint8_t* score_out, uint8_t* blur_out);
-/* host wall-clock phases of the last ccm_orb_extract call, ms: [queue phase 1, wait for candidates, octree, queue phase 2,
- * wait + D2H, total] */
-int  ccm_orb_debug_timing(const ccm_orb* orb, double out_ms[6]);
-/* pre-octree FAST candidates of the last frame: returns count for the level, fills up to cap */
-int  ccm_orb_debug_candidates(ccm_orb* orb, int level, ccm_keypoint* out, int cap, int* n_out);
 
 /* Per-frame glue between extraction and matching.  A ccm_frame holds, on the device, what the
  * window searches read from a Frame / KeyFrame: undistorted keypoints (Frame::UndistortKeyPoints, Frame.cpp:284-312 —
@@ -304,25 +291,12 @@ int  ccm_ba_partition(const int64_t* weight, int n, int nranks, int32_t* begin_o
 int  ccm_ba_counts(const ccm_ba* ba, int64_t* n_active_edges, int64_t* n_active_pts,
                    int64_t* n_free_cams, int64_t* n_blocks, int64_t* n_pairs);
 
-/* test hook: this rank's partial reduced camera system [36*(n_free_cams+n_blocks) S | 6*n_free_cams b]
- * at the current state, i.e. the buffer the per-trial RCCL all-reduce sums; out == NULL only queries *count. */
-int  ccm_ba_debug_partial_reduced(ccm_ba* ba, double lambda, double* out, size_t cap, size_t* count);
-
-/* test hook: coarse level of the two-level PCG preconditioner at the current state: *na aggregates (0 = not in use), Ac and
- * its inverse [6 na x 6 na], prolongation blocks P_k = Ad(T_cw,k) [n_free_cams x 36]; cap = doubles available in Ac / Ainv. */
-int  ccm_ba_debug_coarse(ccm_ba* ba, double lambda, int* na, double* Ac, double* Ainv, double* Pm, size_t cap);
 
 /* RCCL communicator for the sharded GBA.  id_bytes is an ncclUniqueId (128 bytes) produced by
  * ccm_comm_unique_id on rank 0 and broadcast by the launcher (bench.py uses torch.distributed). */
 int ccm_comm_unique_id(uint8_t id_bytes[128]);
 int ccm_comm_init(ccm_ctx* ctx, int nranks, int rank, const uint8_t id_bytes[128]);
 int ccm_comm_destroy(ccm_ctx* ctx);
-/* TEST-ONLY in-process communicator: the ranks are threads of one process sharing one GPU, each with its own ccm_ctx; an all-reduce is
- * a rendezvous plus one reduction kernel that leaves the same bits in every rank's buffer (RCCL's contract).  Lets a single-GPU box
- * execute the complete multi-rank control flow of the sharded global BA (tests/test_sharded_loopback_gpu.py). */
-int  ccm_comm_loopback_create(int nranks, void** group);
-void ccm_comm_loopback_destroy(void* group);
-int  ccm_comm_init_loopback(ccm_ctx* ctx, void* group, int rank);
 
 /* motion-only pose optimisation: Optimizer::PoseOptimizationClient (Optimizer.cpp:215-347):
  * 4 rounds x 10 LM iterations on one SE3 vertex with unary EdgeSE3ProjectXYZOnlyPose edges,
@@ -363,15 +337,6 @@ int  ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3 /* n_vert x 
                              int fix_scale, int n_edge, const int32_t* e_i, const int32_t* e_j,
                              const double* meas /* n_edge x 8 */, int max_iters, double lambda_init,
                              const volatile unsigned char* stop_flag /* nullable */, ccm_pg_stats* stats /* nullable */);
-/* test hook for the dense f64 Cholesky (MFMA tiles) behind ccm_pose_graph_optimize: solves A x = b for a host matrix
- * (n x n row-major, symmetric positive definite); *info = 0 or (first non-positive pivot + 1). */
-int  ccm_debug_dense_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info);
-/* test hook for the tile-sparse, level-scheduled form of the same factorisation (what ccm_pose_graph_optimize uses by default): only the
- * non-zero 64 x 64 tiles of the factor are stored, tile columns of one elimination level run in one launch; the tile pattern is taken from
- * the non-zeros of A.  levels / tiles (nullable) receive the plan's level and tile counts. */
-int  ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n, double* x, int* info, int* levels, int* tiles);
-/* same machinery, explicit inverse (used for the coarse level of the BA preconditioner) */
-int  ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info);
 
 #ifdef __cplusplus
 }

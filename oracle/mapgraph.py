@@ -72,6 +72,12 @@ class MapGraph:
             self.lib.mapg_destroy(self.h)
             self.h = None
 
+    def lock_points(self, locked, server: bool = False):
+        """MapPoint::mbPoseLock of every point (set by the server's corrections in the real system) and the system state the points live in"""
+        locked = np.ascontiguousarray(locked, np.uint8)
+        self.lib.mapg_lock_points.restype = None
+        self.lib.mapg_lock_points(self.h, _p(locked), int(bool(server)))
+
     def local_ba(self, kf_index: int, client_id: int = 0, server: bool = False, stop_flag=None) -> int:
         fn = self.lib.mapg_local_ba
         fn.restype = C.c_int

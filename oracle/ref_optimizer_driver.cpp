@@ -109,6 +109,12 @@ void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, cons
   return g;
 }
 void mapg_destroy(void* h) { delete (MapG*)h; }
+// MapPoint::mbPoseLock / mSysState of every point (MapPoint.h:277): locked[p] != 0 marks a position the server has fixed; on a CLIENT (server_state == 0)
+// SetWorldPos then returns without writing (MapPoint.cpp:340-341)
+void mapg_lock_points(void* h, const uint8_t* locked, int server_state) {
+  MapG* g = (MapG*)h;
+  for (size_t p = 0; p < g->mps.size(); p++) { g->mp_store[p].mbPoseLock = locked[p] != 0; g->mp_store[p].mSysState = server_state ? cslam::eSystemState::SERVER : cslam::eSystemState::CLIENT; }
+}
 
 // cslam::Optimizer::LocalBundleAdjustmentClient(pKF, pbStopFlag, pMap, ClientId, SysState)   (Optimizer.h:84-86)
 int mapg_local_ba(void* h, int kf_index, int client_id, int server_state, uint8_t* stop_flag) {

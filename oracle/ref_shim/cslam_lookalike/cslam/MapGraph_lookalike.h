@@ -122,7 +122,16 @@ class MapPoint : public boost::enable_shared_from_this<MapPoint> {
   size_t mCorrectedReference_LC = 0, mCorrectedReference_MM = 0;
   cv::Mat mPosGBA;
   bool mbUpdatedByServer = false;
-  void SetWorldPos(const cv::Mat& Pos, bool bLock, bool bIgnorePosMutex = false) { (void)bLock; (void)bIgnorePosMutex; Pos.copyTo(mWorldPos); }   // MapPoint.cpp:338-363
+  // MapPoint.cpp:338-363: a point whose position was locked (by the server's corrections) ignores later writes on a CLIENT; bLock locks it
+  void SetWorldPos(const cv::Mat& Pos, bool bLock, bool bIgnorePosMutex = false) {
+    (void)bIgnorePosMutex;
+    if (mbPoseLock && mSysState == eSystemState::CLIENT) return;
+    Pos.copyTo(mWorldPos);
+    if (bLock) mbPoseLock = true;
+  }
+  bool IsPosLocked() { return mbPoseLock; }                                                                                                         // MapPoint.h:135
+  bool mbPoseLock = false;                                                                                                                          // MapPoint.h:277
+  eSystemState mSysState = eSystemState::CLIENT;
   cv::Mat GetWorldPos() { return mWorldPos.clone(); }                                                                                              // :393-397
   cv::Mat GetNormal() { return mNormalVector.clone(); }
   kfptr GetReferenceKeyFrame() { return mpRefKF; }

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
 from ccm_slam_amd import orb, synth, matcher, optimizer
-from ccm_slam_amd._lib import Context, K
+from ccm_slam_amd._lib import hooks, Context, K
 
 ctx = Context(0)
 ex = orb.ORBextractor(ctx, 1000)
@@ -16,7 +16,7 @@ dt = (time.perf_counter() - t) / 16
 print(f"host-API extract: {dt*1e3:.3f} ms/frame = {1/dt:.1f} fps, n={len(kps)}")
 import ctypes as C
 from ccm_slam_amd._lib import lib
-tm = (C.c_double * 6)(); lib().ccm_orb_debug_timing(ex._h, tm)
+tm = (C.c_double * 6)(); hooks().ccm_orb_debug_timing(ex._h, tm)
 print("  phases ms [queue1, wait cand, octree, queue2, wait+D2H, total]:", [round(x, 4) for x in tm])
 ctx.prof_enable(-1); ctx.prof_reset()
 b = orb.OrbBatchDev(ctx, ex, imgs)

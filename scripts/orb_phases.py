@@ -7,7 +7,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccm_slam_amd import orb, synth  # noqa: E402
-from ccm_slam_amd._lib import Context, lib  # noqa: E402
+from ccm_slam_amd._lib import hooks, Context, lib  # noqa: E402
 
 ctx = Context(0)
 ex = orb.ORBextractor(ctx, 1000)
@@ -16,7 +16,7 @@ acc = []
 for i in range(60):
     ex(img)
     ph = (C.c_double * 6)()
-    lib().ccm_orb_debug_timing(ex._h, ph)
+    hooks().ccm_orb_debug_timing(ex._h, ph)
     if i >= 10:
         acc.append(list(ph))
 a = np.array(acc)

@@ -316,8 +316,11 @@ void batched_point_writeback(FlatBA& f, const std::vector<char>* edge_skip, bool
       if (pMP->isBad()) continue;
       cv::Mat p(3, 1, CV_32F);
       for (int c = 0; c < 3; c++) p.at<float>(c) = pos[3 * i + c];
+      // A point whose position is locked may ignore the write (MapPoint::SetWorldPos returns early on a CLIENT, MapPoint.cpp:340-341): the batch values were
+      // computed from the NEW position, so such a point takes the reference's own per-point method, which reads whatever position the point really has.
+      const bool locked = pMP->IsPosLocked();
       pMP->SetWorldPos(p, pos_lock);
-      if (regular[i]) store_normal_depth(pMP, &normal[3 * i], dmin[i], dmax[i], has_normal_depth_setter<MapPoint>());
+      if (regular[i] && !locked) store_normal_depth(pMP, &normal[3 * i], dmin[i], dmax[i], has_normal_depth_setter<MapPoint>());
       else pMP->UpdateNormalAndDepth();
     }
   });
@@ -625,6 +628,12 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   static thread_local std::vector<FlatBA> part_keep;
   FlatBA& f = f_keep;
   f.reset();
+  // the flat arrays keep their capacity from call to call (per thread); the references into the caller's object graph do not outlive the call: a keyframe
+  // erased from the map afterwards is destroyed when the reference would destroy it
+  struct DropRefs {
+    FlatBA& a; std::vector<FlatBA>& parts;
+    ~DropRefs() { a.cam_kf.clear(); a.pt_mp.clear(); for (auto& g : parts) { g.cam_kf.clear(); g.pt_mp.clear(); } }
+  } drop_refs{f_keep, part_keep};
   size_t maxKFid = 0;
   for (size_t i = 0; i < vpKFs.size(); i++) {
     kfptr pKF = vpKFs[i];

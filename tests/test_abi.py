@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    hdr = open(os.path.join(ROOT, "include", "ccm_hip.h")).read()
+def _declared(header="ccm_hip.h"):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(ccm_[a-z0-9_]+)\s*\(", hdr)))
 
@@ -23,6 +23,21 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
+
+
+def test_test_hooks_live_in_their_own_library():
+    """include/ccm_testhooks.h <-> libccm_testhooks.so; the product library exports no test-only name and its header declares none."""
+    import subprocess
+    from ccm_slam_amd import _lib
+    hooks = _lib.hooks()
+    names = _declared("ccm_testhooks.h")
+    assert len(names) >= 13
+    assert not [n for n in names if not hasattr(hooks, n)]
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("ccm_")}
+    assert not [n for n in exported if "debug" in n or "loopback" in n], sorted(exported)
+    assert not (set(names) & set(_declared())), "a test hook is declared in the product header"
+    assert exported >= set(_declared())
 
 
 def test_version_and_error_strings():

@@ -452,6 +452,37 @@ def test_full_length_gba_follows_the_reference_g2o_fixture(ctx, name):
     assert np.abs(pts[::50] - g["pts_every_50th"]).max() <= 1e-4
 
 
+def test_device_resident_create_is_the_same_call_as_the_host_array_create(ctx):
+    """The entry bench.py times: ccm_ba_create from a flat problem ALREADY RESIDENT IN HBM (ccm_ba_problem holding device pointers,
+    optimizer.ResidentProblem) + ccm_ba_run(20) on gba_c4.  It must walk the reference's own g2o run (tests/golden/gba_c4_ref.npz:
+    sparse_optimizer.cpp:354-419, optimization_algorithm_levenberg.cpp:61-164) and leave exactly the bits the host-array handle leaves;
+    a second resident handle built from the same device arrays (bench.py re-creates one per step) repeats them."""
+    g = np.load(os.path.join(_G, "gba_c4_ref.npz"))
+    prob = synth.make_ba_config("gba_c4")
+    res = optimizer.ResidentProblem(ctx, prob)
+    out = []
+    for resident in (None, res, res):
+        h = optimizer.BAHandle(ctx, prob, resident=resident)
+        st = h.run(20)
+        chi, lam, tr = h.history()
+        cam, pts, chi2, dpos = h.download()
+        h.close()
+        out.append((st, chi, lam, tr, cam, pts, chi2, dpos))
+    res.close()
+    st, chi, lam, tr, cam, pts, _, _ = out[1]
+    assert (st.iters_done, st.lm_trials) == (int(g["iters_done"]), int(g["lm_trials"])), (st.iters_done, st.lm_trials, list(tr))
+    assert np.array_equal(tr, g["trials_hist"]), (list(tr), list(g["trials_hist"]))
+    assert np.abs(chi / g["chi2_hist"] - 1).max() <= TOL_CHI
+    assert abs(lam[-1] / float(g["lambda_final"]) - 1) <= 1e-3
+    dt, dr = synth.pose_errors(cam, g["cam"])
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts[::50] - g["pts_every_50th"]).max() <= 1e-4
+    for other in (out[0], out[2]):
+        assert (other[0].iters_done, other[0].lm_trials, other[0].pcg_iters) == (st.iters_done, st.lm_trials, st.pcg_iters)
+        for a, b in zip(other[1:], out[1][1:]):
+            assert np.array_equal(a, b)
+
+
 def _run_with_abort(run, raise_at_total_trial):
     """Drives `run(stop_flag, hook)`; a second thread raises the stop flag (the reference: Communicator.cpp:444-453 writes
     mbStopGBA from the comm thread) while the optimising thread sits in the trial callback of total trial `raise_at_total_trial`,

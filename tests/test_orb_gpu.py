@@ -138,3 +138,34 @@ def test_levels_that_do_not_fit_the_octree_kernel_fall_back_to_the_host(ctx, ora
     """CCM_ORB_OCT_KCAP shrinks the kernel's candidate capacity: level 0 overflows, the frame is redone through the host octree, same result."""
     monkeypatch.setenv("CCM_ORB_OCT_KCAP", "1024")
     _compare(ctx, oracle_lib, synth.gen_image(1000, 3), 1000)
+
+
+_SWEEP = synth.orb_sweep_cases()
+
+
+@pytest.mark.parametrize("case", range(len(_SWEEP)), ids=[c[0] for c in _SWEEP])
+def test_wide_sweep(ctx, oracle_lib, case):
+    """ORBextractor.cpp:933-998 / :1280-1304 over 70 images (synth.orb_sweep_cases): widths and heights of every residue mod 4, levels smaller than
+    one 30-px cell (64x48, 40x40: no keypoints at all, the pyramid is still produced), single-cell levels with 59-px cells, dense checkerboards and
+    noise (up to 33 000 octree candidates on a level: the device octree's LDS plan overflows and the frame is redone through the host octree),
+    saturated / step images, nlevels 1 and 12, scale factors 1.1 - 2.0, 7 - 5000 features, iniThFAST == minThFAST.  Bit-exact against the oracle, which
+    tests/test_ref_orb.py pins to the reference's own translation unit on the same images."""
+    name, img, nf, kw = _SWEEP[case]
+    kw = {{"scale": "scale_factor", "ini_th": "ini_th_fast", "min_th": "min_th_fast"}.get(k, k): v for k, v in kw.items()}
+    _compare(ctx, oracle_lib, img, nf, **kw)
+
+
+def test_sweep_images_also_agree_through_the_batch_entry(ctx, oracle_lib):
+    """ccm_orb_extract_batch_dev (four frames in flight) on 12 frames of an odd size: identical to frame-by-frame extraction."""
+    imgs = np.stack([synth.gen_image(5000 + k, k, 751, 479) for k in range(12)])
+    ex = orb.ORBextractor(ctx, 1000)
+    b = orb.OrbBatchDev(ctx, ex, imgs)
+    b.run()
+    res = b.results()
+    b.close()
+    for k in range(12):
+        kps, desc = ex(imgs[k])
+        assert len(kps) == len(res[k][0]) and np.array_equal(desc, res[k][1])
+        for f in kps.dtype.names:
+            assert np.array_equal(kps[f], res[k][0][f])
+    ex.close()

@@ -108,3 +108,25 @@ def test_reference_descriptor_distance_and_three_maxima():
         if rng.random() < 0.2:
             counts[:] = 0; counts[rng.integers(0, 30)] = 25; counts[rng.integers(0, 30)] = 2   # second below 10 %
         assert ref.three_maxima(counts) == oracle.three_maxima(counts), counts
+
+
+def test_reference_extractor_equals_oracle_on_the_wide_sweep():
+    """The wide sweep of tests/test_orb_gpu.py, here against the reference's own ORBextractor.cpp: 70 images — every residue of width and height mod 4,
+    levels smaller than one cell (and images where every level is), dense checkerboards (15 000 candidates on a level), noise, saturated and
+    step images, nlevels 1 and 12, other scale factors / feature budgets / FAST thresholds.  Cases on which the reference itself throws
+    (synth.ORB_SWEEP_REFERENCE_THROWS) are compared HIP <-> oracle only."""
+    n = 0
+    for name, img, nf, kw in synth.orb_sweep_cases():
+        if name in synth.ORB_SWEEP_REFERENCE_THROWS:
+            continue
+        r = ref.RefOrb(nf, kw.get("scale", 1.2), kw.get("nlevels", 8), kw.get("ini_th", 20), kw.get("min_th", 7))
+        o = oracle.OrbOracle(nf, kw.get("scale", 1.2), kw.get("nlevels", 8), kw.get("ini_th", 20), kw.get("min_th", 7))
+        rk, rd = r.extract_cli(img)
+        ok, od = o.extract(img)
+        assert len(rk) == len(ok), (name, len(rk), len(ok))
+        for f in rk.dtype.names:
+            assert np.array_equal(rk[f], ok[f]), (name, f)
+        assert np.array_equal(rd, od), name
+        r.close(); o.close()
+        n += 1
+    assert n >= 50

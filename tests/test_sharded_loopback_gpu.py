@@ -11,20 +11,20 @@ import numpy as np
 import pytest
 
 from ccm_slam_amd import optimizer, synth
-from ccm_slam_amd._lib import Context, check, lib
+from ccm_slam_amd._lib import Context, check, hooks, lib
 
 pytestmark = pytest.mark.gpu
 
 
 def run_sharded(prob, nranks, iters, stop_rank=None, stop_at_trial=None, lambda_init=0.0):
     group = C.c_void_p()
-    check(lib().ccm_comm_loopback_create(nranks, C.byref(group)))
+    check(hooks().ccm_comm_loopback_create(nranks, C.byref(group)))
     out, err = [None] * nranks, [None] * nranks
 
     def rank_main(rank):
         try:
             ctx = Context(0)
-            check(lib().ccm_comm_init_loopback(ctx.handle, group, rank), ctx.handle)
+            check(hooks().ccm_comm_init_loopback(ctx.handle, group, rank), ctx.handle)
             h = optimizer.BAHandle(ctx, prob, rank=rank, nranks=nranks)
             flag = np.zeros(1, np.uint8)
             if stop_rank == rank:
@@ -49,7 +49,7 @@ def run_sharded(prob, nranks, iters, stop_rank=None, stop_at_trial=None, lambda_
     for t in th:
         t.join(timeout=300)
     assert not any(t.is_alive() for t in th), "a rank is stuck in a collective (mismatched call sequence)"
-    lib().ccm_comm_loopback_destroy(group)
+    hooks().ccm_comm_loopback_destroy(group)
     assert all(e is None for e in err), err
     return out
 

@@ -248,3 +248,38 @@ def test_batched_normal_and_depth_of_the_patched_shim_equals_the_per_point_metho
     assert (a["obs_alive"] == 0).sum() > 100                                                       # outlier observations were erased
     for k in ("kf_Tcw", "mp_pos", "mp_normal", "mp_dmin", "mp_dmax", "mp_bad", "obs_alive"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_pose_locked_points_keep_their_position_and_get_consistent_normals():
+    """MapPoint::SetWorldPos returns without writing when the point's position is locked and the system is a CLIENT (MapPoint.cpp:340-341), so the
+    UpdateNormalAndDepth() that follows (Optimizer.cpp:635-636) works from the OLD position.  Every third point of a local window is locked: the
+    reference's own Optimizer.cpp, the shim and the shim with the batched write-back (which computes normals from the optimised positions and therefore
+    must send locked points through the per-point method) have to leave the same map: locked points bit-identical to the input, their normals /
+    distance ranges those of the old position."""
+    lflat = mg.flat_from_ba_problem(synth.make_ba_config("lba_c2"))
+    locked = (np.arange(lflat["n_mp"]) % 3 == 0).astype(np.uint8)
+    libs = [mg.REF_LIB, mg.SHIM_LIB]
+    patched = os.path.join(os.path.dirname(mg.SHIM_LIB), "liboptimizer_hip_shim_patched.so")
+    if os.path.exists(patched):
+        libs.append(patched)
+    out = []
+    for lib in libs:
+        g = mg.MapGraph(lib, lflat)
+        g.lock_points(locked, server=False)
+        assert g.local_ba(15, client_id=0) == 0
+        out.append(g.state())
+        g.close()
+    r = out[0]
+    lk = locked.astype(bool)
+    moved = (r["mp_pos"] != lflat["mp_pos"]).any(axis=1)
+    assert moved[~lk].sum() > 500 and not moved[lk].any()                       # the reference: locked points did not move, others did
+    for s in out[1:]:
+        assert np.array_equal(s["mp_pos"][lk], lflat["mp_pos"][lk])
+        keep = (r["mp_bad"] == 0) & (s["mp_bad"] == 0)
+        assert (r["obs_alive"] != s["obs_alive"]).sum() <= 2
+        assert ulps32(r["mp_pos"][keep], s["mp_pos"][keep]).max() <= 1024
+        assert np.abs(r["mp_normal"][keep] - s["mp_normal"][keep]).max() < 1e-4
+        assert np.abs(r["mp_dmax"][keep] / np.maximum(s["mp_dmax"][keep], 1e-30) - 1).max() < 1e-4
+    if len(out) == 3:                                                            # batched and per-point write-back: the same bits
+        for k in ("kf_Tcw", "mp_pos", "mp_normal", "mp_dmin", "mp_dmax", "mp_bad", "obs_alive"):
+            assert np.array_equal(out[1][k], out[2][k]), k
