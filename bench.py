@@ -329,6 +329,63 @@ def ba_kernel_bytes(counts):
     }
 
 
+def large_map_leg(ctx, workload="gba_c5", reps=2):
+    """BASELINE config 5 (8 agents, 10 000 keyframes / 300 000 landmarks / 1.9 M observations): the maps above 2048 free cameras, whose reduced solve runs as
+    separate kernels per CG iteration (ba_pcg_spmv / ba_pcg_update / ba_pcg_coarse_apply) instead of the persistent kernel.  One step = ccm_ba_create from the
+    HBM-resident flat problem + ccm_ba_run(20) to g2o's stop rule, exactly like the headline workload; best of `reps`, then one more call with HIP events
+    around every launch for the kernel table.  The roofline is that of the dominant kernel (the SpMV): 288 B + 192 C algorithmic bytes per CG iteration."""
+    import numpy as np  # noqa: F401
+    from ccm_slam_amd import optimizer, synth
+    from ccm_slam_amd._lib import K
+    prob = synth.make_ba_config(workload)
+    res = optimizer.ResidentProblem(ctx, prob)
+    best = None
+    for _ in range(reps + 1):     # the first call of a size pays pool allocations
+        t0 = time.perf_counter()
+        hh = optimizer.BAHandle(ctx, prob, resident=res)
+        t1 = time.perf_counter()
+        st = hh.run(20)
+        t2 = time.perf_counter()
+        counts = hh.counts()
+        _, _, tr = hh.history()
+        hh.close()
+        cur = {"ms_per_call": (t2 - t0) * 1e3, "create_ms": (t1 - t0) * 1e3, "run_ms": (t2 - t1) * 1e3}
+        if best is None or cur["ms_per_call"] < best["ms_per_call"]:
+            best = cur
+    ctx.prof_enable(-1)
+    ctx.prof_reset()
+    hh = optimizer.BAHandle(ctx, prob, resident=res)
+    hh.run(20)
+    hh.close()
+    ctx.sync()
+    prof = {name: ctx.prof_read(k) for name, k in K.items() if name.startswith("BA_")}
+    ctx.prof_enable(-2)
+    res.close()
+    kb = ba_kernel_bytes(counts)
+    pmc = pmc_lookup(workload)
+    kernels = []
+    for name, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+        if not n:
+            continue
+        avg_us = ms * 1e3 / n
+        ach = kb[name] / (avg_us * 1e-6) / 1e9
+        kname = {"BA_PCG_UPDATE": "ba_pcg_update"}.get(name, KERNEL_OF_CLASS[name].split("+")[0])
+        ent = pmc.get(kname)
+        kernels.append({"class": name.lower(), "kernel": KERNEL_OF_CLASS[name] + ("+ba_pcg_coarse_apply" if name == "BA_PCG_UPDATE" else ""), "launches_per_call": n,
+                        "avg_us": round(avg_us, 2), "ms_per_call": round(ms, 3), "algorithmic_bytes_per_launch": kb[name], "achieved_GBps": round(ach, 1),
+                        "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 5), "pmc_hbm_bytes_per_launch": ent["hbm_bytes_per_launch"] if ent else None})
+    dom = kernels[0] if kernels else None
+    out = {"workload": f"{workload}: {prob['n_cam']} KFs / {prob['n_pt']} landmarks / {prob['n_edge']} observations, {counts['blocks']} Schur blocks",
+           "ms_per_call": round(best["ms_per_call"], 2), "create_ms": round(best["create_ms"], 2), "run_ms": round(best["run_ms"], 2),
+           "lm_iterations": st.iters_done, "lm_trials": st.lm_trials, "cg_iterations": st.pcg_iters, "trials_per_iteration": [int(v) for v in tr],
+           "ms_per_lm_iteration": round(best["ms_per_call"] / max(st.iters_done, 1), 3), "kernels": kernels}
+    if dom:
+        out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac_of_hbm_peak"],
+                           "traffic": dom["pmc_hbm_bytes_per_launch"], "traffic_source": f"profiles/pmc_{workload}.json (committed rocprofv3 --pmc passes), not measured in this run",
+                           "avg_us": dom["avg_us"], "launches": dom["launches_per_call"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]}
+    return {workload: out}
+
+
 KERNEL_OF_CLASS = {   # device kernel(s) behind every profiling class on the gba-sized path (names as rocprofv3 prints them)
     "BA_LINEARIZE": "ba_linearize_pts_e", "BA_CAM": "ba_linearize_cams", "BA_DINV": "ba_dinv", "BA_SCHUR_DIAG": "ba_schur_diag",
     "BA_SCHUR_OFF": "ba_schur_row3", "BA_PCG_SPMV": "ba_pcg_spmv", "BA_PCG_UPDATE": "ba_pcg_update", "BA_BACKSUB": "ba_backsub_chi2_e",
@@ -344,7 +401,8 @@ def pmc_lookup(workload):
     passes over `bench.py --gba-only`, keyed by kernel AND grid so that launches of different problem sizes never mix).  PMC
     counters cannot be collected from inside this process: these are the last committed values for this workload."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        name = "pmc_latest.json" if workload == "gba_c4" else f"pmc_{workload}.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         if pmc.get("workload") != workload:
             return {}
         out = {}
@@ -460,6 +518,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gba-only", action="store_true", help="skip the tracking / local-BA legs and the CPU baseline (profiling runs)")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-large-map", action="store_true", help="skip the extra.gba_c5 leg (BASELINE config 5)")
     ap.add_argument("--pcg-max-iters", type=int, default=0)
     ap.add_argument("--plumbing-only", action="store_true", help="N-rank launch path up to (not including) the first device call; runs without a GPU")
     args = ap.parse_args()
@@ -690,6 +749,11 @@ def main():
         if world == 1:   # per-agent figure, independent of N; a single-rank solve has no business inside a sharded job's timing run
             extra.update(local_ba_leg(ctx, with_cpu=not args.no_cpu_baseline))
             extra.update(pose_graph_leg(ctx, with_cpu=not args.no_cpu_baseline))
+            if args.workload != "gba_c5" and not args.no_large_map:
+                try:
+                    extra.update(large_map_leg(ctx))
+                except Exception as e:
+                    extra["gba_c5"] = {"error": str(e)}
 
     if rank == 0:
         out = {

@@ -898,7 +898,9 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // round trips plus ~10 ns per WORKGROUP dispatched, whatever the workgroups do (a pass that only adds six numbers per row: 20 us for 2 500
 // workgroups), so 5 000 two-row workgroups spent most of the kernel being dispatched.  (Also measured and dropped: a two-pass symmetric
 // form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
-__global__ __launch_bounds__(kSpmvTPB) void ba_pcg_spmv(BaDev d, int k) {
+// (round 4) 66 VGPRs left ONE 16-wave workgroup per CU (7 waves per SIMD); the kernel is bound by the bytes it keeps in flight (per wave 8 blocks of 288 B behind
+// an index load), so it is held to 64 registers: two workgroups per CU.
+__global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
   __shared__ double redp[4 * (kSpmvTPB / kWave)];
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(kSpmvTPB) void ba_pcg_spmv(BaDev d, int k) {
 // one workgroup per cluster
 __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   __shared__ double rc[kCluN];
-  __shared__ double zpart[4][kCluN];
+  __shared__ double zpart[8][kCluN];
   __shared__ double red[kTPB / kWave];
   const int t = threadIdx.x, c = blockIdx.x;
   const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
@@ -1034,23 +1036,25 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   // puts consecutive threads on consecutive addresses, and the 24 16-byte loads of a thread are all in flight at once: the whole 74 KB block
   // of the cluster arrives in ONE memory round trip (two threads per row with 8 loads in flight took six; rocprofv3: 13.5 us per launch on the
   // 10 000-keyframe map).  Rows / columns beyond a short last cluster: W is the identity there and r is zero.
-  const double* W = d.Wc + (size_t)c * kCluN * kCluN;
+  // (round 4: W is stored as f32 — 37 KB per cluster and iteration instead of 74; thread (rp, seg) = (t % 24, t / 24) takes rows 4 rp .. 4 rp + 3 and the
+  // columns [12 seg, 12 seg + 12): twelve 16-byte loads in flight)
+  const float* W = d.Wc + (size_t)c * kCluN * kCluN;
   if (t < 192) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    const int rp = t % 48, seg = t / 48;
-    const v2d* Wp = reinterpret_cast<const v2d*>(W + (size_t)(24 * seg) * kCluN + 2 * rp);
-    v2d w[24];
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int rp = t % 24, seg = t / 24;
+    const v4f* Wp = reinterpret_cast<const v4f*>(W + (size_t)(12 * seg) * kCluN + 4 * rp);
+    v4f w[12];
 #pragma unroll
-    for (int q = 0; q < 24; q++) w[q] = Wp[(size_t)q * (kCluN / 2)];
-    double s0 = 0, s1 = 0;
+    for (int q = 0; q < 12; q++) w[q] = Wp[(size_t)q * (kCluN / 4)];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int q = 0; q < 24; q++) { const double rq = rc[24 * seg + q]; s0 += w[q][0] * rq; s1 += w[q][1] * rq; }
-    zpart[seg][2 * rp] = s0; zpart[seg][2 * rp + 1] = s1;
+    for (int q = 0; q < 12; q++) { const double rq = rc[12 * seg + q]; s0 += (double)w[q][0] * rq; s1 += (double)w[q][1] * rq; s2 += (double)w[q][2] * rq; s3 += (double)w[q][3] * rq; }
+    zpart[seg][4 * rp] = s0; zpart[seg][4 * rp + 1] = s1; zpart[seg][4 * rp + 2] = s2; zpart[seg][4 * rp + 3] = s3;
   }
   __syncthreads();
   double rz = 0;
   if (t < m) {
-    const double z = ((zpart[0][t] + zpart[1][t]) + zpart[2][t]) + zpart[3][t];
+    const double z = (((zpart[0][t] + zpart[1][t]) + (zpart[2][t] + zpart[3][t])) + ((zpart[4][t] + zpart[5][t]) + (zpart[6][t] + zpart[7][t])));
     d.z[g] = z;
     rz = rc[t] * z;
   }
@@ -1099,11 +1103,11 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
     // trees and the four wave sums in order.
     __shared__ double yred[12][kTPB / kWave];
     double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double* ar = d.mk_Ainv + (size_t)(6 * agg) * d.mk_Nc;
+    const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;   // f32 copy (round 4): the 12 rows are re-read by every cluster in every CG iteration
     for (int jj = t; jj < nca; jj += kTPB) {
       const double rv = rcs[jj];
 #pragma unroll
-      for (int rr = 0; rr < 12; rr++) a12[rr] += ar[(size_t)rr * d.mk_Nc + jj] * rv;
+      for (int rr = 0; rr < 12; rr++) a12[rr] += (double)ar[(size_t)rr * d.mk_Nc + jj] * rv;
     }
 #pragma unroll
     for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
@@ -1319,6 +1323,10 @@ struct PersArgs {
   // coarse level (nullptr = cluster-Jacobi only): explicit inverse [Nc x Nc], prolongation blocks [Cp][36], aggregates
   const double* Ainv; const double* Pm; int na, Nc;   // na camera intervals, na + 1 coarse nodes
   double* cparts;              // [12][grid]: the units' parts of the coarse restriction P^T q (6 for the first node of the unit's interval, 6 for the second), component-major; exchanged like p, q and z
+  // the cluster inverse across trials (round 4): [grid][96 * 48] the unit's own 48 rows of W, transposed, as the kernel keeps them in LDS.  w_load != 0: this
+  // launch takes them from here instead of assembling and factoring the cluster block (a stale W — another lambda, an earlier linearisation — is still a
+  // symmetric positive definite block-Jacobi preconditioner: PCG stays exact, only the iteration count moves; the host decides, lm_trial)
+  double* wsave; int w_load;
 };
 
 // a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double in the PCG loop)
@@ -1802,17 +1810,26 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
   long long* tacc = reinterpret_cast<long long*>(ibuf + 4);   // [13]: 12 phases + last stamp
   const bool timing = a.dbg != nullptr && blockIdx.x == 0 && t == 0;
   if (timing) { for (int q = 0; q < 12; q++) tacc[q] = 0; tacc[12] = wall_clock64(); }
-  pers_factor_cluster(A, Li, ibuf, a.cij, a.cblk, has ? a.coff[c] : 0, has ? a.coff[c + 1] : 0, d.S, s0, s1, lambda, has, tacc, timing);
   // keep only the unit's own 48 rows of W, transposed (WT[col][row]: conflict-free for the mat-vec); the other half of the
   // A region then holds the coarse level: Ac^-1 rows of the two nodes of the unit's interval (as f32: it is only a preconditioner, and 12 rows in f64
   // would not fit) | coarse residual | own P_k | y of the two nodes
-  {
+  if (a.w_load) {   // the inverse an earlier launch of this handle left behind: 36 KB per unit out of L2 instead of ~80 us of assembly + tile factorisation
+    const double* src = a.wsave + (size_t)u * (N * (N / 2));
+    double wreg[5];
+    int nw = 0;
+    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) wreg[nw] = src[e];
+    nw = 0;
+    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) A[e] = wreg[nw];
+    __syncthreads();
+  } else {
+    pers_factor_cluster(A, Li, ibuf, a.cij, a.cblk, has ? a.coff[c] : 0, has ? a.coff[c + 1] : 0, d.S, s0, s1, lambda, has, tacc, timing);
     double wreg[5];
     int nw = 0;
     for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) wreg[nw] = A[(e / (N / 2)) * N + ob + e % (N / 2)];
     __syncthreads();
     nw = 0;
-    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) A[e] = wreg[nw];
+    double* dst = a.wsave ? a.wsave + (size_t)u * (N * (N / 2)) : nullptr;
+    for (int e = t; e < N * (N / 2); e += kPersTPB, nw++) { A[e] = wreg[nw]; if (dst) dst[e] = wreg[nw]; }
   }
   const bool coarse = a.Ainv != nullptr;
   const int Nc = a.Nc, nca = 6 * (a.na + 1);
@@ -2095,14 +2112,14 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_init_tiles(BaDev d, double la
   if (t < 4) ibuf[t] = 0;
   __syncthreads();
   pers_factor_cluster(A, Li, ibuf, cij, cblk, coff[c], coff[c + 1], d.S, s0, s1, lambda, true, nullptr, false);
-  double* W = d.Wc + (size_t)c * N * N;
-  for (int e = t; e < N * N; e += kPersTPB) W[e] = A[e];
+  float* W = d.Wc + (size_t)c * N * N;
+  for (int e = t; e < N * N; e += kPersTPB) W[e] = (float)A[e];
   if (t < N) rc[t] = (t < m) ? d.bs[6 * (size_t)s0 + t] : 0.0;
   __syncthreads();
   double rz = 0;
   if (t < m) {
     double z = 0;
-    for (int col = 0; col < m; col++) z += A[col * N + t] * rc[col];   // W is symmetric: column access is conflict-free
+    for (int col = 0; col < m; col++) z += (double)(float)A[col * N + t] * rc[col];   // W is symmetric: column access is conflict-free; rounded as ba_pcg_update will read it (ONE preconditioner for the whole solve)
     const size_t g = 6 * (size_t)s0 + t;
     d.x[g] = 0; d.r[g] = rc[t]; d.z[g] = z; d.p[0][g] = 0;
     rz = rc[t] * z;
@@ -2655,6 +2672,11 @@ int max_diag(ccm_ba* ba, double* out) {
   return CCM_OK;
 }
 
+__global__ void ba_f64_to_f32(const double* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
 // coarse operator of the current linearisation at this lambda and its explicit inverse (needs S of the trial)
 int coarse_build(ccm_ba* ba, double lambda) {
   ccm_ctx* ctx = ba->ctx;
@@ -2667,7 +2689,13 @@ int coarse_build(ccm_ba* ba, double lambda) {
   hipLaunchKernelGGL(ba_coarse_sum, dim3(ccm_div_up((int64_t)Nc * Nc, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)ba->d_cstage, (const unsigned*)ba->d_cb_key,
                      ba->coarse_ncb, na, nn, ba->d_cA, Nc);
   CCM_HIP_CHECK(ctx, hipGetLastError());
-  return ccm_dense_chol_inverse_dev(ctx, ba->d_cA, Nc, ba->d_cLinv, ba->d_cX, ba->d_cAinv, ba->d_cinfo);
+  RC(ccm_dense_chol_inverse_dev(ctx, ba->d_cA, Nc, ba->d_cLinv, ba->d_cX, ba->d_cAinv, ba->d_cinfo));
+  if (ba->d_cAinv32) {   // multi-kernel PCG: the rows the clusters re-read every CG iteration, as f32
+    const size_t n = (size_t)Nc * Nc;
+    hipLaunchKernelGGL(ba_f64_to_f32, dim3((unsigned)ccm_div_up((int64_t)n, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)ba->d_cAinv, ba->d_cAinv32, n);
+    CCM_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return CCM_OK;
 }
 
 int coarse_prepare(ccm_ba* ba, double lambda) {
@@ -2742,6 +2770,22 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.test_abort = getenv("CCM_BA_TEST_ABORT") ? 1 : 0;
       pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
       pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
+      // Cluster inverse across trials.  Offline (1000-keyframe 4-agent reduced systems, numpy PCG to 1e-8): W built at a lambda 10 / 100 / 1000 times away
+      // costs 0-2 / 2-3 / 5 more CG iterations of 24-46; W of the INITIAL linearisation used three LM iterations later costs 13-19 more (the robust weights move),
+      // later linearisations hardly differ.  So: always reuse inside an LM iteration (rejected trials: only lambda moved) within a lambda window, and across
+      // iterations as long as the solve that first used a carried-over inverse did not need noticeably more iterations than the last fresh one (the counts
+      // are deterministic, so the decision is — on every rank of a sharded run alike).  CCM_BA_W_REUSE=0 never, 1 inside an iteration only, 2 (default) adaptive.
+      static const int w_mode = getenv("CCM_BA_W_REUSE") ? atoi(getenv("CCM_BA_W_REUSE")) : 2;
+      static const double w_win = getenv("CCM_BA_W_WIN") ? atof(getenv("CCM_BA_W_WIN")) : 1000.0;
+      pa.wsave = ba->d_pers_wsave;
+      {
+        const bool same_lin = ba->w_lin_id == ba->lin_id;
+        const bool in_win = ba->w_lambda_built > 0 && lambda <= w_win * ba->w_lambda_built && lambda >= ba->w_lambda_built / w_win;
+        const bool reuse = ba->d_pers_wsave && w_mode > 0 && ba->w_valid && in_win && !pa.test_abort && (same_lin || (w_mode >= 2 && !ba->w_stale_bad));
+        pa.w_load = reuse ? 1 : 0;
+        ba->w_loaded = reuse;
+        if (!reuse) { ba->w_valid = ba->d_pers_wsave != nullptr; ba->w_lambda_built = lambda; ba->w_lin_id = ba->lin_id; ba->w_stale_bad = false; }
+      }
       const bool use_coarse = ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
       ba->coarse_used = use_coarse;
       if (use_coarse) {
@@ -2755,6 +2799,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.cparts = ba->d_cparts;
       }
       void* kargs[2] = {(void*)&d, (void*)&pa};
+      static const bool trial_dbg = getenv("CCM_BA_TRIAL_DBG") != nullptr;   // development: wall clock of every persistent solve (adds two stream syncs per trial)
+      double tdbg0 = 0;
+      if (trial_dbg) { hipStreamSynchronize(ctx->stream); tdbg0 = now_ms(); }
       {
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
         // A cooperative launch guarantees co-residency but, measured with rocprofv3 on MI355X / ROCm 7.2, leaves the
@@ -2773,6 +2820,13 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         else { (void)hipGetLastError(); ba->pers_grid = 0; pers_launch_failed = true; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
       }
       if (persist_ok) small_path = pers_trial = true;
+      if (trial_dbg) {
+        hipStreamSynchronize(ctx->stream);
+        int fl[4] = {0, 0, 0, 0};
+        hipMemcpy(fl, d.pcg_flag, sizeof(fl), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[ccm_ba] trial: lin %d lambda %.4g persist %.1f us, %d CG iterations, coarse %s, W %s\n", ba->lin_id, lambda, (now_ms() - tdbg0) * 1e3, fl[1],
+                !use_coarse ? "off" : ba->coarse_fresh ? "built" : "reused", pa.w_load ? "loaded" : "factored");
+      }
     }
     if (!persist_ok) {
       d.mk_on = 0;
@@ -2843,6 +2897,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }
   if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
+  if (pers_trial) {   // iteration guard of the carried-over cluster inverse
+    if (!ba->w_loaded) ba->w_fresh_iters = *pcg_iters;
+    else if (ba->w_lin_id != ba->lin_id && *pcg_iters > ba->w_fresh_iters + ba->w_fresh_iters / 8 + 3) ba->w_stale_bad = true;
+    if (small_flags[2]) ba->w_valid = false;   // a failed solve never leaves an inverse behind to be reused
+  }
   if (ba->coarse_na && (small_path || d.mk_cpart)) {
     if (ba->coarse_used) {
       if (ba->coarse_fresh) ba->coarse_fresh_iters = *pcg_iters;
@@ -2957,6 +3016,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   if (opt_in) opt = *opt_in;
   ba->coarse_active = false;   // every run starts from the same preconditioner state
   ba->coarse_valid = false; ba->coarse_stale_bad = false; ba->coarse_fresh_iters = 0;
+  ba->w_valid = false; ba->w_stale_bad = false; ba->w_fresh_iters = 0; ba->w_lambda_built = 0; ba->lin_id = 0; ba->w_lin_id = -1;
   ba->stop_flag = stop_flag; ba->stop_any = false;
   ba->hist_chi2.clear(); ba->hist_lambda.clear(); ba->hist_trials.clear();
   if (ba->nranks > 1 && !ba->pers_agreed) {
@@ -2994,6 +3054,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
     if (ba->nranks > 1 && ba->stop_requested()) { reason = 1; break; }
     const double iniChi = currentChi;
     if ((rc = build_system(ba))) return rc;
+    ba->lin_id++;
     if (it == 0) {
       if (opt.lambda_init > 0) lambda = opt.lambda_init;
       else { double md = 0; if ((rc = max_diag(ba, &md))) return rc; lambda = 1e-5 * md; }

@@ -813,7 +813,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     AL(Dinv, 6 * (size_t)Lloc, double) AL(dl, 3 * (size_t)Lloc, double) AL(Hpp, 36 * (size_t)Cp, double) AL(bp, 6 * (size_t)Cp, double)
     AL(x, 6 * (size_t)Cp, double) AL(r, 6 * (size_t)Cp, double) AL(z, 6 * (size_t)Cp, double) AL(q, 6 * (size_t)Cp, double)
     AL(p[0], 6 * (size_t)Cp, double) AL(p[1], 6 * (size_t)Cp, double)
-    AL(Wc, (size_t)n_cl * kCluN * kCluN, double)
+    AL(Wc, (size_t)n_cl * kCluN * kCluN, float)
     d.n_wg_spmv = ((ccm_div_up(std::max(Cp, 1), kRowsPerWG) + 7) / 8) * 8;   // padded to 8 (one chunk per XCD)
     d.n_wg_wave4 = ccm_div_up(std::max(Cp, 1), kTPB / kWave);
     d.n_wg_upd = n_cl;   // one workgroup per preconditioner cluster
@@ -844,11 +844,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     };
     // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device and every unit's lists fit its LDS
     ba->pers_grid = 0;
-    d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
+    d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_Ainv32 = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
     if (pers_try && !hs.pers_bad) {
       BB_RC(keep_get(ba, 4 + 2 * 16 + 4 * 512, &ba->d_pers_bar, true));   // abort flag + debug clocks (workgroup 0's phases; then per workgroup the time spent in the two exchanges)
       BB_RC(keep_get(ba, 4 * (size_t)pers_grid_want, &ba->d_pers_part, true));   // [2][2][grid] slot words
       ba->pers_grid = pers_grid_want;
+      BB_RC(keep_get(ba, (size_t)pers_grid_want * (kCluN * (kCluN / 2)), &ba->d_pers_wsave, false));   // the units' halves of the cluster inverse, carried from trial to trial (written before read)
       if (coarse_pers) BB_RC(coarse_buffers(pers_grid_want));
     } else if (pers_try) { ba->d_pers_uoff = nullptr; ba->d_pers_ucol = nullptr; ba->d_pers_loc = nullptr; }
     if (Cp > kSmallMaxCp && Cp <= kDense2MaxCp && ba->d_pers_coff)
@@ -860,6 +861,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       BB_RC(keep_get(ba, 12 * (size_t)n_cl, &p1, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p2, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p3, true));
       d.mk_cpart = p1; d.mk_cry[0] = p2; d.mk_cry[1] = p3;
       d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
+      BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv32, false)); d.mk_Ainv32 = ba->d_cAinv32;
     }
     BB_RC(flush_zero_list(ba));   // (no kernel above reads a buffer it asked to have zeroed)
     BB_RC(ccm_ba_state_from_raw(ba));

@@ -85,7 +85,7 @@ struct BaDev {
   const uint32_t* row_blk;   // [..] block id | transpose bit
   // PCG
   double *x, *r, *z, *q, *p[2];
-  double* Wc;                // [n_clusters][96*96] explicit inverses of the damped cluster blocks
+  float* Wc;                 // [n_clusters][96*96] explicit inverses of the damped cluster blocks, multi-kernel PCG; f32: only a preconditioner (offline: the same CG iteration counts as f64), half the 74 KB a cluster re-reads in every CG iteration
   double *ppq, *prz[2];      // partials
   double* pcg_scal;          // [0]=rz0 [1]=thresh^2  [2]=lambda
   int* pcg_flag;             // [0]=done [1]=iters [2]=fail
@@ -107,6 +107,7 @@ struct BaDev {
   double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
   const double* mk_P;        // [Cp][36] prolongation blocks
   const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse
+  const float* mk_Ainv32;    // the same rounded to f32: what ba_pcg_coarse_apply reads (12 rows per cluster and CG iteration)
   int mk_on, mk_Nc, mk_na;   // mk_on: this trial's solve uses the coarse level
   int agg;                   // cameras per interval of the coarse space (kAggFine / kAggWide); a multiple of the 8 cameras of a persistent unit
 };
@@ -143,6 +144,10 @@ struct ccm_ba {
   // earlier linearisation point) still gives a fixed SPD M^-1 for the whole solve, so PCG converges to the same tolerance, just a few
   // iterations later.  It is rebuilt when lambda has left [1/4, 4] x the lambda it was built at, or when a solve with the stale
   // operator needed clearly more iterations than the solve right after the last build (counts are deterministic => so is the policy).
+  // cluster inverse of the persistent solver carried from trial to trial (ba.hip, lm_trial): what it was built at, and the iteration guard
+  double* d_pers_wsave = nullptr;   // [pers_grid][96 * 48]
+  float* d_cAinv32 = nullptr;       // [Nc][Nc] multi-kernel path
+  bool w_valid = false, w_loaded = false, w_stale_bad = false; double w_lambda_built = 0; int w_fresh_iters = 0, lin_id = 0, w_lin_id = -1;
   bool coarse_valid = false, coarse_fresh = false, coarse_stale_bad = false, coarse_reuse = true;
   double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
   double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial

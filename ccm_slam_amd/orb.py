@@ -146,7 +146,7 @@ def distribute_octree(x, y, response, minX, maxX, minY, maxY, N):
 def debug_octree_dev(ctx: Context, x, y, response, W, H, N):
     """Test hook: the device octree kernel on one level's candidates; returns (selected indices in output order, overflow flag)."""
     x, y, r = (np.ascontiguousarray(a, np.int32) for a in (x, y, response))
-    sel = np.zeros(4 * N + 16, np.int32)
+    sel = np.zeros(max(4 * N + 16, 64), np.int32)   # (the first pass turns up to 15 roots into 60 nodes whatever N is)
     n = C.c_int(0); over = C.c_int(0)
     check(hooks().ccm_orb_debug_octree_dev(ctx.handle, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
                                          int(x.size), int(W), int(H), int(N), sel.ctypes.data_as(C.c_void_p), int(sel.size), C.byref(n), C.byref(over)), ctx.handle)

@@ -82,5 +82,5 @@ json.dump({"source": f"rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE, --pmc
            "workload": workload.group(1) if workload else "gba_c4",
            "correction": "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, "
                          "both reported by rocprofv3 in KiB; WRITE_SIZE and narrow / gathered reads are uncalibrated per the same section",
-           "kernels": out}, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+           "kernels": out}, open(os.path.join(dst, "pmc_latest.json" if not workload or workload.group(1) == "gba_c4" else f"pmc_{workload.group(1)}.json"), "w"), indent=1)
 print("wrote", len(out), "rows for", tag)

@@ -5,10 +5,11 @@
 TAG=${1:-r02}
 STEPS=${2:-20}
 WARMUP=${3:-5}
+EXTRA=${4:-}      # e.g. "--workload gba_c5" (collect_profiles.py then writes profiles/pmc_gba_c5.json instead of pmc_latest.json)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --gba-only --steps $STEPS --warmup $WARMUP"
+CMD="python bench.py --gba-only --steps $STEPS --warmup $WARMUP $EXTRA"
 echo "$CMD" > $OUT/command.txt
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/pmc_fetch.log 2>&1
