@@ -2703,7 +2703,14 @@ int coarse_prepare(ccm_ba* ba, double lambda) {
   // 21.9 ms per call, 16: 4 builds / 976 / 20.4 ms, 64: 4 builds / 982 / 20.8 ms.  The stale-iterations guard below still forces a rebuild when
   // a reused operator costs a third more iterations than a fresh one did.
   static const double win = getenv("CCM_BA_COARSE_WIN") ? atof(getenv("CCM_BA_COARSE_WIN")) : 16.0;
-  const bool need = !ba->coarse_reuse || !ba->coarse_valid || ba->coarse_stale_bad || lambda > win * ba->coarse_lambda_built || lambda < ba->coarse_lambda_built / win;
+  // (round 4) UPWARDS the window is wider: lambda only grows along a chain of rejected trials (x2, x4, x8, ...), where every trial has its own lambda and a
+  // rebuilt operator would serve that one solve — a 768-unknown build costs ~50 CG iterations, an operator built at a 10 - 60 times smaller lambda 5 - 15;
+  // the stale-iterations guard still forces a rebuild when a reused operator does badly
+  // (measured, one box, complete calls: gba_c4 15.6 -> 15.2 ms with 2 builds instead of 3 and 567 instead of 538 CG iterations; gba_c3 unchanged; on the
+  // multi-kernel path of gba_c5, where a CG iteration costs ~100 us against a 2.5 ms build, the wider window LOSES 10 ms (1546 instead of 1438 iterations): 16 there)
+  static const double win_up_env = getenv("CCM_BA_COARSE_WIN_UP") ? atof(getenv("CCM_BA_COARSE_WIN_UP")) : 0.0;
+  const double win_up = win_up_env > 0 ? win_up_env : (ba->pers_grid ? 64.0 : win);
+  const bool need = !ba->coarse_reuse || !ba->coarse_valid || ba->coarse_stale_bad || lambda > win_up * ba->coarse_lambda_built || lambda < ba->coarse_lambda_built / win;
   ba->coarse_fresh = need;
   if (!need) return CCM_OK;
   RC(coarse_build(ba, lambda));
@@ -2772,11 +2779,16 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
       // Cluster inverse across trials.  Offline (1000-keyframe 4-agent reduced systems, numpy PCG to 1e-8): W built at a lambda 10 / 100 / 1000 times away
       // costs 0-2 / 2-3 / 5 more CG iterations of 24-46; W of the INITIAL linearisation used three LM iterations later costs 13-19 more (the robust weights move),
-      // later linearisations hardly differ.  So: always reuse inside an LM iteration (rejected trials: only lambda moved) within a lambda window, and across
+      // later linearisations hardly differ (the map itself disagreed, see the measurements below).  Policy: reuse inside an LM iteration (rejected trials: only lambda moved) within a lambda window, and across
       // iterations as long as the solve that first used a carried-over inverse did not need noticeably more iterations than the last fresh one (the counts
-      // are deterministic, so the decision is — on every rank of a sharded run alike).  CCM_BA_W_REUSE=0 never, 1 inside an iteration only, 2 (default) adaptive.
-      static const int w_mode = getenv("CCM_BA_W_REUSE") ? atoi(getenv("CCM_BA_W_REUSE")) : 2;
-      static const double w_win = getenv("CCM_BA_W_WIN") ? atof(getenv("CCM_BA_W_WIN")) : 1000.0;
+      // are deterministic, so the decision is — on every rank of a sharded run alike).  CCM_BA_W_REUSE=0 never, 1 (default) inside an iteration only, 2 adaptive across iterations.
+      // MEASURED on gba_c4 (CCM_BA_TRIAL_DBG, one box): a launch that loads W is 55-65 us shorter than one that factors (589 against 646 us at 39 CG iterations);
+      // inside an LM iteration a W built at lambda / 2 ... lambda / 8 costs no iteration, at lambda / 64 three (28 against 25), at lambda / 32 on a lambda-dominated
+      // system (1.4e4) ten (21 against 11); ACROSS linearisations it is erratic: 32 against 31, 41 / 41, 43 / 43, but 87 against 48 (second linearisation), 58 / 43,
+      // 66 / 41 — and every bad solve also trips the coarse level's stale guard (6 builds instead of 4): 19.2 ms per call against 17.0.  Hence the default:
+      // mode 1 (same linearisation only) with a window of 8: 3 of the 7 rejected trials of gba_c4 load, ~0.2 ms of 17.
+      static const int w_mode = getenv("CCM_BA_W_REUSE") ? atoi(getenv("CCM_BA_W_REUSE")) : 1;
+      static const double w_win = getenv("CCM_BA_W_WIN") ? atof(getenv("CCM_BA_W_WIN")) : 8.5;
       pa.wsave = ba->d_pers_wsave;
       {
         const bool same_lin = ba->w_lin_id == ba->lin_id;
@@ -2786,8 +2798,14 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         ba->w_loaded = reuse;
         if (!reuse) { ba->w_valid = ba->d_pers_wsave != nullptr; ba->w_lambda_built = lambda; ba->w_lin_id = ba->lin_id; ba->w_stale_bad = false; }
       }
-      const bool use_coarse = ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
+      // (round 4) a strongly damped system does not need the coarse level: above the call's first lambda (g2o's 1e-5 max diag(H): the scale at which the damping
+      // takes over the smooth modes as well) cluster-Jacobi alone converges in 10-24 iterations on the 4-agent map, while a stale coarse operator carried up
+      // there from a 16 times smaller lambda needed 46 and a fresh build costs ~50 iterations' worth.  CCM_BA_COARSE_LMAX scales the limit (0 = no limit).
+      static const double coarse_lmax = getenv("CCM_BA_COARSE_LMAX") ? atof(getenv("CCM_BA_COARSE_LMAX")) : 1.0;
+      const bool damped = ba->coarse_force == 0 && coarse_lmax > 0 && ba->lambda_first > 0 && lambda >= coarse_lmax * ba->lambda_first;
+      const bool use_coarse = ba->coarse_na && !damped && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
       ba->coarse_used = use_coarse;
+      ba->coarse_skipped_damped = damped;
       if (use_coarse) {
         if (getenv("CCM_BA_COARSE_DBG")) {
           hipStreamSynchronize(ctx->stream); const double tc0 = now_ms();
@@ -2830,7 +2848,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     if (!persist_ok) {
       d.mk_on = 0;
-      if (d.mk_cpart && ba->coarse_na && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active))) {
+      static const double coarse_lmax_mk = getenv("CCM_BA_COARSE_LMAX") ? atof(getenv("CCM_BA_COARSE_LMAX")) : 1.0;
+      const bool damped_mk = ba->coarse_force == 0 && coarse_lmax_mk > 0 && ba->lambda_first > 0 && lambda >= coarse_lmax_mk * ba->lambda_first;
+      ba->coarse_skipped_damped = damped_mk;
+      if (d.mk_cpart && ba->coarse_na && !damped_mk && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active))) {
         RC(coarse_prepare(ba, lambda));
         d.mk_on = 1;
       }
@@ -2911,7 +2932,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     static const int off_env = getenv("CCM_BA_COARSE_OFF") ? atoi(getenv("CCM_BA_COARSE_OFF")) : 0;
     const int on_it = on_env ? on_env : (d.agg < kAggWide ? kCoarseOnItersFine : kCoarseOnIters);
     const int off_it = off_env ? off_env : (d.agg < kAggWide ? kCoarseOffItersFine : kCoarseOffIters);
-    if (!ba->coarse_used && *pcg_iters >= on_it) ba->coarse_active = true;
+    if (ba->coarse_skipped_damped) { /* the level was left out because of the damping, not by the switch: the switch keeps its state */ }
+    else if (!ba->coarse_used && *pcg_iters >= on_it) ba->coarse_active = true;
     else if (ba->coarse_used && *pcg_iters <= off_it) ba->coarse_active = false;
   }
   *temp_chi = s[0];
@@ -3058,6 +3080,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
     if (it == 0) {
       if (opt.lambda_init > 0) lambda = opt.lambda_init;
       else { double md = 0; if ((rc = max_diag(ba, &md))) return rc; lambda = 1e-5 * md; }
+      ba->lambda_first = lambda;
       ni = 2; nBad = 0;
     }
     double rho = 0;

@@ -234,35 +234,42 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 
 constexpr int kBlurTW = 64, kBlurTH = 16;
+constexpr int kBlurInBytes = (kBlurTH + 6) * (kBlurTW + 6), kBlurHsBytes = (kBlurTH + 6) * kBlurTW * 2;
+constexpr int kBlurLds = (kBlurInBytes + kBlurHsBytes + 15) & ~15;   // LDS of one 256-thread tile team
+// one 64 x 16 tile by a team of 256 threads (tid 0..255); `live` = the team has a tile (a team without one only keeps the two barriers of its workgroup)
+__device__ __forceinline__ void orb_blur_tile(const OrbDev& d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, bool live, int l, int bx, int by, int tid,
+                                              uint8_t* in, uint16_t* hs) {
+  const LevelInfo L = d.lv[live ? l : 0];
+  const uint8_t* src = pyr + L.off;
+  if (live)
+    for (int t = tid; t < (kBlurTH + 6) * (kBlurTW + 6); t += 256) {
+      const int ty = t / (kBlurTW + 6), tx = t % (kBlurTW + 6);
+      const int gx = reflect101(bx + tx - 3, L.w), gy = reflect101(by + ty - 3, L.h);
+      in[t] = src[(size_t)gy * L.stride + gx];
+    }
+  __syncthreads();
+  if (live)
+    for (int t = tid; t < (kBlurTH + 6) * kBlurTW; t += 256) {
+      const int ty = t / kBlurTW, tx = t % kBlurTW;
+      const uint8_t* r = in + ty * (kBlurTW + 6) + tx;
+      hs[t] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+    }
+  __syncthreads();
+  if (live)
+    for (int t = tid; t < kBlurTH * kBlurTW; t += 256) {
+      const int ty = t / kBlurTW, tx = t % kBlurTW;
+      const int gx = bx + tx, gy = by + ty;
+      if (gx < L.w && gy < L.h) {
+        const uint16_t* c = hs + ty * kBlurTW + tx;
+        const uint32_t s = 18u * (c[0] + c[6 * kBlurTW]) + 34u * (c[kBlurTW] + c[5 * kBlurTW]) + 48u * (c[2 * kBlurTW] + c[4 * kBlurTW]) + 56u * c[3 * kBlurTW];
+        blur[L.off + (size_t)gy * L.stride + gx] = (uint8_t)((s + (1u << 15)) >> 16);
+      }
+    }
+}
 __global__ __launch_bounds__(256) void orb_blur_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                        const int* __restrict__ tile_level, const int* __restrict__ tile_xy) {
-  __shared__ uint8_t in[(kBlurTH + 6) * (kBlurTW + 6)];
-  __shared__ uint16_t hs[(kBlurTH + 6) * kBlurTW];
-  const int l = tile_level[blockIdx.x];
-  const LevelInfo L = d.lv[l];
-  const int bx = tile_xy[2 * blockIdx.x], by = tile_xy[2 * blockIdx.x + 1];
-  const uint8_t* src = pyr + L.off;
-  for (int t = threadIdx.x; t < (kBlurTH + 6) * (kBlurTW + 6); t += 256) {
-    const int ty = t / (kBlurTW + 6), tx = t % (kBlurTW + 6);
-    const int gx = reflect101(bx + tx - 3, L.w), gy = reflect101(by + ty - 3, L.h);
-    in[t] = src[(size_t)gy * L.stride + gx];
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < (kBlurTH + 6) * kBlurTW; t += 256) {
-    const int ty = t / kBlurTW, tx = t % kBlurTW;
-    const uint8_t* r = in + ty * (kBlurTW + 6) + tx;
-    hs[t] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < kBlurTH * kBlurTW; t += 256) {
-    const int ty = t / kBlurTW, tx = t % kBlurTW;
-    const int gx = bx + tx, gy = by + ty;
-    if (gx < L.w && gy < L.h) {
-      const uint16_t* c = hs + ty * kBlurTW + tx;
-      const uint32_t s = 18u * (c[0] + c[6 * kBlurTW]) + 34u * (c[kBlurTW] + c[5 * kBlurTW]) + 48u * (c[2 * kBlurTW] + c[4 * kBlurTW]) + 56u * c[3 * kBlurTW];
-      blur[L.off + (size_t)gy * L.stride + gx] = (uint8_t)((s + (1u << 15)) >> 16);
-    }
-  }
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kBlurLds];
+  orb_blur_tile(d, pyr, blur, true, tile_level[blockIdx.x], tile_xy[2 * blockIdx.x], tile_xy[2 * blockIdx.x + 1], threadIdx.x, lds, reinterpret_cast<uint16_t*>(lds + ((kBlurInBytes + 1) & ~1)));
 }
 
 // ---- orientation + descriptor: one wave per keypoint -----------------------------------------------
@@ -294,6 +301,11 @@ struct OctArgs {
   int* counts;            // [nlevels] list sizes, [nlevels] = arrival counter
   KpIn* kin; int* n_out; int kp_cap;   // n_out: [keypoint count, overflow flag]
   unsigned long long* dbg;   // nullable: phase clocks of level 0 (timing experiments)
+  // round 4: the per-cell lists of orb_cells_kernel read directly (no orb_compact_kernel in front); nullptr = `cand` holds the compacted lists
+  const uint32_t* cell_slots; const int* cell_counts;
+  // round 4: workgroups behind the `nlevels` octree ones blur 64 x 16 tiles (TPB / 256 tiles each): the 7 x 7 Gaussian does not depend on the octree and the
+  // octree's one-workgroup-per-level rounds leave the rest of the chip idle, so both travel in ONE launch.  n_blur_tiles = 0: no blur workgroups.
+  const uint8_t* pyr; uint8_t* blur; const int* tile_level; const int* tile_xy; int n_blur_tiles;
 };
 
 // exclusive scan of two consecutive items per thread over the workgroup (items 2t, 2t+1); returns the total.  wsum: LDS [TPB / 64 + 1]
@@ -322,12 +334,35 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   __shared__ int sh[16];                 // [0] list size  [1] cur buffer  [2] created  [3] new candidates  [4] finish  [5] cut rank  [6] overflow
   __shared__ int rootcnt[16], rootslot[16];
   const int t = threadIdx.x;
+  if ((int)blockIdx.x >= a.nlevels) {   // a blur workgroup: TPB / 256 teams, one tile each
+    const int team = t >> 8, tile = ((int)blockIdx.x - a.nlevels) * (TPB / 256) + team;
+    const bool live = tile < a.n_blur_tiles;
+    uint8_t* in = oct_lds + (size_t)team * kBlurLds;
+    orb_blur_tile(d, a.pyr, a.blur, live, live ? a.tile_level[tile] : 0, live ? a.tile_xy[2 * tile] : 0, live ? a.tile_xy[2 * tile + 1] : 0, t & 255, in,
+                  reinterpret_cast<uint16_t*>(in + ((kBlurInBytes + 1) & ~1)));
+    return;
+  }
   const int l = blockIdx.x;
   const LevelInfo Lv = d.lv[l];
   const int N = a.nfeat[l], Lcap = a.lcap[l];
-  const int c0 = a.cand[Lv.cellBase], c1 = a.cand[Lv.cellBase + Lv.nCols * Lv.nRows];
-  const int n = c1 - c0;
-  const uint32_t* grec = reinterpret_cast<const uint32_t*>(a.cand + a.ncells + 1) + c0;
+  const int ncl = Lv.nCols * Lv.nRows;
+  const bool from_cells = a.cell_counts != nullptr;      // (the host chooses this form only when every level has at most 2 TPB cells)
+  int c0 = 0, n;
+  if (from_cells) {
+    // exclusive scan of the level's cell counts in LDS (the list slots are not in use yet): cell i's records go to [coff[i], coff[i + 1])
+    int* coff = reinterpret_cast<int*>(oct_lds + (((size_t)a.kcap * 7 + 15) & ~(size_t)15));
+    const int i0 = 2 * t, i1 = 2 * t + 1;
+    const int v0 = i0 < ncl ? a.cell_counts[Lv.cellBase + i0] : 0, v1 = i1 < ncl ? a.cell_counts[Lv.cellBase + i1] : 0;
+    int e0, e1;
+    n = oct_scan2<TPB>(v0, v1, e0, e1, wsum);
+    if (i0 <= ncl) coff[i0] = e0;
+    if (i1 <= ncl) coff[i1] = e1;
+    __syncthreads();
+  } else {
+    c0 = a.cand[Lv.cellBase];
+    n = a.cand[Lv.cellBase + ncl] - c0;
+  }
+  const uint32_t* grec = from_cells ? nullptr : reinterpret_cast<const uint32_t*>(a.cand + a.ncells + 1) + c0;
   // LDS carve-up
   uint32_t* rec = reinterpret_cast<uint32_t*>(oct_lds);                       // [kcap]
   uint16_t* knode = reinterpret_cast<uint16_t*>(rec + a.kcap);                // [kcap]
@@ -353,6 +388,26 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   if (!overflow && n > 0) {
     const float hX = static_cast<float>(W) / nIni;
     // roots: bin the candidates (order inside a node never matters, see above)
+    if (from_cells) {
+      // record k of the level = record k - coff[i] of cell i, i = the last cell whose offset is <= k (binary search over the offsets in LDS); the offsets
+      // live where the list slots will: they are copied to registers before the first slot is written
+      const int* coff = reinterpret_cast<const int*>(oct_lds + (((size_t)a.kcap * 7 + 15) & ~(size_t)15));
+      for (int k0 = t; k0 < n; k0 += 4 * TPB) {   // four global loads in flight per thread
+        uint32_t r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k = k0 + q * TPB;
+          r4[q] = 0u;
+          if (k < n) {
+            int lo = 0, hi = ncl - 1;       // invariant: coff[lo] <= k < coff[hi + 1]
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (coff[mid] <= k) lo = mid; else hi = mid - 1; }
+            r4[q] = a.cell_slots[(size_t)(Lv.cellBase + lo) * kCellCap + (k - coff[lo])];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (k0 + q * TPB < n) rec[k0 + q * TPB] = r4[q];
+      }
+    } else
     for (int k0 = t; k0 < n; k0 += 4 * TPB) {   // four global loads in flight per thread
       uint32_t r4[4];
 #pragma unroll
@@ -830,6 +885,7 @@ struct ccm_orb {
   Octree tree_ws; std::vector<int> sel_ws;   // reusable host workspaces
   // device octree (orb_octree_kernel): LDS plan of this geometry; oct_ok = false -> host octree
   bool oct_ok = false; int oct_tpb = 1024; int oct_kcap = 0, oct_stride = 0; size_t oct_lds = 0; int oct_lcap[kMaxLevels] = {0};
+  bool oct_cells = false;   // the octree kernel reads the per-cell lists itself (no orb_compact_kernel on the device-octree path)
   hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
   hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;   // host-octree batch path
   hipStream_t bstream[kOrbSets] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t bev[kOrbSets] = {nullptr, nullptr, nullptr, nullptr};   // device-octree batch path: stream / "done" event of sets 1..3
@@ -1049,6 +1105,11 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     o->oct_tpb = (4 * nmax + 16 <= 1024 && !getenv("CCM_ORB_OCT_1024")) ? 512 : 1024;
     if (getenv("CCM_ORB_OCT_KCAP")) o->oct_kcap = std::min(o->oct_kcap, std::max(256, atoi(getenv("CCM_ORB_OCT_KCAP"))) & ~15);   // tests: force the host fallback
     o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
+    {
+      int max_cells = 0;
+      for (int l = 0; l < o->nlevels; l++) max_cells = std::max(max_cells, d.lv[l].nCols * d.lv[l].nRows);
+      o->oct_cells = o->oct_ok && !getenv("CCM_ORB_COMPACT") && max_cells <= 2 * o->oct_tpb && ((size_t)max_cells + 1) * sizeof(int) <= slots;
+    }
   }
   if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 64)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 64)); }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
@@ -1071,7 +1132,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
 }
 
 // device phase 1: pyramid, scores, cells, compaction; blur is queued too (it does not depend on the octree)
-static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
+static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
   for (int l = 1; l < o->nlevels; l++) {
@@ -1090,15 +1151,16 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true) {
   } else {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
     hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
-    hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
-                       (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
+    if (!(dev_octree && o->oct_cells))   // (the octree kernel gathers from the cell lists itself; the compacted form is only made when the host or a test asks for it)
+      hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
+                         (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
   }
   if (copy_cand) {
     const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].h_cand, o->B[o->cur].d_cand, first, hipMemcpyDeviceToHost, o->st));
     CCM_HIP_CHECK(ctx, hipEventRecord(o->B[o->cur].ev_cand, o->st));
   }
-  if (o->n_blur_tiles > 0) {
+  if (o->n_blur_tiles > 0 && !dev_octree) {   // (device octree: the blur tiles ride in the octree kernel's launch, orb_phase2_dev)
     ccm_prof_scope ps(ctx, CCM_K_BLUR, o->st);
     hipLaunchKernelGGL(orb_blur_kernel, dim3(o->n_blur_tiles), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->d_tile_level, o->d_tile_xy);
   }
@@ -1220,14 +1282,17 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr,
   a.kcap = o->oct_kcap; a.stage = b.d_oct_stage; a.stage_stride = o->oct_stride; a.counts = b.d_oct_counts;
   a.kin = b.d_kin; a.n_out = b.d_n; a.kp_cap = std::min(o->kp_cap, out_cap);
   a.dbg = o->d_oct_dbg;
+  a.cell_slots = o->oct_cells ? b.d_cell_slots : nullptr; a.cell_counts = o->oct_cells ? b.d_cell_counts : nullptr;
+  a.pyr = b.d_pyr; a.blur = b.d_blur; a.tile_level = o->d_tile_level; a.tile_xy = o->d_tile_xy; a.n_blur_tiles = o->n_blur_tiles;
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
+    const int blur_wgs = ccm_div_up(o->n_blur_tiles, o->oct_tpb / 256);
     if (o->oct_tpb == 512) {   // two list slots per thread: 512 threads hold up to 4 N + 16 = 1024 slots, and a barrier of 8 waves is cheaper than one of 16
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel<512>, 152 * 1024);
-      hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(o->nlevels), dim3(512), o->oct_lds, o->st, o->dev, a);
+      hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(o->nlevels + blur_wgs), dim3(512), o->oct_lds, o->st, o->dev, a);
     } else {
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT2, orb_octree_kernel<1024>, 152 * 1024);
-      hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(o->nlevels), dim3(1024), o->oct_lds, o->st, o->dev, a);
+      hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(o->nlevels + blur_wgs), dim3(1024), o->oct_lds, o->st, o->dev, a);
     }
   }
   {
@@ -1257,7 +1322,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   if (o->oct_ok) {
     // no host in the middle: pyramid, FAST, octree, orientation and descriptors are queued back to back; ONE wait at the end
     ccm_orb::Bufs& b = o->B[o->cur];
-    if ((rc = orb_phase1(o, false))) return rc;
+    if ((rc = orb_phase1(o, false, true))) return rc;
     if ((rc = orb_phase2_dev(o, cap))) return rc;
     const double t1 = now();
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->h_io, b.d_kout, o_d + (size_t)std::min(cap, o->kp_cap) * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -1279,6 +1344,8 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
     }
     // a level did not fit the kernel's LDS plan: clear the flag and select on the host from the candidates that are still on the device
     CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_n + 1, 0, sizeof(int), ctx->stream));
+    if (o->oct_cells && o->dev.ncells > 0)   // the compacted lists were not made on the way
+      hipLaunchKernelGGL(orb_compact_kernel, dim3(o->dev.ncells), dim3(256), 0, ctx->stream, o->dev.ncells, b.d_cell_slots, b.d_cell_counts, b.d_cand, (uint32_t*)(b.d_cand + o->dev.ncells + 1));
     const size_t first = ((size_t)o->dev.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(b.h_cand, b.d_cand, first, hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipEventRecord(b.ev_cand, ctx->stream));
@@ -1344,7 +1411,7 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
       o->st = o->cur ? o->bstream[o->cur] : ctx->stream;
       ccm_orb::Bufs& b = o->B[o->cur];
       CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
-      if ((rc = orb_phase1(o, false))) { o->cur = 0; o->st = ctx->stream; return rc; }
+      if ((rc = orb_phase1(o, false, true))) { o->cur = 0; o->st = ctx->stream; return rc; }
       if ((rc = orb_phase2_dev(o, cap, d_kps + (size_t)f * cap, d_desc + (size_t)f * cap * 32, d_counts + f))) { o->cur = 0; o->st = ctx->stream; return rc; }
     }
     o->cur = 0; o->st = ctx->stream;
@@ -1414,6 +1481,9 @@ int ccm_internal::orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out,
     ccm_ctx* ctx = o->ctx;
     ccm_orb::Bufs& b = o->B[o->cur];
     if (!b.d_cand) return CCM_E_ARG;
+    if (o->oct_cells && o->dev.ncells > 0)   // the device-octree path skips the compaction: make the lists for this call
+      hipLaunchKernelGGL(orb_compact_kernel, dim3(o->dev.ncells), dim3(256), 0, ctx->stream, o->dev.ncells, b.d_cell_slots, b.d_cell_counts, b.d_cand, (uint32_t*)(b.d_cand + o->dev.ncells + 1));
+    else if (o->dev.ncells == 0) CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_cand, 0, sizeof(int), ctx->stream));
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(b.h_cand, b.d_cand, ((size_t)o->dev.ncells + 1 + o->cand_cap) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const int* offs = b.h_cand;
@@ -1465,7 +1535,7 @@ int ccm_internal::orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int
   hipMemcpyAsync(d_cand, cand.data(), cand.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
   hipMemsetAsync(d_counts, 0, 4 * sizeof(int), ctx->stream);
   hipMemsetAsync(d_nout, 0, 2 * sizeof(int), ctx->stream);
-  OctArgs a{};
+  OctArgs a{};   // (cell lists / blur payload: none)
   a.cand = d_cand; a.ncells = 1; a.nlevels = 1; a.nfeat[0] = N; a.lcap[0] = lcap; a.kcap = kcap; a.stage = d_stage; a.stage_stride = stride;
   a.counts = d_counts; a.kin = d_kin; a.n_out = d_nout; a.kp_cap = stride;
   const size_t lds = ((size_t)kcap * 7 + 15) / 16 * 16 + slots;

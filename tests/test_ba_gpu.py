@@ -428,7 +428,7 @@ def test_full_length_gba_follows_the_oracle_to_the_stop_rule(ctx, name):
     assert int((dpos == 0).sum()) == int(g["n_depth_nonpos"])
 
 
-@pytest.mark.parametrize("name", ["gba_c3", "gba_c4"])
+@pytest.mark.parametrize("name", ["gba_c3", "gba_c4", "gba_c5"])
 def test_full_length_gba_follows_the_reference_g2o_fixture(ctx, name):
     """Against the REFERENCE ITSELF at BASELINE scale: tests/golden/<name>_ref.npz holds the run of the reference's own g2o (thirdparty/g2o compiled
     verbatim, graph built as MapFusionGBA builds it; scripts/make_ref_fixture.py) to its stop rule.  Same LM iterations, same trials in every iteration,
