@@ -25,6 +25,7 @@
 #include <thread>
 #include <type_traits>
 #include <utility>
+#include <unistd.h>   // usleep (the wait loops of the reference around SetNotErase, Optimizer.cpp:620-626)
 
 #include "../include/ccm_hip.h"
 #include "../ccm_slam_amd/host/ccm_convert.h"
