@@ -492,9 +492,15 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
   const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (i >= d.Cp) return;
   const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;   // ne <= kRowMaxEdges < kRow2TPB: one observation per thread
+  // phase clocks: compiled in only with -DCCM_BA_ROW_DBG_BUILD (round 4: as a run-time option their 64-bit time stamp stayed live through the whole kernel and
+  // was one of the values the register allocator spilled to scratch memory)
+#ifdef CCM_BA_ROW_DBG_BUILD
   long long tk0 = 0;
   if (d.row_dbg && threadIdx.x == 0) tk0 = wall_clock64();
 #define ROW2_TICK(slot) { if (d.row_dbg && threadIdx.x == 0) { const long long tn_ = wall_clock64(); atomicAdd((unsigned long long*)(d.row_dbg + slot), (unsigned long long)(tn_ - tk0)); tk0 = tn_; } }
+#else
+#define ROW2_TICK(slot) {}
+#endif
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int grp = lane / G, q = lane % G;
   const int zrow = d.max_cam_edges;        // a zero row of Y behind the real ones: what the idle lanes of a unit multiply
@@ -640,7 +646,9 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
     }
   }
   ROW2_TICK(3)
+#ifdef CCM_BA_ROW_DBG_BUILD
   if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
+#endif
 #undef ROW2_TICK
 }
 
@@ -675,9 +683,15 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
   const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (i >= d.Cp) return;
   const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;   // ne <= kRowMaxEdges < kRow2TPB: one observation per thread
+  // phase clocks: compiled in only with -DCCM_BA_ROW_DBG_BUILD (round 4: as a run-time option their 64-bit time stamp stayed live through the whole kernel and
+  // was one of the values the register allocator spilled to scratch memory)
+#ifdef CCM_BA_ROW_DBG_BUILD
   long long tk0 = 0;
   if (d.row_dbg && threadIdx.x == 0) tk0 = wall_clock64();
 #define ROW3_TICK(slot) { if (d.row_dbg && threadIdx.x == 0) { const long long tn_ = wall_clock64(); atomicAdd((unsigned long long*)(d.row_dbg + slot), (unsigned long long)(tn_ - tk0)); tk0 = tn_; } }
+#else
+#define ROW3_TICK(slot) {}
+#endif
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int grp = lane / G, q = lane % G;
   const int zrow = d.max_cam_edges;        // a zero row of Y behind the real ones: what the idle lanes of a unit multiply
@@ -763,9 +777,15 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
   // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
   for (int p = wv; p * UPW < n_units; p += NW) {
     const int uu = p * UPW + grp;
+    // (round 4) the table entry of a LATER pass is loaded when that pass begins: prefetched one pass ahead, its four values stayed live across the inner loop,
+    // were spilled to scratch memory there (16 bytes per lane and pass, 12 more per lane around the loop) and reloaded before the butterfly — rocprofv3 counted
+    // 59.5 MB written per launch for 18.9 MB of S blocks (WRITE_SIZE is exact for this store pattern: scripts/write_size_probe.hip), the rest was scratch.
+    // A row of the 4-agent map has ~57 units, i.e. ONE pass per wave: the prefetch bought nothing there.
+    if (p != wv) {
+      n_s0 = n_s1 = n_slot = n_j = 0;
+      if (p * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + p * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
+    }
     const int s0 = n_s0, s1 = n_s1, slot = n_slot, jc = n_j;
-    n_s0 = n_s1 = n_slot = n_j = 0;
-    if ((p + NW) * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + (p + NW) * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
@@ -854,7 +874,9 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
     }
   }
   ROW3_TICK(3)
+#ifdef CCM_BA_ROW_DBG_BUILD
   if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
+#endif
 #undef ROW3_TICK
 }
 

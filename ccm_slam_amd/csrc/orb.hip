@@ -91,15 +91,8 @@ __device__ __forceinline__ int find_level(const OrbDev& d, int grow) {
 // score = max over the 16 arcs of 9 contiguous ring pixels of min(v - p)  (dark ring)  or of min(p - v)
 // (bright ring), minus 1  ==  cornerScore<16>() of OpenCV for any pixel that is a corner at threshold t
 // (then score >= t); a pixel is a corner at threshold t iff score >= t.  Stored clamped to [0,255].
-__global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
-  const int grow = blockIdx.y;
-  const int l = find_level(d, grow);
-  const LevelInfo L = d.lv[l];
-  const int y = grow - L.rowBase;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x < kEdge || x >= L.w - kEdge || y < kEdge || y >= L.h - kEdge) return;
-  const uint8_t* p = pyr + L.off + (size_t)y * L.stride + x;
-  const int s = L.stride;
+// score of the pixel at p (row stride s, any address space): see above
+__device__ __forceinline__ int orb_fast_score_at(const uint8_t* p, int s) {
   const int v = p[0];
   int dd[16];
   dd[0] = v - p[3 * s];          dd[1] = v - p[3 * s + 1];      dd[2] = v - p[2 * s + 2];      dd[3] = v - p[s + 3];
@@ -118,7 +111,17 @@ __global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uin
 #pragma unroll
   for (int k = 0; k < 16; k++) { A = max(A, min(mn8[k], dd[(k + 8) & 15])); B = min(B, max(mx8[k], dd[(k + 8) & 15])); }
   const int sc = max(A, -B) - 1;
-  score[L.off + (size_t)y * L.stride + x] = (uint8_t)min(max(sc, 0), 255);
+  return min(max(sc, 0), 255);
+}
+// the whole score map (every level in one launch): since round 4 only for ccm_orb_debug_level — the extraction computes the scores inside orb_cells_kernel
+__global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+  const int grow = blockIdx.y;
+  const int l = find_level(d, grow);
+  const LevelInfo L = d.lv[l];
+  const int y = grow - L.rowBase;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x < kEdge || x >= L.w - kEdge || y < kEdge || y >= L.h - kEdge) return;
+  score[L.off + (size_t)y * L.stride + x] = (uint8_t)orb_fast_score_at(pyr + L.off + (size_t)y * L.stride + x, L.stride);
 }
 
 // ---- per-cell threshold + NMS + fallback + ordered compaction ------------------------------------
@@ -128,9 +131,14 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t* __restrict__ score, int iniTh, int minTh,
+// Round 4: the FAST scores of the cell's interior are computed HERE, from a (w + 6) x (h + 6) pixel tile staged in LDS (the score kernel over all levels and its
+// 1.1 MB score map are gone from the extraction: one launch and one round trip through memory less per frame; 13 % of the pixels are scored twice, by the
+// two cells whose tiles overlap).  `pyr` = the pyramid; the scores are the same integers, so everything downstream is unchanged.
+__global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t* __restrict__ pyr, int iniTh, int minTh,
                                                         uint32_t* __restrict__ cell_slots, int* __restrict__ cell_counts) {
   __shared__ uint8_t tile[(kCellMax + 2) * (kCellMax + 2)];
+  __shared__ uint8_t pix[(kCellMax + 6) * (kCellMax + 6 + 2)];
+  __shared__ uint8_t sct[kCellMax * kCellMax];
   __shared__ int wsum[4];
   __shared__ int total_s;
   const int cell = blockIdx.x;
@@ -152,13 +160,27 @@ __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t*
   const int npx = iw * ih;
   const int per = (npx + 255) / 256;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  {
+    // pixels of [x0 - 3, x0 + iw + 3) x [y0 - 3, y0 + ih + 3): inside the level, every cell interior lies >= 19 px from the level's edges
+    const int pw = iw + 6, ps = (pw + 3) & ~3;
+    for (int t = threadIdx.x; t < (ih + 6) * pw; t += 256) {
+      const int ty = t / pw, tx = t % pw;
+      pix[ty * ps + tx] = pyr[L.off + (size_t)(y0 - 3 + ty) * L.stride + (x0 - 3 + tx)];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < npx; t += 256) {
+      const int ty = t / iw, tx = t % iw;
+      sct[t] = (uint8_t)orb_fast_score_at(pix + (ty + 3) * ps + tx + 3, ps);
+    }
+    __syncthreads();
+  }
   for (int pass = 0; pass < 2; pass++) {
     const int th = pass == 0 ? iniTh : minTh;
     for (int t = threadIdx.x; t < (ih + 2) * tw; t += 256) {
       const int ty = t / tw - 1, tx = t % tw - 1;
       int m = 0;
       if (tx >= 0 && tx < iw && ty >= 0 && ty < ih) {
-        const int sc = score[L.off + (size_t)(y0 + ty) * L.stride + x0 + tx];
+        const int sc = sct[ty * iw + tx];
         m = sc >= th ? sc : 0;
       }
       tile[t] = (uint8_t)m;
@@ -1142,15 +1164,11 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false
                        o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
-  {
-    ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE, o->st);
-    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(d.maxW, 256), d.totalRows), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
-  }
   if (d.ncells == 0) {   // no level holds a cell (image below 62 px): the candidate list is empty, the pyramid above is the whole result
     CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[o->cur].d_cand, 0, sizeof(int), o->st));
   } else {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
-    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_score, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
+    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
     if (!(dev_octree && o->oct_cells))   // (the octree kernel gathers from the cell lists itself; the compacted form is only made when the host or a test asks for it)
       hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
                          (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
@@ -1469,7 +1487,11 @@ int ccm_internal::orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uin
   if (!o || !o->B[o->cur].d_pyr || level < 0 || level >= o->nlevels) return CCM_E_ARG;
   ccm_ctx* ctx = o->ctx;
   const LevelInfo& L = o->dev.lv[level];
-  if (score_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->B[o->cur].d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  if (score_out) {   // (the extraction no longer makes the score map: computed here for the caller)
+    ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
+    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(o->dev.maxW, 256), o->dev.totalRows), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
+    CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->B[o->cur].d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if (blur_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(blur_out, L.w, o->B[o->cur].d_blur + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CCM_OK;

@@ -553,7 +553,7 @@ def test_formulations_of_the_large_map_path_agree():
     """The large-map path in its default form (observations as 32-byte compact records, Hpl blocks never stored; coarse space with nodes every 16 cameras;
     blocked Cholesky tiles) against its alternatives, each in its own process (the switches are read once): the row kernel on STORED blocks
     (CCM_BA_ROW=2), stored blocks next to the compact row kernel (CCM_BA_KEEP_W=1), coarse nodes every 32 cameras, column-wise diagonal tiles.  All of
-    them must take the same LM path (iterations, trials per iteration) and end in the same poses to 1e-9 (they differ in summation order and in the
+    them must take the same LM path (iterations, trials per iteration) and end in the same poses to 5e-9 (they differ in summation order and in the
     preconditioner only; the CG tolerance is 1e-8 of the initial residual)."""
     base = _variant({})
     assert base["counts"]["blocks"] - base["counts"]["free_cams"] > 256          # the row kernel's path
@@ -562,6 +562,9 @@ def test_formulations_of_the_large_map_path_agree():
         v = _variant(env)
         assert (v["iters"], v["trials"]) == (base["iters"], base["trials"]), (env, v["trials"], base["trials"])
         assert np.abs(np.array(v["chi2"]) / np.array(base["chi2"]) - 1).max() < 1e-9, env
-        assert np.abs(np.array(v["cam"]) - cam0).max() < 1e-9, (env, np.abs(np.array(v["cam"]) - cam0).max())
+        # (every variant stops CG at 1e-8 of the initial residual with a DIFFERENT preconditioner / summation order, so their steps differ at that level:
+        # 1e-10 ... 1e-9 per pose component measured; the bound is 5e-9 since round 4, when the damped-system rule and the wider reuse window of the coarse level
+        # moved the coarse-32 variant to 1.02e-9)
+        assert np.abs(np.array(v["cam"]) - cam0).max() < 5e-9, (env, np.abs(np.array(v["cam"]) - cam0).max())
         assert abs(v["pts_sum"] / base["pts_sum"] - 1) < 1e-9
     assert _variant({"CCM_BA_COARSE_AGG": "32"})["pcg_iters"] > base["pcg_iters"]   # the finer coarse space is what saves CG iterations
