@@ -880,6 +880,222 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
 #undef ROW3_TICK
 }
 
+// ---- round 4: the row kernel with TWO rows per CU -------------------------------------------------------------------------------------------------------
+// ba_schur_row3 keeps Y_e = W_e D^-1 (6 x 3 = 144 B) of every own observation in LDS: 70-100 KB per row, hence ONE 16-wave workgroup per CU, and the row is a
+// chain of dependent round trips (indices -> records -> landmark data; table -> index vectors -> partner records; block ranges -> partial sums) that nothing
+// overlaps.  Here an own observation keeps 72 B: G_e = (w Omega Ji)_e D^-1 (2 x 3) and (a, b, 1/z) = (x/z, y/z, 1/z), from which Jj_e is two multiplications
+// per entry, and an instance's contribution is regrouped as
+//     W_a D^-1 W_c^T = Jj_a^T [ G_a (w Omega Ji)_c^T ] Jj_c          (2 x 2 core: 12 multiply-adds; times Jj_c: 20; times Jj_a^T: 60 — 36 + 60 in row3)
+// A workgroup is 8 waves (512 threads, 128 registers per lane as before) and needs ~60 KB of LDS on the 4-agent map, so TWO rows are resident per CU and each
+// one's round trips run under the other's arithmetic.  Same work units, same unit table, same fixed summation tree as row3 (32 units per pass instead of 64);
+// the diagonal block and b_schur are formed by the staging thread as Jj_e^T [G_e (w Omega Ji)_e^T] Jj_e and Jj_e^T (G_e b_l).  The regrouping changes
+// the rounding of S in the last bits against row3 / row2 (tests/test_ba_gpu.py::test_formulations_of_the_large_map_path_agree compares complete runs).
+// MEASURED (gba_c4, one box, bench events): 146 us against 134 us for row3 — SLOWER, so it is opt-in (CCM_BA_ROW=4).  Why: a CU holds 16 waves either way (128
+// registers per lane), and the waves of ONE 16-wave workgroup already run under each other's round trips; two 8-wave workgroups only add the overlap of one
+// row's staging with the other's block passes, and pay for it with two passes per row (32 units per pass for ~57 units), a second prologue per CU and 72 B of
+// scratch spills per lane in the staging loop (27 diagonal sums next to the factors).  More rows per CU would need fewer than 128 registers per lane, which
+// the 36 sums of an instance's 6 x 6 block do not leave.
+constexpr int kRow4TPB = 512;
+__global__ __launch_bounds__(kRow4TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_schur_row4(BaDev d) {
+  extern __shared__ __attribute__((aligned(16))) double Ys[];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  constexpr int G = kRow2Group, UPW = kWave / G, NW = kRow4TPB / kWave, YS = 10;   // 9 values per observation, rows padded to 10 doubles (16-byte aligned pairs)
+  const int per_xcd = gridDim.x >> 3;
+  const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (i >= d.Cp) return;
+  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int grp = lane / G, q = lane % G;
+  const int zrow = d.max_cam_edges;        // a zero row behind the real ones: what the idle lanes of a unit multiply
+  double* dpart = Ys + YS * (size_t)(zrow + 1);                          // [NW][27] per-wave partials of the diagonal block / b_schur
+  double* part = dpart + 27 * NW + 1;                                     // [row_units_max][36]
+  const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
+  int n_s0 = 0, n_s1 = 0, n_slot = 0, n_j = 0;
+  if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
+  // the row camera's record: rotation rows, fx, fy — workgroup-uniform, forced into scalar registers (as vector registers the two focal lengths were spilled
+  // around the inner loop and reloaded in every iteration)
+  auto uni = [](double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(bits & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  const double* rki = d.camRK + 12 * (size_t)i;
+  const double fxi = uni(rki[9]), fyi = uni(rki[10]);
+  // ---- staging: G_e, (a, b, 1/z) of the own observations; diagonal block and b_schur ----
+  {
+    double dacc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) dacc[k] = 0.0;
+    v2d ri[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { ri[k][0] = uni(rki[2 * k]); ri[k][1] = uni(rki[2 * k + 1]); }
+    for (int t = threadIdx.x; t < ne; t += kRow4TPB) {
+      const int pt = d.cam_pt[base + t];
+      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)(base + t));
+      const v2d* Dp = reinterpret_cast<const v2d*>(d.Dinv + 6 * (size_t)pt);
+      const v2d ea = Ep[0], eb = Ep[1];
+      const v2d d0 = Dp[0], d1 = Dp[1], d2 = Dp[2];
+      const double bl0 = d.bl[3 * (size_t)pt], bl1 = d.bl[3 * (size_t)pt + 1], bl2 = d.bl[3 * (size_t)pt + 2];
+      double wj0[3], wj1[3], pj[5], qj[5];
+      ba_compact_factors(ea, eb, ri, wj0, wj1, pj, qj);
+      const double D0 = d0[0], D1 = d0[1], D2 = d1[0], D3 = d1[1], D4 = d2[0], D5 = d2[1];
+      const double g00 = wj0[0] * D0 + wj0[1] * D1 + wj0[2] * D2, g01 = wj0[0] * D1 + wj0[1] * D3 + wj0[2] * D4, g02 = wj0[0] * D2 + wj0[1] * D4 + wj0[2] * D5;
+      const double g10 = wj1[0] * D0 + wj1[1] * D1 + wj1[2] * D2, g11 = wj1[0] * D1 + wj1[1] * D3 + wj1[2] * D4, g12 = wj1[0] * D2 + wj1[1] * D4 + wj1[2] * D5;
+      const double iz = eb[0], aa = ea[0] * iz, bb = ea[1] * iz;
+      v2d* Yp = reinterpret_cast<v2d*>(Ys + YS * (size_t)t);
+      v2d o0, o1, o2, o3, o4; o0[0] = g00; o0[1] = g01; o1[0] = g02; o1[1] = g10; o2[0] = g11; o2[1] = g12; o3[0] = aa; o3[1] = bb; o4[0] = iz; o4[1] = 0.0;
+      Yp[0] = o0; Yp[1] = o1; Yp[2] = o2; Yp[3] = o3; Yp[4] = o4;
+      // own part of the diagonal block: Jj^T M Jj with M = G (w Omega Ji)^T (2 x 2), and of b_schur: Jj^T (G b_l)
+      const double m00 = g00 * wj0[0] + g01 * wj0[1] + g02 * wj0[2], m01 = g00 * wj1[0] + g01 * wj1[1] + g02 * wj1[2];
+      const double m10 = g10 * wj0[0] + g11 * wj0[1] + g12 * wj0[2], m11 = g10 * wj1[0] + g11 * wj1[1] + g12 * wj1[2];
+      const double gb0 = g00 * bl0 + g01 * bl1 + g02 * bl2, gb1 = g10 * bl0 + g11 * bl1 + g12 * bl2;
+      // Jj as 2 x 6: row 0 = (pj0 pj1 pj2 pj3 0 pj4), row 1 = (qj0 qj1 qj2 0 qj3 qj4)
+      const double P6[6] = {pj[0], pj[1], pj[2], pj[3], 0.0, pj[4]}, Q6[6] = {qj[0], qj[1], qj[2], 0.0, qj[3], qj[4]};
+      double n0[6], n1[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) { n0[c] = m00 * P6[c] + m01 * Q6[c]; n1[c] = m10 * P6[c] + m11 * Q6[c]; }
+      constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+#pragma unroll
+        for (int c = r; c < 6; c++) dacc[kTri[r] + c] += P6[r] * n0[c] + Q6[r] * n1[c];
+        dacc[21 + r] += P6[r] * gb0 + Q6[r] * gb1;
+      }
+    }
+    // 27 sums over the 64 lanes of every wave (fixed tree), one partial per wave
+    {
+      double t0[14], t1[7], t2[4], t3[2];
+#pragma unroll
+      for (int k = 0; k < 27; k++) { dacc[k] += __shfl_xor(dacc[k], 32, kWave); dacc[k] += __shfl_xor(dacc[k], 16, kWave); }
+      row2_halve<27>(dacc, t0, (q & 8) != 0, 8);
+      row2_halve<14>(t0, t1, (q & 4) != 0, 4);
+      row2_halve<7>(t1, t2, (q & 2) != 0, 2);
+      row2_halve<4>(t2, t3, (q & 1) != 0, 1);
+      int e0, cnt;
+      row2_range(27, q, &e0, &cnt);
+      if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * wv + e0 + k] = t3[k];
+      }
+    }
+  }
+  if (threadIdx.x < YS) Ys[YS * (size_t)zrow + threadIdx.x] = 0.0;
+  __syncthreads();
+  // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
+  for (int p = wv; p * UPW < n_units; p += NW) {
+    const int uu = p * UPW + grp;
+    if (p != wv) {
+      n_s0 = n_s1 = n_slot = n_j = 0;
+      if (uu < n_units) { const int4 te = d.unit_tab[u_first + uu]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
+    }
+    const int s0 = n_s0, jc = n_j;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0.0;
+    const int nit = __builtin_amdgcn_readfirstlane((n_s1 - s0 + G - 1) / G);   // the table lists the units longest first: group 0 sets the trip count of the wave
+    int ce_n = (s0 + q < n_s1) ? d.inst_cp[s0 + q] : 0;
+    int ar_n = (s0 + q < n_s1) ? d.inst_al[s0 + q] : zrow;
+    int jq = jc;
+    // the loop keeps TWO integers of the table entry (its end and the running index), each in a register of its own: held as the 16-byte entry, the whole
+    // entry was spilled and reloaded in every iteration for the bounds test of the index prefetch; the partial-sum slot is read again after the loop
+    int s1 = n_s1, sn = s0 + q;
+    asm volatile("" : "+v"(s1), "+v"(sn));
+    for (int it = 0; it < nit; it++) {
+      const int ce = ce_n, ar = ar_n;
+      asm volatile("" : "+v"(jq));            // (see ba_schur_row3: keeps the loop-invariant camera record from being hoisted and spilled)
+      const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jq);
+      v2d r2[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) r2[k] = rk[k];
+      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce);
+      const v2d ea = Ep[0], eb = Ep[1];
+      sn += G;
+      ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
+      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
+      const v2d* Yp = reinterpret_cast<const v2d*>(Ys + YS * (size_t)ar);
+      const v2d y0 = Yp[0], y1 = Yp[1], y2 = Yp[2];
+      double n0[6], n1[6];
+      {
+        double wj0[3], wj1[3], pj[5], qj[5];
+        ba_compact_factors(ea, eb, r2, wj0, wj1, pj, qj);
+        // M = G_a (w Omega Ji)_c^T
+        const double m00 = __builtin_fma(y1[0], wj0[2], __builtin_fma(y0[1], wj0[1], y0[0] * wj0[0]));
+        const double m01 = __builtin_fma(y1[0], wj1[2], __builtin_fma(y0[1], wj1[1], y0[0] * wj1[0]));
+        const double m10 = __builtin_fma(y2[1], wj0[2], __builtin_fma(y2[0], wj0[1], y1[1] * wj0[0]));
+        const double m11 = __builtin_fma(y2[1], wj1[2], __builtin_fma(y2[0], wj1[1], y1[1] * wj1[0]));
+        // N = M Jj_c (structural zeros: pj column 4, qj column 3)
+        n0[0] = __builtin_fma(m01, qj[0], m00 * pj[0]); n1[0] = __builtin_fma(m11, qj[0], m10 * pj[0]);
+        n0[1] = __builtin_fma(m01, qj[1], m00 * pj[1]); n1[1] = __builtin_fma(m11, qj[1], m10 * pj[1]);
+        n0[2] = __builtin_fma(m01, qj[2], m00 * pj[2]); n1[2] = __builtin_fma(m11, qj[2], m10 * pj[2]);
+        n0[3] = m00 * pj[3];                            n1[3] = m10 * pj[3];
+        n0[4] = m01 * qj[3];                            n1[4] = m11 * qj[3];
+        n0[5] = __builtin_fma(m01, qj[4], m00 * pj[4]); n1[5] = __builtin_fma(m11, qj[4], m10 * pj[4]);
+      }
+      // Jj_a from (a, b, 1/z) and the row camera's focal lengths, one row of the result at a time
+      // (the two factors of a row are formed right before the row's six updates: as two arrays they were 20 more live registers next to the 36 sums)
+      asm volatile("" ::: "memory");          // (a, b, 1/z) are read from LDS only now: two more live pairs above would not fit
+      const v2d y3 = Yp[3];
+      const double iza = Yp[4][0];
+      const double a = y3[0], bq = y3[1];
+      const double fxa = fxi * a, fyb = fyi * bq;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double pa = r == 0 ? fxa * bq : r == 1 ? -__builtin_fma(fxa, a, fxi) : r == 2 ? fxi * bq : r == 3 ? -(fxi * iza) : r == 4 ? 0.0 : fxa * iza;
+        const double qa = r == 0 ? __builtin_fma(fyb, bq, fyi) : r == 1 ? -(fyb * a) : r == 2 ? -(fyi * a) : r == 3 ? 0.0 : r == 4 ? -(fyi * iza) : fyb * iza;
+        asm volatile("" :: "v"(pa), "v"(qa));   // materialised here, not hoisted above the loop
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          if (r == 4) acc[6 * r + c] = __builtin_fma(qa, n1[c], acc[6 * r + c]);
+          else if (r == 3) acc[6 * r + c] = __builtin_fma(pa, n0[c], acc[6 * r + c]);
+          else acc[6 * r + c] = __builtin_fma(qa, n1[c], __builtin_fma(pa, n0[c], acc[6 * r + c]));
+        }
+      }
+    }
+    const int slot = (uu < n_units) ? d.unit_tab[u_first + uu].w : 0;   // (its round trip runs under the butterfly)
+    double t1[18], t2[9], t3[5], t4[3];
+    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
+    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
+    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
+    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
+    int e0, cnt;
+    row2_range(36, q, &e0, &cnt);
+    if (uu < n_units) {
+      double* pu = part + 36 * (size_t)slot;
+#pragma unroll
+      for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
+    }
+  }
+  const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
+  constexpr int kGroups = kRow4TPB / 36;
+  const int fb0 = d.rowblk_off[i] + grp36, fb_end = d.rowblk_off[i + 1];
+  int f_ub = 0, f_n = 0;
+  if (grp36 < kGroups && fb0 < fb_end) { f_ub = d.blk_unit0[fb0]; f_n = d.inst_off[fb0 + 1] - d.inst_off[fb0]; }
+  __syncthreads();
+  // ---- final sums: per block over its units; diagonal block + b_schur over the waves' partials ----
+  if (grp36 < kGroups)
+    for (int bI = fb0; bI < fb_end; bI += kGroups) {
+      double sum = 0;
+      const int ub = (bI == fb0) ? f_ub : d.blk_unit0[bI];
+      const int ni = (bI == fb0) ? f_n : d.inst_off[bI + 1] - d.inst_off[bI];
+      const int ue = ub + max(1, (ni + d.unit_chunk - 1) / d.unit_chunk);
+      for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
+      d.S[36 * (size_t)(d.Cp + bI) + el] = -sum;
+    }
+  if (threadIdx.x >= kRow4TPB - 64 && threadIdx.x - (kRow4TPB - 64) < 27) {
+    const int e = threadIdx.x - (kRow4TPB - 64);
+    double sum = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) sum += dpart[27 * w + e];
+    if (e < 21) {
+      const int r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+      const int tri = r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15;
+      const int c = e - tri;
+      const double v = d.Hpp[36 * (size_t)i + 6 * r + c] - sum;
+      d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;
+    } else d.bs[6 * (size_t)i + e - 21] = d.bp[6 * (size_t)i + e - 21] - sum;
+  }
+}
+
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
 // Preconditioner: block-Jacobi over CLUSTERS of kClu consecutive camera slots (dense 96x96 blocks).  Keyframes of
 // one agent are consecutive and covisibility is mostly local in time, so a cluster captures the strong
@@ -2507,7 +2723,12 @@ static int launch_schur(ccm_ba* ba) {
     if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
     else if (d.row_units_max) {
       const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
-      if (d.E4) {
+      static const int row_form = getenv("CCM_BA_ROW") ? atoi(getenv("CCM_BA_ROW")) : 3;
+      const size_t lds_row4 = ((size_t)(d.max_cam_edges + 1) * 10 + 27 * (kRow4TPB / kWave) + 1 + (size_t)d.row_units_max * 36) * sizeof(double);
+      if (d.E4 && row_form == 4 && lds_row4 <= 158 * 1024) {   // compact Y, 8-wave workgroups: two rows per CU when lds_row4 <= ~78 KB
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW4, ba_schur_row4, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row4, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow4TPB), lds_row4, ctx->stream, d);
+      } else if (d.E4) {
         CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
         hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
       } else {

@@ -552,13 +552,13 @@ def _variant(env):
 def test_formulations_of_the_large_map_path_agree():
     """The large-map path in its default form (observations as 32-byte compact records, Hpl blocks never stored; coarse space with nodes every 16 cameras;
     blocked Cholesky tiles) against its alternatives, each in its own process (the switches are read once): the row kernel on STORED blocks
-    (CCM_BA_ROW=2), stored blocks next to the compact row kernel (CCM_BA_KEEP_W=1), coarse nodes every 32 cameras, column-wise diagonal tiles.  All of
+    (CCM_BA_ROW=2), the two compact-record row kernels (CCM_BA_ROW=3: 144-byte Y rows, one row per CU; CCM_BA_ROW=4: 72-byte rows, two rows per CU), stored blocks next to the compact row kernel (CCM_BA_KEEP_W=1), coarse nodes every 32 cameras, column-wise diagonal tiles.  All of
     them must take the same LM path (iterations, trials per iteration) and end in the same poses to 5e-9 (they differ in summation order and in the
     preconditioner only; the CG tolerance is 1e-8 of the initial residual)."""
     base = _variant({})
     assert base["counts"]["blocks"] - base["counts"]["free_cams"] > 256          # the row kernel's path
     cam0 = np.array(base["cam"])
-    for env in ({"CCM_BA_ROW": "2"}, {"CCM_BA_KEEP_W": "1"}, {"CCM_BA_COARSE_AGG": "32"}, {"CCM_CHOL_DIAG": "columns"}):
+    for env in ({"CCM_BA_ROW": "2"}, {"CCM_BA_ROW": "3"}, {"CCM_BA_ROW": "4"}, {"CCM_BA_KEEP_W": "1"}, {"CCM_BA_COARSE_AGG": "32"}, {"CCM_CHOL_DIAG": "columns"}):
         v = _variant(env)
         assert (v["iters"], v["trials"]) == (base["iters"], base["trials"]), (env, v["trials"], base["trials"])
         assert np.abs(np.array(v["chi2"]) / np.array(base["chi2"]) - 1).max() < 1e-9, env
