@@ -145,7 +145,7 @@ _SWEEP = synth.orb_sweep_cases()
 
 @pytest.mark.parametrize("case", range(len(_SWEEP)), ids=[c[0] for c in _SWEEP])
 def test_wide_sweep(ctx, oracle_lib, case):
-    """ORBextractor.cpp:933-998 / :1280-1304 over 70 images (synth.orb_sweep_cases): widths and heights of every residue mod 4, levels smaller than
+    """ORBextractor.cpp:933-998 / :1280-1304 over 66 images (synth.orb_sweep_cases): widths and heights of every residue mod 4, levels smaller than
     one 30-px cell (64x48, 40x40: no keypoints at all, the pyramid is still produced), single-cell levels with 59-px cells, dense checkerboards and
     noise (up to 33 000 octree candidates on a level: the device octree's LDS plan overflows and the frame is redone through the host octree),
     saturated / step images, nlevels 1 and 12, scale factors 1.1 - 2.0, 7 - 5000 features, iniThFAST == minThFAST.  Bit-exact against the oracle, which
