@@ -314,9 +314,9 @@ def ba_kernel_bytes(counts):
         # per observation: landmark / camera / slot indices 12, observation 16, information 8, record (or block) out; per landmark: range 8, position 24 in,
         # Hll 48 + b_l 24 out; per camera (a 56 + 32-byte table that the observations gather from and that stays in L2): pose + intrinsics, counted ONCE
         "BA_LINEARIZE": (36.0 + w_e) * E + 104.0 * L + 88.0 * C,
-        # camera-major pass: edge / landmark indices 8, observation 16, information 8, record out; the landmark positions it gathers are a 24 L table (once);
-        # per camera pose + intrinsics 88 in, Hpp 288 + b_p 48 (+ rotation / focal record 96) out
-        "BA_CAM": (32.0 + (32.0 if compact else 0.0)) * E + 24.0 * L + (88.0 + 288.0 + 48.0 + (96.0 if compact else 0.0)) * C,
+        # camera-major pass: landmark index 4 and the camera-major (observation, information) record 32 in, compact record out; the landmark positions it gathers are a
+        # 24 L table (once); per camera pose + intrinsics 88 in, Hpp 288 + b_p 48 (+ rotation / focal record 96) out
+        "BA_CAM": (36.0 + (32.0 if compact else 0.0)) * E + 24.0 * L + (88.0 + 288.0 + 48.0 + (96.0 if compact else 0.0)) * C,
         "BA_DINV": (48.0 + 24.0 + 48.0 + 24.0) * L,
         # per observation: indices 12, record (or block) in, observation 16 + information 8 in, chi2 8 + depth flag 1 out; per landmark: range 4, position 24 +
         # b_l 24 + D^-1 48 in, trial position 24 out; per camera, gathered tables counted ONCE (round 3 counted them per observation, which put this kernel

@@ -254,11 +254,14 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
 #pragma unroll
   for (int k = 0; k < 32; k++) acc[k] = 0;
   for (int s = d.cam_off[i] + lane; s < d.cam_off[i + 1]; s += kWave) {
-    const int e = d.cam_edge[s];
-    const int l = d.ed_pt[e];
+    // (round 4) landmark, observation and information come from the camera-major copies (cam_pt, cam_oi: contiguous per camera) instead of three gathers by
+    // edge index; only the landmark position is still gathered
+    const int l = d.cam_pt[s];
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d oi0 = reinterpret_cast<const v2d*>(d.cam_oi)[2 * (size_t)s], oi1 = reinterpret_cast<const v2d*>(d.cam_oi)[2 * (size_t)s + 1];
     const double X[3] = {d.pt[cur][3 * l], d.pt[cur][3 * l + 1], d.pt[cur][3 * l + 2]};
     double r0, r1;
-    ba_residual(T, K4, X, d.obs[2 * (size_t)e], d.obs[2 * (size_t)e + 1], r0, r1);
+    ba_residual(T, K4, X, oi0[0], oi0[1], r0, r1);
     double Xc[3];
     ba_map(T, X, Xc);
     double Jj[12];
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
       Jj[0] = x * y * iz2 * fx; Jj[1] = -(1 + (x * x * iz2)) * fx; Jj[2] = y * iz * fx; Jj[3] = -iz * fx; Jj[4] = 0; Jj[5] = x * iz2 * fx;
       Jj[6] = (1 + y * y * iz2) * fy; Jj[7] = -x * y * iz2 * fy; Jj[8] = -x * iz * fy; Jj[9] = 0; Jj[10] = -iz * fy; Jj[11] = y * iz2 * fy;
     }
-    const double om = d.info[e];
+    const double om = oi1[0];
     const bool off = om == 0.0;   // (see ba_linearize_pts_e)
     double rho0, w;
     ba_huber(off ? 0.0 : (r0 * r0 + r1 * r1) * om, d.huber, rho0, w);
@@ -279,7 +282,6 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_cams(BaDev d, int cur) {
       for (int k = 0; k < 12; k++) Jj[k] = 0.0;
     }
     if (d.E4) {   // what ba_schur_row3 re-derives this observation's Hpl block from (the values the landmark-side kernel computes for the same observation)
-      typedef double v2d __attribute__((ext_vector_type(2)));
       v2d* E = reinterpret_cast<v2d*>(d.E4 + 4 * (size_t)s);
       v2d ea, eb; ea[0] = Xc[0]; ea[1] = Xc[1]; eb[0] = off ? 0.0 : iz; eb[1] = wom;
       E[0] = ea; E[1] = eb;
@@ -3367,6 +3369,12 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   return CCM_OK;
 }
 
+// the camera-major copy of the informations follows ba_deactivate_edges
+__global__ void ba_refresh_cam_info(BaDev d) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= d.cam_off[d.Cp]) return;
+  d.cam_oi[4 * (size_t)s + 2] = d.info[d.cam_edge[s]];
+}
 // edges whose level is not 0 leave the optimisation: their information becomes 0, so every sum they enter gets an exact zero; an edge whose level is 0
 // (again) gets the information it was created with
 __global__ void ba_deactivate_edges(double* info, const double* info_orig, const int* loc_edge_orig, const uint8_t* level, int Eloc) {
@@ -3395,6 +3403,7 @@ extern "C" int ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double
     }
     if (ba->Eloc) hipLaunchKernelGGL(ba_deactivate_edges, dim3(ccm_div_up(ba->Eloc, kTPB)), dim3(kTPB), 0, ctx->stream, const_cast<double*>(ba->d.info), (const double*)ba->d_info_orig,
                                      (const int*)ba->d_loc_edge_orig, (const uint8_t*)d_lvl, ba->Eloc);
+    if (ba->Eloc && ba->d.Cp && ba->d.cam_oi) hipLaunchKernelGGL(ba_refresh_cam_info, dim3(ccm_div_up(ba->Eloc, kTPB)), dim3(kTPB), 0, ctx->stream, ba->d);
     CCM_HIP_CHECK(ctx, hipGetLastError());
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // e_level may be a pageable host array
   }

@@ -236,6 +236,16 @@ __global__ void bb_cam_lists(int Eloc, const int* off_all /* [Cp+2] */, const in
   const int k = cval[nfix + q];
   cam_edge[q] = k; cam_pt[q] = ed_pt[k];
 }
+// camera-major copy of (observation, information) (ba.hip refreshes it after ccm_ba_set_edge_levels has changed the informations)
+__global__ void bb_cam_oi_bounded(int Eloc, const int* __restrict__ off_all, const int* __restrict__ cam_edge, const double* __restrict__ obs, const double* __restrict__ info,
+                                  double* __restrict__ cam_oi) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= Eloc - off_all[1]) return;     // off_all[1] = edges of fixed cameras: they have no list slot
+  const int e = cam_edge[s];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  v2d a, b; a[0] = obs[2 * (size_t)e]; a[1] = obs[2 * (size_t)e + 1]; b[0] = info[e]; b[1] = 0.0;
+  reinterpret_cast<v2d*>(cam_oi)[2 * (size_t)s] = a; reinterpret_cast<v2d*>(cam_oi)[2 * (size_t)s + 1] = b;
+}
 __global__ void bb_cam_off(int Cp, const int* off_all, int* cam_off, BuildSizes* sz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > Cp) return;
@@ -624,6 +634,11 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     }
     hipLaunchKernelGGL(bb_lower_bound, dim3(grid_for(Cp + 2)), dim3(kB), 0, st, (const unsigned*)ckey_s, Eloc, Cp + 2, off_all);
     if (Eloc) hipLaunchKernelGGL(bb_cam_lists, dim3(grid_for(Eloc)), dim3(kB), 0, st, Eloc, (const int*)off_all, (const int*)cval_s, (const int*)p_ed_pt, p_cam_edge, p_cam_pt);
+    double* p_cam_oi = nullptr;
+    BB_RC(keep_get(ba, 4 * (size_t)Eloc, &p_cam_oi));
+    // (the number of list slots, Eloc minus the edges of fixed cameras, lives on the device: the kernel bounds itself through off_all)
+    if (Eloc) hipLaunchKernelGGL(bb_cam_oi_bounded, dim3(grid_for(Eloc)), dim3(kB), 0, st, Eloc, (const int*)off_all, (const int*)p_cam_edge, (const double*)p_obs, (const double*)p_info, p_cam_oi);
+    d.cam_oi = p_cam_oi;
     hipLaunchKernelGGL(bb_cam_off, dim3(grid_for(Cp + 1)), dim3(kB), 0, st, Cp, (const int*)off_all, p_cam_off, sz);
     BB_HIP(hipGetLastError());
     d.pt_off = p_pt_off; d.ed_cam = p_ed_cam; d.ed_cslot = p_ed_cslot; d.ed_pt = p_ed_pt; d.obs = p_obs; d.info = p_info;

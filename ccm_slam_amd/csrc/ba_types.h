@@ -46,6 +46,7 @@ struct BaDev {
   const int* cam_off;        // [Cp+1]
   const int* cam_edge;       // [..]
   const int* cam_pt;         // [..] landmark of every camera-list slot (ed_pt[cam_edge[s]])
+  double* cam_oi;            // [..][4] (round 4) observation and information of every camera-list slot (obs x, obs y, info, 0): what ba_linearize_cams reads contiguously instead of three gathers by edge index; refreshed by ccm_ba_set_edge_levels
   // linear system pieces
   double* W;                 // [Eloc*18]  Hpl block of each edge (pose rows x landmark cols)
   double* Hll;               // [Lloc*6]   symmetric 3x3

@@ -39,6 +39,9 @@ extern "C" int ccm_ba_debug_array(ccm_ba* ba, const char* name, void* out, size_
   if (n == "cam_edge" || n == "cam_pt") {
     if (int rc = host_int(d.cam_off, Cp, &tail)) return rc;
     src = n == "cam_edge" ? d.cam_edge : d.cam_pt; sz = (size_t)tail * sizeof(int);
+  } else if (n == "cam_oi") {
+    if (int rc = host_int(d.cam_off, Cp, &tail)) return rc;
+    src = d.cam_oi; sz = 4 * (size_t)tail * sizeof(double);
   } else if (n == "pers_ucol") {
     if (ba->d_pers_uoff) { if (int rc = host_int(ba->d_pers_uoff, 2 * n_cl, &tail)) return rc; }
     src = ba->d_pers_ucol; sz = (size_t)tail * sizeof(int);
@@ -58,7 +61,7 @@ extern "C" int ccm_ba_debug_array(ccm_ba* ba, const char* name, void* out, size_
     *bytes = sizeof(v);
     if (out) { if (cap_bytes < sizeof(v)) return CCM_E_ARG; std::memcpy(out, v, sizeof(v)); }
     return CCM_OK;
-  } else if (!src && sz == 0 && n != "chunk_off" && n.rfind("pers_", 0) != 0 && n != "row_unit_off" && n != "blk_unit0") {
+  } else if (!src && sz == 0 && n != "chunk_off" && n != "cam_oi" && n.rfind("pers_", 0) != 0 && n != "row_unit_off" && n != "blk_unit0") {
     bool known = false;
     for (const char* k : {"slot_cam", "slot_pt", "loc_edge_orig", "pt_off", "ed_cam", "ed_cslot", "ed_pt", "obs", "info", "cam_off", "rowblk_off", "row_off", "row_col", "row_blk",
                           "inst_off", "inst_a", "inst_c", "inst_al", "blk_i", "blk_j"}) known = known || n == k;

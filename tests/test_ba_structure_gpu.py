@@ -73,6 +73,7 @@ def host_structure(prob, rank=0, nranks=1, agg=32):
     free = np.flatnonzero(S["ed_cslot"] >= 0)
     cam_edge = free[np.argsort(S["ed_cslot"][free], kind="stable")]
     S["cam_edge"] = cam_edge; S["cam_pt"] = S["ed_pt"][cam_edge]
+    S["cam_oi"] = np.column_stack([S["obs"].reshape(-1, 2)[cam_edge], S["info"][cam_edge], np.zeros(cam_edge.size)]).reshape(-1)   # camera-major (obs x, obs y, info, 0)
     S["cam_off"] = np.concatenate([[0], np.cumsum(np.bincount(S["ed_cslot"][free], minlength=Cp))])
     S["max_cam_edges"] = int(np.diff(S["cam_off"]).max()) if Cp else 0
 
@@ -187,6 +188,7 @@ def check(ctx, prob, rank=0, nranks=1):
         assert np.array_equal(dev_array(h, nm, np.int32), np.asarray(S[nm], np.int64)), nm
     assert np.array_equal(dev_array(h, "row_blk", np.uint32), S["row_blk"])
     assert np.array_equal(dev_array(h, "obs", np.float64), S["obs"]) and np.array_equal(dev_array(h, "info", np.float64), S["info"])
+    assert np.array_equal(dev_array(h, "cam_oi", np.float64), S["cam_oi"])
     if Cp > KCLU:
         for nm in ("pers_coff", "pers_cij"):
             assert np.array_equal(dev_array(h, nm, np.int32), S[nm]), nm
