@@ -87,6 +87,35 @@ def test_local_ba_two_stage(ctx, oracle_lib, one_handle):
     assert (erase != oerase).sum() <= 2
 
 
+def test_edge_levels_are_reversible_on_one_handle(ctx):
+    """ccm_ba_set_edge_levels is a pure function of (levels, Huber delta) and of the information stored at create time (round-3 advisor finding: it used to zero
+    the informations in place, so a handle that was re-run with push / pop state silently repeated stage 1 on the reduced edge set without its robust kernel):
+    stage 1, stage 2 with outlier edges at level 1, state popped, levels back to 0 with the stage-1 kernel — the second stage-1 run must leave exactly the bits
+    of the first.  Edges with information 0 contribute exact zeros whatever their residual is."""
+    prob = dict(synth.make_ba_config("lba_c2"))
+    delta = float(np.float32(np.sqrt(np.float32(5.991))))
+    prob["huber_delta"] = delta
+    h = optimizer.BAHandle(ctx, prob)
+    h.push_state()
+    st1 = h.run(5)
+    cam1, pts1, chi1, dpos1 = h.download()
+    level = np.zeros(prob["n_edge"], np.uint8)
+    level[(chi1 > 5.991) | (dpos1 == 0)] = 1
+    assert 100 < level.sum() < prob["n_edge"] // 2
+    h.set_edge_levels(level, 0.0)
+    st2 = h.run(10)
+    cam2, _, chi2, _ = h.download(chi1)
+    assert st2.iters_done == 10 and np.isfinite(st2.chi2_final) and not np.array_equal(cam1, cam2)
+    assert np.array_equal(chi2[level == 1], chi1[level == 1])            # a level-1 edge keeps the chi2 of the pass before (g2o leaves its _error alone)
+    h.pop_state()
+    h.set_edge_levels(np.zeros(prob["n_edge"], np.uint8), delta)          # every edge back in, the robust kernel back on
+    st1b = h.run(5)
+    cam1b, pts1b, chi1b, dpos1b = h.download()
+    h.close()
+    assert (st1b.iters_done, st1b.lm_trials, st1b.pcg_iters) == (st1.iters_done, st1.lm_trials, st1.pcg_iters) and st1b.chi2_final == st1.chi2_final
+    assert np.array_equal(cam1b, cam1) and np.array_equal(pts1b, pts1) and np.array_equal(chi1b, chi1) and np.array_equal(dpos1b, dpos1)
+
+
 def test_stop_flag_before_start_returns_immediately(ctx):
     import ctypes as C
     from ccm_slam_amd._lib import BAOptions, BAStats, lib, check
