@@ -135,8 +135,11 @@ int  ccm_orb_extract(ccm_orb* orb, const uint8_t* img, int w, int h, int stride,
                      ccm_keypoint* kps, uint8_t* desc, int cap, int* n_out,
                      uint8_t* const* pyramid_out);
 int  ccm_orb_level_size(const ccm_orb* orb, int w, int h, int level, int* lw, int* lh);
-/* upper bound of keypoints one frame can return: DistributeOctTree stops at >= N nodes per level and
- * may overshoot by up to 3 (ORBextractor.cpp:837,898), so the total can exceed nfeatures.          */
+/* upper bound of keypoints one frame can return: nfeatures + 67 per level.  DistributeOctTree stops at >= N nodes per level and may overshoot by up to 3
+ * (ORBextractor.cpp:837,898), but its FIRST pass splits every root before any count is checked (:759-843): a level returns up to 4 nIni nodes whatever N is
+ * (7 features on a 752 x 480 frame: 64 keypoints); nIni = round(W / H) <= 16 is assumed, wider levels are truncated at this capacity.
+ * A pyramid level smaller than one 30-px cell contributes no keypoint (its image is still produced); an image whose level is more than twice as high as wide,
+ * or empty, is rejected with CCM_E_ARG (the reference divides by zero / throws there). */
 int  ccm_orb_max_keypoints(const ccm_orb* orb);
 /* host-only (no GPU): DistributeOctTree (ORBextractor.cpp:707-931) on candidates given relative to
  * (minX,minY); sel_out receives the indices of the kept candidates in the reference's output order. */
@@ -272,8 +275,10 @@ int  ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt, const volatile unsigned c
 int  ccm_ba_download(ccm_ba* ba, double* cam_qt, double* pt_xyz, double* chi2_per_edge);
 /* Second stage of Optimizer::LocalBundleAdjustmentClient on the SAME handle (Optimizer.cpp:545-566: outlier edges -> setLevel(1), robust kernel off,
  * optimize(10)): edges with e_level[e] != 0 ([n_edge], the caller's numbering) leave the optimisation, the Huber delta is replaced (<= 0: none), the
- * estimate stays; the next ccm_ba_run is the reference's initializeOptimization(0) + optimize(n) on the reduced edge set.  Edges inactive at
- * ccm_ba_create cannot be re-activated.  A deactivated edge keeps reporting the chi2 of the last pass it took part in. */
+ * estimate stays; the next ccm_ba_run is the reference's initializeOptimization(0) + optimize(n) on the reduced edge set.  The call is a pure function of
+ * (e_level, huber_delta) and of the informations given to ccm_ba_create: an edge whose level goes back to 0 takes part again with its original information
+ * (a handle re-run after ccm_ba_pop_state passes its first-stage levels and delta again).  Only edges inactive at ccm_ba_create are not part of the handle
+ * and cannot come back.  A deactivated edge contributes exact zeros whatever its residual is and keeps reporting the chi2 of the last pass it took part in. */
 int  ccm_ba_set_edge_levels(ccm_ba* ba, const uint8_t* e_level, double huber_delta);
 /* per-iteration record of the last ccm_ba_run: robust chi2 after the iteration, lambda after it, LM trials it took
  * (what g2o prints with setVerbose(true), sparse_optimizer.cpp:400-410); fills min(*n_iters, cap) entries */
