@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts(BaDev d, int cur) {
 // 6x3 W block (written as 144 contiguous bytes per thread, contiguous across the workgroup), parks the 9 landmark-side
 // contributions in LDS, and one thread per landmark adds them in observation order: the same additions in the same
 // order as the loop above, hence bit-identical Hll / b_l.
-__global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
+__global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur, double lambda_fused /* >= 0: also form D^-1 and D^-1 b_l for this lambda (ba_dinv folded in: one launch less per LM iteration) */) {
   __shared__ double hb[kTPB][9];
   const int l0 = d.chunk_off[blockIdx.x], l1 = d.chunk_off[blockIdx.x + 1];
   const int e0 = d.pt_off[l0], ne = d.pt_off[l1] - e0, nl = l1 - l0;
@@ -207,6 +207,18 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur) {
 #pragma unroll
     for (int i = 0; i < 6; i++) d.Hll[6 * (size_t)l + i] = H[i];
     d.bl[3 * (size_t)l] = b[0]; d.bl[3 * (size_t)l + 1] = b[1]; d.bl[3 * (size_t)l + 2] = b[2];
+    if (lambda_fused >= 0.0) {   // exactly ba_dinv's arithmetic on the values just stored
+      double a[6], r[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) a[i] = H[i];
+      a[0] += lambda_fused; a[3] += lambda_fused; a[5] += lambda_fused;
+      ba_sym3_inv(a, r);
+#pragma unroll
+      for (int i = 0; i < 6; i++) d.Dinv[6 * (size_t)l + i] = r[i];
+      d.dl[3 * (size_t)l] = r[0] * b[0] + r[1] * b[1] + r[2] * b[2];
+      d.dl[3 * (size_t)l + 1] = r[1] * b[0] + r[3] * b[1] + r[4] * b[2];
+      d.dl[3 * (size_t)l + 2] = r[2] * b[0] + r[4] * b[1] + r[5] * b[2];
+    }
   }
 }
 
@@ -2881,13 +2893,18 @@ int eval_chi2(ccm_ba* ba, double* chi) {
   return CCM_OK;
 }
 
-int build_system(ccm_ba* ba) {
+// lambda_next >= 0: the damping of the FIRST trial on this linearisation is already known (every LM iteration but the first): the landmark-side kernel also forms
+// D^-1 and D^-1 b_l for it and lm_trial skips its ba_dinv launch for that lambda
+int build_system(ccm_ba* ba, double lambda_next = -1.0) {
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
+  ba->dinv_done_lambda = -1.0;
   if (d.Lloc) {
     ccm_prof_scope ps(ctx, CCM_K_BA_LINEARIZE);
-    if (d.chunk_off) hipLaunchKernelGGL(ba_linearize_pts_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, ba->cur);
-    else hipLaunchKernelGGL(ba_linearize_pts, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur);
+    if (d.chunk_off) {
+      hipLaunchKernelGGL(ba_linearize_pts_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, ba->cur, lambda_next);
+      if (lambda_next >= 0.0) ba->dinv_done_lambda = lambda_next;
+    } else hipLaunchKernelGGL(ba_linearize_pts, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur);
   }
   if (d.Cp) {
     ccm_prof_scope ps(ctx, CCM_K_BA_CAM);
@@ -2968,10 +2985,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   const int cur = ba->cur;
-  if (d.Lloc) {
+  if (d.Lloc && ba->dinv_done_lambda != lambda) {   // (the linearisation already formed D^-1 for this lambda: build_system)
     ccm_prof_scope ps(ctx, CCM_K_BA_DINV);
     hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
   }
+  ba->dinv_done_lambda = -1.0;   // the next trial on this linearisation has another lambda
   *ok = true;
   *pcg_iters = 0;
   bool small_path = false, pers_trial = false, pers_launch_failed = false;
@@ -3320,7 +3338,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
     if (!have_chi) { if ((rc = eval_chi2(ba, &currentChi))) return rc; have_chi = true; st.chi2_initial = currentChi; }
     if (ba->nranks > 1 && ba->stop_requested()) { reason = 1; break; }
     const double iniChi = currentChi;
-    if ((rc = build_system(ba))) return rc;
+    if ((rc = build_system(ba, it > 0 ? lambda : -1.0))) return rc;
     ba->lin_id++;
     if (it == 0) {
       if (opt.lambda_init > 0) lambda = opt.lambda_init;
