@@ -1865,7 +1865,7 @@ __device__ __forceinline__ void pers_factor_cluster(double* A, double* Li, int* 
 static inline size_t dense2_lds_bytes() { return (size_t)(2 * kCluN * kCluN + 5 * kCluN + 8 * kCluN) * sizeof(double) + 16 + 14 * sizeof(long long) + 64 * sizeof(int); }
 
 __global__ __launch_bounds__(kPersTPB) void ba_solve_dense2(BaDev d, double lambda, const int* coff, const int* cij, const uint32_t* cblk, double* gTt /* [96][96] T transposed */,
-                                                               long long* dbg /* nullable: [9] phase clocks (10 ns ticks) + launches */) {
+                                                               long long* dbg /* nullable: [9] phase clocks (10 ns ticks) + launches */, int cur, int add_lambda_term) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   typedef double v4d __attribute__((ext_vector_type(4)));
   constexpr int N = kCluN;
@@ -2014,6 +2014,27 @@ __global__ __launch_bounds__(kPersTPB) void ba_solve_dense2(BaDev d, double lamb
       for (int q = 1; q < 8; q++) r += zpart[q * N + t];
       d.x[t] = t1[t] - r;
       if (t < m2) d.x[N + t] = x2[t];
+    }
+  }
+  // (round 4) the camera update of the trial rides in this launch: ba_update_cams' arithmetic for the window's <= 32 free cameras (one launch less per LM trial
+  // of a local BA; the window has one workgroup's worth of cameras, so its partial of the gain denominator is the whole of it)
+  __syncthreads();
+  {
+    double sc = 0;
+    if (t < Cp) {
+      const int c = d.slot_cam[t];
+      double u[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) u[q] = d.x[6 * (size_t)t + q];
+      const BaPose T = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+      const BaPose Tn = ba_oplus(u, T);
+      ba_store_pose(d.cam[cur ^ 1] + 7 * (size_t)c, Tn);
+#pragma unroll
+      for (int q = 0; q < 6; q++) sc += u[q] * ((add_lambda_term ? lambda * u[q] : 0.0) + d.bp[6 * (size_t)t + q]);
+    }
+    if (t < kWave) {   // Cp <= 32: all terms sit in wave 0; ba_update_cams' block_sum adds the four wave sums of its 256 threads, the other three being zero
+      const double s = wave_sum(sc);
+      if (t == 0) d.part_cam[0] = ((s + 0.0) + 0.0) + 0.0;
     }
   }
   D2_TICK(7)
@@ -2992,7 +3013,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   ba->dinv_done_lambda = -1.0;   // the next trial on this linearisation has another lambda
   *ok = true;
   *pcg_iters = 0;
-  bool small_path = false, pers_trial = false, pers_launch_failed = false;
+  bool small_path = false, pers_trial = false, pers_launch_failed = false, cams_updated = false;
   int small_flags[4] = {0, 0, 0, 0};
   if (d.Cp) {
     RC(launch_schur(ba));
@@ -3010,9 +3031,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
         hipLaunchKernelGGL(ba_solve_dense2, dim3(1), dim3(kPersTPB), dense2_lds_bytes(), ctx->stream, d, lambda, (const int*)ba->d_pers_coff, (const int*)ba->d_pers_cij,
                            (const uint32_t*)ba->d_pers_cblk, ba->d_dense_T,
-                           getenv("CCM_BA_DENSE2_DBG") ? (long long*)(ba->d_dense_T + kCluN * kCluN) : (long long*)nullptr);
+                           getenv("CCM_BA_DENSE2_DBG") ? (long long*)(ba->d_dense_T + kCluN * kCluN) : (long long*)nullptr, cur, ba->rank == 0 ? 1 : 0);
       }
       small_path = true;
+      cams_updated = true;   // (the solve's launch also applied the step to the cameras)
     } else if (d.Cp <= kSmallMaxCp) {
       // one launch, no host round trip: the flags are read back after the trial kernels are queued
       size_t lds = (size_t)(5 * 6 * d.Cp + 36 * d.Cp + 18) * sizeof(double);
@@ -3152,10 +3174,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     if (flags[2]) *ok = false;   // not SPD / NaN: linear solver failure (levenberg.cpp:126-127)
   }
-  if (d.Cp) {
+  if (d.Cp && !cams_updated) {
     ccm_prof_scope ps(ctx, CCM_K_BA_UPDATE);
     hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0, ba->pers_grid ? ba->d_pers_bar : (unsigned*)nullptr);
-  } else hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
+  } else if (!d.Cp) hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_BACKSUB);
     if (d.chunk_off) hipLaunchKernelGGL(ba_backsub_chi2_e, dim3(d.n_chunk), dim3(kTPB), 0, ctx->stream, d, cur, lambda, 0);
