@@ -16,6 +16,7 @@ struct ccm_prof_slot {
   double total_ms = 0.0;
 };
 
+constexpr int kCtxTickets = 4096;
 struct ccm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -35,6 +36,7 @@ struct ccm_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_io = nullptr; size_t d_io_bytes = 0;   // staging for the host-pointer entry points
   void* h_pin = nullptr; size_t h_pin_bytes = 0; // pinned host staging (one H2D / D2H per small call)
+  int* d_tickets = nullptr;                      // [kCtxTickets] arrival counters of "the last workgroup finishes the job" kernels (zero between launches: the last arrival resets its counter)
   // size-bucketed cache of device blocks released by BA handles: a local BA builds a fresh problem for every keyframe, and
   // ~45 hipMalloc + hipFree per problem cost more than the host-side structure build itself
   std::multimap<size_t, void*> pool_free; size_t pool_bytes = 0;

@@ -68,6 +68,7 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  if (ctx->d_tickets) hipFree(ctx->d_tickets);
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   hipStreamDestroy(ctx->stream);
   delete ctx;
