@@ -418,6 +418,43 @@ def test_camera_counts_around_the_cluster_size(ctx, oracle_lib, kfs):
     assert np.abs(pts - opts).max() <= 1e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_problem_shapes_against_the_oracle(ctx, oracle_lib, seed):
+    """Seeded random shapes between the named configurations: 1 - 3 agents, 10 - 160 keyframes each, 1 - 40 fixed cameras at the front or at every agent's tail,
+    0 - 10 % of the edges at level 1, robust kernel on or off, short and long tracks — 7 to 400 free cameras, i.e. every solver path below the large-map one (one-workgroup PCG, exact
+    two-cluster solve, persistent PCG with and without the coarse level) with fixed cameras in the way of the 16-camera clusters."""
+    rng = np.random.default_rng(9000 + seed)
+    kfs = [10, 22, 38, 54, 90, 120, 150, 160][seed]
+    agents = 1 if kfs < 50 else int(rng.integers(1, 4)); fixed = int(rng.integers(1, 41)); mode = "tail" if rng.random() < 0.5 else "first"
+    fixed = min(fixed, kfs // 3)
+    prob = synth.make_ba_problem(n_agents=agents, kfs_per_agent=kfs, n_points=int(rng.integers(30, 80)) * kfs * agents // 2, seed=9100 + seed, n_fixed=fixed, fixed_mode=mode,
+                                 mean_track=float(rng.choice([3.0, 6.0, 12.0])))
+    prob["e_level"] = (rng.random(prob["n_edge"]) < rng.choice([0.0, 0.03, 0.10])).astype(np.uint8)
+    if rng.random() < 0.3:
+        prob["huber_delta"] = 0.0
+    _check(prob, 4, ctx, oracle_lib)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kfs", [2041, 2049, 2050, 2066])
+def test_camera_counts_around_the_persistent_solvers_limit(ctx, oracle_lib, kfs):
+    """2040 / 2048 free cameras (255 / 256 units of the persistent solver: the last sizes whose workgroups are all co-resident on the 256 CUs) and 2049 / 2065 (the
+    first sizes on the multi-kernel path, the second with a cluster of ONE camera at the end): the same LM iterations and trials as the oracle, the stated tolerances."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=kfs, n_points=40 * kfs, seed=700 + kfs)
+    h = optimizer.BAHandle(ctx, prob)
+    assert h.counts()["free_cams"] == kfs - 1
+    st = h.run(3)
+    cam, pts, _, _ = h.download()
+    h.close()
+    ocam, opts, _, _, ost = oracle_lib.ba_optimize(prob, 3)
+    assert st.iters_done == ost.iters_done and st.lm_trials == ost.lm_trials
+    assert abs(st.chi2_final - ost.chi2_final) <= TOL_CHI * ost.chi2_final
+    dt, dr = synth.pose_errors(cam, ocam)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts - opts).max() <= 1e-4
+
+
 # ---- full-length parity on the BASELINE global-BA configurations -------------------------------------------------------------
 # The fixtures (tests/golden/gba_*_full.npz, generator tests/golden/make_golden.py gba_c4 gba_c3 gba_c5) hold the ORACLE's complete
 # optimize(20) call: per-iteration chi2 / lambda / trial counts, stop reason and final estimate.  The oracle needs 35 s - 10 min per
