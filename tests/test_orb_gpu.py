@@ -169,3 +169,32 @@ def test_sweep_images_also_agree_through_the_batch_entry(ctx, oracle_lib):
         for f in kps.dtype.names:
             assert np.array_equal(kps[f], res[k][0][f])
     ex.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries_and_parameters(ctx, oracle_lib, seed):
+    """Seeded random extractor set-ups: image sizes 70 ... 1000 x 70 ... 700 (never more than twice as high as wide on any level that holds a cell: the reference divides by
+    nIni = 0 there and the product rejects the frame), 1 - 10 levels, scale factors 1.1 - 1.7, 20 - 3000 features, FAST thresholds 5 - 40 — bit-exact against the oracle."""
+    rng = np.random.default_rng(31000 + seed)
+    w = int(rng.integers(70, 1001)); h = int(rng.integers(70, min(701, 2 * w - 40)))
+    nlevels = int(rng.integers(1, 11)); scale = float(np.float32(rng.uniform(1.1, 1.7)))
+    nf = int(rng.choice([20, 100, 500, 1000, 3000])); ini = int(rng.integers(8, 41)); mn = int(rng.integers(5, ini + 1))
+    img = synth.gen_image(32000 + seed, seed, w, h)
+    if rng.random() < 0.25:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    # a level that holds a cell but is more than twice as high as wide: DistributeOctTree computes nIni = round(W / H) = 0 and divides by it (ORBextractor.cpp:711-716);
+    # the product refuses such a frame, the oracle (like the reference) must not be run on it
+    ex = orb.ORBextractor(ctx, nf, scale, nlevels, ini, mn)
+    tall = False
+    for l in range(nlevels):
+        lw, lh = ex.level_size(w, h, l)
+        W, H = lw - 32, lh - 32
+        tall = tall or (W >= 30 and H >= 30 and int(np.floor(np.float32(W) / np.float32(H) + np.float32(0.5))) < 1)
+    if tall:
+        from ccm_slam_amd._lib import CcmError
+        with pytest.raises(CcmError, match="twice as high as wide"):
+            ex(img)
+        ex.close()
+        return
+    ex.close()
+    _compare(ctx, oracle_lib, img, nf, nlevels=nlevels, scale_factor=scale, ini_th_fast=ini, min_th_fast=mn)
