@@ -637,37 +637,41 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   OCT_T(6);
   if (a.dbg && l == 0 && t == 0) for (int q = 0; q < 8; q++) a.dbg[q] += tq[q];
 #undef OCT_T
-  __shared__ int last;
-  __threadfence();
-  __syncthreads();
+  // (round 4) no concatenation here: the level leaves its count and its staged keypoints, the orientation + descriptor kernel behind it maps its waves to
+  // (level, entry) through the eight counts — the device-scope fences, the arrival counter and the last workgroup's copy are gone from the frame's longest kernel
   if (t == 0) {
     a.counts[l] = Ls;
     if (overflow) atomicExch(g_over, 1);
-    __threadfence();
-    last = atomicAdd(a.counts + a.nlevels, 1) == a.nlevels - 1;
   }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  int off = 0;
-  for (int q = 0; q < a.nlevels; q++) {
-    const int c = __hip_atomic_load(a.counts + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int e = t; e < c && off + e < a.kp_cap; e += TPB) a.kin[off + e] = a.stage[(size_t)q * a.stage_stride + e];
-    off += c;
-  }
-  if (t == 0) { *a.n_out = off < a.kp_cap ? off : a.kp_cap; a.counts[a.nlevels] = 0; }
 }
 
 
+// Keypoints come either as one list (`kin`, n entries: host octree) or STAGED per level by the device octree (`stage` [level][stage_stride] with `lcounts`: output
+// position i belongs to the level whose running count passes it — the concatenation in level order that ComputeKeyPointsOctTree's loop over levels produces); in the
+// staged form thread 0 of workgroup 0 also publishes the frame's count (`n_dev`[0], and `count_out` of the batch API), clamped to the caller's capacity.
 __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                              const KpIn* __restrict__ kin, int n, const int* __restrict__ n_dev /* nullable: count on the device */,
-                                                              ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc, int* __restrict__ count_out /* nullable */) {
+                                                              const KpIn* __restrict__ kin, int n, int* __restrict__ n_dev /* staged form: receives the count */,
+                                                              ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc, int* __restrict__ count_out /* nullable */,
+                                                              const KpIn* __restrict__ stage, int stage_stride, const int* __restrict__ lcounts, int kp_cap) {
   const int lane = threadIdx.x & (kWave - 1);
   const int i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
-  if (n_dev) n = *n_dev;
-  if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;   // batch API: the frame's keypoint count lands next to its results, no copy launch
-  if (i >= n) return;
-  const KpIn kp = kin[i];
+  KpIn kp;
+  if (stage) {
+    int off = 0, lv = -1, e = 0;
+    for (int q = 0; q < d.nlevels; q++) {      // uniform: scalar loads of the counts
+      const int c = lcounts[q];
+      if (lv < 0 && i < off + c) { lv = q; e = i - off; }
+      off += c;
+    }
+    n = off < kp_cap ? off : kp_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *n_dev = n; if (count_out) *count_out = n; }
+    if (i >= n) return;
+    kp = stage[(size_t)lv * stage_stride + e];
+  } else {
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    if (i >= n) return;
+    kp = kin[i];
+  }
   const LevelInfo L = d.lv[kp.level];
   // IC_Angle (:68-95): integer moments over the radius-15 disc of the UNBLURRED level
   const uint8_t* center = pyr + L.off + (size_t)kp.y * L.stride + kp.x;
@@ -1283,7 +1287,8 @@ static int orb_phase2(ccm_orb* o, int n) {
   CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[o->cur].d_kin, o->B[o->cur].h_kin, (size_t)n * sizeof(KpIn), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (const int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc, (int*)nullptr);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc, (int*)nullptr,
+                       (const KpIn*)nullptr, 0, (const int*)nullptr, o->kp_cap);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1315,7 +1320,8 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr,
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF, o->st);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, (const int*)b.d_n, kout ? kout : b.d_kout, dout ? dout : b.d_desc, count_out);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, b.d_n, kout ? kout : b.d_kout, dout ? dout : b.d_desc, count_out,
+                       (const KpIn*)b.d_oct_stage, o->oct_stride, (const int*)b.d_oct_counts, a.kp_cap);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1568,8 +1574,9 @@ int ccm_internal::orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int
   if (rc == CCM_OK) {
     if (lcap <= 1024) hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(1), dim3(512), lds, ctx->stream, d, a);
     else hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, a);
-    hipMemcpyAsync(out.data(), d_kin, out.size() * sizeof(KpIn), hipMemcpyDeviceToHost, ctx->stream);
-    hipMemcpyAsync(hn, d_nout, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(out.data(), d_stage, out.size() * sizeof(KpIn), hipMemcpyDeviceToHost, ctx->stream);   // the one level's staged list IS the output
+    hipMemcpyAsync(hn, d_nout, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream);                              // [1] = overflow flag
+    hipMemcpyAsync(hn, d_counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);                           // [0] = the level's count
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, "ccm_orb_debug_octree_dev: kernel");
   }
   hipFree(d_cand); hipFree(d_counts); hipFree(d_nout); hipFree(d_stage); hipFree(d_kin);
