@@ -45,7 +45,9 @@ constexpr int kCellCap = 900;      // >= ceil(60/2)^2: strict 3x3 NMS keeps no t
 constexpr int kCandFirstCopy = 16384;
 
 struct LevelInfo {
-  int w, h, stride, off;           // off: pixel offset of the level in the pyramid buffer
+  int w, h, stride, off;           // off: pixel offset of the level in the pyramid buffer (and in the score / blur buffers that mirror it)
+  long long poff; int pstride;     // where the level's PIXELS are read, relative to the pyramid buffer: (off, stride), except level 0 of a batch frame, which is read in
+                                   // place from the caller's image (round 4: no device-to-device copy of every frame into the pyramid buffer)
   int nCols, nRows, wCell, hCell, cellBase;
   int rowBase;                     // first global row index (sum of h of previous levels)
   int tabOff;                      // offset into the resize tables
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uin
   const int y = grow - L.rowBase;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x < kEdge || x >= L.w - kEdge || y < kEdge || y >= L.h - kEdge) return;
-  score[L.off + (size_t)y * L.stride + x] = (uint8_t)orb_fast_score_at(pyr + L.off + (size_t)y * L.stride + x, L.stride);
+  score[L.off + (size_t)y * L.stride + x] = (uint8_t)orb_fast_score_at(pyr + L.poff + (size_t)y * L.pstride + x, L.pstride);
 }
 
 // ---- per-cell threshold + NMS + fallback + ordered compaction ------------------------------------
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t*
     const int pw = iw + 6, ps = (pw + 3) & ~3;
     for (int t = threadIdx.x; t < (ih + 6) * pw; t += 256) {
       const int ty = t / pw, tx = t % pw;
-      pix[ty * ps + tx] = pyr[L.off + (size_t)(y0 - 3 + ty) * L.stride + (x0 - 3 + tx)];
+      pix[ty * ps + tx] = pyr[L.poff + (long long)(y0 - 3 + ty) * L.pstride + (x0 - 3 + tx)];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < npx; t += 256) {
@@ -262,12 +264,12 @@ constexpr int kBlurLds = (kBlurInBytes + kBlurHsBytes + 15) & ~15;   // LDS of o
 __device__ __forceinline__ void orb_blur_tile(const OrbDev& d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, bool live, int l, int bx, int by, int tid,
                                               uint8_t* in, uint16_t* hs) {
   const LevelInfo L = d.lv[live ? l : 0];
-  const uint8_t* src = pyr + L.off;
+  const uint8_t* src = pyr + L.poff;
   if (live)
     for (int t = tid; t < (kBlurTH + 6) * (kBlurTW + 6); t += 256) {
       const int ty = t / (kBlurTW + 6), tx = t % (kBlurTW + 6);
       const int gx = reflect101(bx + tx - 3, L.w), gy = reflect101(by + ty - 3, L.h);
-      in[t] = src[(size_t)gy * L.stride + gx];
+      in[t] = src[(size_t)gy * L.pstride + gx];
     }
   __syncthreads();
   if (live)
@@ -674,14 +676,14 @@ __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const ui
   }
   const LevelInfo L = d.lv[kp.level];
   // IC_Angle (:68-95): integer moments over the radius-15 disc of the UNBLURRED level
-  const uint8_t* center = pyr + L.off + (size_t)kp.y * L.stride + kp.x;
+  const uint8_t* center = pyr + L.poff + (long long)kp.y * L.pstride + kp.x;
   int m10 = 0, m01 = 0;
   {
     const int u = lane - kHalfPatch;   // lanes 0..30 <-> u = -15..15
     for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
       const int av = v < 0 ? -v : v;
       if (lane <= 2 * kHalfPatch && (u <= d.umax[av] && u >= -d.umax[av])) {
-        const int val = center[v * L.stride + u];
+        const int val = center[v * L.pstride + u];
         m10 += u * val; m01 += v * val;
       }
     }
@@ -1068,6 +1070,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     if (L.w > 4000 || L.h > 4000) return ccm_set_error(ctx, CCM_E_ARG, "orb: image too large (packed candidate coordinates are 12 bit)");
     L.stride = (L.w + 63) & ~63;
     L.off = off; off += L.stride * L.h;
+    L.poff = L.off; L.pstride = L.stride;
     L.rowBase = rowBase; rowBase += L.h;
     L.scale = o->sf[l];
     maxW = std::max(maxW, L.w);
@@ -1164,7 +1167,7 @@ static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false
   for (int l = 1; l < o->nlevels; l++) {
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
-    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.off, P.w, P.h, P.stride,
+    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.poff, P.w, P.h, P.pstride,
                        o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
@@ -1428,15 +1431,19 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
     if (!o->ev_a) CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_a, hipEventDisableTiming));
     CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_a, ctx->stream));            // whatever produced the images on the context's stream comes first
     for (int k = 1; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->bstream[k], o->ev_a, 0));
-    const int nc = std::min(cap, o->kp_cap);
-    (void)nc;
+    static const bool inplace = !(getenv("CCM_ORB_BATCH_COPY") && atoi(getenv("CCM_ORB_BATCH_COPY")));
     for (int f = 0; f < n_frames; f++) {
       o->cur = f % kOrbSets;
       o->st = o->cur ? o->bstream[o->cur] : ctx->stream;
       ccm_orb::Bufs& b = o->B[o->cur];
-      CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
-      if ((rc = orb_phase1(o, false, true))) { o->cur = 0; o->st = ctx->stream; return rc; }
-      if ((rc = orb_phase2_dev(o, cap, d_kps + (size_t)f * cap, d_desc + (size_t)f * cap * 32, d_counts + f))) { o->cur = 0; o->st = ctx->stream; return rc; }
+      // level 0 is read IN PLACE from the caller's frame (no device-to-device copy into the pyramid buffer: 3 us of copy and ~10 us of idle stream per frame);
+      // the kernels take the level table by value, so the per-frame offset travels with each launch
+      if (inplace) { o->dev.lv[0].poff = (long long)((d_imgs + (size_t)f * w * h) - b.d_pyr); o->dev.lv[0].pstride = w; }
+      else CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
+      rc = orb_phase1(o, false, true);
+      if (!rc) rc = orb_phase2_dev(o, cap, d_kps + (size_t)f * cap, d_desc + (size_t)f * cap * 32, d_counts + f);
+      o->dev.lv[0].poff = L0.off; o->dev.lv[0].pstride = L0.stride;
+      if (rc) { o->cur = 0; o->st = ctx->stream; return rc; }
     }
     o->cur = 0; o->st = ctx->stream;
     // the overflow flags are sticky over the batch
