@@ -203,7 +203,7 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
     ctx.prof_enable(-1); ctx.prof_reset()
     bat.run()
     ctx.sync()
-    orb_classes = (("PYR_RESIZE", "orb_resize_kernel x7"), ("FAST_SCORE", "orb_fast_score_kernel"), ("FAST_NMS", "orb_cells_kernel + orb_compact_kernel + orb_octree_kernel"),
+    orb_classes = (("PYR_RESIZE", "orb_pyramid_kernel (all levels in one launch)"), ("FAST_SCORE", "orb_fast_score_kernel"), ("FAST_NMS", "orb_cells_kernel + orb_compact_kernel + orb_octree_kernel"),
                    ("BLUR", "orb_blur_kernel"), ("BRIEF", "orb_orient_desc_kernel"))
     orb_kernels = []
     for cls, kname in orb_classes:

@@ -82,6 +82,126 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const uint8_t* __restri
   dst[(size_t)dy * dstride + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// ---- the whole pyramid in ONE launch (round 4) ------------------------------------------------------------------------
+// Seven dependent launches of orb_resize_kernel are ~42 us of a single frame's ~130 us chain (3.9 us + a 2 us gap each, 40 K pixels or fewer
+// per launch after level 2).  Here a workgroup owns a tile of level 1 and, recursively, the pixels of every later level whose top-left source
+// pixel it owns (the offset tables are monotone, so that is a rectangle per level and the rectangles of all workgroups tile the level).  It
+// stages its level-0 source rectangle and the table entries of all its levels in LDS once, then walks down the levels LDS -> LDS, writing the
+// owned rectangle of each level to the pyramid buffer.  A level's computed rectangle is its owned one plus the columns / rows to the right /
+// below that the NEXT level's owned + halo pixels read (1, 2.2, 3.6 ... ~10 pixels at level 1 for 8 levels at 1.2): the halo is recomputed
+// instead of exchanged.  The per-pixel arithmetic is orb_resize_kernel's.
+// Tile tables (host, orb_prepare): per (tile column, level): x0 (first owned column; level 0: first source column), x1 (end of the owned
+// columns), cx1 (end of the computed columns), start of the level's entries in the staged tables; the same per (tile row, level).
+constexpr int kPyrTW = 32, kPyrTH = 32, kPyrTPB = 1024;
+
+struct PyrArgs {
+  const int4* tcol; const int4* trow;   // [tile column / row][level] {x0, x1, cx1, start of the level's entries among the tile column's / row's}
+  const uint2* ent;                     // table entries: a block of ent_sx entries per tile column, then (from ent_y0) a block of ent_sy entries per tile row
+  int ntx, buf_bytes, ent_sx, ent_sy, ent_y0;
+  int ex0, ey0;                         // extent of the level-0 rectangle every workgroup stages (the largest any tile needs; clipped to the image)
+  double scale_x, scale_y;              // level 0 / level 1 size ratios: a tile's first source column / row is computed, not loaded (see the kernel)
+  unsigned long long* dbg;              // CCM_ORB_OCT_DBG: phase clocks of workgroup 0, else nullptr
+};
+
+// barrier that orders LDS traffic only: __syncthreads() also waits for the level's global stores (~0.8 us per level, measured)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t* __restrict__ pyr, PyrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t plds[];
+  __shared__ int4 s_c[kMaxLevels], s_r[kMaxLevels];
+  const int t = threadIdx.x;
+  const bool timing = a.dbg && blockIdx.x == 0 && t == 0;
+  long long tk = timing ? wall_clock64() : 0;
+  const int tc = blockIdx.x % a.ntx, tr = blockIdx.x / a.ntx;
+  const int4* C = a.tcol + (size_t)tc * d.nlevels;
+  const int4* Rw = a.trow + (size_t)tr * d.nlevels;
+  uint8_t* buf[2] = {plds, plds + a.buf_bytes};
+  uint2* tx = reinterpret_cast<uint2*>(plds + 2 * (size_t)a.buf_bytes);   // per computed column of every level {sx - x0_prev, sx1 - x0_prev, a0, a1} (4 x int16); from a.ent_sx: per computed row {sy0 - y0_prev, sy1 - y0_prev, b0, b1}
+  // Staging: level descriptors, the tile column's / row's table entries (built by the host: they depend on the tile column / row only) and the level-0 source
+  // rectangle, in ONE memory round trip: no address depends on a loaded value (the rectangle's origin is the offset-table formula of orb_prepare evaluated here,
+  // its extent the largest any tile needs; entry blocks have a fixed stride), and every load is issued before the first LDS store.  (Measured on the way: a loop of
+  // load -> store pairs 27 us per launch; descriptors loaded first, then entries and pixels: 5 us of staging.)
+  const LevelInfo& L0 = d.lv[0];
+  int x0, y0;
+  {
+    const float fx = (float)((tc * kPyrTW + 0.5) * a.scale_x - 0.5), fy = (float)((tr * kPyrTH + 0.5) * a.scale_y - 0.5);
+    x0 = min(max((int)floorf(fx), 0), L0.w - 1); y0 = min(max((int)floorf(fy), 0), L0.h - 1);
+  }
+  const int cw0 = min(a.ex0, L0.w - x0), ch0 = min(a.ey0, L0.h - y0);
+  {
+    const uint2* gx = a.ent + (size_t)tc * a.ent_sx;
+    const uint2* gy = a.ent + a.ent_y0 + (size_t)tr * a.ent_sy;
+    const uint8_t* src = pyr + L0.poff + (long long)y0 * L0.pstride + x0;
+    const float rcw = 1.f / (float)cw0;
+    const int ne = a.ent_sx + a.ent_sy;
+    constexpr int UE = 1024 / kPyrTPB, UP = 3072 / kPyrTPB;
+    uint2 e[UE]; uint8_t v[UP];
+    int4 dsc = make_int4(0, 0, 0, 0);
+    if (t < d.nlevels) dsc = C[t]; else if (t >= 64 && t < 64 + d.nlevels) dsc = Rw[t - 64];
+#pragma unroll
+    for (int k = 0; k < UE; k++) { const int i = k * kPyrTPB + t; e[k] = make_uint2(0, 0); if (i < a.ent_sx) e[k] = gx[i]; else if (i < ne) e[k] = gy[i - a.ent_sx]; }
+#pragma unroll
+    for (int k = 0; k < UP; k++) {
+      const int i = k * kPyrTPB + t;
+      v[k] = 0;
+      if (i < cw0 * ch0) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; v[k] = src[(long long)yy * L0.pstride + xx]; }
+    }
+    if (t < d.nlevels) s_c[t] = dsc; else if (t >= 64 && t < 64 + d.nlevels) s_r[t - 64] = dsc;
+#pragma unroll
+    for (int k = 0; k < UE; k++) { const int i = k * kPyrTPB + t; if (i < ne) tx[i] = e[k]; }
+#pragma unroll
+    for (int k = 0; k < UP; k++) { const int i = k * kPyrTPB + t; if (i < cw0 * ch0) buf[0][i] = v[k]; }
+    // (tiles beyond the unrolled batches: plain loops)
+    for (int i = UE * kPyrTPB + t; i < ne; i += kPyrTPB) tx[i] = i < a.ent_sx ? gx[i] : gy[i - a.ent_sx];
+    for (int i = UP * kPyrTPB + t; i < cw0 * ch0; i += kPyrTPB) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; buf[0][i] = src[(long long)yy * L0.pstride + xx]; }
+  }
+  __syncthreads();
+  if (timing) { const long long tn = wall_clock64(); a.dbg[0] += tn - tk; tk = tn; a.dbg[23] += 1; }
+  int pcw = cw0;     // width of the previous level's rectangle in LDS
+  for (int l = 1; l < d.nlevels; l++) {
+    const LevelInfo& L = d.lv[l];
+    const int4 cl = s_c[l], rl = s_r[l];
+    const int lx0 = cl.x, x1 = cl.y, cw = cl.z - lx0, ly0 = rl.x, y1 = rl.y, ch = rl.z - ly0;
+    const uint8_t* S = buf[(l - 1) & 1];
+    uint8_t* D = buf[l & 1];
+    uint8_t* dst = pyr + L.off + (size_t)ly0 * L.stride + lx0;
+    const uint2* ex = tx + cl.w;
+    const uint2* ey = tx + a.ent_sx + rl.w;
+    const float rcw = 1.f / (float)max(cw, 1);
+    const int n = cw * ch, ow = x1 - lx0, oh = y1 - ly0;
+    constexpr int UL = 1024 / kPyrTPB;   // pixels per thread and batch: their LDS reads (entries, then four source bytes) overlap
+    for (int base = 0; base < n; base += UL * kPyrTPB) {
+      uint8_t v[UL]; int xx[UL], yy[UL];
+#pragma unroll
+      for (int k = 0; k < UL; k++) {
+        v[k] = 0; xx[k] = yy[k] = 0;
+        if (base + k * kPyrTPB + (t & ~63) >= n) continue;   // the whole wave is beyond the rectangle (the small levels keep half of the 16 waves busy: the loop is issue-bound)
+        const int i = min(base + k * kPyrTPB + t, n - 1);
+        yy[k] = (int)(((float)i + 0.5f) * rcw); xx[k] = i - yy[k] * cw;
+        const uint2 qx = ex[xx[k]], qy = ey[yy[k]];
+        const int sx = (int16_t)(qx.x & 0xffff), sx1 = (int16_t)(qx.x >> 16), a0 = (int16_t)(qx.y & 0xffff), a1 = (int16_t)(qx.y >> 16);
+        const int sy0 = (int16_t)(qy.x & 0xffff), sy1 = (int16_t)(qy.x >> 16), b0 = (int16_t)(qy.y & 0xffff), b1 = (int16_t)(qy.y >> 16);
+        const uint8_t* S0 = S + sy0 * pcw;
+        const uint8_t* S1 = S + sy1 * pcw;
+        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        v[k] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+      }
+#pragma unroll
+      for (int k = 0; k < UL; k++) {
+        const int i = base + k * kPyrTPB + t;
+        if (i < n) {
+          D[i] = v[k];
+          if (xx[k] < ow && yy[k] < oh) dst[(size_t)yy[k] * L.stride + xx[k]] = v[k];
+        }
+      }
+    }
+    pcw = cw;
+    lds_barrier();
+    if (timing && l < 20) { const long long tn = wall_clock64(); a.dbg[l] += tn - tk; tk = tn; }
+  }
+}
+
 __device__ __forceinline__ int find_level(const OrbDev& d, int grow) {
   int l = 0;
 #pragma unroll 1
@@ -904,6 +1024,10 @@ struct ccm_orb {
   } B[kOrbSets];
   int cur = 0;
   int16_t* d_tabs = nullptr; std::vector<int> tab_xofs, tab_ialpha, tab_yofs, tab_ibeta;   // per level offsets into d_tabs
+  // one-launch pyramid (orb_pyramid_kernel): tile tables [tile column / row][level][4], grid, LDS plan; pyr_fused = false -> one orb_resize_kernel per level
+  int4* d_pyr_tcol = nullptr; int4* d_pyr_trow = nullptr; int pyr_ntx = 0, pyr_nty = 0, pyr_buf_bytes = 0; size_t pyr_lds = 0; bool pyr_fused = false;
+  uint2* d_pyr_ent = nullptr;   // staged-table entries of every tile column, then of every tile row
+  PyrArgs pyr_args{};
   int cand_cap = 0;
   int* d_tile_level = nullptr; int* d_tile_xy = nullptr; int n_blur_tiles = 0;
   int kp_cap = 0;
@@ -935,7 +1059,8 @@ static void orb_free_bufs(ccm_orb::Bufs& b) {
 }
 static void orb_free_geometry(ccm_orb* o) {
   for (int k = 0; k < kOrbSets; k++) orb_free_bufs(o->B[k]);
-  hipFree(o->d_tabs); hipFree(o->d_tile_level); hipFree(o->d_tile_xy);
+  hipFree(o->d_tabs); hipFree(o->d_tile_level); hipFree(o->d_tile_xy); hipFree(o->d_pyr_tcol); hipFree(o->d_pyr_trow); hipFree(o->d_pyr_ent);
+  o->d_pyr_tcol = o->d_pyr_trow = nullptr; o->d_pyr_ent = nullptr; o->pyr_fused = false;
   if (o->h_io) hipHostFree(o->h_io);
   o->d_tabs = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
 }
@@ -981,6 +1106,13 @@ extern "C" void ccm_orb_destroy(ccm_orb* o) {
     const double nl = (double)std::max<unsigned long long>(h[7], 1);
     fprintf(stderr, "[ccm_orb] octree kernel, level 0, clock ticks: load+roots %llu | per pass (%llu passes): count %.0f scan(main) %.0f rank+scan(final) %.0f new list %.0f remap+loop %.0f | final select %llu\n",
             h[0], h[7], h[1] / nl, h[2] / nl, h[3] / nl, h[4] / nl, h[5] / nl, h[6]);
+    unsigned long long hp[24];
+    hipMemcpy(hp, o->d_oct_dbg + 8, sizeof(hp), hipMemcpyDeviceToHost);
+    if (hp[23]) {
+      fprintf(stderr, "[ccm_orb] pyramid kernel, workgroup 0, clock ticks per launch (%llu launches): staging %.1f | levels", hp[23], (double)hp[0] / hp[23]);
+      for (int l = 1; l < o->nlevels && l < 20; l++) fprintf(stderr, " %.1f", (double)hp[l] / hp[23]);
+      fprintf(stderr, "\n");
+    }
     hipFree(o->d_oct_dbg);
   }
   orb_free_geometry(o);
@@ -1140,7 +1272,89 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
       o->oct_cells = o->oct_ok && !getenv("CCM_ORB_COMPACT") && max_cells <= 2 * o->oct_tpb && ((size_t)max_cells + 1) * sizeof(int) <= slots;
     }
   }
-  if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 64)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 64)); }
+  o->pyr_fused = false;
+  if (o->nlevels > 1 && !(getenv("CCM_ORB_PYR_FUSED") && atoi(getenv("CCM_ORB_PYR_FUSED")) == 0)) {
+    // tile tables of orb_pyramid_kernel.  One axis at a time: size[l], offset table of level l (clamped to the source as the kernels clamp it), tile size.
+    int max_ent = 0;
+    std::vector<int16_t> ent;   // 4 x int16 per computed column / row of every level, tile column by tile column, then tile row by tile row
+    std::vector<size_t> blk_start; int max_src = 0;
+    auto axis = [&](bool is_x, int tile, std::vector<int>& out) -> int {   // returns the largest extent of a computed range over tiles and levels, fills out[tile][level][4]
+      const int nl = o->nlevels;
+      std::vector<int> size(nl);
+      for (int l = 0; l < nl; l++) size[l] = is_x ? d.lv[l].w : d.lv[l].h;
+      auto ofs = [&](int l, int i) { const int v = tabs[(is_x ? o->tab_xofs[l] : o->tab_yofs[l]) + i]; return std::min(std::max(v, 0), size[l - 1] - 1); };
+      const int nt = ccm_div_up(size[1], tile);
+      out.assign((size_t)4 * nt * nl, 0);
+      int max_ext = 1;
+      std::vector<int> a0(nl), a1(nl), c1(nl);
+      for (int tI = 0; tI < nt; tI++) {
+        a0[1] = tI * tile; a1[1] = std::min((tI + 1) * tile, size[1]);
+        for (int l = 2; l < nl; l++) {   // owned range: the pixels whose first source pixel is owned one level up (the offset tables are non-decreasing)
+          int lo = 0; while (lo < size[l] && ofs(l, lo) < a0[l - 1]) lo++;
+          int hi = lo; while (hi < size[l] && ofs(l, hi) < a1[l - 1]) hi++;
+          a0[l] = lo; a1[l] = hi;
+        }
+        // computed range, from the last level up: owned + what the next level's computed range reads (its last pixel's first source + 1)
+        c1[nl - 1] = a1[nl - 1];
+        for (int l = nl - 1; l >= 1; l--) {
+          const int src_end = c1[l] > a0[l] ? std::min(ofs(l, c1[l] - 1) + 2, size[l - 1]) : 0;
+          if (l - 1 >= 1) c1[l - 1] = std::max(a1[l - 1], src_end);
+          else { a0[0] = c1[1] > a0[1] ? ofs(1, a0[1]) : 0; a1[0] = a0[0]; c1[0] = std::max(src_end, a0[0]); }
+        }
+        int n_ent = 0;
+        for (int l = 0; l < nl; l++) {
+          int* e = out.data() + 4 * ((size_t)tI * nl + l);
+          e[0] = a0[l]; e[1] = a1[l]; e[2] = c1[l];
+          if (l >= 1) { e[3] = n_ent; n_ent += c1[l] - a0[l]; }
+          max_ext = std::max(max_ext, c1[l] - a0[l]);
+        }
+        max_ent = std::max(max_ent, n_ent);
+        blk_start.push_back(ent.size() / 4);
+        max_src = std::max(max_src, c1[0] - a0[0]);
+        for (int l = 1; l < nl; l++)
+          for (int i = a0[l]; i < c1[l]; i++) {
+            const int v = tabs[(is_x ? o->tab_xofs[l] : o->tab_yofs[l]) + i], wo = (is_x ? o->tab_ialpha[l] : o->tab_ibeta[l]) + 2 * i;
+            const int s0 = std::min(std::max(v, 0), size[l - 1] - 1), s1 = std::min(std::max(v + 1, 0), size[l - 1] - 1);
+            ent.push_back((int16_t)(s0 - a0[l - 1])); ent.push_back((int16_t)(s1 - a0[l - 1])); ent.push_back(tabs[wo]); ent.push_back(tabs[wo + 1]);
+          }
+      }
+      return max_ext;
+    };
+    std::vector<int> tcol, trow;
+    const int ex = axis(true, kPyrTW, tcol);
+    const int ent_x = max_ent, src_x = max_src; max_ent = 0; max_src = 0;
+    const size_t n_xblk = blk_start.size();
+    const int ey = axis(false, kPyrTH, trow);
+    const int ent_y = max_ent, src_y = max_src;
+    o->pyr_ntx = ccm_div_up(d.lv[1].w, kPyrTW); o->pyr_nty = ccm_div_up(d.lv[1].h, kPyrTH);
+    o->pyr_buf_bytes = (ex * ey + 15) & ~15;
+    // staged tables: 8 bytes per computed column / row of every level
+    o->pyr_lds = 2 * (size_t)o->pyr_buf_bytes + 8 * (size_t)(ent_x + ent_y) + 64;
+    if (o->pyr_lds <= 60 * 1024) {
+      // entry blocks at a fixed stride per tile column / row (the kernel's staging loads must not depend on a loaded offset)
+      std::vector<int16_t> entp((size_t)4 * (n_xblk * ent_x + (blk_start.size() - n_xblk) * ent_y), 0);
+      blk_start.push_back(ent.size() / 4);
+      for (size_t bI = 0; bI + 1 < blk_start.size(); bI++) {
+        const size_t dst = bI < n_xblk ? bI * ent_x : n_xblk * ent_x + (bI - n_xblk) * ent_y;
+        std::copy(ent.begin() + 4 * blk_start[bI], ent.begin() + 4 * blk_start[bI + 1], entp.begin() + 4 * dst);
+      }
+      PyrArgs& pa = o->pyr_args;
+      pa.ntx = o->pyr_ntx; pa.buf_bytes = o->pyr_buf_bytes; pa.ent_sx = ent_x; pa.ent_sy = ent_y; pa.ent_y0 = (int)(n_xblk * ent_x);
+      pa.ex0 = src_x; pa.ey0 = src_y;
+      pa.scale_x = 1. / ((double)d.lv[1].w / d.lv[0].w); pa.scale_y = 1. / ((double)d.lv[1].h / d.lv[0].h);
+      pa.dbg = nullptr;
+      CCM_HIP_CHECK(ctx, hipMalloc(&o->d_pyr_ent, std::max<size_t>(entp.size(), 4) * sizeof(int16_t)));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_pyr_ent, entp.data(), entp.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipMalloc(&o->d_pyr_tcol, tcol.size() * sizeof(int)));
+      CCM_HIP_CHECK(ctx, hipMalloc(&o->d_pyr_trow, trow.size() * sizeof(int)));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_pyr_tcol, tcol.data(), tcol.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_pyr_trow, trow.data(), trow.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // tcol / trow / entp are locals
+      pa.tcol = o->d_pyr_tcol; pa.trow = o->d_pyr_trow; pa.ent = o->d_pyr_ent;
+      o->pyr_fused = true;
+    }
+  }
+  if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 256)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 256)); }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1164,7 +1378,12 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
 static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
-  for (int l = 1; l < o->nlevels; l++) {
+  if (o->pyr_fused) {
+    ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
+    PyrArgs pa = o->pyr_args;
+    pa.dbg = o->d_oct_dbg ? o->d_oct_dbg + 8 : nullptr;
+    hipLaunchKernelGGL(orb_pyramid_kernel, dim3(o->pyr_ntx * o->pyr_nty), dim3(kPyrTPB), o->pyr_lds, o->st, d, o->B[o->cur].d_pyr, pa);
+  } else for (int l = 1; l < o->nlevels; l++) {
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
     hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.poff, P.w, P.h, P.pstride,

@@ -140,6 +140,13 @@ def test_levels_that_do_not_fit_the_octree_kernel_fall_back_to_the_host(ctx, ora
     _compare(ctx, oracle_lib, synth.gen_image(1000, 3), 1000)
 
 
+@pytest.mark.parametrize("w,h,nlevels,scale", [(752, 480, 8, 1.2), (333, 251, 5, 1.7)])
+def test_per_level_resize_kernels_still_agree(ctx, oracle_lib, monkeypatch, w, h, nlevels, scale):
+    """CCM_ORB_PYR_FUSED=0: one orb_resize_kernel launch per level instead of orb_pyramid_kernel (the default, which every other test of this file runs on)."""
+    monkeypatch.setenv("CCM_ORB_PYR_FUSED", "0")
+    _compare(ctx, oracle_lib, synth.gen_image(777, 2, w, h), 600, nlevels=nlevels, scale_factor=scale)
+
+
 _SWEEP = synth.orb_sweep_cases()
 
 
