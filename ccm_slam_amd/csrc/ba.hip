@@ -1123,21 +1123,26 @@ __global__ __launch_bounds__(kRow4TPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 __device__ __forceinline__ double coarse_hat_t(int k, int agg) { return ((double)(k % agg) + 0.5) * (1.0 / (double)agg); }
 
 // cluster part of the coarse restriction P^T r: 6 values for the first node of the cluster's interval, 6 for the second.  The 6 products of every
-// (camera, component) go through LDS and are added in a fixed order.  prod: LDS scratch of 6 * 96 doubles; needs all kTPB threads (barriers).
+// (camera, component), weighted for either node, go through LDS and are added in a fixed order.  prod: LDS scratch of 12 * 96 doubles; needs all kTPB threads (barriers).
+// (round 4: the hat weights are applied by the 96 threads that form the products; the 12 serial sums used to evaluate `k % agg` and a multiply per term: ~5 us of a 12.8 us launch)
 __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m, const double* rc, double* prod) {
   const int t = threadIdx.x;
   if (t < m) {
     const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
     const double rv = rc[t];
+    const double w1 = coarse_hat_t(s0 + t / 6, d.agg), w0 = 1.0 - w1;
 #pragma unroll
-    for (int cc = 0; cc < 6; cc++) prod[t * 6 + cc] = P[cc] * rv;
+    for (int cc = 0; cc < 6; cc++) { const double pr = P[cc] * rv; prod[t * 6 + cc] = w0 * pr; prod[6 * kCluN + t * 6 + cc] = w1 * pr; }
   }
   __syncthreads();
   if (t < 12) {
     const int cc = t % 6, second = t / 6;
+    const double* pw = prod + (second ? 6 * kCluN : 0) + cc;
     double sv = 0;
-    for (int q = 0; q < m; q++) { const double w1 = coarse_hat_t(s0 + q / 6, d.agg); sv += (second ? w1 : 1.0 - w1) * prod[q * 6 + cc]; }
-    d.mk_cpart[12 * (size_t)c + t] = sv;
+    for (int q = 0; q < m; q++) sv += pw[q * 6];
+    // node-major, four contributor slots per node (first-node parts of clusters 2n / 2n + 1, second-node parts of clusters 2n - 2 / 2n - 1): the gather of
+    // ba_pcg_coarse_apply is four coalesced streams; slots no cluster writes stay zero from the allocation
+    d.mk_cpart[(size_t)(2 * second + (c & 1)) * (6 * (size_t)(d.mk_na + 1)) + 6 * (size_t)((c >> 1) + second) + cc] = sv;
   }
 }
 
@@ -1168,9 +1173,6 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   // XCD-aware row assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give
   // XCD x the CONTIGUOUS row chunk x: covisible cameras are close in index, hence a block S_ij and its mirror use
   // (row i and, transposed, row j) are read by the same XCD and the second read can hit that XCD's 4 MiB L2.
-  const int per_xcd = gridDim.x >> 3;            // grid is padded to a multiple of 8 workgroups
-  const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int i = wg * kRowsPerWG + rl;
   double rz_k, beta = 0;
   {
     const int nco = d.mk_on ? d.n_wg_upd : 0, npr = k ? d.n_wg_upd : 0;
@@ -1196,8 +1198,14 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   const double lambda = d.pcg_scal[2];
   const double* pold = d.p[k & 1];
   double* pnew = d.p[(k + 1) & 1];
-  double acc = 0;
   const int g = lane >> 3, r = lane & 7;
+  // (round 4) the grid is at most two workgroups per CU; a workgroup takes several groups of 8 rows one after the other (XCD x keeps the contiguous chunk x of them): the
+  // sums above are formed 512 times per launch instead of once per 8 rows, and no workgroup waits for a slot
+  const int per_xcd = d.n_wg_spmv >> 3, g_per_xcd = gridDim.x >> 3;   // both padded to multiples of 8
+  for (int li = blockIdx.x >> 3; li < per_xcd; li += g_per_xcd) {
+  const int wg = (blockIdx.x & 7) * per_xcd + li;
+  const int i = wg * kRowsPerWG + rl;
+  double acc = 0;
   if (i < d.Cp && r < 6) {
     const int e0 = d.row_off[i], e1 = d.row_off[i + 1];
     for (int s = e0 + h * 8 + g; s < e1; s += 16) {
@@ -1243,6 +1251,127 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     for (int q = 1; q < kRowsPerWG; q++) tot += lds[q];
     d.ppq[wg] = tot;
   }
+  }
+}
+
+// The same step with every stored block read ONCE (round 4).  ba_pcg_spmv reads a block twice per product — in its own row and, transposed, in its column's row —
+// and S (114 MB on the 10 000-keyframe map) fits no L2, so the second read comes from memory again (PMC: 201 MB per launch).  Here the waves of row i walk the row's
+// diagonal and UPPER blocks only, which lie contiguously in S: y_i += S_ij p_j as before, and S_ij^T p_i (a sum over the six row lanes of a block: a halving butterfly
+// inside the 8-lane group) goes to the slot of the block among row j's lower entries (sym_T, scattered 48-byte stores, no atomics: one writer per slot, a fixed summation
+// order in the reader).  ba_pcg_update adds a row's slots to the partial q written here.  p.q needs no complete q: p.Sp = sum_i p_i.(D_i p_i) + 2 sum_(i<j) p_i.(S_ij p_j).
+__global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv_sym(BaDev d, int k) {
+  __shared__ double half_sum[kRowsPerWG][2][16];   // [0..7] diagonal + upper part of y, [8..15] diagonal part alone
+  __shared__ double lds[kRowsPerWG];
+  __shared__ double redp[4 * (kSpmvTPB / kWave)];
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = d.pcg_flag[0];
+  __syncthreads();
+  if (s_done) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int rl = wv >> 1, h = wv & 1;            // local row, half
+  double rz_k, beta = 0;
+  {
+    const int nco = d.mk_on ? d.n_wg_upd : 0, npr = k ? d.n_wg_upd : 0;
+    const double* const ps[4] = {d.prz[k & 1], d.mk_cry[k & 1], d.prz[(k + 1) & 1], d.mk_cry[(k + 1) & 1]};
+    const int ns[4] = {d.n_wg_upd, nco, npr, k ? nco : 0};
+    double sm[4];
+    block_sum_partials<4, kSpmvTPB>(ps, ns, sm, redp);
+    rz_k = sm[0];
+    if (d.mk_on) rz_k += sm[1];
+    if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
+    else {
+      double rz_prev = sm[2];
+      if (d.mk_on) rz_prev += sm[3];
+      beta = rz_k / rz_prev;
+    }
+  }
+  const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
+  if (rz_k <= d.pcg_scal[1] * rz0 || !(rz_k > 0.0)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; if (rz_k != rz_k) d.pcg_flag[2] = 1; }
+    return;
+  }
+  const double lambda = d.pcg_scal[2];
+  const double* pold = d.p[k & 1];
+  double* pnew = d.p[(k + 1) & 1];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const int g = lane >> 3, r = lane & 7;
+  // The grid is at most two workgroups per CU (all resident at once); a workgroup takes several groups of 8 rows one after the other, so the sums above are formed
+  // 512 times per launch, not once per 8 rows, and no workgroup waits for a slot (1 250 workgroups of 16 waves: ~12 us of dispatch on the 10 000-keyframe map).
+  // XCD x (workgroups b % 8 == x) keeps the contiguous chunk x of the row groups.
+  const int per_xcd = d.n_wg_spmv >> 3, g_per_xcd = gridDim.x >> 3;   // both padded to multiples of 8
+  for (int li = blockIdx.x >> 3; li < per_xcd; li += g_per_xcd) {
+  const int wg = (blockIdx.x & 7) * per_xcd + li;
+  const int i = wg * kRowsPerWG + rl;
+  double acc = 0, accd = 0;
+  if (i < d.Cp) {
+    const int rr = min(r, 5);                    // lanes 6, 7 of a group load row 5 again and contribute zeros
+    const double vi = r < 6 ? d.z[6 * (size_t)i + rr] + beta * pold[6 * (size_t)i + rr] : 0.0;
+    const int u0 = d.rowblk_off[i], nu = d.rowblk_off[i + 1] - u0;
+    for (int s = h * 8 + g; s <= nu; s += 16) {   // s == 0: the diagonal block
+      const int tid = u0 + s - 1;
+      const int j = s ? d.blk_j[tid] : i;
+      const int dst = s ? d.sym_dst[tid] : 0;
+      const v2d* B = reinterpret_cast<const v2d*>(d.S + 36 * (size_t)(s ? d.Cp + tid : i) + 6 * rr);
+      const v2d* zj = reinterpret_cast<const v2d*>(d.z + 6 * (size_t)j);
+      const v2d* pj = reinterpret_cast<const v2d*>(pold + 6 * (size_t)j);
+      const v2d b0 = B[0], b1 = B[1], b2 = B[2];
+      const v2d z0 = zj[0], z1 = zj[1], z2 = zj[2], p0 = pj[0], p1 = pj[1], p2 = pj[2];
+      const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+      const double vj[6] = {z0.x + beta * p0.x, z0.y + beta * p0.y, z1.x + beta * p1.x, z1.y + beta * p1.y, z2.x + beta * p2.x, z2.y + beta * p2.y};
+      if (r < 6) {
+        double y = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) y += b[c] * vj[c];
+        acc += y;
+        if (s == 0) accd = y;
+      }
+      if (s) {
+        // S_ij^T p_i: component c = sum over the row lanes r of B[r][c] p_i[r].  xor 4: the lanes 0..3 of the group keep c = 0, 1, 2 and send 3, 4, 5 (lanes 4..7 the
+        // other way), then xor 2 and xor 1 on the three kept values: 9 cross-lane adds instead of 18
+        const bool hi = (r & 4) != 0;
+        double kp[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const double lo_v = b[c] * vi, hi_v = b[3 + c] * vi;
+          const double send = hi ? lo_v : hi_v, keep = hi ? hi_v : lo_v;
+          kp[c] = keep + __shfl_xor(send, 4, kWave);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 2, kWave);
+#pragma unroll
+        for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 1, kWave);
+        const int q3 = r & 3;
+        if (q3 < 3) d.sym_T[6 * (size_t)dst + (hi ? 3 : 0) + q3] = q3 == 0 ? kp[0] : q3 == 1 ? kp[1] : kp[2];
+      }
+    }
+  }
+  // sum over the 8 groups (lanes with equal r): fixed xor tree
+  acc += __shfl_xor(acc, 8, kWave);  accd += __shfl_xor(accd, 8, kWave);
+  acc += __shfl_xor(acc, 16, kWave); accd += __shfl_xor(accd, 16, kWave);
+  acc += __shfl_xor(acc, 32, kWave); accd += __shfl_xor(accd, 32, kWave);
+  if (lane < 8) { half_sum[rl][h][lane] = acc; half_sum[rl][h][8 + lane] = accd; }
+  __syncthreads();
+  double pq = 0;
+  if (h == 0 && i < d.Cp) {
+    if (lane < 6) {
+      const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
+      const double y = half_sum[rl][0][lane] + half_sum[rl][1][lane], yd = half_sum[rl][0][8 + lane] + half_sum[rl][1][8 + lane];
+      d.q[6 * (size_t)i + lane] = y + lambda * pi;          // diagonal + upper part; ba_pcg_update adds the lower part
+      pnew[6 * (size_t)i + lane] = pi;
+      pq = pi * ((yd + lambda * pi) + 2.0 * (y - yd));
+    }
+    pq = wave_sum(lane < 6 ? pq : 0.0);
+    if (lane == 0) lds[rl] = pq;
+  } else if (h == 0 && lane == 0) lds[rl] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = lds[0];
+#pragma unroll
+    for (int q = 1; q < kRowsPerWG; q++) tot += lds[q];
+    d.ppq[wg] = tot;
+  }
+  }
 }
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
@@ -1260,6 +1389,23 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   const size_t g = 6 * (size_t)s0 + t;
   double xv = 0, rv = 0, qv = 0, pv = 0;
   if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g]; }
+  if (d.sym_T && t < m) {
+    // symmetric product (ba_pcg_spmv_sym): q so far holds the diagonal + upper part of the row; the lower part S_ji^T p_j was stored by the rows j < i at this row's lower
+    // slots, which are contiguous: added in slot order, 16 loads in flight
+    const int cam = s0 + t / 6;
+    const int ro0 = d.row_off[cam], ro1 = d.row_off[cam + 1], rb0 = d.rowblk_off[cam], rb1 = d.rowblk_off[cam + 1];
+    const int nl = (ro1 - ro0) - 1 - (rb1 - rb0);
+    const double* Tp = d.sym_T + 6 * (size_t)(ro0 - cam - rb0) + t % 6;
+    double ql = 0;
+    for (int k0 = 0; k0 < nl; k0 += 16) {
+      double tv[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) tv[u] = k0 + u < nl ? Tp[6 * (size_t)(k0 + u)] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) if (k0 + u < nl) ql += tv[u];
+    }
+    qv += ql;
+  }
   __shared__ double redp[3 * (kTPB / kWave)];
   double rz_k, pq;
   {
@@ -1318,48 +1464,79 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
     if (c == 0) d.pcg_flag[1] = k + 1;
   }
   if (d.mk_on) {
-    __shared__ double prod[6 * kCluN];
+    __shared__ double prod[12 * kCluN];
     mk_restrict(d, c, s0, m, rc, prod);
   }
 }
 
-// Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per cluster after ba_pcg_init_tiles / ba_pcg_update:
-// rc = P^T r per coarse node (the second-node parts of the previous interval's two clusters + the first-node parts of this interval's),
-// y = Ac^-1[rows of the two nodes of the cluster's interval] rc (each cluster recomputes these 12 values: 12 x Nc multiply-adds, cheaper than another
-// grid-wide step), z += P (w0 y_a + w1 y_a+1) for the cluster's cameras, and the coarse part of r.z = rc . y, every node counted once (by the first
-// cluster of its interval; the last node by the first cluster of the last interval).
+// Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per INTERVAL (two clusters) after ba_pcg_init_tiles / ba_pcg_update:
+// rc = P^T r per coarse node (the first-node parts of the node's interval's two clusters + the second-node parts of the previous interval's),
+// y = Ac^-1[rows of the two nodes of the interval] rc (every interval recomputes these 12 values: 12 x Nc multiply-adds, cheaper than another
+// grid-wide step), z += P (w0 y_a + w1 y_a+1) for the interval's cameras, and the coarse part of r.z = rc . y, every node counted once (by its own
+// interval; the last node by the last interval).
+// (round 4: a workgroup per cluster read the 60 KB of parts and the 90 KB of inverse rows twice per interval, the parts cluster-major — 16 us per launch on the
+// 10 000-keyframe map, bound by the 94 MB that 625 workgroups pulled from L2; parts node-major in four contributor slots, one workgroup per interval)
 __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
   extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * (na + 1)]
   __shared__ double ys[12];
   if (d.pcg_flag[0]) return;
-  const int t = threadIdx.x, c = blockIdx.x;
+  const int t = threadIdx.x, agg = blockIdx.x;
   const int lane = t & (kWave - 1), wv = t / kWave;
   const int nca = 6 * (d.mk_na + 1), n_clu = d.n_wg_upd;
-  for (int e = t; e < nca; e += kTPB) {
-    const int n = e / 6, cc = e % 6;
-    double v = 0;
-    if (n < d.mk_na) {
-      v += d.mk_cpart[12 * (size_t)(2 * n) + cc];
-      if (2 * n + 1 < n_clu) v += d.mk_cpart[12 * (size_t)(2 * n + 1) + cc];
+  // the thread's prolongation row and its z entry are requested first (7 loads; also requesting the first columns of the 12 inverse rows up here was measured:
+  // 27 instead of 12 us per launch — 48 loads per thread queued ahead of the gather that the whole workgroup waits for)
+  const int c_own = 2 * agg + (t >> 7), tl = t & 127;
+  const int s0_own = c_own * kClu;
+  const int m_own = c_own < n_clu ? 6 * (min(d.Cp, s0_own + kClu) - s0_own) : 0;
+  double Prow[6] = {0, 0, 0, 0, 0, 0}, z_old = 0;
+  if (tl < m_own) {
+    const double* P = d.mk_P + 36 * (size_t)(s0_own + tl / 6) + 6 * (tl % 6);
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) Prow[cc] = P[cc];
+    z_old = d.z[6 * (size_t)s0_own + tl];
+  }
+  // the loads of a batch of 8 entries per thread are all issued before the first LDS store
+  for (int base = 0; base < nca; base += 8 * kTPB) {
+    double va[8], vb[8], vc[8], vd[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int e = base + k * kTPB + t;
+      va[k] = vb[k] = vc[k] = vd[k] = 0.0;
+      if (e < nca) { va[k] = d.mk_cpart[e]; vb[k] = d.mk_cpart[(size_t)nca + e]; vc[k] = d.mk_cpart[2 * (size_t)nca + e]; vd[k] = d.mk_cpart[3 * (size_t)nca + e]; }
     }
-    if (n >= 1) {
-      v += d.mk_cpart[12 * (size_t)(2 * n - 2) + 6 + cc];
-      if (2 * n - 1 < n_clu) v += d.mk_cpart[12 * (size_t)(2 * n - 1) + 6 + cc];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int e = base + k * kTPB + t;
+      if (e < nca) rcs[e] = (((0.0 + va[k]) + vb[k]) + vc[k]) + vd[k];   // clusters 2n, 2n + 1 (first-node parts), 2n - 2, 2n - 1 (second-node parts); absent: + 0.0
     }
-    rcs[e] = v;
   }
   __syncthreads();
-  const int agg = c >> 1;
   {
     // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows with its loads in flight together, then wave
     // trees and the four wave sums in order.
     __shared__ double yred[12][kTPB / kWave];
     double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;   // f32 copy (round 4): the 12 rows are re-read by every cluster in every CG iteration
-    for (int jj = t; jj < nca; jj += kTPB) {
-      const double rv = rcs[jj];
+    const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;   // f32 copy (round 4): the 12 rows are re-read by every interval in every CG iteration
+    for (int base = t; base < nca; base += 4 * kTPB) {   // 4 x 12 loads in flight per thread, accumulated in the plain loop's order
+      float w[4][12]; double rv[4];
 #pragma unroll
-      for (int rr = 0; rr < 12; rr++) a12[rr] += (double)ar[(size_t)rr * d.mk_Nc + jj] * rv;
+      for (int k = 0; k < 4; k++) {
+        const int jj = base + k * kTPB;
+        rv[k] = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 12; rr++) w[k][rr] = 0.f;
+        if (jj < nca) {
+          rv[k] = rcs[jj];
+#pragma unroll
+          for (int rr = 0; rr < 12; rr++) w[k][rr] = ar[(size_t)rr * d.mk_Nc + jj];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (base + k * kTPB < nca) {
+#pragma unroll
+          for (int rr = 0; rr < 12; rr++) a12[rr] += (double)w[k][rr] * rv[k];
+        }
     }
 #pragma unroll
     for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
@@ -1367,23 +1544,19 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
     if (t < 12) ys[t] = ((yred[t][0] + yred[t][1]) + yred[t][2]) + yred[t][3];
   }
   __syncthreads();
-  const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
-  const int m = 6 * (s1 - s0);
-  if (t < m) {
-    const double* P = d.mk_P + 36 * (size_t)(s0 + t / 6) + 6 * (t % 6);
-    const double w1 = coarse_hat_t(s0 + t / 6, d.agg), w0 = 1.0 - w1;
+  if (tl < m_own) {   // threads 0 .. 95: the interval's first cluster, 128 .. 223: its second one
+    const double w1 = coarse_hat_t(s0_own + tl / 6, d.agg), w0 = 1.0 - w1;
     double zc = 0;
 #pragma unroll
-    for (int cc = 0; cc < 6; cc++) zc += P[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
-    d.z[6 * (size_t)s0 + t] += zc;
+    for (int cc = 0; cc < 6; cc++) zc += Prow[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
+    d.z[6 * (size_t)s0_own + tl] = z_old + zc;
   }
   if (t == 0) {
     double sv = 0;
-    if ((c & 1) == 0) {
-      for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
-      if (agg == d.mk_na - 1) for (int rr = 0; rr < 6; rr++) sv += rcs[6 * (agg + 1) + rr] * ys[6 + rr];
-    }
-    d.mk_cry[par][c] = sv;
+    for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
+    if (agg == d.mk_na - 1) for (int rr = 0; rr < 6; rr++) sv += rcs[6 * (agg + 1) + rr] * ys[6 + rr];
+    d.mk_cry[par][2 * agg] = sv;
+    if (2 * agg + 1 < n_clu) d.mk_cry[par][2 * agg + 1] = 0.0;
   }
 }
 
@@ -3148,21 +3321,23 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (!ba->d_pers_coff) return ccm_set_error(ctx, CCM_E_STATE, "ccm_ba: cluster entry lists missing");
         hipLaunchKernelGGL(ba_pcg_init_tiles, dim3(d.n_wg_upd), dim3(kPersTPB), lds_tiles, ctx->stream, d, lambda, tol, (const int*)ba->d_pers_coff,
                            (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
-        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, 0);
+        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, 0);
       }
       const int chunk = 24;
+      static const int sym_grid = getenv("CCM_BA_SPMV_GRID") ? std::max(8, atoi(getenv("CCM_BA_SPMV_GRID")) & ~7) : 512;   // two 16-wave workgroups per CU
       int k = 0;
       while (k < max_it) {
         const int kend = std::min(max_it, k + chunk);
         for (; k < kend; k++) {
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-            hipLaunchKernelGGL(ba_pcg_spmv, dim3(d.n_wg_spmv), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            if (d.sym_T) hipLaunchKernelGGL(ba_pcg_spmv_sym, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            else hipLaunchKernelGGL(ba_pcg_spmv, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
           }
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
             hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.n_wg_upd), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
+            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));

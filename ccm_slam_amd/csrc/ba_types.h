@@ -84,6 +84,10 @@ struct BaDev {
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]
   const uint32_t* row_blk;   // [..] block id | transpose bit
+  // symmetric product of the multi-kernel PCG (round 4; nullptr: every row reads its lower blocks transposed, ba_pcg_spmv): the row of an upper block (i, j) also forms
+  // S_ij^T p_i and stores it at the block's place among row j's lower entries; ba_pcg_update adds a row's lower parts to q
+  const int* sym_dst;        // [nOff] for the off-diagonal block: low_off[j] + its rank among row j's lower entries
+  double* sym_T;             // [nOff][6]
   // PCG
   double *x, *r, *z, *q, *p[2];
   float* Wc;                 // [n_clusters][96*96] explicit inverses of the damped cluster blocks, multi-kernel PCG; f32: only a preconditioner (offline: the same CG iteration counts as f64), half the 74 KB a cluster re-reads in every CG iteration
@@ -104,7 +108,7 @@ struct BaDev {
   int n_chunk;
   int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
   // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
-  double* mk_cpart;          // [n_clusters][6] restriction parts P^T r of every cluster
+  double* mk_cpart;          // [4][6 (na + 1)] restriction parts P^T r, node-major: slot 0 / 1 = first-node part of cluster 2n / 2n + 1, slot 2 / 3 = second-node part of cluster 2n - 2 / 2n - 1
   double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
   const double* mk_P;        // [Cp][36] prolongation blocks
   const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse

@@ -455,6 +455,27 @@ def test_camera_counts_around_the_persistent_solvers_limit(ctx, oracle_lib, kfs)
     assert np.abs(pts - opts).max() <= 1e-4
 
 
+@pytest.mark.gpu
+def test_both_products_of_the_multi_kernel_solver_agree(ctx, monkeypatch):
+    """ba_pcg_spmv_sym (every stored block read once: S_ij p_j for row i and S_ij^T p_i for row j from the same registers, the second through sym_T) against
+    ba_pcg_spmv (CCM_BA_SPMV_SYM=0: every row reads its lower blocks transposed) on a 2300-keyframe map: the same LM path, poses to 5e-9 (the two differ in
+    summation order only)."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=2300, n_points=40 * 2300, seed=4242)
+    res = []
+    for sym in ("1", "0"):
+        monkeypatch.setenv("CCM_BA_SPMV_SYM", sym)
+        h = optimizer.BAHandle(ctx, prob)
+        st = h.run(4)
+        cam, pts, _, _ = h.download()
+        h.close()
+        res.append((st, cam, pts))
+    (s1, c1, p1), (s0, c0, p0) = res
+    assert (s1.iters_done, s1.lm_trials) == (s0.iters_done, s0.lm_trials)
+    assert abs(s1.chi2_final / s0.chi2_final - 1) < 1e-9
+    assert np.abs(c1 - c0).max() < 5e-9, np.abs(c1 - c0).max()
+    assert np.abs(p1 - p0).max() < 1e-7
+
+
 # ---- full-length parity on the BASELINE global-BA configurations -------------------------------------------------------------
 # The fixtures (tests/golden/gba_*_full.npz, generator tests/golden/make_golden.py gba_c4 gba_c3 gba_c5) hold the ORACLE's complete
 # optimize(20) call: per-iteration chi2 / lambda / trial counts, stop reason and final estimate.  The oracle needs 35 s - 10 min per
