@@ -72,6 +72,13 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= kTPB/kWa
 // sums with four loads in flight, wave tree, waves in order).  The whole workgroup shares the work: with every WAVE summing all partials on its
 // own (one load in flight per lane) the 10 000-keyframe map spent ~45 us of each ba_pcg_update and ~20 us of each ba_pcg_spmv on 6 000 /
 // 2 500 serial L2 round trips before touching its rows.  red: LDS scratch [NS][kTPB / kWave]; contains a block barrier.
+// a value every lane already agrees on, moved to scalar registers (frees 2 VGPRs per double)
+__device__ __forceinline__ double to_sgpr(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <int NS, int TPB = kTPB>
 __device__ __forceinline__ void block_sum_partials(const double* const (&p)[NS], const int (&n)[NS], double (&out)[NS], double* red) {
   const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
@@ -1157,9 +1164,11 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
 // (round 4) 66 VGPRs left ONE 16-wave workgroup per CU (7 waves per SIMD); the kernel is bound by the bytes it keeps in flight (per wave 8 blocks of 288 B behind
 // an index load), so it is held to 64 registers: two workgroups per CU.
+template <bool QP /* also leave P^T q of the 8 rows for ba_pcg_update_coarse (CCM_BA_MK_FUSED=1) */>
 __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
+  __shared__ double qp[kRowsPerWG][6][6];
   __shared__ double redp[4 * (kSpmvTPB / kWave)];
   // the "done" flag is read ONCE per workgroup: workgroup 0 sets it further down in this very launch, and waves of another workgroup that read it at
   // different times would leave the block-wide sums below with missing members
@@ -1195,7 +1204,8 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; if (rz_k != rz_k) d.pcg_flag[2] = 1; }
     return;
   }
-  const double lambda = d.pcg_scal[2];
+  const double lambda = to_sgpr(d.pcg_scal[2]);
+  beta = to_sgpr(beta);                          // (uniform values in scalar registers: the kernel is held to 64 vector registers)
   const double* pold = d.p[k & 1];
   double* pnew = d.p[(k + 1) & 1];
   const int g = lane >> 3, r = lane & 7;
@@ -1232,11 +1242,11 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   acc += __shfl_xor(acc, 32, kWave);
   if (lane < 8) half_sum[rl][h][lane] = acc;
   __syncthreads();
-  double pq = 0;
+  double pq = 0, qv = 0;
   if (h == 0 && i < d.Cp) {
     if (lane < 6) {
       const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
-      const double qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * pi;
+      qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * pi;
       d.q[6 * (size_t)i + lane] = qv;
       pnew[6 * (size_t)i + lane] = pi;
       pq = pi * qv;
@@ -1244,7 +1254,30 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     pq = wave_sum(lane < 6 ? pq : 0.0);
     if (lane == 0) lds[rl] = pq;
   } else if (h == 0 && lane == 0) lds[rl] = 0.0;
+  const bool with_qparts = QP && d.mk_on && d.mk_qpart;
+  if (with_qparts && h == 0 && lane < 6) {
+    // P^T q of the row (the coarse residual follows r's recurrence: ba_pcg_update_coarse): the 36 products go to LDS, 12 threads add them up below
+    if (i < d.Cp) {
+      const double* P = d.mk_P + 36 * (size_t)i + 6 * lane;
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) qp[rl][lane][cc] = P[cc] * qv;
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) qp[rl][lane][cc] = 0.0;
+    }
+  }
   __syncthreads();
+  if (with_qparts && threadIdx.x < 12) {
+    const int cc = threadIdx.x % 6, second = threadIdx.x / 6;
+    double sv = 0;
+    for (int q = 0; q < kRowsPerWG; q++) {
+      const int iq = wg * kRowsPerWG + q;
+      const double w1 = coarse_hat_t(iq, d.agg), w = second ? w1 : 1.0 - w1;
+      sv += w * (((qp[q][0][cc] + qp[q][1][cc]) + (qp[q][2][cc] + qp[q][3][cc])) + (qp[q][4][cc] + qp[q][5][cc]));
+    }
+    const int gpi = d.agg / kRowsPerWG;          // row groups per interval
+    d.mk_qpart[(size_t)(second * gpi + wg % gpi) * (6 * (size_t)(d.mk_na + 1)) + 6 * (size_t)(wg / gpi + second) + cc] = sv;
+  }
   if (threadIdx.x == 0) {
     double tot = lds[0];
 #pragma unroll
@@ -1469,6 +1502,154 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
+// Update + coarse correction in ONE kernel (round 4), a 512-thread workgroup per interval of the coarse space: threads 0..255 do ba_pcg_update's work for the interval's first
+// cluster, 256..511 for its second one; the coarse residual is not gathered from the clusters' parts of P^T r (that needs a grid-wide step after the update, which
+// was ba_pcg_coarse_apply's launch: 12 us + a gap per CG iteration on the 10 000-keyframe map) but follows the recurrence of r, rc <- rc - alpha P^T q, with P^T q
+// left by ba_pcg_spmv per group of 8 rows; every workgroup forms the whole of rc (as ba_pcg_coarse_apply did), interval 0 stores it for the next iteration.
+constexpr int kUpd2TPB = 2 * kTPB;
+__global__ __launch_bounds__(kUpd2TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_pcg_update_coarse(BaDev d, int k) {   // 128 registers: two workgroups per CU, so
+  // that the 313 intervals of the 10 000-keyframe map are resident at once (171 registers: one per CU, two rounds, 35 us per launch)
+  extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * (na + 1)]
+  __shared__ double rc[2][kCluN];
+  __shared__ double zpart[2][8][kCluN];
+  __shared__ double red[kUpd2TPB / kWave];
+  __shared__ double redp[3 * (kUpd2TPB / kWave)];
+  __shared__ double yred[12][kUpd2TPB / kWave];
+  __shared__ double ys[12];
+  const int t = threadIdx.x, agg = blockIdx.x, sg = t >> 8, tl = t & (kTPB - 1);
+  const int lane = t & (kWave - 1), wv = t / kWave;
+  const int n_clu = d.n_wg_upd, nca = 6 * (d.mk_na + 1);
+  const int c = 2 * agg + sg;
+  const int s0 = c * kClu;
+  const int m = c < n_clu ? 6 * (min(d.Cp, s0 + kClu) - s0) : 0;
+  const int done = d.pcg_flag[0];
+  const double* p = d.p[(k + 1) & 1];
+  const size_t g = 6 * (size_t)s0 + tl;
+  double xv = 0, rv = 0, qv = 0, pv = 0;
+  double Prow[6] = {0, 0, 0, 0, 0, 0};
+  if (tl < m) {
+    xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g];
+    const double* P = d.mk_P + 36 * (size_t)(s0 + tl / 6) + 6 * (tl % 6);
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) Prow[cc] = P[cc];
+  }
+  double rz_k, pq;
+  {
+    const double* const ps[3] = {d.prz[k & 1], d.mk_cry[k & 1], d.ppq};
+    const int ns[3] = {n_clu, n_clu, d.n_wg_spmv};
+    double sm[3];
+    block_sum_partials<3, kUpd2TPB>(ps, ns, sm, redp);
+    rz_k = sm[0] + sm[1];
+    pq = sm[2];
+  }
+  if (done) return;
+  if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = 1; }
+    return;
+  }
+  const double alpha = rz_k / pq;
+  if (tl < m) {
+    d.x[g] = xv + alpha * pv;
+    rv -= alpha * qv;
+    d.r[g] = rv;
+    rc[sg][tl] = rv;
+  } else if (tl < kCluN) rc[sg][tl] = 0.0;
+  {   // coarse residual of this iteration: the previous one minus alpha x the row groups' parts of P^T q (slots in a fixed order), 2 entries per thread and batch
+    const int nsl = 2 * (d.agg / kRowsPerWG);
+    const double* rc_old = d.mk_rc[k & 1];
+    for (int base = 0; base < nca; base += 2 * kUpd2TPB) {
+      double vo[2], sq[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int e = base + u * kUpd2TPB + t;
+        vo[u] = 0; sq[u] = 0;
+        if (e < nca) {
+          vo[u] = rc_old[e];
+          double q8[8];
+#pragma unroll
+          for (int sl = 0; sl < 8; sl++) q8[sl] = sl < nsl ? d.mk_qpart[(size_t)sl * nca + e] : 0.0;
+          for (int sl = 8; sl < nsl; sl++) sq[u] += d.mk_qpart[(size_t)sl * nca + e];   // (intervals wider than 32 cameras: not the multi-kernel path's choice)
+#pragma unroll
+          for (int sl = 0; sl < 8; sl++) sq[u] += q8[sl];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) { const int e = base + u * kUpd2TPB + t; if (e < nca) rcs[e] = vo[u] - alpha * sq[u]; }
+    }
+  }
+  __syncthreads();
+  if (agg == 0) for (int e = t; e < nca; e += kUpd2TPB) d.mk_rc[(k + 1) & 1][e] = rcs[e];
+  // z = W r of both clusters (ba_pcg_update's mapping per 256 threads)
+  if (tl < 192 && c < n_clu) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const float* W = d.Wc + (size_t)c * kCluN * kCluN;
+    const int rp = tl % 24, seg = tl / 24;
+    const v4f* Wp = reinterpret_cast<const v4f*>(W + (size_t)(12 * seg) * kCluN + 4 * rp);
+    v4f w[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) w[q] = Wp[(size_t)q * (kCluN / 4)];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int q = 0; q < 12; q++) { const double rq = rc[sg][12 * seg + q]; a0 += (double)w[q][0] * rq; a1 += (double)w[q][1] * rq; a2 += (double)w[q][2] * rq; a3 += (double)w[q][3] * rq; }
+    zpart[sg][seg][4 * rp] = a0; zpart[sg][seg][4 * rp + 1] = a1; zpart[sg][seg][4 * rp + 2] = a2; zpart[sg][seg][4 * rp + 3] = a3;
+  }
+  {   // y = Ac^-1[12 rows of the interval's two nodes] rc
+    double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;
+    for (int base = t; base < nca; base += 2 * kUpd2TPB) {
+      float w[2][12]; double rvv[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int jj = base + u * kUpd2TPB;
+        rvv[u] = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 12; rr++) w[u][rr] = 0.f;
+        if (jj < nca) {
+          rvv[u] = rcs[jj];
+#pragma unroll
+          for (int rr = 0; rr < 12; rr++) w[u][rr] = ar[(size_t)rr * d.mk_Nc + jj];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+        if (base + u * kUpd2TPB < nca) {
+#pragma unroll
+          for (int rr = 0; rr < 12; rr++) a12[rr] += (double)w[u][rr] * rvv[u];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
+  }
+  __syncthreads();
+  if (t < 12) { double y = yred[t][0]; for (int w = 1; w < kUpd2TPB / kWave; w++) y += yred[t][w]; ys[t] = y; }
+  double rz = 0, zl = 0;
+  if (tl < m) {
+    zl = (((zpart[sg][0][tl] + zpart[sg][1][tl]) + (zpart[sg][2][tl] + zpart[sg][3][tl])) + ((zpart[sg][4][tl] + zpart[sg][5][tl]) + (zpart[sg][6][tl] + zpart[sg][7][tl])));
+    rz = rc[sg][tl] * zl;
+  }
+  rz = wave_sum(rz);
+  if (lane == 0) red[wv] = rz;
+  __syncthreads();
+  if (tl < m) {
+    const double w1 = coarse_hat_t(s0 + tl / 6, d.agg), w0 = 1.0 - w1;
+    double zc = 0;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) zc += Prow[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
+    d.z[g] = zl + zc;
+  }
+  if (tl == 0 && c < n_clu) {
+    d.prz[(k + 1) & 1][c] = ((red[4 * sg] + red[4 * sg + 1]) + red[4 * sg + 2]) + red[4 * sg + 3];
+    if (c == 0) d.pcg_flag[1] = k + 1;
+  }
+  if (t == 0) {
+    double sv = 0;
+    for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
+    if (agg == d.mk_na - 1) for (int rr = 0; rr < 6; rr++) sv += rcs[6 * (agg + 1) + rr] * ys[6 + rr];
+    d.mk_cry[(k + 1) & 1][2 * agg] = sv;
+    if (2 * agg + 1 < n_clu) d.mk_cry[(k + 1) & 1][2 * agg + 1] = 0.0;
+  }
+}
+
 // Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per INTERVAL (two clusters) after ba_pcg_init_tiles / ba_pcg_update:
 // rc = P^T r per coarse node (the first-node parts of the node's interval's two clusters + the second-node parts of the previous interval's),
 // y = Ac^-1[rows of the two nodes of the interval] rc (every interval recomputes these 12 values: 12 x Nc multiply-adds, cheaper than another
@@ -1511,6 +1692,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
     }
   }
   __syncthreads();
+  if (agg == 0 && d.mk_rc[par]) for (int e = t; e < nca; e += kTPB) d.mk_rc[par][e] = rcs[e];   // start of the recurrence of ba_pcg_update_coarse
   {
     // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows with its loads in flight together, then wave
     // trees and the four wave sums in order.
@@ -3332,12 +3514,16 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
             if (d.sym_T) hipLaunchKernelGGL(ba_pcg_spmv_sym, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
-            else hipLaunchKernelGGL(ba_pcg_spmv, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            else if (d.mk_on && d.mk_qpart) hipLaunchKernelGGL(ba_pcg_spmv<true>, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            else hipLaunchKernelGGL(ba_pcg_spmv<false>, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
           }
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
-            hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
+            if (d.mk_on && d.mk_qpart) hipLaunchKernelGGL(ba_pcg_update_coarse, dim3(d.mk_na), dim3(kUpd2TPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, k);
+            else {
+              hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+              if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
+            }
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));

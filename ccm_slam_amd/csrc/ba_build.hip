@@ -866,7 +866,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     };
     // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device and every unit's lists fit its LDS
     ba->pers_grid = 0;
-    d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_Ainv32 = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
+    d.mk_cpart = nullptr; d.mk_qpart = nullptr; d.mk_rc[0] = d.mk_rc[1] = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_Ainv32 = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
     if (pers_try && !hs.pers_bad) {
       BB_RC(keep_get(ba, 4 + 2 * 16 + 4 * 512, &ba->d_pers_bar, true));   // abort flag + debug clocks (workgroup 0's phases; then per workgroup the time spent in the two exchanges)
       BB_RC(keep_get(ba, 4 * (size_t)pers_grid_want, &ba->d_pers_part, true));   // [2][2][grid] slot words
@@ -882,6 +882,13 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       double *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
       BB_RC(keep_get(ba, 24 * (size_t)(na + 1), &p1, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p2, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p3, true));
       d.mk_cpart = p1; d.mk_cry[0] = p2; d.mk_cry[1] = p3;
+      // (opt-in: measured on the 10 000-keyframe map, product 46 -> 53.7 us with the P^T q parts, update + coarse correction 9.9 + 12.3 + a gap -> 20.1 us in one kernel:
+      // 151.0 against 151.7 ms per call on one box — what the saved launch gives, the product's extra epilogue takes)
+      if (getenv("CCM_BA_MK_FUSED") && atoi(getenv("CCM_BA_MK_FUSED")) != 0 && !(getenv("CCM_BA_SPMV_SYM") && atoi(getenv("CCM_BA_SPMV_SYM")) != 0) && agg % 8 == 0) {
+        double *pq = nullptr, *r0 = nullptr, *r1 = nullptr;
+        BB_RC(keep_get(ba, (size_t)(2 * (agg / 8)) * 6 * (size_t)(na + 1), &pq, true)); BB_RC(keep_get(ba, 6 * (size_t)(na + 1), &r0, true)); BB_RC(keep_get(ba, 6 * (size_t)(na + 1), &r1, true));
+        d.mk_qpart = pq; d.mk_rc[0] = r0; d.mk_rc[1] = r1;
+      }
       d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv32, false)); d.mk_Ainv32 = ba->d_cAinv32;
     }

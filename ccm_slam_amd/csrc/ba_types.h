@@ -109,6 +109,10 @@ struct BaDev {
   int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
   // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
   double* mk_cpart;          // [4][6 (na + 1)] restriction parts P^T r, node-major: slot 0 / 1 = first-node part of cluster 2n / 2n + 1, slot 2 / 3 = second-node part of cluster 2n - 2 / 2n - 1
+  // round 4: the coarse residual follows the recurrence of r (P^T r <- P^T r - alpha P^T q), so the multi-kernel PCG runs TWO kernels per iteration: ba_pcg_spmv also
+  // leaves P^T q of its 8 rows, ba_pcg_update_coarse does the update AND the coarse correction (nullptr: three kernels, ba_pcg_update + ba_pcg_coarse_apply)
+  double* mk_qpart;          // [2 agg/8][6 (na + 1)] node-major: first-node parts of the interval's agg/8 row groups, then second-node parts of the previous interval's
+  double* mk_rc[2];          // [6 (na + 1)] coarse residual P^T r by iteration parity
   double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
   const double* mk_P;        // [Cp][36] prolongation blocks
   const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse

@@ -456,24 +456,29 @@ def test_camera_counts_around_the_persistent_solvers_limit(ctx, oracle_lib, kfs)
 
 
 @pytest.mark.gpu
-def test_both_products_of_the_multi_kernel_solver_agree(ctx, monkeypatch):
-    """ba_pcg_spmv_sym (every stored block read once: S_ij p_j for row i and S_ij^T p_i for row j from the same registers, the second through sym_T) against
-    ba_pcg_spmv (CCM_BA_SPMV_SYM=0: every row reads its lower blocks transposed) on a 2300-keyframe map: the same LM path, poses to 5e-9 (the two differ in
-    summation order only)."""
+def test_the_forms_of_the_multi_kernel_solver_agree(ctx, monkeypatch):
+    """The default multi-kernel PCG (three kernels per iteration, every row reads its lower blocks transposed) against its two opt-in forms on a 2300-keyframe map:
+    CCM_BA_SPMV_SYM=1 (ba_pcg_spmv_sym: every stored block read once, S_ij^T p_i handed to row j through sym_T) and CCM_BA_MK_FUSED=1 (ba_pcg_update_coarse: update and
+    coarse correction in one kernel, the coarse residual following r's recurrence with P^T q from the product kernel).  The same LM path, poses to 5e-9 (they differ in
+    summation order / in rounding of the coarse residual only)."""
     prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=2300, n_points=40 * 2300, seed=4242)
     res = []
-    for sym in ("1", "0"):
-        monkeypatch.setenv("CCM_BA_SPMV_SYM", sym)
+    for env in ({}, {"CCM_BA_SPMV_SYM": "1"}, {"CCM_BA_MK_FUSED": "1"}):
+        for k in ("CCM_BA_SPMV_SYM", "CCM_BA_MK_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         h = optimizer.BAHandle(ctx, prob)
         st = h.run(4)
         cam, pts, _, _ = h.download()
         h.close()
         res.append((st, cam, pts))
-    (s1, c1, p1), (s0, c0, p0) = res
-    assert (s1.iters_done, s1.lm_trials) == (s0.iters_done, s0.lm_trials)
-    assert abs(s1.chi2_final / s0.chi2_final - 1) < 1e-9
-    assert np.abs(c1 - c0).max() < 5e-9, np.abs(c1 - c0).max()
-    assert np.abs(p1 - p0).max() < 1e-7
+    s0, c0, p0 = res[0]
+    for s1, c1, p1 in res[1:]:
+        assert (s1.iters_done, s1.lm_trials) == (s0.iters_done, s0.lm_trials)
+        assert abs(s1.chi2_final / s0.chi2_final - 1) < 1e-9
+        assert np.abs(c1 - c0).max() < 5e-9, np.abs(c1 - c0).max()
+        assert np.abs(p1 - p0).max() < 1e-7
 
 
 # ---- full-length parity on the BASELINE global-BA configurations -------------------------------------------------------------
