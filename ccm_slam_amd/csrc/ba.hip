@@ -1374,8 +1374,9 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 2, kWave);
 #pragma unroll
         for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 1, kWave);
+        // slots of 64 bytes (6 values + 2 zeros), written whole by the 8 lanes of the group: a 48-byte store leaves a partial line to be merged at the memory side
         const int q3 = r & 3;
-        if (q3 < 3) d.sym_T[6 * (size_t)dst + (hi ? 3 : 0) + q3] = q3 == 0 ? kp[0] : q3 == 1 ? kp[1] : kp[2];
+        d.sym_T[8 * (size_t)dst + (q3 < 3 ? (hi ? 3 : 0) + q3 : (hi ? 7 : 6))] = q3 == 0 ? kp[0] : q3 == 1 ? kp[1] : q3 == 2 ? kp[2] : 0.0;
       }
     }
   }
@@ -1428,12 +1429,12 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
     const int cam = s0 + t / 6;
     const int ro0 = d.row_off[cam], ro1 = d.row_off[cam + 1], rb0 = d.rowblk_off[cam], rb1 = d.rowblk_off[cam + 1];
     const int nl = (ro1 - ro0) - 1 - (rb1 - rb0);
-    const double* Tp = d.sym_T + 6 * (size_t)(ro0 - cam - rb0) + t % 6;
+    const double* Tp = d.sym_T + 8 * (size_t)(ro0 - cam - rb0) + t % 6;
     double ql = 0;
     for (int k0 = 0; k0 < nl; k0 += 16) {
       double tv[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) tv[u] = k0 + u < nl ? Tp[6 * (size_t)(k0 + u)] : 0.0;
+      for (int u = 0; u < 16; u++) tv[u] = k0 + u < nl ? Tp[8 * (size_t)(k0 + u)] : 0.0;
 #pragma unroll
       for (int u = 0; u < 16; u++) if (k0 + u < nl) ql += tv[u];
     }

@@ -893,11 +893,11 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv32, false)); d.mk_Ainv32 = ba->d_cAinv32;
     }
     d.sym_dst = nullptr; d.sym_T = nullptr;
-    // (opt-in: measured on the 10 000-keyframe map, 45.1 + 13.8 us per CG iteration for product + update against 47 + 9.9 with every block read twice — the product runs at
-    // the same ~4 TB/s either way and the 48-byte scattered stores and their gather cost what the halved block traffic saves: 146.4 against 144.2 ms per call)
+    // (opt-in: measured on the 10 000-keyframe map, 41.6 + 14.3 us per CG iteration for product + update against 46.5 + 9.9 with every block read twice — the scattered
+    // stores (64-byte slots; 48-byte slots: 45.1 us) and their gather in the update cost what the halved block traffic saves: 141.8 against 142.4 ms per call on one box)
     if (!ba->pers_grid && Cp > kDense2MaxCp && nOff > 0 && getenv("CCM_BA_SPMV_SYM") && atoi(getenv("CCM_BA_SPMV_SYM")) != 0) {
       int* p_dst = nullptr; double* p_T = nullptr;
-      BB_RC(keep_get(ba, (size_t)nOff, &p_dst)); BB_RC(keep_get(ba, 6 * (size_t)nOff, &p_T));
+      BB_RC(keep_get(ba, (size_t)nOff, &p_dst)); BB_RC(keep_get(ba, 8 * (size_t)nOff, &p_T));
       hipLaunchKernelGGL(bb_sym_dst, dim3(grid_for(Cp)), dim3(kB), 0, st, Cp, d.row_off, d.rowblk_off, d.row_blk, p_dst);
       d.sym_dst = p_dst; d.sym_T = p_T;
     }

@@ -87,7 +87,7 @@ struct BaDev {
   // symmetric product of the multi-kernel PCG (round 4; nullptr: every row reads its lower blocks transposed, ba_pcg_spmv): the row of an upper block (i, j) also forms
   // S_ij^T p_i and stores it at the block's place among row j's lower entries; ba_pcg_update adds a row's lower parts to q
   const int* sym_dst;        // [nOff] for the off-diagonal block: low_off[j] + its rank among row j's lower entries
-  double* sym_T;             // [nOff][6]
+  double* sym_T;             // [nOff][8]: 6 values + 2 zeros, one 64-byte line per slot
   // PCG
   double *x, *r, *z, *q, *p[2];
   float* Wc;                 // [n_clusters][96*96] explicit inverses of the damped cluster blocks, multi-kernel PCG; f32: only a preconditioner (offline: the same CG iteration counts as f64), half the 74 KB a cluster re-reads in every CG iteration
