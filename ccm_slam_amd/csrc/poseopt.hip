@@ -95,9 +95,19 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
     double* base = sm + kPoseRed;
     double* lx = base; double* lo = base + 3 * (size_t)a.n; double* li = base + 5 * (size_t)a.n; double* le = base + 6 * (size_t)a.n;
     uint8_t* lb = reinterpret_cast<uint8_t*>(base + 8 * (size_t)a.n);
-    for (int i = tid; i < 3 * a.n; i += kPoseThreads) lx[i] = a.Xw[i];
-    for (int i = tid; i < 2 * a.n; i += kPoseThreads) lo[i] = a.obs[i];
-    for (int i = tid; i < a.n; i += kPoseThreads) li[i] = a.info[i];
+    // [Xw | obs | info] are contiguous in the device block and in LDS alike: one flat copy of 6 n doubles, 8 loads per thread in flight before the first LDS store (round 4:
+    // as three plain loops the staging was ~8 dependent memory round trips, one per iteration)
+    {
+      const double* src = a.Xw;   // = din of ccm_pose_optimize
+      const int n6 = 6 * a.n;
+      for (int b0 = 0; b0 < n6; b0 += 8 * kPoseThreads) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = b0 + u * kPoseThreads + tid; v[u] = i < n6 ? src[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = b0 + u * kPoseThreads + tid; if (i < n6) base[i] = v[u]; }
+      }
+    }
     a.Xw = lx; a.obs = lo; a.info = li; a.err = le;
     a.level = lb; a.robust = lb + a.n; a.outlier = lb + 2 * (size_t)a.n;
     __syncthreads();
@@ -285,12 +295,19 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   memcpy(hin, Xw, 3 * (size_t)n * sizeof(double));
   memcpy(hin + 3 * (size_t)n, obs, 2 * (size_t)n * sizeof(double));
   memcpy(hin + 5 * (size_t)n, info, (size_t)n * sizeof(double));
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
+  const size_t lds_full = kPoseRed * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+  const int use_lds = lds_full <= 150 * 1024;
+  // (round 4) a problem that is staged in LDS touches its inputs once and its outputs once: the kernel reads them from / writes them to the PINNED HOST block itself (same
+  // layout), which takes the two copy commands and their latency out of the call (0.147 -> ~0.13 ms for 300 edges).  CCM_POSEOPT_COPY=1: through the device block as before.
+  static const bool copy_env = getenv("CCM_POSEOPT_COPY") && atoi(getenv("CCM_POSEOPT_COPY")) != 0;
+  const bool zero_copy = use_lds && !copy_env;
+  if (zero_copy) {
+    a.cam = h; a.n_bad = (int*)(h + 7); a.outlier = (uint8_t*)(h + 8);
+    a.Xw = hin; a.obs = hin + 3 * (size_t)n; a.info = hin + 5 * (size_t)n;
+  } else CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
-    // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
-    const size_t lds_full = kPoseRed * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
-    const int use_lds = lds_full <= 150 * 1024;
     const size_t lds_bytes = use_lds ? lds_full : kPoseRed * sizeof(double);
     if (lds_bytes > 64 * 1024) {
       CCM_LDS_ATTR(ctx, CCM_LDS_POSEOPT, poseopt_kernel, 150 * 1024);
@@ -299,7 +316,7 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   uint8_t* h_out = (uint8_t*)(h + 8);
-  CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, (8 + n_ob) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (!zero_copy) CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, (8 + n_ob) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(cam_qt, h, 7 * sizeof(double));
   memcpy(outlier, h_out, (size_t)n);
