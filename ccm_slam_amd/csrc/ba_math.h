@@ -122,6 +122,44 @@ BA_HD BaPose ba_oplus(const double u[6], const BaPose& T) {
   return r;
 }
 
+// The same update for the single-workgroup LM kernels, where it sits on the serial path of every trial (pose optimisation: ~45 trials per call, every lane executing it
+// redundantly): ba_oplus is ~380 mostly dependent f64 instructions (sincos, four square roots, four divisions, a rotation matrix turned into a quaternion) ~ 1 us.
+// For 1e-5 <= theta < 0.5 — every LM step that matters — the rotation part of exp is written directly as the unit quaternion (omega sin(theta/2)/theta, cos(theta/2)) and
+// the coefficients sin(theta/2)/theta, cos(theta/2), (1 - cos theta)/theta^2, (theta - sin theta)/theta^3 are even power series in theta^2 (truncation < 1e-17 relative
+// at theta = 0.5; three independent Horner chains), so no sincos, no matrix -> quaternion conversion and one normalisation are left.  Same rotation as ba_oplus to 1 ulp; the translation
+// differs by up to 1e-11 relative, because the closed forms (1 - cos t)/t^2 and (t - sin t)/t^3 cancel for small angles and the series do not (tests/test_ba_math_host.py builds
+// both for the host and compares them over 2 000 000 updates); outside the range (g2o's small-angle branch R = I + Om + Om^2 below 1e-5 included) it IS ba_oplus.
+BA_HD BaPose ba_oplus_fast(const double u[6], const BaPose& T) {
+  const double o0 = u[0], o1 = u[1], o2 = u[2];
+  const double x = o0 * o0 + o1 * o1 + o2 * o2;          // theta^2
+  if (!(x >= 1e-10 && x < 0.25)) return ba_oplus(u, T);
+  const double y = 0.25 * x;                               // (theta / 2)^2
+  // sin(h)/h = sum (-1)^k y^k / (2k+1)!,  cos(h) = sum (-1)^k y^k / (2k)!   (h = theta / 2, y <= 0.0625)
+  const double sh = 1.0 + y * (-1.0 / 6 + y * (1.0 / 120 + y * (-1.0 / 5040 + y * (1.0 / 362880 + y * (-1.0 / 39916800 + y * (1.0 / 6227020800.0))))));
+  const double cw = 1.0 + y * (-1.0 / 2 + y * (1.0 / 24 + y * (-1.0 / 720 + y * (1.0 / 40320 + y * (-1.0 / 3628800 + y * (1.0 / 479001600.0 + y * (-1.0 / 87178291200.0)))))));
+  // b = (1 - cos theta)/theta^2 = sum (-1)^k x^k / (2k+2)!,  c = (theta - sin theta)/theta^3 = sum (-1)^k x^k / (2k+3)!   (x < 0.25)
+  const double b = 1.0 / 2 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600.0 + x * (1.0 / 87178291200.0 + x * (-1.0 / 20922789888000.0)))))));
+  const double c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0 + x * (1.0 / 1307674368000.0 + x * (-1.0 / 355687428096000.0)))))));
+  const double hs = 0.5 * sh;                              // sin(theta/2) / theta
+  BaPose E;
+  E.qx = hs * o0; E.qy = hs * o1; E.qz = hs * o2; E.qw = cw;   // unit up to rounding; cw > 0.96
+  // V upsilon = upsilon + b (omega x upsilon) + c (omega x (omega x upsilon))
+  const double w0 = o1 * u[5] - o2 * u[4], w1 = o2 * u[3] - o0 * u[5], w2 = o0 * u[4] - o1 * u[3];
+  const double z0 = o1 * w2 - o2 * w1, z1 = o2 * w0 - o0 * w2, z2 = o0 * w1 - o1 * w0;
+  E.tx = u[3] + b * w0 + c * z0; E.ty = u[4] + b * w1 + c * z1; E.tz = u[5] + b * w2 + c * z2;
+  BaPose r;
+  const double tv[3] = {T.tx, T.ty, T.tz};
+  double rt[3];
+  ba_qrot(E.qx, E.qy, E.qz, E.qw, tv, rt);
+  r.tx = E.tx + rt[0]; r.ty = E.ty + rt[1]; r.tz = E.tz + rt[2];
+  r.qw = E.qw * T.qw - E.qx * T.qx - E.qy * T.qy - E.qz * T.qz;
+  r.qx = E.qw * T.qx + E.qx * T.qw + E.qy * T.qz - E.qz * T.qy;
+  r.qy = E.qw * T.qy + E.qy * T.qw + E.qz * T.qx - E.qx * T.qz;
+  r.qz = E.qw * T.qz + E.qz * T.qw + E.qx * T.qy - E.qy * T.qx;
+  ba_normalize_rotation(r);
+  return r;
+}
+
 // Huber: rho0 (robustified chi2) and rho1 (weight)
 BA_HD void ba_huber(double e2, double delta, double& rho0, double& rho1) {
   // the reference's g2o fork keeps delta^2 in a FLOAT member (robust_kernel_impl.h:84, set in RobustKernelHuber::setDelta, .cpp:65-69):

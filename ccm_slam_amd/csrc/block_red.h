@@ -76,6 +76,34 @@ struct BlockRedT {
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = bcast_lane(v, k);   // entry 27 is free for a 28th value (e.g. a chi2 partial)
   }
+  // 28 values at once THROUGH LDS (round 4).  The halving butterfly above is six dependent levels of cross-lane moves (ds_bpermute: 1.35 us per reduction, measured with the
+  // phase clocks of poseopt.hip: 26 reductions = 35 of the kernel's 115 us).  Here every thread stores its 28 values column-wise ([28][64 NW + 8]: the row pad keeps the rows
+  // a half-wave reads on different banks), 224 threads add 64 NW / 8 entries each (value = t / 8, every 8th entry from t % 8, four running sums), three cross-lane steps join
+  // the 8 parts, and every thread reads the 28 totals back (LDS broadcast): two barriers, 1.15 us.  tr: LDS [kTrDoubles], not shared with `buf`.
+  static constexpr int kTrCols = NW * 64, kTrStride = kTrCols + 8, kTrDoubles = 28 * kTrStride + 32;
+  __device__ __forceinline__ void sum28_lds(double* acc /* [32], entries 28..31 unused */, double* tr) {
+    static_assert(NW * 64 >= 224, "sum28_lds: 224 threads add the columns");
+    const int t = wave * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 28; k++) tr[k * kTrStride + t] = acc[k];
+    __syncthreads();
+    double s = 0.0;
+    if (t < 224) {
+      const double* row = tr + (t >> 3) * kTrStride + (t & 7);
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+      for (int i = 0; i < kTrCols / 8; i += 4) { s0 += row[8 * i]; s1 += row[8 * (i + 1)]; s2 += row[8 * (i + 2)]; s3 += row[8 * (i + 3)]; }
+      s = (s0 + s1) + (s2 + s3);
+    }
+    s += __shfl_xor(s, 1, kWave); s += __shfl_xor(s, 2, kWave); s += __shfl_xor(s, 4, kWave);
+    double* out = tr + 28 * kTrStride;
+    if (t < 224 && (t & 7) == 0) out[t >> 3] = s;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = out[k];
+    // (no trailing barrier: the columns are rewritten only by threads that have passed the second barrier, i.e. after every column read; `out` lies outside the columns and is
+    // rewritten only after the NEXT call's first barrier, i.e. after every thread's reads of it)
+  }
   // up to 64 values (NV of them meaningful): halving butterfly 32+16+8+4+2+1 = 63 cross-lane moves, lane l then owns
   // the wave total of value l
   template <int NV>

@@ -53,7 +53,7 @@ int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
                                __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
   } while (0)
 
-enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT, CCM_LDS_BA_DENSE2, CCM_LDS_ORB_OCT, CCM_LDS_ORB_OCT2, CCM_LDS_BA_ROW3, CCM_LDS_BA_ROW4 };
+enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT, CCM_LDS_BA_DENSE2, CCM_LDS_ORB_OCT, CCM_LDS_ORB_OCT2, CCM_LDS_BA_ROW3, CCM_LDS_BA_ROW4, CCM_LDS_POSEOPT1 };
 #define CCM_LDS_ATTR(ctx, bit, func, bytes)                                                                              \
   do {                                                                                                                   \
     if (!((ctx)->lds_attr_done & (1u << (bit)))) {                                                                       \

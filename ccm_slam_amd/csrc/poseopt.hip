@@ -30,7 +30,9 @@ struct PoseOptArgs {
   uint8_t* robust;      // scratch [n]
   uint8_t* outlier;     // out [n]
   int* n_bad;           // out
+  long long* dbg;       // CCM_POSEOPT_DBG: phase clocks of thread 0 (10 ns ticks): [0] staging [1] edge passes [2] 27-value reductions [3] solve + update [4] classification [5] passes [6] whole kernel
 };
+#define POSE_TICK(slot) { if (timing) { const long long tn_ = wall_clock64(); a.dbg[slot] += tn_ - tk; tk = tn_; } }
 
 __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
   double L[36], inv[6];
@@ -79,10 +81,24 @@ __device__ __forceinline__ bool chol6_solve(const double* H, double lambda, cons
 // Waves per workgroup, measured on a tracked frame (~1000 edges, host-API time per call): 2 waves 0.176 ms, 4 waves
 // 0.153 ms, 8 waves 0.180 ms — more waves shorten the f64 edge pass (~250 instructions per edge) but lengthen the two
 // block reductions and barriers of every LM trial.
-constexpr int kPoseWaves = 4, kPoseThreads = 64 * kPoseWaves, kPoseRed = 2 * kPoseWaves * 64;
+// (round 4, phase clocks CCM_POSEOPT_DBG=1 on 300 edges: 26 passes; per pass edges 1.68 us — 44 threads own two edges and a lone wave per SIMD issues a dependent f64 instruction
+// every ~8 cycles —, the 27-value reduction 1.35 us, solve + update 1.9 us per trial.)  TR: the 27 sums go through LDS (BlockRedT::sum28_lds: 1.15 us, and the kernel around it
+// schedules better: 0.141 -> 0.126 ms per call at 300 edges, 0.187 -> 0.144 at 150, 0.278 -> 0.257 at 1000) whenever its 62 KB transpose block fits beside the staged problem.
+// Measured and dropped: 8 waves above 256 edges with the serial solve + update on waves 0..3 only and the result broadcast through LDS — the edge passes shrink (43.6 -> 29.6 us)
+// but the reductions double (58 us: a cross-lane pre-step and eight waves at every barrier) and the call is slower at every size tried (150 / 300 / 600 / 1000 edges).
+constexpr int kPoseWaves = 4, kPoseThreads = 64 * kPoseWaves;
+template <bool TR> struct PoseCfg {
+  static constexpr int kRed = 2 * kPoseWaves * 64 + (TR ? BlockRedT<kPoseWaves>::kTrDoubles : 0);   // doubles at the head of the LDS: [sum1 / sum27 buffers | transpose block]
+};
+template <bool TR>
 __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, int use_lds) {
+  constexpr int kPoseRed = PoseCfg<TR>::kRed;
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* const tr = sm + 2 * kPoseWaves * 64;
   const int tid = threadIdx.x;
+  const bool timing = a.dbg != nullptr && tid == 0;
+  long long tk = timing ? wall_clock64() : 0;
+  const long long tk0 = tk;
   BlockRedT<kPoseWaves> red{sm, 0, tid & 63, tid >> 6};
   const double delta = (double)(float)sqrt(5.991);
   const double K4[4] = {a.K[0], a.K[1], a.K[2], a.K[3]};
@@ -113,6 +129,7 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
     __syncthreads();
   }
   for (int i = tid; i < a.n; i += kPoseThreads) { a.level[i] = 0; a.robust[i] = 1; a.outlier[i] = 0; a.err[2 * i] = 0; a.err[2 * i + 1] = 0; }
+  POSE_TICK(0)
   BaPose T = T0;
   int nBad = 0;
 
@@ -172,7 +189,10 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
             acc[21 + r] += v;
           }
         }
-        red.sum27(acc);
+        POSE_TICK(1)
+        if (TR) red.sum28_lds(acc, tr); else red.sum27(acc);
+        if (timing) a.dbg[5] += 1;
+        POSE_TICK(2)
       };
       for (int iter = 0; iter < 10; iter++) {
         if (!lin_current) linearise(T);
@@ -204,7 +224,8 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
 #pragma unroll
             for (int k = 0; k < 6; k++) xs[k] = 0;
           }
-          T = ba_oplus(xs, T);
+          T = ba_oplus_fast(xs, T);              // (round 4: the update is ~1 us of every trial's serial path in its closed form, ba_math.h)
+          POSE_TICK(3)
           linearise(T);
           double tempChi = acc[27];
           if (!ok2) tempChi = DBL_MAX;
@@ -251,10 +272,12 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
       if (it == 2) a.robust[i] = 0;
     }
     nBad = (int)red.sum1(bad);
+    POSE_TICK(4)
     if (a.n < 10) break;
   }
   if (use_lds) for (int i = tid; i < a.n; i += kPoseThreads) g_outlier[i] = a.outlier[i];
   if (tid == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
+  if (timing) a.dbg[6] += wall_clock64() - tk0;
 }
 
 }  // namespace
@@ -289,6 +312,14 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   uint8_t* bytes_base = (uint8_t*)(d + nd);
   a.level = bytes_base; a.robust = bytes_base + n;
   for (int k = 0; k < 4; k++) a.K[k] = K[k];
+  static const bool dbg_env = getenv("CCM_POSEOPT_DBG") != nullptr;
+  static long long* d_dbg = nullptr;
+  a.dbg = nullptr;
+  if (dbg_env) {
+    if (!d_dbg) CCM_HIP_CHECK(ctx, hipMalloc(&d_dbg, 8 * sizeof(long long)));
+    CCM_HIP_CHECK(ctx, hipMemsetAsync(d_dbg, 0, 8 * sizeof(long long), ctx->stream));
+    a.dbg = d_dbg;
+  }
   memcpy(h, cam_qt, 7 * sizeof(double));
   h[7] = 0;
   double* hin = h + 8 + n_ob;
@@ -296,7 +327,12 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   memcpy(hin + 3 * (size_t)n, obs, 2 * (size_t)n * sizeof(double));
   memcpy(hin + 5 * (size_t)n, info, (size_t)n * sizeof(double));
   // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
-  const size_t lds_full = kPoseRed * sizeof(double) + 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+  const size_t staged = 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
+  // the 27 sums through LDS whenever the transpose block fits beside the staged problem (up to ~1290 edges); CCM_POSEOPT_SHAPE=0: the cross-lane reduction always
+  static const bool shape0_env = getenv("CCM_POSEOPT_SHAPE") && atoi(getenv("CCM_POSEOPT_SHAPE")) == 0;
+  const bool tr_red = !shape0_env && PoseCfg<true>::kRed * sizeof(double) + staged <= 150 * 1024;
+  const size_t red_bytes = (tr_red ? PoseCfg<true>::kRed : PoseCfg<false>::kRed) * sizeof(double);
+  const size_t lds_full = red_bytes + staged;
   const int use_lds = lds_full <= 150 * 1024;
   // (round 4) a problem that is staged in LDS touches its inputs once and its outputs once: the kernel reads them from / writes them to the PINNED HOST block itself (same
   // layout), which takes the two copy commands and their latency out of the call (0.147 -> ~0.13 ms for 300 edges).  CCM_POSEOPT_COPY=1: through the device block as before.
@@ -308,16 +344,25 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   } else CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
-    const size_t lds_bytes = use_lds ? lds_full : kPoseRed * sizeof(double);
-    if (lds_bytes > 64 * 1024) {
-      CCM_LDS_ATTR(ctx, CCM_LDS_POSEOPT, poseopt_kernel, 150 * 1024);
+    const size_t lds_bytes = use_lds ? lds_full : red_bytes;
+    if (tr_red) {
+      CCM_LDS_ATTR(ctx, CCM_LDS_POSEOPT1, poseopt_kernel<true>, 150 * 1024);
+      hipLaunchKernelGGL(poseopt_kernel<true>, dim3(1), dim3(kPoseThreads), lds_bytes, ctx->stream, a, use_lds);
+    } else {
+      if (lds_bytes > 64 * 1024) { CCM_LDS_ATTR(ctx, CCM_LDS_POSEOPT, poseopt_kernel<false>, 150 * 1024); }
+      hipLaunchKernelGGL(poseopt_kernel<false>, dim3(1), dim3(kPoseThreads), lds_bytes, ctx->stream, a, use_lds);
     }
-    hipLaunchKernelGGL(poseopt_kernel, dim3(1), dim3(kPoseThreads), lds_bytes, ctx->stream, a, use_lds);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   uint8_t* h_out = (uint8_t*)(h + 8);
   if (!zero_copy) CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, (8 + n_ob) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (dbg_env) {
+    long long hd[8];
+    CCM_HIP_CHECK(ctx, hipMemcpy(hd, d_dbg, sizeof(hd), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[ccm_pose_optimize] n %d: kernel %.1f us = staging %.1f + %lld passes (edges %.1f, reductions %.1f) + solve/update %.1f + classification %.1f\n", n, hd[6] * 0.01, hd[0] * 0.01,
+            hd[5], hd[1] * 0.01, hd[2] * 0.01, hd[3] * 0.01, hd[4] * 0.01);
+  }
   memcpy(cam_qt, h, 7 * sizeof(double));
   memcpy(outlier, h_out, (size_t)n);
   int n_bad = 0;
