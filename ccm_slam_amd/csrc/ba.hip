@@ -3041,7 +3041,9 @@ __global__ __launch_bounds__(kTPB) void ba_backsub_chi2_e(BaDev d, int cur, doub
 // stop_local / abort_local: this rank's view of the caller's stop flag and of a failed persistent-PCG launch; together with the
 // kernel-side give-up flag they ride in the same all-reduce as chi2, so that every rank of a sharded run takes the same
 // decision (a rank leaving the LM loop alone would leave its peers waiting in the next collective)
-__global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_local, int abort_local, int pers_trial) {
+// h_out != nullptr (one rank): the eight read-back words also go straight to the handle's pinned host block, followed by `ticket` (system-scope release): the host polls the
+// ticket instead of queueing a 64-byte copy and waiting for the stream (read_scalars_polled)
+__global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_local, int abort_local, int pers_trial, double* h_out, unsigned long long ticket) {
   __shared__ double lds[kTPB / kWave];
   double chi = 0, sc = 0;
   for (int i = threadIdx.x; i < d.n_part; i += kTPB) { chi += d.part_pt[2 * i]; sc += d.part_pt[2 * i + 1]; }
@@ -3051,7 +3053,13 @@ __global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_loca
   if (threadIdx.x == 0) {
     d.scal[0] = a; d.scal[1] = b;
     d.scal[2] = stop_local ? 1.0 : 0.0;
-    d.scal[3] = (abort_local || (pers_trial && d.pcg_flag[3])) ? 1.0 : 0.0;
+    const double s3 = (abort_local || (pers_trial && d.pcg_flag[3])) ? 1.0 : 0.0;
+    d.scal[3] = s3;
+    if (h_out) {
+      h_out[0] = a; h_out[1] = b; h_out[2] = stop_local ? 1.0 : 0.0; h_out[3] = s3;
+      h_out[4] = d.scal[4]; h_out[5] = d.scal[5]; h_out[6] = d.scal[6]; h_out[7] = d.scal[7];   // [6..7]: the four PCG flags
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(h_out) + 8, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -3251,6 +3259,31 @@ int read_scalars(ccm_ba* ba, double out[6], int flags[4] = nullptr) {
   return CCM_OK;
 }
 
+// The same read-back without a copy command and without waiting for the stream: ba_reduce_scalars wrote the words and then `ticket` into the pinned block (round 4: the
+// 64-byte copy + stream wait were ~25 us of every LM trial, 18 trials per 4-agent call, ~25 per local BA).  CCM_BA_POLL=0: the copy.  A ticket that does not arrive within
+// two seconds falls back to the stream wait (a failed launch must not hang the caller).
+bool poll_enabled() { static const bool on = !(getenv("CCM_BA_POLL") && atoi(getenv("CCM_BA_POLL")) == 0); return on; }
+int read_scalars_polled(ccm_ba* ba, double out[6], int flags[4], unsigned long long ticket) {
+  volatile unsigned long long* tk = reinterpret_cast<volatile unsigned long long*>(ba->h_rb) + 8;
+  bool got = false;
+  for (long spin = 0; !got; spin++) {
+    if (*tk == ticket) { got = true; break; }
+    if ((spin & 0xffff) == 0xffff) {
+      static thread_local double t_start = 0;
+      if (spin == 0xffff) t_start = now_ms();
+      else if (now_ms() - t_start > 2000.0) break;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!got) return read_scalars(ba, out, flags);
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  memcpy(out, ba->h_rb, 6 * sizeof(double));
+  if (flags) memcpy(flags, ba->h_rb + 6, 4 * sizeof(int));
+  return CCM_OK;
+}
+
 // chi2 of the current state (computeActiveErrors + activeRobustChi2)
 int eval_chi2(ccm_ba* ba, double* chi) {
   ccm_ctx* ctx = ba->ctx;
@@ -3261,10 +3294,12 @@ int eval_chi2(ccm_ba* ba, double* chi) {
     else hipLaunchKernelGGL(ba_backsub_chi2, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, ba->cur, 0.0, 1);
   }
   hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
-  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d, ba->stop_local(), 0, 0);
+  const bool poll = ba->nranks == 1 && poll_enabled();
+  const unsigned long long ticket = ++ba->rb_ticket;
+  hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d, ba->stop_local(), 0, 0, poll ? ba->h_rb : (double*)nullptr, ticket);
   RC(ba_allreduce_sum(ba, d.scal, 4));
   double s[6];
-  RC(read_scalars(ba, s));
+  if (poll) { RC(read_scalars_polled(ba, s, nullptr, ticket)); } else { RC(read_scalars(ba, s)); }
   *chi = s[0];
   ba->stop_any = s[2] > 0.0;
   return CCM_OK;
@@ -3547,14 +3582,16 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   // a sharded run repeats the trial on EVERY rank when the persistent kernel gave up (or could not be launched) on ANY rank:
   // the repeat issues the same collectives again, and all ranks must keep bit-identical camera states
+  const bool poll = ba->nranks == 1 && poll_enabled();
+  const unsigned long long ticket = ++ba->rb_ticket;
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_REDUCE);
     hipLaunchKernelGGL(ba_reduce_scalars, dim3(1), dim3(kTPB), 0, ctx->stream, d, ba->stop_local(), (pers_launch_failed && ba->nranks > 1) ? 1 : 0,
-                       pers_trial ? 1 : 0);
+                       pers_trial ? 1 : 0, poll ? ba->h_rb : (double*)nullptr, ticket);
   }
   RC(ba_allreduce_sum(ba, d.scal, 4));
   double s[6];
-  RC(read_scalars(ba, s, small_flags));
+  if (poll) { RC(read_scalars_polled(ba, s, small_flags, ticket)); } else { RC(read_scalars(ba, s, small_flags)); }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   ba->stop_any = s[2] > 0.0;
   // s[3] is summed over the ranks: the persistent kernel gave up (or could not be launched) SOMEWHERE.  Every rank repeats the trial on the multi-kernel

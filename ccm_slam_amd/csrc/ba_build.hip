@@ -847,7 +847,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 8, double)
 #undef AL
     d.pcg_flag = reinterpret_cast<int*>(d.scal + 6);   // [scalars | PCG flags]: one 64-byte read-back per LM trial
-    if (hipHostMalloc(&ba->h_rb, 64, hipHostMallocDefault) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
+    if (hipHostMalloc(&ba->h_rb, 128, hipHostMallocDefault) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
+    memset(ba->h_rb, 0, 128);
     ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
     BB_RC(keep_get(ba, ba->red_count, &ba->d_red, true));
     d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);

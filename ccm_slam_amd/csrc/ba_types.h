@@ -161,7 +161,8 @@ struct ccm_ba {
   double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
   double dinv_done_lambda = -1.0;   // lambda for which the landmark-side linearisation already formed D^-1 (ba_dinv folded in), -1 = none
   double lambda_first = 0; bool coarse_skipped_damped = false;   // the call's first lambda; the coarse level is left out at and above it (lm_trial)
-  double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial
+  double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial, then the ticket ba_reduce_scalars writes after them (read_scalars_polled)
+  unsigned long long rb_ticket = 0;
   int coarse_force = 0;      // CCM_BA_COARSE=always / never (tests), 0 = adaptive
   double *d_cP = nullptr, *d_cA = nullptr, *d_cX = nullptr, *d_cAinv = nullptr, *d_cLinv = nullptr;
   double* d_cparts = nullptr;
