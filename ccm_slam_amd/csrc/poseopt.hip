@@ -13,6 +13,7 @@
 #include "common.h"
 #include "ba_math.h"
 #include "block_red.h"
+#include <chrono>
 #include <cfloat>
 #include <cstring>
 
@@ -30,6 +31,7 @@ struct PoseOptArgs {
   uint8_t* robust;      // scratch [n]
   uint8_t* outlier;     // out [n]
   int* n_bad;           // out
+  unsigned long long* h_ticket; unsigned long long ticket;   // zero-copy calls: written (system scope) after the results are in the pinned block; the host polls it
   long long* dbg;       // CCM_POSEOPT_DBG: phase clocks of thread 0 (10 ns ticks): [0] staging [1] edge passes [2] 27-value reductions [3] solve + update [4] classification [5] passes [6] whole kernel
 };
 #define POSE_TICK(slot) { if (timing) { const long long tn_ = wall_clock64(); a.dbg[slot] += tn_ - tk; tk = tn_; } }
@@ -277,6 +279,11 @@ __global__ __launch_bounds__(kPoseThreads) void poseopt_kernel(PoseOptArgs a, in
   }
   if (use_lds) for (int i = tid; i < a.n; i += kPoseThreads) g_outlier[i] = a.outlier[i];
   if (tid == 0) { ba_store_pose(a.cam, T); *a.n_bad = nBad; }
+  if (a.h_ticket) {   // every thread's result stores are out (system scope) before thread 0 raises the ticket
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(a.h_ticket, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (timing) a.dbg[6] += wall_clock64() - tk0;
 }
 
@@ -338,9 +345,15 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   // layout), which takes the two copy commands and their latency out of the call (0.147 -> ~0.13 ms for 300 edges).  CCM_POSEOPT_COPY=1: through the device block as before.
   static const bool copy_env = getenv("CCM_POSEOPT_COPY") && atoi(getenv("CCM_POSEOPT_COPY")) != 0;
   const bool zero_copy = use_lds && !copy_env;
+  // ... and the host polls a ticket the kernel writes behind its results instead of waiting for the stream (~7 us per call; CCM_POSEOPT_POLL=0: stream wait)
+  static const bool poll_env = !(getenv("CCM_POSEOPT_POLL") && atoi(getenv("CCM_POSEOPT_POLL")) == 0);
+  static thread_local unsigned long long ticket_counter = 0;   // (a ticket only has to differ from the zero written before the launch)
+  volatile unsigned long long* h_ticket = reinterpret_cast<volatile unsigned long long*>(h + n_in);
+  a.h_ticket = nullptr; a.ticket = 0;
   if (zero_copy) {
     a.cam = h; a.n_bad = (int*)(h + 7); a.outlier = (uint8_t*)(h + 8);
     a.Xw = hin; a.obs = hin + 3 * (size_t)n; a.info = hin + 5 * (size_t)n;
+    if (poll_env && !dbg_env) { a.h_ticket = const_cast<unsigned long long*>(h_ticket); a.ticket = ++ticket_counter; *h_ticket = 0; }
   } else CCM_HIP_CHECK(ctx, hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   {
     ccm_prof_scope ps(ctx, CCM_K_POSEOPT);
@@ -356,7 +369,19 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   CCM_HIP_CHECK(ctx, hipGetLastError());
   uint8_t* h_out = (uint8_t*)(h + 8);
   if (!zero_copy) CCM_HIP_CHECK(ctx, hipMemcpyAsync(h, d, (8 + n_ob) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  bool polled = false;
+  if (a.h_ticket) {
+    const auto t_start = std::chrono::steady_clock::now();
+    for (long spin = 0;; spin++) {
+      if (*h_ticket == a.ticket) { polled = true; break; }
+      if ((spin & 0xffff) == 0xffff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > 2.0) break;   // a failed launch must not hang the caller
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  if (!polled) CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (dbg_env) {
     long long hd[8];
     CCM_HIP_CHECK(ctx, hipMemcpy(hd, d_dbg, sizeof(hd), hipMemcpyDeviceToHost));
