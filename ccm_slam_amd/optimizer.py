@@ -242,6 +242,35 @@ def pose_optimization(ctx: Context, cam_qt, Xw, obs, info, K):
     return cam, outl[:n], ninl.value
 
 
+class PoseOptCall:
+    """Call object for ccm_pose_optimize: arguments converted once; run() restores the initial pose (7 doubles) and makes exactly one C-ABI call
+    (bench.py times this; pose_optimization() above spends ~10 us per call in numpy / ctypes conversions).  Results: .cam, .outlier, .n_inlier."""
+
+    def __init__(self, ctx: Context, cam_qt, Xw, obs, info, K):
+        f = lambda a: np.ascontiguousarray(a, np.float64)
+        self.ctx = ctx
+        self._cam0 = f(cam_qt).copy()
+        self.cam = self._cam0.copy()
+        self._in = (f(Xw), f(obs), f(info), f(K))
+        n = self._in[0].shape[0]
+        self.n = n
+        self.outlier = np.zeros(max(n, 1), np.uint8)
+        self._ninl = C.c_int(0)
+        v = lambda a: C.c_void_p(_vp(a))
+        self._args = (ctx.handle, v(self.cam), n, v(self._in[0]), v(self._in[1]), v(self._in[2]), v(self._in[3]), v(self.outlier), C.byref(self._ninl))
+        self._fn = lib().ccm_pose_optimize
+
+    def run(self):
+        self.cam[:] = self._cam0
+        rc = self._fn(*self._args)
+        if rc:
+            check(rc, self.ctx.handle)
+
+    @property
+    def n_inlier(self):
+        return self._ninl.value
+
+
 def sim3_optimization(ctx: Context, sim3, P1c, P2c, obs1, obs2, info1, info2, K1, K2, th2: float = 10.0, fix_scale: bool = False):
     """Optimizer::OptimizeSim3 (Optimizer.cpp:861-1056) through ccm_sim3_optimize.  Returns (sim3[8], inlier flags, nIn)."""
     f = lambda a: np.ascontiguousarray(a, np.float64)
