@@ -90,7 +90,10 @@ struct WinQ { const float* u; const float* v; const float* r; const int* minl; c
 constexpr int kQL = 16;   // lanes per query
 template <int FILL>
 __global__ void frame_window_kernel(int Q, WinQ q, FrameBounds b, const float* xy, const int* oct, const int* cell_off, const int* cell_idx,
-                                    int* cnt, const int* off, int* out_idx, int cap = 0x7fffffff) {
+                                    int* cnt, const int* off, int* out_idx, int cap = 0x7fffffff, const uint32_t* qdesc = nullptr, const uint32_t* tdesc = nullptr,
+                                    uint16_t* out_dist = nullptr) {
+  // FILL with descriptors: the Hamming distance of every candidate is written with its index (round 4: one launch less than running ccm_hamming_csr_dev over the lists
+  // afterwards; the same XOR + popcount of eight words)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid / kQL, sub = gid % kQL;
   if (i >= Q) return;                                       // whole 16-lane groups leave together
@@ -130,7 +133,16 @@ __global__ void frame_window_kernel(int Q, WinQ q, FrameBounds b, const float* x
             if (oct[k] < minLevel) continue;
             if (maxLevel >= 0 && oct[k] > maxLevel) continue;
           }
-          if (fabsf(xy[2 * k] - x) < r && fabsf(xy[2 * k + 1] - y) < r) out_idx[w++] = k;
+          if (fabsf(xy[2 * k] - x) < r && fabsf(xy[2 * k + 1] - y) < r) {
+            if (out_dist) {
+              const uint4* qp = reinterpret_cast<const uint4*>(qdesc + 8 * (size_t)i);
+              const uint4* tp = reinterpret_cast<const uint4*>(tdesc + 8 * (size_t)k);
+              const uint4 ql = qp[0], qh = qp[1], tl = tp[0], th = tp[1];
+              out_dist[w] = (uint16_t)(__builtin_popcount(ql.x ^ tl.x) + __builtin_popcount(ql.y ^ tl.y) + __builtin_popcount(ql.z ^ tl.z) + __builtin_popcount(ql.w ^ tl.w) +
+                                       __builtin_popcount(qh.x ^ th.x) + __builtin_popcount(qh.y ^ th.y) + __builtin_popcount(qh.z ^ th.z) + __builtin_popcount(qh.w ^ th.w));
+            }
+            out_idx[w++] = k;
+          }
         }
       }
       carry += chunk_total;
@@ -354,9 +366,8 @@ extern "C" int ccm_frame_window_search(ccm_frame* f, int Q, const float* u, cons
     // optimistic single-sync path: fill and distances are queued behind the scan without waiting for the total; the
     // fill kernel never writes past cap (queries whose list would cross it are skipped) and the total is checked after
     hipLaunchKernelGGL(frame_window_kernel<1>, dim3(nb), dim3(128), 0, ctx->stream, Q, wq, f->b, f->d_xy, f->d_oct, f->d_cell_off, f->d_cell_idx,
-                       (int*)nullptr, (const int*)d_off, d_idx, (int)std::min<int64_t>(cap, 0x7fffffff));
+                       (int*)nullptr, (const int*)d_off, d_idx, (int)std::min<int64_t>(cap, 0x7fffffff), (const uint32_t*)d_qdesc, (const uint32_t*)f->d_desc, d_dist);
     CCM_HIP_CHECK(ctx, hipGetLastError());
-    if (int rc = ccm_hamming_csr_dev(ctx, d_qdesc, Q, f->d_desc, f->N, d_off, d_idx, cap, d_dist, nullptr, nullptr, nullptr)) return rc;
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, o_dist + 2 * (size_t)cap, hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t total = h_off[Q];
