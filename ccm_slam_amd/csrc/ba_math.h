@@ -135,11 +135,12 @@ BA_HD BaPose ba_oplus_fast(const double u[6], const BaPose& T) {
   if (!(x >= 1e-10 && x < 0.25)) return ba_oplus(u, T);
   const double y = 0.25 * x;                               // (theta / 2)^2
   // sin(h)/h = sum (-1)^k y^k / (2k+1)!,  cos(h) = sum (-1)^k y^k / (2k)!   (h = theta / 2, y <= 0.0625)
-  const double sh = 1.0 + y * (-1.0 / 6 + y * (1.0 / 120 + y * (-1.0 / 5040 + y * (1.0 / 362880 + y * (-1.0 / 39916800 + y * (1.0 / 6227020800.0))))));
-  const double cw = 1.0 + y * (-1.0 / 2 + y * (1.0 / 24 + y * (-1.0 / 720 + y * (1.0 / 40320 + y * (-1.0 / 3628800 + y * (1.0 / 479001600.0 + y * (-1.0 / 87178291200.0)))))));
+  // (Horner steps as explicit fused multiply-adds: four dependent chains of 6 - 7 steps on the serial path)
+  const double sh = fma(y, fma(y, fma(y, fma(y, fma(y, fma(y, 1.0 / 6227020800.0, -1.0 / 39916800), 1.0 / 362880), -1.0 / 5040), 1.0 / 120), -1.0 / 6), 1.0);
+  const double cw = fma(y, fma(y, fma(y, fma(y, fma(y, fma(y, fma(y, -1.0 / 87178291200.0, 1.0 / 479001600.0), -1.0 / 3628800), 1.0 / 40320), -1.0 / 720), 1.0 / 24), -1.0 / 2), 1.0);
   // b = (1 - cos theta)/theta^2 = sum (-1)^k x^k / (2k+2)!,  c = (theta - sin theta)/theta^3 = sum (-1)^k x^k / (2k+3)!   (x < 0.25)
-  const double b = 1.0 / 2 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600.0 + x * (1.0 / 87178291200.0 + x * (-1.0 / 20922789888000.0)))))));
-  const double c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0 + x * (1.0 / 1307674368000.0 + x * (-1.0 / 355687428096000.0)))))));
+  const double b = fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, -1.0 / 20922789888000.0, 1.0 / 87178291200.0), -1.0 / 479001600.0), 1.0 / 3628800), -1.0 / 40320), 1.0 / 720), -1.0 / 24), 1.0 / 2);
+  const double c = fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, fma(x, -1.0 / 355687428096000.0, 1.0 / 1307674368000.0), -1.0 / 6227020800.0), 1.0 / 39916800), -1.0 / 362880), 1.0 / 5040), -1.0 / 120), 1.0 / 6);
   const double hs = 0.5 * sh;                              // sin(theta/2) / theta
   BaPose E;
   E.qx = hs * o0; E.qy = hs * o1; E.qz = hs * o2; E.qw = cw;   // unit up to rounding; cw > 0.96
