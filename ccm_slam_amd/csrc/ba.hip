@@ -2090,7 +2090,7 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
         for (int c = 0; c < 16; c++) {
           double sv = row[c];
 #pragma unroll
-          for (int k = 0; k < c; k++) sv -= row[k] * pers_bcast(row[k], c);
+          for (int k = 0; k < c; k++) sv = fma(-row[k], pers_bcast(row[k], c), sv);   // (fused: the dot product is a serial chain on the pivot path; nothing downstream matches these bits)
           double dd = pers_bcast(sv, c);
           if (!(dd > 0.0)) { bad = true; dd = 1.0; }      // (padding rows of a short cluster carry a unit diagonal)
           const double inv = rsqrt(dd);
@@ -2148,7 +2148,7 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
       for (int r = 0; r < 16; r++) {
         double sv = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < r; k++) sv -= A[(b0 + r) * N + b0 + k] * x[k];
+        for (int k = 0; k < r; k++) sv = fma(-A[(b0 + r) * N + b0 + k], x[k], sv);
         const double dg = A[(b0 + r) * N + b0 + r];
         x[r] = (b0 + r < m) ? sv / dg : 0.0;          // rows beyond the cluster's cameras are padding
       }
