@@ -2065,6 +2065,10 @@ __device__ __noinline__ void pers_factor_dense(double* A, double* Li, int* ibuf,
   // trailing updates 7; then 14 us for L^-1 and 5 us for W).  Tried and dropped (round 2): right-looking diagonal tile with scalar-register
   // broadcasts + the tile's inverse in the same wave + the panel as one MFMA product per tile: 51 us — the 16 dependent pivots
   // (rsqrt, broadcast, update: ~300 cycles each) set the time of a tile whichever way the off-path work is arranged.
+  // Round 4, measured and dropped as well: the same fused updates applied right-looking inside the registers (column c's multiples leave the later columns as 15 - c
+  // independent multiply-adds, so that the next pivot waits for one of them instead of a dot product of c terms; bit-identical): both factorisations of the two-cluster
+  // solve 59.7 -> 79.9 us — the broadcasts of the freshly scaled column (v_readlane into scalar registers, then the wait states before a vector instruction may read them)
+  // land on the pivot path, while the left-looking dot product broadcasts values that were final long before.
   double* invd = Li;   // 16 reciprocal pivots of the current step (Li is all zero otherwise and is restored below)
   {
     typedef double v4d __attribute__((ext_vector_type(4)));
