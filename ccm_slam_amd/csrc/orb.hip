@@ -1278,6 +1278,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     int max_ent = 0;
     std::vector<int16_t> ent;   // 4 x int16 per computed column / row of every level, tile column by tile column, then tile row by tile row
     std::vector<size_t> blk_start; int max_src = 0;
+    bool plan_ok = true;        // the plan is re-checked below against what the kernel assumes; a plan that fails falls back to one launch per level
     auto axis = [&](bool is_x, int tile, std::vector<int>& out) -> int {   // returns the largest extent of a computed range over tiles and levels, fills out[tile][level][4]
       const int nl = o->nlevels;
       std::vector<int> size(nl);
@@ -1286,7 +1287,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
       const int nt = ccm_div_up(size[1], tile);
       out.assign((size_t)4 * nt * nl, 0);
       int max_ext = 1;
-      std::vector<int> a0(nl), a1(nl), c1(nl);
+      std::vector<int> a0(nl), a1(nl), c1(nl), own_end(nl, 0);
       for (int tI = 0; tI < nt; tI++) {
         a0[1] = tI * tile; a1[1] = std::min((tI + 1) * tile, size[1]);
         for (int l = 2; l < nl; l++) {   // owned range: the pixels whose first source pixel is owned one level up (the offset tables are non-decreasing)
@@ -1311,6 +1312,22 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
         max_ent = std::max(max_ent, n_ent);
         blk_start.push_back(ent.size() / 4);
         max_src = std::max(max_src, c1[0] - a0[0]);
+        // what the kernel relies on: (1) the owned ranges of consecutive tiles tile every level without gap or overlap (checked against `own_end`), (2) every computed
+        // pixel's two sources lie inside the previous level's computed range, (3) the level-0 origin is the offset-table formula the kernel evaluates, (4) int16 entries
+        for (int l = 1; l < nl; l++) {
+          if (a0[l] != own_end[l] || a1[l] < a0[l] || c1[l] < a1[l] || c1[l] > size[l]) plan_ok = false;
+          own_end[l] = a1[l];
+          for (int i = a0[l]; i < c1[l]; i++) {
+            const int v = tabs[(is_x ? o->tab_xofs[l] : o->tab_yofs[l]) + i];
+            const int s0 = std::min(std::max(v, 0), size[l - 1] - 1), s1 = std::min(std::max(v + 1, 0), size[l - 1] - 1);
+            if (s0 < a0[l - 1] || s1 >= c1[l - 1] || s1 - a0[l - 1] > 32767) plan_ok = false;
+          }
+        }
+        {
+          const double sc = 1. / ((double)size[1] / size[0]);
+          const float f0 = (float)((tI * tile + 0.5) * sc - 0.5);
+          if (std::min(std::max((int)std::floor(f0), 0), size[0] - 1) != a0[0]) plan_ok = false;
+        }
         for (int l = 1; l < nl; l++)
           for (int i = a0[l]; i < c1[l]; i++) {
             const int v = tabs[(is_x ? o->tab_xofs[l] : o->tab_yofs[l]) + i], wo = (is_x ? o->tab_ialpha[l] : o->tab_ibeta[l]) + 2 * i;
@@ -1318,6 +1335,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
             ent.push_back((int16_t)(s0 - a0[l - 1])); ent.push_back((int16_t)(s1 - a0[l - 1])); ent.push_back(tabs[wo]); ent.push_back(tabs[wo + 1]);
           }
       }
+      for (int l = 1; l < nl; l++) if (own_end[l] != size[l]) plan_ok = false;
       return max_ext;
     };
     std::vector<int> tcol, trow;
@@ -1330,7 +1348,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     o->pyr_buf_bytes = (ex * ey + 15) & ~15;
     // staged tables: 8 bytes per computed column / row of every level
     o->pyr_lds = 2 * (size_t)o->pyr_buf_bytes + 8 * (size_t)(ent_x + ent_y) + 64;
-    if (o->pyr_lds <= 60 * 1024) {
+    if (o->pyr_lds <= 60 * 1024 && plan_ok) {
       // entry blocks at a fixed stride per tile column / row (the kernel's staging loads must not depend on a loaded offset)
       std::vector<int16_t> entp((size_t)4 * (n_xblk * ent_x + (blk_start.size() - n_xblk) * ent_y), 0);
       blk_start.push_back(ent.size() / 4);
@@ -1354,6 +1372,7 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
       o->pyr_fused = true;
     }
   }
+  if (getenv("CCM_ORB_OCT_DBG")) fprintf(stderr, "[ccm_orb] %d x %d, %d levels: pyramid %s\n", w, h, o->nlevels, o->pyr_fused ? "in one launch" : "one launch per level");
   if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 256)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 256)); }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
