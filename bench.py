@@ -196,7 +196,7 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
     kps, desc = ex(imgs[-1])
     assert n_kp == len(kps) and np.array_equal(pex.desc[:n_kp], desc) and np.array_equal(pex.kps[:n_kp], kps)
     T = len(kps)
-    # the batch figure SURVEY 8(d) asks for: 64 frames resident in HBM, results left in HBM, two frames in flight (ccm_orb_extract_batch_dev)
+    # the batch figure SURVEY 8(d) asks for: 64 frames resident in HBM, results left in HBM, groups of four frames per launch, two groups in flight (ccm_orb_extract_batch_dev)
     from ccm_slam_amd.orb import OrbBatchDev
     bimgs = np.stack([synth.gen_image(1000, t) for t in range(64)])
     bat = OrbBatchDev(ctx, ex, bimgs)
@@ -275,7 +275,7 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
                            "frac_of_hbm_peak": round(ORB_BYTES_PER_FRAME / t_batch / 1e9 / HBM_PEAK_GBS, 5),
                            "kernels": orb_kernels,
                            "note": "64 frames resident in HBM, outputs stay in HBM; DistributeOctTree runs on the device (one workgroup per level), "
-                                   "the whole batch is queued on two streams (even / odd frames) without host work; the 9 MB working set lives in the "
+                                   "the whole batch is queued in groups of four frames per launch on two streams without host work; the 9 MB working set of a frame lives in the "
                                    "256 MB Infinity Cache, so the pipeline is bound by its ~13 short dependent launches per frame, not by HBM"},
            "window_candidates": int(idx1.size),
            "note": "host-API timings (H2D/D2H included), one C-ABI call per stage with its arguments converted once (prepared call objects; the plain Python wrappers add 10 - 30 us of numpy / ctypes work per call); every stage bit-exact vs the oracle (tests/test_orb_gpu.py, test_frame_gpu.py, "

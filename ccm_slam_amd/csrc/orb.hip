@@ -60,6 +60,18 @@ struct OrbDev {
   int umax[16];
 };
 
+// Several frames in ONE launch (round 4, batch API): blockIdx.y is the frame.  Every device buffer of a frame's buffer set is carved from one block with the same layout in
+// every set (orb_alloc_bufs), so frame f's buffers are the kernel's pointer arguments (those of the group's first set) moved by ONE byte offset; the caller's output arrays and
+// the frames' level-0 pixels have their own strides.  n = 1 with zero offsets is the single-frame form of the same kernels.
+constexpr int kOrbGroup = 4;
+struct OrbFrames {
+  int n, pstride0;                 // frames of the launch; row stride of level 0 where the frames' pixels are read
+  long long set[kOrbGroup];        // bytes from the first set's block to frame f's
+  long long poff0[kOrbGroup];      // level 0 of frame f relative to ITS pyramid buffer (in place in the caller's frames for the batch API)
+  long long kout[kOrbGroup], desc[kOrbGroup], cnt[kOrbGroup];   // bytes from the output pointers given to frame f's outputs
+};
+template <typename T> __device__ __forceinline__ T* orb_shift(T* p, long long bytes) { return p ? (T*)((uintptr_t)p + (uintptr_t)bytes) : p; }
+
 __constant__ int8_t c_pattern[1024];
 
 // ---- pyramid: cv::resize INTER_LINEAR 8UC1 fixed point (oracle/orb_ref.cpp resize_linear_u8) ----
@@ -106,11 +118,13 @@ struct PyrArgs {
 // barrier that orders LDS traffic only: __syncthreads() also waits for the level's global stores (~0.8 us per level, measured)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t* __restrict__ pyr, PyrArgs a) {
+__global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t* __restrict__ pyr, PyrArgs a, OrbFrames fr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t plds[];
+  const int fy = blockIdx.y;
+  pyr = orb_shift(pyr, fr.set[fy]);
   __shared__ int4 s_c[kMaxLevels], s_r[kMaxLevels];
   const int t = threadIdx.x;
-  const bool timing = a.dbg && blockIdx.x == 0 && t == 0;
+  const bool timing = a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && t == 0;
   long long tk = timing ? wall_clock64() : 0;
   const int tc = blockIdx.x % a.ntx, tr = blockIdx.x / a.ntx;
   const int4* C = a.tcol + (size_t)tc * d.nlevels;
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t*
   {
     const uint2* gx = a.ent + (size_t)tc * a.ent_sx;
     const uint2* gy = a.ent + a.ent_y0 + (size_t)tr * a.ent_sy;
-    const uint8_t* src = pyr + L0.poff + (long long)y0 * L0.pstride + x0;
+    const uint8_t* src = pyr + fr.poff0[fy] + (long long)y0 * fr.pstride0 + x0;
     const float rcw = 1.f / (float)cw0;
     const int ne = a.ent_sx + a.ent_sy;
     constexpr int UE = 1024 / kPyrTPB, UP = 3072 / kPyrTPB;
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t*
     for (int k = 0; k < UP; k++) {
       const int i = k * kPyrTPB + t;
       v[k] = 0;
-      if (i < cw0 * ch0) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; v[k] = src[(long long)yy * L0.pstride + xx]; }
+      if (i < cw0 * ch0) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; v[k] = src[(long long)yy * fr.pstride0 + xx]; }
     }
     if (t < d.nlevels) s_c[t] = dsc; else if (t >= 64 && t < 64 + d.nlevels) s_r[t - 64] = dsc;
 #pragma unroll
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(kPyrTPB) void orb_pyramid_kernel(OrbDev d, uint8_t*
     for (int k = 0; k < UP; k++) { const int i = k * kPyrTPB + t; if (i < cw0 * ch0) buf[0][i] = v[k]; }
     // (tiles beyond the unrolled batches: plain loops)
     for (int i = UE * kPyrTPB + t; i < ne; i += kPyrTPB) tx[i] = i < a.ent_sx ? gx[i] : gy[i - a.ent_sx];
-    for (int i = UP * kPyrTPB + t; i < cw0 * ch0; i += kPyrTPB) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; buf[0][i] = src[(long long)yy * L0.pstride + xx]; }
+    for (int i = UP * kPyrTPB + t; i < cw0 * ch0; i += kPyrTPB) { const int yy = (int)(((float)i + 0.5f) * rcw), xx = i - yy * cw0; buf[0][i] = src[(long long)yy * fr.pstride0 + xx]; }
   }
   __syncthreads();
   if (timing) { const long long tn = wall_clock64(); a.dbg[0] += tn - tk; tk = tn; a.dbg[23] += 1; }
@@ -257,7 +271,9 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // 1.1 MB score map are gone from the extraction: one launch and one round trip through memory less per frame; 13 % of the pixels are scored twice, by the
 // two cells whose tiles overlap).  `pyr` = the pyramid; the scores are the same integers, so everything downstream is unchanged.
 __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t* __restrict__ pyr, int iniTh, int minTh,
-                                                        uint32_t* __restrict__ cell_slots, int* __restrict__ cell_counts) {
+                                                        uint32_t* __restrict__ cell_slots, int* __restrict__ cell_counts, OrbFrames fr) {
+  const int fy = blockIdx.y;
+  pyr = orb_shift(pyr, fr.set[fy]); cell_slots = orb_shift(cell_slots, fr.set[fy]); cell_counts = orb_shift(cell_counts, fr.set[fy]);
   __shared__ uint8_t tile[(kCellMax + 2) * (kCellMax + 2)];
   __shared__ uint8_t pix[(kCellMax + 6) * (kCellMax + 6 + 2)];
   __shared__ uint8_t sct[kCellMax * kCellMax];
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(256) void orb_cells_kernel(OrbDev d, const uint8_t*
     const int pw = iw + 6, ps = (pw + 3) & ~3;
     for (int t = threadIdx.x; t < (ih + 6) * pw; t += 256) {
       const int ty = t / pw, tx = t % pw;
-      pix[ty * ps + tx] = pyr[L.poff + (long long)(y0 - 3 + ty) * L.pstride + (x0 - 3 + tx)];
+      pix[ty * ps + tx] = pyr[(l == 0 ? fr.poff0[fy] : (long long)L.off) + (long long)(y0 - 3 + ty) * (l == 0 ? fr.pstride0 : L.stride) + (x0 - 3 + tx)];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < npx; t += 256) {
@@ -382,8 +398,9 @@ constexpr int kBlurInBytes = (kBlurTH + 6) * (kBlurTW + 6), kBlurHsBytes = (kBlu
 constexpr int kBlurLds = (kBlurInBytes + kBlurHsBytes + 15) & ~15;   // LDS of one 256-thread tile team
 // one 64 x 16 tile by a team of 256 threads (tid 0..255); `live` = the team has a tile (a team without one only keeps the two barriers of its workgroup)
 __device__ __forceinline__ void orb_blur_tile(const OrbDev& d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, bool live, int l, int bx, int by, int tid,
-                                              uint8_t* in, uint16_t* hs) {
-  const LevelInfo L = d.lv[live ? l : 0];
+                                              uint8_t* in, uint16_t* hs, long long poff0, int pstride0) {
+  LevelInfo L = d.lv[live ? l : 0];
+  if (!live || l == 0) { L.poff = poff0; L.pstride = pstride0; }   // level 0 of THIS frame (OrbFrames)
   const uint8_t* src = pyr + L.poff;
   if (live)
     for (int t = tid; t < (kBlurTH + 6) * (kBlurTW + 6); t += 256) {
@@ -413,7 +430,8 @@ __device__ __forceinline__ void orb_blur_tile(const OrbDev& d, const uint8_t* __
 __global__ __launch_bounds__(256) void orb_blur_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
                                                        const int* __restrict__ tile_level, const int* __restrict__ tile_xy) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[kBlurLds];
-  orb_blur_tile(d, pyr, blur, true, tile_level[blockIdx.x], tile_xy[2 * blockIdx.x], tile_xy[2 * blockIdx.x + 1], threadIdx.x, lds, reinterpret_cast<uint16_t*>(lds + ((kBlurInBytes + 1) & ~1)));
+  orb_blur_tile(d, pyr, blur, true, tile_level[blockIdx.x], tile_xy[2 * blockIdx.x], tile_xy[2 * blockIdx.x + 1], threadIdx.x, lds, reinterpret_cast<uint16_t*>(lds + ((kBlurInBytes + 1) & ~1)),
+                d.lv[0].poff, d.lv[0].pstride);
 }
 
 // ---- orientation + descriptor: one wave per keypoint -----------------------------------------------
@@ -472,41 +490,56 @@ __device__ __forceinline__ int oct_scan2(int v0, int v1, int& e0, int& e1, int* 
 }
 
 template <int TPB>
-__global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
+__global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a, OrbFrames fr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char oct_lds[];
+  // 1-D grid, the octree workgroups of ALL frames first (level-major inside a frame), then the frames' blur workgroups: every workgroup of this kernel asks for a whole CU's
+  // LDS, and with the frames along blockIdx.y the octree workgroups of the later frames queued behind hundreds of blur workgroups (132 us for four frames, 36 for one)
+  const int n_oct = a.nlevels * fr.n;
+  const int bwg = (int)(gridDim.x - n_oct) / fr.n;                         // blur workgroups per frame
+  const int fy = (int)blockIdx.x < n_oct ? (int)blockIdx.x / a.nlevels : ((int)blockIdx.x - n_oct) / bwg;
+  const int bx = (int)blockIdx.x < n_oct ? (int)blockIdx.x % a.nlevels : a.nlevels + ((int)blockIdx.x - n_oct) % bwg;   // the frame's own index: [levels | blur workgroups]
+  // frame fy's buffers (the arguments are those of the group's first set).  Local copies: writing into the by-value argument block would move all of it — the per-level
+  // tables are indexed at run time — to scratch memory (272 bytes per lane, the kernel 36 -> 54 us).
+  const long long sh_ = fr.set[fy];
+  const int* const f_cand = orb_shift(a.cand, sh_); KpIn* const f_stage = orb_shift(a.stage, sh_); int* const f_counts = orb_shift(a.counts, sh_);
+  KpIn* const f_kin = orb_shift(a.kin, sh_); int* const f_n_out = orb_shift(a.n_out, sh_);
+  const uint32_t* const f_cell_slots = orb_shift(a.cell_slots, sh_); const int* const f_cell_counts = orb_shift(a.cell_counts, sh_);
+  const uint8_t* const f_pyr = orb_shift(a.pyr, sh_); uint8_t* const f_blur = orb_shift(a.blur, sh_);
+  unsigned long long* const f_dbg = fy ? nullptr : a.dbg;
+  (void)f_kin;
   __shared__ int wsum[TPB / 64 + 1];
   __shared__ int sh[16];                 // [0] list size  [1] cur buffer  [2] created  [3] new candidates  [4] finish  [5] cut rank  [6] overflow
   __shared__ int rootcnt[16], rootslot[16];
   const int t = threadIdx.x;
-  if ((int)blockIdx.x >= a.nlevels) {   // a blur workgroup: TPB / 256 teams, one tile each
-    const int team = t >> 8, tile = ((int)blockIdx.x - a.nlevels) * (TPB / 256) + team;
+  if (bx >= a.nlevels) {   // a blur workgroup: TPB / 256 teams, one tile each
+    const int team = t >> 8, tile = (bx - a.nlevels) * (TPB / 256) + team;
     const bool live = tile < a.n_blur_tiles;
     uint8_t* in = oct_lds + (size_t)team * kBlurLds;
-    orb_blur_tile(d, a.pyr, a.blur, live, live ? a.tile_level[tile] : 0, live ? a.tile_xy[2 * tile] : 0, live ? a.tile_xy[2 * tile + 1] : 0, t & 255, in,
-                  reinterpret_cast<uint16_t*>(in + ((kBlurInBytes + 1) & ~1)));
+    orb_blur_tile(d, f_pyr, f_blur, live, live ? a.tile_level[tile] : 0, live ? a.tile_xy[2 * tile] : 0, live ? a.tile_xy[2 * tile + 1] : 0, t & 255, in,
+                  reinterpret_cast<uint16_t*>(in + ((kBlurInBytes + 1) & ~1)), fr.poff0[fy], fr.pstride0);
     return;
   }
-  const int l = blockIdx.x;
+  const int l = bx;
   const LevelInfo Lv = d.lv[l];
   const int N = a.nfeat[l], Lcap = a.lcap[l];
   const int ncl = Lv.nCols * Lv.nRows;
-  const bool from_cells = a.cell_counts != nullptr;      // (the host chooses this form only when every level has at most 2 TPB cells)
+  const bool from_cells = f_cell_counts != nullptr;      // (the host chooses this form only when every level has at most 2 TPB cells)
   int c0 = 0, n;
   if (from_cells) {
     // exclusive scan of the level's cell counts in LDS (the list slots are not in use yet): cell i's records go to [coff[i], coff[i + 1])
     int* coff = reinterpret_cast<int*>(oct_lds + (((size_t)a.kcap * 7 + 15) & ~(size_t)15));
     const int i0 = 2 * t, i1 = 2 * t + 1;
-    const int v0 = i0 < ncl ? a.cell_counts[Lv.cellBase + i0] : 0, v1 = i1 < ncl ? a.cell_counts[Lv.cellBase + i1] : 0;
+    const int v0 = i0 < ncl ? f_cell_counts[Lv.cellBase + i0] : 0, v1 = i1 < ncl ? f_cell_counts[Lv.cellBase + i1] : 0;
     int e0, e1;
     n = oct_scan2<TPB>(v0, v1, e0, e1, wsum);
     if (i0 <= ncl) coff[i0] = e0;
     if (i1 <= ncl) coff[i1] = e1;
     __syncthreads();
   } else {
-    c0 = a.cand[Lv.cellBase];
-    n = a.cand[Lv.cellBase + ncl] - c0;
+    c0 = f_cand[Lv.cellBase];
+    n = f_cand[Lv.cellBase + ncl] - c0;
   }
-  const uint32_t* grec = from_cells ? nullptr : reinterpret_cast<const uint32_t*>(a.cand + a.ncells + 1) + c0;
+  const uint32_t* grec = from_cells ? nullptr : reinterpret_cast<const uint32_t*>(f_cand + a.ncells + 1) + c0;
   // LDS carve-up
   uint32_t* rec = reinterpret_cast<uint32_t*>(oct_lds);                       // [kcap]
   uint16_t* knode = reinterpret_cast<uint16_t*>(rec + a.kcap);                // [kcap]
@@ -521,9 +554,9 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
   uint32_t* ckey = reinterpret_cast<uint32_t*>(oct_lds + o); o += (size_t)Lcap * 4;     // expandable children of the last pass: size << 16 | creation index
   uint16_t* cslot = reinterpret_cast<uint16_t*>(oct_lds + o); o += (size_t)Lcap * 2;    //   and their list slot
   uint8_t* mark = reinterpret_cast<uint8_t*>(oct_lds + o);                                  // [Lcap] node takes part in the counting
-  int* g_over = a.n_out + 1;                                                                  // [count, overflow flag]
-  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
-#define OCT_T(slot) do { if (a.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tq[slot] += t_ - tl; tl = t_; } } while (0)
+  int* g_over = f_n_out + 1;                                                                  // [count, overflow flag]
+  unsigned long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = f_dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define OCT_T(slot) do { if (f_dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tq[slot] += t_ - tl; tl = t_; } } while (0)
   if (t < 16) { sh[t] = 0; rootcnt[t] = 0; }
   __syncthreads();
   const int W = (Lv.w - kEdge + 3) - (kEdge - 3), H = (Lv.h - kEdge + 3) - (kEdge - 3);
@@ -545,7 +578,7 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
           if (k < n) {
             int lo = 0, hi = ncl - 1;       // invariant: coff[lo] <= k < coff[hi + 1]
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (coff[mid] <= k) lo = mid; else hi = mid - 1; }
-            r4[q] = a.cell_slots[(size_t)(Lv.cellBase + lo) * kCellCap + (k - coff[lo])];
+            r4[q] = f_cell_slots[(size_t)(Lv.cellBase + lo) * kCellCap + (k - coff[lo])];
           }
         }
 #pragma unroll
@@ -751,18 +784,18 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
     const int minB = kEdge - 3;
     for (int e = t; e < Ls && e < a.stage_stride; e += TPB) {
       const uint32_t r = rec[0xFFFF - (cnt[e] & 0xFFFF)];
-      a.stage[(size_t)l * a.stage_stride + e] = KpIn{(int16_t)((int)(r & 0xFFF) + minB), (int16_t)((int)((r >> 12) & 0xFFF) + minB), (int16_t)l, (int16_t)(r >> 24)};
+      f_stage[(size_t)l * a.stage_stride + e] = KpIn{(int16_t)((int)(r & 0xFFF) + minB), (int16_t)((int)((r >> 12) & 0xFFF) + minB), (int16_t)l, (int16_t)(r >> 24)};
     }
     if (Ls > a.stage_stride) overflow = true;
   }
   // ---- the last level to finish concatenates the levels ----
   OCT_T(6);
-  if (a.dbg && l == 0 && t == 0) for (int q = 0; q < 8; q++) a.dbg[q] += tq[q];
+  if (f_dbg && l == 0 && t == 0) for (int q = 0; q < 8; q++) f_dbg[q] += tq[q];
 #undef OCT_T
   // (round 4) no concatenation here: the level leaves its count and its staged keypoints, the orientation + descriptor kernel behind it maps its waves to
   // (level, entry) through the eight counts — the device-scope fences, the arrival counter and the last workgroup's copy are gone from the frame's longest kernel
   if (t == 0) {
-    a.counts[l] = Ls;
+    f_counts[l] = Ls;
     if (overflow) atomicExch(g_over, 1);
   }
 }
@@ -774,7 +807,13 @@ __global__ __launch_bounds__(TPB) void orb_octree_kernel(OrbDev d, OctArgs a) {
 __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                               const KpIn* __restrict__ kin, int n, int* __restrict__ n_dev /* staged form: receives the count */,
                                                               ccm_keypoint* __restrict__ kout, uint8_t* __restrict__ desc, int* __restrict__ count_out /* nullable */,
-                                                              const KpIn* __restrict__ stage, int stage_stride, const int* __restrict__ lcounts, int kp_cap) {
+                                                              const KpIn* __restrict__ stage, int stage_stride, const int* __restrict__ lcounts, int kp_cap, OrbFrames fr) {
+  const int fy = blockIdx.y;
+  {
+    const long long sh_ = fr.set[fy];
+    pyr = orb_shift(pyr, sh_); blur = orb_shift(blur, sh_); kin = orb_shift(kin, sh_); n_dev = orb_shift(n_dev, sh_); stage = orb_shift(stage, sh_); lcounts = orb_shift(lcounts, sh_);
+    kout = orb_shift(kout, fr.kout[fy]); desc = orb_shift(desc, fr.desc[fy]); count_out = orb_shift(count_out, fr.cnt[fy]);
+  }
   const int lane = threadIdx.x & (kWave - 1);
   const int i = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
   KpIn kp;
@@ -794,7 +833,8 @@ __global__ __launch_bounds__(256) void orb_orient_desc_kernel(OrbDev d, const ui
     if (i >= n) return;
     kp = kin[i];
   }
-  const LevelInfo L = d.lv[kp.level];
+  LevelInfo L = d.lv[kp.level];
+  if (kp.level == 0) { L.poff = fr.poff0[fy]; L.pstride = fr.pstride0; }   // level 0 of THIS frame
   // IC_Angle (:68-95): integer moments over the radius-15 disc of the UNBLURRED level
   const uint8_t* center = pyr + L.poff + (long long)kp.y * L.pstride + kp.x;
   int m10 = 0, m01 = 0;
@@ -998,7 +1038,7 @@ static void distribute_octree(Octree& T, const Cand* c, int n, int minX, int max
 }  // namespace
 
 // =================================================================================================
-constexpr int kOrbSets = 4;   // frames in flight of the batch API with the device octree (sets 0 / 1 also serve the single-frame and host-octree paths)
+constexpr int kOrbSets = 2 * kOrbGroup;   // buffer sets: two groups of kOrbGroup frames in flight in the batch API with the device octree (sets 0 / 1 also serve the single-frame and host-octree paths)
 struct ccm_orb {
   ccm_ctx* ctx = nullptr;
   int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
@@ -1013,6 +1053,7 @@ struct ccm_orb {
   // everything one frame in flight owns.  Two sets: the single-frame entry points use set 0; ccm_orb_extract_batch_dev alternates, so
   // that frame t+1's device phase 1 runs while the host selects keypoints (DistributeOctTree) for frame t.
   struct Bufs {
+    uint8_t* d_block = nullptr;   // every device buffer below is carved from this one block, with the same layout in every set (OrbFrames)
     uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
     uint32_t* d_cell_slots = nullptr; int* d_cell_counts = nullptr; int* d_cand = nullptr;   // d_cand: [ncells+1 offsets][records]
     KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr;
@@ -1040,16 +1081,14 @@ struct ccm_orb {
   bool oct_cells = false;   // the octree kernel reads the per-cell lists itself (no orb_compact_kernel on the device-octree path)
   hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
   hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;   // host-octree batch path
-  hipStream_t bstream[kOrbSets] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t bev[kOrbSets] = {nullptr, nullptr, nullptr, nullptr};   // device-octree batch path: stream / "done" event of sets 1..3
+  hipStream_t bstream[kOrbSets] = {}; hipEvent_t bev[kOrbSets] = {};   // device-octree batch path: stream / "done" event of sets 1..3
   unsigned long long* d_oct_dbg = nullptr;   // CCM_ORB_OCT_DBG: phase clocks of the octree kernel, printed by ccm_orb_destroy
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand; bool last_cand_valid = false;
 };
 
 static void orb_free_bufs(ccm_orb::Bufs& b) {
-  hipFree(b.d_pyr); hipFree(b.d_score); hipFree(b.d_blur); hipFree(b.d_cell_slots); hipFree(b.d_cell_counts); hipFree(b.d_cand);
-  hipFree(b.d_kin); hipFree(b.d_kout);   // d_desc is part of d_kout's block
-  hipFree(b.d_oct_stage); hipFree(b.d_oct_counts); hipFree(b.d_n);
+  hipFree(b.d_block);   // every device buffer of the set
   if (b.h_cand) hipHostFree(b.h_cand);
   if (b.h_kin) hipHostFree(b.h_kin);
   if (b.h_count) hipHostFree(b.h_count);
@@ -1152,30 +1191,24 @@ static int orb_alloc_bufs(ccm_orb* o, int k) {
   ccm_orb::Bufs& b = o->B[k];
   if (b.d_pyr) return CCM_OK;
   const OrbDev& d = o->dev;
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_pyr, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_score, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_blur, o->pyr_bytes));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_pyr, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_score, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_blur, 0, o->pyr_bytes, ctx->stream));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_slots, std::max<size_t>(o->cand_cap, 1) * sizeof(uint32_t)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cell_counts, std::max<size_t>(d.ncells, 1) * sizeof(int)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)));
-  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_kin, (size_t)o->kp_cap * sizeof(KpIn)));
-  if (o->oct_ok) {
-    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_oct_stage, (size_t)o->nlevels * o->oct_stride * sizeof(KpIn)));
-    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_oct_counts, (size_t)(o->nlevels + 2) * sizeof(int)));
-    CCM_HIP_CHECK(ctx, hipMalloc(&b.d_n, 2 * sizeof(int)));
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_oct_counts, 0, (size_t)(o->nlevels + 2) * sizeof(int), ctx->stream));
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_n, 0, 2 * sizeof(int), ctx->stream));
-  }
-  {   // keypoints and descriptors in one block [kout | desc] so that the results leave with one copy
-    uint8_t* blk = nullptr;
-    const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
-    CCM_HIP_CHECK(ctx, hipMalloc(&blk, o_d + (size_t)o->kp_cap * 32 + 256));
-    b.d_kout = reinterpret_cast<ccm_keypoint*>(blk);
-    b.d_desc = blk + o_d;
-  }
+  // one block per set, the same layout in every set: a launch over several frames reaches frame f's buffers by adding ONE byte offset to the pointers of the group's first set
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += ccm_align256(std::max<size_t>(bytes, 1)); return at; };
+  const size_t o_pyr = take(o->pyr_bytes), o_score = take(o->pyr_bytes), o_blur = take(o->pyr_bytes);
+  const size_t o_slots = take(std::max<size_t>(o->cand_cap, 1) * sizeof(uint32_t)), o_counts = take(std::max<size_t>(d.ncells, 1) * sizeof(int));
+  const size_t o_cand = take(((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)), o_kin = take((size_t)o->kp_cap * sizeof(KpIn));
+  const size_t o_stage = take(o->oct_ok ? (size_t)o->nlevels * o->oct_stride * sizeof(KpIn) : 1), o_octc = take((size_t)(o->nlevels + 2) * sizeof(int)), o_n = take(2 * sizeof(int));
+  const size_t o_d = ccm_align256((size_t)o->kp_cap * sizeof(ccm_keypoint));
+  const size_t o_kout = take(o_d + (size_t)o->kp_cap * 32 + 256);   // keypoints and descriptors in one piece [kout | desc] so that the results leave with one copy
+  CCM_HIP_CHECK(ctx, hipMalloc(&b.d_block, off));
+  CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_block, 0, off, ctx->stream));
+  uint8_t* base = b.d_block;
+  b.d_pyr = base + o_pyr; b.d_score = base + o_score; b.d_blur = base + o_blur;
+  b.d_cell_slots = reinterpret_cast<uint32_t*>(base + o_slots); b.d_cell_counts = reinterpret_cast<int*>(base + o_counts); b.d_cand = reinterpret_cast<int*>(base + o_cand);
+  b.d_kin = reinterpret_cast<KpIn*>(base + o_kin);
+  if (o->oct_ok) { b.d_oct_stage = reinterpret_cast<KpIn*>(base + o_stage); b.d_oct_counts = reinterpret_cast<int*>(base + o_octc); b.d_n = reinterpret_cast<int*>(base + o_n); }
+  b.d_kout = reinterpret_cast<ccm_keypoint*>(base + o_kout);
+  b.d_desc = base + o_kout + o_d;
   CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_cand, ((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int), hipHostMallocDefault));
   CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_kin, (size_t)o->kp_cap * sizeof(KpIn), hipHostMallocDefault));
   CCM_HIP_CHECK(ctx, hipHostMalloc((void**)&b.h_count, 64, hipHostMallocDefault));
@@ -1393,30 +1426,43 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
   return CCM_OK;
 }
 
+// the single-frame form of OrbFrames: the buffers are those of the pointer arguments, level 0 lies in the pyramid buffer
+static OrbFrames orb_one_frame(const ccm_orb* o) {
+  OrbFrames fr;
+  memset(&fr, 0, sizeof(fr));
+  fr.n = 1; fr.pstride0 = o->dev.lv[0].pstride; fr.poff0[0] = o->dev.lv[0].poff;
+  return fr;
+}
+
 // device phase 1: pyramid, scores, cells, compaction; blur is queued too (it does not depend on the octree)
-static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false) {
+// fr != nullptr: a group of frames in one launch per kernel (batch API, device octree): o->cur is the group's FIRST buffer set
+static int orb_phase1(ccm_orb* o, bool copy_cand = true, bool dev_octree = false, const OrbFrames* frp = nullptr) {
   ccm_ctx* ctx = o->ctx;
   const OrbDev& d = o->dev;
+  const OrbFrames fr = frp ? *frp : orb_one_frame(o);
   if (o->pyr_fused) {
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
     PyrArgs pa = o->pyr_args;
     pa.dbg = o->d_oct_dbg ? o->d_oct_dbg + 8 : nullptr;
-    hipLaunchKernelGGL(orb_pyramid_kernel, dim3(o->pyr_ntx * o->pyr_nty), dim3(kPyrTPB), o->pyr_lds, o->st, d, o->B[o->cur].d_pyr, pa);
-  } else for (int l = 1; l < o->nlevels; l++) {
+    hipLaunchKernelGGL(orb_pyramid_kernel, dim3(o->pyr_ntx * o->pyr_nty, fr.n), dim3(kPyrTPB), o->pyr_lds, o->st, d, o->B[o->cur].d_pyr, pa, fr);
+  } else for (int fI = 0; fI < fr.n; fI++) for (int l = 1; l < o->nlevels; l++) {   // (one launch per frame and level)
     const LevelInfo &P = d.lv[l - 1], &L = d.lv[l];
+    uint8_t* pyr_f = o->B[o->cur].d_pyr + fr.set[fI];
     ccm_prof_scope ps(ctx, CCM_K_PYR_RESIZE, o->st);
-    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, o->B[o->cur].d_pyr + P.poff, P.w, P.h, P.pstride,
-                       o->B[o->cur].d_pyr + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
+    hipLaunchKernelGGL(orb_resize_kernel, dim3(ccm_div_up(L.w, 256), L.h), dim3(256), 0, o->st, pyr_f + (l == 1 ? fr.poff0[fI] : (long long)P.off), P.w, P.h, l == 1 ? fr.pstride0 : P.stride,
+                       pyr_f + L.off, L.w, L.h, L.stride, o->d_tabs + o->tab_xofs[l], o->d_tabs + o->tab_ialpha[l],
                        o->d_tabs + o->tab_yofs[l], o->d_tabs + o->tab_ibeta[l]);
   }
   if (d.ncells == 0) {   // no level holds a cell (image below 62 px): the candidate list is empty, the pyramid above is the whole result
-    CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[o->cur].d_cand, 0, sizeof(int), o->st));
+    for (int fI = 0; fI < fr.n; fI++) CCM_HIP_CHECK(ctx, hipMemsetAsync(reinterpret_cast<uint8_t*>(o->B[o->cur].d_cand) + fr.set[fI], 0, sizeof(int), o->st));
   } else {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
-    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts);
+    hipLaunchKernelGGL(orb_cells_kernel, dim3(d.ncells, fr.n), dim3(256), 0, o->st, d, o->B[o->cur].d_pyr, o->iniTh, o->minTh, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, fr);
     if (!(dev_octree && o->oct_cells))   // (the octree kernel gathers from the cell lists itself; the compacted form is only made when the host or a test asks for it)
-      hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, o->B[o->cur].d_cell_slots, o->B[o->cur].d_cell_counts, o->B[o->cur].d_cand,
-                         (uint32_t*)(o->B[o->cur].d_cand + d.ncells + 1));
+      for (int fI = 0; fI < fr.n; fI++) {
+        ccm_orb::Bufs& bf = o->B[o->cur + fI];   // (the sets of a group are consecutive)
+        hipLaunchKernelGGL(orb_compact_kernel, dim3(d.ncells), dim3(256), 0, o->st, d.ncells, bf.d_cell_slots, bf.d_cell_counts, bf.d_cand, (uint32_t*)(bf.d_cand + d.ncells + 1));
+      }
   }
   if (copy_cand) {
     const size_t first = ((size_t)d.ncells + 1 + std::min(o->cand_cap, kCandFirstCopy)) * sizeof(int);
@@ -1529,7 +1575,7 @@ static int orb_phase2(ccm_orb* o, int n) {
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF);
     hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(n, 4)), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_blur, o->B[o->cur].d_kin, n, (int*)nullptr, o->B[o->cur].d_kout, o->B[o->cur].d_desc, (int*)nullptr,
-                       (const KpIn*)nullptr, 0, (const int*)nullptr, o->kp_cap);
+                       (const KpIn*)nullptr, 0, (const int*)nullptr, o->kp_cap, orb_one_frame(o));
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1537,9 +1583,10 @@ static int orb_phase2(ccm_orb* o, int n) {
 
 // keypoint selection and phase 2 without the host: octree kernel (one workgroup per level), then orientation + descriptors for the count the
 // device wrote (the grid covers the capacity, surplus waves leave at once)
-static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr, uint8_t* dout = nullptr, int* count_out = nullptr) {
+static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr, uint8_t* dout = nullptr, int* count_out = nullptr, const OrbFrames* frp = nullptr) {
   ccm_ctx* ctx = o->ctx;
   ccm_orb::Bufs& b = o->B[o->cur];
+  const OrbFrames fr = frp ? *frp : orb_one_frame(o);
   OctArgs a;
   a.cand = b.d_cand; a.ncells = o->dev.ncells; a.nlevels = o->nlevels;
   for (int l = 0; l < o->nlevels; l++) { a.nfeat[l] = o->nfeat[l]; a.lcap[l] = o->oct_lcap[l]; }
@@ -1553,16 +1600,16 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr,
     const int blur_wgs = ccm_div_up(o->n_blur_tiles, o->oct_tpb / 256);
     if (o->oct_tpb == 512) {   // two list slots per thread: 512 threads hold up to 4 N + 16 = 1024 slots, and a barrier of 8 waves is cheaper than one of 16
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel<512>, 152 * 1024);
-      hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(o->nlevels + blur_wgs), dim3(512), o->oct_lds, o->st, o->dev, a);
+      hipLaunchKernelGGL(orb_octree_kernel<512>, dim3((o->nlevels + blur_wgs) * fr.n), dim3(512), o->oct_lds, o->st, o->dev, a, fr);
     } else {
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT2, orb_octree_kernel<1024>, 152 * 1024);
-      hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(o->nlevels + blur_wgs), dim3(1024), o->oct_lds, o->st, o->dev, a);
+      hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3((o->nlevels + blur_wgs) * fr.n), dim3(1024), o->oct_lds, o->st, o->dev, a, fr);
     }
   }
   {
     ccm_prof_scope ps(ctx, CCM_K_BRIEF, o->st);
-    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4)), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, b.d_n, kout ? kout : b.d_kout, dout ? dout : b.d_desc, count_out,
-                       (const KpIn*)b.d_oct_stage, o->oct_stride, (const int*)b.d_oct_counts, a.kp_cap);
+    hipLaunchKernelGGL(orb_orient_desc_kernel, dim3(ccm_div_up(o->kp_cap, 4), fr.n), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, b.d_kin, 0, b.d_n, kout ? kout : b.d_kout, dout ? dout : b.d_desc, count_out,
+                       (const KpIn*)b.d_oct_stage, o->oct_stride, (const int*)b.d_oct_counts, a.kp_cap, fr);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
@@ -1655,10 +1702,9 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   if ((rc = orb_alloc_bufs(o, 1))) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
   if (o->oct_ok && cap > 0) {
-    // device octree: the whole batch is queued without a single host wait, kOrbSets frames in flight: frame f runs on stream f % kOrbSets with its own
-    // buffer set (the octree kernel is eight workgroups of serial rounds, ~40 us: the other frames' pyramid / FAST / descriptor kernels fill the
-    // GPU meanwhile), and the orientation + descriptor kernel writes keypoints, descriptors and the count straight into the caller's arrays
-    // (round 2: two frames in flight and three device-to-device copies per frame, 15 us of a stream's time: 0.069 ms per frame).
+    // device octree: the whole batch is queued without a single host wait, in groups of kOrbGroup frames per launch (below), two groups in flight on two streams with
+    // their own buffer sets; the orientation + descriptor kernel writes keypoints, descriptors and the counts straight into the caller's arrays
+    // (round 2: two frames in flight and three device-to-device copies per frame: 0.069 ms per frame; round 4 until its last step: one frame per launch on four streams, 0.0345).
     for (int k = 1; k < kOrbSets; k++) {
       if ((rc = orb_alloc_bufs(o, k))) return rc;
       if (!o->bstream[k]) {
@@ -1670,31 +1716,42 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
     CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_a, ctx->stream));            // whatever produced the images on the context's stream comes first
     for (int k = 1; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->bstream[k], o->ev_a, 0));
     static const bool inplace = !(getenv("CCM_ORB_BATCH_COPY") && atoi(getenv("CCM_ORB_BATCH_COPY")));
-    for (int f = 0; f < n_frames; f++) {
-      o->cur = f % kOrbSets;
-      o->st = o->cur ? o->bstream[o->cur] : ctx->stream;
-      ccm_orb::Bufs& b = o->B[o->cur];
-      // level 0 is read IN PLACE from the caller's frame (no device-to-device copy into the pyramid buffer: 3 us of copy and ~10 us of idle stream per frame);
-      // the kernels take the level table by value, so the per-frame offset travels with each launch
-      if (inplace) { o->dev.lv[0].poff = (long long)((d_imgs + (size_t)f * w * h) - b.d_pyr); o->dev.lv[0].pstride = w; }
-      else CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(b.d_pyr + L0.off, L0.stride, d_imgs + (size_t)f * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
-      rc = orb_phase1(o, false, true);
-      if (!rc) rc = orb_phase2_dev(o, cap, d_kps + (size_t)f * cap, d_desc + (size_t)f * cap * 32, d_counts + f);
-      o->dev.lv[0].poff = L0.off; o->dev.lv[0].pstride = L0.stride;
+    // groups of kOrbGroup frames, ONE launch per kernel and group (blockIdx.y = frame, OrbFrames), two groups in flight on two streams with their own buffer sets:
+    // the kernels of a frame are small (8 octree workgroups, ~260 pyramid tiles), four frames per launch fill the chip four times better and cost a quarter of the launches
+    // (round 4: one frame per launch on four streams 0.0345 ms per frame).  Level 0 is read IN PLACE from the caller's frames.
+    static const int group_env = getenv("CCM_ORB_BATCH_GROUP") ? std::max(1, std::min(kOrbGroup, atoi(getenv("CCM_ORB_BATCH_GROUP")))) : kOrbGroup;
+    int gi = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += group_env, gi++) {
+      const int nf = std::min(group_env, n_frames - f0);
+      const int s0 = (gi & 1) * kOrbGroup;
+      o->cur = s0;
+      o->st = (gi & 1) ? o->bstream[1] : ctx->stream;
+      OrbFrames fr;
+      memset(&fr, 0, sizeof(fr));
+      fr.n = nf; fr.pstride0 = inplace ? w : L0.stride;
+      for (int j = 0; j < nf; j++) {
+        ccm_orb::Bufs& bj = o->B[s0 + j];
+        fr.set[j] = (long long)(bj.d_block - o->B[s0].d_block);
+        if (inplace) fr.poff0[j] = (long long)((d_imgs + (size_t)(f0 + j) * w * h) - bj.d_pyr);
+        else {
+          fr.poff0[j] = L0.off;
+          CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(bj.d_pyr + L0.off, L0.stride, d_imgs + (size_t)(f0 + j) * w * h, w, w, h, hipMemcpyDeviceToDevice, o->st));
+        }
+        fr.kout[j] = (long long)j * cap * (long long)sizeof(ccm_keypoint); fr.desc[j] = (long long)j * cap * 32; fr.cnt[j] = (long long)j * (long long)sizeof(int32_t);
+      }
+      rc = orb_phase1(o, false, true, &fr);
+      if (!rc) rc = orb_phase2_dev(o, cap, d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, d_counts + f0, &fr);
       if (rc) { o->cur = 0; o->st = ctx->stream; return rc; }
     }
     o->cur = 0; o->st = ctx->stream;
     // the overflow flags are sticky over the batch
-    for (int k = 1; k < kOrbSets; k++) {
-      CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[k].h_count, o->B[k].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, o->bstream[k]));
-      CCM_HIP_CHECK(ctx, hipEventRecord(o->bev[k], o->bstream[k]));
-      CCM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->bev[k], 0));
-    }
-    CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[0].h_count, o->B[0].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CCM_HIP_CHECK(ctx, hipEventRecord(o->bev[1], o->bstream[1]));
+    CCM_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, o->bev[1], 0));
+    for (int k = 0; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->B[k].h_count, o->B[k].d_n, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     o->last_cand_valid = false;
     bool overflow = false;
-    for (int k = 0; k < kOrbSets && k < n_frames; k++) overflow = overflow || o->B[k].h_count[1] != 0;
+    for (int k = 0; k < kOrbSets; k++) overflow = overflow || o->B[k].h_count[1] != 0;
     if (!overflow) return CCM_OK;
     // some level of some frame did not fit the kernel's LDS plan: redo the batch with the host octree
     for (int k = 0; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[k].d_n + 1, 0, sizeof(int), ctx->stream));
@@ -1817,8 +1874,11 @@ int ccm_internal::orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int
   std::vector<KpIn> out(stride);
   int hn[2] = {0, 0};
   if (rc == CCM_OK) {
-    if (lcap <= 1024) hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(1), dim3(512), lds, ctx->stream, d, a);
-    else hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, a);
+    OrbFrames fr1;
+    memset(&fr1, 0, sizeof(fr1));
+    fr1.n = 1;
+    if (lcap <= 1024) hipLaunchKernelGGL(orb_octree_kernel<512>, dim3(1), dim3(512), lds, ctx->stream, d, a, fr1);
+    else hipLaunchKernelGGL(orb_octree_kernel<1024>, dim3(1), dim3(1024), lds, ctx->stream, d, a, fr1);
     hipMemcpyAsync(out.data(), d_stage, out.size() * sizeof(KpIn), hipMemcpyDeviceToHost, ctx->stream);   // the one level's staged list IS the output
     hipMemcpyAsync(hn, d_nout, sizeof(hn), hipMemcpyDeviceToHost, ctx->stream);                              // [1] = overflow flag
     hipMemcpyAsync(hn, d_counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);                           // [0] = the level's count
