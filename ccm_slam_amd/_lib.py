@@ -173,6 +173,14 @@ class Context:
         check(lib().ccm_comm_init(self._h, int(nranks), int(rank), buf), self._h)
 
 
+def coresidency_stats(device: int = 0) -> dict:
+    """ccm_coresidency_stats: the per-device lease of this process (launches that need the whole device, how many were ordered behind another
+    context's launch, how many gave up waiting for their peers, live contexts)."""
+    a, b, c, n = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+    check(lib().ccm_coresidency_stats(int(device), C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+    return dict(launches=a.value, chained=b.value, aborted=c.value, contexts=n.value)
+
+
 def comm_unique_id() -> bytes:
     buf = (C.c_uint8 * 128)()
     check(lib().ccm_comm_unique_id(buf))

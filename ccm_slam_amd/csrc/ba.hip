@@ -1914,7 +1914,12 @@ __global__ void ba_coarse_sum(const double* stage, const unsigned* cb_key, int n
 // A barrier gives up after a bounded spin (abort flag -> solver failure -> LM rejects the step) so a scheduling
 // accident can never hang the device.  Cooperative launch guarantees co-residency; the host uses this path when
 // the cluster count fits (<= 4096 free cameras on 256 CUs), the multi-kernel path otherwise.
-constexpr long kPersMaxSpins = 3000000;    // x ~60 ns sleep: ~0.2 s per barrier worst case
+// One spin = two dependent device-coherent loads (~0.8 us measured inside a solve) + the sleep: ~50-100 ms per exchange at worst.  Round 5: was 3 000 000 (seconds —
+// two contexts of one process that launched at the same time each held part of the chip for that long before giving up).  With the per-device lease
+// (ccm_coresident_scope) two such kernels never meet; what a launch can still wait for is another context's ORDINARY kernels to leave the CUs its last
+// workgroups need, i.e. single kernel durations (<= a few ms).
+constexpr long kPersMaxSpins = 60000;
+constexpr int kPersCooldownTrials = 8;   // LM trials a single-rank handle spends on the multi-kernel solver after a persistent launch gave up, before it tries again
 
 struct PersArgs {
   double lambda, rel_tol;
@@ -3270,10 +3275,10 @@ bool poll_enabled() { static const bool on = !(getenv("CCM_BA_POLL") && atoi(get
 int read_scalars_polled(ccm_ba* ba, double out[6], int flags[4], unsigned long long ticket) {
   volatile unsigned long long* tk = reinterpret_cast<volatile unsigned long long*>(ba->h_rb) + 8;
   bool got = false;
+  double t_start = 0;
   for (long spin = 0; !got; spin++) {
     if (*tk == ticket) { got = true; break; }
     if ((spin & 0xffff) == 0xffff) {
-      static thread_local double t_start = 0;
       if (spin == 0xffff) t_start = now_ms();
       else if (now_ms() - t_start > 2000.0) break;
     }
@@ -3285,6 +3290,9 @@ int read_scalars_polled(ccm_ba* ba, double out[6], int flags[4], unsigned long l
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   memcpy(out, ba->h_rb, 6 * sizeof(double));
   if (flags) memcpy(flags, ba->h_rb + 6, 4 * sizeof(int));
+  // the ticket says the trial's kernels ran; a sticky asynchronous error (a fault in a LATER launch of this stream cannot exist yet, an earlier one would have
+  // kept the ticket from arriving) is still picked up here so that it is attributed to this call, not to whoever synchronises next
+  CCM_HIP_CHECK(ba->ctx, hipGetLastError());
   return CCM_OK;
 }
 
@@ -3401,6 +3409,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   ccm_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   const int cur = ba->cur;
+  if (!ba->pers_grid && ba->pers_grid_built && ba->pers_cooldown > 0 && --ba->pers_cooldown == 0) ba->pers_grid = ba->pers_grid_built;   // back to the persistent solver after an abort
   if (d.Lloc && ba->dinv_done_lambda != lambda) {   // (the linearisation already formed D^-1 for this lambda: build_system)
     ccm_prof_scope ps(ctx, CCM_K_BA_DINV);
     hipLaunchKernelGGL(ba_dinv, dim3(d.n_wg_pt), dim3(kTPB), 0, ctx->stream, d, lambda);
@@ -3476,7 +3485,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         const bool reuse = ba->d_pers_wsave && w_mode > 0 && ba->w_valid && in_win && !pa.test_abort && (same_lin || (w_mode >= 2 && !ba->w_stale_bad));
         pa.w_load = reuse ? 1 : 0;
         ba->w_loaded = reuse;
-        if (!reuse) { ba->w_valid = ba->d_pers_wsave != nullptr; ba->w_lambda_built = lambda; ba->w_lin_id = ba->lin_id; ba->w_stale_bad = false; }
+        // (advisor, round 4) what this launch will leave in wsave becomes reusable only AFTER its flags have been read and show a clean solve (below): until
+        // then no inverse is on offer, so a repeat of this trial on the multi-kernel path, a failed launch or a bad pivot can never hand a half-written or
+        // patched W to a later trial
+        if (!reuse) { ba->w_valid = false; ba->w_pending = ba->d_pers_wsave != nullptr; ba->w_lambda_built = lambda; ba->w_lin_id = ba->lin_id; ba->w_stale_bad = false; }
       }
       // (round 4) a strongly damped system does not need the coarse level: above the call's first lambda (g2o's 1e-5 max diag(H): the scale at which the damping
       // takes over the smooth modes as well) cluster-Jacobi alone converges in 10-24 iterations on the 4-agent map, while a stale coarse operator carried up
@@ -3501,6 +3513,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       double tdbg0 = 0;
       if (trial_dbg) { hipStreamSynchronize(ctx->stream); tdbg0 = now_ms(); }
       {
+        // per-device lease: a persistent launch of ANOTHER context of this process (a second Map's global BA, a local BA beside it) is ordered before this
+        // one on the GPU; nothing is recorded or waited for while this is the only context on the device
+        ccm_coresident_scope lease(ctx);
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
         // A cooperative launch guarantees co-residency but, measured with rocprofv3 on MI355X / ROCm 7.2, leaves the
         // GPU idle for ~0.55 ms before the kernel starts (18 launches: 10.5 ms of 53); an ordinary launch starts after
@@ -3515,7 +3530,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
                                                          (unsigned)pers_lds_bytes(), ctx->stream);
         if (le == hipSuccess) persist_ok = true;
-        else { (void)hipGetLastError(); ba->pers_grid = 0; pers_launch_failed = true; }   // e.g. the device is shared and co-residency cannot be granted: multi-kernel path from now on
+        else { (void)hipGetLastError(); ba->pers_grid = 0; ba->pers_grid_built = 0; ba->w_valid = false; pers_launch_failed = true; }   // the launch itself was refused: multi-kernel path from now on
       }
       if (persist_ok) small_path = pers_trial = true;
       if (trial_dbg) {
@@ -3577,7 +3592,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   }
   if (d.Cp && !cams_updated) {
     ccm_prof_scope ps(ctx, CCM_K_BA_UPDATE);
-    hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0, ba->pers_grid ? ba->d_pers_bar : (unsigned*)nullptr);
+    hipLaunchKernelGGL(ba_update_cams, dim3(d.n_wg_cam), dim3(kTPB), 0, ctx->stream, d, cur, lambda, ba->rank == 0 ? 1 : 0, ba->d_pers_bar /* nullptr when the handle has no persistent solver; cleared also while it is cooling down after an abort */);
   } else if (!d.Cp) hipMemsetAsync(d.part_cam, 0, sizeof(double) * d.n_wg_cam, ctx->stream);
   {
     ccm_prof_scope ps(ctx, CCM_K_BA_BACKSUB);
@@ -3602,14 +3617,22 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
   // path, whatever its own solver did — the repeat issues the Schur and scalar all-reduces again, so a rank that skipped it would fall out of step with
   // its peers, and all ranks must keep bit-identical camera states.  The repeat runs with pers_grid = 0 and contributes 0: it cannot recurse.
   if (s[3] > 0.0) {
-    ba->pers_grid = 0;
+    // (round 5) the give-up is no longer for good: the handle takes the multi-kernel path for kPersCooldownTrials trials (this repeat included) and then tries
+    // the persistent kernel again — whatever held the CUs (another process on the device, a long foreign kernel) has usually gone by then.  s[3] is the
+    // reduced value, so every rank of a sharded run counts the same trials.  The carried-over cluster inverse is dropped: the aborted launch may have
+    // written part of it.
+    if (pers_trial) { ccm_coresident_note_abort(ctx); ba->pers_aborts++; }
+    ba->pers_grid = 0; ba->pers_cooldown = kPersCooldownTrials;
+    if (ba->nranks > 1) ba->pers_grid_built = 0;   // sharded: for good, as before — a rank whose LAUNCH was refused cannot come back, and all ranks must keep the same solver path
+    ba->w_valid = false; ba->w_pending = false;
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }
   if (small_path) { *pcg_iters = small_flags[1]; if (small_flags[2]) *ok = false; }
   if (pers_trial) {   // iteration guard of the carried-over cluster inverse
     if (!ba->w_loaded) ba->w_fresh_iters = *pcg_iters;
     else if (ba->w_lin_id != ba->lin_id && *pcg_iters > ba->w_fresh_iters + ba->w_fresh_iters / 8 + 3) ba->w_stale_bad = true;
-    if (small_flags[2]) ba->w_valid = false;   // a failed solve never leaves an inverse behind to be reused
+    if (ba->w_pending) { ba->w_valid = !small_flags[2]; ba->w_pending = false; }   // the launch that factored has finished cleanly: its W may be loaded from now on
+    if (small_flags[2]) ba->w_valid = false;   // a failed solve (bad pivot, NaN) never leaves an inverse behind to be reused
   }
   if (ba->coarse_na && (small_path || d.mk_cpart)) {
     if (ba->coarse_used) {
@@ -3739,7 +3762,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
     double any = 0;
     CCM_HIP_CHECK(ctx, hipMemcpyAsync(&any, ba->d.scal + 5, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (any > 0.0) ba->pers_grid = 0;
+    if (any > 0.0) { ba->pers_grid = 0; ba->pers_grid_built = 0; }
     ba->pers_agreed = true;
   }
   const double t_start = now_ms();

@@ -871,7 +871,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     if (pers_try && !hs.pers_bad) {
       BB_RC(keep_get(ba, 4 + 2 * 16 + 4 * 512, &ba->d_pers_bar, true));   // abort flag + debug clocks (workgroup 0's phases; then per workgroup the time spent in the two exchanges)
       BB_RC(keep_get(ba, 4 * (size_t)pers_grid_want, &ba->d_pers_part, true));   // [2][2][grid] slot words
-      ba->pers_grid = pers_grid_want;
+      ba->pers_grid = pers_grid_want; ba->pers_grid_built = pers_grid_want;
       BB_RC(keep_get(ba, (size_t)pers_grid_want * (kCluN * (kCluN / 2)), &ba->d_pers_wsave, false));   // the units' halves of the cluster inverse, carried from trial to trial (written before read)
       if (coarse_pers) BB_RC(coarse_buffers(pers_grid_want));
     } else if (pers_try) { ba->d_pers_uoff = nullptr; ba->d_pers_ucol = nullptr; ba->d_pers_loc = nullptr; }

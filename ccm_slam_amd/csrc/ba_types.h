@@ -142,6 +142,10 @@ struct ccm_ba {
   int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
   uint32_t* d_pers_cblk = nullptr;
   unsigned long long pers_launch = 0;
+  // (round 5) pers_grid_built: the grid the handle was created for (0: it has no persistent solver); pers_grid goes to 0 for pers_cooldown trials after a launch
+  // gave up waiting for its peers and then returns to it; pers_aborts counts those launches
+  int pers_grid_built = 0, pers_cooldown = 0, pers_aborts = 0;
+  bool w_pending = false;     // the running / last persistent launch factored the cluster blocks: its wsave becomes valid once its flags have been read clean
   bool pers_agreed = false;   // sharded handle: the ranks have agreed on whether the persistent kernel is used (first ccm_ba_run)
   // coarse level (two-level preconditioner of the persistent PCG); na = 0 -> disabled
   int coarse_na = 0, coarse_Nc = 0, coarse_ncb = 0;

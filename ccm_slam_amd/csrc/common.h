@@ -44,6 +44,23 @@ struct ccm_ctx {
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
 
+// Bracket around the launch of a kernel that needs ALL its workgroups co-resident on the device (ba_pcg_persist: up to one workgroup per CU, grid-wide
+// exchanges inside).  The reference runs one global-BA thread per Map (cslam/src/Map.cpp:1401-1402, LoopFinder.cpp:686-688) beside LocalMapping and Tracking
+// (ClientHandler.cpp:184): two such launches from two contexts of one process would each get part of the chip and spin until their bounded waits give up.
+// The bracket is a per-device, process-wide LEASE kept on the GPU, not on the host: under a short host mutex the launching stream first waits for the event
+// the previous lease holder recorded behind ITS kernel, then the kernel is launched and this stream's event becomes the one to wait for — the kernels run one
+// after the other whatever stream they are on, no host thread ever blocks (so ranks that are threads of one process, joined by a collective, cannot deadlock),
+// and a process with ONE context on the device pays nothing (no event is recorded or waited for).  Kernels that merely want many CUs are not bracketed: they
+// finish on their own, and the persistent kernel's bounded waits cover the time its last workgroups need to become resident behind them.
+struct ccm_coresident_scope {
+  ccm_ctx* ctx; bool chained = false;
+  explicit ccm_coresident_scope(ccm_ctx* c);
+  ~ccm_coresident_scope();
+  ccm_coresident_scope(const ccm_coresident_scope&) = delete;
+  ccm_coresident_scope& operator=(const ccm_coresident_scope&) = delete;
+};
+void ccm_coresident_note_abort(ccm_ctx* ctx);   // a bracketed kernel gave up waiting for its peers (counted per device: ccm_coresidency_stats)
+
 #define CCM_HIP_CHECK(ctx, expr)                                                        \
   do {                                                                                  \
     hipError_t _e = (expr);                                                             \

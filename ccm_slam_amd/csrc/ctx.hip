@@ -12,6 +12,69 @@ int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg) {
   return code;
 }
 
+// ---- co-residency lease (common.h: ccm_coresident_scope) --------------------------------------
+namespace {
+constexpr int kLeaseDevices = 64, kLeaseRing = 64;
+struct DevLease {
+  std::mutex mu;
+  int n_ctx = 0;                      // live contexts of this process on the device
+  hipEvent_t ring[kLeaseRing] = {};   // created on first use; an event is re-recorded only kLeaseRing launches later (a wait captures the record it was issued behind)
+  int head = -1;                      // ring[head]: recorded behind the last bracketed kernel
+  hipStream_t last_stream = nullptr;  // the stream that kernel went to (the same stream needs no wait: stream order)
+  int64_t launches = 0, chained = 0, aborts = 0;
+};
+DevLease g_lease[kLeaseDevices];
+}  // namespace
+
+ccm_coresident_scope::ccm_coresident_scope(ccm_ctx* c) : ctx(c) {
+  DevLease& L = g_lease[c->device % kLeaseDevices];
+  L.mu.lock();
+  L.launches++;
+  if (L.n_ctx > 1 && L.head >= 0 && L.last_stream != c->stream) {
+    if (hipStreamWaitEvent(c->stream, L.ring[L.head], 0) == hipSuccess) { chained = true; L.chained++; }
+    else (void)hipGetLastError();
+  }
+}
+ccm_coresident_scope::~ccm_coresident_scope() {
+  DevLease& L = g_lease[ctx->device % kLeaseDevices];
+  if (L.n_ctx > 1) {
+    const int nxt = (L.head + 1) % kLeaseRing;
+    if (!L.ring[nxt] && hipEventCreateWithFlags(&L.ring[nxt], hipEventDisableTiming) != hipSuccess) { L.ring[nxt] = nullptr; (void)hipGetLastError(); }
+    if (L.ring[nxt] && hipEventRecord(L.ring[nxt], ctx->stream) == hipSuccess) { L.head = nxt; L.last_stream = ctx->stream; }
+    else (void)hipGetLastError();
+  }
+  L.mu.unlock();
+}
+void ccm_coresident_note_abort(ccm_ctx* ctx) {
+  DevLease& L = g_lease[ctx->device % kLeaseDevices];
+  std::lock_guard<std::mutex> lk(L.mu);
+  L.aborts++;
+}
+// a context joins / leaves its device's lease.  The second context of a process waits once for the device: a bracketed kernel the first context launched
+// while it was alone has no event behind it.
+static void lease_join(ccm_ctx* c) {
+  DevLease& L = g_lease[c->device % kLeaseDevices];
+  std::lock_guard<std::mutex> lk(L.mu);
+  if (++L.n_ctx == 2) { (void)hipDeviceSynchronize(); L.head = -1; L.last_stream = nullptr; }
+}
+static void lease_leave(ccm_ctx* c) {
+  DevLease& L = g_lease[c->device % kLeaseDevices];
+  std::lock_guard<std::mutex> lk(L.mu);
+  L.n_ctx--;
+  if (L.last_stream == c->stream) { L.last_stream = nullptr; L.head = -1; }   // (the stream was synchronised by the caller: nothing of it is in flight, and its handle may be reused)
+}
+
+extern "C" int ccm_coresidency_stats(int device_id, int64_t* launches, int64_t* chained, int64_t* aborted, int* contexts) {
+  if (device_id < 0 || device_id >= kLeaseDevices) return CCM_E_ARG;
+  DevLease& L = g_lease[device_id];
+  std::lock_guard<std::mutex> lk(L.mu);
+  if (launches) *launches = L.launches;
+  if (chained) *chained = L.chained;
+  if (aborted) *aborted = L.aborts;
+  if (contexts) *contexts = L.n_ctx;
+  return CCM_OK;
+}
+
 extern "C" const char* ccm_version(void) { return "ccm_hip 0.1 gfx950"; }
 
 extern "C" int ccm_device_count(void) {
@@ -53,6 +116,7 @@ extern "C" int ccm_ctx_create(int device_id, ccm_ctx** out) {
     delete c;
     return ccm_set_error(nullptr, CCM_E_HIP, "ccm_ctx_create: stream creation failed");
   }
+  lease_join(c);
   *out = c;
   return CCM_OK;
 }
@@ -61,6 +125,7 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  lease_leave(ctx);
   ccm_comm_destroy(ctx);
   for (auto& s : ctx->prof)
     for (auto& p : s.pending) { ctx->ev_pool.push_back(p.first); ctx->ev_pool.push_back(p.second); }

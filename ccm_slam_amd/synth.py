@@ -264,6 +264,8 @@ def make_ba_problem(n_agents: int = 1, kfs_per_agent: int = 70, n_points: int = 
 # BASELINE.json configs -> BA problem sizes
 BA_CONFIGS = {
     "lba_c2": dict(n_agents=1, kfs_per_agent=70, n_points=4000, n_fixed=40, fixed_mode="tail", seed=2001),
+    # the reference's configured local window (cslam/conf/config.yaml:78-79: Mapping.LocalMapSize 50 + Mapping.LocalMapBuffer 20): 50 free + 20 fixed keyframes
+    "lba_50": dict(n_agents=1, kfs_per_agent=70, n_points=5000, n_fixed=20, fixed_mode="tail", seed=2050),
     "gba_c3": dict(n_agents=3, kfs_per_agent=400, n_points=90000, seed=3100),
     "gba_c4": dict(n_agents=4, kfs_per_agent=500, n_points=150000, seed=4100),
     "gba_c5": dict(n_agents=8, kfs_per_agent=1250, n_points=300000, seed=5100),

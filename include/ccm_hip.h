@@ -5,14 +5,21 @@
  * The reference has no FFI for this path: cslam::ORBextractor, cslam::ORBmatcher and
  * cslam::Optimizer are concrete C++ classes (cslam/include/cslam/ORBextractor.h:103-138,
  * ORBmatcher.h:100-139, Optimizer.h:84-112).  The drop-in replaces their three translation
- * units with shims (ccm_slam_amd/host/) that flatten the shared_ptr graph into the POD
- * buffers below and call this ABI.  Every entry point cites the reference code it stands for.
+ * units with the drop-in translation units under shim/ ({Optimizer,ORBextractor,ORBmatcher}_hip.cpp,
+ * compiled against the reference's own headers), which flatten the shared_ptr graph into the POD
+ * buffers below and call this ABI (matchers: through the host mirror ccm_slam_amd/host/).  Every
+ * entry point cites the reference code it stands for.
  *
  * Conventions
  *   - plain C, POD only, caller-owned memory, no exceptions across the boundary;
  *   - return value: 0 = ok, <0 = error (CCM_E_*); ccm_last_error() gives a message;
  *   - handle based and re-entrant: one ccm_ctx per calling thread (own HIP stream);
- *     a ctx must not be used from two threads at once (reference threading: SURVEY §8b);
+ *     a ctx must not be used from two threads at once (reference threading: SURVEY §8b).
+ *     Any number of contexts of ONE process may work on one device at the same time — the
+ *     reference runs Tracking, LocalMapping and one global-BA thread per Map concurrently
+ *     (ClientHandler.cpp:184, Map.cpp:1401-1402, LoopFinder.cpp:686-688): launches that need the
+ *     whole device to themselves (the persistent reduced solve of ccm_ba_run) are put in order on
+ *     the GPU by a per-device lease, see ccm_coresidency_stats;
  *   - "host" entry points take host pointers and do their own H2D/D2H; "_dev" entry points
  *     take device pointers obtained from ccm_dev_alloc (used by bench.py so that inputs are
  *     resident in HBM when the timed region starts).
@@ -45,6 +52,13 @@ int         ccm_ctx_sync(ccm_ctx* ctx);           /* hipStreamSynchronize on the
 int         ccm_device_count(void);
 /* library/build identification, e.g. "ccm_hip 0.1 gfx950" */
 const char* ccm_version(void);
+/* The per-device lease of this process (all pointers nullable): launches = kernels launched under it (each needs all its workgroups
+ * co-resident: the persistent PCG of a 33 .. 2048-camera bundle adjustment), chained = those that were ordered behind another
+ * context's launch by an event wait on their own stream (no host thread blocks), aborted = those that still gave up waiting for their
+ * peers — the trial is then repeated on the multi-kernel solver and the handle returns to the persistent one a few trials later —,
+ * contexts = live contexts on the device.  Two PROCESSES sharing one device are not covered: give each its own GPU (north_star: one
+ * agent per GPU) or run one of them with CCM_BA_NO_PERSIST=1. */
+int         ccm_coresidency_stats(int device_id, int64_t* launches, int64_t* chained, int64_t* aborted, int* contexts);
 
 /* device memory owned by the ctx' device (thin wrappers so callers need no HIP headers) */
 int ccm_dev_alloc(ccm_ctx* ctx, size_t bytes, void** dptr);
@@ -56,6 +70,10 @@ int ccm_memcpy_d2h(ccm_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
  * bench.py's roofline leg: when enabled, every launch of the selected kernel class is
  * bracketed by hipEventRecord on the launching stream; ccm_prof_read drains the events and
  * returns launches and summed milliseconds since the last ccm_prof_reset.               */
+/* Classes, not kernels.  ORB: CCM_K_PYR_RESIZE = orb_pyramid_kernel (all levels of a frame in one launch), CCM_K_FAST_NMS = orb_cells_kernel (per 30-px cell:
+ * FAST-9/16 score, 3x3 NMS, the minThFAST retry) AND orb_octree_kernel (DistributeOctTree on the device; the 7x7 blur tiles ride in its launch, so
+ * CCM_K_BLUR counts only the host-octree path), CCM_K_BRIEF = orientation + steered descriptors (one kernel; CCM_K_ORIENT is unused), CCM_K_FAST_SCORE =
+ * the score map of the test hook only. */
 enum {
   CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
   CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
@@ -147,8 +165,9 @@ int  ccm_orb_distribute_octree(const float* x, const float* y, const float* resp
                                int minY, int maxY, int N, int32_t* sel_out, int cap, int* n_out);
 /* batch of frames already resident in HBM (d_imgs: n_frames images, tightly packed w*h each);
  * outputs stay on the device: d_kps [n_frames][cap], d_desc [n_frames][cap][32],
- * d_counts [n_frames].  Host octree selection (DistributeOctTree) runs between the two device
- * phases exactly as in ccm_orb_extract.                                                   */
+ * d_counts [n_frames].  Every stage runs on the device (DistributeOctTree included, as in
+ * ccm_orb_extract); frames go out in groups of four per launch, two groups in flight; only a frame
+ * whose candidates overflow the octree kernel's LDS plan is redone through the host octree.  */
 int  ccm_orb_extract_batch_dev(ccm_orb* orb, const uint8_t* d_imgs, int n_frames, int w, int h,
                                ccm_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
 

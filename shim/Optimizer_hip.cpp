@@ -59,13 +59,23 @@ void check(int rc, const char* what) {
 // wall-clock phases of the last bundle-adjustment call made by this thread (ms): [0] graph walk (vertices + edges gathered), [1] flatten (ids -> indices,
 // f32 -> f64), [2] ccm_ba_create (structure build: g2o's initializeOptimization + buildStructure), [3] ccm_ba_run (optimize(n)), [4] download (+ depth
 // test), [5] keyframe write-back, [6] map-point write-back (SetWorldPos + UpdateNormalAndDepth), [7] whole call.  Read with ccm_shim_last_phases().
-thread_local double g_phase[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+// (round 5) [8] GetAll* + camera vertices, [9] dropping the call's references into the flat problem, [10] RELEASE of the call's copies of the caller's pointer
+// vectors (Map::GetAllMapPoints() returns 150 000 shared_ptr by value: their destructors are 150 000 lock-prefixed decrements on cache lines that the write-back
+// threads have just scattered over the host's cores — they ran at scope exit, after the last lap, and were the largest unlabelled part of the call), [11] what is
+// still unaccounted (total - sum of the others).  Read with ccm_shim_phases().
+constexpr int kPhases = 12;
+thread_local double g_phase[kPhases] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct PhaseClock {
   double t0, t;
   PhaseClock() : t0(now_ms()), t(t0) { for (double& v : g_phase) v = 0; }
   void lap(int i) { const double n = now_ms(); g_phase[i] += n - t; t = n; }
-  ~PhaseClock() { g_phase[7] = now_ms() - t0; }
+  ~PhaseClock() {
+    g_phase[7] = now_ms() - t0;
+    double sum = 0;
+    for (int i = 0; i < kPhases - 1; i++) if (i != 7) sum += g_phase[i];
+    g_phase[kPhases - 1] = g_phase[7] - sum;
+  }
 };
 
 // host threads for the per-map-point work of a global bundle adjustment (graph walk, write-back): every map point is independent and the
@@ -89,6 +99,14 @@ void parallel_chunks(size_t n, int n_thr, F fn /* (chunk index, begin, end) */) 
     });
   for (auto& x : th) x.join();
   for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+
+// the call's own copies of the caller's pointer vectors, released on the host threads that have just written the objects back (their reference counts sit in
+// those cores' caches; one thread doing 150 000 lock-prefixed decrements on remote lines took ~29 ms at the end of MapFusionGBA on the 4-agent map)
+template <typename P>
+void release_refs(std::vector<P>& v) {
+  parallel_chunks(v.size(), shim_threads(v.size(), 32), [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) v[i].reset(); });
+  std::vector<P>().swap(v);
 }
 
 // vertex id -> index: a direct table when the ids are compact (mUniqueId, GetID of a few clients), a sorted list otherwise
@@ -129,6 +147,7 @@ struct FlatBA {
   std::vector<int32_t> pt_ref_level;
   std::vector<char> pt_regular;
   bool aux_ok = true;                                // false once flatten() had to reorder the points (the per-point arrays above are in insertion order)
+  std::vector<double> pt_xyz_walk;                   // optional: Converter::toVector3d(pMP->GetWorldPos()) taken by the graph walk while it holds the point (3 per point, insertion order)
   // flattened
   std::vector<double> cam_qt, cam_K, pt_xyz, e_obs, e_info;
   std::vector<uint8_t> cam_fix, e_level;
@@ -139,11 +158,12 @@ struct FlatBA {
   void reset() {   // keeps every vector's capacity: the global BA of a 4-agent map builds ~60 MB of flat arrays, and allocating (first-touch page faults) and
                    // releasing (munmap) them cost ~50 ms per call — the server thread keeps one FlatBA for its lifetime instead
     cam_id.clear(); pt_id.clear(); cam_kf.clear(); cam_is_fixed.clear(); pt_mp.clear(); e_cam_id.clear(); e_pt_id.clear();
-    pt_ref_cam_id.clear(); pt_ref_level.clear(); pt_regular.clear(); aux_ok = true;
+    pt_ref_cam_id.clear(); pt_ref_level.clear(); pt_regular.clear(); aux_ok = true; pt_xyz_walk.clear();
     cam_qt.clear(); cam_K.clear(); pt_xyz.clear(); e_obs.clear(); e_info.clear(); cam_fix.clear(); e_level.clear(); e_cam.clear(); e_pt.clear();
   }
   void addCam(size_t id, Optimizer::kfptr kf, bool is_fixed) { cam_id.push_back(id); cam_kf.push_back(kf); cam_is_fixed.push_back(is_fixed ? 1 : 0); }
   void addPoint(size_t id, const Optimizer::mpptr& mp) { pt_id.push_back(id); pt_mp.push_back(mp.get()); }
+  void addPointPos(const cv::Mat& P) { const float p[3] = {P.at<float>(0), P.at<float>(1), P.at<float>(2)}; double d[3]; ccmh::toVector3d(p, d); pt_xyz_walk.insert(pt_xyz_walk.end(), d, d + 3); }
   void addPointAux(size_t ref_cam_id, int level, bool regular) { pt_ref_cam_id.push_back(ref_cam_id); pt_ref_level.push_back(level); pt_regular.push_back(regular ? 1 : 0); }
   void addEdge(size_t p_id, const Optimizer::kfptr& kf, size_t c_id, const cv::KeyPoint& kpUn) {
     const float& invSigma2 = kf->mvInvLevelSigma2[kpUn.octave];
@@ -159,6 +179,7 @@ struct FlatBA {
     e_obs.insert(e_obs.end(), o.e_obs.begin(), o.e_obs.end()); e_info.insert(e_info.end(), o.e_info.begin(), o.e_info.end());
     pt_ref_cam_id.insert(pt_ref_cam_id.end(), o.pt_ref_cam_id.begin(), o.pt_ref_cam_id.end());
     pt_ref_level.insert(pt_ref_level.end(), o.pt_ref_level.begin(), o.pt_ref_level.end()); pt_regular.insert(pt_regular.end(), o.pt_regular.begin(), o.pt_regular.end());
+    pt_xyz_walk.insert(pt_xyz_walk.end(), o.pt_xyz_walk.begin(), o.pt_xyz_walk.end());
   }
   template <typename P>
   static void sort_by_id(std::vector<size_t>& ids, std::vector<P>& ptrs, std::vector<char>* flags) {
@@ -186,6 +207,8 @@ struct FlatBA {
       cam_K[4 * i] = cam_kf[i]->fx; cam_K[4 * i + 1] = cam_kf[i]->fy; cam_K[4 * i + 2] = cam_kf[i]->cx; cam_K[4 * i + 3] = cam_kf[i]->cy;
       cam_fix[i] = cam_is_fixed[i] ? 1 : 0;
     }
+    if (aux_ok && pt_xyz_walk.size() == 3 * np) pt_xyz.swap(pt_xyz_walk);             // the walk already read every position (same order: no point was moved)
+    else
     parallel_chunks(np, shim_threads(np), [&](int, size_t b, size_t e) {
       for (size_t i = b; i < e; i++) {
         const cv::Mat P = pt_mp[i]->GetWorldPos();                                   // Converter::toVector3d(pMP->GetWorldPos())
@@ -195,13 +218,23 @@ struct FlatBA {
     });
     const size_t ne = e_cam_id.size();
     e_cam.resize(ne); e_pt.resize(ne);
-    size_t w = 0;
-    for (size_t k = 0; k < ne; k++) {
-      const int32_t ci = cam_index.find(e_cam_id[k]);
-      if (ci < 0 && drop_edges_without_camera) continue;
-      e_cam[w] = ci; e_pt[w] = pt_index.find(e_pt_id[k]);
-      if (w != k) { e_cam_id[w] = e_cam_id[k]; e_pt_id[w] = e_pt_id[k]; e_obs[2 * w] = e_obs[2 * k]; e_obs[2 * w + 1] = e_obs[2 * k + 1]; e_info[w] = e_info[k]; }
-      w++;
+    // ids -> indices: two table look-ups per observation (955 000 on the 4-agent map: ~7 ms on one thread), independent from edge to edge
+    std::vector<char> missing((size_t)shim_threads(ne) + 1, 0);
+    parallel_chunks(ne, shim_threads(ne), [&](int t, size_t b, size_t e) {
+      char miss = 0;
+      for (size_t k = b; k < e; k++) { const int32_t ci = cam_index.find(e_cam_id[k]); e_cam[k] = ci; e_pt[k] = pt_index.find(e_pt_id[k]); miss |= ci < 0; }
+      missing[(size_t)t] = miss;
+    });
+    bool any_missing = false;
+    for (char m : missing) any_missing |= m != 0;
+    size_t w = ne;
+    if (any_missing && drop_edges_without_camera) {   // (rare: an observation of a keyframe that is not a vertex) ordered compaction
+      w = 0;
+      for (size_t k = 0; k < ne; k++) {
+        if (e_cam[k] < 0) continue;
+        if (w != k) { e_cam[w] = e_cam[k]; e_pt[w] = e_pt[k]; e_cam_id[w] = e_cam_id[k]; e_pt_id[w] = e_pt_id[k]; e_obs[2 * w] = e_obs[2 * k]; e_obs[2 * w + 1] = e_obs[2 * k + 1]; e_info[w] = e_info[k]; }
+        w++;
+      }
     }
     e_cam.resize(w); e_pt.resize(w); e_cam_id.resize(w); e_pt_id.resize(w); e_obs.resize(2 * w); e_info.resize(w);
     e_level.assign(w, 0);
@@ -667,6 +700,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
         }
         if (nEdges < 2) { vbNotIncludedMP[i] = true; continue; }
         g.addPoint(id, pMP);
+        g.addPointPos(pMP->GetWorldPos());   // (the vertex estimate, Optimizer.cpp:724: read here, while this thread has the point's lines, instead of in a second pass over all points)
         if (kBatchedNormals) {   // what the batched UpdateNormalAndDepth of the write-back needs beside the edges
           int nLive = 0;         // observations the reference's method would use (non-bad keyframes): all of them must be edges
           for (map<kfptr, size_t>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit) if (mit->first && !mit->first->isBad()) nLive++;
@@ -725,6 +759,11 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   pc.lap(6);
   f.cam_kf.clear(); f.pt_mp.clear();   // no keyframe / map point is kept alive between calls; the flat arrays stay allocated
   pc.lap(9);
+  // the copies Map::GetAllMapPoints() / GetAllKeyFrames() handed out by value: released on several threads and INSIDE the phase clock (round 5: their
+  // destructors used to run after the last lap, 29 ms that no phase showed)
+  release_refs(vpMP);
+  release_refs(vpKFs);
+  pc.lap(10);
 }
 
 // Optimizer.cpp:861-1056
@@ -999,3 +1038,5 @@ void Optimizer::OptimizeEssentialGraphMapFusion(mapptr pMap, kfptr pLoopKF, kfpt
 
 // phases (ms) of the last LocalBundleAdjustmentClient / MapFusionGBA call of the calling thread, see g_phase above
 extern "C" void ccm_shim_last_phases(double* out10) { for (int i = 0; i < 10; i++) out10[i] = cslam::g_phase[i]; }
+// all phases: fills min(cap, 12) entries, returns 12
+extern "C" int ccm_shim_phases(double* out, int cap) { for (int i = 0; i < cap && i < cslam::kPhases; i++) out[i] = cslam::g_phase[i]; return cslam::kPhases; }

@@ -284,9 +284,10 @@ def test_config5_10k_keyframes_multi_kernel_path(ctx, oracle_lib):
 @pytest.mark.gpu
 def test_persistent_kernel_abort_falls_back_to_the_multi_kernel_solver(ctx, oracle_lib, monkeypatch):
     """The persistent PCG kernel needs all its workgroups resident at once.  If they are not, the bounded spins of its
-    grid exchange abort the solve, the host repeats the trial with the multi-kernel PCG and never uses the persistent
-    kernel on that handle again.  CCM_BA_TEST_ABORT makes one workgroup leave immediately: the result must still follow
-    the oracle, with exactly one (aborted) persistent launch and the rest of the solves on the multi-kernel path."""
+    grid exchange abort the solve, the host repeats the trial with the multi-kernel PCG and keeps to it for the next
+    trials (round 5: kPersCooldownTrials = 8, then the handle tries the persistent kernel again —
+    tests/test_concurrency_gpu.py).  CCM_BA_TEST_ABORT makes one workgroup leave immediately: the result must still follow
+    the oracle, with exactly one (aborted) persistent launch and the rest of this short run's solves on the multi-kernel path."""
     from ccm_slam_amd._lib import K
     monkeypatch.setenv("CCM_BA_TEST_ABORT", "1")
     prob = synth.make_ba_problem(n_agents=3, kfs_per_agent=60, n_points=6000, seed=11)

@@ -26,3 +26,98 @@ def test_fewer_than_three_correspondences_returns_zero(ctx):
     p = synth.make_pose_problem(2, 0, 0.0)
     cam, outl, ninl = optimizer.pose_optimization(ctx, p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
     assert ninl == 0 and np.array_equal(cam, p["cam_qt"])
+
+
+# ---- round 5: wide seeded sweep with residuals planted AT the outlier threshold ---------------------------------------------------------------
+# Optimizer.cpp:305-330 decides mvbOutlier per edge by `const float chi2 = e->chi2(); if (chi2 > chi2Mono[it])` after each of the four rounds: the
+# observable of the call (flags + returned inlier count) is a comparison of an f64 quantity ROUNDED TO FLOAT against 5.991f, evaluated at the pose of the
+# last LM trial of the round.  The device code departs from the oracle's arithmetic in rounding only (series exp-map, explicit FMAs in the H / b sums and
+# the 6x6 solve: csrc/ba_math.h, poseopt.hip), so a flag can differ only where the oracle's own decision hangs on the last bits.  _plant() finds such a
+# point by bisection ON THE ORACLE — the scale s* of one observation's offset from its projection at which the oracle's final flag of that edge flips —
+# and the test then runs both sides at s* (1 +- delta).
+
+_SIZES = (3, 4, 5, 6, 8, 11, 16, 25, 40, 64, 100, 150, 220, 300, 300, 450, 700, 1000, 1400, 2000)
+_FRACS = (0.0, 0.02, 0.05, 0.1, 0.2, 0.3, 0.4, 0.5)
+
+
+def _project(cam_qt, Xw, K):
+    R = synth.R_from_quat(np.asarray(cam_qt)[None, :4])[0]
+    Xc = Xw @ R.T + cam_qt[4:]
+    return np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+
+
+def _plant(oracle_lib, p, j, iters=60):
+    """bisection on the oracle: scale of observation j's offset (from its projection at the oracle's optimum) at which the oracle's flag of edge j flips;
+    returns (obs with the offset direction fixed, base point, offset vector, s_lo, s_hi) with flag(s_lo) = inlier, flag(s_hi) = outlier, s_hi / s_lo - 1 < 1e-13, or None"""
+    ocam, _, _ = oracle_lib.pose_optimize(p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"])
+    base = _project(ocam, p["Xw"][j:j + 1], p["K"])[0]
+    off = p["obs"][j] - base
+    nrm = np.hypot(*off)
+    if not np.isfinite(nrm) or nrm < 1e-3:
+        off = np.array([0.7, -0.4]); nrm = np.hypot(*off)
+    off = off / nrm * np.sqrt(5.991 / p["info"][j])   # s = 1: chi2 of edge j ~ 5.991 at the oracle's optimum
+
+    def flag(s):
+        obs = p["obs"].copy(); obs[j] = base + s * off
+        return oracle_lib.pose_optimize(p["cam_qt"], p["Xw"], obs, p["info"], p["K"])[1][j]
+    lo, hi = 0.5, 2.0
+    if flag(lo) != 0 or flag(hi) != 1:
+        return None
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        if flag(mid):
+            hi = mid
+        else:
+            lo = mid
+        if hi / lo - 1 < 1e-13:
+            break
+    return base, off, lo, hi
+
+
+def _sweep_cases():
+    k = 0
+    for rep in range(2):
+        for n in _SIZES:
+            for of in _FRACS:
+                yield k, n, 5000 + k, of
+                k += 1
+
+
+def test_pose_optimization_sweep_with_residuals_planted_at_the_threshold(ctx, oracle_lib):
+    """320 seeded problems (n = 3 .. 2000, outlier fraction 0 .. 0.5, pose noise x1 / x3) as generated, and every one again with one observation moved to
+    within a relative 1e-6 / 1e-7 of the point where the oracle's own decision for that edge flips: flags and inlier count IDENTICAL, pose within 1e-7.
+    Closer than that the decision is not defined by the reference's algorithm but by its compilation: the oracle itself rebuilt with -O3 -march=native (FMA
+    contraction) decides differently from the plain build in 5 / 11 / 33 of 518 calls at 1e-8 / 1e-9 / 1e-10 and in none at 1e-7 (tests/test_poseopt_threshold_cpu.py;
+    the estimate of a frame with few inliers amplifies last-bit differences by 1e5 - 1e6) — the device measures 6 / 11 / 23 (scripts/poseopt_flip_probe.py,
+    DESIGN 3).  The planted points at 1e-8 and 1e-9 are therefore run and COUNTED: at most 5 % of those calls may differ, and only in the flag of an edge whose
+    float-rounded chi2 sits at the threshold."""
+    n_cases = n_planted = n_close = n_close_diff = 0
+    worst = 0.0
+    for k, n, seed, of in _sweep_cases():
+        p = synth.make_pose_problem(n, seed, of, pose_sigma_t=0.05 * (1 + 2 * (k % 2)), pose_sigma_r_deg=1.0 * (1 + 2 * (k % 2)))
+        variants = [("as generated", p["obs"], True)]
+        if n >= 6:
+            j = (7 * k) % n
+            pl = _plant(oracle_lib, p, j)
+            if pl is not None:
+                base, off, lo, hi = pl
+                for delta, must in ((10.0 ** -(6 + k % 2), True), (10.0 ** -(8 + k % 2), False)):
+                    for s in (lo * (1 - delta), hi * (1 + delta)):
+                        obs = p["obs"].copy(); obs[j] = base + s * off
+                        variants.append((f"edge {j} planted at s = {s!r} (delta {delta:g})", obs, must))
+                n_planted += 1
+        for what, obs, must in variants:
+            cam, outl, ninl = optimizer.pose_optimization(ctx, p["cam_qt"], p["Xw"], obs, p["info"], p["K"])
+            ocam, ooutl, oninl = oracle_lib.pose_optimize(p["cam_qt"], p["Xw"], obs, p["info"], p["K"])
+            same = ninl == oninl and np.array_equal(outl, ooutl)
+            if must:
+                assert same, (n, seed, of, what, int(ninl), int(oninl), np.flatnonzero(outl != ooutl))
+                if oninl >= 6:   # (fewer inliers than unknowns: the damped 6x6 system is near-singular and the pose is not an observable the reference relies on)
+                    worst = max(worst, float(np.abs(cam - ocam).max()))
+                n_cases += 1
+            else:
+                n_close += 1
+                n_close_diff += 0 if same else 1
+    assert n_cases >= 800 and n_planted >= 200, (n_cases, n_planted)
+    assert worst < 1e-7, worst
+    assert n_close >= 800 and n_close_diff <= 0.05 * n_close, (n_close_diff, n_close)

@@ -88,3 +88,4 @@ def test_bench_n_rank_launch_path_up_to_the_first_device_call():
     lines = [json.loads(m) for m in re.findall(r'\{"plumbing".*?\}', out.stdout)]   # the two ranks share one stdout: their lines may run together
     assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["world"] == 2 for l in lines)
     assert lines[0]["id_sha"] == lines[1]["id_sha"] and all(l["max"] == 2.0 for l in lines)
+    assert all(l["gathered_ranks"] == [0, 1] for l in lines)   # the object gather that carries every agent's figures to rank 0 (extra.agents)
