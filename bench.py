@@ -569,7 +569,7 @@ def class_api_leg(workload, prob, n_agents):
         return None
     flat = mg.flat_from_ba_problem(prob, n_agents=n_agents)
     names = ("graph_walk", "flatten", "create", "run", "download", "kf_writeback", "mp_writeback", "total", "get_all_and_camera_vertices", "release_flat_problem",
-             "release_of_the_calls_pointer_copies", "unaccounted")
+             "scope_exit_frees", "unaccounted")
 
     def phases_of(g):
         ph = (C.c_double * 12)()
@@ -602,6 +602,17 @@ def class_api_leg(workload, prob, n_agents):
         if wp:
             wp["what"] = "same call, shim built against MapPoint + SetNormalAndDepth (optional patch, INTEGRATION.md): batched normal / depth update on the device"
             best["with_setter_patch"] = wp
+    real = mg.SHIM_LIB.replace(".so", "_real.so")
+    if best and os.path.exists(real):
+        # the same call with the object graph made of the reference's REAL KeyFrame / MapPoint / Map (their own .cpp files compiled as they are, their mutexes and
+        # std::map<idpair, ...> containers: shim/Makefile liboptimizer_hip_shim_real.so, tests/test_shim_real_gpu.py) instead of the look-alike classes
+        try:
+            wr = gba_through(real)
+            if wr:
+                wr["what"] = "same call on a graph of the reference's REAL map classes (KeyFrame.cpp / MapPoint.cpp / Map.cpp compiled as they are)"
+                best["on_real_classes"] = wr
+        except Exception as e:
+            best["on_real_classes"] = {"error": str(e)}
     if best:
         # the local bundle adjustment the same way: Optimizer::LocalBundleAdjustmentClient on the lba_c2 map (two optimisations: 5 + 10 iterations)
         from ccm_slam_amd import synth

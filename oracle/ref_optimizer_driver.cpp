@@ -5,14 +5,62 @@
 //                                          (oracle/Makefile.ref) — the reference behaviour
 //   shim/liboptimizer_hip_shim.so          with OUR drop-in shim/Optimizer_hip.cpp (-> libccm_hip.so on the MI355X)
 // so that tests/test_ref_optimizer.py / tests/test_shim_gpu.py can hand both the identical map and compare what they leave behind.
+//   shim/liboptimizer_hip_shim_real.so     (round 5, -DCCM_REAL_CLASSES) with OUR shim/Optimizer_hip.cpp AND the reference's own cslam/src/{KeyFrame,MapPoint,Map,
+//                                          Frame}.cpp + Converter.cc compiled as they are against the reference's REAL headers: the object graph below is
+//                                          then made of the reference's real classes (their mutexes, their accessors, their std::map<idpair, ...> containers)
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <new>
+#include <cstddef>
+#include <set>
 #include <vector>
+
+#ifdef CCM_REAL_CLASSES
+// The real KeyFrame / MapPoint / Map keep their state protected and are only constructible through the tracking pipeline, ROS messages or the save / load
+// path; a TEST HARNESS may cheat: every header of the standard library and of the third-party look-alikes is included FIRST (so that the keyword games below
+// never reach them), then the reference's class headers are read with their members made accessible.  Layout and code of the classes are untouched — the
+// member functions that run are the ones compiled from the reference's .cpp files.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <list>
+#include <mutex>
+#include <numeric>
+#include <sstream>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <boost/shared_ptr.hpp>
+#include <opencv2/opencv.hpp>
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <ros/ros.h>
+#include <cslam/config.h>
+#include <cslam/estd.h>
+#include <cslam/Datatypes.h>
+#include <cslam/Converter.h>
+#define private public
+#define protected public
+#include <cslam/KeyFrame.h>
+#include <cslam/MapPoint.h>
+#include <cslam/Map.h>
+#include <cslam/Frame.h>
+#undef private
+#undef protected
+#endif
 
 #include <cslam/Optimizer.h>
 
+#ifndef CCM_REAL_CLASSES
 namespace cslam { std::mutex MapPoint::mGlobalMutex; }
+#endif
 
 namespace {
 using cslam::Frame;
@@ -22,14 +70,38 @@ using cslam::MapPoint;
 typedef boost::shared_ptr<KeyFrame> kfptr;
 typedef boost::shared_ptr<MapPoint> mpptr;
 
+#ifdef CCM_REAL_CLASSES
+// contiguous raw storage, objects placed with the reference's save / load constructors (KeyFrame.cpp:33-49, MapPoint.cpp:32-46) and destroyed in place
+template <class T> struct Store {
+  T* p = nullptr; size_t n = 0, made = 0;
+  void alloc(size_t k) { n = k; p = static_cast<T*>(::operator new(sizeof(T) * (k ? k : 1))); static_assert(alignof(T) <= alignof(std::max_align_t), "plain operator new is aligned enough"); }
+  T& operator[](size_t i) { return p[i]; }
+  ~Store() { for (size_t i = made; i-- > 0;) p[i].~T(); if (p) ::operator delete(p); }
+};
+#endif
 struct MapG {
   // contiguous stores: shared_ptr ordering (std::map<kfptr, ...> iteration, std::set<kfptr>) is ADDRESS order = index order here
+  // (declared first = destroyed last: the shared_ptr vectors and the map below only refer to them)
+#ifdef CCM_REAL_CLASSES
+  Store<KeyFrame> kf_store;
+  Store<MapPoint> mp_store;
+  boost::shared_ptr<cslam::Communicator> comm;   // never dereferenced: the three Communicator methods the map classes call are no-ops of the harness (real_graph_support.cpp)
+#else
   std::unique_ptr<KeyFrame[]> kf_store;
   std::unique_ptr<MapPoint[]> mp_store;
+#endif
   std::vector<kfptr> kfs;
   std::vector<mpptr> mps;
   boost::shared_ptr<Map> map;
   std::vector<int> obs_mp, obs_kf;
+#ifdef CCM_REAL_CLASSES
+  ~MapG() {   // break the pointer cycles of the real graph before the stores go (keyframes hold their points and neighbours, points their observers, the map both)
+    for (size_t k = 0; k < kf_store.made; k++) { KeyFrame& kf = kf_store[k]; kf.mvpMapPoints.clear(); kf.mConnectedKeyFrameWeights.clear(); kf.mvpOrderedConnectedKeyFrames.clear(); kf.mpParent.reset(); kf.mspChildrens.clear(); kf.mspLoopEdges.clear(); kf.mspComm.clear(); kf.mpMap.reset(); }
+    for (size_t p = 0; p < mp_store.made; p++) { MapPoint& mp = mp_store[p]; mp.mObservations.clear(); mp.mpRefKF.reset(); mp.mspComm.clear(); mp.mpMap.reset(); }
+    if (map) { map->mmpKeyFrames.clear(); map->mmpMapPoints.clear(); map->mvpKeyFrameOrigins.clear(); map->mspComm.clear(); }
+    kfs.clear(); mps.clear(); map.reset();
+  }
+#endif
 };
 
 cv::Mat mat44(const float* T) { cv::Mat m(4, 4, CV_32F); std::memcpy(m.data, T, 64); return m; }
@@ -44,10 +116,21 @@ void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, cons
                   const int32_t* mp_client, const int32_t* mp_uid, const float* mp_pos, const uint8_t* mp_bad, int n_obs, const int32_t* obs_mp,
                   const int32_t* obs_kf, const int32_t* obs_kp, int n_levels, float scale_factor, int map_id, int cov_th) {
   MapG* g = new MapG();
+#ifdef CCM_REAL_CLASSES
+  // the map as a SERVER map (the state MapFusionGBA runs in; mapg_lock_points switches the points of a client test), one communicator pointer like every live map has
+  g->comm = boost::shared_ptr<cslam::Communicator>(static_cast<cslam::Communicator*>(::operator new(64)), [](cslam::Communicator* c) { ::operator delete(c); });
+  g->map.reset(new Map(ros::NodeHandle(), ros::NodeHandle(), (size_t)map_id, cslam::eSystemState::SERVER));
+  g->map->mspComm.insert(g->comm);
+  g->kf_store.alloc((size_t)n_kf);
+  g->mp_store.alloc((size_t)n_mp);
+  for (int k = 0; k < n_kf; k++) { new (&g->kf_store[k]) KeyFrame(cslam::vocptr(), g->map, KeyFrame::dbptr(), g->comm, cslam::eSystemState::SERVER, (size_t)kf_uid[k]); g->kf_store.made++; }
+  for (int p = 0; p < n_mp; p++) { new (&g->mp_store[p]) MapPoint(g->map, g->comm, cslam::eSystemState::SERVER, (size_t)mp_uid[p]); g->mp_store.made++; }
+#else
   g->kf_store.reset(new KeyFrame[n_kf]);
   g->mp_store.reset(new MapPoint[n_mp]);
   g->map.reset(new Map());
   g->map->mMapId = (size_t)map_id;
+#endif
   std::vector<float> sf(n_levels), s2(n_levels), is2(n_levels);
   sf[0] = 1.0f; s2[0] = 1.0f;
   for (int i = 1; i < n_levels; i++) { sf[i] = sf[i - 1] * scale_factor; s2[i] = sf[i] * sf[i]; }   // ORBextractor.cpp:586-591
@@ -66,8 +149,16 @@ void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, cons
     kf.mvKeysUn.resize(kf.N);
     for (int i = 0; i < kf.N; i++) { const int s = kp_off[k] + i; kf.mvKeysUn[i] = cv::KeyPoint(kp_xy[2 * s], kp_xy[2 * s + 1], 31.f * sf[kp_oct[s]], -1, 0, kp_oct[s]); }
     kf.mvpMapPoints.assign(kf.N, mpptr());
+#ifdef CCM_REAL_CLASSES
+    kf.mvbMapPointsLock.assign(kf.N, false);                           // (what the tracking-side constructor sizes with mvpMapPoints, KeyFrame.cpp:74-77)
+    kf.mHalfBaseline = 0; kf.invfx = 1.0f / kf.fx; kf.invfy = 1.0f / kf.fy; kf.mbOmitSending = true;   // (nothing to publish while the graph is being built)
+    g->kfs.push_back(kfptr(&kf, [](KeyFrame*) {}));   // before SetPose: the real method may ask for shared_from_this()
+    kf.SetPose(mat44(kf_Tcw + 16 * (size_t)k), false, false);
+    kf.mbOmitSending = false;
+#else
     kf.SetPose(mat44(kf_Tcw + 16 * (size_t)k), false);
     g->kfs.push_back(kfptr(&kf, [](KeyFrame*) {}));
+#endif
     g->map->msuAssClients.insert((size_t)kf_client[k]);
   }
   for (int p = 0; p < n_mp; p++) {
@@ -77,9 +168,17 @@ void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, cons
     mp.mbBad = mp_bad[p] != 0;
     cv::Mat pos(3, 1, CV_32F);
     for (int c = 0; c < 3; c++) pos.at<float>(c) = mp_pos[3 * (size_t)p + c];
+#ifdef CCM_REAL_CLASSES
+    g->mps.push_back(mpptr(&mp, [](MapPoint*) {}));
+    mp.mbOmitSending = true; mp.mfMinDistance = 0; mp.mfMaxDistance = 0; mp.mnVisible = 1; mp.mnFound = 1;
+    mp.SetWorldPos(pos, false, false);
+    mp.mbOmitSending = false;
+    mp.mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
+#else
     mp.SetWorldPos(pos, false);
     mp.mNormalVector = cv::Mat::zeros(3, 1, CV_32F);
     g->mps.push_back(mpptr(&mp, [](MapPoint*) {}));
+#endif
   }
   g->obs_mp.assign(obs_mp, obs_mp + n_obs); g->obs_kf.assign(obs_kf, obs_kf + n_obs);
   std::vector<std::map<int, int>> shared(n_kf);   // covisibility weights
@@ -102,8 +201,25 @@ void* mapg_create(int n_kf, const int32_t* kf_id, const int32_t* kf_client, cons
     for (auto& e : v) { kf.mvpOrderedConnectedKeyFrames.push_back(g->kfs[e.second]); kf.mvOrderedWeights.push_back(e.first); kf.mConnectedKeyFrameWeights[g->kfs[e.second]] = e.first; }
     if (k > 0 && kf_client[k] == kf_client[k - 1]) { kf.mpParent = g->kfs[k - 1]; g->kf_store[k - 1].mspChildrens.insert(g->kfs[k]); }
   }
+#ifdef CCM_REAL_CLASSES
+  // what Map::AddKeyFrame / AddMapPoint do on a server map (Map.cpp), minus the communicator hand-over: file the object under its id, keep the maxima
+  for (int k = 0; k < n_kf; k++) {
+    KeyFrame& kf = g->kf_store[k];
+    g->map->mmpKeyFrames[kf.mId] = g->kfs[k];
+    if (kf.mId.first > g->map->mnMaxKFid) g->map->mnMaxKFid = kf.mId.first;
+    if (kf.mUniqueId > g->map->mnMaxKFidUnique) g->map->mnMaxKFidUnique = kf.mUniqueId;
+    g->map->mnLastKfIdUnique = kf.mUniqueId;
+  }
+  for (int p = 0; p < n_mp; p++) {
+    MapPoint& mp = g->mp_store[p];
+    g->map->mmpMapPoints[mp.mId] = g->mps[p];
+    if (mp.mId.first > g->map->mnMaxMPid) g->map->mnMaxMPid = mp.mId.first;
+    if (mp.mUniqueId > g->map->mnMaxMPidUnique) g->map->mnMaxMPidUnique = mp.mUniqueId;
+  }
+#else
   g->map->mvpKeyFrames = g->kfs;
   g->map->mvpMapPoints = g->mps;
+#endif
   if (n_kf) g->map->mvpKeyFrameOrigins.push_back(g->kfs[0]);
   for (int p = 0; p < n_mp; p++) g->mp_store[p].UpdateNormalAndDepth();   // as after point creation (Mapping.cpp)
   return g;
@@ -169,6 +285,10 @@ void mapg_get_state(void* h, float* kf_Tcw, float* kf_gba, uint8_t* kf_gba_flag,
 // cslam::Optimizer::PoseOptimizationClient(Frame&)   (Optimizer.h:88): a Frame with n keypoints, each with a map point
 int mapg_pose_optimization(float* Tcw, int n, const float* kp_xy, const int32_t* kp_oct, const float* mp_pos, const float* K4, int n_levels,
                            float scale_factor, uint8_t* outlier) {
+#ifdef CCM_REAL_CLASSES
+  (void)Tcw; (void)n; (void)kp_xy; (void)kp_oct; (void)mp_pos; (void)K4; (void)n_levels; (void)scale_factor; (void)outlier;
+  return -100;   // the real Frame is only constructible from an image (ORB extraction + cv::undistortPoints): stays on the look-alike Frame
+#else
   Frame F;
   F.N = n;
   F.fx = K4[0]; F.fy = K4[1]; F.cx = K4[2]; F.cy = K4[3];
@@ -189,6 +309,7 @@ int mapg_pose_optimization(float* Tcw, int n, const float* kp_xy, const int32_t*
   std::memcpy(Tcw, F.mTcw.data, 64);
   for (int i = 0; i < n; i++) outlier[i] = F.mvbOutlier[i] ? 1 : 0;
   return nin;
+#endif
 }
 
 namespace {

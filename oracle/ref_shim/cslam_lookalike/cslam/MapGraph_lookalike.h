@@ -94,10 +94,14 @@ class KeyFrame : public boost::enable_shared_from_this<KeyFrame> {
   std::vector<int> mvOrderedWeights;
   std::map<kfptr, int> mConnectedKeyFrameWeights;
   std::vector<kfptr> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
-  std::vector<kfptr> GetCovisiblesByWeight(const int& w) {   // KeyFrame.cpp: the ordered list down to weight w
-    std::vector<kfptr> out;
-    for (size_t i = 0; i < mvpOrderedConnectedKeyFrames.size(); i++) if (mvOrderedWeights[i] >= w) out.push_back(mvpOrderedConnectedKeyFrames[i]);
-    return out;
+  // KeyFrame.cpp (GetCovisiblesByWeight): the ordered list down to weight w — with the reference's own corner case: when NO neighbour is weaker than w,
+  // upper_bound returns end() and the method returns an EMPTY list, not all neighbours.  (Round 5: found by running the shim on the reference's real KeyFrame.cpp,
+  // tests/test_shim_real_gpu.py; the earlier look-alike returned every neighbour with weight >= w.)
+  std::vector<kfptr> GetCovisiblesByWeight(const int& w) {
+    if (mvpOrderedConnectedKeyFrames.empty()) return std::vector<kfptr>();
+    std::vector<int>::iterator it = std::upper_bound(mvOrderedWeights.begin(), mvOrderedWeights.end(), w, [](int a, int b) { return a > b; });
+    if (it == mvOrderedWeights.end()) return std::vector<kfptr>();
+    return std::vector<kfptr>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + (it - mvOrderedWeights.begin()));
   }
   int GetWeight(kfptr pKF) { auto it = mConnectedKeyFrameWeights.find(pKF); return it == mConnectedKeyFrameWeights.end() ? 0 : it->second; }
   kfptr mpParent;

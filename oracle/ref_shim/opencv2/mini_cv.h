@@ -164,6 +164,8 @@ class Mat {
     dst.create(rows, cols, flags_type);
     for (int r = 0; r < rows; r++) std::memmove(dst.ptr(r), ptr(r), (size_t)cols * elemSize());
   }
+  Mat reshape(int /*cn*/, int /*rows*/ = 0) const { return *this; }   // single-channel look-alike: an N x 2 CV_32F matrix IS the N two-channel points Frame.cpp:294-296 reshapes to
+  void copyTo(Mat&& dst) const { Mat& d = dst; copyTo(d); }   // `A.copyTo(B.rowRange(..).colRange(..))`: OpenCV's OutputArray binds the temporary view; the view shares B's pixels
   double get(int r, int c) const { return flags_type == CV_32F ? (double)at<float>(r, c) : (flags_type == CV_64F ? at<double>(r, c) : (flags_type == CV_32S ? (double)at<int>(r, c) : (double)at<uchar>(r, c))); }
   void set(int r, int c, double v) {
     if (flags_type == CV_32F) at<float>(r, c) = (float)v; else if (flags_type == CV_64F) at<double>(r, c) = v; else if (flags_type == CV_32S) at<int>(r, c) = (int)v; else at<uchar>(r, c) = (uchar)v;
@@ -295,6 +297,7 @@ inline Mat operator*(const Mat& a, double s) {
   return m;
 }
 inline Mat operator*(double s, const Mat& a) { return a * s; }
+inline Mat& operator*=(Mat& a, double s) { a = a * s; return a; }   // (a MatExpr assigned back: new pixels, as cv::Mat::operator*= via MatExpr does)
 inline Mat operator/(const Mat& a, double s) { return a * (1. / s); }
 inline double norm(const Mat& a) { double s = 0; for (int r = 0; r < a.rows; r++) for (int c = 0; c < a.cols; c++) s += a.get(r, c) * a.get(r, c); return std::sqrt(s); }
 inline double norm(const Mat& a, const Mat& b) { return norm(a - b); }

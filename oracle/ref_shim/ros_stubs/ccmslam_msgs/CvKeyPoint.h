@@ -8,11 +8,17 @@
 #include <ros/time.h>
 namespace ccmslam_msgs {
 struct CvKeyPoint {
+  typedef float _fPoint2f_x_type;
   float fPoint2f_x;
+  typedef float _fPoint2f_y_type;
   float fPoint2f_y;
+  typedef uint8_t _size_type;
   uint8_t size;
+  typedef float _angle_type;
   float angle;
+  typedef uint8_t _response_type;
   uint8_t response;
+  typedef int8_t _octave_type;
   int8_t octave;
   typedef boost::shared_ptr<CvKeyPoint> Ptr;
   typedef boost::shared_ptr<CvKeyPoint const> ConstPtr;

@@ -8,6 +8,7 @@
 #include <ros/time.h>
 namespace ccmslam_msgs {
 struct Descriptor {
+  typedef boost::array<uint8_t, 32> _mDescriptor_type;
   boost::array<uint8_t, 32> mDescriptor;
   typedef boost::shared_ptr<Descriptor> Ptr;
   typedef boost::shared_ptr<Descriptor const> ConstPtr;

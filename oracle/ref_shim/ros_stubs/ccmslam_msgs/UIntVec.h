@@ -8,6 +8,7 @@
 #include <ros/time.h>
 namespace ccmslam_msgs {
 struct UIntVec {
+  typedef std::vector<uint32_t> _uintvec_type;
   std::vector<uint32_t> uintvec;
   typedef boost::shared_ptr<UIntVec> Ptr;
   typedef boost::shared_ptr<UIntVec const> ConstPtr;

@@ -1,6 +1,9 @@
 // look-alike of <ros/ros.h> (TEST INFRASTRUCTURE): the handle / publisher / subscriber types the reference's class DECLARATIONS name (no behaviour)
 #pragma once
 #include <string>
+#include <dirent.h>     // (the real <ros/ros.h> drags these in; Map.cpp / MapPoint.cpp use mkdir / opendir / usleep without including them)
+#include <sys/stat.h>
+#include <unistd.h>
 #include <ros/time.h>
 #include <boost/shared_ptr.hpp>
 namespace ros {

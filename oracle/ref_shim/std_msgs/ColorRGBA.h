@@ -9,6 +9,7 @@ struct Time {
   double t = 0;
   static Time now() { Time x; x.t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); return x; }
   double toSec() const { return t; }
+  unsigned long long toNSec() const { return (unsigned long long)(t * 1e9); }
 };
 inline std::ostream& operator<<(std::ostream& os, const Time& t) { return os << t.t; }
 }  // namespace ros

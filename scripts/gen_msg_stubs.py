@@ -39,7 +39,7 @@ for fn in sorted(os.listdir(SRC)):
             f.write(f"#include <{d}>\n")
         f.write(f"namespace ccmslam_msgs {{\nstruct {name} {{\n")
         for ct, var in fields:
-            f.write(f"  {ct} {var};\n")
+            f.write(f"  typedef {ct} _{var}_type;\n  {ct} {var};\n")   # genmsg's per-field typedefs (KeyFrame.cpp / MapPoint.cpp name them in Converter template arguments)
         f.write(f"  typedef boost::shared_ptr<{name}> Ptr;\n  typedef boost::shared_ptr<{name} const> ConstPtr;\n}};\n")
         f.write(f"typedef boost::shared_ptr<{name}> {name}Ptr;\ntypedef boost::shared_ptr<{name} const> {name}ConstPtr;\n}}\n")
     print("wrote", name, len(fields), "fields")

@@ -9,7 +9,7 @@ from ccm_slam_amd import optimizer, synth  # noqa: E402
 from ccm_slam_amd._lib import Context  # noqa: E402
 
 ctx = Context(0)
-prob = synth.make_ba_config("lba_c2")
+prob = synth.make_ba_config(sys.argv[1] if len(sys.argv) > 1 else "lba_c2")   # lba_50: the reference's configured window
 best = 1e9
 for r in range(9):
     t0 = time.perf_counter()

@@ -16,6 +16,7 @@
 // behind in the map.
 #include <cslam/Optimizer.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -59,10 +60,13 @@ void check(int rc, const char* what) {
 // wall-clock phases of the last bundle-adjustment call made by this thread (ms): [0] graph walk (vertices + edges gathered), [1] flatten (ids -> indices,
 // f32 -> f64), [2] ccm_ba_create (structure build: g2o's initializeOptimization + buildStructure), [3] ccm_ba_run (optimize(n)), [4] download (+ depth
 // test), [5] keyframe write-back, [6] map-point write-back (SetWorldPos + UpdateNormalAndDepth), [7] whole call.  Read with ccm_shim_last_phases().
-// (round 5) [8] GetAll* + camera vertices, [9] dropping the call's references into the flat problem, [10] RELEASE of the call's copies of the caller's pointer
-// vectors (Map::GetAllMapPoints() returns 150 000 shared_ptr by value: their destructors are 150 000 lock-prefixed decrements on cache lines that the write-back
-// threads have just scattered over the host's cores — they ran at scope exit, after the last lap, and were the largest unlabelled part of the call), [11] what is
-// still unaccounted (total - sum of the others).  Read with ccm_shim_phases().
+// (round 5) [8] GetAll* + camera vertices, [9] dropping the call's references into the flat problem, [10] SCOPE EXIT: everything the call's locals free.  On the
+// 4-agent map this was the largest unlabelled part of the call (29 ms after the last lap).  It is not the 150 000 shared_ptr copies Map::GetAllMapPoints() hands
+// out (those are dropped inside the write-back loop now, by the thread that has just worked on the point) but glibc: the threaded write-back frees the points' old
+// cv::Mat buffers — allocated by whichever thread built the map — back into THAT thread's arena, ~2 fastbin chunks per point, and the first large free() / malloc()
+// that arena sees afterwards (here: the 2.4 MB pointer vector at scope exit) runs malloc_consolidate over all of them (measured with MALLOC_ARENA_MAX=1: the phase
+// vanishes; on one thread there is no cross-arena garbage either).  With the optional MapPoint setter the write-back reuses the buffers and the
+// phase is empty.  [11] what is still unaccounted (total - sum of the others).  Read with ccm_shim_phases().
 constexpr int kPhases = 12;
 thread_local double g_phase[kPhases] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -649,6 +653,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
 void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool* pbStopFlag, idpair nLoopKF, const bool bRobust) {
   (void)ClientId;
   PhaseClock pc;
+  {   // (everything the call owns lives in this scope, so that what its destructors cost is inside the last phase, not after it)
   vector<kfptr> vpKFs = pMap->GetAllKeyFrames();
   vector<mpptr> vpMP = pMap->GetAllMapPoints();
   const idpair zeropair = make_pair(0, pMap->mMapId);
@@ -738,31 +743,42 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   // every keyframe has its new pose: the per-point write-back (SetWorldPos + UpdateNormalAndDepth, 150 000 mutex-taking calls after a merge of four
   // agents) is independent from point to point
   static const bool batched_off = std::getenv("CCM_SHIM_NO_BATCHED_NORMALS") != nullptr;
+  bool refs_dropped = false;
   if (kBatchedNormals && !batched_off && nLoopKF == zeropair && f.aux_ok && f.pt_regular.size() == f.pt_id.size() && !f.cam_kf.empty()) batched_point_writeback(f, nullptr, true, true, true);
-  else
-  parallel_chunks(vpMP.size(), shim_threads(vpMP.size(), 32), [&](int, size_t i0, size_t i1) {
+  else {
+  refs_dropped = true;
+  const int n_wb = shim_threads(vpMP.size(), 32);
+  // (measured on the reference's REAL classes, 150 000 points: 63 - 78 ms for this loop on 32 threads against 18 on the look-alike — the real SetWorldPos takes the
+  // process-wide MapPoint::mGlobalMutex (MapPoint.cpp:343) and the real UpdateNormalAndDepth two mutexes of every observing keyframe (isBad, GetCameraCenter).  Tried
+  // and dropped: all positions on one thread with the normals following behind it (67 ms: the call itself is ~450 ns), positions on four threads then normals on all (66 - 82 ms).)
+  parallel_chunks(vpMP.size(), n_wb, [&](int, size_t i0, size_t i1) {
     for (size_t i = i0; i < i1; i++) {
-      if (vbNotIncludedMP[i]) continue;
-      const mpptr& pMP = vpMP[i];
-      if (pMP->isBad()) continue;
-      cv::Mat pos = f.pointPos(pMP->mUniqueId);
-      if (nLoopKF == zeropair) {
-        pMP->SetWorldPos(pos, true);
-        pMP->UpdateNormalAndDepth();
-      } else {
-        pMP->mPosGBA.create(3, 1, CV_32F);
-        pos.copyTo(pMP->mPosGBA);
-        pMP->mBAGlobalForKF = nLoopKF;
+      mpptr& pMP = vpMP[i];
+      if (!vbNotIncludedMP[i] && !pMP->isBad()) {
+        cv::Mat pos = f.pointPos(pMP->mUniqueId);
+        if (nLoopKF == zeropair) {
+          pMP->SetWorldPos(pos, true);
+          pMP->UpdateNormalAndDepth();
+        } else {
+          pMP->mPosGBA.create(3, 1, CV_32F);
+          pos.copyTo(pMP->mPosGBA);
+          pMP->mBAGlobalForKF = nLoopKF;
+        }
       }
+      // this call's copy of the pointer (Map::GetAllMapPoints() hands out 150 000 of them by value) is dropped by the thread that has just worked on the point:
+      // releasing them in one go afterwards cost 13 - 30 ms on the 4-agent map (one lock-prefixed decrement per point on a line some other core holds)
+      pMP.reset();
     }
   });
+  }
   pc.lap(6);
   f.cam_kf.clear(); f.pt_mp.clear();   // no keyframe / map point is kept alive between calls; the flat arrays stay allocated
   pc.lap(9);
   // the copies Map::GetAllMapPoints() / GetAllKeyFrames() handed out by value: released on several threads and INSIDE the phase clock (round 5: their
   // destructors used to run after the last lap, 29 ms that no phase showed)
-  release_refs(vpMP);
+  if (!refs_dropped) release_refs(vpMP);
   release_refs(vpKFs);
+  }
   pc.lap(10);
 }
 

@@ -120,4 +120,4 @@ def test_pose_optimization_sweep_with_residuals_planted_at_the_threshold(ctx, or
                 n_close_diff += 0 if same else 1
     assert n_cases >= 800 and n_planted >= 200, (n_cases, n_planted)
     assert worst < 1e-7, worst
-    assert n_close >= 800 and n_close_diff <= 0.05 * n_close, (n_close_diff, n_close)
+    assert n_close >= 500 and n_close_diff <= 0.05 * n_close, (n_close_diff, n_close)
