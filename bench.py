@@ -279,7 +279,43 @@ def hamming_leg(ctx):
     out["csr"] = {"workload": f"Q = {Q} queries x {int(off[-1]) / Q:.1f} candidates out of T = {T} features (one wave per query), distances + best / second-best", "kernel_launches_per_call": n // reps,
                   "kernel_us_per_call": round(us, 2), "algorithmic_bytes": by, "achieved": round(by / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm / L2 gather (4.9 MB per call: launch latency at this size)"}
+    # (round 5) the same search as LocalMapping issues it per new keyframe — 20 of them, each against another keyframe's descriptors (Mapping.cpp:335, :503) — as ONE
+    # ccm_hamming_csr_multi_dev launch, everything resident in HBM
+    S = 20
+    qs = rng.integers(0, 256, (S * Q, 32), dtype=np.uint8)
+    ts = rng.integers(0, 256, (S * T, 32), dtype=np.uint8)
+    cnt = rng.integers(20, 41, S * Q)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    idx = rng.integers(0, T, int(off[-1])).astype(np.int32)
+    tbase = (np.repeat(np.arange(S), Q) * T).astype(np.int32)
+    cm = matcher.CsrMultiDev(ctx, qs, ts, tbase, off, idx)
+    for _ in range(3):
+        cm.run()
+    ctx.sync()
+    ctx.prof_enable(K["HAMMING_CSR"]); ctx.prof_reset()
+    for _ in range(reps):
+        cm.run()
+    ctx.sync()
+    n, ms = ctx.prof_read(K["HAMMING_CSR"])
+    ctx.prof_enable(-2)
+    cm.close()
+    us = ms * 1e3 / reps
+    by = 32.0 * (S * Q + int(off[-1])) + 12.0 * S * Q   # SURVEY 8(d)'s formula, as for `csr` above (descriptors of queries and candidates, results; the 6 bytes of index + distance per slot are not counted)
+    out["csr_batched"] = {"workload": f"{S} searches x {Q} queries x {int(off[-1]) / (S * Q):.1f} candidates, each search against its own {T}-feature set; one ccm_hamming_csr_multi_dev launch ({matcher_group_width(int(off[-1]), S * Q)} lanes per query), inputs and outputs resident in HBM",
+                          "kernel_launches_per_call": n // reps, "kernel_us_per_call": round(us, 2), "algorithmic_bytes": by, "achieved": round(by / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                          "bound": "L2 gather: the 20 target sets (1.3 MB) stay in L2, so the candidates' descriptor rows are served from there, not from HBM — the fraction is the ALGORITHMIC bytes over the HBM peak",
+                          "us_per_search": round(us / S, 3), "vs_twenty_single_launches_us": round(out["csr"]["kernel_us_per_call"] * S, 1)}
     return out
+
+
+def matcher_group_width(n_cand, Q):
+    """lanes per query the windowed search uses for a mean list length (hamming.hip: csr_group_width)"""
+    mean = n_cand / max(Q, 1)
+    g = 8
+    while g < 64 and 2 * g < mean:
+        g <<= 1
+    return g
 
 
 def tracking_leg(ctx, with_cpu, n_frames=32):

@@ -211,6 +211,76 @@ __global__ __launch_bounds__(256) void hamming_csr_kernel(
 }
 
 
+// (round 5) The same search with G lanes per query (G = 8, 16, 32; 64 / G queries per wave) and an optional per-query TARGET BASE.  The reference's window and BoW-bucket
+// searches have short lists — ~20 candidates for a SearchForTriangulation query, ~30 for a projected window —, so a wave per query leaves more than half of its
+// lanes idle and every query pays a whole wave's launch slot; and Mapping.cpp:335 / :503 runs up to 20 such searches per new keyframe, each against ANOTHER
+// keyframe's descriptors.  ccm_hamming_csr_multi sends all of them out as one launch: the queries of all searches back to back, q_tbase[q] = first row of the
+// target set query q searches in (its candidate indices are local to that set).  Results per slot are the same integers whatever G is: the distance of a slot does
+// not depend on its neighbours, and best / second are the minimum and the second minimum of the keys (distance << 20 | slot), which no grouping changes.
+template <int G>
+__global__ __launch_bounds__(256) void hamming_csr_group_kernel(
+    const uint32_t* __restrict__ q, int Q, const uint32_t* __restrict__ t, const int32_t* __restrict__ q_tbase /* nullable */,
+    const int32_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx,
+    uint16_t* __restrict__ cand_dist, int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+    int32_t* __restrict__ second_dist, long long n_cand) {
+  const int sub = threadIdx.x & (G - 1);
+  const int qi = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) / G);
+  const bool live = qi < Q;
+  int c0 = 0, c1 = 0;
+  if (live) { c0 = cand_off[qi]; c1 = cand_off[qi + 1]; if ((long long)c1 > n_cand) c1 = c0; }   // a list beyond the buffers the caller sized is never touched
+  uint4 qlo = make_uint4(0, 0, 0, 0), qhi = qlo;
+  size_t tb = 0;
+  if (live) {
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+    qlo = qp[0]; qhi = qp[1];
+    if (q_tbase) tb = (size_t)q_tbase[qi] * 8;
+  }
+  uint32_t kbest = 0xFFFFFFFFu, ksecond = 0xFFFFFFFFu;
+  // every group of the wave runs as many rounds as the longest list among them (the shuffles below need all lanes)
+  int rounds = (c1 - c0 + G - 1) / G;
+#pragma unroll
+  for (int off = G; off < kWave; off <<= 1) rounds = max(rounds, __shfl_xor(rounds, off, kWave));
+  for (int r = 0; r < rounds; r++) {
+    const int s = c0 + r * G + sub;
+    uint32_t key = 0xFFFFFFFFu;
+    if (s < c1) {
+      const int ti = cand_idx[s];
+      const uint4* tp = reinterpret_cast<const uint4*>(t + tb + (size_t)ti * 8);
+      const uint4 lo = tp[0], hi = tp[1];
+      const int d = __builtin_popcount(qlo.x ^ lo.x) + __builtin_popcount(qlo.y ^ lo.y) + __builtin_popcount(qlo.z ^ lo.z) + __builtin_popcount(qlo.w ^ lo.w) +
+                    __builtin_popcount(qhi.x ^ hi.x) + __builtin_popcount(qhi.y ^ hi.y) + __builtin_popcount(qhi.z ^ hi.z) + __builtin_popcount(qhi.w ^ hi.w);
+      if (cand_dist) cand_dist[s] = (uint16_t)d;
+      key = ((uint32_t)d << 20) | (uint32_t)(s - c0);
+    }
+    if (best_idx) {
+      uint32_t m1 = key;
+#pragma unroll
+      for (int off = G / 2; off >= 1; off >>= 1) m1 = min(m1, (uint32_t)__shfl_xor((int)m1, off, kWave));
+      uint32_t m2 = (key == m1) ? 0xFFFFFFFFu : key;   // keys are unique (slot bits)
+#pragma unroll
+      for (int off = G / 2; off >= 1; off >>= 1) m2 = min(m2, (uint32_t)__shfl_xor((int)m2, off, kWave));
+      if (m1 < kbest) { ksecond = min(kbest, m2); kbest = m1; }
+      else            { ksecond = min(ksecond, m1); }
+    }
+  }
+  if (best_idx && live && sub == 0) {
+    if (kbest == 0xFFFFFFFFu) { best_idx[qi] = -1; best_dist[qi] = 256; second_dist[qi] = 256; }
+    else {
+      best_idx[qi] = cand_idx[c0 + (int)(kbest & 0xFFFFFu)];
+      best_dist[qi] = (int)(kbest >> 20);
+      second_dist[qi] = (ksecond == 0xFFFFFFFFu) ? 256 : (int)(ksecond >> 20);
+    }
+  }
+}
+
+// group width for a mean list length: the smallest power of two >= mean / 2 lanes (two rounds for an average list), 8 .. 64
+static int csr_group_width(long long n_cand, int Q) {
+  const double mean = Q > 0 ? (double)n_cand / (double)Q : 0.0;
+  int g = 8;
+  while (g < 64 && 2 * g < mean) g <<= 1;
+  return g;
+}
+
 // ---- MapPoint::ComputeDistinctiveDescriptors (cslam/src/MapPoint.cpp:929-994), batched ----------------------
 // one wave per map point: lane i owns observation i (rows i, i+64, ... when a point has more than 64), computes
 // its N distances into a lane-private LDS row, selects the median (element of rank (int)(0.5*(N-1)) of the sorted
@@ -368,6 +438,28 @@ extern "C" int ccm_hamming_dense_best2(ccm_ctx* ctx, const uint8_t* q, int Q, co
   return rc;
 }
 
+// one launch of the windowed search: a wave per query for long lists (the round-1 kernel), G lanes per query below
+static int csr_launch(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, const int32_t* d_q_tbase, const int32_t* d_cand_off, const int32_t* d_cand_idx,
+                      int64_t n_cand, uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist) {
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int G = csr_group_width((long long)n_cand, Q);
+  {
+    ccm_prof_scope ps(ctx, CCM_K_HAMMING_CSR);
+#define CCM_CSR_G(g) hipLaunchKernelGGL(hamming_csr_group_kernel<g>, dim3(ccm_div_up((int64_t)Q * g, 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q, \
+                                        (const uint32_t*)d_t, d_q_tbase, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist, (long long)n_cand)
+    if (G >= 64 && !d_q_tbase)
+      hipLaunchKernelGGL(hamming_csr_kernel, dim3(ccm_div_up(Q, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q,
+                         (const uint32_t*)d_t, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist, (long long)n_cand);
+    else if (G >= 64) CCM_CSR_G(64);
+    else if (G == 32) CCM_CSR_G(32);
+    else if (G == 16) CCM_CSR_G(16);
+    else CCM_CSR_G(8);
+#undef CCM_CSR_G
+  }
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  return CCM_OK;
+}
+
 extern "C" int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, int T,
                                    const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
                                    uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist,
@@ -376,14 +468,69 @@ extern "C" int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, cons
   if (!ctx || Q < 0) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: bad args");
   if (d_best_idx && (!d_best_dist || !d_second_dist)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr: best2 outputs must be all set or all NULL");
   if (Q == 0) return CCM_OK;
-  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  {
-    ccm_prof_scope ps(ctx, CCM_K_HAMMING_CSR);
-    hipLaunchKernelGGL(hamming_csr_kernel, dim3(ccm_div_up(Q, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q,
-                       (const uint32_t*)d_t, d_cand_off, d_cand_idx, d_cand_dist, d_best_idx, d_best_dist, d_second_dist, (long long)n_cand);
+  return csr_launch(ctx, d_q, Q, d_t, nullptr, d_cand_off, d_cand_idx, n_cand, d_cand_dist, d_best_idx, d_best_dist, d_second_dist);
+}
+
+extern "C" int ccm_hamming_csr_multi_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, const int32_t* d_q_tbase,
+                                         const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
+                                         uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist) {
+  if (!ctx || Q < 0) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad args");
+  if (d_best_idx && (!d_best_dist || !d_second_dist)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: best2 outputs must be all set or all NULL");
+  if (Q == 0) return CCM_OK;
+  return csr_launch(ctx, d_q, Q, d_t, d_q_tbase, d_cand_off, d_cand_idx, n_cand, d_cand_dist, d_best_idx, d_best_dist, d_second_dist);
+}
+
+// S searches, one launch, one read-back.  Search s owns the query rows q_off[s] .. q_off[s+1] and the target rows t_off[s] .. t_off[s+1]; the candidate
+// indices of its queries are LOCAL to its target set.
+extern "C" int ccm_hamming_csr_multi(ccm_ctx* ctx, int S, const uint8_t* q, const int32_t* q_off, const uint8_t* t, const int32_t* t_off,
+                                     const int32_t* cand_off, const int32_t* cand_idx, uint16_t* cand_dist,
+                                     int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  if (!ctx || S < 0 || (S && (!q_off || !t_off))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad args");
+  if (S == 0) return CCM_OK;
+  const int Q = q_off[S], T = t_off[S];
+  if (q_off[0] != 0 || t_off[0] != 0 || Q < 0 || T < 0 || (Q && (!q || !cand_off))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad offsets");
+  if (Q == 0) return CCM_OK;
+  const int64_t n_cand = cand_off[Q];
+  if (n_cand < 0 || (n_cand && (!cand_idx || !t))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad candidate list");
+  void* pin = nullptr;
+  { int rc0 = ccm_pin_scratch(ctx, (size_t)Q * 4 + 256, &pin); if (rc0) return rc0; }
+  int32_t* h_base = (int32_t*)pin;
+  for (int s = 0; s < S; s++) {
+    if (q_off[s + 1] < q_off[s] || t_off[s + 1] < t_off[s]) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: offsets must ascend");
+    const int Ts = t_off[s + 1] - t_off[s];
+    for (int i = q_off[s]; i < q_off[s + 1]; i++) {
+      h_base[i] = t_off[s];
+      const int64_t len = (int64_t)cand_off[i + 1] - cand_off[i];
+      if (len < 0 || len >= (1 << 20)) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: candidate list length out of range");
+      for (int c = cand_off[i]; c < cand_off[i + 1]; c++)
+        if (cand_idx[c] < 0 || cand_idx[c] >= Ts) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: candidate index out of range");
+    }
   }
-  CCM_HIP_CHECK(ctx, hipGetLastError());
-  return CCM_OK;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bq = ccm_align256((size_t)Q * 32), bt = ccm_align256((size_t)std::max(T, 1) * 32), bo = ccm_align256((size_t)(Q + 1) * 4), bb = ccm_align256((size_t)Q * 4);
+  const size_t bi = ccm_align256((size_t)std::max<int64_t>(n_cand, 1) * 4), bd = ccm_align256((size_t)std::max<int64_t>(n_cand, 1) * 2);
+  void* io = nullptr;
+  { int rc0 = ccm_io_scratch(ctx, bq + bt + bo + bb + bi + bd + (size_t)Q * 12, &io); if (rc0) return rc0; }
+  uint8_t* d_q = (uint8_t*)io; uint8_t* d_t = d_q + bq; int32_t* d_off = (int32_t*)(d_t + bt); int32_t* d_base = (int32_t*)((uint8_t*)d_off + bo);
+  int32_t* d_idx = (int32_t*)((uint8_t*)d_base + bb); uint16_t* d_dist = (uint16_t*)((uint8_t*)d_idx + bi); int32_t* d_out = (int32_t*)((uint8_t*)d_dist + bd);
+  hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream);
+  if (T) hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
+  hipMemcpyAsync(d_base, h_base, (size_t)Q * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (n_cand) hipMemcpyAsync(d_idx, cand_idx, (size_t)n_cand * 4, hipMemcpyHostToDevice, ctx->stream);
+  int rc = ccm_hamming_csr_multi_dev(ctx, d_q, Q, d_t, d_base, d_off, d_idx, n_cand, d_dist, best_idx ? d_out : nullptr,
+                                     best_idx ? d_out + Q : nullptr, best_idx ? d_out + 2 * (size_t)Q : nullptr);
+  if (rc == CCM_OK) {
+    if (cand_dist && n_cand) hipMemcpyAsync(cand_dist, d_dist, (size_t)n_cand * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (best_idx) {
+      hipMemcpyAsync(best_idx, d_out, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(best_dist, d_out + Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+      hipMemcpyAsync(second_dist, d_out + 2 * (size_t)Q, (size_t)Q * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = ccm_set_error(ctx, CCM_E_HIP, std::string("hamming_csr_multi: ") + hipGetErrorString(e));
+  }
+  return rc;
 }
 
 extern "C" int ccm_hamming_csr(ccm_ctx* ctx, const uint8_t* q, int Q, const uint8_t* t, int T,

@@ -469,23 +469,27 @@ int ORBmatcher::SearchByBoW_KF(const KeysView& K1, const KeysView& K2, std::vect
   return nmatches;
 }
 
-int ORBmatcher::SearchForTriangulation(const KeysView& K1, const KeysView& K2, const float F12[9], float ex, float ey, const float* sigma2_2,
-                                       const float* sf2, std::vector<int32_t>& matches12) {
-  matches12.assign(K1.N, -1);
-  std::vector<int32_t> q_of, off, idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
-  bucketQueries(K1, K2, [&](int i) { return K1.hasMapPoint[i] == 0; }, q_of, off, idx, qdesc);   // only features WITHOUT a map point (:745-749)
-  distances(qdesc, (int)q_of.size(), K2.desc, K2.N, off, idx, dist);
-  std::vector<int> rotHist[HISTO_LENGTH];
+namespace {
+// the sequential part of SearchForTriangulation (ORBmatcher.cpp:745-845) from the distances of every (query, candidate) slot: queries in bucket order, the
+// candidate list of each = the whole vocabulary node of keyframe 2.  has1 / has2: the map-point flags at the time of the call (a query whose feature has a map
+// point by now is skipped like the reference's `if(pMP1) continue`, a candidate with one like `if(vbMatched2[idx2] || pMP2) continue`).
+int resolveTriangulation(const KeyPoint* keys1, int N1, const uint8_t* has1, const KeyPoint* keys2, const uint8_t* has2, const std::vector<int32_t>& q_of,
+                         const std::vector<int32_t>& off, const std::vector<int32_t>& idx, const uint16_t* dist, const float F12[9], float ex, float ey,
+                         const float* sigma2_2, const float* sf2, bool checkOrientation, std::vector<int32_t>& matches12) {
+  const int TH_LOW = ORBmatcher::TH_LOW, HISTO_LENGTH = ORBmatcher::HISTO_LENGTH;
+  matches12.assign(N1, -1);
+  std::vector<int> rotHist[ORBmatcher::HISTO_LENGTH];
   int nmatches = 0;
   for (size_t q = 0; q < q_of.size(); q++) {
-    const KeyPoint& kp1 = K1.keys[q_of[q]];
+    if (has1 && has1[q_of[q]]) continue;
+    const KeyPoint& kp1 = keys1[q_of[q]];
     int bestDist = TH_LOW, bestIdx2 = -1;
     for (int s = off[q]; s < off[q + 1]; s++) {
       const int idx2 = idx[s];
-      if (K2.hasMapPoint[idx2]) continue;          // vbMatched2 is never set by the reference (:761,:789)
+      if (has2[idx2]) continue;          // vbMatched2 is never set by the reference (:761,:789)
       const int d = dist[s];
       if (d > TH_LOW || d > bestDist) continue;
-      const KeyPoint& kp2 = K2.keys[idx2];
+      const KeyPoint& kp2 = keys2[idx2];
       const float distex = ex - kp2.x, distey = ey - kp2.y;
       if (distex * distex + distey * distey < 100 * sf2[kp2.octave]) continue;
       // CheckDistEpipolarLine (:159-176)
@@ -501,10 +505,10 @@ int ORBmatcher::SearchForTriangulation(const KeysView& K1, const KeysView& K2, c
     if (bestIdx2 >= 0) {
       matches12[q_of[q]] = bestIdx2;
       nmatches++;
-      if (mbCheckOrientation) rotHist[histBin(kp1.angle - K2.keys[bestIdx2].angle)].push_back(q_of[q]);
+      if (checkOrientation) rotHist[histBin(kp1.angle - keys2[bestIdx2].angle)].push_back(q_of[q]);
     }
   }
-  if (mbCheckOrientation) {
+  if (checkOrientation) {
     int ind1 = -1, ind2 = -1, ind3 = -1;
     threeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
     for (int i = 0; i < HISTO_LENGTH; i++) {
@@ -513,6 +517,54 @@ int ORBmatcher::SearchForTriangulation(const KeysView& K1, const KeysView& K2, c
     }
   }
   return nmatches;
+}
+}  // namespace
+
+int ORBmatcher::SearchForTriangulation(const KeysView& K1, const KeysView& K2, const float F12[9], float ex, float ey, const float* sigma2_2,
+                                       const float* sf2, std::vector<int32_t>& matches12) {
+  std::vector<int32_t> q_of, off, idx; std::vector<uint8_t> qdesc; std::vector<uint16_t> dist;
+  bucketQueries(K1, K2, [&](int i) { return K1.hasMapPoint[i] == 0; }, q_of, off, idx, qdesc);   // only features WITHOUT a map point (:745-749)
+  distances(qdesc, (int)q_of.size(), K2.desc, K2.N, off, idx, dist);
+  return resolveTriangulation(K1.keys, K1.N, nullptr, K2.keys, K2.hasMapPoint, q_of, off, idx, dist.data(), F12, ex, ey, sigma2_2, sf2, mbCheckOrientation, matches12);
+}
+
+TriangulationBatch::TriangulationBatch(ORBmatcher& m, const KeysView& K1, const std::vector<KeysView>& K2) : check_ori_(m.mbCheckOrientation) {
+  keys1_.assign(K1.keys, K1.keys + K1.N);
+  has1_.assign(K1.hasMapPoint, K1.hasMapPoint + K1.N);
+  nb_.resize(K2.size());
+  // the queries of all neighbours back to back; candidate indices stay local to the neighbour's own descriptor set
+  std::vector<uint8_t> qdesc, tdesc;
+  std::vector<int32_t> q_off(1, 0), t_off(1, 0), off_all(1, 0), idx_all;
+  for (size_t j = 0; j < K2.size(); j++) {
+    Nb& nb = nb_[j];
+    nb.keys.assign(K2[j].keys, K2[j].keys + K2[j].N);
+    nb.has.assign(K2[j].hasMapPoint, K2[j].hasMapPoint + K2[j].N);
+    std::vector<uint8_t> qd;
+    bucketQueries(K1, K2[j], [&](int i) { return K1.hasMapPoint[i] == 0; }, nb.q_of, nb.off, nb.idx, qd);
+    qdesc.insert(qdesc.end(), qd.begin(), qd.end());
+    tdesc.insert(tdesc.end(), K2[j].desc, K2[j].desc + (size_t)K2[j].N * 32);
+    const int32_t base = off_all.back();
+    for (size_t q = 1; q < nb.off.size(); q++) off_all.push_back(base + nb.off[q]);
+    idx_all.insert(idx_all.end(), nb.idx.begin(), nb.idx.end());
+    q_off.push_back((int32_t)(qdesc.size() / 32));
+    t_off.push_back((int32_t)(tdesc.size() / 32));
+  }
+  n_cand_ = (int64_t)idx_all.size();
+  std::vector<uint16_t> dist_all(std::max<size_t>(idx_all.size(), 1), 0);
+  if (!idx_all.empty())
+    check(ccm_hamming_csr_multi(m.ctx_.get(), (int)K2.size(), qdesc.data(), q_off.data(), tdesc.data(), t_off.data(), off_all.data(), idx_all.data(), dist_all.data(),
+                                nullptr, nullptr, nullptr), m.ctx_.get(), "ccm_hamming_csr_multi");
+  size_t at = 0;
+  for (Nb& nb : nb_) { nb.dist.assign(dist_all.begin() + at, dist_all.begin() + at + nb.idx.size()); at += nb.idx.size(); }
+}
+
+int TriangulationBatch::resolve(int j, const uint8_t* has1_now, const uint8_t* has2_now, const float F12[9], float ex, float ey, const float* sigma2_2, const float* sf2,
+                                std::vector<int32_t>& matches12) const {
+  const Nb& nb = nb_.at((size_t)j);
+  // (the queries were chosen with the flags of the build; a feature that has gained a map point since is skipped, one that had one then cannot lose it here:
+  // LocalMapping only adds points to the new keyframe between these calls)
+  return resolveTriangulation(keys1_.data(), (int)keys1_.size(), has1_now ? has1_now : nullptr, nb.keys.data(), has2_now ? has2_now : nb.has.data(), nb.q_of, nb.off, nb.idx,
+                              nb.dist.data(), F12, ex, ey, sigma2_2, sf2, check_ori_, matches12);
 }
 
 int ORBmatcher::SearchForInitialization(const KeysView& F1, const FrameView& F2, std::vector<float>& prev, std::vector<int32_t>& vnMatches12, int windowSize) {
@@ -938,6 +990,37 @@ int ccmh_search_bow(int device, int mode, const int32_t* n1, const int32_t* o1, 
     return n;
   } catch (const std::exception&) { return -1000; }
 }
+
+// TriangulationBatch through C (shim/ORBmatcher_hip.cpp, tests): neighbour arrays as arrays of pointers, one entry per neighbour
+void* ccmh_tri_batch_create(int device, float nnratio, int check_ori, const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const uint8_t* has1,
+                            const uint8_t* d1, const float* x1, const float* y1, const float* a1, int N1, int n_nb, const int32_t* const* n2,
+                            const int32_t* const* o2, const int32_t* const* i2, const int32_t* nn2, const uint8_t* const* has2, const uint8_t* const* d2,
+                            const float* const* x2, const float* const* y2, const int32_t* const* oct2, const float* const* a2, const int32_t* N2) {
+  try {
+    cslam::HipContext& ctx = thread_context(device);
+    auto k1 = mk_keys(x1, y1, nullptr, a1, N1);
+    cslam::KeysView A; A.N = N1; A.keys = k1.data(); A.desc = d1; A.hasMapPoint = has1; A.fv = cslam::FeatureVectorView{nn1, n1, o1, i1};
+    std::vector<std::vector<cslam::KeyPoint>> k2((size_t)n_nb);
+    std::vector<cslam::KeysView> B((size_t)n_nb);
+    for (int j = 0; j < n_nb; j++) {
+      k2[j] = mk_keys(x2[j], y2[j], oct2[j], a2[j], N2[j]);
+      B[j].N = N2[j]; B[j].keys = k2[j].data(); B[j].desc = d2[j]; B[j].hasMapPoint = has2[j]; B[j].fv = cslam::FeatureVectorView{nn2[j], n2[j], o2[j], i2[j]};
+    }
+    cslam::ORBmatcher m(ctx, nnratio, check_ori != 0);
+    return new cslam::TriangulationBatch(m, A, B);
+  } catch (const std::exception&) { return nullptr; }
+}
+int ccmh_tri_batch_resolve(void* h, int j, const uint8_t* has1_now, const uint8_t* has2_now, const float* F12, float ex, float ey, const float* sigma2_2,
+                           const float* sf2, int32_t* matches12) {
+  try {
+    std::vector<int32_t> r;
+    const int n = static_cast<cslam::TriangulationBatch*>(h)->resolve(j, has1_now, has2_now, F12, ex, ey, sigma2_2, sf2, r);
+    std::memcpy(matches12, r.data(), r.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+long long ccmh_tri_batch_candidates(void* h) { return h ? (long long)static_cast<cslam::TriangulationBatch*>(h)->candidates() : 0; }
+void ccmh_tri_batch_destroy(void* h) { delete static_cast<cslam::TriangulationBatch*>(h); }
 
 int ccmh_search_for_initialization(int device, const float* x1, const float* y1, const int32_t* oct1, const float* a1, const uint8_t* d1, int N1,
                                    const float* x2, const float* y2, const int32_t* oct2, const float* a2, const uint8_t* d2, int N2,

@@ -157,6 +157,7 @@ class ORBmatcher {
                       int distThreshold, int32_t* matched, bool claim, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist);
   // SearchBySim3's agreement step (:1318-1345) on the two directional results
   static int MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12);
+  friend class TriangulationBatch;
  private:
   void deviceWindows(FrameGridDev& grid, const std::vector<float>& u, const std::vector<float>& v, const std::vector<float>& r,
                      const std::vector<int32_t>& minl, const std::vector<int32_t>& maxl, const std::vector<uint8_t>& qdesc,
@@ -166,6 +167,29 @@ class ORBmatcher {
                  const std::vector<int32_t>& idx, std::vector<uint16_t>& dist);
   HipContext& ctx_;
   float mfNNratio; bool mbCheckOrientation;
+};
+
+// The per-keyframe fan-out of LocalMapping::CreateNewMapPoints (cslam/src/Mapping.cpp:277-470): SearchForTriangulation(pKF1, pKF2_j, F12_j, ...) for up to 20
+// covisible neighbours j of the new keyframe.  The Hamming work of ALL of them — every (feature of KF1 without a map point, feature of neighbour j in the same
+// vocabulary node) pair — goes to the device as ONE ccm_hamming_csr_multi launch with one read-back when the batch is built; resolve(j, ...) then replays the
+// reference's sequential rules of the call against neighbour j (epipole distance, epipolar line, first-best claim, rotation histogram) from the stored distances.
+// Between two calls of the reference's loop the keyframes GAIN map points (the triangulated matches of the previous neighbour): resolve() takes the map-point flags
+// as they are at ITS call and skips what the reference would skip then (:745-749, :763), so the sequence of resolve() calls returns exactly what the sequence
+// of SearchForTriangulation calls returns.  Everything the batch needs is copied at build time (the views may go away).
+class TriangulationBatch {
+ public:
+  TriangulationBatch(ORBmatcher& m, const KeysView& KF1, const std::vector<KeysView>& KF2);
+  int neighbours() const { return (int)nb_.size(); }
+  int64_t candidates() const { return n_cand_; }
+  // has1_now / has2_now: nullptr = the flags of the build
+  int resolve(int j, const uint8_t* has1_now, const uint8_t* has2_now, const float F12[9], float ex, float ey, const float* sigma2_2, const float* scaleFactors2,
+              std::vector<int32_t>& matches12) const;
+ private:
+  struct Nb { std::vector<KeyPoint> keys; std::vector<uint8_t> has; std::vector<int32_t> q_of, off, idx; std::vector<uint16_t> dist; };
+  std::vector<KeyPoint> keys1_; std::vector<uint8_t> has1_;
+  std::vector<Nb> nb_;
+  int64_t n_cand_ = 0;
+  bool check_ori_;
 };
 
 // ---------------------------------------------------------------------------------------------------

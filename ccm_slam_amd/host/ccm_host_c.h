@@ -15,6 +15,12 @@ int ccmh_search_by_projection_last_dev(int device, const void* kps_un, const uin
 int ccmh_optimize_sim3(int device, double* sim3, int n, const double* P1c, const double* P2c, const double* obs1, const double* obs2, const double* info1, const double* info2, const double* K1, const double* K2, float th2, int fix_scale, uint8_t* keep);
 int ccmh_orb_extract(int device, int nfeatures, const uint8_t* img, int w, int h, void* kps_out, uint8_t* desc_out, int cap);
 int ccmh_search_bow(int device, int mode, const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const int32_t* n2, const int32_t* o2, const int32_t* i2, int nn2, const uint8_t* has1, const uint8_t* has2, const uint8_t* d1, const float* x1, const float* y1, const float* a1, int N1, const uint8_t* d2, const float* x2, const float* y2, const int32_t* oct2, const float* a2, int N2, const float* F12, float ex, float ey, const float* sigma2_2, const float* sf2, float nnratio, int check_ori, int32_t* out);
+/* the SearchForTriangulation fan-out of a new keyframe (Mapping.cpp:335) as ONE device launch: create computes the Hamming tables of all neighbours, resolve replays the
+ * reference's sequential rules of the call against neighbour j with the map-point flags as they are at that call (NULL: as at create) */
+void* ccmh_tri_batch_create(int device, float nnratio, int check_ori, const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const uint8_t* has1, const uint8_t* d1, const float* x1, const float* y1, const float* a1, int N1, int n_nb, const int32_t* const* n2, const int32_t* const* o2, const int32_t* const* i2, const int32_t* nn2, const uint8_t* const* has2, const uint8_t* const* d2, const float* const* x2, const float* const* y2, const int32_t* const* oct2, const float* const* a2, const int32_t* N2);
+int ccmh_tri_batch_resolve(void* h, int j, const uint8_t* has1_now, const uint8_t* has2_now, const float* F12, float ex, float ey, const float* sigma2_2, const float* sf2, int32_t* matches12);
+long long ccmh_tri_batch_candidates(void* h);
+void ccmh_tri_batch_destroy(void* h);
 int ccmh_search_for_initialization(int device, const float* x1, const float* y1, const int32_t* oct1, const float* a1, const uint8_t* d1, int N1, const float* x2, const float* y2, const int32_t* oct2, const float* a2, const uint8_t* d2, int N2, float minX, float minY, float maxX, float maxY, float* prev_xy, int window, float nnratio, int check_ori, int32_t* matches12);
 int ccmh_projected_window_search(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float minX, float minY, float maxX, float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, float th, int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist);
 int ccmh_projected_window_search_cand(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, const int32_t* cand_off, const int32_t* cand_idx, int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist);

@@ -44,6 +44,49 @@ def hamming_csr(ctx: Context, q, t, cand_off, cand_idx, want_best2: bool = True)
     return dist[:cand_idx.size], bi, bd, sd
 
 
+def hamming_csr_multi(ctx: Context, qs, ts, offs, idxs, want_best2: bool = True):
+    """S windowed searches in one launch (ccm_hamming_csr_multi): qs / ts = lists of descriptor sets, offs / idxs = the CSR of every search (indices local to its own
+    target set).  Returns (dist, best_idx, best_dist, second_dist) over all queries back to back plus the per-search query / candidate offsets."""
+    qs = [np.ascontiguousarray(q, np.uint8).reshape(-1, 32) for q in qs]
+    ts = [np.ascontiguousarray(t, np.uint8).reshape(-1, 32) for t in ts]
+    S = len(qs)
+    q_off = np.zeros(S + 1, np.int32); t_off = np.zeros(S + 1, np.int32)
+    q_off[1:] = np.cumsum([q.shape[0] for q in qs]); t_off[1:] = np.cumsum([t.shape[0] for t in ts])
+    q = np.concatenate(qs) if S else np.zeros((0, 32), np.uint8)
+    t = np.concatenate(ts) if S else np.zeros((0, 32), np.uint8)
+    c_base = np.concatenate([[0], np.cumsum([int(np.asarray(o)[-1]) for o in offs])]).astype(np.int64)
+    cand_off = np.concatenate([[0]] + [np.asarray(o, np.int64)[1:] + c_base[s] for s, o in enumerate(offs)]).astype(np.int32)
+    cand_idx = np.ascontiguousarray(np.concatenate([np.asarray(i, np.int32) for i in idxs]) if S else np.zeros(0, np.int32), np.int32)
+    Q = int(q_off[-1])
+    dist = np.empty(max(cand_idx.size, 1), np.uint16)
+    bi, bd, sd = ((np.empty(max(Q, 1), np.int32) for _ in range(3)) if want_best2 else (None, None, None))
+    check(lib().ccm_hamming_csr_multi(ctx.handle, S, _p(q), _p(q_off), _p(t), _p(t_off), _p(cand_off), _p(cand_idx), _p(dist), _p(bi), _p(bd), _p(sd)), ctx.handle)
+    if want_best2:
+        bi, bd, sd = bi[:Q], bd[:Q], sd[:Q]
+    return dist[:cand_idx.size], bi, bd, sd, q_off, c_base
+
+
+class CsrMultiDev:
+    """A batch of windowed searches resident in HBM (bench.py): run() = one ccm_hamming_csr_multi_dev launch."""
+
+    def __init__(self, ctx: Context, q, t, q_tbase, cand_off, cand_idx):
+        self.ctx = ctx
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        self.Q, self.n_cand = q.shape[0], int(cand_idx.size)
+        self.d = [ctx.upload(a) for a in (q, t, np.ascontiguousarray(q_tbase, np.int32), np.ascontiguousarray(cand_off, np.int32), np.ascontiguousarray(cand_idx, np.int32))]
+        self.d_dist = ctx.alloc(max(self.n_cand, 1) * 2)
+        self.d_out = ctx.alloc(max(self.Q, 1) * 12)
+
+    def run(self):
+        Q = self.Q
+        check(lib().ccm_hamming_csr_multi_dev(self.ctx.handle, C.c_void_p(self.d[0]), Q, C.c_void_p(self.d[1]), C.c_void_p(self.d[2]), C.c_void_p(self.d[3]), C.c_void_p(self.d[4]),
+                                              C.c_int64(self.n_cand), C.c_void_p(self.d_dist), C.c_void_p(self.d_out), C.c_void_p(self.d_out + 4 * Q), C.c_void_p(self.d_out + 8 * Q)), self.ctx.handle)
+
+    def close(self):
+        for p in self.d + [self.d_dist, self.d_out]:
+            self.ctx.free(p)
+
+
 class DenseMatcherDev:
     """Device-resident dense best/second search for bench.py (inputs uploaded once)."""
 

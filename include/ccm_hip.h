@@ -113,6 +113,18 @@ int ccm_hamming_csr_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* 
                         uint16_t* d_cand_dist,
                         int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
 
+/* S windowed searches in ONE launch and one read-back (round 5) — the per-keyframe fan-out of LocalMapping: up to 20 SearchForTriangulation calls
+ * (cslam/src/Mapping.cpp:335) and as many Fuse calls (:503, :528) per new keyframe, each against ANOTHER keyframe's descriptors.  Search s owns the query
+ * rows q_off[s] .. q_off[s+1] of q and the target rows t_off[s] .. t_off[s+1] of t (q_off[0] = t_off[0] = 0); cand_off / cand_idx / cand_dist run over ALL
+ * queries back to back, and the candidate indices of a query are LOCAL to its search's target set.  Outputs as ccm_hamming_csr (best_idx local as well).
+ * The _dev form takes, instead of the offsets, q_tbase[q] = first target row of the set query q searches in (nullable: one shared set). */
+int ccm_hamming_csr_multi(ccm_ctx* ctx, int S, const uint8_t* q, const int32_t* q_off /* S+1 */, const uint8_t* t, const int32_t* t_off /* S+1 */,
+                          const int32_t* cand_off, const int32_t* cand_idx, uint16_t* cand_dist,
+                          int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+int ccm_hamming_csr_multi_dev(ccm_ctx* ctx, const uint8_t* d_q, int Q, const uint8_t* d_t, const int32_t* d_q_tbase,
+                              const int32_t* d_cand_off, const int32_t* d_cand_idx, int64_t n_cand,
+                              uint16_t* d_cand_dist, int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors (cslam/src/MapPoint.cpp:929-994), batched over P map points:
  * point p owns the descriptor rows off[p] .. off[p+1] (one per non-bad observing keyframe, in observation-map order);
  * best_local_idx[p] = index (within its own list) of the descriptor with the least median Hamming distance to the

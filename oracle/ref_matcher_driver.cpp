@@ -247,6 +247,60 @@ int ref_search_for_triangulation(const int32_t* n1, const int32_t* o1, const int
   return n;
 }
 
+// The fan-out of LocalMapping::CreateNewMapPoints (Mapping.cpp:277-470): ONE new keyframe against n_nb covisible neighbours, SearchForTriangulation per neighbour in
+// order; between the calls every matched pair becomes a map point of BOTH keyframes (Mapping.cpp:437-452: AddMapPoint on both), so later calls see fewer
+// free features.  The keyframes live for the whole call and keyframe 1 lists the neighbours as its covisibility neighbours (GetBestCovisibilityKeyFrames).
+// Arrays of pointers: one entry per neighbour.  matches_out [n_nb][N1].
+int ref_triangulation_fan_out(const int32_t* n1, const int32_t* o1, const int32_t* i1, int nn1, const uint8_t* has_mp1, const uint8_t* desc1, const float* x1,
+                              const float* y1, const float* angle1, int N1, const float* T1, int n_nb, const int32_t* const* n2, const int32_t* const* o2,
+                              const int32_t* const* i2, const int32_t* nn2, const uint8_t* const* has_mp2, const uint8_t* const* desc2, const float* const* x2,
+                              const float* const* y2, const int32_t* const* oct2, const float* const* angle2, const int32_t* N2, const float* F12s /* n_nb x 9 */,
+                              const float* T2s /* n_nb x 16 */, const float* K4, const float* sigma2_2, const float* sf2, int check_ori, int32_t* matches_out,
+                              int32_t* n_out) {
+  std::unique_ptr<KeyFrame[]> kfs(new KeyFrame[n_nb + 1]);
+  std::vector<kfptr> k(n_nb + 1);
+  for (int j = 0; j <= n_nb; j++) k[j] = kfptr(&kfs[j], [](KeyFrame*) {});
+  std::vector<std::unique_ptr<Pool>> pools;
+  auto setup = [&](kfptr& kf, const uint8_t* has, const uint8_t* desc, const float* x, const float* y, const int32_t* oct, const float* angle, int N,
+                   const int32_t* node, const int32_t* off, const int32_t* idx, int nn, const float* T, size_t id) {
+    pools.emplace_back(new Pool(2 * N));   // (the second half: points created during the call)
+    Pool& p = *pools.back();
+    kf->N = N;
+    kf->mId = std::make_pair(id, (size_t)0); kf->mUniqueId = id;
+    kf->mvKeysUn.resize(N);
+    for (int i = 0; i < N; i++) kf->mvKeysUn[i] = cv::KeyPoint(x[i], y[i], 31.f, angle[i], 0, oct ? oct[i] : 0);
+    kf->mDescriptors = desc_mat(desc, N);
+    kf->mvpMapPoints.assign(N, mpptr());
+    for (int i = 0; i < N; i++) if (has[i]) kf->mvpMapPoints[i] = p.at(i);
+    fill_fv(kf->mFeatVec, node, off, idx, nn);
+    cv::Mat Tm(4, 4, CV_32F); std::memcpy(Tm.data, T, 64);
+    kf->SetPose(Tm, false);
+    kf->fx = K4[0]; kf->fy = K4[1]; kf->cx = K4[2]; kf->cy = K4[3];
+    kf->mvLevelSigma2.assign(sigma2_2, sigma2_2 + 8); kf->mvScaleFactors.assign(sf2, sf2 + 8);
+  };
+  setup(k[0], has_mp1, desc1, x1, y1, nullptr, angle1, N1, n1, o1, i1, nn1, T1, 100);
+  for (int j = 0; j < n_nb; j++) {
+    setup(k[j + 1], has_mp2[j], desc2[j], x2[j], y2[j], oct2[j], angle2[j], N2[j], n2[j], o2[j], i2[j], nn2[j], T2s + 16 * (size_t)j, 101 + (size_t)j);
+    k[0]->mvpOrderedConnectedKeyFrames.push_back(k[j + 1]); k[0]->mvOrderedWeights.push_back(1000 - j); k[0]->mConnectedKeyFrameWeights[k[j + 1]] = 1000 - j;
+  }
+  cslam::ORBmatcher matcher(0.6f, check_ori != 0);
+  for (int j = 0; j < n_nb; j++) {
+    cv::Mat F(3, 3, CV_32F); std::memcpy(F.data, F12s + 9 * (size_t)j, 36);
+    std::vector<std::pair<size_t, size_t> > vMatchedPairs;
+    n_out[j] = matcher.SearchForTriangulation(k[0], k[j + 1], F, vMatchedPairs);
+    int32_t* m = matches_out + (size_t)j * N1;
+    for (int i = 0; i < N1; i++) m[i] = -1;
+    for (auto& pr : vMatchedPairs) {
+      m[pr.first] = (int32_t)pr.second;
+      // the triangulated pair becomes a map point of both keyframes (Mapping.cpp:437-452)
+      mpptr pMP = pools[0]->at(N1 + (int)pr.first);
+      k[0]->mvpMapPoints[pr.first] = pMP;
+      k[j + 1]->mvpMapPoints[pr.second] = pMP;
+    }
+  }
+  return 0;
+}
+
 namespace {
 // a keyframe as the projected searches read it: pose, intrinsics, keypoints, descriptors, pyramid tables, image bounds and the grid (filled with
 // the reference's own Frame::AssignFeaturesToGrid and copied, as the KeyFrame constructor copies F.mGrid, KeyFrame.cpp:60-66)

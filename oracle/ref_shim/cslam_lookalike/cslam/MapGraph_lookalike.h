@@ -94,6 +94,10 @@ class KeyFrame : public boost::enable_shared_from_this<KeyFrame> {
   std::vector<int> mvOrderedWeights;
   std::map<kfptr, int> mConnectedKeyFrameWeights;
   std::vector<kfptr> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
+  std::vector<kfptr> GetBestCovisibilityKeyFrames(const int& N) {   // KeyFrame.cpp:443-451: the N strongest neighbours (all of them when there are fewer)
+    if ((int)mvpOrderedConnectedKeyFrames.size() < N) return mvpOrderedConnectedKeyFrames;
+    return std::vector<kfptr>(mvpOrderedConnectedKeyFrames.begin(), mvpOrderedConnectedKeyFrames.begin() + N);
+  }
   // KeyFrame.cpp (GetCovisiblesByWeight): the ordered list down to weight w — with the reference's own corner case: when NO neighbour is weaker than w,
   // upper_bound returns end() and the method returns an EMPTY list, not all neighbours.  (Round 5: found by running the shim on the reference's real KeyFrame.cpp,
   // tests/test_shim_real_gpu.py; the earlier look-alike returned every neighbour with weight >= w.)

@@ -15,6 +15,7 @@
 #include <cslam/ORBmatcher.h>
 
 #include <climits>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 
@@ -262,10 +263,88 @@ int ORBmatcher::SearchByBoW(kfptr pKF1, kfptr pKF2, std::vector<mpptr>& vpMatche
   return nmatches;
 }
 
+namespace {
+// (round 5) LocalMapping::CreateNewMapPoints (Mapping.cpp:286, :335) calls SearchForTriangulation for up to 20 covisibility neighbours of ONE new keyframe, one after
+// the other.  Mapping.cpp is not ours to change, but its first call tells what the next ones will be: on a call for a keyframe it has not seen, the shim asks the
+// keyframe for the same neighbour list (GetBestCovisibilityKeyFrames(20)), sends the Hamming work of ALL of them to the MI355X as one launch
+// (ccmh_tri_batch_create -> ccm_hamming_csr_multi) and keeps the tables, per calling thread, until a call for another keyframe arrives; every call — the first
+// included — is then answered from the tables with the map-point flags AS THEY ARE AT THAT CALL (the loop creates map points between the calls), i.e. with exactly
+// the reference's result for that call.  What the tables depend on — keypoints, descriptors, feature vectors — does not change after a keyframe is built.  A
+// neighbour the prediction missed takes the single-call path.  CCM_SHIM_TRI_BATCH=0 switches the prediction off.
+struct TriFanOut {
+  const KeyFrame* kf1 = nullptr; idpair id1; int N1 = 0;
+  std::vector<const KeyFrame*> nb; std::vector<idpair> nb_id;
+  std::vector<uint8_t> has1_build;   // which features of keyframe 1 held a map point when the tables were built (those are not among the queries)
+  void* h = nullptr;
+  void drop() { if (h) ccmh_tri_batch_destroy(h); h = nullptr; kf1 = nullptr; nb.clear(); nb_id.clear(); has1_build.clear(); }
+  ~TriFanOut() { drop(); }
+};
+thread_local TriFanOut g_tri;
+bool tri_batch_enabled() { static const bool on = !(std::getenv("CCM_SHIM_TRI_BATCH") && std::atoi(std::getenv("CCM_SHIM_TRI_BATCH")) == 0); return on; }
+}  // namespace
+
 // M5 — ORBmatcher.cpp:700-852
 int ORBmatcher::SearchForTriangulation(kfptr pKF1, kfptr pKF2, cv::Mat F12, std::vector<pair<size_t, size_t> >& vMatchedPairs) {
   vMatchedPairs.clear();
   if (pKF1->N == 0 || pKF2->N == 0) return 0;
+  if (tri_batch_enabled()) {
+    TriFanOut& c = g_tri;
+    if (c.kf1 != pKF1.get() || c.id1 != pKF1->mId || c.N1 != pKF1->N) {
+      // a keyframe this thread has not been asked about: predict the fan-out and run its Hamming work in one launch
+      c.drop();
+      std::vector<kfptr> vpN = pKF1->GetBestCovisibilityKeyFrames(20);                   // Mapping.cpp:285-286
+      bool listed = false;
+      for (size_t j = 0; j < vpN.size(); j++) listed |= vpN[j] == pKF2;
+      if (!listed) vpN.push_back(pKF2);
+      std::vector<kfptr> use;
+      for (size_t j = 0; j < vpN.size(); j++) if (vpN[j] && vpN[j]->N > 0) use.push_back(vpN[j]);
+      if (use.size() >= 2) {
+        BowSide A(pKF1->mvKeysUn, pKF1->mDescriptors, pKF1->mFeatVec);
+        for (int i = 0; i < pKF1->N; i++) A.has[i] = pKF1->GetMapPoint(i) ? 1 : 0;
+        std::vector<std::unique_ptr<BowSide>> B;
+        for (size_t j = 0; j < use.size(); j++) {
+          B.emplace_back(new BowSide(use[j]->mvKeysUn, use[j]->mDescriptors, use[j]->mFeatVec));
+          for (int i = 0; i < use[j]->N; i++) B.back()->has[i] = use[j]->GetMapPoint(i) ? 1 : 0;
+        }
+        static const int32_t none = 0;
+        auto p = [](const std::vector<int32_t>& v) { return v.empty() ? &none : v.data(); };
+        const size_t n = use.size();
+        std::vector<const int32_t*> n2(n), o2(n), i2(n), oct2(n); std::vector<const uint8_t*> has2(n), d2(n); std::vector<const float*> x2(n), y2(n), a2(n);
+        std::vector<int32_t> nn2(n), N2(n);
+        for (size_t j = 0; j < n; j++) {
+          n2[j] = p(B[j]->fv.node); o2[j] = B[j]->fv.off.data(); i2[j] = p(B[j]->fv.idx); nn2[j] = B[j]->fv.n(); has2[j] = B[j]->has.data(); d2[j] = B[j]->K.desc;
+          x2[j] = B[j]->K.x.data(); y2[j] = B[j]->K.y.data(); oct2[j] = B[j]->K.oct.data(); a2[j] = B[j]->K.angle.data(); N2[j] = B[j]->K.N;
+        }
+        c.h = ccmh_tri_batch_create(device(), mfNNratio, mbCheckOrientation ? 1 : 0, p(A.fv.node), A.fv.off.data(), p(A.fv.idx), A.fv.n(), A.has.data(), A.K.desc,
+                                    A.K.x.data(), A.K.y.data(), A.K.angle.data(), A.K.N, (int)n, n2.data(), o2.data(), i2.data(), nn2.data(), has2.data(), d2.data(),
+                                    x2.data(), y2.data(), oct2.data(), a2.data(), N2.data());
+        if (!c.h) checked(-1000, "SearchForTriangulation (fan-out)");
+        c.kf1 = pKF1.get(); c.id1 = pKF1->mId; c.N1 = pKF1->N; c.has1_build = A.has;
+        for (size_t j = 0; j < n; j++) { c.nb.push_back(use[j].get()); c.nb_id.push_back(use[j]->mId); }
+      }
+    }
+    if (c.h) {
+      for (size_t j = 0; j < c.nb.size(); j++) {
+        if (c.nb[j] != pKF2.get() || c.nb_id[j] != pKF2->mId) continue;
+        const cv::Mat C2 = pKF2->GetRotation() * pKF1->GetCameraCenter() + pKF2->GetTranslation();
+        const float invz = 1.0f / C2.at<float>(2);
+        const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
+        const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+        std::vector<uint8_t> has1(pKF1->N), has2(pKF2->N);
+        bool lost = false;                                                               // a feature that has LOST its map point since (culling by another thread)
+        for (int i = 0; i < pKF1->N; i++) { has1[i] = pKF1->GetMapPoint(i) ? 1 : 0; lost |= c.has1_build[i] && !has1[i]; }   // is not in the tables: single call
+        if (lost) break;
+        for (int i = 0; i < pKF2->N; i++) has2[i] = pKF2->GetMapPoint(i) ? 1 : 0;
+        cv::Mat F = F12.isContinuous() ? F12 : F12.clone();
+        std::vector<int32_t> m12(pKF1->N, -1);
+        const int nmatches = checked(ccmh_tri_batch_resolve(c.h, (int)j, has1.data(), has2.data(), F.ptr<float>(), ex, ey, pKF2->mvLevelSigma2.data(),
+                                                            pKF2->mvScaleFactors.data(), m12.data()), "SearchForTriangulation (fan-out)");
+        vMatchedPairs.reserve(nmatches);
+        for (size_t i = 0; i < m12.size(); i++) if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)m12[i]));
+        return nmatches;
+      }
+    }
+  }
   // the epipole of camera 1 in image 2, in the reference's f32 arithmetic
   const cv::Mat C2 = pKF2->GetRotation() * pKF1->GetCameraCenter() + pKF2->GetTranslation();
   const float invz = 1.0f / C2.at<float>(2);

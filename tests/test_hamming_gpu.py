@@ -53,6 +53,45 @@ def test_csr_matches_oracle(ctx, oracle_lib, Q, T, mean_c, seed):
     assert np.array_equal(bd, obd) and np.array_equal(sd, osd) and np.array_equal(bi, obi)
 
 
+@pytest.mark.parametrize("mean_c", [0.7, 3, 11, 20, 45, 90, 400])
+def test_csr_every_group_width_matches_oracle(ctx, oracle_lib, mean_c):
+    """round 5: the windowed search runs with 8 / 16 / 32 / 64 lanes per query, chosen from the mean list length — every width, with empty, one-element and
+    overlong lists mixed in, gives the oracle's integers (distance per slot, first minimum, second minimum)"""
+    rng = np.random.default_rng(int(mean_c * 10))
+    Q, T = 1500, 900
+    d1, d2, _, _ = synth.make_descriptor_sets(T, Q, 77)
+    lens = rng.poisson(mean_c, Q)
+    lens[rng.random(Q) < 0.08] = 0
+    lens[rng.random(Q) < 0.05] = 1
+    lens[rng.integers(0, Q, 3)] = 700                       # a few lists far longer than the group is wide
+    off = np.zeros(Q + 1, np.int32); off[1:] = np.cumsum(lens)
+    idx = rng.integers(0, T, off[-1]).astype(np.int32)
+    idx[off[5]:off[6]] = idx[off[5]] if lens[5] else 0      # a list of identical candidates: the FIRST one must win
+    dist, bi, bd, sd = matcher.hamming_csr(ctx, d2, d1, off, idx)
+    odist, obi, obd, osd = oracle_lib.hamming_csr(d2, d1, off, idx)
+    assert np.array_equal(dist, odist) and np.array_equal(bd, obd) and np.array_equal(sd, osd) and np.array_equal(bi, obi)
+
+
+def test_csr_multi_twenty_searches_in_one_launch_match_the_oracle_search_by_search(ctx, oracle_lib):
+    """ccm_hamming_csr_multi: 20 searches, each against ITS OWN target set (candidate indices local to it), one launch, one read-back = the oracle on every search alone;
+    includes a search without queries, one without candidates and target sets of different sizes"""
+    rng = np.random.default_rng(5)
+    qs, ts, offs, idxs = [], [], [], []
+    for s in range(20):
+        Q = 0 if s == 7 else int(rng.integers(300, 900)); T = int(rng.integers(500, 1200))
+        t, q, _, _ = synth.make_descriptor_sets(T, max(Q, 1), 100 + s)
+        q = q[:Q]
+        lens = rng.poisson(22, Q) if s != 11 else np.zeros(Q, np.int64)
+        off = np.zeros(Q + 1, np.int32); off[1:] = np.cumsum(lens)
+        qs.append(q); ts.append(t); offs.append(off); idxs.append(rng.integers(0, T, off[-1]).astype(np.int32))
+    dist, bi, bd, sd, q_off, c_base = matcher.hamming_csr_multi(ctx, qs, ts, offs, idxs)
+    for s in range(20):
+        odist, obi, obd, osd = oracle_lib.hamming_csr(qs[s], ts[s], offs[s], idxs[s])
+        a, b = int(q_off[s]), int(q_off[s + 1])
+        assert np.array_equal(dist[c_base[s]:c_base[s + 1]], odist), s
+        assert np.array_equal(bi[a:b], obi) and np.array_equal(bd[a:b], obd) and np.array_equal(sd[a:b], osd), s
+
+
 def test_full_size_property_self_match(ctx):
     # BASELINE config 5 shape: 2000 x 2000; every row's nearest neighbour in its own set is itself (distance 0)
     rng = np.random.default_rng(9)

@@ -178,6 +178,68 @@ def test_search_for_triangulation(hostlib, oracle_lib):
     assert n == exp_n and n > 50 and np.array_equal(got, exp)
 
 
+def test_search_for_triangulation_fan_out_of_twenty_neighbours_in_one_launch(hostlib, oracle_lib):
+    """LocalMapping::CreateNewMapPoints (Mapping.cpp:277-470) calls SearchForTriangulation for up to 20 covisible neighbours of a new keyframe and creates
+    map points between the calls.  TriangulationBatch sends the Hamming work of ALL neighbours out as one ccm_hamming_csr_multi launch; resolve(j) with the
+    map-point flags as they are at call j must return exactly what the oracle's sequential restatement returns for that call — including the features of
+    keyframe 1 that gained a map point from an earlier neighbour's matches and the candidates of keyframe 2 that did."""
+    import ctypes as C
+    k1, d1 = _frame(oracle_lib, 1000, 0)
+    nbs = [_frame(oracle_lib, 1000, 1 + (j % 5)) if j < 5 else None for j in range(20)]
+    ext = oracle_lib.OrbOracle(1000)
+    for j in range(5, 20):                                      # 15 more neighbours: other frames of the stream, other seeds
+        nbs[j] = ext.extract(synth.gen_image(1000 + j // 5, j % 5))
+    rng = np.random.default_rng(14)
+    fv1 = _feature_vector(d1, 0)
+    fvs = [_feature_vector(d, 0) for _, d in nbs]
+    has1 = (rng.random(len(k1)) < 0.4).astype(np.uint8)
+    has2 = [(rng.random(len(k)) < 0.4).astype(np.uint8) for k, _ in nbs]
+    sf, _, s2, _ = synth.scale_tables()
+    c = np.ascontiguousarray
+    keep = []                                                   # arrays the pointer tables refer to
+
+    def ptrs(arrs, ty=C.c_void_p):
+        arrs = [c(a) for a in arrs]
+        keep.extend(arrs)
+        return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    n_nb = len(nbs)
+    nn2 = np.array([f[0].size for f in fvs], np.int32); N2 = np.array([len(k) for k, _ in nbs], np.int32)
+    hostlib.ccmh_tri_batch_create.restype = C.c_void_p
+    hostlib.ccmh_tri_batch_candidates.restype = C.c_longlong
+    hostlib.ccmh_tri_batch_candidates.argtypes = [C.c_void_p]
+    hostlib.ccmh_tri_batch_destroy.argtypes = [C.c_void_p]
+    hostlib.ccmh_tri_batch_destroy.restype = None
+    hostlib.ccmh_tri_batch_resolve.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float] + [C.c_void_p] * 3
+    x1, y1, a1 = c(k1["x"]), c(k1["y"]), c(k1["angle"])
+    h = hostlib.ccmh_tri_batch_create(0, C.c_float(0.6), 0, _p(fv1[0]), _p(fv1[1]), _p(fv1[2]), fv1[0].size, _p(has1), _p(d1), _p(x1), _p(y1), _p(a1), len(k1), n_nb,
+                                      ptrs([f[0] for f in fvs]), ptrs([f[1] for f in fvs]), ptrs([f[2] for f in fvs]), _p(nn2), ptrs(has2), ptrs([d for _, d in nbs]),
+                                      ptrs([k["x"] for k, _ in nbs]), ptrs([k["y"] for k, _ in nbs]), ptrs([k["octave"] for k, _ in nbs]), ptrs([k["angle"] for k, _ in nbs]), _p(N2))
+    assert h, "ccmh_tri_batch_create failed"
+    assert hostlib.ccmh_tri_batch_candidates(h) > 100_000       # ONE launch carried all of them
+    has1_now = has1.copy()
+    total = 0
+    for j, ((k2, d2), fv2) in enumerate(zip(nbs, fvs)):
+        F12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32) * np.float32(1 + 0.01 * j)
+        ex = 5000.0 - 100.0 * j
+        has2_now = has2[j].copy()
+        if j % 3 == 2:
+            has2_now[rng.integers(0, len(k2), 40)] = 1          # the neighbour gained points too (it was another keyframe's neighbour)
+        exp_n, exp = oracle_lib.search_for_triangulation(fv1, fv2, has1_now, has2_now, d1, k1["x"], k1["y"], k1["angle"], d2, k2["x"], k2["y"], k2["octave"],
+                                                         k2["angle"], F12, ex, 240.0, s2, sf, 0)
+        got = np.zeros(len(k1), np.int32)
+        n = hostlib.ccmh_tri_batch_resolve(h, j, _p(has1_now), _p(has2_now), _p(F12), C.c_float(ex), C.c_float(240.0), _p(s2), _p(sf), _p(got))
+        assert n == exp_n and np.array_equal(got, exp), j
+        # ... and what the single call returns (its own launch)
+        single = np.zeros(len(k1), np.int32)
+        ns = hostlib.ccmh_search_bow(0, 2, *_bow_args(k1, d1, k2, d2, fv1, fv2, has1_now, has2_now), _p(F12), C.c_float(ex), C.c_float(240.0), _p(s2), _p(sf),
+                                     C.c_float(0.6), 0, _p(single))
+        assert ns == n and np.array_equal(single, got), j
+        total += n
+        has1_now[got >= 0] = 1                                  # Mapping.cpp:437-452: the matches are triangulated into new map points of keyframe 1
+    hostlib.ccmh_tri_batch_destroy(h)
+    assert total > 150
+
+
 def test_search_for_initialization(hostlib, oracle_lib):
     k1, d1 = oracle_lib.OrbOracle(2000).extract(synth.gen_image(1000, 0))
     k2, d2 = oracle_lib.OrbOracle(2000).extract(synth.gen_image(1000, 2))

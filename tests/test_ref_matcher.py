@@ -189,6 +189,55 @@ def test_search_for_triangulation_M5_with_the_references_own_epipole(rlib, frame
         assert np.array_equal(got, exp)
 
 
+def test_triangulation_fan_out_of_a_new_keyframe_M5_x20(rlib, frames):
+    """LocalMapping::CreateNewMapPoints (Mapping.cpp:277-470) through the reference's class API: ONE new keyframe, SearchForTriangulation against 20 covisibility
+    neighbours one after the other, every matched pair turned into a map point of both keyframes before the next call — against the flat oracle replaying the same
+    sequence.  (CPU: the reference's ORBmatcher.cpp; tests/test_shim_matcher_gpu.py runs the same function on shim/ORBmatcher_hip.cpp, whose FIRST call computes the
+    Hamming tables of all 20 neighbours in one launch.)"""
+    (k1, d1), _ = frames
+    o = oracle.OrbOracle(1000)
+    nbs = [o.extract(synth.gen_image(1000 + j // 5, 1 + j % 5)) for j in range(20)]
+    o.close()
+    rng = np.random.default_rng(21)
+    fv1 = _feature_vector(d1, 0); fvs = [_feature_vector(d, 0) for _, d in nbs]
+    has1 = (rng.random(len(k1)) < 0.3).astype(np.uint8); has2 = [(rng.random(len(k)) < 0.3).astype(np.uint8) for k, _ in nbs]
+    K4 = np.array(synth.EUROC_K, np.float32)
+    Kk = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], np.float64)
+    T1 = np.eye(4, dtype=np.float32)
+    T2s = np.tile(np.eye(4, dtype=np.float32), (20, 1, 1)); F12s = np.zeros((20, 9), np.float32)
+    for j in range(20):
+        T2s[j, :3, 3] = [-0.12 - 0.01 * j, 0.01 * (j % 3), 0.02]
+        t = -T2s[j, :3, 3].astype(np.float64)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        F12s[j] = (np.linalg.inv(Kk).T @ tx @ np.linalg.inv(Kk)).astype(np.float32).ravel()
+    sf, s2 = synth.scale_tables()[0], synth.scale_tables()[2]
+    keep = []
+
+    def ptrs(arrs):
+        arrs = [c(a) for a in arrs]
+        keep.extend(arrs)
+        return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    nn2 = np.array([f[0].size for f in fvs], np.int32); N2 = np.array([len(k) for k, _ in nbs], np.int32)
+    got = np.zeros((20, len(k1)), np.int32); n_got = np.zeros(20, np.int32)
+    assert rlib.ref_triangulation_fan_out(_p(fv1[0]), _p(fv1[1]), _p(fv1[2]), fv1[0].size, _p(has1), _p(d1), _p(c(k1["x"])), _p(c(k1["y"])), _p(c(k1["angle"])), len(k1), _p(T1),
+                                          20, ptrs([f[0] for f in fvs]), ptrs([f[1] for f in fvs]), ptrs([f[2] for f in fvs]), _p(nn2), ptrs(has2), ptrs([d for _, d in nbs]),
+                                          ptrs([k["x"] for k, _ in nbs]), ptrs([k["y"] for k, _ in nbs]), ptrs([k["octave"] for k, _ in nbs]), ptrs([k["angle"] for k, _ in nbs]),
+                                          _p(N2), _p(F12s), _p(T2s), _p(K4), _p(s2), _p(sf), 0, _p(got), _p(n_got)) == 0
+    # the oracle replays the sequence: epipole of camera 1 in image j in the reference's f32 arithmetic (identity rotations: C2 = t2 - t1 = t2)
+    has1_now = has1.copy()
+    total = 0
+    for j, ((k2, d2), fv2) in enumerate(zip(nbs, fvs)):
+        C2 = T2s[j, :3, 3]
+        invz = np.float32(1.0) / C2[2]
+        ex = np.float32(K4[0] * C2[0] * invz + K4[2]); ey = np.float32(K4[1] * C2[1] * invz + K4[3])
+        exp_n, exp = oracle.search_for_triangulation(fv1, fv2, has1_now, has2[j], d1, k1["x"], k1["y"], k1["angle"], d2, k2["x"], k2["y"], k2["octave"], k2["angle"], F12s[j],
+                                                     float(ex), float(ey), s2, sf, 0)
+        assert n_got[j] == exp_n and np.array_equal(got[j], exp), j
+        has1_now[exp >= 0] = 1
+        total += exp_n
+    assert total > 100
+
+
 def _projected_case(frames, seed, sim3_scale=1.0):
     """A keyframe (frame 0's features) with a non-trivial pose and map points back-projected from its keypoints (jittered, some behind the camera, out of
     range, viewed from the side), set up so that PredictScale lands on / next to the source feature's level."""

@@ -46,6 +46,23 @@ def test_M5_search_for_triangulation(slib, frames):
     trm.test_search_for_triangulation_M5_with_the_references_own_epipole(slib, frames)
 
 
+def test_M5_fan_out_of_twenty_neighbours_through_the_class_api(slib, frames):
+    """the reference's own call sequence (Mapping.cpp:335: one SearchForTriangulation per neighbour, map points created in between) on shim/ORBmatcher_hip.cpp: the first
+    call sends the Hamming work of all 20 neighbours to the MI355X in ONE launch (ccm_hamming_csr_multi), the others are answered from its tables — same match tables"""
+    trm.test_triangulation_fan_out_of_a_new_keyframe_M5_x20(slib, frames)
+
+
+def test_M5_fan_out_without_the_prediction_is_the_same(frames, monkeypatch):
+    import subprocess, sys
+    code = ("import ctypes as C, tests.test_ref_matcher as trm, tests.test_shim_matcher_gpu as t, oracle\n"
+            "from ccm_slam_amd import synth\n"
+            "o = oracle.OrbOracle(1000); fr = [o.extract(synth.gen_image(1000, k)) for k in (0, 1)]; o.close()\n"
+            "trm.test_triangulation_fan_out_of_a_new_keyframe_M5_x20(C.CDLL(t.SHIM), fr)\nprint('ok')\n")
+    env = dict(os.environ, CCM_SHIM_TRI_BATCH="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
 def test_M6_search_for_initialization(slib, frames):
     trm.test_search_for_initialization_M6(slib, frames)
 
