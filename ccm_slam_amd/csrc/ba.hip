@@ -505,173 +505,8 @@ __device__ __forceinline__ void row2_range(int N, int q, int* e0, int* cnt) {
   *e0 = off; *cnt = n;
 }
 
-__global__ __launch_bounds__(kRow2TPB) void ba_schur_row2(BaDev d) {
-  extern __shared__ __attribute__((aligned(16))) double Ys[];
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  constexpr int G = kRow2Group, UPW = kWave / G, NW = kRow2TPB / kWave;
-  const int per_xcd = gridDim.x >> 3;      // workgroup b runs on XCD b % 8: XCD x walks the contiguous row range [x * per, (x + 1) * per) (rows in flight share W_c rows)
-  const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (i >= d.Cp) return;
-  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;   // ne <= kRowMaxEdges < kRow2TPB: one observation per thread
-  // phase clocks: compiled in only with -DCCM_BA_ROW_DBG_BUILD (round 4: as a run-time option their 64-bit time stamp stayed live through the whole kernel and
-  // was one of the values the register allocator spilled to scratch memory)
-#ifdef CCM_BA_ROW_DBG_BUILD
-  long long tk0 = 0;
-  if (d.row_dbg && threadIdx.x == 0) tk0 = wall_clock64();
-#define ROW2_TICK(slot) { if (d.row_dbg && threadIdx.x == 0) { const long long tn_ = wall_clock64(); atomicAdd((unsigned long long*)(d.row_dbg + slot), (unsigned long long)(tn_ - tk0)); tk0 = tn_; } }
-#else
-#define ROW2_TICK(slot) {}
-#endif
-  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int grp = lane / G, q = lane % G;
-  const int zrow = d.max_cam_edges;        // a zero row of Y behind the real ones: what the idle lanes of a unit multiply
-  const int n_dgrp = (ne + G - 1) / G;     // 16-observation groups of the diagonal partials
-  double* dpart = Ys + 18 * (size_t)(zrow + 1);                           // [ceil(max_cam_edges / 16)][27]
-  double* part = dpart + 27 * (size_t)((d.max_cam_edges + G - 1) / G);    // [row_units_max][36]
-  // the table entry and the index vectors of this wave's first block pass are requested before anything else: their round trips overlap the staging
-  const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
-  int n_s0 = 0, n_s1 = 0, n_slot = 0;
-  if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; }
-  // ---- Y_e = W_e D^-1 of the camera's observations, one thread per observation; the same thread adds the observation's part of the diagonal block
-  //      (Y_e W_e^T, symmetric: entries r <= c) and of b_schur (Y_e b_l) ----
-  {
-    const int t = threadIdx.x;
-    double dacc[27];
-#pragma unroll
-    for (int k = 0; k < 27; k++) dacc[k] = 0.0;
-    if (t < ne) {
-      const int e = d.cam_edge[base + t], pt = d.cam_pt[base + t];
-      const v2d* Wp = reinterpret_cast<const v2d*>(d.W + 18 * (size_t)e);
-      const v2d* Dp = reinterpret_cast<const v2d*>(d.Dinv + 6 * (size_t)pt);
-      v2d w2[9], d2[3];
-#pragma unroll
-      for (int k = 0; k < 9; k++) w2[k] = Wp[k];
-#pragma unroll
-      for (int k = 0; k < 3; k++) d2[k] = Dp[k];
-      const double bl0 = d.bl[3 * (size_t)pt], bl1 = d.bl[3 * (size_t)pt + 1], bl2 = d.bl[3 * (size_t)pt + 2];
-      double wf[18], yf[18];
-#pragma unroll
-      for (int k = 0; k < 9; k++) { wf[2 * k] = w2[k][0]; wf[2 * k + 1] = w2[k][1]; }
-      const double D0 = d2[0][0], D1 = d2[0][1], D2 = d2[1][0], D3 = d2[1][1], D4 = d2[2][0], D5 = d2[2][1];
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const double a0 = wf[3 * r], a1 = wf[3 * r + 1], a2 = wf[3 * r + 2];
-        yf[3 * r + 0] = a0 * D0 + a1 * D1 + a2 * D2;
-        yf[3 * r + 1] = a0 * D1 + a1 * D3 + a2 * D4;
-        yf[3 * r + 2] = a0 * D2 + a1 * D4 + a2 * D5;
-      }
-      v2d* Yp = reinterpret_cast<v2d*>(Ys + 18 * (size_t)t);
-#pragma unroll
-      for (int k = 0; k < 9; k++) { v2d v; v[0] = yf[2 * k]; v[1] = yf[2 * k + 1]; Yp[k] = v; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is read back three values at a time below (same thread): Y, W_e and the 27 sums do not fit 128 registers together
-      const double* Yr = Ys + 18 * (size_t)t;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};   // compact index of (r, c), r <= c: kTri[r] + c
-        const double y0 = Yr[3 * r], y1 = Yr[3 * r + 1], y2 = Yr[3 * r + 2];
-#pragma unroll
-        for (int c = r; c < 6; c++)
-          dacc[kTri[r] + c] = __builtin_fma(y2, wf[3 * c + 2], __builtin_fma(y1, wf[3 * c + 1], y0 * wf[3 * c]));
-        dacc[21 + r] = __builtin_fma(y2, bl2, __builtin_fma(y1, bl1, y0 * bl0));
-      }
-    }
-    if (wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
-      double t1[14], t2[7], t3[4], t4[2];
-      row2_halve<27>(dacc, t1, (q & 8) != 0, 8);
-      row2_halve<14>(t1, t2, (q & 4) != 0, 4);
-      row2_halve<7>(t2, t3, (q & 2) != 0, 2);
-      row2_halve<4>(t3, t4, (q & 1) != 0, 1);
-      int e0, cnt;
-      row2_range(27, q, &e0, &cnt);
-      const int g = threadIdx.x / G;
-      if (g < n_dgrp) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * (size_t)g + e0 + k] = t4[k];
-      }
-    }
-  }
-  if (threadIdx.x < 18) Ys[18 * (size_t)zrow + threadIdx.x] = 0.0;
-  __syncthreads();
-  ROW2_TICK(0)
-  // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
-  for (int p = wv; p * UPW < n_units; p += NW) {
-    const int uu = p * UPW + grp;
-    const int s0 = n_s0, s1 = n_s1, slot = n_slot;
-    n_s0 = n_s1 = n_slot = 0;
-    if ((p + NW) * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + (p + NW) * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; }
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    // the table lists the units longest first, so group 0 of the pass sets the trip count of the wave
-    const int nit = __builtin_amdgcn_readfirstlane((s1 - s0 + G - 1) / G);
-    int ce_n = (s0 + q < s1) ? d.inst_c[s0 + q] : 0;          // index vectors one iteration ahead of the W_c rows they address
-    int ar_n = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow;
-    for (int it = 0; it < nit; it++) {
-      const int ce = ce_n, ar = ar_n;
-      const int sn = s0 + (it + 1) * G + q;
-      ce_n = (sn < s1) ? d.inst_c[sn] : 0;
-      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
-      const v2d* Wp = reinterpret_cast<const v2d*>(d.W + 18 * (size_t)ce);
-      const double* Yp = Ys + 18 * (size_t)ar;
-      v2d w2[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) w2[k] = Wp[k];
-      double wf[18];
-#pragma unroll
-      for (int k = 0; k < 9; k++) { wf[2 * k] = w2[k][0]; wf[2 * k + 1] = w2[k][1]; }
-#pragma unroll
-      for (int r = 0; r < 6; r++) {   // the Y row comes out of LDS three values at a time: 16 waves leave 128 registers per lane
-        const double y0 = Yp[3 * r], y1 = Yp[3 * r + 1], y2 = Yp[3 * r + 2];
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc[6 * r + c] = __builtin_fma(y2, wf[3 * c + 2], __builtin_fma(y1, wf[3 * c + 1], __builtin_fma(y0, wf[3 * c], acc[6 * r + c])));   // explicit: the library is built -ffp-contract=off
-      }
-    }
-    double t1[18], t2[9], t3[5], t4[3];
-    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
-    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
-    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
-    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
-    int e0, cnt;
-    row2_range(36, q, &e0, &cnt);
-    if (uu < n_units) {
-      double* pu = part + 36 * (size_t)slot;
-#pragma unroll
-      for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
-    }
-  }
-  ROW2_TICK(1)   // (wave 0's share of the block passes)
-  __syncthreads();
-  ROW2_TICK(2)   // (waiting for the slowest wave)
-  // ---- final sums: per block over its units (slot = creation order: a block's units are consecutive); diagonal block + b_schur over the 16-observation groups ----
-  {
-    const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
-    constexpr int kGroups = kRow2TPB / 36;
-    if (grp36 < kGroups)
-      for (int b = d.rowblk_off[i] + grp36; b < d.rowblk_off[i + 1]; b += kGroups) {
-        double sum = 0;
-        const int ub = d.blk_unit0[b], ue = ub + max(1, (d.inst_off[b + 1] - d.inst_off[b] + d.unit_chunk - 1) / d.unit_chunk);
-        for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
-        d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
-      }
-    if (threadIdx.x >= kRow2TPB - 64 && threadIdx.x - (kRow2TPB - 64) < 27) {   // the last wave (it has no block of the loop above when the row is short)
-      const int e = threadIdx.x - (kRow2TPB - 64);
-      double sum = 0;
-      for (int g = 0; g < n_dgrp; g++) sum += dpart[27 * (size_t)g + e];
-      if (e < 21) {
-        const int r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
-        const int tri = r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15;
-        const int c = e - tri;
-        const double v = d.Hpp[36 * (size_t)i + 6 * r + c] - sum;
-        d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;   // the upper triangle is mirrored: S_ii is exactly symmetric
-      } else d.bs[6 * (size_t)i + e - 21] = d.bp[6 * (size_t)i + e - 21] - sum;
-    }
-  }
-  ROW2_TICK(3)
-#ifdef CCM_BA_ROW_DBG_BUILD
-  if (d.row_dbg && threadIdx.x == 0) atomicAdd((unsigned long long*)(d.row_dbg + 5), 1ull);
-#endif
-#undef ROW2_TICK
-}
+// (round 5: ba_schur_row2 — this kernel on the STORED 144-byte Hpl blocks, nine divergent 16-byte loads per lane and instance — is gone from the library: 211 us per launch
+// against 131 for ba_schur_row3 below on the 4-agent map; DESIGN 4.1 keeps the measurements.  Its reduction helpers above serve row3.)
 
 // Factors of an observation's Hpl block W = Jj^T (wom Ji) from its compact record (x, y, 1 / z | wom) and its camera's record (rotation matrix rows
 // R_0 R_1 R_2, fx, fy), W itself never formed.  With a = x / z, b = y / z:
@@ -901,221 +736,8 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
 #undef ROW3_TICK
 }
 
-// ---- round 4: the row kernel with TWO rows per CU -------------------------------------------------------------------------------------------------------
-// ba_schur_row3 keeps Y_e = W_e D^-1 (6 x 3 = 144 B) of every own observation in LDS: 70-100 KB per row, hence ONE 16-wave workgroup per CU, and the row is a
-// chain of dependent round trips (indices -> records -> landmark data; table -> index vectors -> partner records; block ranges -> partial sums) that nothing
-// overlaps.  Here an own observation keeps 72 B: G_e = (w Omega Ji)_e D^-1 (2 x 3) and (a, b, 1/z) = (x/z, y/z, 1/z), from which Jj_e is two multiplications
-// per entry, and an instance's contribution is regrouped as
-//     W_a D^-1 W_c^T = Jj_a^T [ G_a (w Omega Ji)_c^T ] Jj_c          (2 x 2 core: 12 multiply-adds; times Jj_c: 20; times Jj_a^T: 60 — 36 + 60 in row3)
-// A workgroup is 8 waves (512 threads, 128 registers per lane as before) and needs ~60 KB of LDS on the 4-agent map, so TWO rows are resident per CU and each
-// one's round trips run under the other's arithmetic.  Same work units, same unit table, same fixed summation tree as row3 (32 units per pass instead of 64);
-// the diagonal block and b_schur are formed by the staging thread as Jj_e^T [G_e (w Omega Ji)_e^T] Jj_e and Jj_e^T (G_e b_l).  The regrouping changes
-// the rounding of S in the last bits against row3 / row2 (tests/test_ba_gpu.py::test_formulations_of_the_large_map_path_agree compares complete runs).
-// MEASURED (gba_c4, one box, bench events): 146 us against 134 us for row3 — SLOWER, so it is opt-in (CCM_BA_ROW=4).  Why: a CU holds 16 waves either way (128
-// registers per lane), and the waves of ONE 16-wave workgroup already run under each other's round trips; two 8-wave workgroups only add the overlap of one
-// row's staging with the other's block passes, and pay for it with two passes per row (32 units per pass for ~57 units), a second prologue per CU and 72 B of
-// scratch spills per lane in the staging loop (27 diagonal sums next to the factors).  More rows per CU would need fewer than 128 registers per lane, which
-// the 36 sums of an instance's 6 x 6 block do not leave.
-constexpr int kRow4TPB = 512;
-__global__ __launch_bounds__(kRow4TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_schur_row4(BaDev d) {
-  extern __shared__ __attribute__((aligned(16))) double Ys[];
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  constexpr int G = kRow2Group, UPW = kWave / G, NW = kRow4TPB / kWave, YS = 10;   // 9 values per observation, rows padded to 10 doubles (16-byte aligned pairs)
-  const int per_xcd = gridDim.x >> 3;
-  const int i = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (i >= d.Cp) return;
-  const int base = d.cam_off[i], ne = d.cam_off[i + 1] - base;
-  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int grp = lane / G, q = lane % G;
-  const int zrow = d.max_cam_edges;        // a zero row behind the real ones: what the idle lanes of a unit multiply
-  double* dpart = Ys + YS * (size_t)(zrow + 1);                          // [NW][27] per-wave partials of the diagonal block / b_schur
-  double* part = dpart + 27 * NW + 1;                                     // [row_units_max][36]
-  const int u_first = d.row_unit_off[i], n_units = d.row_unit_off[i + 1] - u_first;
-  int n_s0 = 0, n_s1 = 0, n_slot = 0, n_j = 0;
-  if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
-  // the row camera's record: rotation rows, fx, fy — workgroup-uniform, forced into scalar registers (as vector registers the two focal lengths were spilled
-  // around the inner loop and reloaded in every iteration)
-  auto uni = [](double v) {
-    const long long bits = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readfirstlane((int)(bits & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-  };
-  const double* rki = d.camRK + 12 * (size_t)i;
-  const double fxi = uni(rki[9]), fyi = uni(rki[10]);
-  // ---- staging: G_e, (a, b, 1/z) of the own observations; diagonal block and b_schur ----
-  {
-    double dacc[27];
-#pragma unroll
-    for (int k = 0; k < 27; k++) dacc[k] = 0.0;
-    v2d ri[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { ri[k][0] = uni(rki[2 * k]); ri[k][1] = uni(rki[2 * k + 1]); }
-    for (int t = threadIdx.x; t < ne; t += kRow4TPB) {
-      const int pt = d.cam_pt[base + t];
-      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)(base + t));
-      const v2d* Dp = reinterpret_cast<const v2d*>(d.Dinv + 6 * (size_t)pt);
-      const v2d ea = Ep[0], eb = Ep[1];
-      const v2d d0 = Dp[0], d1 = Dp[1], d2 = Dp[2];
-      const double bl0 = d.bl[3 * (size_t)pt], bl1 = d.bl[3 * (size_t)pt + 1], bl2 = d.bl[3 * (size_t)pt + 2];
-      double wj0[3], wj1[3], pj[5], qj[5];
-      ba_compact_factors(ea, eb, ri, wj0, wj1, pj, qj);
-      const double D0 = d0[0], D1 = d0[1], D2 = d1[0], D3 = d1[1], D4 = d2[0], D5 = d2[1];
-      const double g00 = wj0[0] * D0 + wj0[1] * D1 + wj0[2] * D2, g01 = wj0[0] * D1 + wj0[1] * D3 + wj0[2] * D4, g02 = wj0[0] * D2 + wj0[1] * D4 + wj0[2] * D5;
-      const double g10 = wj1[0] * D0 + wj1[1] * D1 + wj1[2] * D2, g11 = wj1[0] * D1 + wj1[1] * D3 + wj1[2] * D4, g12 = wj1[0] * D2 + wj1[1] * D4 + wj1[2] * D5;
-      const double iz = eb[0], aa = ea[0] * iz, bb = ea[1] * iz;
-      v2d* Yp = reinterpret_cast<v2d*>(Ys + YS * (size_t)t);
-      v2d o0, o1, o2, o3, o4; o0[0] = g00; o0[1] = g01; o1[0] = g02; o1[1] = g10; o2[0] = g11; o2[1] = g12; o3[0] = aa; o3[1] = bb; o4[0] = iz; o4[1] = 0.0;
-      Yp[0] = o0; Yp[1] = o1; Yp[2] = o2; Yp[3] = o3; Yp[4] = o4;
-      // own part of the diagonal block: Jj^T M Jj with M = G (w Omega Ji)^T (2 x 2), and of b_schur: Jj^T (G b_l)
-      const double m00 = g00 * wj0[0] + g01 * wj0[1] + g02 * wj0[2], m01 = g00 * wj1[0] + g01 * wj1[1] + g02 * wj1[2];
-      const double m10 = g10 * wj0[0] + g11 * wj0[1] + g12 * wj0[2], m11 = g10 * wj1[0] + g11 * wj1[1] + g12 * wj1[2];
-      const double gb0 = g00 * bl0 + g01 * bl1 + g02 * bl2, gb1 = g10 * bl0 + g11 * bl1 + g12 * bl2;
-      // Jj as 2 x 6: row 0 = (pj0 pj1 pj2 pj3 0 pj4), row 1 = (qj0 qj1 qj2 0 qj3 qj4)
-      const double P6[6] = {pj[0], pj[1], pj[2], pj[3], 0.0, pj[4]}, Q6[6] = {qj[0], qj[1], qj[2], 0.0, qj[3], qj[4]};
-      double n0[6], n1[6];
-#pragma unroll
-      for (int c = 0; c < 6; c++) { n0[c] = m00 * P6[c] + m01 * Q6[c]; n1[c] = m10 * P6[c] + m11 * Q6[c]; }
-      constexpr int kTri[6] = {0, 5, 9, 12, 14, 15};
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-#pragma unroll
-        for (int c = r; c < 6; c++) dacc[kTri[r] + c] += P6[r] * n0[c] + Q6[r] * n1[c];
-        dacc[21 + r] += P6[r] * gb0 + Q6[r] * gb1;
-      }
-    }
-    // 27 sums over the 64 lanes of every wave (fixed tree), one partial per wave
-    {
-      double t0[14], t1[7], t2[4], t3[2];
-#pragma unroll
-      for (int k = 0; k < 27; k++) { dacc[k] += __shfl_xor(dacc[k], 32, kWave); dacc[k] += __shfl_xor(dacc[k], 16, kWave); }
-      row2_halve<27>(dacc, t0, (q & 8) != 0, 8);
-      row2_halve<14>(t0, t1, (q & 4) != 0, 4);
-      row2_halve<7>(t1, t2, (q & 2) != 0, 2);
-      row2_halve<4>(t2, t3, (q & 1) != 0, 1);
-      int e0, cnt;
-      row2_range(27, q, &e0, &cnt);
-      if (grp == 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * wv + e0 + k] = t3[k];
-      }
-    }
-  }
-  if (threadIdx.x < YS) Ys[YS * (size_t)zrow + threadIdx.x] = 0.0;
-  __syncthreads();
-  // ---- off-diagonal blocks: units of <= kRow2Chunk pair instances, longest first, four per wave pass ----
-  for (int p = wv; p * UPW < n_units; p += NW) {
-    const int uu = p * UPW + grp;
-    if (p != wv) {
-      n_s0 = n_s1 = n_slot = n_j = 0;
-      if (uu < n_units) { const int4 te = d.unit_tab[u_first + uu]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
-    }
-    const int s0 = n_s0, jc = n_j;
-    double acc[36];
-#pragma unroll
-    for (int k = 0; k < 36; k++) acc[k] = 0.0;
-    const int nit = __builtin_amdgcn_readfirstlane((n_s1 - s0 + G - 1) / G);   // the table lists the units longest first: group 0 sets the trip count of the wave
-    int ce_n = (s0 + q < n_s1) ? d.inst_cp[s0 + q] : 0;
-    int ar_n = (s0 + q < n_s1) ? d.inst_al[s0 + q] : zrow;
-    int jq = jc;
-    // the loop keeps TWO integers of the table entry (its end and the running index), each in a register of its own: held as the 16-byte entry, the whole
-    // entry was spilled and reloaded in every iteration for the bounds test of the index prefetch; the partial-sum slot is read again after the loop
-    int s1 = n_s1, sn = s0 + q;
-    asm volatile("" : "+v"(s1), "+v"(sn));
-    for (int it = 0; it < nit; it++) {
-      const int ce = ce_n, ar = ar_n;
-      asm volatile("" : "+v"(jq));            // (see ba_schur_row3: keeps the loop-invariant camera record from being hoisted and spilled)
-      const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jq);
-      v2d r2[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) r2[k] = rk[k];
-      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce);
-      const v2d ea = Ep[0], eb = Ep[1];
-      sn += G;
-      ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
-      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
-      const v2d* Yp = reinterpret_cast<const v2d*>(Ys + YS * (size_t)ar);
-      const v2d y0 = Yp[0], y1 = Yp[1], y2 = Yp[2];
-      double n0[6], n1[6];
-      {
-        double wj0[3], wj1[3], pj[5], qj[5];
-        ba_compact_factors(ea, eb, r2, wj0, wj1, pj, qj);
-        // M = G_a (w Omega Ji)_c^T
-        const double m00 = __builtin_fma(y1[0], wj0[2], __builtin_fma(y0[1], wj0[1], y0[0] * wj0[0]));
-        const double m01 = __builtin_fma(y1[0], wj1[2], __builtin_fma(y0[1], wj1[1], y0[0] * wj1[0]));
-        const double m10 = __builtin_fma(y2[1], wj0[2], __builtin_fma(y2[0], wj0[1], y1[1] * wj0[0]));
-        const double m11 = __builtin_fma(y2[1], wj1[2], __builtin_fma(y2[0], wj1[1], y1[1] * wj1[0]));
-        // N = M Jj_c (structural zeros: pj column 4, qj column 3)
-        n0[0] = __builtin_fma(m01, qj[0], m00 * pj[0]); n1[0] = __builtin_fma(m11, qj[0], m10 * pj[0]);
-        n0[1] = __builtin_fma(m01, qj[1], m00 * pj[1]); n1[1] = __builtin_fma(m11, qj[1], m10 * pj[1]);
-        n0[2] = __builtin_fma(m01, qj[2], m00 * pj[2]); n1[2] = __builtin_fma(m11, qj[2], m10 * pj[2]);
-        n0[3] = m00 * pj[3];                            n1[3] = m10 * pj[3];
-        n0[4] = m01 * qj[3];                            n1[4] = m11 * qj[3];
-        n0[5] = __builtin_fma(m01, qj[4], m00 * pj[4]); n1[5] = __builtin_fma(m11, qj[4], m10 * pj[4]);
-      }
-      // Jj_a from (a, b, 1/z) and the row camera's focal lengths, one row of the result at a time
-      // (the two factors of a row are formed right before the row's six updates: as two arrays they were 20 more live registers next to the 36 sums)
-      asm volatile("" ::: "memory");          // (a, b, 1/z) are read from LDS only now: two more live pairs above would not fit
-      const v2d y3 = Yp[3];
-      const double iza = Yp[4][0];
-      const double a = y3[0], bq = y3[1];
-      const double fxa = fxi * a, fyb = fyi * bq;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const double pa = r == 0 ? fxa * bq : r == 1 ? -__builtin_fma(fxa, a, fxi) : r == 2 ? fxi * bq : r == 3 ? -(fxi * iza) : r == 4 ? 0.0 : fxa * iza;
-        const double qa = r == 0 ? __builtin_fma(fyb, bq, fyi) : r == 1 ? -(fyb * a) : r == 2 ? -(fyi * a) : r == 3 ? 0.0 : r == 4 ? -(fyi * iza) : fyb * iza;
-        asm volatile("" :: "v"(pa), "v"(qa));   // materialised here, not hoisted above the loop
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          if (r == 4) acc[6 * r + c] = __builtin_fma(qa, n1[c], acc[6 * r + c]);
-          else if (r == 3) acc[6 * r + c] = __builtin_fma(pa, n0[c], acc[6 * r + c]);
-          else acc[6 * r + c] = __builtin_fma(qa, n1[c], __builtin_fma(pa, n0[c], acc[6 * r + c]));
-        }
-      }
-    }
-    const int slot = (uu < n_units) ? d.unit_tab[u_first + uu].w : 0;   // (its round trip runs under the butterfly)
-    double t1[18], t2[9], t3[5], t4[3];
-    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
-    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
-    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
-    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
-    int e0, cnt;
-    row2_range(36, q, &e0, &cnt);
-    if (uu < n_units) {
-      double* pu = part + 36 * (size_t)slot;
-#pragma unroll
-      for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
-    }
-  }
-  const int grp36 = threadIdx.x / 36, el = threadIdx.x % 36;
-  constexpr int kGroups = kRow4TPB / 36;
-  const int fb0 = d.rowblk_off[i] + grp36, fb_end = d.rowblk_off[i + 1];
-  int f_ub = 0, f_n = 0;
-  if (grp36 < kGroups && fb0 < fb_end) { f_ub = d.blk_unit0[fb0]; f_n = d.inst_off[fb0 + 1] - d.inst_off[fb0]; }
-  __syncthreads();
-  // ---- final sums: per block over its units; diagonal block + b_schur over the waves' partials ----
-  if (grp36 < kGroups)
-    for (int bI = fb0; bI < fb_end; bI += kGroups) {
-      double sum = 0;
-      const int ub = (bI == fb0) ? f_ub : d.blk_unit0[bI];
-      const int ni = (bI == fb0) ? f_n : d.inst_off[bI + 1] - d.inst_off[bI];
-      const int ue = ub + max(1, (ni + d.unit_chunk - 1) / d.unit_chunk);
-      for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
-      d.S[36 * (size_t)(d.Cp + bI) + el] = -sum;
-    }
-  if (threadIdx.x >= kRow4TPB - 64 && threadIdx.x - (kRow4TPB - 64) < 27) {
-    const int e = threadIdx.x - (kRow4TPB - 64);
-    double sum = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) sum += dpart[27 * w + e];
-    if (e < 21) {
-      const int r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
-      const int tri = r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15;
-      const int c = e - tri;
-      const double v = d.Hpp[36 * (size_t)i + 6 * r + c] - sum;
-      d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;
-    } else d.bs[6 * (size_t)i + e - 21] = d.bp[6 * (size_t)i + e - 21] - sum;
-  }
-}
+// (round 5: ba_schur_row4 — two rows per CU, 8-wave workgroups, own observations as 72 bytes — was built and measured in round 4 (146 us against 134 for row3: a CU holds
+// 16 waves either way, and two half-size workgroups pay two passes per row) and is gone from the library; DESIGN 4.1 keeps the measurement.)
 
 // ---- PCG on (S + lambda I_diag) x = bs ---------------------------------------------------------
 // Preconditioner: block-Jacobi over CLUSTERS of kClu consecutive camera slots (dense 96x96 blocks).  Keyframes of
@@ -1164,11 +786,9 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
 // (round 4) 66 VGPRs left ONE 16-wave workgroup per CU (7 waves per SIMD); the kernel is bound by the bytes it keeps in flight (per wave 8 blocks of 288 B behind
 // an index load), so it is held to 64 registers: two workgroups per CU.
-template <bool QP /* also leave P^T q of the 8 rows for ba_pcg_update_coarse (CCM_BA_MK_FUSED=1) */>
 __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
-  __shared__ double qp[kRowsPerWG][6][6];
   __shared__ double redp[4 * (kSpmvTPB / kWave)];
   // the "done" flag is read ONCE per workgroup: workgroup 0 sets it further down in this very launch, and waves of another workgroup that read it at
   // different times would leave the block-wide sums below with missing members
@@ -1254,30 +874,7 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     pq = wave_sum(lane < 6 ? pq : 0.0);
     if (lane == 0) lds[rl] = pq;
   } else if (h == 0 && lane == 0) lds[rl] = 0.0;
-  const bool with_qparts = QP && d.mk_on && d.mk_qpart;
-  if (with_qparts && h == 0 && lane < 6) {
-    // P^T q of the row (the coarse residual follows r's recurrence: ba_pcg_update_coarse): the 36 products go to LDS, 12 threads add them up below
-    if (i < d.Cp) {
-      const double* P = d.mk_P + 36 * (size_t)i + 6 * lane;
-#pragma unroll
-      for (int cc = 0; cc < 6; cc++) qp[rl][lane][cc] = P[cc] * qv;
-    } else {
-#pragma unroll
-      for (int cc = 0; cc < 6; cc++) qp[rl][lane][cc] = 0.0;
-    }
-  }
   __syncthreads();
-  if (with_qparts && threadIdx.x < 12) {
-    const int cc = threadIdx.x % 6, second = threadIdx.x / 6;
-    double sv = 0;
-    for (int q = 0; q < kRowsPerWG; q++) {
-      const int iq = wg * kRowsPerWG + q;
-      const double w1 = coarse_hat_t(iq, d.agg), w = second ? w1 : 1.0 - w1;
-      sv += w * (((qp[q][0][cc] + qp[q][1][cc]) + (qp[q][2][cc] + qp[q][3][cc])) + (qp[q][4][cc] + qp[q][5][cc]));
-    }
-    const int gpi = d.agg / kRowsPerWG;          // row groups per interval
-    d.mk_qpart[(size_t)(second * gpi + wg % gpi) * (6 * (size_t)(d.mk_na + 1)) + 6 * (size_t)(wg / gpi + second) + cc] = sv;
-  }
   if (threadIdx.x == 0) {
     double tot = lds[0];
 #pragma unroll
@@ -1287,126 +884,9 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
 }
 
-// The same step with every stored block read ONCE (round 4).  ba_pcg_spmv reads a block twice per product — in its own row and, transposed, in its column's row —
-// and S (114 MB on the 10 000-keyframe map) fits no L2, so the second read comes from memory again (PMC: 201 MB per launch).  Here the waves of row i walk the row's
-// diagonal and UPPER blocks only, which lie contiguously in S: y_i += S_ij p_j as before, and S_ij^T p_i (a sum over the six row lanes of a block: a halving butterfly
-// inside the 8-lane group) goes to the slot of the block among row j's lower entries (sym_T, scattered 48-byte stores, no atomics: one writer per slot, a fixed summation
-// order in the reader).  ba_pcg_update adds a row's slots to the partial q written here.  p.q needs no complete q: p.Sp = sum_i p_i.(D_i p_i) + 2 sum_(i<j) p_i.(S_ij p_j).
-__global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv_sym(BaDev d, int k) {
-  __shared__ double half_sum[kRowsPerWG][2][16];   // [0..7] diagonal + upper part of y, [8..15] diagonal part alone
-  __shared__ double lds[kRowsPerWG];
-  __shared__ double redp[4 * (kSpmvTPB / kWave)];
-  __shared__ int s_done;
-  if (threadIdx.x == 0) s_done = d.pcg_flag[0];
-  __syncthreads();
-  if (s_done) return;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int rl = wv >> 1, h = wv & 1;            // local row, half
-  double rz_k, beta = 0;
-  {
-    const int nco = d.mk_on ? d.n_wg_upd : 0, npr = k ? d.n_wg_upd : 0;
-    const double* const ps[4] = {d.prz[k & 1], d.mk_cry[k & 1], d.prz[(k + 1) & 1], d.mk_cry[(k + 1) & 1]};
-    const int ns[4] = {d.n_wg_upd, nco, npr, k ? nco : 0};
-    double sm[4];
-    block_sum_partials<4, kSpmvTPB>(ps, ns, sm, redp);
-    rz_k = sm[0];
-    if (d.mk_on) rz_k += sm[1];
-    if (k == 0) { if (blockIdx.x == 0 && threadIdx.x == 0) d.pcg_scal[0] = rz_k; }
-    else {
-      double rz_prev = sm[2];
-      if (d.mk_on) rz_prev += sm[3];
-      beta = rz_k / rz_prev;
-    }
-  }
-  const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
-  if (rz_k <= d.pcg_scal[1] * rz0 || !(rz_k > 0.0)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; if (rz_k != rz_k) d.pcg_flag[2] = 1; }
-    return;
-  }
-  const double lambda = d.pcg_scal[2];
-  const double* pold = d.p[k & 1];
-  double* pnew = d.p[(k + 1) & 1];
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  const int g = lane >> 3, r = lane & 7;
-  // The grid is at most two workgroups per CU (all resident at once); a workgroup takes several groups of 8 rows one after the other, so the sums above are formed
-  // 512 times per launch, not once per 8 rows, and no workgroup waits for a slot (1 250 workgroups of 16 waves: ~12 us of dispatch on the 10 000-keyframe map).
-  // XCD x (workgroups b % 8 == x) keeps the contiguous chunk x of the row groups.
-  const int per_xcd = d.n_wg_spmv >> 3, g_per_xcd = gridDim.x >> 3;   // both padded to multiples of 8
-  for (int li = blockIdx.x >> 3; li < per_xcd; li += g_per_xcd) {
-  const int wg = (blockIdx.x & 7) * per_xcd + li;
-  const int i = wg * kRowsPerWG + rl;
-  double acc = 0, accd = 0;
-  if (i < d.Cp) {
-    const int rr = min(r, 5);                    // lanes 6, 7 of a group load row 5 again and contribute zeros
-    const double vi = r < 6 ? d.z[6 * (size_t)i + rr] + beta * pold[6 * (size_t)i + rr] : 0.0;
-    const int u0 = d.rowblk_off[i], nu = d.rowblk_off[i + 1] - u0;
-    for (int s = h * 8 + g; s <= nu; s += 16) {   // s == 0: the diagonal block
-      const int tid = u0 + s - 1;
-      const int j = s ? d.blk_j[tid] : i;
-      const int dst = s ? d.sym_dst[tid] : 0;
-      const v2d* B = reinterpret_cast<const v2d*>(d.S + 36 * (size_t)(s ? d.Cp + tid : i) + 6 * rr);
-      const v2d* zj = reinterpret_cast<const v2d*>(d.z + 6 * (size_t)j);
-      const v2d* pj = reinterpret_cast<const v2d*>(pold + 6 * (size_t)j);
-      const v2d b0 = B[0], b1 = B[1], b2 = B[2];
-      const v2d z0 = zj[0], z1 = zj[1], z2 = zj[2], p0 = pj[0], p1 = pj[1], p2 = pj[2];
-      const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
-      const double vj[6] = {z0.x + beta * p0.x, z0.y + beta * p0.y, z1.x + beta * p1.x, z1.y + beta * p1.y, z2.x + beta * p2.x, z2.y + beta * p2.y};
-      if (r < 6) {
-        double y = 0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) y += b[c] * vj[c];
-        acc += y;
-        if (s == 0) accd = y;
-      }
-      if (s) {
-        // S_ij^T p_i: component c = sum over the row lanes r of B[r][c] p_i[r].  xor 4: the lanes 0..3 of the group keep c = 0, 1, 2 and send 3, 4, 5 (lanes 4..7 the
-        // other way), then xor 2 and xor 1 on the three kept values: 9 cross-lane adds instead of 18
-        const bool hi = (r & 4) != 0;
-        double kp[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const double lo_v = b[c] * vi, hi_v = b[3 + c] * vi;
-          const double send = hi ? lo_v : hi_v, keep = hi ? hi_v : lo_v;
-          kp[c] = keep + __shfl_xor(send, 4, kWave);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 2, kWave);
-#pragma unroll
-        for (int c = 0; c < 3; c++) kp[c] += __shfl_xor(kp[c], 1, kWave);
-        // slots of 64 bytes (6 values + 2 zeros), written whole by the 8 lanes of the group: a 48-byte store leaves a partial line to be merged at the memory side
-        const int q3 = r & 3;
-        d.sym_T[8 * (size_t)dst + (q3 < 3 ? (hi ? 3 : 0) + q3 : (hi ? 7 : 6))] = q3 == 0 ? kp[0] : q3 == 1 ? kp[1] : q3 == 2 ? kp[2] : 0.0;
-      }
-    }
-  }
-  // sum over the 8 groups (lanes with equal r): fixed xor tree
-  acc += __shfl_xor(acc, 8, kWave);  accd += __shfl_xor(accd, 8, kWave);
-  acc += __shfl_xor(acc, 16, kWave); accd += __shfl_xor(accd, 16, kWave);
-  acc += __shfl_xor(acc, 32, kWave); accd += __shfl_xor(accd, 32, kWave);
-  if (lane < 8) { half_sum[rl][h][lane] = acc; half_sum[rl][h][8 + lane] = accd; }
-  __syncthreads();
-  double pq = 0;
-  if (h == 0 && i < d.Cp) {
-    if (lane < 6) {
-      const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
-      const double y = half_sum[rl][0][lane] + half_sum[rl][1][lane], yd = half_sum[rl][0][8 + lane] + half_sum[rl][1][8 + lane];
-      d.q[6 * (size_t)i + lane] = y + lambda * pi;          // diagonal + upper part; ba_pcg_update adds the lower part
-      pnew[6 * (size_t)i + lane] = pi;
-      pq = pi * ((yd + lambda * pi) + 2.0 * (y - yd));
-    }
-    pq = wave_sum(lane < 6 ? pq : 0.0);
-    if (lane == 0) lds[rl] = pq;
-  } else if (h == 0 && lane == 0) lds[rl] = 0.0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = lds[0];
-#pragma unroll
-    for (int q = 1; q < kRowsPerWG; q++) tot += lds[q];
-    d.ppq[wg] = tot;
-  }
-  }
-}
+// (round 5: ba_pcg_spmv_sym — every stored block read once, S_ij^T p_i scattered to the slot of block (i, j) among row j's lower entries — was built and measured in round 4
+// (41.6 + 14.3 us per CG iteration against 46.5 + 9.9 on the 10 000-keyframe map: 141.8 against 142.4 ms per call, a wash: the product is bound by the requests in flight, not
+// by its bytes) and is gone from the library; DESIGN 4.1 keeps the measurement.)
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
 // one workgroup per cluster
@@ -1423,23 +903,6 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   const size_t g = 6 * (size_t)s0 + t;
   double xv = 0, rv = 0, qv = 0, pv = 0;
   if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g]; }
-  if (d.sym_T && t < m) {
-    // symmetric product (ba_pcg_spmv_sym): q so far holds the diagonal + upper part of the row; the lower part S_ji^T p_j was stored by the rows j < i at this row's lower
-    // slots, which are contiguous: added in slot order, 16 loads in flight
-    const int cam = s0 + t / 6;
-    const int ro0 = d.row_off[cam], ro1 = d.row_off[cam + 1], rb0 = d.rowblk_off[cam], rb1 = d.rowblk_off[cam + 1];
-    const int nl = (ro1 - ro0) - 1 - (rb1 - rb0);
-    const double* Tp = d.sym_T + 8 * (size_t)(ro0 - cam - rb0) + t % 6;
-    double ql = 0;
-    for (int k0 = 0; k0 < nl; k0 += 16) {
-      double tv[16];
-#pragma unroll
-      for (int u = 0; u < 16; u++) tv[u] = k0 + u < nl ? Tp[8 * (size_t)(k0 + u)] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; u++) if (k0 + u < nl) ql += tv[u];
-    }
-    qv += ql;
-  }
   __shared__ double redp[3 * (kTPB / kWave)];
   double rz_k, pq;
   {
@@ -1503,153 +966,9 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
 }
 
-// Update + coarse correction in ONE kernel (round 4), a 512-thread workgroup per interval of the coarse space: threads 0..255 do ba_pcg_update's work for the interval's first
-// cluster, 256..511 for its second one; the coarse residual is not gathered from the clusters' parts of P^T r (that needs a grid-wide step after the update, which
-// was ba_pcg_coarse_apply's launch: 12 us + a gap per CG iteration on the 10 000-keyframe map) but follows the recurrence of r, rc <- rc - alpha P^T q, with P^T q
-// left by ba_pcg_spmv per group of 8 rows; every workgroup forms the whole of rc (as ba_pcg_coarse_apply did), interval 0 stores it for the next iteration.
-constexpr int kUpd2TPB = 2 * kTPB;
-__global__ __launch_bounds__(kUpd2TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void ba_pcg_update_coarse(BaDev d, int k) {   // 128 registers: two workgroups per CU, so
-  // that the 313 intervals of the 10 000-keyframe map are resident at once (171 registers: one per CU, two rounds, 35 us per launch)
-  extern __shared__ __attribute__((aligned(16))) double rcs[];   // [6 * (na + 1)]
-  __shared__ double rc[2][kCluN];
-  __shared__ double zpart[2][8][kCluN];
-  __shared__ double red[kUpd2TPB / kWave];
-  __shared__ double redp[3 * (kUpd2TPB / kWave)];
-  __shared__ double yred[12][kUpd2TPB / kWave];
-  __shared__ double ys[12];
-  const int t = threadIdx.x, agg = blockIdx.x, sg = t >> 8, tl = t & (kTPB - 1);
-  const int lane = t & (kWave - 1), wv = t / kWave;
-  const int n_clu = d.n_wg_upd, nca = 6 * (d.mk_na + 1);
-  const int c = 2 * agg + sg;
-  const int s0 = c * kClu;
-  const int m = c < n_clu ? 6 * (min(d.Cp, s0 + kClu) - s0) : 0;
-  const int done = d.pcg_flag[0];
-  const double* p = d.p[(k + 1) & 1];
-  const size_t g = 6 * (size_t)s0 + tl;
-  double xv = 0, rv = 0, qv = 0, pv = 0;
-  double Prow[6] = {0, 0, 0, 0, 0, 0};
-  if (tl < m) {
-    xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g];
-    const double* P = d.mk_P + 36 * (size_t)(s0 + tl / 6) + 6 * (tl % 6);
-#pragma unroll
-    for (int cc = 0; cc < 6; cc++) Prow[cc] = P[cc];
-  }
-  double rz_k, pq;
-  {
-    const double* const ps[3] = {d.prz[k & 1], d.mk_cry[k & 1], d.ppq};
-    const int ns[3] = {n_clu, n_clu, d.n_wg_spmv};
-    double sm[3];
-    block_sum_partials<3, kUpd2TPB>(ps, ns, sm, redp);
-    rz_k = sm[0] + sm[1];
-    pq = sm[2];
-  }
-  if (done) return;
-  if (!(pq > 0.0)) {   // not positive definite (or NaN): solver failure -> LM rejects the step
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; d.pcg_flag[2] = 1; }
-    return;
-  }
-  const double alpha = rz_k / pq;
-  if (tl < m) {
-    d.x[g] = xv + alpha * pv;
-    rv -= alpha * qv;
-    d.r[g] = rv;
-    rc[sg][tl] = rv;
-  } else if (tl < kCluN) rc[sg][tl] = 0.0;
-  {   // coarse residual of this iteration: the previous one minus alpha x the row groups' parts of P^T q (slots in a fixed order), 2 entries per thread and batch
-    const int nsl = 2 * (d.agg / kRowsPerWG);
-    const double* rc_old = d.mk_rc[k & 1];
-    for (int base = 0; base < nca; base += 2 * kUpd2TPB) {
-      double vo[2], sq[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int e = base + u * kUpd2TPB + t;
-        vo[u] = 0; sq[u] = 0;
-        if (e < nca) {
-          vo[u] = rc_old[e];
-          double q8[8];
-#pragma unroll
-          for (int sl = 0; sl < 8; sl++) q8[sl] = sl < nsl ? d.mk_qpart[(size_t)sl * nca + e] : 0.0;
-          for (int sl = 8; sl < nsl; sl++) sq[u] += d.mk_qpart[(size_t)sl * nca + e];   // (intervals wider than 32 cameras: not the multi-kernel path's choice)
-#pragma unroll
-          for (int sl = 0; sl < 8; sl++) sq[u] += q8[sl];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++) { const int e = base + u * kUpd2TPB + t; if (e < nca) rcs[e] = vo[u] - alpha * sq[u]; }
-    }
-  }
-  __syncthreads();
-  if (agg == 0) for (int e = t; e < nca; e += kUpd2TPB) d.mk_rc[(k + 1) & 1][e] = rcs[e];
-  // z = W r of both clusters (ba_pcg_update's mapping per 256 threads)
-  if (tl < 192 && c < n_clu) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const float* W = d.Wc + (size_t)c * kCluN * kCluN;
-    const int rp = tl % 24, seg = tl / 24;
-    const v4f* Wp = reinterpret_cast<const v4f*>(W + (size_t)(12 * seg) * kCluN + 4 * rp);
-    v4f w[12];
-#pragma unroll
-    for (int q = 0; q < 12; q++) w[q] = Wp[(size_t)q * (kCluN / 4)];
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int q = 0; q < 12; q++) { const double rq = rc[sg][12 * seg + q]; a0 += (double)w[q][0] * rq; a1 += (double)w[q][1] * rq; a2 += (double)w[q][2] * rq; a3 += (double)w[q][3] * rq; }
-    zpart[sg][seg][4 * rp] = a0; zpart[sg][seg][4 * rp + 1] = a1; zpart[sg][seg][4 * rp + 2] = a2; zpart[sg][seg][4 * rp + 3] = a3;
-  }
-  {   // y = Ac^-1[12 rows of the interval's two nodes] rc
-    double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;
-    for (int base = t; base < nca; base += 2 * kUpd2TPB) {
-      float w[2][12]; double rvv[2];
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int jj = base + u * kUpd2TPB;
-        rvv[u] = 0.0;
-#pragma unroll
-        for (int rr = 0; rr < 12; rr++) w[u][rr] = 0.f;
-        if (jj < nca) {
-          rvv[u] = rcs[jj];
-#pragma unroll
-          for (int rr = 0; rr < 12; rr++) w[u][rr] = ar[(size_t)rr * d.mk_Nc + jj];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-        if (base + u * kUpd2TPB < nca) {
-#pragma unroll
-          for (int rr = 0; rr < 12; rr++) a12[rr] += (double)w[u][rr] * rvv[u];
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
-  }
-  __syncthreads();
-  if (t < 12) { double y = yred[t][0]; for (int w = 1; w < kUpd2TPB / kWave; w++) y += yred[t][w]; ys[t] = y; }
-  double rz = 0, zl = 0;
-  if (tl < m) {
-    zl = (((zpart[sg][0][tl] + zpart[sg][1][tl]) + (zpart[sg][2][tl] + zpart[sg][3][tl])) + ((zpart[sg][4][tl] + zpart[sg][5][tl]) + (zpart[sg][6][tl] + zpart[sg][7][tl])));
-    rz = rc[sg][tl] * zl;
-  }
-  rz = wave_sum(rz);
-  if (lane == 0) red[wv] = rz;
-  __syncthreads();
-  if (tl < m) {
-    const double w1 = coarse_hat_t(s0 + tl / 6, d.agg), w0 = 1.0 - w1;
-    double zc = 0;
-#pragma unroll
-    for (int cc = 0; cc < 6; cc++) zc += Prow[cc] * (w0 * ys[cc] + w1 * ys[6 + cc]);
-    d.z[g] = zl + zc;
-  }
-  if (tl == 0 && c < n_clu) {
-    d.prz[(k + 1) & 1][c] = ((red[4 * sg] + red[4 * sg + 1]) + red[4 * sg + 2]) + red[4 * sg + 3];
-    if (c == 0) d.pcg_flag[1] = k + 1;
-  }
-  if (t == 0) {
-    double sv = 0;
-    for (int rr = 0; rr < 6; rr++) sv += rcs[6 * agg + rr] * ys[rr];
-    if (agg == d.mk_na - 1) for (int rr = 0; rr < 6; rr++) sv += rcs[6 * (agg + 1) + rr] * ys[6 + rr];
-    d.mk_cry[(k + 1) & 1][2 * agg] = sv;
-    if (2 * agg + 1 < n_clu) d.mk_cry[(k + 1) & 1][2 * agg + 1] = 0.0;
-  }
-}
+// (round 5: ba_pcg_update_coarse — update + coarse correction in one 512-thread workgroup per interval, the coarse residual following r's recurrence with P^T q left by the product
+// kernel — was built and measured in round 4 (151.0 against 151.7 ms per call on the 10 000-keyframe map: what the saved launch gives, the product's extra epilogue takes) and is
+// gone from the library; DESIGN 4.1 keeps the measurement.)
 
 // Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per INTERVAL (two clusters) after ba_pcg_init_tiles / ba_pcg_update:
 // rc = P^T r per coarse node (the first-node parts of the node's interval's two clusters + the second-node parts of the previous interval's),
@@ -1693,7 +1012,6 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
     }
   }
   __syncthreads();
-  if (agg == 0 && d.mk_rc[par]) for (int e = t; e < nca; e += kTPB) d.mk_rc[par][e] = rcs[e];   // start of the recurrence of ba_pcg_update_coarse
   {
     // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows with its loads in flight together, then wave
     // trees and the four wave sums in order.
@@ -3114,7 +2432,7 @@ int dev_alloc(ccm_ba* ba, size_t n, T** out, bool zero = true) {
 
 // reduced systems with at most this many off-diagonal blocks use the one-workgroup-per-block Schur kernel; above, the row kernel (which also forms the
 // diagonal blocks and b_schur).  CCM_BA_ROW_MIN_BLOCKS overrides (experiments).
-static inline int row_min_blocks() { static const int v = getenv("CCM_BA_ROW_MIN_BLOCKS") ? atoi(getenv("CCM_BA_ROW_MIN_BLOCKS")) : 256; return v; }
+static inline int row_min_blocks() { return 256; }
 
 // S and b_schur of the current linearisation and D^-1 (one rank's part): the row kernel on large maps (it also forms the diagonal blocks and b_schur), the
 // per-block kernels otherwise.  Also what the test hooks below call, so that they see the kernels the LM loop runs.
@@ -3131,18 +2449,8 @@ static int launch_schur(ccm_ba* ba) {
     if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
     else if (d.row_units_max) {
       const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
-      static const int row_form = getenv("CCM_BA_ROW") ? atoi(getenv("CCM_BA_ROW")) : 3;
-      const size_t lds_row4 = ((size_t)(d.max_cam_edges + 1) * 10 + 27 * (kRow4TPB / kWave) + 1 + (size_t)d.row_units_max * 36) * sizeof(double);
-      if (d.E4 && row_form == 4 && lds_row4 <= 158 * 1024) {   // compact Y, 8-wave workgroups: two rows per CU when lds_row4 <= ~78 KB
-        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW4, ba_schur_row4, 158 * 1024);
-        hipLaunchKernelGGL(ba_schur_row4, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow4TPB), lds_row4, ctx->stream, d);
-      } else if (d.E4) {
-        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
-        hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
-      } else {
-        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW, ba_schur_row2, 158 * 1024);
-        hipLaunchKernelGGL(ba_schur_row2, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
-      }
+      CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
+      hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
     } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
@@ -3271,7 +2579,7 @@ int read_scalars(ccm_ba* ba, double out[6], int flags[4] = nullptr) {
 // The same read-back without a copy command and without waiting for the stream: ba_reduce_scalars wrote the words and then `ticket` into the pinned block (round 4: the
 // 64-byte copy + stream wait were ~25 us of every LM trial, 18 trials per 4-agent call, ~25 per local BA).  CCM_BA_POLL=0: the copy.  A ticket that does not arrive within
 // two seconds falls back to the stream wait (a failed launch must not hang the caller).
-bool poll_enabled() { static const bool on = !(getenv("CCM_BA_POLL") && atoi(getenv("CCM_BA_POLL")) == 0); return on; }
+bool poll_enabled() { return true; }
 int read_scalars_polled(ccm_ba* ba, double out[6], int flags[4], unsigned long long ticket) {
   volatile unsigned long long* tk = reinterpret_cast<volatile unsigned long long*>(ba->h_rb) + 8;
   bool got = false;
@@ -3388,13 +2696,13 @@ int coarse_prepare(ccm_ba* ba, double lambda) {
   // lambda window inside which a stale coarse operator is kept.  Measured on gba_c4 (10 calls each): window 4: 6 builds / 926 CG iterations /
   // 21.9 ms per call, 16: 4 builds / 976 / 20.4 ms, 64: 4 builds / 982 / 20.8 ms.  The stale-iterations guard below still forces a rebuild when
   // a reused operator costs a third more iterations than a fresh one did.
-  static const double win = getenv("CCM_BA_COARSE_WIN") ? atof(getenv("CCM_BA_COARSE_WIN")) : 16.0;
+  const double win = 16.0;
   // (round 4) UPWARDS the window is wider: lambda only grows along a chain of rejected trials (x2, x4, x8, ...), where every trial has its own lambda and a
   // rebuilt operator would serve that one solve — a 768-unknown build costs ~50 CG iterations, an operator built at a 10 - 60 times smaller lambda 5 - 15;
   // the stale-iterations guard still forces a rebuild when a reused operator does badly
   // (measured, one box, complete calls: gba_c4 15.6 -> 15.2 ms with 2 builds instead of 3 and 567 instead of 538 CG iterations; gba_c3 unchanged; on the
   // multi-kernel path of gba_c5, where a CG iteration costs ~100 us against a 2.5 ms build, the wider window LOSES 10 ms (1546 instead of 1438 iterations): 16 there)
-  static const double win_up_env = getenv("CCM_BA_COARSE_WIN_UP") ? atof(getenv("CCM_BA_COARSE_WIN_UP")) : 0.0;
+  const double win_up_env = 0.0;
   const double win_up = win_up_env > 0 ? win_up_env : (ba->pers_grid ? 64.0 : win);
   const bool need = !ba->coarse_reuse || !ba->coarse_valid || ba->coarse_stale_bad || lambda > win_up * ba->coarse_lambda_built || lambda < ba->coarse_lambda_built / win;
   ba->coarse_fresh = need;
@@ -3423,11 +2731,11 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     RC(launch_schur(ba));
     RC(ba_allreduce_sum(ba, ba->d_red, ba->red_count));
     // ---- PCG ----
-    static const double tol_default = getenv("CCM_BA_PCG_TOL") ? atof(getenv("CCM_BA_PCG_TOL")) : 1e-8;   // experiments only; the parity tests run at 1e-8
+    const double tol_default = 1e-8;   // (ccm_ba_options.pcg_rel_tol overrides; the parity tests run at 1e-8)
     const double tol = opt.pcg_rel_tol > 0 ? opt.pcg_rel_tol : tol_default;
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
     int flags[4] = {0, 0, 0, 0};
-    static const bool dense2_on = !(getenv("CCM_BA_DENSE2") && atoi(getenv("CCM_BA_DENSE2")) == 0);
+    const bool dense2_on = true;
     if (d.Cp > kSmallMaxCp && d.Cp <= kDense2MaxCp && ba->d_dense_T && ba->d_pers_coff && dense2_on) {
       // exact block solve in one workgroup (see ba_solve_dense2): one launch, flags read back with the trial scalars
       CCM_LDS_ATTR(ctx, CCM_LDS_BA_DENSE2, ba_solve_dense2, dense2_lds_bytes());
@@ -3435,7 +2743,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
         hipLaunchKernelGGL(ba_solve_dense2, dim3(1), dim3(kPersTPB), dense2_lds_bytes(), ctx->stream, d, lambda, (const int*)ba->d_pers_coff, (const int*)ba->d_pers_cij,
                            (const uint32_t*)ba->d_pers_cblk, ba->d_dense_T,
-                           getenv("CCM_BA_DENSE2_DBG") ? (long long*)(ba->d_dense_T + kCluN * kCluN) : (long long*)nullptr, cur, ba->rank == 0 ? 1 : 0);
+                           ccm_dbg("dense2") ? (long long*)(ba->d_dense_T + kCluN * kCluN) : (long long*)nullptr, cur, ba->rank == 0 ? 1 : 0);
       }
       small_path = true;
       cams_updated = true;   // (the solve's launch also applied the step to the cameras)
@@ -3464,7 +2772,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       pa.uoff = ba->d_pers_uoff; pa.ucol = ba->d_pers_ucol; pa.loc = ba->d_pers_loc;
       pa.coff = ba->d_pers_coff; pa.cij = ba->d_pers_cij; pa.cblk = ba->d_pers_cblk;
       pa.test_abort = getenv("CCM_BA_TEST_ABORT") ? 1 : 0;
-      pa.dbg = getenv("CCM_BA_PERS_DBG") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
+      pa.dbg = ccm_dbg("pers") ? (long long*)(ba->d_pers_bar + 4) : nullptr;
       pa.Ainv = nullptr; pa.Pm = nullptr; pa.na = 0; pa.Nc = 0; pa.cparts = nullptr;
       // Cluster inverse across trials.  Offline (1000-keyframe 4-agent reduced systems, numpy PCG to 1e-8): W built at a lambda 10 / 100 / 1000 times away
       // costs 0-2 / 2-3 / 5 more CG iterations of 24-46; W of the INITIAL linearisation used three LM iterations later costs 13-19 more (the robust weights move),
@@ -3476,8 +2784,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       // system (1.4e4) ten (21 against 11); ACROSS linearisations it is erratic: 32 against 31, 41 / 41, 43 / 43, but 87 against 48 (second linearisation), 58 / 43,
       // 66 / 41 — and every bad solve also trips the coarse level's stale guard (6 builds instead of 4): 19.2 ms per call against 17.0.  Hence the default:
       // mode 1 (same linearisation only) with a window of 8: 3 of the 7 rejected trials of gba_c4 load, ~0.2 ms of 17.
-      static const int w_mode = getenv("CCM_BA_W_REUSE") ? atoi(getenv("CCM_BA_W_REUSE")) : 1;
-      static const double w_win = getenv("CCM_BA_W_WIN") ? atof(getenv("CCM_BA_W_WIN")) : 8.5;
+      const int w_mode = 1;
+      const double w_win = 8.5;
       pa.wsave = ba->d_pers_wsave;
       {
         const bool same_lin = ba->w_lin_id == ba->lin_id;
@@ -3493,13 +2801,13 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       // (round 4) a strongly damped system does not need the coarse level: above the call's first lambda (g2o's 1e-5 max diag(H): the scale at which the damping
       // takes over the smooth modes as well) cluster-Jacobi alone converges in 10-24 iterations on the 4-agent map, while a stale coarse operator carried up
       // there from a 16 times smaller lambda needed 46 and a fresh build costs ~50 iterations' worth.  CCM_BA_COARSE_LMAX scales the limit (0 = no limit).
-      static const double coarse_lmax = getenv("CCM_BA_COARSE_LMAX") ? atof(getenv("CCM_BA_COARSE_LMAX")) : 1.0;
+      const double coarse_lmax = 1.0;
       const bool damped = ba->coarse_force == 0 && coarse_lmax > 0 && ba->lambda_first > 0 && lambda >= coarse_lmax * ba->lambda_first;
       const bool use_coarse = ba->coarse_na && !damped && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active));
       ba->coarse_used = use_coarse;
       ba->coarse_skipped_damped = damped;
       if (use_coarse) {
-        if (getenv("CCM_BA_COARSE_DBG")) {
+        if (ccm_dbg("coarse")) {
           hipStreamSynchronize(ctx->stream); const double tc0 = now_ms();
           RC(coarse_prepare(ba, lambda));
           const double tc1 = now_ms(); hipStreamSynchronize(ctx->stream);
@@ -3508,8 +2816,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         RC(coarse_prepare(ba, lambda));
         pa.Ainv = ba->d_cAinv; pa.Pm = ba->d_cP; pa.na = ba->coarse_na; pa.Nc = ba->coarse_Nc; pa.cparts = ba->d_cparts;
       }
-      void* kargs[2] = {(void*)&d, (void*)&pa};
-      static const bool trial_dbg = getenv("CCM_BA_TRIAL_DBG") != nullptr;   // development: wall clock of every persistent solve (adds two stream syncs per trial)
+      static const bool trial_dbg = ccm_dbg("trial");   // development: wall clock of every persistent solve (adds two stream syncs per trial)
       double tdbg0 = 0;
       if (trial_dbg) { hipStreamSynchronize(ctx->stream); tdbg0 = now_ms(); }
       {
@@ -3522,13 +2829,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         // ~13 us.  The grid was sized at create time to fit the device at the kernel's occupancy, so on a stream whose
         // earlier work has drained all workgroups become resident; if they ever do not (device shared with another
         // long-running kernel), the bounded spins of pers_exchange abort the solve, pcg_flag[3] reports it and the trial
-        // is repeated on the multi-kernel path below.  CCM_BA_COOP_LAUNCH=1 selects the cooperative launch.
-        hipError_t le;
-        static const bool coop = getenv("CCM_BA_COOP_LAUNCH") != nullptr;
-        if (!coop) { hipLaunchKernelGGL(ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), pers_lds_bytes(), ctx->stream, d, pa); le = hipGetLastError(); }
-        else
-        le = hipLaunchCooperativeKernel((const void*)ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), kargs,
-                                                         (unsigned)pers_lds_bytes(), ctx->stream);
+        // is repeated on the multi-kernel path below.  (The cooperative launch itself was removed in round 5.)
+        hipLaunchKernelGGL(ba_pcg_persist, dim3(ba->pers_grid), dim3(kPersTPB), pers_lds_bytes(), ctx->stream, d, pa);
+        const hipError_t le = hipGetLastError();
         if (le == hipSuccess) persist_ok = true;
         else { (void)hipGetLastError(); ba->pers_grid = 0; ba->pers_grid_built = 0; ba->w_valid = false; pers_launch_failed = true; }   // the launch itself was refused: multi-kernel path from now on
       }
@@ -3543,7 +2846,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     }
     if (!persist_ok) {
       d.mk_on = 0;
-      static const double coarse_lmax_mk = getenv("CCM_BA_COARSE_LMAX") ? atof(getenv("CCM_BA_COARSE_LMAX")) : 1.0;
+      const double coarse_lmax_mk = 1.0;
       const bool damped_mk = ba->coarse_force == 0 && coarse_lmax_mk > 0 && ba->lambda_first > 0 && lambda >= coarse_lmax_mk * ba->lambda_first;
       ba->coarse_skipped_damped = damped_mk;
       if (d.mk_cpart && ba->coarse_na && !damped_mk && (ba->coarse_force > 0 || (ba->coarse_force == 0 && ba->coarse_active))) {
@@ -3561,24 +2864,19 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, 0);
       }
       const int chunk = 24;
-      static const int sym_grid = getenv("CCM_BA_SPMV_GRID") ? std::max(8, atoi(getenv("CCM_BA_SPMV_GRID")) & ~7) : 512;   // two 16-wave workgroups per CU
+      const int sym_grid = 512;   // two 16-wave workgroups per CU
       int k = 0;
       while (k < max_it) {
         const int kend = std::min(max_it, k + chunk);
         for (; k < kend; k++) {
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-            if (d.sym_T) hipLaunchKernelGGL(ba_pcg_spmv_sym, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
-            else if (d.mk_on && d.mk_qpart) hipLaunchKernelGGL(ba_pcg_spmv<true>, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
-            else hipLaunchKernelGGL(ba_pcg_spmv<false>, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            hipLaunchKernelGGL(ba_pcg_spmv, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
           }
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
-            if (d.mk_on && d.mk_qpart) hipLaunchKernelGGL(ba_pcg_update_coarse, dim3(d.mk_na), dim3(kUpd2TPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, k);
-            else {
-              hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-              if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
-            }
+            hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
@@ -3639,8 +2937,8 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       if (ba->coarse_fresh) ba->coarse_fresh_iters = *pcg_iters;
       else if (*pcg_iters > ba->coarse_fresh_iters + ba->coarse_fresh_iters / 3 + 8) ba->coarse_stale_bad = true;
     }
-    static const int on_env = getenv("CCM_BA_COARSE_ON") ? atoi(getenv("CCM_BA_COARSE_ON")) : 0;
-    static const int off_env = getenv("CCM_BA_COARSE_OFF") ? atoi(getenv("CCM_BA_COARSE_OFF")) : 0;
+    const int on_env = 0;
+    const int off_env = 0;
     const int on_it = on_env ? on_env : (d.agg < kAggWide ? kCoarseOnItersFine : kCoarseOnIters);
     const int off_it = off_env ? off_env : (d.agg < kAggWide ? kCoarseOffItersFine : kCoarseOffIters);
     if (ba->coarse_skipped_damped) { /* the level was left out because of the damping, not by the switch: the switch keeps its state */ }
@@ -3710,14 +3008,14 @@ static void pers_dbg_dump(ccm_ba* ba) {
     fprintf(stderr, "[ccm_ba] row Schur kernel, thread 0 of every workgroup (%lld workgroups): us per row: staging + diagonal %.2f block passes %.2f wait %.2f final sums %.2f\n",
             h[5], h[0] * 0.01 / nw, h[1] * 0.01 / nw, h[2] * 0.01 / nw, h[3] * 0.01 / nw);
   }
-  if (ba->d_dense_T && getenv("CCM_BA_DENSE2_DBG")) {
+  if (ba->d_dense_T && ccm_dbg("dense2")) {
     long long h[11];
     hipMemcpy(h, ba->d_dense_T + kCluN * kCluN, sizeof(h), hipMemcpyDeviceToHost);
     const double nl = (double)std::max<long long>(h[8], 1);
     fprintf(stderr, "[ccm_ba] exact two-cluster solve: %lld launches; us/launch: assemble1 %.1f factor1 %.1f t1+A12 %.1f T %.1f P+c %.1f assemble2 %.1f factor2 %.1f x %.1f | both factorisations: cholesky %.1f inverse-factor %.1f\n", h[8],
             h[0] * 0.01 / nl, h[1] * 0.01 / nl, h[2] * 0.01 / nl, h[3] * 0.01 / nl, h[4] * 0.01 / nl, h[5] * 0.01 / nl, h[6] * 0.01 / nl, h[7] * 0.01 / nl, h[9] * 0.01 / nl, h[10] * 0.01 / nl);
   }
-  if (!ba->pers_grid || !getenv("CCM_BA_PERS_DBG")) return;
+  if (!ba->pers_grid || !ccm_dbg("pers")) return;
   long long h[16];
   hipMemcpy(h, ba->d_pers_bar + 4, sizeof(h), hipMemcpyDeviceToHost);
   {

@@ -281,13 +281,6 @@ __global__ void bb_row_off(int Cp, const int* rowblk_off, const int* low_off, in
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= Cp) row_off[i] = i + rowblk_off[i] + low_off[i];
 }
-// destination of S_ij^T p_i (symmetric product): row j's lower entry that refers to block b sits at row_off[j] + k, k-th lower entry -> slot low_off[j] + k = pos - j - rowblk_off[j]
-__global__ void bb_sym_dst(int Cp, const int* row_off, const int* rowblk_off, const uint32_t* row_blk, int* dst) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= Cp) return;
-  const int e0 = row_off[j], nl = (row_off[j + 1] - e0) - 1 - (rowblk_off[j + 1] - rowblk_off[j]);
-  for (int k = 0; k < nl; k++) dst[(int)(row_blk[e0 + k] & ~kTransposeBit) - Cp] = e0 + k - j - rowblk_off[j];
-}
 __global__ void bb_row_fill(int Cp, int nOff, const int* bi, const int* bj, const unsigned* jkey_sorted, const int* jval_sorted, const int* rowblk_off,
                             const int* low_off, const int* row_off, int* row_col, uint32_t* row_blk) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,7 +477,7 @@ __global__ void bb_points_out(int Lp, const int* slot_pt, const double* pt_slots
 
 inline int grid_for(int64_t n) { return std::max(1, ccm_div_up(n, kB)); }
 
-static inline int row_min_blocks() { static const int v = getenv("CCM_BA_ROW_MIN_BLOCKS") ? atoi(getenv("CCM_BA_ROW_MIN_BLOCKS")) : 256; return v; }
+static inline int row_min_blocks() { return 256; }
 
 }  // namespace
 
@@ -514,7 +507,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       (P->n_pt && !P->pt_xyz) || (P->n_edge && (!P->e_cam || !P->e_pt || !P->e_obs || !P->e_info)))
     return ccm_set_error(ctx, CCM_E_ARG, "ccm_ba_create: incomplete problem");
   const double t0 = now_ms();
-  const bool setup_dbg = getenv("CCM_BA_SETUP_DBG") != nullptr;
+  const bool setup_dbg = ccm_dbg("setup");
   double t_last = t0;
   auto lap = [&](const char* what) {
     if (setup_dbg) { hipStreamSynchronize(ctx->stream); const double t = now_ms(); fprintf(stderr, "[ccm_ba] setup %-26s %7.2f ms\n", what, t - t_last); t_last = t; }
@@ -716,7 +709,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     int *nub = nullptr, *blk_pref = nullptr, *p_row_u = nullptr, *p_blk_u = nullptr;
     BB_RC(tmp.get((size_t)nOff + 1, &nub)); BB_RC(tmp.get((size_t)nOff + 1, &blk_pref));
     BB_RC(keep_get(ba, (size_t)Cp + 1, &p_row_u)); BB_RC(keep_get(ba, (size_t)nOff + 1, &p_blk_u));
-    static const int chunk_env = getenv("CCM_BA_ROW_CHUNK") ? atoi(getenv("CCM_BA_ROW_CHUNK")) : 0;   // experiments: 16 / 32 / 64 / 128
+    const int chunk_env = 0;   // experiments: 16 / 32 / 64 / 128
     const int unit_chunk = d.unit_chunk = chunk_env >= kRow2Group ? chunk_env : kRow2Chunk;
     hipLaunchKernelGGL(bb_unit_counts, dim3(grid_for(nOff + 1)), dim3(kB), 0, st, nOff, unit_chunk, (const int*)d_inst_off, nub);
     BB_RC(scan_excl(ctx, tmp, nub, blk_pref, (size_t)nOff + 1));
@@ -729,8 +722,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     d.inst_al = p_al;
     // ---- compact observation records of the row kernel (ba_schur_row3): camera-major positions ----
     d.E4 = nullptr; d.camRK = nullptr; d.inst_cp = nullptr; d.blk_j = ba->d_blk_j + Cp;
-    static const bool row3_on = !(getenv("CCM_BA_ROW") && atoi(getenv("CCM_BA_ROW")) == 2);
-    if (row3_on && Cp && Eloc) {
+    if (Cp && Eloc) {
       int *p_cpos = nullptr, *p_icp = nullptr; double *p_e4 = nullptr, *p_rk = nullptr;
       BB_RC(tmp.get((size_t)Eloc, &p_cpos)); BB_RC(keep_get(ba, (size_t)std::max<int64_t>(ba->n_inst, 1), &p_icp));
       BB_RC(keep_get(ba, 4 * (size_t)Eloc, &p_e4)); BB_RC(keep_get(ba, 12 * (size_t)Cp, &p_rk));   // (written by the linearisation before any kernel reads them)
@@ -747,7 +739,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     auto pers_fits = [&](int agg, int na_, int Nc_) { return 6 * (size_t)Nc_ <= (size_t)kCluN * kCluN / 2 && (agg / 8) * na_ <= pers_grid_want + agg / 8 - 1; };
     int agg = kAggWide, na = 0, Nc = 0;
     static const int agg_env = getenv("CCM_BA_COARSE_AGG") ? atoi(getenv("CCM_BA_COARSE_AGG")) : 0;        // experiments: 16 / 24 / 32
-    static const int nc_cap = getenv("CCM_BA_COARSE_NC") ? atoi(getenv("CCM_BA_COARSE_NC")) : kCoarseNcCap;
+    const int nc_cap = kCoarseNcCap;
     if (pers_try)
       for (int cand : {kAggFine, kAggMid}) {
         if (agg_env ? cand != agg_env : false) continue;
@@ -758,9 +750,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     d.agg = agg;
     // (windows of up to 32 free cameras are solved exactly by ba_solve_dense2 and never see a coarse level: its block lists — a sort, a run-length encode and
     // half a dozen short kernels of a launch-bound 0.7 ms build — are skipped there unless that solver is switched off)
-    static const bool dense2_off = getenv("CCM_BA_DENSE2") && atoi(getenv("CCM_BA_DENSE2")) == 0;
-    const bool coarse_pers = pers_try && !getenv("CCM_BA_NO_COARSE") && pers_fits(agg, na, Nc) && (Cp > kDense2MaxCp || dense2_off);
-    const bool coarse_mk = pers_wanted && !getenv("CCM_BA_NO_COARSE") && agg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
+    const bool dense2_off = false;
+    const bool coarse_pers = pers_try && pers_fits(agg, na, Nc) && (Cp > kDense2MaxCp || dense2_off);
+    const bool coarse_mk = pers_wanted && agg == 2 * kClu && Nc <= 6144;   // multi-kernel PCG (when the persistent kernel is not usable); three Nc^2 f64 buffers: <= 0.9 GB
     unsigned* uq = nullptr; unsigned* cnts = nullptr; int* n_runs = nullptr;
     if (coarse_pers || coarse_mk) {
       const size_t nk = (size_t)Cp + nOff;
@@ -808,7 +800,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     d.max_cam_edges = hs.max_cam_edges;
     // ---- row Schur kernel: the unit table, when every row's partial sums fit the LDS beside its Y ----
     d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0; d.row_dbg = nullptr;
-    if (getenv("CCM_BA_ROW_DBG")) { long long* p_dbg = nullptr; BB_RC(keep_get(ba, 8, &p_dbg, true)); d.row_dbg = p_dbg; }
+    if (ccm_dbg("row")) { long long* p_dbg = nullptr; BB_RC(keep_get(ba, 8, &p_dbg, true)); d.row_dbg = p_dbg; }
     if (nOff > row_min_blocks() && d.max_cam_edges <= kRowMaxEdges && (uint64_t)std::max(Eloc, 1) * 144u < (1ull << 31)) {
       // LDS of a row: Y of its observations + a zero row, the diagonal partials (27 per 16 observations), 36 doubles per unit
       const size_t lds_free = 158 * 1024 - ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group)) * sizeof(double);
@@ -829,7 +821,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     // the Hpl blocks (144 bytes per observation) exist only where a kernel reads them: with the row kernel on compact records and the edge-parallel
     // landmark kernels every consumer re-derives them (32 bytes per observation in landmark-major order for the back-substitution)
     d.E4L = nullptr;
-    d.w_free = (d.E4 && d.chunk_off && d.unit_tab && nOff > row_min_blocks() && !getenv("CCM_BA_KEEP_W")) ? 1 : 0;
+    d.w_free = (d.E4 && d.chunk_off && d.unit_tab && nOff > row_min_blocks()) ? 1 : 0;
     if (d.w_free) { double* p_l = nullptr; BB_RC(keep_get(ba, 4 * (size_t)Eloc, &p_l)); d.E4L = p_l; }
     AL(W, d.w_free ? 1 : 18 * (size_t)Eloc, double) AL(Hll, 6 * (size_t)Lloc, double) AL(bl, 3 * (size_t)Lloc, double)
     AL(Dinv, 6 * (size_t)Lloc, double) AL(dl, 3 * (size_t)Lloc, double) AL(Hpp, 36 * (size_t)Cp, double) AL(bp, 6 * (size_t)Cp, double)
@@ -847,7 +839,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 8, double)
 #undef AL
     d.pcg_flag = reinterpret_cast<int*>(d.scal + 6);   // [scalars | PCG flags]: one 64-byte read-back per LM trial
-    if (hipHostMalloc(&ba->h_rb, 128, hipHostMallocDefault) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
+    if (hipHostMalloc(&ba->h_rb, 128, hipHostMallocCoherent /* polled by the host while the kernel is in flight (read_scalars_polled): fine-grained, explicitly */) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
     memset(ba->h_rb, 0, 128);
     ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
     BB_RC(keep_get(ba, ba->red_count, &ba->d_red, true));
@@ -861,13 +853,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       BB_RC(keep_get(ba, 4, &ba->d_cinfo, true));
       BB_RC(keep_get(ba, 12 * (size_t)std::max(n_units, 1), &ba->d_cparts, true));
       ba->coarse_na = na; ba->coarse_Nc = Nc; ba->coarse_ncb = hs.ncb;
-      if (const char* cr = getenv("CCM_BA_COARSE_REUSE")) ba->coarse_reuse = atoi(cr) != 0;
       if (const char* cf = getenv("CCM_BA_COARSE")) ba->coarse_force = !strcmp(cf, "always") ? 1 : !strcmp(cf, "never") ? -1 : 0;
       return CCM_OK;
     };
     // persistent single-launch PCG: usable when all workgroups (two per cluster) can be co-resident on the device and every unit's lists fit its LDS
     ba->pers_grid = 0;
-    d.mk_cpart = nullptr; d.mk_qpart = nullptr; d.mk_rc[0] = d.mk_rc[1] = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_Ainv32 = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
+    d.mk_cpart = nullptr; d.mk_cry[0] = d.mk_cry[1] = nullptr; d.mk_P = nullptr; d.mk_Ainv = nullptr; d.mk_Ainv32 = nullptr; d.mk_on = 0; d.mk_Nc = 0; d.mk_na = 0;
     if (pers_try && !hs.pers_bad) {
       BB_RC(keep_get(ba, 4 + 2 * 16 + 4 * 512, &ba->d_pers_bar, true));   // abort flag + debug clocks (workgroup 0's phases; then per workgroup the time spent in the two exchanges)
       BB_RC(keep_get(ba, 4 * (size_t)pers_grid_want, &ba->d_pers_part, true));   // [2][2][grid] slot words
@@ -883,24 +874,8 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       double *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
       BB_RC(keep_get(ba, 24 * (size_t)(na + 1), &p1, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p2, true)); BB_RC(keep_get(ba, (size_t)n_cl, &p3, true));
       d.mk_cpart = p1; d.mk_cry[0] = p2; d.mk_cry[1] = p3;
-      // (opt-in: measured on the 10 000-keyframe map, product 46 -> 53.7 us with the P^T q parts, update + coarse correction 9.9 + 12.3 + a gap -> 20.1 us in one kernel:
-      // 151.0 against 151.7 ms per call on one box — what the saved launch gives, the product's extra epilogue takes)
-      if (getenv("CCM_BA_MK_FUSED") && atoi(getenv("CCM_BA_MK_FUSED")) != 0 && !(getenv("CCM_BA_SPMV_SYM") && atoi(getenv("CCM_BA_SPMV_SYM")) != 0) && agg % 8 == 0) {
-        double *pq = nullptr, *r0 = nullptr, *r1 = nullptr;
-        BB_RC(keep_get(ba, (size_t)(2 * (agg / 8)) * 6 * (size_t)(na + 1), &pq, true)); BB_RC(keep_get(ba, 6 * (size_t)(na + 1), &r0, true)); BB_RC(keep_get(ba, 6 * (size_t)(na + 1), &r1, true));
-        d.mk_qpart = pq; d.mk_rc[0] = r0; d.mk_rc[1] = r1;
-      }
       d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv32, false)); d.mk_Ainv32 = ba->d_cAinv32;
-    }
-    d.sym_dst = nullptr; d.sym_T = nullptr;
-    // (opt-in: measured on the 10 000-keyframe map, 41.6 + 14.3 us per CG iteration for product + update against 46.5 + 9.9 with every block read twice — the scattered
-    // stores (64-byte slots; 48-byte slots: 45.1 us) and their gather in the update cost what the halved block traffic saves: 141.8 against 142.4 ms per call on one box)
-    if (!ba->pers_grid && Cp > kDense2MaxCp && nOff > 0 && getenv("CCM_BA_SPMV_SYM") && atoi(getenv("CCM_BA_SPMV_SYM")) != 0) {
-      int* p_dst = nullptr; double* p_T = nullptr;
-      BB_RC(keep_get(ba, (size_t)nOff, &p_dst)); BB_RC(keep_get(ba, 8 * (size_t)nOff, &p_T));
-      hipLaunchKernelGGL(bb_sym_dst, dim3(grid_for(Cp)), dim3(kB), 0, st, Cp, d.row_off, d.rowblk_off, d.row_blk, p_dst);
-      d.sym_dst = p_dst; d.sym_T = p_T;
     }
     BB_RC(flush_zero_list(ba));   // (no kernel above reads a buffer it asked to have zeroed)
     BB_RC(ccm_ba_state_from_raw(ba));

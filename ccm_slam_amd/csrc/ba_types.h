@@ -70,7 +70,7 @@ struct BaDev {
   const int* blk_unit0;      // [nOff+1] first unit of every block (a block's units are consecutive)
   int row_units_max;         // most units in one row (LDS partial sums); 0 = row kernel not usable
   int unit_chunk;            // pair instances per work unit (kRow2Chunk)
-  // compact form of the Hpl blocks for the row kernel (ba_schur_row3; E4 == nullptr: ba_schur_row2 reads the stored blocks instead)
+  // compact form of the Hpl blocks for the row kernel (ba_schur_row3)
   double* E4;                // [cam_off[Cp]][4] per observation of a free camera, CAMERA-MAJOR (the order of cam_edge): x, y, 1 / z of the landmark in the camera frame, w * information
   double* E4L;               // [Eloc][4] the same four numbers in LANDMARK-major order (the order of the edge arrays), written by the landmark-side linearisation;
                              // nullptr unless w_free
@@ -86,8 +86,6 @@ struct BaDev {
   const uint32_t* row_blk;   // [..] block id | transpose bit
   // symmetric product of the multi-kernel PCG (round 4; nullptr: every row reads its lower blocks transposed, ba_pcg_spmv): the row of an upper block (i, j) also forms
   // S_ij^T p_i and stores it at the block's place among row j's lower entries; ba_pcg_update adds a row's lower parts to q
-  const int* sym_dst;        // [nOff] for the off-diagonal block: low_off[j] + its rank among row j's lower entries
-  double* sym_T;             // [nOff][8]: 6 values + 2 zeros, one 64-byte line per slot
   // PCG
   double *x, *r, *z, *q, *p[2];
   float* Wc;                 // [n_clusters][96*96] explicit inverses of the damped cluster blocks, multi-kernel PCG; f32: only a preconditioner (offline: the same CG iteration counts as f64), half the 74 KB a cluster re-reads in every CG iteration
@@ -109,10 +107,6 @@ struct BaDev {
   int n_part;                // entries of part_pt written by the last chi2 kernel (n_chunk or n_wg_pt)
   // coarse level of the multi-kernel PCG (maps above 2048 free cameras)
   double* mk_cpart;          // [4][6 (na + 1)] restriction parts P^T r, node-major: slot 0 / 1 = first-node part of cluster 2n / 2n + 1, slot 2 / 3 = second-node part of cluster 2n - 2 / 2n - 1
-  // round 4: the coarse residual follows the recurrence of r (P^T r <- P^T r - alpha P^T q), so the multi-kernel PCG runs TWO kernels per iteration: ba_pcg_spmv also
-  // leaves P^T q of its 8 rows, ba_pcg_update_coarse does the update AND the coarse correction (nullptr: three kernels, ba_pcg_update + ba_pcg_coarse_apply)
-  double* mk_qpart;          // [2 agg/8][6 (na + 1)] node-major: first-node parts of the interval's agg/8 row groups, then second-node parts of the previous interval's
-  double* mk_rc[2];          // [6 (na + 1)] coarse residual P^T r by iteration parity
   double* mk_cry[2];         // [n_clusters] coarse part of r.z per cluster (first cluster of an aggregate), by iteration parity
   const double* mk_P;        // [Cp][36] prolongation blocks
   const double* mk_Ainv;     // [mk_Nc][mk_Nc] coarse inverse

@@ -2,6 +2,12 @@
 // gfx950 only: wave = 64 lanes, no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
+// (advisor, round 4) several kernels rely on gfx950 behaviour the HIP model does not promise — 64-lane waves everywhere, the raw `s_waitcnt lgkmcnt(0); s_barrier`
+// of orb_pyramid_kernel, wave-divergent loops that meet at the same number of barriers in dense_chol.hip, sc1 loads for cross-XCD coherence in ba_pcg_persist:
+// another target must be a build error, not silent corruption.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libccm_hip.so is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
 #include <stdint.h>
 #include <map>
 #include <cstring>
@@ -16,7 +22,6 @@ struct ccm_prof_slot {
   double total_ms = 0.0;
 };
 
-constexpr int kCtxTickets = 4096;
 struct ccm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -36,13 +41,14 @@ struct ccm_ctx {
   void* d_scratch = nullptr; size_t d_scratch_bytes = 0;
   void* d_io = nullptr; size_t d_io_bytes = 0;   // staging for the host-pointer entry points
   void* h_pin = nullptr; size_t h_pin_bytes = 0; // pinned host staging (one H2D / D2H per small call)
-  int* d_tickets = nullptr;                      // [kCtxTickets] arrival counters of "the last workgroup finishes the job" kernels (zero between launches: the last arrival resets its counter)
   // size-bucketed cache of device blocks released by BA handles: a local BA builds a fresh problem for every keyframe, and
   // ~45 hipMalloc + hipFree per problem cost more than the host-side structure build itself
   std::multimap<size_t, void*> pool_free; size_t pool_bytes = 0;
 };
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
+// development prints / device phase clocks: CCM_DBG = comma-separated list of topics (pers, trial, coarse, dense2, setup, row, orb, pg, poseopt) or "all"; read once
+bool ccm_dbg(const char* topic);
 
 // Bracket around the launch of a kernel that needs ALL its workgroups co-resident on the device (ba_pcg_persist: up to one workgroup per CU, grid-wide
 // exchanges inside).  The reference runs one global-BA thread per Map (cslam/src/Map.cpp:1401-1402, LoopFinder.cpp:686-688) beside LocalMapping and Tracking

@@ -5,6 +5,21 @@
 static std::mutex g_err_mu;
 static std::string g_last_err;
 
+bool ccm_dbg(const char* topic) {
+  static const std::string list = [] { const char* e = std::getenv("CCM_DBG"); return std::string(e ? e : ""); }();
+  if (list.empty()) return false;
+  if (list == "all" || list == "1") return true;
+  const std::string t(topic);
+  size_t at = 0;
+  while (at <= list.size()) {
+    size_t end = list.find(',', at);
+    if (end == std::string::npos) end = list.size();
+    if (list.compare(at, end - at, t) == 0) return true;
+    at = end + 1;
+  }
+  return false;
+}
+
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   std::lock_guard<std::mutex> lk(g_err_mu);
@@ -133,7 +148,6 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
-  if (ctx->d_tickets) hipFree(ctx->d_tickets);
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -249,7 +263,7 @@ int ccm_pin_scratch(ccm_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->h_pin_bytes) {
     if (ctx->h_pin) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
     const size_t nb = ccm_align256(bytes * 2);
-    hipError_t e = hipHostMalloc(&ctx->h_pin, nb, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&ctx->h_pin, nb, hipHostMallocCoherent);   // (the pose optimisation polls a ticket its kernel writes into this block: fine-grained, explicitly)
     if (e != hipSuccess) { ctx->h_pin_bytes = 0; return ccm_set_error(ctx, CCM_E_HIP, "pinned scratch hipHostMalloc failed"); }
     ctx->h_pin_bytes = nb;
   }

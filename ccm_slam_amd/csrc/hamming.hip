@@ -59,72 +59,8 @@ __global__ __launch_bounds__(256) void hamming_dense_partial(
   }
 }
 
-// Round 4: the merge rides in the partial kernel's launch — the LAST of a query block's n_split workgroups to arrive (one ticket per query block) combines the
-// partial results in ascending split order, exactly as hamming_dense_merge does.  Bit-identical results, but SLOWER than the two launches it replaces (see the
-// dispatch below): kept as a measured, opt-in variant.
-__global__ __launch_bounds__(256) void hamming_dense_fused(
-    const uint32_t* __restrict__ q, int Q, const uint32_t* __restrict__ t, int T, int t_per_split, int n_split,
-    int32_t* p_best_idx, int32_t* p_best, int32_t* p_second, int* __restrict__ tickets,
-    int32_t* __restrict__ best_idx, int32_t* __restrict__ best, int32_t* __restrict__ second) {
-  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-  const int split = blockIdx.y;
-  const int t0 = split * t_per_split;
-  const int t1 = min(T, t0 + t_per_split);
-  uint32_t qa[8];
-  if (qi < Q) {
-    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
-    uint4 lo = qp[0], hi = qp[1];
-    qa[0] = lo.x; qa[1] = lo.y; qa[2] = lo.z; qa[3] = lo.w;
-    qa[4] = hi.x; qa[5] = hi.y; qa[6] = hi.z; qa[7] = hi.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) qa[k] = 0;
-  }
-  int bb = 256, ss = 256, bidx = -1;
-  for (int ti = t0; ti < t1; ++ti) {       // ti is wave-uniform -> scalar loads of the target row
-    const uint32_t* tp = t + (size_t)ti * 8;
-    const int d = ham256(qa, tp);
-    if (d < bb) { ss = bb; bb = d; bidx = ti; }
-    else if (d < ss) { ss = d; }
-  }
-  if (n_split == 1) {
-    if (qi < Q) { best_idx[qi] = bidx; best[qi] = bb; second[qi] = ss; }
-    return;
-  }
-  if (qi < Q) {
-    const size_t o = (size_t)split * Q + qi;
-    __hip_atomic_store(p_best_idx + o, bidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p_best + o, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p_second + o, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __shared__ int last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(tickets + blockIdx.x, 1) == n_split - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  if (threadIdx.x == 0) tickets[blockIdx.x] = 0;   // ready for the next launch on this context (stream order)
-  if (qi >= Q) return;
-  int b = 256, s = 256, bi = -1;
-  for (int sp0 = 0; sp0 < n_split; sp0 += 8) {   // eight splits per round trip, combined in ascending target order: strict '<' keeps the first minimum
-    int pb[8], ps[8], pi[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const bool v = sp0 + u < n_split;
-      const size_t o = (size_t)(v ? sp0 + u : 0) * Q + qi;
-      pb[u] = v ? __hip_atomic_load(p_best + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 256;
-      ps[u] = v ? __hip_atomic_load(p_second + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 256;
-      pi[u] = v ? __hip_atomic_load(p_best_idx + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (pb[u] < b) { s = min(b, ps[u]); b = pb[u]; bi = pi[u]; }
-      else           { s = min(s, pb[u]); }
-    }
-  }
-  best_idx[qi] = bi; best[qi] = b; second[qi] = s;
-}
+// (round 5: the one-launch form of this search — hamming_dense_fused, the last workgroup of a query block to take a ticket merging the splits — was built and measured in
+// round 4 (29.1 us against 15.9 for partial + merge at 2000 x 2000: the device-scope fence before the ticket costs more than the launch it saves) and is gone from the library.)
 
 __global__ __launch_bounds__(256) void hamming_dense_merge(
     int Q, int n_split, const int32_t* __restrict__ p_best_idx, const int32_t* __restrict__ p_best,
@@ -390,20 +326,6 @@ extern "C" int ccm_hamming_dense_best2_dev(ccm_ctx* ctx, const uint8_t* d_q, int
   int32_t* p_idx = (int32_t*)scratch;
   int32_t* p_best = p_idx + (size_t)n_split * Q;
   int32_t* p_second = p_best + (size_t)n_split * Q;
-  // MEASURED (2000 x 2000, one box): 29.1 us for the single launch against 15.9 us for partial + merge — the device-scope fence every workgroup needs before its
-  // ticket (an L2 write-back on this part) costs more than the second launch it saves.  Opt-in only (CCM_HAMMING_FUSED=1); the two launches stay the default.
-  static const bool fused = getenv("CCM_HAMMING_FUSED") != nullptr;
-  if (qblocks <= kCtxTickets && fused) {
-    if (!ctx->d_tickets) {
-      CCM_HIP_CHECK(ctx, hipMalloc(&ctx->d_tickets, kCtxTickets * sizeof(int)));
-      CCM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_tickets, 0, kCtxTickets * sizeof(int), ctx->stream));
-    }
-    ccm_prof_scope ps(ctx, CCM_K_HAMMING_DENSE);
-    hipLaunchKernelGGL(hamming_dense_fused, dim3(qblocks, n_split), dim3(256), 0, ctx->stream, (const uint32_t*)d_q, Q, (const uint32_t*)d_t, T, t_per_split, n_split,
-                       p_idx, p_best, p_second, ctx->d_tickets, d_best_idx, d_best_dist, d_second_dist);
-    CCM_HIP_CHECK(ctx, hipGetLastError());
-    return CCM_OK;
-  }
   {
     ccm_prof_scope ps(ctx, CCM_K_HAMMING_DENSE);
     hipLaunchKernelGGL(hamming_dense_partial, dim3(qblocks, n_split), dim3(256), 0, ctx->stream,

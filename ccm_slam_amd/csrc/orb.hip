@@ -1054,7 +1054,7 @@ struct ccm_orb {
   // that frame t+1's device phase 1 runs while the host selects keypoints (DistributeOctTree) for frame t.
   struct Bufs {
     uint8_t* d_block = nullptr;   // every device buffer below is carved from this one block, with the same layout in every set (OrbFrames)
-    uint8_t *d_pyr = nullptr, *d_score = nullptr, *d_blur = nullptr;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
     uint32_t* d_cell_slots = nullptr; int* d_cell_counts = nullptr; int* d_cand = nullptr;   // d_cand: [ncells+1 offsets][records]
     KpIn* d_kin = nullptr; ccm_keypoint* d_kout = nullptr; uint8_t* d_desc = nullptr;
     int* h_cand = nullptr;   // pinned
@@ -1082,7 +1082,9 @@ struct ccm_orb {
   hipStream_t st = nullptr;        // stream the phase functions queue on (the context's, or stream2 for every other frame of a batch)
   hipStream_t stream2 = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr;   // host-octree batch path
   hipStream_t bstream[kOrbSets] = {}; hipEvent_t bev[kOrbSets] = {};   // device-octree batch path: stream / "done" event of sets 1..3
-  unsigned long long* d_oct_dbg = nullptr;   // CCM_ORB_OCT_DBG: phase clocks of the octree kernel, printed by ccm_orb_destroy
+  unsigned long long* d_oct_dbg = nullptr;   // CCM_DBG=orb: phase clocks of the octree kernel, printed by ccm_orb_destroy
+  uint8_t* d_score_dbg = nullptr;            // score map of the test hook (orb_debug_level), allocated on its first call: the extraction itself has none since round 4
+  bool last_call_read_level0_in_place = false;   // the batch API reads level 0 from the caller's frames: the pyramid buffer then holds no level 0 to score
   // last-frame debug
   std::vector<std::vector<Cand>> last_cand; bool last_cand_valid = false;
 };
@@ -1101,6 +1103,7 @@ static void orb_free_geometry(ccm_orb* o) {
   hipFree(o->d_tabs); hipFree(o->d_tile_level); hipFree(o->d_tile_xy); hipFree(o->d_pyr_tcol); hipFree(o->d_pyr_trow); hipFree(o->d_pyr_ent);
   o->d_pyr_tcol = o->d_pyr_trow = nullptr; o->d_pyr_ent = nullptr; o->pyr_fused = false;
   if (o->h_io) hipHostFree(o->h_io);
+  if (o->d_score_dbg) { hipFree(o->d_score_dbg); o->d_score_dbg = nullptr; }   // (sized for the geometry)
   o->d_tabs = nullptr; o->d_tile_level = o->d_tile_xy = nullptr; o->h_io = nullptr; o->h_io_bytes = 0;
 }
 
@@ -1194,7 +1197,7 @@ static int orb_alloc_bufs(ccm_orb* o, int k) {
   // one block per set, the same layout in every set: a launch over several frames reaches frame f's buffers by adding ONE byte offset to the pointers of the group's first set
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += ccm_align256(std::max<size_t>(bytes, 1)); return at; };
-  const size_t o_pyr = take(o->pyr_bytes), o_score = take(o->pyr_bytes), o_blur = take(o->pyr_bytes);
+  const size_t o_pyr = take(o->pyr_bytes), o_blur = take(o->pyr_bytes);
   const size_t o_slots = take(std::max<size_t>(o->cand_cap, 1) * sizeof(uint32_t)), o_counts = take(std::max<size_t>(d.ncells, 1) * sizeof(int));
   const size_t o_cand = take(((size_t)d.ncells + 1 + o->cand_cap) * sizeof(int)), o_kin = take((size_t)o->kp_cap * sizeof(KpIn));
   const size_t o_stage = take(o->oct_ok ? (size_t)o->nlevels * o->oct_stride * sizeof(KpIn) : 1), o_octc = take((size_t)(o->nlevels + 2) * sizeof(int)), o_n = take(2 * sizeof(int));
@@ -1203,7 +1206,7 @@ static int orb_alloc_bufs(ccm_orb* o, int k) {
   CCM_HIP_CHECK(ctx, hipMalloc(&b.d_block, off));
   CCM_HIP_CHECK(ctx, hipMemsetAsync(b.d_block, 0, off, ctx->stream));
   uint8_t* base = b.d_block;
-  b.d_pyr = base + o_pyr; b.d_score = base + o_score; b.d_blur = base + o_blur;
+  b.d_pyr = base + o_pyr; b.d_blur = base + o_blur;
   b.d_cell_slots = reinterpret_cast<uint32_t*>(base + o_slots); b.d_cell_counts = reinterpret_cast<int*>(base + o_counts); b.d_cand = reinterpret_cast<int*>(base + o_cand);
   b.d_kin = reinterpret_cast<KpIn*>(base + o_kin);
   if (o->oct_ok) { b.d_oct_stage = reinterpret_cast<KpIn*>(base + o_stage); b.d_oct_counts = reinterpret_cast<int*>(base + o_octc); b.d_n = reinterpret_cast<int*>(base + o_n); }
@@ -1296,13 +1299,13 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
     o->oct_stride = nmax + 64;
     o->oct_kcap = slots < budget ? (int)std::min<size_t>((budget - slots) / 7, 65000) & ~15 : 0;
     o->oct_ok = !host_oct && o->oct_kcap >= 2048 && 4 * nmax + 16 <= 2 * kOctTPB;
-    o->oct_tpb = (4 * nmax + 16 <= 1024 && !getenv("CCM_ORB_OCT_1024")) ? 512 : 1024;
+    o->oct_tpb = (4 * nmax + 16 <= 1024) ? 512 : 1024;
     if (getenv("CCM_ORB_OCT_KCAP")) o->oct_kcap = std::min(o->oct_kcap, std::max(256, atoi(getenv("CCM_ORB_OCT_KCAP"))) & ~15);   // tests: force the host fallback
     o->oct_lds = ((size_t)o->oct_kcap * 7 + 15) / 16 * 16 + slots;
     {
       int max_cells = 0;
       for (int l = 0; l < o->nlevels; l++) max_cells = std::max(max_cells, d.lv[l].nCols * d.lv[l].nRows);
-      o->oct_cells = o->oct_ok && !getenv("CCM_ORB_COMPACT") && max_cells <= 2 * o->oct_tpb && ((size_t)max_cells + 1) * sizeof(int) <= slots;
+      o->oct_cells = o->oct_ok && max_cells <= 2 * o->oct_tpb && ((size_t)max_cells + 1) * sizeof(int) <= slots;
     }
   }
   o->pyr_fused = false;
@@ -1405,8 +1408,8 @@ static int orb_prepare(ccm_orb* o, int w, int h) {
       o->pyr_fused = true;
     }
   }
-  if (getenv("CCM_ORB_OCT_DBG")) fprintf(stderr, "[ccm_orb] %d x %d, %d levels: pyramid %s\n", w, h, o->nlevels, o->pyr_fused ? "in one launch" : "one launch per level");
-  if (getenv("CCM_ORB_OCT_DBG") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 256)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 256)); }
+  if (ccm_dbg("orb")) fprintf(stderr, "[ccm_orb] %d x %d, %d levels: pyramid %s\n", w, h, o->nlevels, o->pyr_fused ? "in one launch" : "one launch per level");
+  if (ccm_dbg("orb") && !o->d_oct_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_oct_dbg, 256)); CCM_HIP_CHECK(ctx, hipMemset(o->d_oct_dbg, 0, 256)); }
   if (int rc = orb_alloc_bufs(o, 0)) return rc;
   CCM_HIP_CHECK(ctx, hipMalloc(&o->d_tabs, std::max<size_t>(tabs.size(), 2) * sizeof(int16_t)));
   if (!tabs.empty()) CCM_HIP_CHECK(ctx, hipMemcpyAsync(o->d_tabs, tabs.data(), tabs.size() * sizeof(int16_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1621,6 +1624,7 @@ extern "C" int ccm_orb_extract(ccm_orb* o, const uint8_t* img, int w, int h, int
   ccm_ctx* ctx = o->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   o->st = ctx->stream;
+  o->last_call_read_level0_in_place = false;
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
   const LevelInfo& L0 = o->dev.lv[0];
@@ -1697,6 +1701,7 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
   ccm_ctx* ctx = o->ctx;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   o->st = ctx->stream;
+  o->last_call_read_level0_in_place = true;   // (group path below; the host-octree path copies level 0 and clears the flag)
   int rc = orb_prepare(o, w, h);
   if (rc) return rc;
   if ((rc = orb_alloc_bufs(o, 1))) return rc;
@@ -1715,11 +1720,11 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
     if (!o->ev_a) CCM_HIP_CHECK(ctx, hipEventCreateWithFlags(&o->ev_a, hipEventDisableTiming));
     CCM_HIP_CHECK(ctx, hipEventRecord(o->ev_a, ctx->stream));            // whatever produced the images on the context's stream comes first
     for (int k = 1; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipStreamWaitEvent(o->bstream[k], o->ev_a, 0));
-    static const bool inplace = !(getenv("CCM_ORB_BATCH_COPY") && atoi(getenv("CCM_ORB_BATCH_COPY")));
+    const bool inplace = true;
     // groups of kOrbGroup frames, ONE launch per kernel and group (blockIdx.y = frame, OrbFrames), two groups in flight on two streams with their own buffer sets:
     // the kernels of a frame are small (8 octree workgroups, ~260 pyramid tiles), four frames per launch fill the chip four times better and cost a quarter of the launches
     // (round 4: one frame per launch on four streams 0.0345 ms per frame).  Level 0 is read IN PLACE from the caller's frames.
-    static const int group_env = getenv("CCM_ORB_BATCH_GROUP") ? std::max(1, std::min(kOrbGroup, atoi(getenv("CCM_ORB_BATCH_GROUP")))) : kOrbGroup;
+    const int group_env = kOrbGroup;
     int gi = 0;
     for (int f0 = 0; f0 < n_frames; f0 += group_env, gi++) {
       const int nf = std::min(group_env, n_frames - f0);
@@ -1757,8 +1762,9 @@ extern "C" int ccm_orb_extract_batch_dev(ccm_orb* o, const uint8_t* d_imgs, int 
     for (int k = 0; k < kOrbSets; k++) CCM_HIP_CHECK(ctx, hipMemsetAsync(o->B[k].d_n + 1, 0, sizeof(int), ctx->stream));
     CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   }
-  // the octrees of a frame's levels run on this thread + a few helpers for the duration of the call (CCM_ORB_BATCH_THREADS, default 3 helpers, 0 = none)
-  static const int n_helpers = getenv("CCM_ORB_BATCH_THREADS") ? std::max(0, std::min(7, atoi(getenv("CCM_ORB_BATCH_THREADS")))) : 3;
+  o->last_call_read_level0_in_place = false;   // (the host-octree path copies every frame's level 0 into the pyramid buffer)
+  // the octrees of a frame's levels run on this thread + three helpers for the duration of the call
+  const int n_helpers = 3;
   std::unique_ptr<LevelPool> pool;
   if (n_helpers > 0 && n_frames > 1) { pool.reset(new LevelPool()); pool->start(o, n_helpers); }
   // Two frames in flight on ONE in-order stream: iteration f queues the device phase 1 of frame f (into buffer set f & 1), then finishes
@@ -1796,9 +1802,12 @@ int ccm_internal::orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, uin
   ccm_ctx* ctx = o->ctx;
   const LevelInfo& L = o->dev.lv[level];
   if (score_out) {   // (the extraction no longer makes the score map: computed here for the caller)
+    // (advisor, round 4) after a batch call level 0 was read in place from the caller's frames and never copied into the pyramid buffer: there is nothing to score
+    if (level == 0 && o->last_call_read_level0_in_place) return ccm_set_error(ctx, CCM_E_STATE, "ccm_orb_debug_level: level 0 of the last (batch) call was read in place from the caller's frames");
+    if (!o->d_score_dbg) { CCM_HIP_CHECK(ctx, hipMalloc(&o->d_score_dbg, o->pyr_bytes)); CCM_HIP_CHECK(ctx, hipMemsetAsync(o->d_score_dbg, 0, o->pyr_bytes, ctx->stream)); }
     ccm_prof_scope ps(ctx, CCM_K_FAST_SCORE);
-    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(o->dev.maxW, 256), o->dev.totalRows), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->B[o->cur].d_score);
-    CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->B[o->cur].d_score + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(orb_fast_score_kernel, dim3(ccm_div_up(o->dev.maxW, 256), o->dev.totalRows), dim3(256), 0, ctx->stream, o->dev, o->B[o->cur].d_pyr, o->d_score_dbg);
+    CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(score_out, L.w, o->d_score_dbg + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
   }
   if (blur_out) CCM_HIP_CHECK(ctx, hipMemcpy2DAsync(blur_out, L.w, o->B[o->cur].d_blur + L.off, L.stride, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -792,7 +792,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     row_off[a + 1] = (int)row_col.size();
   }
   // ---- spanning forest for the preconditioner: Kruskal by |i - j| (local edges first), all fixed vertices = one root ----
-  const bool use_tree = F <= kPgTreeMaxF && !getenv("CCM_PG_NO_TREE");
+  const bool use_tree = F <= kPgTreeMaxF;
   std::vector<int> t_parent(F, -1), t_code(F, -1), t_order, t_pos(F, 0), t_out(F, 0), ends_off(F + 2, 0), ends_idx;
   if (use_tree) {
     std::vector<int> eo(E);
@@ -868,7 +868,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
   const bool want_exact = !(solver_env && !strcmp(solver_env, "pcg"));
   // (<= 20 000 keyframes: the symbolic step keeps dense T x T tile-pattern tables on host and device, T ~ 4000 tiles at that size, and packs tile
   // coordinates as (i << 16) | j in a signed int, i.e. T < 32768; larger graphs take the tree-preconditioned PCG path)
-  const bool use_tiles = want_exact && !(solver_env && !strcmp(solver_env, "dense")) && !getenv("CCM_PG_DENSE_FULL") && n_dense <= 140000;
+  const bool use_tiles = want_exact && !(solver_env && !strcmp(solver_env, "dense")) && n_dense <= 140000;
   const bool use_dense = want_exact && (use_tiles || n_dense <= 24000);
   double *d_A = nullptr, *d_rhs = nullptr, *d_linv = nullptr; int *d_info = nullptr, *d_blk_a = nullptr, *d_blk_b = nullptr;
   ccm_tile_plan plan;
@@ -882,7 +882,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     std::vector<std::vector<int>> adj(F);
     for (int k = 0; k < nBlk; k++) if (ka[k] != kb[k]) { adj[ka[k]].push_back(kb[k]); adj[kb[k]].push_back(ka[k]); }
     std::vector<std::vector<int>> pieces;
-    static const int nd_leaf = getenv("CCM_PG_ND_LEAF") ? atoi(getenv("CCM_PG_ND_LEAF")) : 31;   // 31 vertices = 217 unknowns = 4 tiles (2000 keyframes: leaf 31: 17.2 ms / 11 levels, 63: 18.9 / 13, 127: 23.4 / 19)
+    const int nd_leaf = 31;   // 31 vertices = 217 unknowns = 4 tiles (2000 keyframes: leaf 31: 17.2 ms / 11 levels, 63: 18.9 / 13, 127: 23.4 / 19)
     pg_nd_order(F, adj, std::max(nd_leaf, 9), &pieces);
     std::vector<int> dpos(F, 0), dsrc;
     for (auto& pc : pieces) {
@@ -899,7 +899,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
     }
     PG_RC(ccm_tsc_create(ctx, T, nz, &tsc));
     PG_RC(up(ctx, allocs, dpos, &d_dpos)); PG_RC(up(ctx, allocs, dsrc, &d_dsrc)); PG_RC(al(ctx, allocs, (size_t)N_tiles, &d_rhs));
-    if (getenv("CCM_PG_DBG")) fprintf(stderr, "[ccm_pg] tile-sparse cholesky: %d unknowns in %d pieces -> %d tiles columns, %d non-zero tiles, %d levels\n", (int)n_dense, (int)pieces.size(), T, tsc.n_tiles, tsc.n_levels);
+    if (ccm_dbg("pg")) fprintf(stderr, "[ccm_pg] tile-sparse cholesky: %d unknowns in %d pieces -> %d tiles columns, %d non-zero tiles, %d levels\n", (int)n_dense, (int)pieces.size(), T, tsc.n_tiles, tsc.n_levels);
   } else if (use_dense) {
     std::vector<int> ka(nBlk), kb(nBlk);
     for (int k = 0; k < nBlk; k++) { ka[k] = keys[k].first; kb[k] = keys[k].second; }
@@ -998,7 +998,7 @@ extern "C" int ccm_pose_graph_optimize(ccm_ctx* ctx, int n_vert, double* sim3, c
         hipMemsetAsync(d_A, 0, (size_t)N_dense * N_dense * sizeof(double), ctx->stream);
         hipLaunchKernelGGL(pg_dense_fill, dim3(ccm_div_up(std::max(nBlk * 49, N_dense), kTPB)), dim3(kTPB), 0, ctx->stream, d, d_blk_a, d_blk_b, d_A, d_rhs,
                            lambda, N_dense);
-        if ((rc = ccm_dense_chol_solve_dev(ctx, d_A, N_dense, d_rhs, d_linv, d_info, getenv("CCM_PG_DENSE_FULL") ? nullptr : &plan))) break;
+        if ((rc = ccm_dense_chol_solve_dev(ctx, d_A, N_dense, d_rhs, d_linv, d_info, &plan))) break;
         if (hipMemcpyAsync(d.x, d_rhs, n_dense * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
           rc = ccm_set_error(ctx, CCM_E_HIP, "pose graph: dense solve readback"); break;

@@ -321,7 +321,7 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   uint8_t* bytes_base = (uint8_t*)(d + nd);
   a.level = bytes_base; a.robust = bytes_base + n;
   for (int k = 0; k < 4; k++) a.K[k] = K[k];
-  static const bool dbg_env = getenv("CCM_POSEOPT_DBG") != nullptr;
+  static const bool dbg_env = ccm_dbg("poseopt");
   static long long* d_dbg = nullptr;
   a.dbg = nullptr;
   if (dbg_env) {
@@ -338,17 +338,17 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   // LDS staging: 64 B of f64 data + 3 flag bytes per edge; the 160 KiB LDS of one CU holds ~2400 edges
   const size_t staged = 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
   // the 27 sums through LDS whenever the transpose block fits beside the staged problem (up to ~1290 edges); CCM_POSEOPT_SHAPE=0: the cross-lane reduction always
-  static const bool shape0_env = getenv("CCM_POSEOPT_SHAPE") && atoi(getenv("CCM_POSEOPT_SHAPE")) == 0;
+  const bool shape0_env = false;
   const bool tr_red = !shape0_env && PoseCfg<true>::kRed * sizeof(double) + staged <= 150 * 1024;
   const size_t red_bytes = (tr_red ? PoseCfg<true>::kRed : PoseCfg<false>::kRed) * sizeof(double);
   const size_t lds_full = red_bytes + staged;
   const int use_lds = lds_full <= 150 * 1024;
   // (round 4) a problem that is staged in LDS touches its inputs once and its outputs once: the kernel reads them from / writes them to the PINNED HOST block itself (same
   // layout), which takes the two copy commands and their latency out of the call (0.147 -> ~0.13 ms for 300 edges).  CCM_POSEOPT_COPY=1: through the device block as before.
-  static const bool copy_env = getenv("CCM_POSEOPT_COPY") && atoi(getenv("CCM_POSEOPT_COPY")) != 0;
+  const bool copy_env = false;
   const bool zero_copy = use_lds && !copy_env;
   // ... and the host polls a ticket the kernel writes behind its results instead of waiting for the stream (~7 us per call; CCM_POSEOPT_POLL=0: stream wait)
-  static const bool poll_env = !(getenv("CCM_POSEOPT_POLL") && atoi(getenv("CCM_POSEOPT_POLL")) == 0);
+  const bool poll_env = true;
   static thread_local unsigned long long ticket_counter = 0;   // (a ticket only has to differ from the zero written before the launch)
   volatile unsigned long long* h_ticket = reinterpret_cast<volatile unsigned long long*>(h + n_in);
   a.h_ticket = nullptr; a.ticket = 0;
@@ -384,6 +384,7 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   if (!polled) CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  else CCM_HIP_CHECK(ctx, hipGetLastError());   // (the ticket says the kernel ran; a sticky asynchronous error is still attributed to THIS call, not to whoever synchronises next)
   if (dbg_env) {
     long long hd[8];
     CCM_HIP_CHECK(ctx, hipMemcpy(hd, d_dbg, sizeof(hd), hipMemcpyDeviceToHost));

@@ -1,4 +1,4 @@
-"""Development probe (GPU box): phase clocks of ccm_ba_create (CCM_BA_SETUP_DBG=1) on a warm handle, from HBM-resident arrays like bench.py."""
+"""Development probe (GPU box): phase clocks of ccm_ba_create (CCM_DBG=1) on a warm handle, from HBM-resident arrays like bench.py."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccm_slam_amd import optimizer, synth
