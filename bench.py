@@ -626,6 +626,16 @@ def class_api_leg(workload, prob, n_agents):
             dt = (time.perf_counter() - t0) * 1e3
             if rc == 0 and (best is None or dt < best["call_ms"]):
                 best = {"call_ms": round(dt, 2), "phases_ms": phases_of(g)}
+        # ... and once more on a map that has ALREADY been optimised through this shim: a server keeps calling MapFusionGBA on the same Map, and from the second call on
+        # the points' cv::Mat buffers belong to the write-back threads' arenas, so what the write-back frees no longer lands in the calling thread's arena — the
+        # scope-exit phase of the first call (glibc consolidating ~2 fastbin chunks per point at the caller's next large free) is a first-call effect
+        if best:
+            g = graphs[0]
+            t0 = time.perf_counter()
+            rc, _txt = _capture_stdout_fd(lambda: g.map_fusion_gba(0, 20))
+            dt = (time.perf_counter() - t0) * 1e3
+            if rc == 0:
+                best["second_call_on_the_same_map"] = {"call_ms": round(dt, 2), "phases_ms": phases_of(g)}
         for g in graphs:
             g.close()
         return best

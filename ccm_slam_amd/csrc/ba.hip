@@ -2863,10 +2863,16 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
                            (const int*)ba->d_pers_cij, (const uint32_t*)ba->d_pers_cblk);
         if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, 0);
       }
-      const int chunk = 24;
+      // The host learns that the solve has converged from the flags it reads back between chunks of queued iterations; every iteration queued beyond the converged
+      // one is three launches that return at once (~3 us each + their gaps).  Round 5: the first chunk is sized by the PREVIOUS solve of the handle (consecutive
+      // trials of a call need similar counts: 60 - 75 on the 10 000-keyframe map), the following ones are short — ~3 instead of ~12 idle iterations per solve
+      // (1680 -> ~1510 launches of each kernel for the 1440 iterations of that call).  The counts are deterministic, so every rank of a sharded run queues alike.
       const int sym_grid = 512;   // two 16-wave workgroups per CU
       int k = 0;
+      bool first_chunk = true;
       while (k < max_it) {
+        const int chunk = first_chunk ? (ba->mk_prev_iters > 0 ? std::max(8, ba->mk_prev_iters - 2) : 24) : 6;
+        first_chunk = false;
         const int kend = std::min(max_it, k + chunk);
         for (; k < kend; k++) {
           {
@@ -2884,6 +2890,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (flags[0]) break;
       }
       *pcg_iters = flags[0] ? flags[1] : k;
+      ba->mk_prev_iters = *pcg_iters;
     }
     }
     if (flags[2]) *ok = false;   // not SPD / NaN: linear solver failure (levenberg.cpp:126-127)
@@ -3046,6 +3053,7 @@ extern "C" int ccm_ba_run(ccm_ba* ba, const ccm_ba_options* opt_in, const volati
   ccm_ba_options opt{};
   if (opt_in) opt = *opt_in;
   ba->coarse_active = false;   // every run starts from the same preconditioner state
+  ba->mk_prev_iters = 0;
   ba->coarse_valid = false; ba->coarse_stale_bad = false; ba->coarse_fresh_iters = 0;
   ba->w_valid = false; ba->w_stale_bad = false; ba->w_fresh_iters = 0; ba->w_lambda_built = 0; ba->lin_id = 0; ba->w_lin_id = -1;
   ba->stop_flag = stop_flag; ba->stop_any = false;

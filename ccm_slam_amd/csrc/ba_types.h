@@ -157,6 +157,7 @@ struct ccm_ba {
   bool w_valid = false, w_loaded = false, w_stale_bad = false; double w_lambda_built = 0; int w_fresh_iters = 0, lin_id = 0, w_lin_id = -1;
   bool coarse_valid = false, coarse_fresh = false, coarse_stale_bad = false, coarse_reuse = true;
   double coarse_lambda_built = 0; int coarse_fresh_iters = 0;
+  int mk_prev_iters = 0;   // CG iterations of the handle's previous multi-kernel solve (sizes the first chunk of queued iterations of the next one)
   double dinv_done_lambda = -1.0;   // lambda for which the landmark-side linearisation already formed D^-1 (ba_dinv folded in), -1 = none
   double lambda_first = 0; bool coarse_skipped_damped = false;   // the call's first lambda; the coarse level is left out at and above it (lm_trial)
   double* h_rb = nullptr;    // pinned: [6 scalars | 4 flags] of a trial, then the ticket ba_reduce_scalars writes after them (read_scalars_polled)
