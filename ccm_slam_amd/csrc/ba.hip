@@ -786,6 +786,12 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 // form that reads every block once — upper pass 61 us, lower pass 20 us against 56 us for this kernel: the traffic was never the limit.)
 // (round 4) 66 VGPRs left ONE 16-wave workgroup per CU (7 waves per SIMD); the kernel is bound by the bytes it keeps in flight (per wave 8 blocks of 288 B behind
 // an index load), so it is held to 64 registers: two workgroups per CU.
+// (round 5) F32: the blocks come from S32, the f32 copy of S made once per trial (ba_s_to_f32): 24 instead of 48 bytes per lane and block.  The solve stays an f64 solve:
+// every kMkReplaceEvery-th iteration (and once more when the recurrence reports convergence) the residual is REPLACED by the true one, r = b - (S + lambda I) x formed with
+// the f64 blocks — XMODE: the same kernel with x as the source vector, no direction update, no dot products —, so what the rounding of S to f32 puts into the recurrence
+// never accumulates into the answer (offline, scripts/offline/precond_study.py f32: the same iteration counts and the same 8e-9 final error as the all-f64 solve with a
+// replacement every 4 or 8 iterations; without any the error stalls at 4e-7 ... 1.6e-6).  Only maps above 2048 free cameras (S32 != nullptr).
+template <bool F32, bool XMODE>
 __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void ba_pcg_spmv(BaDev d, int k) {
   __shared__ double half_sum[kRowsPerWG][2][8];
   __shared__ double lds[kRowsPerWG];
@@ -802,8 +808,8 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   // XCD-aware row assignment: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give
   // XCD x the CONTIGUOUS row chunk x: covisible cameras are close in index, hence a block S_ij and its mirror use
   // (row i and, transposed, row j) are read by the same XCD and the second read can hit that XCD's 4 MiB L2.
-  double rz_k, beta = 0;
-  {
+  double rz_k = 0, beta = 0;
+  if (!XMODE) {
     const int nco = d.mk_on ? d.n_wg_upd : 0, npr = k ? d.n_wg_upd : 0;
     const double* const ps[4] = {d.prz[k & 1], d.mk_cry[k & 1], d.prz[(k + 1) & 1], d.mk_cry[(k + 1) & 1]};
     const int ns[4] = {d.n_wg_upd, nco, npr, k ? nco : 0};
@@ -818,16 +824,19 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
       beta = rz_k / rz_prev;
     }
   }
+  if (!XMODE) {
   const double rz0 = (k == 0) ? rz_k : d.pcg_scal[0];
   // convergence test (identical in every workgroup): sqrt(rz_k / rz_0) <= rel_tol, or exact zero residual
   if (rz_k <= d.pcg_scal[1] * rz0 || !(rz_k > 0.0)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = k; if (rz_k != rz_k) d.pcg_flag[2] = 1; }
     return;
   }
+  }
   const double lambda = to_sgpr(d.pcg_scal[2]);
   beta = to_sgpr(beta);                          // (uniform values in scalar registers: the kernel is held to 64 vector registers)
   const double* pold = d.p[k & 1];
   double* pnew = d.p[(k + 1) & 1];
+  const double* zsrc = XMODE ? d.x : d.z;        // XMODE: q = (S + lambda I) x
   const int g = lane >> 3, r = lane & 7;
   // (round 4) the grid is at most two workgroups per CU; a workgroup takes several groups of 8 rows one after the other (XCD x keeps the contiguous chunk x of them): the
   // sums above are formed 512 times per launch instead of once per 8 rows, and no workgroup waits for a slot
@@ -841,19 +850,37 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     for (int s = e0 + h * 8 + g; s < e1; s += 16) {
       const int j = d.row_col[s];
       const uint32_t bt = d.row_blk[s];
-      const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
-      const double* zj = d.z + 6 * (size_t)j;
+      const double* zj = zsrc + 6 * (size_t)j;
       const double* pj = pold + 6 * (size_t)j;
       double v[6];
-      if (bt & kTransposeBit) {
+      if (F32) {
+        const float* B = d.S32 + 36 * (size_t)(bt & ~kTransposeBit);
+        if (bt & kTransposeBit) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
+          for (int c = 0; c < 6; c++) v[c] = (double)B[c * 6 + r];
+        } else {
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v2f* B2 = reinterpret_cast<const v2f*>(B + r * 6);   // rows start at multiples of 24 bytes: 8-byte aligned
+          const v2f b0 = B2[0], b1 = B2[1], b2 = B2[2];
+          v[0] = (double)b0[0]; v[1] = (double)b0[1]; v[2] = (double)b1[0]; v[3] = (double)b1[1]; v[4] = (double)b2[0]; v[5] = (double)b2[1];
+        }
+      } else {
+        const double* B = d.S + 36 * (size_t)(bt & ~kTransposeBit);
+        if (bt & kTransposeBit) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) v[c] = B[c * 6 + r];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
+        }
+      }
+      if (XMODE) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc += v[c] * zj[c];
       } else {
 #pragma unroll
-        for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
+        for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
       }
-#pragma unroll
-      for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
     }
   }
   // sum over the 8 groups (lanes with equal r): fixed xor tree
@@ -865,17 +892,17 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   double pq = 0, qv = 0;
   if (h == 0 && i < d.Cp) {
     if (lane < 6) {
-      const double pi = d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
+      const double pi = XMODE ? d.x[6 * (size_t)i + lane] : d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
       qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * pi;
       d.q[6 * (size_t)i + lane] = qv;
-      pnew[6 * (size_t)i + lane] = pi;
+      if (!XMODE) pnew[6 * (size_t)i + lane] = pi;
       pq = pi * qv;
     }
     pq = wave_sum(lane < 6 ? pq : 0.0);
     if (lane == 0) lds[rl] = pq;
   } else if (h == 0 && lane == 0) lds[rl] = 0.0;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (!XMODE && threadIdx.x == 0) {
     double tot = lds[0];
 #pragma unroll
     for (int q = 1; q < kRowsPerWG; q++) tot += lds[q];
@@ -890,6 +917,8 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // alpha = rz_k / p.q ; x += alpha p ; r -= alpha q ; z = W r (cluster-wise dense) ; partial rz_{k+1}   [CCM_K_BA_PCG_UPDATE]
 // one workgroup per cluster
+// REPLACE (round 5, f32 product): x was already advanced by ba_pcg_xupdate and q holds (S + lambda I) x formed with the f64 blocks: r = b - q instead of r -= alpha q
+template <bool REPLACE>
 __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   __shared__ double rc[kCluN];
   __shared__ double zpart[8][kCluN];
@@ -921,8 +950,8 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   }
   const double alpha = rz_k / pq;
   if (t < m) {
-    d.x[g] = xv + alpha * pv;
-    rv -= alpha * qv;
+    if (REPLACE) rv = d.bs[g] - qv;
+    else { d.x[g] = xv + alpha * pv; rv -= alpha * qv; }
     d.r[g] = rv;
     rc[t] = rv;
   } else if (t < kCluN) rc[t] = 0.0;
@@ -969,6 +998,40 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
 // (round 5: ba_pcg_update_coarse — update + coarse correction in one 512-thread workgroup per interval, the coarse residual following r's recurrence with P^T q left by the product
 // kernel — was built and measured in round 4 (151.0 against 151.7 ms per call on the 10 000-keyframe map: what the saved launch gives, the product's extra epilogue takes) and is
 // gone from the library; DESIGN 4.1 keeps the measurement.)
+
+// x += alpha p alone (round 5: the first half of an iteration that replaces its residual), alpha from the same partial sums as ba_pcg_update; one workgroup per cluster
+__global__ __launch_bounds__(kTPB) void ba_pcg_xupdate(BaDev d, int k) {
+  __shared__ double redp[3 * (kTPB / kWave)];
+  const int t = threadIdx.x, c = blockIdx.x;
+  const int s0 = c * kClu, s1 = min(d.Cp, s0 + kClu);
+  const int m = 6 * (s1 - s0);
+  const int done = d.pcg_flag[0];
+  const size_t g = 6 * (size_t)s0 + t;
+  double xv = 0, pv = 0;
+  if (t < m) { xv = d.x[g]; pv = d.p[(k + 1) & 1][g]; }
+  double rz_k, pq;
+  {
+    const double* const ps[3] = {d.prz[k & 1], d.mk_cry[k & 1], d.ppq};
+    const int ns[3] = {d.n_wg_upd, d.mk_on ? d.n_wg_upd : 0, d.n_wg_spmv};
+    double sm[3];
+    block_sum_partials<3>(ps, ns, sm, redp);
+    rz_k = sm[0];
+    if (d.mk_on) rz_k += sm[1];
+    pq = sm[2];
+  }
+  if (done || !(pq > 0.0)) return;   // (a non-positive p.q is reported by the ba_pcg_update that follows)
+  if (t < m) d.x[g] = xv + (rz_k / pq) * pv;
+}
+__global__ void ba_s_to_f32(const double* __restrict__ S, float* __restrict__ S32, size_t n4) {   // n4 = number of 4-element groups
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v2d a = reinterpret_cast<const v2d*>(S)[2 * i], b = reinterpret_cast<const v2d*>(S)[2 * i + 1];
+  v4f o; o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)b[0]; o[3] = (float)b[1];
+  reinterpret_cast<v4f*>(S32)[i] = o;
+}
+constexpr int kMkReplaceEvery = 8;   // iterations between two residual replacements of the f32 product
 
 // Coarse part of the preconditioner in the multi-kernel PCG, one workgroup per INTERVAL (two clusters) after ba_pcg_init_tiles / ba_pcg_update:
 // rc = P^T r per coarse node (the first-node parts of the node's interval's two clusters + the second-node parts of the previous interval's),
@@ -2855,6 +2918,10 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       }
       ba->coarse_used = d.mk_on != 0;
       CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 4 * sizeof(int), ctx->stream));
+      if (d.S32) {   // the f32 copy of this trial's S for the product kernel (114 -> 57 MB on the 10 000-keyframe map, once per trial)
+        const size_t n4 = 9 * (size_t)(d.Cp + d.nOff);
+        hipLaunchKernelGGL(ba_s_to_f32, dim3((unsigned)ccm_div_up((int64_t)n4, kTPB)), dim3(kTPB), 0, ctx->stream, (const double*)d.S, d.S32, n4);
+      }
       {
         const size_t lds_tiles = (size_t)(2 * kCluN * kCluN + kCluN + kPersWaves) * sizeof(double) + 16;
         CCM_LDS_ATTR(ctx, CCM_LDS_BA_TILES, ba_pcg_init_tiles, lds_tiles);
@@ -2868,7 +2935,17 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
       // trials of a call need similar counts: 60 - 75 on the 10 000-keyframe map), the following ones are short — ~3 instead of ~12 idle iterations per solve
       // (1680 -> ~1510 launches of each kernel for the 1440 iterations of that call).  The counts are deterministic, so every rank of a sharded run queues alike.
       const int sym_grid = 512;   // two 16-wave workgroups per CU
-      int k = 0;
+      const dim3 g_spmv(std::min(d.n_wg_spmv, sym_grid));
+      const size_t lds_ca = 6 * (size_t)(d.mk_na + 1) * sizeof(double);
+      const bool f32 = d.S32 != nullptr;
+      // the true residual r = b - (S + lambda I) x in place of the recurrence's (f64 blocks), followed by z = M^-1 r and its dot products: what iteration kk's update leaves
+      auto replace_residual = [&](int kk) {
+        { ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV); hipLaunchKernelGGL((ba_pcg_spmv<false, true>), g_spmv, dim3(kSpmvTPB), 0, ctx->stream, d, kk); }
+        ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
+        hipLaunchKernelGGL(ba_pcg_update<true>, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, kk);
+        if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), lds_ca, ctx->stream, d, (kk + 1) & 1);
+      };
+      int k = 0, verified_at = -1;
       bool first_chunk = true;
       while (k < max_it) {
         const int chunk = first_chunk ? (ba->mk_prev_iters > 0 ? std::max(8, ba->mk_prev_iters - 2) : 24) : 6;
@@ -2877,17 +2954,35 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         for (; k < kend; k++) {
           {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_SPMV);
-            hipLaunchKernelGGL(ba_pcg_spmv, dim3(std::min(d.n_wg_spmv, sym_grid)), dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            if (f32) hipLaunchKernelGGL((ba_pcg_spmv<true, false>), g_spmv, dim3(kSpmvTPB), 0, ctx->stream, d, k);
+            else hipLaunchKernelGGL((ba_pcg_spmv<false, false>), g_spmv, dim3(kSpmvTPB), 0, ctx->stream, d, k);
           }
-          {
+          if (f32 && (k + 1) % kMkReplaceEvery == 0) {
+            { ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE); hipLaunchKernelGGL(ba_pcg_xupdate, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k); }
+            replace_residual(k);
+          } else {
             ccm_prof_scope ps(ctx, CCM_K_BA_PCG_UPDATE);
-            hipLaunchKernelGGL(ba_pcg_update, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
-            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), 6 * (size_t)(d.mk_na + 1) * sizeof(double), ctx->stream, d, (k + 1) & 1);
+            hipLaunchKernelGGL(ba_pcg_update<false>, dim3(d.n_wg_upd), dim3(kTPB), 0, ctx->stream, d, k);
+            if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), lds_ca, ctx->stream, d, (k + 1) & 1);
           }
         }
         CCM_HIP_CHECK(ctx, hipMemcpyAsync(flags, d.pcg_flag, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (flags[0]) break;
+        if (flags[0]) {
+          // f32 product: the recurrence says "converged at iteration N" (the launches queued behind that test returned at once, so x = x_N).  Unless r_N is a replaced
+          // residual already, form the true one and put the question again: the test at the top of iteration N then speaks about b - (S + lambda I) x_N itself.
+          const int N = flags[1];
+          if (f32 && !flags[2] && N > 0 && N % kMkReplaceEvery != 0 && verified_at != N) {
+            verified_at = N;
+            CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 2 * sizeof(int), ctx->stream));
+            replace_residual(N - 1);
+            k = N;
+            first_chunk = false;
+            flags[0] = 0;
+            continue;
+          }
+          break;
+        }
       }
       *pcg_iters = flags[0] ? flags[1] : k;
       ba->mk_prev_iters = *pcg_iters;

@@ -58,6 +58,7 @@ struct BaDev {
   // reduced system (contiguous: all-reduced in one call)
   double* S;                 // [(Cp+nOff)*36] diagonal blocks first
   double* bs;                // [Cp*6]
+  float* S32;                // [(Cp + nOff) * 36] f32 copy of S for the product kernel of the multi-kernel PCG (maps above 2048 free cameras; nullptr otherwise), remade every trial
   const int* inst_off;       // [nOff+1]
   const int* inst_a;         // edge with the block-row camera
   const int* inst_c;         // edge with the block-col camera

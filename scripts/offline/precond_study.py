@@ -5,6 +5,7 @@ DESIGN.md section 4.1 ("Candidates the round's measurements leave for the next o
   python scripts/offline/precond_study.py ns    [kfs_per_agent]   spectral radius of I - Ac_new Ac_old^-1 (Newton-Schulz refresh of the coarse inverse)
   python scripts/offline/precond_study.py defl  [kfs_per_agent]   previous LM steps / exact slow modes as extra coarse columns; spectrum of M^-1 A
   python scripts/offline/precond_study.py adef  [kfs_per_agent]   additive two-level (the product) vs A-DEF2 / A-DEF1 hybrids
+  python scripts/offline/precond_study.py f32   [kfs_per_agent]   S rounded to f32 inside the product, f64 residual replacement every R iterations
 
 The preconditioner is the product's: 16-camera cluster-Jacobi + one rigid-body twist per node, nodes every 16 cameras, hat-function interpolation, prolongation by Ad(T_cw)."""
 import os
@@ -132,6 +133,33 @@ elif what == "defl":
         e = L @ V[:, :k]
         Wk, Qk = levels(H, np.concatenate([P, e / np.linalg.norm(e, axis=0)], 1)); Mk = lambda r: Wk(r) + Qk(r)
         print(f"   {k} exact slowest modes deflated: {pcg(H, b, Mk, np.zeros(n), 1e-8 * np.sqrt(b @ Mk(b)))[1]} iterations (hats only: {n0})", flush=True)
+elif what == "f32":
+    # S as f32 inside the product, f64 residual replacement every R iterations (round 5 costing of VERDICT r4 item 3): iterations and final error against the f64 solve
+    def pcg_f32(A, A32, b, M, target, R, cap=2000):
+        x = np.zeros_like(b); r = b.copy(); z = M(r); p = z.copy(); rz = r @ z; it = 0
+        while np.sqrt(abs(rz)) > target and it < cap:
+            q = A32 @ p; al = rz / (p @ q); x += al * p
+            it += 1
+            if R and it % R == 0: r = b - A @ x          # the true residual, one f64 product
+            else: r -= al * q
+            z = M(r); rzn = r @ z; p = z + (rzn / rz) * p; rz = rzn
+        return x, it
+    p, cam = state(3)
+    for mult in (1.0, 10.0, 100.0, 1e4):
+        lam = LAM0 * mult
+        H, b = system(p, lam)
+        D = H - lam * np.eye(len(b))
+        H32 = D.astype(np.float32).astype(np.float64) + lam * np.eye(len(b))     # the kernel adds lambda p in f64 beside the f32 blocks
+        W, Q = levels(H, Pmat(cam, H.shape[0])); M = lambda r, W=W, Q=Q: W(r) + Q(r)
+        tgt = 1e-8 * np.sqrt(b @ M(b))
+        xe = np.linalg.solve(H, b)
+        x64, it64 = pcg(H, b, M, np.zeros_like(b), tgt)
+        row = [f"lambda {lam:.3g}: f64 {it64} it (err {np.linalg.norm(x64 - xe) / np.linalg.norm(xe):.1e})"]
+        for R in (0, 4, 8, 16):
+            x, it = pcg_f32(H, H32, b, M, tgt, R)
+            true_res = b - H @ x
+            row.append(f"R={R}: {it} it, err {np.linalg.norm(x - xe) / np.linalg.norm(xe):.1e}, true |r|_M/|b|_M {np.sqrt(true_res @ M(true_res)) / np.sqrt(b @ M(b)):.1e}")
+        print(" | ".join(row), flush=True)
 else:
     for it, mult in ((0, 1.0), (3, 1 / 27.0), (5, 1 / 243.0), (5, 1.0), (5, 30.0)):
         p, cam = state(it); lam = LAM0 * mult
@@ -145,3 +173,4 @@ else:
         x2, k2 = pcg(H, b, Mdef2, Q(b), tgt, 500)
         x1, k1 = pcg(H, b, Mdef1, np.zeros(n), tgt, 500)
         print(f"state {it}, lambda {lam:.3g}: additive {ka}, A-DEF2 {k2}, A-DEF1 {k1} iterations; |x_def2 - x_add| / |x| = {np.linalg.norm(x2 - xa) / np.linalg.norm(xa):.1e}", flush=True)
+
