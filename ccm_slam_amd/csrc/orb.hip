@@ -434,6 +434,19 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(OrbDev d, const uint8_t* 
                 d.lv[0].poff, d.lv[0].pstride);
 }
 
+// the blur tiles of a GROUP of frames (batch API; frame = blockIdx.y) with the tile's own 5 KB of LDS.  Round 4 let the blur tiles of a frame ride in the octree kernel's
+// launch, whose workgroups all ask for a whole CU's LDS (one plan size per launch): right for ONE frame — 8 octree workgroups leave the chip idle —, but a group of
+// four frames brought ~600 blur workgroups that could only run one per CU: 128 us per group against 36 for a single frame.  Groups launch this kernel and an
+// octree kernel without blur workgroups instead (round 5).
+__global__ __launch_bounds__(256) void orb_blur_frames_kernel(OrbDev d, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                              const int* __restrict__ tile_level, const int* __restrict__ tile_xy, OrbFrames fr) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kBlurLds];
+  const int fy = blockIdx.y;
+  const long long sh_ = fr.set[fy];
+  orb_blur_tile(d, orb_shift(pyr, sh_), orb_shift(blur, sh_), true, tile_level[blockIdx.x], tile_xy[2 * blockIdx.x], tile_xy[2 * blockIdx.x + 1], threadIdx.x, lds,
+                reinterpret_cast<uint16_t*>(lds + ((kBlurInBytes + 1) & ~1)), fr.poff0[fy], fr.pstride0);
+}
+
 // ---- orientation + descriptor: one wave per keypoint -----------------------------------------------
 struct KpIn { int16_t x, y; int16_t level; int16_t response; };
 
@@ -1597,10 +1610,15 @@ static int orb_phase2_dev(ccm_orb* o, int out_cap, ccm_keypoint* kout = nullptr,
   a.kin = b.d_kin; a.n_out = b.d_n; a.kp_cap = std::min(o->kp_cap, out_cap);
   a.dbg = o->d_oct_dbg;
   a.cell_slots = o->oct_cells ? b.d_cell_slots : nullptr; a.cell_counts = o->oct_cells ? b.d_cell_counts : nullptr;
-  a.pyr = b.d_pyr; a.blur = b.d_blur; a.tile_level = o->d_tile_level; a.tile_xy = o->d_tile_xy; a.n_blur_tiles = o->n_blur_tiles;
+  const bool split_blur = fr.n > 1 && o->n_blur_tiles > 0;   // a group of frames: the blur tiles get their own launch (see orb_blur_frames_kernel)
+  a.pyr = b.d_pyr; a.blur = b.d_blur; a.tile_level = o->d_tile_level; a.tile_xy = o->d_tile_xy; a.n_blur_tiles = split_blur ? 0 : o->n_blur_tiles;
+  if (split_blur) {
+    ccm_prof_scope ps(ctx, CCM_K_BLUR, o->st);
+    hipLaunchKernelGGL(orb_blur_frames_kernel, dim3(o->n_blur_tiles, fr.n), dim3(256), 0, o->st, o->dev, b.d_pyr, b.d_blur, o->d_tile_level, o->d_tile_xy, fr);
+  }
   {
     ccm_prof_scope ps(ctx, CCM_K_FAST_NMS, o->st);
-    const int blur_wgs = ccm_div_up(o->n_blur_tiles, o->oct_tpb / 256);
+    const int blur_wgs = split_blur ? 0 : ccm_div_up(o->n_blur_tiles, o->oct_tpb / 256);
     if (o->oct_tpb == 512) {   // two list slots per thread: 512 threads hold up to 4 N + 16 = 1024 slots, and a barrier of 8 waves is cheaper than one of 16
       CCM_LDS_ATTR(ctx, CCM_LDS_ORB_OCT, orb_octree_kernel<512>, 152 * 1024);
       hipLaunchKernelGGL(orb_octree_kernel<512>, dim3((o->nlevels + blur_wgs) * fr.n), dim3(512), o->oct_lds, o->st, o->dev, a, fr);
