@@ -415,7 +415,15 @@ def tracking_leg(ctx, with_cpu, n_frames=32):
     assert np.array_equal(ppo.cam, ref_pose[0]) and np.array_equal(ppo.outlier[:ppo.n], ref_pose[1]) and ppo.n_inlier == ref_pose[2]
     t_pose = _best_of(ppo.run, 20)
     total = t_orb + t_frame + t_m2 + t_fr + t_m1 + 3 * t_pose
-    out = {"tracked_fps_per_agent": round(1.0 / total, 1), "orb_extract_ms": round(t_orb * 1e3, 4),
+    # (advisor, round 4) the same stages through the plain Python wrappers — arguments converted and outputs allocated on every call, what the figure meant up to r04j — so that the
+    # rounds stay comparable: the difference is harness (numpy / ctypes), not library
+    def _wrap_frame():
+        fg.set_keypoints(kps, desc)
+    w_orb = sorted(_best_of(lambda im=im: ex(im), 1, batches=1) for im in imgs[:16])[8]
+    w_total = (w_orb + _best_of(_wrap_frame, 10) + _best_of(lambda: fg.window_search(*q2), 10) + _best_of(lambda: frame.is_in_frustum(ctx, frame24, 8, P, nrm, dmin, dmax), 10)
+               + _best_of(lambda: fg.window_search(*q1), 10) + 3 * _best_of(lambda: optimizer.pose_optimization(ctx, p["cam_qt"], p["Xw"], p["obs"], p["info"], p["K"]), 10))
+    out = {"tracked_fps_per_agent": round(1.0 / total, 1), "methodology": "prepared call objects: one C-ABI call per stage, arguments converted once (since r04k)",
+           "tracked_fps_per_agent_through_python_wrappers": round(1.0 / w_total, 1), "orb_extract_ms": round(t_orb * 1e3, 4),
            "orb_fps_per_agent": round(1.0 / t_orb, 1), "frame_undistort_grid_ms": round(t_frame * 1e3, 4),
            "search_last_frame_ms": round(t_m2 * 1e3, 4), "frustum_cull_ms": round(t_fr * 1e3, 4),
            "search_local_points_ms": round(t_m1 * 1e3, 4), "pose_opt_ms": round(t_pose * 1e3, 4), "features": int(T),
