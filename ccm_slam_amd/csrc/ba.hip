@@ -1295,11 +1295,13 @@ __global__ void ba_coarse_sum(const double* stage, const unsigned* cb_key, int n
 // A barrier gives up after a bounded spin (abort flag -> solver failure -> LM rejects the step) so a scheduling
 // accident can never hang the device.  Cooperative launch guarantees co-residency; the host uses this path when
 // the cluster count fits (<= 4096 free cameras on 256 CUs), the multi-kernel path otherwise.
-// One spin = two dependent device-coherent loads (~0.8 us measured inside a solve) + the sleep: ~50-100 ms per exchange at worst.  Round 5: was 3 000 000 (seconds —
-// two contexts of one process that launched at the same time each held part of the chip for that long before giving up).  With the per-device lease
-// (ccm_coresident_scope) two such kernels never meet; what a launch can still wait for is another context's ORDINARY kernels to leave the CUs its last
-// workgroups need, i.e. single kernel durations (<= a few ms).
-constexpr long kPersMaxSpins = 60000;
+// One spin = two dependent device-coherent loads (~0.8 us measured inside a solve) + the sleep: ~8 ms per exchange at worst.  Round 5: was 3 000 000 (seconds — two
+// contexts of one process that launched at the same time each held part of the chip for that long before giving up).  With the per-device lease
+// (ccm_coresident_scope) two such kernels never meet; what a launch can still wait for is another context's ORDINARY kernels to leave the CUs its last workgroups need,
+// i.e. single kernel durations (<= a few ms).  Under a CONTINUOUS foreign load — scripts/gpu_soak_concurrency.py: three global BAs, two local BAs, an ORB batch stream and
+// a pose loop at once — the dispatcher does not promise that a whole CU ever falls free for the last workgroups (one launch in 14 681 waited in vain, 60 000 spins =
+// ~60 ms, at the first setting of this round): the bound is what such a launch costs before its trial is repeated on the multi-kernel solver, hence short.
+constexpr long kPersMaxSpins = 8000;
 constexpr int kPersCooldownTrials = 8;   // LM trials a single-rank handle spends on the multi-kernel solver after a persistent launch gave up, before it tries again
 
 struct PersArgs {
