@@ -777,7 +777,9 @@ __device__ __forceinline__ void mk_restrict(const BaDev& d, int c, int s0, int m
 
 // (the start kernel of this path, ba_pcg_init_tiles, is defined after the cluster factorisation it shares with the persistent kernel)
 
-// iteration k: p_k = z_k + beta_k p_{k-1} (computed on the fly), q = A p_k, partial p.q   [CCM_K_BA_PCG_SPMV]
+// iteration k: q_k = A z_k + beta_k q_{k-1}, p_k = z_k + beta_k p_{k-1}, partial p.q   [CCM_K_BA_PCG_SPMV]
+// (round 5: until then q = A (z + beta p) with the direction formed on the fly for every neighbour block — two gathered vectors, nine load requests per lane and block of which
+// three were the block; A p_k = A z_k + beta A p_{k-1} is the same vector and needs ONE gathered vector and two row-local recurrences.)
 // TWO waves per block row: the row product is a chain of dependent loads (index -> block -> vector), so splitting a row's blocks over two
 // waves halves that chain; each wave keeps 8 blocks in flight (lane = g*8 + r: group g takes every 16th block starting at its own offset,
 // r is the block row).  Workgroup = 16 waves = 8 rows: measured on the 10 000-keyframe map (rocprofv3), a launch costs ~10 us of dependent
@@ -847,12 +849,9 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   double acc = 0;
   if (i < d.Cp && r < 6) {
     const int e0 = d.row_off[i], e1 = d.row_off[i + 1];
-    for (int s = e0 + h * 8 + g; s < e1; s += 16) {
-      const int j = d.row_col[s];
-      const uint32_t bt = d.row_blk[s];
-      const double* zj = zsrc + 6 * (size_t)j;
-      const double* pj = pold + 6 * (size_t)j;
-      double v[6];
+    // two blocks of the group per trip, both index pairs loaded before either block: the chain index -> block / vector is walked once for the two (round 5; a row of ~40
+    // blocks gives a group two or three of them).  The sums are taken in the old order.
+    auto block_row = [&](uint32_t bt, double v[6]) {
       if (F32) {
         const float* B = d.S32 + 36 * (size_t)(bt & ~kTransposeBit);
         if (bt & kTransposeBit) {
@@ -874,12 +873,22 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
           for (int c = 0; c < 6; c++) v[c] = B[r * 6 + c];
         }
       }
-      if (XMODE) {
+    };
+    for (int s = e0 + h * 8 + g; s < e1; s += 32) {
+      const bool two = s + 16 < e1;
+      const int sb = two ? s + 16 : s;
+      const int ja = d.row_col[s], jb = d.row_col[sb];
+      const uint32_t bta = d.row_blk[s], btb = d.row_blk[sb];
+      double va[6], vb[6], za[6], zb[6];
+      block_row(bta, va);
+      block_row(btb, vb);
 #pragma unroll
-        for (int c = 0; c < 6; c++) acc += v[c] * zj[c];
-      } else {
+      for (int c = 0; c < 6; c++) { za[c] = zsrc[6 * (size_t)ja + c]; zb[c] = zsrc[6 * (size_t)jb + c]; }
 #pragma unroll
-        for (int c = 0; c < 6; c++) acc += v[c] * (zj[c] + beta * pj[c]);
+      for (int c = 0; c < 6; c++) acc += va[c] * za[c];
+      if (two) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc += vb[c] * zb[c];
       }
     }
   }
@@ -892,11 +901,18 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
   double pq = 0, qv = 0;
   if (h == 0 && i < d.Cp) {
     if (lane < 6) {
-      const double pi = XMODE ? d.x[6 * (size_t)i + lane] : d.z[6 * (size_t)i + lane] + beta * pold[6 * (size_t)i + lane];
-      qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * pi;
-      d.q[6 * (size_t)i + lane] = qv;
-      if (!XMODE) pnew[6 * (size_t)i + lane] = pi;
-      pq = pi * qv;
+      const size_t gi = 6 * (size_t)i + lane;
+      const double src_i = XMODE ? d.x[gi] : d.z[gi];
+      qv = (half_sum[rl][0][lane] + half_sum[rl][1][lane]) + lambda * src_i;
+      if (XMODE) d.qx[gi] = qv;
+      else {
+        // q_k = (S + lambda I) z_k + beta q_{k-1}, p_k = z_k + beta p_{k-1}: row-local (first iteration of a solve: beta = 0 and neither old vector is read)
+        double pi = src_i;
+        if (k) { qv += beta * d.q[gi]; pi += beta * pold[gi]; }
+        d.q[gi] = qv;
+        pnew[gi] = pi;
+        pq = pi * qv;
+      }
     }
     pq = wave_sum(lane < 6 ? pq : 0.0);
     if (lane == 0) lds[rl] = pq;
@@ -931,7 +947,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_update(BaDev d, int k) {
   const double* p = d.p[(k + 1) & 1];
   const size_t g = 6 * (size_t)s0 + t;
   double xv = 0, rv = 0, qv = 0, pv = 0;
-  if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = d.q[g]; pv = p[g]; }
+  if (t < m) { xv = d.x[g]; rv = d.r[g]; qv = REPLACE ? d.qx[g] : d.q[g]; pv = p[g]; }
   __shared__ double redp[3 * (kTPB / kWave)];
   double rz_k, pq;
   {

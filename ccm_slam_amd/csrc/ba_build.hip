@@ -877,11 +877,14 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       d.mk_P = ba->d_cP; d.mk_Ainv = ba->d_cAinv; d.mk_Nc = Nc; d.mk_na = na;
       BB_RC(keep_get(ba, (size_t)Nc * Nc, &ba->d_cAinv32, false)); d.mk_Ainv32 = ba->d_cAinv32;
     }
-    d.S32 = nullptr;
+    d.S32 = nullptr; d.qx = nullptr;
     if (!ba->pers_grid && pers_wanted && pers_grid_want > 4 * kWave) {   // the maps that are too large for the persistent kernel (not its fallback on smaller ones)
       float* p32 = nullptr;
       BB_RC(keep_get(ba, 36 * (size_t)(Cp + nOff), &p32, false));
       d.S32 = p32;
+      double* pqx = nullptr;
+      BB_RC(keep_get(ba, 6 * (size_t)Cp, &pqx, false));
+      d.qx = pqx;
     }
     BB_RC(flush_zero_list(ba));   // (no kernel above reads a buffer it asked to have zeroed)
     BB_RC(ccm_ba_state_from_raw(ba));

@@ -58,6 +58,7 @@ struct BaDev {
   // reduced system (contiguous: all-reduced in one call)
   double* S;                 // [(Cp+nOff)*36] diagonal blocks first
   double* bs;                // [Cp*6]
+  double* qx;                // [6 Cp] (S + lambda I) x of a residual replacement (q itself follows a recurrence across iterations and must survive it); allocated with S32
   float* S32;                // [(Cp + nOff) * 36] f32 copy of S for the product kernel of the multi-kernel PCG (maps above 2048 free cameras; nullptr otherwise), remade every trial
   const int* inst_off;       // [nOff+1]
   const int* inst_a;         // edge with the block-row camera
