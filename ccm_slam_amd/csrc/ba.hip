@@ -2589,7 +2589,7 @@ extern "C" void ccm_ba_destroy(ccm_ba* ba) {
   if (!ba) return;
   if (ba->ctx) { hipSetDevice(ba->ctx->device); hipStreamSynchronize(ba->ctx->stream); }
   for (auto& pr : ba->allocs) ccm_pool_put(ba->ctx, pr.first, pr.second);
-  if (ba->h_rb) hipHostFree(ba->h_rb);
+  if (ba->h_rb) { if (ba->ctx) ba->ctx->rb_free.push_back(ba->h_rb); else hipHostFree(ba->h_rb); }   // (the stream is drained: no kernel still writes its ticket there)
   delete ba;
 }
 

@@ -643,6 +643,23 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     BB_HIP(hipGetLastError());
     d.pt_off = p_pt_off; d.ed_cam = p_ed_cam; d.ed_cslot = p_ed_cslot; d.ed_pt = p_ed_pt; d.obs = p_obs; d.info = p_info;
     d.cam_off = p_cam_off; d.cam_edge = p_cam_edge; d.cam_pt = p_cam_pt;
+    // ---- the greedy landmark chunks (host: a sequential scan over the prefix sums read back above) — here, behind the launches of the camera lists, so that the
+    // ~0.2 ms of the scan on a 150 000-landmark map pass while the device works (round 5: it ran at the end of the build, with the device idle) ----
+    std::vector<int> chunk(1, 0);
+    bool chunk_fits = true;
+    for (int l = 0; l < Lloc && chunk_fits; l++) {   // chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
+      const int o1 = h_pt_off[lb + l + 1] - eb;
+      if (o1 - (h_pt_off[lb + l] - eb) > kTPB) chunk_fits = false;
+      else if (o1 - (h_pt_off[lb + chunk.back()] - eb) > kTPB || l + 1 - chunk.back() > kTPB) chunk.push_back(l);
+    }
+    d.chunk_off = nullptr; d.n_chunk = 0;
+    if (chunk_fits && Lloc) {
+      chunk.push_back(Lloc);
+      int* p_ch = nullptr;
+      BB_RC(keep_get(ba, chunk.size(), &p_ch));
+      BB_HIP(hipMemcpyAsync(p_ch, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, st));   // (`chunk`, a pageable host vector, outlives the build's last synchronisation)
+      d.chunk_off = p_ch; d.n_chunk = (int)chunk.size() - 1;
+    }
     lap("local arrays + camera lists");
     // ---- global off-diagonal block structure + own pair instances (ba_structure.hip) ----
     uint32_t* d_U = nullptr; int nOff = 0;
@@ -777,26 +794,10 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       hipLaunchKernelGGL(bb_coarse_ab, dim3(grid_for((int64_t)max_runs)), dim3(kB), 0, st, (const unsigned*)uq, (const int*)n_runs, na, ba->d_cb_ab, sz);
     }
     BB_HIP(hipGetLastError());
-    // ---- sizes (second read-back) + the greedy landmark chunks (host: a sequential scan over the prefix sums read back above) ----
+    // ---- sizes (second read-back) ----
     BB_HIP(hipMemcpyAsync(&hs, sz, sizeof(hs), hipMemcpyDeviceToHost, st));
-    d.chunk_off = nullptr; d.n_chunk = 0;
-    std::vector<int> chunk(1, 0);
-    bool chunk_fits = true;
-    for (int l = 0; l < Lloc && chunk_fits; l++) {   // chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
-      const int o1 = h_pt_off[lb + l + 1] - eb;
-      if (o1 - (h_pt_off[lb + l] - eb) > kTPB) chunk_fits = false;
-      else if (o1 - (h_pt_off[lb + chunk.back()] - eb) > kTPB || l + 1 - chunk.back() > kTPB) chunk.push_back(l);
-    }
     BB_HIP(hipStreamSynchronize(st));
     lap("rows, lists, unit offsets");
-    if (chunk_fits && Lloc) {
-      chunk.push_back(Lloc);
-      int* p_ch = nullptr;
-      BB_RC(keep_get(ba, chunk.size(), &p_ch));
-      BB_HIP(hipMemcpyAsync(p_ch, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      BB_HIP(hipStreamSynchronize(st));   // `chunk` is a pageable host vector
-      d.chunk_off = p_ch; d.n_chunk = (int)chunk.size() - 1;
-    }
     d.max_cam_edges = hs.max_cam_edges;
     // ---- row Schur kernel: the unit table, when every row's partial sums fit the LDS beside its Y ----
     d.unit_tab = nullptr; d.row_unit_off = nullptr; d.blk_unit0 = nullptr; d.row_units_max = 0; d.row_dbg = nullptr;
@@ -839,8 +840,9 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     AL(part_pt, 2 * (size_t)std::max(d.n_wg_pt, d.n_chunk), double) AL(part_cam, d.n_wg_cam, double) AL(scal, 8, double)
 #undef AL
     d.pcg_flag = reinterpret_cast<int*>(d.scal + 6);   // [scalars | PCG flags]: one 64-byte read-back per LM trial
-    if (hipHostMalloc(&ba->h_rb, 128, hipHostMallocCoherent /* polled by the host while the kernel is in flight (read_scalars_polled): fine-grained, explicitly */) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
-    memset(ba->h_rb, 0, 128);
+    if (!ctx->rb_free.empty()) { ba->h_rb = static_cast<double*>(ctx->rb_free.back()); ctx->rb_free.pop_back(); }
+    else if (hipHostMalloc(&ba->h_rb, 128, hipHostMallocCoherent /* polled by the host while the kernel is in flight (read_scalars_polled): fine-grained, explicitly */) != hipSuccess) return ccm_set_error(ctx, CCM_E_HIP, "ccm_ba_create: pinned read-back buffer");
+    memset(ba->h_rb, 0, 128);   // (a block that served another handle holds that handle's last ticket)
     ba->red_count = 36 * (size_t)(Cp + nOff) + 6 * (size_t)Cp;
     BB_RC(keep_get(ba, ba->red_count, &ba->d_red, true));
     d.S = ba->d_red; d.bs = ba->d_red + 36 * (size_t)(Cp + nOff);

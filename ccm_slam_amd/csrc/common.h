@@ -44,6 +44,8 @@ struct ccm_ctx {
   // size-bucketed cache of device blocks released by BA handles: a local BA builds a fresh problem for every keyframe, and
   // ~45 hipMalloc + hipFree per problem cost more than the host-side structure build itself
   std::multimap<size_t, void*> pool_free; size_t pool_bytes = 0;
+  // 128-byte pinned (coherent) read-back blocks of BA handles, kept across handles: a hipHostMalloc + hipHostFree pair per local BA is two driver calls of tens of microseconds
+  std::vector<void*> rb_free;
 };
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);

@@ -148,6 +148,8 @@ extern "C" void ccm_ctx_destroy(ccm_ctx* ctx) {
   if (ctx->d_scratch) hipFree(ctx->d_scratch);
   if (ctx->d_io) hipFree(ctx->d_io);
   if (ctx->h_pin) hipHostFree(ctx->h_pin);
+  for (void* b : ctx->rb_free) hipHostFree(b);
+  ctx->rb_free.clear();
   for (auto& kv : ctx->pool_free) hipFree(kv.second);
   hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -10,8 +10,9 @@ for f in ab_libs/libccm_hip_*.so; do
   python bench.py --gba-only --steps 20 --warmup 3 --workload $W 2>/dev/null | python -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('ms_per_step', d['ms_per_step'], [ (k['kernel'], k['avg_us']) for k in d.get('kernels',[])[:2]])"
+        d=json.loads(l); print('ms_per_step', d['ms_per_step'], 'create', d['config'].get('create_ms'), 'run', d['config'].get('run_ms'))"
   python scripts/lba_profile.py lba_50 2>&1 | tail -1
+  python scripts/lba_profile.py lba_c2 2>&1 | tail -1
 done
 done
 cp /tmp/cur.so ccm_slam_amd/libccm_hip.so
