@@ -519,6 +519,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
   hipStream_t st = ctx->stream;
   int rc_build = CCM_OK;
   {
+  std::vector<int> chunk(1, 0);   // landmark chunks: uploaded asynchronously from this pageable vector, so it must outlive ~Tmp (which drains the stream) on every path
   Tmp tmp{ctx, {}};
   auto body = [&]() -> int {
     BaDev& d = ba->d;
@@ -645,7 +646,6 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     d.cam_off = p_cam_off; d.cam_edge = p_cam_edge; d.cam_pt = p_cam_pt;
     // ---- the greedy landmark chunks (host: a sequential scan over the prefix sums read back above) — here, behind the launches of the camera lists, so that the
     // ~0.2 ms of the scan on a 150 000-landmark map pass while the device works (round 5: it ran at the end of the build, with the device idle) ----
-    std::vector<int> chunk(1, 0);
     bool chunk_fits = true;
     for (int l = 0; l < Lloc && chunk_fits; l++) {   // chunks of consecutive landmarks with <= kTPB landmarks and <= kTPB observations
       const int o1 = h_pt_off[lb + l + 1] - eb;
@@ -657,7 +657,7 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
       chunk.push_back(Lloc);
       int* p_ch = nullptr;
       BB_RC(keep_get(ba, chunk.size(), &p_ch));
-      BB_HIP(hipMemcpyAsync(p_ch, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, st));   // (`chunk`, a pageable host vector, outlives the build's last synchronisation)
+      BB_HIP(hipMemcpyAsync(p_ch, chunk.data(), chunk.size() * sizeof(int), hipMemcpyHostToDevice, st));   // (`chunk` outlives the stream's drain)
       d.chunk_off = p_ch; d.n_chunk = (int)chunk.size() - 1;
     }
     lap("local arrays + camera lists");
