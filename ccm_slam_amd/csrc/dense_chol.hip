@@ -417,27 +417,34 @@ __device__ __forceinline__ void load_strip_t(double* dst, const double* src, int
   for (int q = 0; q < NB * 16 / kTPB; q++) { const int e = threadIdx.x + q * kTPB; dst[(e % 16) * LD + e / 16] = v[q]; }
 }
 
-// X = L^-1 (lower triangular, tiles in X's lower triangle): workgroup (j, s) owns the 16-column strip s of block column j and
-// walks down it, X_jj = Li_jj, X_ij = -Li_ii * sum_{k=j}^{i-1} L_ik X_kj   (every X_kj it needs is its own earlier
-// output).  The walk is a chain of dependent 64x64 products (20 for the first column of a 6-tile matrix); the strips
-// divide the MFMA work of each link by four.
-__global__ __launch_bounds__(kTPB) void chol_tri_inverse(const double* A, int N, const double* Linv_all, double* X) {
+// X = L^-1 (lower triangular, tiles in X's lower triangle), X_jj = Li_jj, X_ij = -Li_ii * sum_{k=j}^{i-1} L_ik X_kj, one launch per tile ROW (round 5).  Until then one
+// workgroup per column strip walked down its column (chol_tri_inverse): T - j - 1 links of i - j dependent 64 x 64 products each — 435 products in a row for the first
+// column of a 30-tile operator (the 10 000-keyframe map: 717 us), 66 for 12 tiles (116 us; now 11 launches of 5.2 us + the diagonal copy = 63 us, and ~230 us for 30 tiles).
+// Launch k holds every product that has row k of X as its right factor: workgroup (i, j, strip), i > k >= j, adds L_ik X_kj to the sum of X_ij (kept in X_ij's own
+// storage; the first term, k = j, writes), and the workgroups of row i = k + 1 — whose sum is complete with this term — finish it, X_ij = -Li_ii * sum.  The terms enter
+// every sum in the column walk's order through the same accumulator chain, so X has the same bits; the chain is T - 1 launches of one or two products.
+__global__ __launch_bounds__(kTPB) void chol_tri_diag(int N, const double* Linv_all, double* X) {   // X_jj = Li_jj
+  const int j = blockIdx.x;
+  for (int e = threadIdx.x; e < NB * NB; e += kTPB) X[((size_t)j * NB + e / NB) * N + (size_t)j * NB + e % NB] = Linv_all[(size_t)j * NB * NB + e];
+}
+__global__ __launch_bounds__(kTPB) void chol_tri_step(const double* A, int N, const double* Linv_all, double* X, int k) {
   __shared__ double As[NB * LD], Bs[16 * LD];
-  const int j = blockIdx.x, c0 = 16 * blockIdx.y, T = N / NB;
+  const int nj = k + 1;
+  const int i = k + 1 + (int)blockIdx.x / nj, j = (int)blockIdx.x % nj, c0 = 16 * blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i16 = lane & 15, kq = lane >> 4;
-  for (int e = threadIdx.x; e < NB * 16; e += kTPB) { const int r = e / 16, c = e % 16; X[((size_t)j * NB + r) * N + (size_t)j * NB + c0 + c] = Linv_all[(size_t)j * NB * NB + r * NB + c0 + c]; }
-  __threadfence_block();
+  double* Xij = X + ((size_t)i * NB) * N + (size_t)j * NB + c0;
+  v4d acc = {0, 0, 0, 0};
+  if (j != k) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = Xij[(size_t)(16 * wave + kq + 4 * r) * N + i16];
+  }
+  load_tile(As, A + ((size_t)i * NB) * N + (size_t)k * NB, N);                        // L_ik
+  load_strip_t(Bs, X + ((size_t)k * NB) * N + (size_t)j * NB + c0, N);                // strip of X_kj, transposed
   __syncthreads();
-  for (int i = j + 1; i < T; i++) {
-    v4d acc = {0, 0, 0, 0};
-    for (int k = j; k < i; k++) {
-      load_tile(As, A + ((size_t)i * NB) * N + (size_t)k * NB, N);                        // L_ik
-      load_strip_t(Bs, X + ((size_t)k * NB) * N + (size_t)j * NB + c0, N);                // strip of X_kj, transposed
-      __syncthreads();
-      tile_abt16(As, Bs, acc, wave, lane);
-      __syncthreads();
-    }
+  tile_abt16(As, Bs, acc, wave, lane);
+  __syncthreads();
+  if (i == k + 1) {
     // Bs <- acc^T (so that Li_ii * acc = As * Bs^T), As <- Li_ii
 #pragma unroll
     for (int r = 0; r < 4; r++) Bs[i16 * LD + 16 * wave + kq + 4 * r] = acc[r];
@@ -446,9 +453,10 @@ __global__ __launch_bounds__(kTPB) void chol_tri_inverse(const double* A, int N,
     v4d out = {0, 0, 0, 0};
     tile_abt16(As, Bs, out, wave, lane);
 #pragma unroll
-    for (int r = 0; r < 4; r++) X[((size_t)i * NB + 16 * wave + kq + 4 * r) * N + (size_t)j * NB + c0 + i16] = -out[r];
-    __threadfence_block();
-    __syncthreads();
+    for (int r = 0; r < 4; r++) Xij[(size_t)(16 * wave + kq + 4 * r) * N + i16] = -out[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; r++) Xij[(size_t)(16 * wave + kq + 4 * r) * N + i16] = acc[r];
   }
 }
 
@@ -735,7 +743,9 @@ int ccm_dense_chol_inverse_dev(ccm_ctx* ctx, double* d_A, int N, double* d_linv,
       hipLaunchKernelGGL(chol_update, dim3(rem * (rem + 1) / 2), dim3(kTPB), 0, ctx->stream, d_A, N, j, (const int*)nullptr);
     }
   }
-  hipLaunchKernelGGL(chol_tri_inverse, dim3(T, NB / 16), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X);
+  hipLaunchKernelGGL(chol_tri_diag, dim3(T), dim3(kTPB), 0, ctx->stream, N, (const double*)d_linv, d_X);
+  for (int k = 0; k + 1 < T; k++)
+    hipLaunchKernelGGL(chol_tri_step, dim3((T - k - 1) * (k + 1), NB / 16), dim3(kTPB), 0, ctx->stream, (const double*)d_A, N, (const double*)d_linv, d_X, k);
   hipLaunchKernelGGL(chol_xtx, dim3(T * (T + 1) / 2, NB / 16), dim3(kTPB), 0, ctx->stream, (const double*)d_X, N, d_Ainv);
   CCM_HIP_CHECK(ctx, hipGetLastError());
   return CCM_OK;
