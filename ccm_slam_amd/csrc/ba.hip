@@ -2964,10 +2964,13 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
         if (d.mk_on) hipLaunchKernelGGL(ba_pcg_coarse_apply, dim3(d.mk_na), dim3(kTPB), lds_ca, ctx->stream, d, (kk + 1) & 1);
       };
       int k = 0, verified_at = -1;
-      bool first_chunk = true;
+      // (second half of round 5) the first chunk reaches two iterations BEYOND the previous solve's count — an iteration queued in vain is three launches that return at
+      // once (~8 us), a chunk that stops short is a read-back with the device idle (~40 us) plus most of the next chunk in vain —, and the question that follows a
+      // verification (below) is ONE iteration, not a chunk: 13.5 -> ~7 iterations queued in vain per solve on the 10 000-keyframe map.
+      bool first_chunk = true, after_verify = false;
       while (k < max_it) {
-        const int chunk = first_chunk ? (ba->mk_prev_iters > 0 ? std::max(8, ba->mk_prev_iters - 2) : 24) : 6;
-        first_chunk = false;
+        const int chunk = first_chunk ? (ba->mk_prev_iters > 0 ? std::max(8, ba->mk_prev_iters + 2) : 24) : after_verify ? 1 : 6;
+        first_chunk = false; after_verify = false;
         const int kend = std::min(max_it, k + chunk);
         for (; k < kend; k++) {
           {
@@ -2995,7 +2998,7 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
             CCM_HIP_CHECK(ctx, hipMemsetAsync(d.pcg_flag, 0, 2 * sizeof(int), ctx->stream));
             replace_residual(N - 1);
             k = N;
-            first_chunk = false;
+            after_verify = true;
             flags[0] = 0;
             continue;
           }
