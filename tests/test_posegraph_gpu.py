@@ -168,7 +168,7 @@ def test_dense_cholesky_reports_a_non_positive_pivot(ctx):
     assert info == 41
 
 
-@pytest.mark.parametrize("n", [30, 64, 200, 375, 756])
+@pytest.mark.parametrize("n", [30, 64, 65, 200, 375, 756, 1878])   # 1878 = the coarse operator of the 10 000-keyframe map: 30 tile rows
 def test_dense_inverse_tiles(ctx, n):
     rng = np.random.default_rng(n)
     M = rng.normal(size=(n, n))
