@@ -727,6 +727,11 @@ def main():
     args = ap.parse_args()
     if args.gba_only:
         args.no_cpu_baseline = True
+    # stdout carries the ONE JSON line and nothing else: whatever native code prints to file descriptor 1 meanwhile (the reference's own Map.cpp greets every map it
+    # constructs: "+++++ Map 0 Initialized +++++", Map.cpp:67, in the class-API leg on the real classes) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch  # device sync + torch.distributed plumbing only
@@ -773,8 +778,8 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, {"rank": rank})   # the per-agent figures of an N-rank run travel this way (extra.agents)
         import hashlib
-        print(json.dumps({"plumbing": "ok", "rank": rank, "world": world, "local_rank": local_rank, "id_sha": hashlib.sha256(idb).hexdigest()[:16], "max": float(tt.item()),
-                          "gathered_ranks": sorted(g["rank"] for g in gathered)}), flush=True)
+        os.write(json_fd, (json.dumps({"plumbing": "ok", "rank": rank, "world": world, "local_rank": local_rank, "id_sha": hashlib.sha256(idb).hexdigest()[:16], "max": float(tt.item()),
+                                       "gathered_ranks": sorted(g["rank"] for g in gathered)}) + "\n").encode())
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -1026,7 +1031,8 @@ def main():
             out["speedup_vs_cpu_port_per_trial"] = round(port["ms_per_trial"] / trial_ms, 1)
             if cpu.get("kind") == "reference":
                 out["speedup_vs_reference_per_iteration"] = round(cpu["ms_per_iter"] / (elapsed * 1e3 / max(iters, 1)), 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     res.close()
     if dist is not None:
         dist.barrier()   # rank 0 is still busy with the tracking leg / JSON while the others arrive here
