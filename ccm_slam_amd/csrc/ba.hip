@@ -1097,26 +1097,16 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
     __shared__ double yred[12][kTPB / kWave];
     double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float* ar = d.mk_Ainv32 + (size_t)(6 * agg) * d.mk_Nc;   // f32 copy (round 4): the 12 rows are re-read by every interval in every CG iteration
-    for (int base = t; base < nca; base += 4 * kTPB) {   // 4 x 12 loads in flight per thread, accumulated in the plain loop's order
-      float w[4][12]; double rv[4];
+    // one column of the twelve rows per trip (12 loads in flight per thread), accumulated in the plain loop's order.  Measured on one box, loads queued per thread and trip
+    // (round 5, 10 000-keyframe map): 96 -> 20.6 us per launch, 48 (rounds 3 - 4) -> 12.6, 36 -> 12.2, 24 -> 11.9, 12 -> 11.3: the queue of a deeper batch delays the
+    // loads the other waves of the CU are waiting for
+    for (int jj = t; jj < nca; jj += kTPB) {
+      float w[12];
+      const double rv = rcs[jj];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int jj = base + k * kTPB;
-        rv[k] = 0.0;
+      for (int rr = 0; rr < 12; rr++) w[rr] = ar[(size_t)rr * d.mk_Nc + jj];
 #pragma unroll
-        for (int rr = 0; rr < 12; rr++) w[k][rr] = 0.f;
-        if (jj < nca) {
-          rv[k] = rcs[jj];
-#pragma unroll
-          for (int rr = 0; rr < 12; rr++) w[k][rr] = ar[(size_t)rr * d.mk_Nc + jj];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (base + k * kTPB < nca) {
-#pragma unroll
-          for (int rr = 0; rr < 12; rr++) a12[rr] += (double)w[k][rr] * rv[k];
-        }
+      for (int rr = 0; rr < 12; rr++) a12[rr] += (double)w[rr] * rv;
     }
 #pragma unroll
     for (int rr = 0; rr < 12; rr++) { const double w = wave_sum(a12[rr]); if (lane == 0) yred[rr][wv] = w; }
