@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(kTPB) void ba_pcg_coarse_apply(BaDev d, int par) {
   }
   __syncthreads();
   {
-    // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows with its loads in flight together, then wave
+    // y = Ac^-1[12 rows of the interval's two nodes] rc: every thread takes a strided slice of all rows, one column of the twelve per trip, then wave
     // trees and the four wave sums in order.
     __shared__ double yred[12][kTPB / kWave];
     double a12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
