@@ -47,7 +47,7 @@ class BAStats(C.Structure):
 K = {name: i for i, name in enumerate([
     "HAMMING_DENSE", "HAMMING_CSR", "PYR_RESIZE", "FAST_SCORE", "FAST_NMS", "ORIENT", "BLUR", "BRIEF",
     "BA_LINEARIZE", "BA_CAM", "BA_DINV", "BA_SCHUR_DIAG", "BA_SCHUR_OFF", "BA_PCG_SPMV", "BA_PCG_UPDATE",
-    "BA_BACKSUB", "BA_UPDATE", "BA_CHI2", "POSEOPT", "SIM3OPT", "BA_PCG_PERSIST", "BA_COARSE", "BA_REDUCE"])}
+    "BA_BACKSUB", "BA_UPDATE", "BA_CHI2", "POSEOPT", "SIM3OPT", "BA_PCG_PERSIST", "BA_COARSE", "BA_REDUCE", "BA_ALLREDUCE"])}
 
 
 def build(force: bool = False) -> str:

@@ -2535,10 +2535,14 @@ static int launch_schur(ccm_ba* ba) {
 // rank alone would wait for its peers forever).
 static inline int ba_allreduce_sum(ccm_ba* ba, double* buf, size_t n) {
   if (ba->nranks <= 1 && ba->ctx->comm_nranks > 1) return CCM_OK;
+  if (ba->nranks <= 1 && !ba->ctx->comm && !ba->ctx->loop_group) return CCM_OK;   // no communicator: nothing is issued (and nothing is timed)
+  ccm_prof_scope ps(ba->ctx, CCM_K_BA_ALLREDUCE);
   return ccm_allreduce_f64(ba->ctx, buf, n);
 }
 static inline int ba_allreduce_max(ccm_ba* ba, double* buf, size_t n) {
   if (ba->nranks <= 1 && ba->ctx->comm_nranks > 1) return CCM_OK;
+  if (ba->nranks <= 1 && !ba->ctx->comm && !ba->ctx->loop_group) return CCM_OK;   // no communicator: nothing is issued (and nothing is timed)
+  ccm_prof_scope ps(ba->ctx, CCM_K_BA_ALLREDUCE);
   return ccm_allreduce_max_f64(ba->ctx, buf, n);
 }
 

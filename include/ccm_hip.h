@@ -71,15 +71,16 @@ int ccm_memcpy_d2h(ccm_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
  * bracketed by hipEventRecord on the launching stream; ccm_prof_read drains the events and
  * returns launches and summed milliseconds since the last ccm_prof_reset.               */
 /* Classes, not kernels.  ORB: CCM_K_PYR_RESIZE = orb_pyramid_kernel (all levels of a frame in one launch), CCM_K_FAST_NMS = orb_cells_kernel (per 30-px cell:
- * FAST-9/16 score, 3x3 NMS, the minThFAST retry) AND orb_octree_kernel (DistributeOctTree on the device; the 7x7 blur tiles ride in its launch, so
- * CCM_K_BLUR counts only the host-octree path), CCM_K_BRIEF = orientation + steered descriptors (one kernel; CCM_K_ORIENT is unused), CCM_K_FAST_SCORE =
+ * FAST-9/16 score, 3x3 NMS, the minThFAST retry) AND orb_octree_kernel (DistributeOctTree on the device; in the single-frame call the 7x7 blur tiles ride in
+ * its launch), CCM_K_BLUR = orb_blur_frames_kernel of the grouped batch path and orb_blur_kernel of the host-octree path, CCM_K_BRIEF = orientation + steered descriptors (one kernel; CCM_K_ORIENT is unused), CCM_K_FAST_SCORE =
  * the score map of the test hook only. */
 enum {
   CCM_K_HAMMING_DENSE = 0, CCM_K_HAMMING_CSR, CCM_K_PYR_RESIZE, CCM_K_FAST_SCORE, CCM_K_FAST_NMS,
   CCM_K_ORIENT, CCM_K_BLUR, CCM_K_BRIEF, CCM_K_BA_LINEARIZE, CCM_K_BA_CAM, CCM_K_BA_DINV,
   CCM_K_BA_SCHUR_DIAG, CCM_K_BA_SCHUR_OFF, CCM_K_BA_PCG_SPMV, CCM_K_BA_PCG_UPDATE,
   CCM_K_BA_BACKSUB, CCM_K_BA_UPDATE, CCM_K_BA_CHI2, CCM_K_POSEOPT, CCM_K_SIM3OPT, CCM_K_BA_PCG_PERSIST,
-  CCM_K_BA_COARSE /* coarse operator + dense inverse of the two-level preconditioner */, CCM_K_BA_REDUCE /* trial scalars */, CCM_K_COUNT
+  CCM_K_BA_COARSE /* coarse operator + dense inverse of the two-level preconditioner */, CCM_K_BA_REDUCE /* trial scalars */,
+  CCM_K_BA_ALLREDUCE /* the collectives of a sharded handle (RCCL all-reduce of [S | b_schur], of the trial scalars, of lambda_0's max): queue wait + wire time on the stream */, CCM_K_COUNT
 };
 int ccm_prof_enable(ccm_ctx* ctx, int kernel_class /* -1: all, -2: none */);
 int ccm_prof_reset(ccm_ctx* ctx);
