@@ -1797,6 +1797,327 @@ __global__ __launch_bounds__(kPersTPB) void ba_solve_dense2(BaDev d, double lamb
   if (t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = 1; d.pcg_flag[2] = ibuf[1]; d.pcg_flag[3] = 0; }
 }
 
+// ---- reduced systems of 17..50 free cameras (the reference's configured local-BA window, conf/config.yaml:78): EXACT Cholesky solve in ONE workgroup with the matrix in
+// the CU's REGISTER FILE (round 6) --------------------------------------------------------------------------------------------------------------------------------
+// A window's reduced camera system is dense (every keyframe of the window sees the others' points) and small: 300 x 300 for 50 free cameras.  Its lower triangle is
+// 361 KB in f64 — more than the 160 KB of LDS that limited ba_solve_dense2 to two 96 x 96 blocks, but less than the CU's 512 KB of vector registers.  So the trailing
+// matrix lives in registers as 16 x 16 tiles in the accumulator layout of v_mfma_f64_16x16x4 (4 doubles = 8 registers per lane and tile): 8 waves x 24 tiles = 192 tiles
+// = the 190 lower tiles of a 19 x 19 tile matrix (n <= 304).  Right-looking tile Cholesky, one step per tile column T:
+//   (1) the owners of column T's tiles park them in an LDS panel buffer (row = matrix row below the diagonal, 16 columns; double-buffered, so a step costs two barriers),
+//   (2) diagonal tile and panel in ONE instruction stream (as pers_factor_dense): lanes 0..15 of every wave factor the diagonal tile redundantly, lanes 16..63 carry 48
+//       rows below it with the multipliers arriving by v_readlane — and the right-hand side rides along as one more panel row, which makes y = L^-1 b the forward substitution's result for free,
+//   (3) every wave brings ITS tiles (I, J > T) up to date: four f64 MFMAs per tile, operands from the panel buffer, accumulators never leave the registers; the owners of column T's tiles
+//       take the finished L tiles back into the (now dead) accumulators for the backward pass.
+// Backward substitution L^T x = y row by row from the bottom: 16 lanes solve the diagonal tile (saved in LDS), the owners of row I's tiles subtract L_IJ^T x_I from y_J.
+// Replaces the persistent PCG for 33..50 free cameras (a 1.9 x step in the cost of an LM trial between 32 and 33 cameras) and ba_solve_dense2 below that;
+// g2o solves these windows directly as well (LinearSolverEigen on a dense pattern, Optimizer.cpp:371-375 / linear_solver_eigen.h:106-136).
+// broadcast of one lane's double, register class left to the compiler (a scalar-register pair can be the multiplier of v_fma_f64 directly)
+__device__ __forceinline__ double cr_bcast(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// 1 / sqrt(x) for a pivot x > 0 of a damped SPD block (no denormal scaling, no special cases): v_rsq_f64's estimate (relative error d ~ 2^-23 or better) and ONE step of
+// cubic convergence, y (1 + e/2 + 3 e^2 / 8) with e = 1 - x y^2 (error ~ d^3): four dependent operations on the pivot path instead of the six of two Newton steps
+__device__ __forceinline__ double cr_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
+constexpr int kCRWaves = 8, kCRTPB = kCRWaves * kWave, kCRSlots = 24, kCRMaxNT = 19, kCRStride = 18 /* doubles per panel row: 144 B, 16-byte aligned, spreads the lanes' rows over the banks */;
+constexpr int kCRRows = 16 * kCRMaxNT + 16;          // panel rows incl. the right-hand side's
+static inline size_t cholreg_lds_bytes() {
+  return (size_t)(2 * kCRRows * kCRStride + kCRMaxNT * 256 + 4 * kCRRows) * sizeof(double) + 4 * sizeof(int) + 16 * sizeof(long long);
+}
+
+// Where every lane of ba_solve_cholreg finds its four entries of every tile: the element's offset into S (in doubles; bit 30: a diagonal entry, lambda is added),
+// -1: a structural zero, -2: unit diagonal of a padding row.  Depends on the block structure only, so it is built once per handle (first trial) — the solve then starts
+// with one coalesced 16-byte load per lane and tile instead of three dependent round trips (row offsets -> CSR entries -> LDS table -> S).
+constexpr int kCRDiagBit = 1 << 30;
+__global__ __launch_bounds__(kCRTPB) void ba_cholreg_table(BaDev d, int* table /* [8][24][64][4] */) {
+  __shared__ int idx[(kCholRegMaxCp + 1) * (kCholRegMaxCp + 1)];
+  __shared__ int roff[kCholRegMaxCp + 2];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave, i16 = lane & 15, kq = lane >> 4;
+  const int Cp = d.Cp, n = 6 * Cp, NT = (n + 15) / 16, ntiles = NT * (NT + 1) / 2;
+  if (t <= Cp) roff[t] = d.row_off[t];
+  for (int e = t; e < Cp * Cp; e += kCRTPB) idx[e] = -1;
+  __syncthreads();
+  const int ne = roff[Cp];
+  for (int sidx = t; sidx < ne; sidx += kCRTPB) {      // camera pair -> S block, from the block-CSR rows (both triangles are listed; lower entries carry the transpose bit)
+    int i = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) if (i + step < Cp && roff[i + step] <= sidx) i += step;
+    idx[i * Cp + d.row_col[sidx]] = (int)d.row_blk[sidx];
+  }
+  __syncthreads();
+  for (int s = 0; s < kCRSlots; s++) {
+    const int rho = kCRWaves * s + wave;
+    int o[4] = {-1, -1, -1, -1};
+    if (rho < ntiles) {
+      int m = (int)((sqrtf(8.0f * (float)rho + 1.0f) - 1.0f) * 0.5f);
+      while (m * (m + 1) / 2 > rho) m--;
+      while ((m + 1) * (m + 2) / 2 <= rho) m++;
+      const int J = NT - 1 - m, I = J + (rho - m * (m + 1) / 2);
+      const int col = 16 * J + i16, cj = col / 6, c6 = col % 6;
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * I + kq + 4 * r;
+        if (row < n && col < n) {
+          const int ci = row / 6, r6 = row % 6;
+          const int bt = idx[ci * Cp + cj];
+          if (bt != -1) o[r] = (36 * (int)((uint32_t)bt & ~kTransposeBit) + (((uint32_t)bt & kTransposeBit) ? c6 * 6 + r6 : r6 * 6 + c6)) | (row == col ? kCRDiagBit : 0);
+        } else if (row == col) o[r] = -2;
+      }
+    }
+    reinterpret_cast<int4*>(table)[(wave * kCRSlots + s) * kWave + lane] = make_int4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambda, double* gL /* [n_pad][n_pad] scratch: the factor's rows below the diagonal tiles, written once and read once */, const int* table,
+                                                             long long* dbg /* nullable: [8] phase clocks (10 ns ticks) + launches */, int cur, int add_lambda_term) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  typedef double v4d __attribute__((ext_vector_type(4)));
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  double* Pbuf = sm;                                   // [2][kCRRows][kCRStride]
+  double* Dg = Pbuf + 2 * kCRRows * kCRStride;         // [NT][16][16] factored diagonal tiles (row-major, lower)
+  double* invd = Dg + kCRMaxNT * 256;                  // [n_pad] 1 / L_cc
+  double* yv = invd + kCRRows;                         // [n_pad] y = L^-1 b, then the backward pass's running right-hand side
+  double* bv = yv + kCRRows;                           // [n_pad] right-hand side, updated tile column by tile column
+  double* xv = bv + kCRRows;                           // [n_pad] solution
+  int* ibuf = reinterpret_cast<int*>(xv + kCRRows);    // [4]
+  const int t = threadIdx.x, lane = t & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(t / kWave);
+  const int i16 = lane & 15, kq = lane >> 4;
+  const int Cp = d.Cp, n = 6 * Cp, NT = (n + 15) / 16, n_pad = 16 * NT, ntiles = NT * (NT + 1) / 2;
+  long long tprev = (dbg && t == 0) ? wall_clock64() : 0;
+#define CR_TICK(slot) { if (dbg && t == 0) { const long long tn_ = wall_clock64(); dbg[slot] += tn_ - tprev; tprev = tn_; } }
+  if (t < 4) ibuf[t] = 0;
+  // Tiles are RANKED column by column from the last column to the first (inside a column from the diagonal down) and dealt to the waves round-robin: the tile of rank
+  // rho belongs to wave rho % 8, slot rho / 8.  The tiles that step T still has to update (column > T) are then exactly the ranks below R(T) = (NT-T-1)(NT-T)/2 — a
+  // PREFIX of every wave's slots, the same length (+-1) in every wave at every step — and column T's own tiles are the NT - T ranks that follow.
+  int tvec = 0xffff;                                     // lane s: (I << 8 | J) of this wave's slot s; read with v_readlane where a slot needs it
+  if (lane < kCRSlots) {
+    const int rho = kCRWaves * lane + wave;
+    int m = (int)((sqrtf(8.0f * (float)rho + 1.0f) - 1.0f) * 0.5f);      // columns after this tile's column
+    while (m * (m + 1) / 2 > rho) m--;
+    while ((m + 1) * (m + 2) / 2 <= rho) m++;
+    const int J = NT - 1 - m, I = J + (rho - m * (m + 1) / 2);
+    if (rho < ntiles) tvec = (I << 8) | J;
+  }
+#define CR_TIJ(s) __builtin_amdgcn_readlane(tvec, (s))
+  // ---- MINUS the damped system into the accumulators (the update is then acc += L_I L_J^T with the operands as they lie in LDS); padding rows beyond n: unit diagonal.
+  // Every lane fetches its own four entries of every tile straight from the S blocks through the handle's offset table (ba_cholreg_table): one coalesced 16-byte load per
+  // tile, then ~96 independent loads per lane, all in flight together, no staging pass and no barrier (a staged form — all threads fill a dense area with coalesced reads, the
+  // waves then pick their tiles — took 33 us in three barrier-separated passes: the latency of three rounds of loads, not their bytes) ----
+  v4d acc[kCRSlots];
+  {
+    const int4* tab = reinterpret_cast<const int4*>(table) + (size_t)wave * kCRSlots * kWave + lane;
+#pragma unroll
+    for (int s = 0; s < kCRSlots; s++) {
+      const int4 o4 = tab[s * kWave];
+      const int o[4] = {o4.x, o4.y, o4.z, o4.w};
+      v4d a4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        double v = 0.0;
+        if (o[r] >= 0) { v = d.S[o[r] & (kCRDiagBit - 1)]; if (o[r] & kCRDiagBit) v += lambda; }
+        else if (o[r] == -2) v = 1.0;
+        a4[r] = -v;
+      }
+      acc[s] = a4;
+    }
+  }
+  for (int e = t; e < n_pad + 16; e += kCRTPB) { bv[e] = (e < n) ? d.bs[e] : 0.0; yv[e] = 0.0; xv[e] = 0.0; }
+  CR_TICK(0)
+  // ---- right-looking tile Cholesky ----
+  // column 0 -> panel buffer 0 (row 0..15: diagonal tile, then the rows below, then the right-hand side's chunk); from then on step T parks column T + 1 as it updates it
+  {
+    const int R_0 = (NT - 1) * NT / 2;
+#pragma unroll
+    for (int s = 0; s < kCRSlots; s++) {
+      const int rho = kCRWaves * s + wave;
+      if (rho >= R_0 && rho < R_0 + NT) {
+        const int rb = 16 * (rho - R_0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Pbuf[(rb + kq + 4 * r) * kCRStride + i16] = -acc[s][r];
+      }
+    }
+    if (t < 16) Pbuf[n_pad * kCRStride + t] = bv[t];
+  }
+  for (int T = 0; T < NT; T++) {
+    double* P = Pbuf + (T & 1) * (kCRRows * kCRStride);
+    double* Pn = Pbuf + ((T + 1) & 1) * (kCRRows * kCRStride);
+    const int rows_below = n_pad - 16 * (T + 1);
+    const int R_T = (NT - T - 1) * (NT - T) / 2;             // ranks [0, R_T): columns > T (this step's trailing update); [R_T, R_T + NT - T): column T, diagonal tile first
+    const int R_n = (NT - T - 2) * (NT - T - 1) / 2;         // ranks [R_n, R_T): column T + 1
+    __syncthreads();
+    CR_TICK(4)
+    // (2) diagonal tile + panel (+ right-hand side) in one instruction stream
+    if (wave == 0 || 48 * wave <= rows_below) {
+      const bool is_panel = lane >= 16;
+      const int pr = 48 * wave + (lane - 16);              // panel row of lanes 16..63 (pr == rows_below: the right-hand side)
+      const int rowi = is_panel ? 16 + min(pr, rows_below) : lane;
+      double row[16];
+      {
+        const v2d* p2 = reinterpret_cast<const v2d*>(P + rowi * kCRStride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const v2d v = p2[k]; row[2 * k] = v[0]; row[2 * k + 1] = v[1]; }
+      }
+      bool bad = false;
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        double s0 = row[c], s1 = 0.0;                      // the dot product as two interleaved chains (it sits on the pivot path)
+#pragma unroll
+        for (int k = 0; k < c; k++) { if (k & 1) s1 = fma(-row[k], cr_bcast(row[k], c), s1); else s0 = fma(-row[k], cr_bcast(row[k], c), s0); }
+        const double sv = s0 + s1;
+        double dd = cr_bcast(sv, c);
+        if (!(dd > 0.0)) { bad = true; dd = 1.0; }
+        const double inv = cr_rsqrt(dd);                   // (uniform: every lane computes it from the broadcast pivot)
+        row[c] = sv * inv;                                 // diagonal lane c: sv == dd, so this is L_cc = dd * inv; lanes above the diagonal hold unused values
+        if (wave == 0 && lane == 0) invd[16 * T + c] = inv;
+      }
+      if (wave == 0 && bad && lane == 0) ibuf[1] = 1;
+      if (!is_panel) {
+        if (wave == 0) {
+#pragma unroll
+          for (int k = 0; k < 16; k++) Dg[T * 256 + lane * 16 + k] = (k <= lane) ? row[k] : 0.0;
+        }
+      } else if (pr < rows_below) {
+        v2d* p2 = reinterpret_cast<v2d*>(P + rowi * kCRStride);
+        v2d* g2 = reinterpret_cast<v2d*>(gL + (size_t)(16 * (T + 1) + pr) * n_pad + 16 * T);   // for the backward pass (the registers of column T's tiles are NOT rewritten here:
+#pragma unroll                                                                                  // a conditional write of an accumulator inside the step loop costs copies and spills)
+        for (int k = 0; k < 8; k++) { v2d v; v[0] = row[2 * k]; v[1] = row[2 * k + 1]; p2[k] = v; g2[k] = v; }
+      } else if (pr == rows_below) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) yv[16 * T + k] = row[k];
+      }
+    }
+    __syncthreads();
+    CR_TICK(5)
+    // (3) right-hand side; trailing update of this wave's tiles (a prefix of its slots), column T + 1 parked for the next step as soon as it is up to date
+    if (t < rows_below) {
+      const double* pr_ = P + (16 + t) * kCRStride;
+      double sv = bv[16 * (T + 1) + t];
+#pragma unroll
+      for (int k = 0; k < 16; k++) sv = fma(-pr_[k], yv[16 * T + k], sv);
+      bv[16 * (T + 1) + t] = sv;
+      if (t < 16) Pn[(16 + rows_below - 16) * kCRStride + t] = sv;       // the next step's right-hand side row (its rows_below is 16 less)
+    }
+    const int nact = min(max((R_T - wave + kCRWaves - 1) / kCRWaves, 0), kCRSlots);     // this wave's slots [0, nact) hold tiles of the columns > T
+    auto load_ops = [&](int s, double (&xa)[4], double (&xb)[4]) {
+      const int ij = CR_TIJ(s), I = ij >> 8, J = ij & 255;
+      const double* pa = P + (16 * (I - T) + i16) * kCRStride + kq;
+      const double* pb = P + (16 * (J - T) + i16) * kCRStride + kq;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) { xa[kk] = pa[4 * kk]; xb[kk] = pb[4 * kk]; }
+    };
+    auto park = [&](int s) {                                 // column T + 1: up to date now -> the other panel buffer (the accumulators hold minus the matrix)
+      const int rho = kCRWaves * s + wave;
+      if (rho >= R_n) {
+        const int rb = 16 * (rho - R_n);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Pn[(rb + kq + 4 * r) * kCRStride + i16] = -acc[s][r];
+      }
+    };
+    // (-A_IJ) += L_IT L_JT^T, in place (the asm ties every accumulator to ONE register block for the whole kernel), two tiles at a time: the two chains of four
+    // dependent MFMAs alternate, so that an instruction never waits for the result of the one before it
+#pragma unroll
+    for (int s = 0; s < kCRSlots; s += 2) {
+      if (s + 1 < nact) {
+        double xa[4], xb[4], ya[4], yb[4];
+        load_ops(s, xa, xb); load_ops(s + 1, ya, yb);
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %1, %10, %14, %1\n\t"
+                     "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %1, %11, %15, %1\n\t"
+                     "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\tv_mfma_f64_16x16x4_f64 %1, %12, %16, %1\n\t"
+                     "v_mfma_f64_16x16x4_f64 %0, %5, %9, %0\n\tv_mfma_f64_16x16x4_f64 %1, %13, %17, %1\n\t"
+                     "s_nop 15\n\ts_nop 3"      // the results may be read by the LDS stores right below: 18 wait states after a 16x16 f64 MFMA
+                     : "+v"(acc[s]), "+v"(acc[s + 1])
+                     : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]),
+                       "v"(ya[0]), "v"(ya[1]), "v"(ya[2]), "v"(ya[3]), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]));
+        park(s); park(s + 1);
+      } else if (s < nact) {
+        double xa[4], xb[4];
+        load_ops(s, xa, xb);
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
+                     "s_nop 15\n\ts_nop 3"
+                     : "+v"(acc[s]) : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]));
+        park(s);
+      }
+    }
+    CR_TICK(6)
+  }
+  __syncthreads();
+  // the factor's tiles below the diagonal back into the (dead) accumulators for the backward pass: one batch of loads per wave
+#pragma unroll
+  for (int s = 0; s < kCRSlots; s++) {
+    const int ij = CR_TIJ(s), I = min(ij >> 8, NT - 1), J = min(ij & 255, NT - 1);
+    const double* g = gL + (size_t)(16 * I + kq) * n_pad + 16 * J + i16;
+    v4d a4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) a4[r] = g[(size_t)4 * r * n_pad];
+    acc[s] = a4;
+  }
+  CR_TICK(1)
+  // ---- backward substitution L^T x = y, tile row by tile row from the bottom ----
+  for (int I = NT - 1; I >= 0; I--) {
+    if (t < 16) {
+      double v = yv[16 * I + t];
+      double Lc[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) Lc[c] = Dg[I * 256 + c * 16 + t];      // column t of the diagonal tile
+      const double myinv = invd[16 * I + t];
+      double xres = 0.0;
+#pragma unroll
+      for (int c = 15; c >= 0; c--) {
+        const double xc = cr_bcast(v * myinv, c);                          // lane c: x_c = y'_c / L_cc
+        if (t < c) v = fma(-Lc[c], xc, v);
+        if (t == c) xres = xc;
+      }
+      xv[16 * I + t] = xres;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kCRSlots; s++) {
+      const int ij = CR_TIJ(s);
+      if ((ij >> 8) == I && (ij & 255) < I) {
+        const int J = ij & 255;
+        double pv = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) pv = fma(acc[s][r], xv[16 * I + kq + 4 * r], pv);
+        pv += __shfl_xor(pv, 16);
+        pv += __shfl_xor(pv, 32);
+        if (kq == 0) yv[16 * J + i16] -= pv;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < n) d.x[t] = xv[t];
+  CR_TICK(2)
+  // the camera update of the trial rides in this launch (as in ba_solve_dense2): ba_update_cams' arithmetic for the window's <= 50 free cameras, all in wave 0
+  {
+    double sc = 0;
+    if (t < Cp) {
+      const int c = d.slot_cam[t];
+      double u[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) u[q] = xv[6 * t + q];
+      const BaPose Tc = ba_load_pose(d.cam[cur] + 7 * (size_t)c);
+      const BaPose Tn = ba_oplus(u, Tc);
+      ba_store_pose(d.cam[cur ^ 1] + 7 * (size_t)c, Tn);
+#pragma unroll
+      for (int q = 0; q < 6; q++) sc += u[q] * ((add_lambda_term ? lambda * u[q] : 0.0) + d.bp[6 * (size_t)t + q]);
+    }
+    if (t < kWave) {   // Cp <= 50: all terms sit in wave 0; ba_update_cams' block_sum adds the four wave sums of its 256 threads, the other three being zero
+      const double s = wave_sum(sc);
+      if (t == 0) d.part_cam[0] = ((s + 0.0) + 0.0) + 0.0;
+    }
+  }
+  CR_TICK(3)
+  if (dbg && t == 0) dbg[7] += 1;
+#undef CR_TICK
+#undef CR_TIJ
+  if (t == 0) { d.pcg_flag[0] = 1; d.pcg_flag[1] = 1; d.pcg_flag[2] = ibuf[1]; d.pcg_flag[3] = 0; }
+}
+
 __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int N = kCluN;
@@ -2811,7 +3132,22 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     const int max_it = opt.pcg_max_iters > 0 ? opt.pcg_max_iters : 1000;
     int flags[4] = {0, 0, 0, 0};
     const bool dense2_on = true;
-    if (d.Cp > kSmallMaxCp && d.Cp <= kDense2MaxCp && ba->d_dense_T && ba->d_pers_coff && dense2_on) {
+    // (round 6) 17..50 free cameras: exact Cholesky with the matrix in one CU's register file (ba_solve_cholreg).  CCM_BA_CHOLREG=0 keeps the earlier solvers
+    // (two-cluster exact solve up to 32 cameras, persistent PCG above) for A / B measurements and for the tests that compare the paths (read when the handle is created).
+    if (ba->d_cholreg_L) {   // (decided at create time: ba_build.hip, cholreg_win)
+      CCM_LDS_ATTR(ctx, CCM_LDS_BA_CHOLREG, ba_solve_cholreg, cholreg_lds_bytes());
+      if (!ba->cholreg_table_built) {   // structure only: once per handle (ccm_ba_set_edge_levels keeps the block structure)
+        hipLaunchKernelGGL(ba_cholreg_table, dim3(1), dim3(kCRTPB), 0, ctx->stream, d, ba->d_cholreg_tab);
+        ba->cholreg_table_built = true;
+      }
+      {
+        ccm_prof_scope ps(ctx, CCM_K_BA_PCG_PERSIST);
+        hipLaunchKernelGGL(ba_solve_cholreg, dim3(1), dim3(kCRTPB), cholreg_lds_bytes(), ctx->stream, d, lambda, ba->d_cholreg_L, (const int*)ba->d_cholreg_tab,
+                           ccm_dbg("cholreg") ? (long long*)ba->d_cholreg_dbg : (long long*)nullptr, cur, ba->rank == 0 ? 1 : 0);
+      }
+      small_path = true;
+      cams_updated = true;   // (the solve's launch also applied the step to the cameras)
+    } else if (d.Cp > kSmallMaxCp && d.Cp <= kDense2MaxCp && ba->d_dense_T && ba->d_pers_coff && dense2_on) {
       // exact block solve in one workgroup (see ba_solve_dense2): one launch, flags read back with the trial scalars
       CCM_LDS_ATTR(ctx, CCM_LDS_BA_DENSE2, ba_solve_dense2, dense2_lds_bytes());
       {
@@ -3124,6 +3460,13 @@ static void pers_dbg_dump(ccm_ba* ba) {
     const double nw = (double)std::max<long long>(h[5], 1);
     fprintf(stderr, "[ccm_ba] row Schur kernel, thread 0 of every workgroup (%lld workgroups): us per row: staging + diagonal %.2f block passes %.2f wait %.2f final sums %.2f\n",
             h[5], h[0] * 0.01 / nw, h[1] * 0.01 / nw, h[2] * 0.01 / nw, h[3] * 0.01 / nw);
+  }
+  if (ba->d_cholreg_dbg && ccm_dbg("cholreg")) {
+    long long h[8];
+    hipMemcpy(h, ba->d_cholreg_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const double nl = (double)std::max<long long>(h[7], 1);
+    fprintf(stderr, "[ccm_ba] register-resident Cholesky solve (%d free cameras): %lld launches; us/launch: assemble %.1f factor %.1f (barrier wait %.1f, diagonal + panel %.1f, trailing update + park %.1f) backward %.1f camera update %.1f\n", ba->d.Cp, h[7],
+            h[0] * 0.01 / nl, (h[1] + h[4] + h[5] + h[6]) * 0.01 / nl, h[4] * 0.01 / nl, h[5] * 0.01 / nl, h[6] * 0.01 / nl, h[2] * 0.01 / nl, h[3] * 0.01 / nl);
   }
   if (ba->d_dense_T && ccm_dbg("dense2")) {
     long long h[11];

@@ -695,7 +695,11 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     BB_HIP(hipGetLastError());
     d.rowblk_off = p_rowblk; d.row_off = p_row_off; d.row_col = p_row_col; d.row_blk = p_row_blk;
     // ---- persistent PCG: per unit the ascending list of distinct columns + every entry's position in it; cluster entry lists ----
-    const bool pers_wanted = Cp > kSmallMaxCp;
+    // (round 6) windows of 17..50 free cameras are solved exactly by ba_solve_cholreg (ba.hip), which needs the block-CSR rows only: none of the persistent solver's
+    // lists, no cluster entry lists, no coarse level.  CCM_BA_CHOLREG=0 (read here and in lm_trial) keeps the earlier solvers and their structures.
+    const char* cholreg_env = getenv("CCM_BA_CHOLREG");
+    const bool cholreg_win = Cp > kSmallMaxCp && Cp <= kCholRegMaxCp && !(cholreg_env && cholreg_env[0] == '0');
+    const bool pers_wanted = Cp > kSmallMaxCp && !cholreg_win;
     const int n_cl = ccm_div_up(std::max(Cp, 1), kClu);
     const int pers_grid_want = ((2 * n_cl + 7) / 8) * 8;
     const bool pers_try = pers_wanted && !getenv("CCM_BA_NO_PERSIST") && pers_grid_want <= 4 * kWave && ccm_ba_pers_grid_fits(ctx, pers_grid_want);
@@ -870,6 +874,12 @@ extern "C" int ccm_ba_create(ccm_ctx* ctx, const ccm_ba_problem* P, int rank, in
     } else if (pers_try) { ba->d_pers_uoff = nullptr; ba->d_pers_ucol = nullptr; ba->d_pers_loc = nullptr; }
     if (Cp > kSmallMaxCp && Cp <= kDense2MaxCp && ba->d_pers_coff)
       BB_RC(keep_get(ba, (size_t)kCluN * kCluN + 16, &ba->d_dense_T, true));   // + phase clocks (CCM_BA_DENSE2_DBG)
+    if (cholreg_win) {   // register-resident Cholesky solve: phase clocks [16]; the factor's scratch [n_pad][n_pad] (written before read)
+      const size_t np = 16 * (size_t)ccm_div_up(6 * Cp, 16);
+      BB_RC(keep_get(ba, 16, &ba->d_cholreg_dbg, true));
+      BB_RC(keep_get(ba, np * np, &ba->d_cholreg_L, false));
+      BB_RC(keep_get(ba, (size_t)8 * 24 * 64 * 4, &ba->d_cholreg_tab, false));
+    }
     // maps too large for the persistent kernel: the same coarse level inside the multi-kernel PCG (kAgg = 2 clusters)
     if (!ba->pers_grid && coarse_mk) {
       BB_RC(coarse_buffers(0));

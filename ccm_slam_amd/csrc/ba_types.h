@@ -24,6 +24,7 @@ constexpr int kPersIdxCap = 3072;    // CSR entries of one persistent unit's row
 constexpr int kPersColCap = 640;     // distinct neighbour columns of one persistent unit
 constexpr int kSmallMaxCp = 16;      // one cluster: the single-workgroup kernel; above, the persistent kernel with its 16-camera cluster preconditioner
 constexpr int kDense2MaxCp = 2 * kClu;
+constexpr int kCholRegMaxCp = 50;    // (round 6) exact register-resident Cholesky in one workgroup: 19 x 19 tiles of 16 x 16 (n = 6 Cp <= 304), ba_solve_cholreg
 
 struct BaDev {
   // sizes
@@ -135,6 +136,10 @@ struct ccm_ba {
   double* d_red = nullptr; size_t red_count = 0;   // [S | bs]
   unsigned* d_pers_bar = nullptr; double* d_pers_part = nullptr; int pers_grid = 0;   // persistent PCG (0 = not usable)
   double* d_dense_T = nullptr;   // [96][96] scratch of the exact two-cluster solve (17..32 free cameras)
+  double* d_cholreg_dbg = nullptr;   // [16] phase clocks of the register-resident Cholesky solve (17..50 free cameras; CCM_DBG=cholreg)
+  int* d_cholreg_tab = nullptr;      // [8][24][64][4] offsets into S of every lane's entries of every tile (ba_cholreg_table, built at the first trial)
+  bool cholreg_table_built = false;
+  double* d_cholreg_L = nullptr;     // [n_pad][n_pad] scratch of its factor (rows below the diagonal tiles)
   int *d_pers_uoff = nullptr, *d_pers_ucol = nullptr, *d_pers_loc = nullptr, *d_pers_coff = nullptr, *d_pers_cij = nullptr;
   uint32_t* d_pers_cblk = nullptr;
   unsigned long long pers_launch = 0;

@@ -49,7 +49,7 @@ struct ccm_ctx {
 };
 
 int ccm_set_error(ccm_ctx* ctx, int code, const std::string& msg);
-// development prints / device phase clocks: CCM_DBG = comma-separated list of topics (pers, trial, coarse, dense2, setup, row, orb, pg, poseopt) or "all"; read once
+// development prints / device phase clocks: CCM_DBG = comma-separated list of topics (pers, trial, coarse, dense2, cholreg, setup, row, orb, pg, poseopt) or "all"; read once
 bool ccm_dbg(const char* topic);
 
 // Bracket around the launch of a kernel that needs ALL its workgroups co-resident on the device (ba_pcg_persist: up to one workgroup per CU, grid-wide
@@ -78,7 +78,7 @@ void ccm_coresident_note_abort(ccm_ctx* ctx);   // a bracketed kernel gave up wa
                                __FILE__ + ":" + std::to_string(__LINE__) + ")");        \
   } while (0)
 
-enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT, CCM_LDS_BA_DENSE2, CCM_LDS_ORB_OCT, CCM_LDS_ORB_OCT2, CCM_LDS_BA_ROW3, CCM_LDS_BA_ROW4, CCM_LDS_POSEOPT1 };
+enum { CCM_LDS_BA_ROW = 0, CCM_LDS_BA_ROW2 = 8, CCM_LDS_BA_SMALL, CCM_LDS_BA_TILES, CCM_LDS_PG_PRECOND, CCM_LDS_POSEOPT, CCM_LDS_SIM3OPT, CCM_LDS_BA_DENSE2, CCM_LDS_ORB_OCT, CCM_LDS_ORB_OCT2, CCM_LDS_BA_ROW3, CCM_LDS_BA_ROW4, CCM_LDS_POSEOPT1, CCM_LDS_BA_CHOLREG };
 #define CCM_LDS_ATTR(ctx, bit, func, bytes)                                                                              \
   do {                                                                                                                   \
     if (!((ctx)->lds_attr_done & (1u << (bit)))) {                                                                       \

@@ -401,10 +401,11 @@ def test_config3_three_agent_map(ctx, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kfs", [18, 26, 34, 49, 66])
+@pytest.mark.parametrize("kfs", [18, 26, 33, 34, 35, 41, 49, 50, 51, 52, 57, 65, 66])
 def test_camera_counts_around_the_cluster_size(ctx, oracle_lib, kfs):
-    """Free-camera counts that leave the last 16-camera cluster (and its second 8-row unit) partly or wholly empty:
-    17, 25, 33, 48, 65 free cameras through the persistent kernel."""
+    """Free-camera counts around every boundary of the small-window solvers: 17 ... 50 free cameras take the register-resident Cholesky solve (ba_solve_cholreg: 3 ... 19
+    tile rows, a last tile row that is partly padding for most counts, 50 = the reference's configured window, conf/config.yaml:78), 51 ... 65 the persistent PCG with a
+    last 16-camera cluster (and its second 8-row unit) partly or wholly empty."""
     prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=kfs, n_points=60 * kfs, seed=100 + kfs)
     h = optimizer.BAHandle(ctx, prob)
     assert h.counts()["free_cams"] == kfs - 1
@@ -417,6 +418,28 @@ def test_camera_counts_around_the_cluster_size(ctx, oracle_lib, kfs):
     dt, dr = synth.pose_errors(cam, ocam)
     assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
     assert np.abs(pts - opts).max() <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kfs", [20, 33, 42, 51])
+def test_small_window_solvers_agree(ctx, oracle_lib, kfs, monkeypatch):
+    """The exact register-resident Cholesky solve (default for 17 ... 50 free cameras) against the solvers it replaced on the same windows (CCM_BA_CHOLREG=0: exact
+    two-cluster solve up to 32 cameras, persistent PCG to 1e-8 above): the same LM iterations and trials, states within the PCG's tolerance of each other; and the new
+    solve is bit-reproducible."""
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=kfs, n_points=60 * kfs, seed=300 + kfs, n_fixed=1)
+    def run():
+        h = optimizer.BAHandle(ctx, prob); st = h.run(6); cam, pts, chi2, _ = h.download(); h.close()
+        return st, cam, pts, chi2
+    st1, cam1, pts1, chi1 = run()
+    st1b, cam1b, pts1b, chi1b = run()
+    assert np.array_equal(cam1, cam1b) and np.array_equal(pts1, pts1b) and np.array_equal(chi1, chi1b)
+    monkeypatch.setenv("CCM_BA_CHOLREG", "0")
+    st0, cam0, pts0, _ = run()
+    assert (st1.iters_done, st1.lm_trials) == (st0.iters_done, st0.lm_trials)
+    assert abs(st1.chi2_final - st0.chi2_final) <= TOL_CHI * st0.chi2_final
+    dt, dr = synth.pose_errors(cam1, cam0)
+    assert dt.max() <= TOL_T and dr.max() <= TOL_R, (dt.max(), dr.max())
+    assert np.abs(pts1 - pts0).max() <= 1e-4
 
 
 @pytest.mark.gpu
