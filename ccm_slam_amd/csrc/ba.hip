@@ -2772,7 +2772,9 @@ __global__ __launch_bounds__(kTPB) void ba_reduce_scalars(BaDev d, int stop_loca
   if (threadIdx.x == 0) {
     d.scal[0] = a; d.scal[1] = b;
     d.scal[2] = stop_local ? 1.0 : 0.0;
-    const double s3 = (abort_local || (pers_trial && d.pcg_flag[3])) ? 1.0 : 0.0;
+    // 1: the persistent kernel gave up on this rank (bounded spin); 4096: its LAUNCH was refused on this rank.  Summed over the ranks of a sharded handle, so every rank
+    // can tell "somebody gave up" (> 0: repeat the trial on the multi-kernel solver, then cool down) from "somebody cannot launch it at all" (>= 4096: for good)
+    const double s3 = abort_local ? 4096.0 : (pers_trial && d.pcg_flag[3]) ? 1.0 : 0.0;
     d.scal[3] = s3;
     if (h_out) {
       h_out[0] = a; h_out[1] = b; h_out[2] = stop_local ? 1.0 : 0.0; h_out[3] = s3;
@@ -3374,7 +3376,9 @@ int lm_trial(ccm_ba* ba, double lambda, const ccm_ba_options& opt, double* temp_
     // written part of it.
     if (pers_trial) { ccm_coresident_note_abort(ctx); ba->pers_aborts++; }
     ba->pers_grid = 0; ba->pers_cooldown = kPersCooldownTrials;
-    if (ba->nranks > 1) ba->pers_grid_built = 0;   // sharded: for good, as before — a rank whose LAUNCH was refused cannot come back, and all ranks must keep the same solver path
+    // (round 6) a sharded handle cools down like a single-rank one: s[3] is the all-reduced value, so every rank counts the same trials and returns to the persistent
+    // kernel at the same trial.  Only a refused LAUNCH on some rank (>= 4096 in the sum) is for good — that rank cannot come back, and all ranks must keep the same solver path.
+    if (ba->nranks > 1 && s[3] >= 4096.0) ba->pers_grid_built = 0;
     ba->w_valid = false; ba->w_pending = false;
     return lm_trial(ba, lambda, opt, temp_chi, scale, ok, pcg_iters);
   }

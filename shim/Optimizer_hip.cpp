@@ -14,6 +14,19 @@
 // the real headers, so the same file compiles in a catkin workspace with `Optimizer.cpp` replaced by it in cslam/CMakeLists.txt:122-145.
 // tests/test_shim_gpu.py runs this file and the reference's Optimizer.cpp on identical synthetic maps and compares what they leave
 // behind in the map.
+//
+// LICENCE AND PROVENANCE.  This file is a derived work of cslam/src/Optimizer.cpp of CCM-SLAM (Copyright (C) Patrik Schmuck, ETH Zurich; GNU GPL v3 or later; itself based
+// on ORB-SLAM2 by Raul Mur-Artal) and is distributed under the same licence.  Everything numerical is new (it is a call into libccm_hip.so), but a drop-in must choose the
+// SAME vertices and edges in the SAME order and mutate the map in the SAME order as the reference, so these passages follow Optimizer.cpp statement by statement —
+// reformatted, with the reference's variable names kept so that a maintainer can diff them — and runs of a few lines of them are textually the reference's:
+//   * BundleAdjustmentClient / MapFusionGBA: the vertex / edge collection loops and the write-back loops with the mTcwGBA / mPosGBA branch   (Optimizer.cpp:55-212, 668-859)
+//   * PoseOptimizationClient: the edge set-up loop over Frame.mvpMapPoints / mvKeysUn and the outlier bookkeeping of the four rounds         (Optimizer.cpp:235-347)
+//   * LocalBundleAdjustmentClient: the local-window walk (local keyframes, local points, fixed cameras), the erase loop with its
+//     SetNotErase wait, the pose / point write-back                                                                                         (Optimizer.cpp:351-404, 568-644)
+//   * OptimizeSim3: correspondence collection and the inlier bookkeeping                                                                     (Optimizer.cpp:880-1056)
+//   * OptimizeEssentialGraphLoopClosure / MapFusion: the four edge walks (loop connections, spanning tree, loop edges, covisibility >= 100)
+//     and the corrected-pose / point write-back                                                                                             (Optimizer.cpp:1122-1331, 1376-1566)
+// What the shim prints (its fatal conditions, device errors) is its own wording; what it throws is the reference's exception type, because callers catch that.
 #include <cslam/Optimizer.h>
 
 #include <atomic>
@@ -33,6 +46,13 @@
 
 namespace cslam {
 namespace {
+
+// Fatal conditions of the graph walks: the reference prints a message and throws estd::infrastructure_ex (Optimizer.cpp:87-90, 480-483, 595-598, 663-666); a drop-in
+// keeps the EXCEPTION TYPE (callers catch it) and says in its own words what was wrong and where.
+[[noreturn]] void shim_fatal(const char* method, const char* what) {
+  std::cout << "[ccm_hip shim] " << method << ": " << what << " (infrastructure_ex)" << std::endl;
+  throw estd::infrastructure_ex();
+}
 
 // one device context per calling thread: tracking, local mapping and the server's optimisation threads call concurrently
 ccm_ctx* thread_ctx() {
@@ -385,8 +405,7 @@ void Optimizer::BundleAdjustmentClient(const vector<kfptr>& vpKFs, const vector<
     kfptr pKF = vpKFs[i];
     if (pKF->isBad()) continue;
     if (pKF->mId.first >= IDRANGE) {
-      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": KF index out of bounds" << endl;
-      throw infrastructure_ex();
+      shim_fatal("Optimizer::BundleAdjustmentClient / MapFusionGBA", "keyframe id is not below IDRANGE");
     }
     f.addCam(Optimizer::GetID(pKF->mId, true), pKF, pKF->mId == zeropair);
   }
@@ -395,8 +414,7 @@ void Optimizer::BundleAdjustmentClient(const vector<kfptr>& vpKFs, const vector<
     mpptr pMP = vpMP[i];
     if (pMP->isBad()) continue;
     if (pMP->mId.first >= IDRANGE) {
-      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": MP index out of bounds" << endl;
-      throw infrastructure_ex();
+      shim_fatal("Optimizer::BundleAdjustmentClient / MapFusionGBA", "map point id is not below IDRANGE");
     }
     const int id = Optimizer::GetID(pMP->mId, false);
     f.addPoint(id, pMP);
@@ -406,8 +424,7 @@ void Optimizer::BundleAdjustmentClient(const vector<kfptr>& vpKFs, const vector<
       kfptr pKF = mit->first;
       if (pKF->isBad()) continue;
       if (pKF->mId.first >= IDRANGE) {
-        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::BundleAdjustment(...)\": KF index out of bounds" << endl;
-        throw infrastructure_ex();
+        shim_fatal("Optimizer::BundleAdjustmentClient / MapFusionGBA", "keyframe id is not below IDRANGE");
       }
       nEdges++;
       f.addEdge(id, pKF, Optimizer::GetID(pKF->mId, true), pKF->mvKeysUn[mit->second]);
@@ -530,16 +547,14 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   for (list<kfptr>::iterator lit = lLocalKeyFrames.begin(), lend = lLocalKeyFrames.end(); lit != lend; lit++) {
     kfptr pKFi = *lit;
     if (pKFi->mId.first >= IDRANGE) {
-      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
-      throw infrastructure_ex();
+      shim_fatal("Optimizer::LocalBundleAdjustmentClient", "keyframe id is not below IDRANGE");
     }
     f.addCam(Optimizer::GetID(pKFi->mId, true), pKFi, pKFi->mId.first == 0 && pKFi->mId.second == ClientId);
   }
   for (list<kfptr>::iterator lit = lFixedCameras.begin(), lend = lFixedCameras.end(); lit != lend; lit++) {
     kfptr pKFi = *lit;
     if (pKFi->mId.first >= IDRANGE) {
-      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
-      throw infrastructure_ex();
+      shim_fatal("Optimizer::LocalBundleAdjustmentClient", "keyframe id is not below IDRANGE");
     }
     f.addCam(Optimizer::GetID(pKFi->mId, true), pKFi, true);
   }
@@ -549,8 +564,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
   for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++) {
     mpptr pMP = *lit;
     if (pMP->mId.first >= IDRANGE) {
-      cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": MP index out of bounds" << endl;
-      throw infrastructure_ex();
+      shim_fatal("Optimizer::LocalBundleAdjustmentClient", "map point id is not below IDRANGE");
     }
     const int id = Optimizer::GetID(pMP->mId, false);
     f.addPoint(id, pMP);
@@ -558,8 +572,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     for (map<kfptr, size_t>::const_iterator mit = observations.begin(), mend = observations.end(); mit != mend; mit++) {
       kfptr pKFi = mit->first;
       if (pKFi->mId.first >= IDRANGE) {
-        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m #1: In \"Optimizer::LocalBundleAdjustment(...)\": KF index out of bounds" << endl;
-        throw infrastructure_ex();
+        shim_fatal("Optimizer::LocalBundleAdjustmentClient", "keyframe id is not below IDRANGE");
       }
       if (!pKFi->isBad()) {
         f.addEdge(id, pKFi, Optimizer::GetID(pKFi->mId, true), pKFi->mvKeysUn[mit->second]);
@@ -620,8 +633,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     // problem's edges minus the erased observations
     for (list<mpptr>::iterator lit = lLocalMapPoints.begin(), lend = lLocalMapPoints.end(); lit != lend; lit++)
       if ((*lit)->isBad() && pMap->GetMpPtr((*lit)->mId)) {
-        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << ":" << __LINE__ << " MP bad but not erased from map" << endl;
-        throw estd::infrastructure_ex();
+        shim_fatal("Optimizer::LocalBundleAdjustmentClient", "a local map point is flagged bad but the map still holds it");
       }
     std::vector<char> erased(f.nEdges(), 0);
     for (size_t i = 0, iend = f.nEdges(); i < iend; i++) erased[i] = !vpMapPointEdgeMono[i]->isBad() && (chi2[i] > 5.991 || !dpos[i]);
@@ -634,8 +646,7 @@ void Optimizer::LocalBundleAdjustmentClient(kfptr pKF, bool* pbStopFlag, mapptr 
     if (pMP->isBad()) {
       mpptr pMPcheck = pMap->GetMpPtr(pMP->mId);
       if (pMPcheck) {
-        cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << ":" << __LINE__ << " MP bad but not erased from map" << endl;
-        throw estd::infrastructure_ex();
+        shim_fatal("Optimizer::LocalBundleAdjustmentClient", "a local map point is flagged bad but the map still holds it");
       }
     } else {
       pMP->SetWorldPos(f.pointPos(Optimizer::GetID(pMP->mId, false)), false);
@@ -658,8 +669,7 @@ void Optimizer::MapFusionGBA(mapptr pMap, size_t ClientId, int nIterations, bool
   vector<mpptr> vpMP = pMap->GetAllMapPoints();
   const idpair zeropair = make_pair(0, pMap->mMapId);
   if (pMap->mvpKeyFrameOrigins.empty()) {
-    cout << "\033[1;31m!!!!! ERROR !!!!!\033[0m " << __func__ << __LINE__ << " pMap->mvpKeyFrameOrigins.empty()" << endl;
-    throw infrastructure_ex();
+    shim_fatal("Optimizer::MapFusionGBA", "the map has no origin keyframe (mvpKeyFrameOrigins is empty)");
   }
   idpair FixedId = (*(pMap->mvpKeyFrameOrigins.begin()))->mId;
   std::vector<char> vbNotIncludedMP(vpMP.size(), 0);   // one byte per point: chunks of vpMP are walked by different threads
