@@ -82,7 +82,7 @@ struct BaDev {
   double* camRK;             // [Cp][12] per pose slot: rotation matrix (row-major), fx, fy, 0
   const int* inst_cp;        // [n_inst] ed_cpos of the pair instance's block-col observation
   const int* blk_j;          // [nOff] column pose slot of every off-diagonal block
-  long long* row_dbg;        // nullable (CCM_BA_ROW_DBG): [8] phase clocks of the row kernel summed over its workgroups (10 ns ticks) + launches
+  long long* row_dbg;        // nullable (CCM_DBG=row in a -DCCM_BA_ROW_DBG_BUILD build): [8] phase clocks of the row kernel summed over its workgroups (10 ns ticks) + launches
   // block CSR for SpMV (full rows, diag included)
   const int* row_off;        // [Cp+1]
   const int* row_col;        // [..]

@@ -69,8 +69,12 @@ void ccm_coresident_note_abort(ccm_ctx* ctx) {
 // while it was alone has no event behind it.
 static void lease_join(ccm_ctx* c) {
   DevLease& L = g_lease[c->device % kLeaseDevices];
-  std::lock_guard<std::mutex> lk(L.mu);
-  if (++L.n_ctx == 2) { (void)hipDeviceSynchronize(); L.head = -1; L.last_stream = nullptr; }
+  bool second;
+  { std::lock_guard<std::mutex> lk(L.mu); second = ++L.n_ctx == 2; }
+  // (round 6, advisor) the drain runs OUTSIDE the lease mutex: from the increment above every bracketed launch of the other context records its event, so all the drain
+  // has to cover is what that context launched while it was alone — and a thread that launches meanwhile no longer blocks on the mutex for a whole device drain.  The
+  // ring is left as it is: an event recorded in between must not be forgotten, and waiting for an old, completed one costs nothing.
+  if (second) (void)hipDeviceSynchronize();
 }
 static void lease_leave(ccm_ctx* c) {
   DevLease& L = g_lease[c->device % kLeaseDevices];
@@ -80,8 +84,8 @@ static void lease_leave(ccm_ctx* c) {
 }
 
 extern "C" int ccm_coresidency_stats(int device_id, int64_t* launches, int64_t* chained, int64_t* aborted, int* contexts) {
-  if (device_id < 0 || device_id >= kLeaseDevices) return CCM_E_ARG;
-  DevLease& L = g_lease[device_id];
+  if (device_id < 0) return CCM_E_ARG;
+  DevLease& L = g_lease[device_id % kLeaseDevices];   // (the same rule as the lease itself: lease_join)
   std::lock_guard<std::mutex> lk(L.mu);
   if (launches) *launches = L.launches;
   if (chained) *chained = L.chained;

@@ -413,7 +413,7 @@ extern "C" int ccm_hamming_csr_multi(ccm_ctx* ctx, int S, const uint8_t* q, cons
   if (q_off[0] != 0 || t_off[0] != 0 || Q < 0 || T < 0 || (Q && (!q || !cand_off))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad offsets");
   if (Q == 0) return CCM_OK;
   const int64_t n_cand = cand_off[Q];
-  if (n_cand < 0 || (n_cand && (!cand_idx || !t))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad candidate list");
+  if (cand_off[0] != 0 || n_cand < 0 || (n_cand && (!cand_idx || !t))) return ccm_set_error(ctx, CCM_E_ARG, "hamming_csr_multi: bad candidate list (cand_off must start at 0)");
   void* pin = nullptr;
   { int rc0 = ccm_pin_scratch(ctx, (size_t)Q * 4 + 256, &pin); if (rc0) return rc0; }
   int32_t* h_base = (int32_t*)pin;
@@ -435,11 +435,11 @@ extern "C" int ccm_hamming_csr_multi(ccm_ctx* ctx, int S, const uint8_t* q, cons
   { int rc0 = ccm_io_scratch(ctx, bq + bt + bo + bb + bi + bd + (size_t)Q * 12, &io); if (rc0) return rc0; }
   uint8_t* d_q = (uint8_t*)io; uint8_t* d_t = d_q + bq; int32_t* d_off = (int32_t*)(d_t + bt); int32_t* d_base = (int32_t*)((uint8_t*)d_off + bo);
   int32_t* d_idx = (int32_t*)((uint8_t*)d_base + bb); uint16_t* d_dist = (uint16_t*)((uint8_t*)d_idx + bi); int32_t* d_out = (int32_t*)((uint8_t*)d_dist + bd);
-  hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream);
-  if (T) hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream);
-  hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ctx->stream);
-  hipMemcpyAsync(d_base, h_base, (size_t)Q * 4, hipMemcpyHostToDevice, ctx->stream);
-  if (n_cand) hipMemcpyAsync(d_idx, cand_idx, (size_t)n_cand * 4, hipMemcpyHostToDevice, ctx->stream);
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_q, q, (size_t)Q * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (T) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_t, t, (size_t)T * 32, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_base, h_base, (size_t)Q * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_cand) CCM_HIP_CHECK(ctx, hipMemcpyAsync(d_idx, cand_idx, (size_t)n_cand * 4, hipMemcpyHostToDevice, ctx->stream));
   int rc = ccm_hamming_csr_multi_dev(ctx, d_q, Q, d_t, d_base, d_off, d_idx, n_cand, d_dist, best_idx ? d_out : nullptr,
                                      best_idx ? d_out + Q : nullptr, best_idx ? d_out + 2 * (size_t)Q : nullptr);
   if (rc == CCM_OK) {
