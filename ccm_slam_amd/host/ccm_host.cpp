@@ -705,6 +705,70 @@ int ORBmatcher::ProjectedSearch(FrameGridDev& grid, const FrameView& KF, const f
   return nacc;
 }
 
+// ---- FuseBatch: the projected window searches of many target keyframes, Hamming work in one launch ----
+FuseBatch::FuseBatch(ORBmatcher& m, const std::vector<Target>& targets, bool chi2Gate, int distThreshold) : tg_(targets.size()), dist_threshold_(distThreshold) {
+  const int S = (int)targets.size();
+  std::vector<int32_t> q_off(S + 1, 0), t_off(S + 1, 0), cand_off(1, 0), cand_idx;
+  std::vector<uint8_t> qdesc, tdesc;
+  for (int s = 0; s < S; s++) {
+    const Target& T = targets[s];
+    const FrameView& KF = T.KF; const ORBmatcher::ProjectedPoints& P = T.P;
+    Tg& g = tg_[s];
+    g.n_pts = P.n; g.off.assign(1, 0);
+    std::unique_ptr<FrameGrid> grid;
+    if (!P.candOff) grid.reset(new FrameGrid(KF));
+    std::vector<int32_t> win;
+    for (int i = 0; i < P.n; i++) {          // candidate lists exactly as ProjectedSearch builds them (window, level window [lvl - 1, lvl], chi2 gate)
+      if (!P.valid[i]) continue;
+      const int lvl = P.level[i];
+      const size_t before = g.idx.size();
+      win.clear();
+      if (P.candOff) win.assign(P.candIdx + P.candOff[i], P.candIdx + P.candOff[i + 1]);
+      else grid->featuresInArea(P.u[i], P.v[i], T.th * KF.mvScaleFactors[lvl], -1, -1, win);
+      for (int k : win) {
+        const int kpLevel = KF.mvKeysUn[k].octave;
+        if (kpLevel < lvl - 1 || kpLevel > lvl) continue;
+        if (chi2Gate) {
+          const float ex = P.u[i] - KF.mvKeysUn[k].x, ey = P.v[i] - KF.mvKeysUn[k].y;
+          const float e2 = ex * ex + ey * ey;
+          if (e2 * T.invLevelSigma2[kpLevel] > 5.99) continue;
+        }
+        g.idx.push_back(k);
+      }
+      if (g.idx.size() == before) continue;
+      g.q_of.push_back(i); g.off.push_back((int32_t)g.idx.size());
+      qdesc.insert(qdesc.end(), P.desc + (size_t)i * 32, P.desc + (size_t)i * 32 + 32);
+    }
+    q_off[s + 1] = q_off[s] + (int32_t)g.q_of.size();
+    t_off[s + 1] = t_off[s] + KF.N;
+    tdesc.insert(tdesc.end(), KF.mDescriptors, KF.mDescriptors + (size_t)KF.N * 32);
+    const int32_t base = cand_off.back();
+    for (size_t q = 1; q < g.off.size(); q++) cand_off.push_back(base + g.off[q]);
+    cand_idx.insert(cand_idx.end(), g.idx.begin(), g.idx.end());
+  }
+  n_cand_ = (int64_t)cand_idx.size();
+  if (!n_cand_) return;
+  std::vector<uint16_t> dist(cand_idx.size());
+  check(ccm_hamming_csr_multi(m.ctx_.get(), S, qdesc.data(), q_off.data(), tdesc.data(), t_off.data(), cand_off.data(), cand_idx.data(), dist.data(),
+                              nullptr, nullptr, nullptr), m.ctx_.get(), "ccm_hamming_csr_multi");
+  size_t at = 0;
+  for (int s = 0; s < S; s++) { Tg& g = tg_[s]; g.dist.assign(dist.begin() + at, dist.begin() + at + g.idx.size()); at += g.idx.size(); }
+}
+
+int FuseBatch::resolve(int s, const uint8_t* skip_now, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) const {
+  const Tg& g = tg_.at(s);
+  bestIdx.assign(g.n_pts, -1); bestDist.assign(g.n_pts, INT32_MAX);
+  int nacc = 0;
+  for (size_t q = 0; q < g.q_of.size(); q++) {
+    const int i = g.q_of[q];
+    if (skip_now && skip_now[i]) continue;
+    int bd = INT32_MAX, bi = -1;
+    for (int c = g.off[q]; c < g.off[q + 1]; c++) if (g.dist[c] < bd) { bd = g.dist[c]; bi = g.idx[c]; }   // first minimum wins (:941-945)
+    if (bd <= dist_threshold_) { bestIdx[i] = bi; bestDist[i] = bd; nacc++; }
+  }
+  return nacc;
+}
+
 int ORBmatcher::MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12) {
   int nFound = 0;
   matches12.assign(vnMatch1.size(), -1);
@@ -1110,6 +1174,69 @@ extern "C" int ccmh_projected_window_search_dev(int device, const float* kx, con
     return n;
   } catch (const std::exception&) { return -1000; }
 }
+
+// FuseBatch through a flat interface (tests): S targets given as concatenated arrays with offsets; every target is searched with the chi2 gate and TH_LOW like Fuse
+extern "C" void* ccmh_fuse_batch_create(int device, int S, const int32_t* kf_off /* [S+1] features */, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc,
+                                        const float* bounds4 /* [S][4] minX minY maxX maxY */, const float* scale_factors, const float* inv_sigma2,
+                                        const int32_t* pt_off /* [S+1] points */, const uint8_t* valid, const float* u, const float* v, const int32_t* level,
+                                        const uint8_t* pdesc, float th) {
+  try {
+    cslam::HipContext& ctx = thread_context(device);
+    cslam::ORBmatcher m(ctx);
+    std::vector<std::vector<cslam::KeyPoint>> keys(S);
+    std::vector<std::vector<int32_t>> dummy(S);
+    std::vector<cslam::FuseBatch::Target> tg(S);
+    for (int s = 0; s < S; s++) {
+      const int k0 = kf_off[s], N = kf_off[s + 1] - k0, p0 = pt_off[s];
+      keys[s] = mk_keys(kx + k0, ky + k0, oct + k0, nullptr, N);
+      dummy[s].assign(N, -1);
+      cslam::FrameView& F = tg[s].KF;
+      F.N = N; F.mvKeysUn = keys[s].data(); F.mDescriptors = kdesc + (size_t)k0 * 32; F.mnMinX = bounds4[4 * s]; F.mnMinY = bounds4[4 * s + 1]; F.mnMaxX = bounds4[4 * s + 2];
+      F.mnMaxY = bounds4[4 * s + 3]; F.mvScaleFactors = scale_factors; F.mvpMapPoints = dummy[s].data();
+      cslam::ORBmatcher::ProjectedPoints& P = tg[s].P;
+      P.n = pt_off[s + 1] - p0; P.valid = valid + p0; P.u = u + p0; P.v = v + p0; P.level = level + p0; P.desc = pdesc + (size_t)p0 * 32;
+      tg[s].invLevelSigma2 = inv_sigma2; tg[s].th = th;
+    }
+    return new cslam::FuseBatch(m, tg);
+  } catch (const std::exception&) { return nullptr; }
+}
+// the same with every target's window candidates supplied by the caller (its own KeyFrame::GetFeaturesInArea, as ccmh_projected_window_search_cand): target s owns the
+// points pt_off[s] .. pt_off[s+1]; cand_off has one entry per point plus one per target (target s: entries pt_off[s] + s .. pt_off[s+1] + s, starting at 0), its
+// candidate indices start at cand_base[s] in cand_idx
+extern "C" void* ccmh_fuse_batch_create_cand(int device, int S, const int32_t* kf_off, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc,
+                                             const float* const* inv_sigma2 /* [S] */, const int32_t* pt_off, const uint8_t* valid, const float* u, const float* v,
+                                             const int32_t* level, const uint8_t* pdesc, const int32_t* cand_off, const int32_t* cand_base, const int32_t* cand_idx,
+                                             int chi2_gate, int dist_threshold) {
+  try {
+    cslam::HipContext& ctx = thread_context(device);
+    cslam::ORBmatcher m(ctx);
+    std::vector<std::vector<cslam::KeyPoint>> keys(S);
+    std::vector<cslam::FuseBatch::Target> tg(S);
+    for (int s = 0; s < S; s++) {
+      const int k0 = kf_off[s], N = kf_off[s + 1] - k0, p0 = pt_off[s];
+      keys[s] = mk_keys(kx + k0, ky + k0, oct + k0, nullptr, N);
+      cslam::FrameView& F = tg[s].KF;
+      F.N = N; F.mvKeysUn = keys[s].data(); F.mDescriptors = kdesc + (size_t)k0 * 32;
+      cslam::ORBmatcher::ProjectedPoints& P = tg[s].P;
+      P.n = pt_off[s + 1] - p0; P.valid = valid + p0; P.u = u + p0; P.v = v + p0; P.level = level + p0; P.desc = pdesc + (size_t)p0 * 32;
+      P.candOff = cand_off + p0 + s; P.candIdx = cand_idx + cand_base[s];
+      tg[s].invLevelSigma2 = inv_sigma2[s]; tg[s].th = 0.f;
+    }
+    return new cslam::FuseBatch(m, tg, chi2_gate != 0, dist_threshold);
+  } catch (const std::exception&) { return nullptr; }
+}
+extern "C" long long ccmh_fuse_batch_candidates(void* h) { return h ? (long long)((cslam::FuseBatch*)h)->candidates() : -1; }
+extern "C" int ccmh_fuse_batch_resolve(void* h, int s, const uint8_t* skip_now, int n_pts, int32_t* best_idx, int32_t* best_dist) {
+  try {
+    std::vector<int32_t> bi, bd;
+    const int n = ((cslam::FuseBatch*)h)->resolve(s, skip_now, bi, bd);
+    if ((int)bi.size() != n_pts) return -1001;
+    std::memcpy(best_idx, bi.data(), bi.size() * sizeof(int32_t));
+    std::memcpy(best_dist, bd.data(), bd.size() * sizeof(int32_t));
+    return n;
+  } catch (const std::exception&) { return -1000; }
+}
+extern "C" void ccmh_fuse_batch_destroy(void* h) { delete (cslam::FuseBatch*)h; }
 
 extern "C" int ccmh_bow_transform(int device, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc,
                                   const int32_t* word_id, const double* weight, const uint8_t* desc, int N, int levelsup, int32_t* bow_ids,

@@ -158,6 +158,7 @@ class ORBmatcher {
   // SearchBySim3's agreement step (:1318-1345) on the two directional results
   static int MutualAgreement(const std::vector<int32_t>& vnMatch1, const std::vector<int32_t>& vnMatch2, std::vector<int32_t>& matches12);
   friend class TriangulationBatch;
+  friend class FuseBatch;
  private:
   void deviceWindows(FrameGridDev& grid, const std::vector<float>& u, const std::vector<float>& v, const std::vector<float>& r,
                      const std::vector<int32_t>& minl, const std::vector<int32_t>& maxl, const std::vector<uint8_t>& qdesc,
@@ -190,6 +191,28 @@ class TriangulationBatch {
   std::vector<Nb> nb_;
   int64_t n_cand_ = 0;
   bool check_ori_;
+};
+
+// The fan-out of LocalMapping::SearchInNeighbors (cslam/src/Mapping.cpp:497-503): matcher.Fuse(pKFi, vpMapPointMatches) for every target keyframe — up to 20 covisible
+// neighbours and 5 second neighbours of each — and the projected window searches of the same shape elsewhere (Fuse with Sim3 per loop keyframe, MapMatcher / LoopFinder).
+// Fuse never claims features inside its loop (ORBmatcher.cpp:854-993: the best candidate of a point depends on that point alone), and what the calls change between
+// each other — a point Replace()d by an earlier call is bad, a point has meanwhile been added to the keyframe — only makes a later call SKIP points (:884-888).  So the
+// Hamming work of ALL targets goes to the device as ONE ccm_hamming_csr_multi launch when the batch is built (each target = one search against its own descriptor set),
+// and resolve(s, skip_now) replays call s from the stored distances: bit for bit what ProjectedSearch(KF_s, ..., chi2Gate, distThreshold, matched = nullptr) returns
+// for the points that are not skipped at that moment.  Everything the batch needs is copied at build time.
+class FuseBatch {
+ public:
+  struct Target { FrameView KF; const float* invLevelSigma2 = nullptr; ORBmatcher::ProjectedPoints P; float th = 3.0f; };
+  FuseBatch(ORBmatcher& m, const std::vector<Target>& targets, bool chi2Gate = true, int distThreshold = ORBmatcher::TH_LOW);
+  int targets() const { return (int)tg_.size(); }
+  int64_t candidates() const { return n_cand_; }
+  // skip_now: nullable [P.n of target s]; != 0: the reference's loop would `continue` for this point now (isBad() / IsInKeyFrame(pKF) turned true since the build)
+  int resolve(int s, const uint8_t* skip_now, std::vector<int32_t>& bestIdx, std::vector<int32_t>& bestDist) const;
+ private:
+  struct Tg { int n_pts = 0; std::vector<int32_t> q_of, off, idx; std::vector<uint16_t> dist; };
+  std::vector<Tg> tg_;
+  int64_t n_cand_ = 0;
+  int dist_threshold_;
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -23,6 +23,9 @@ long long ccmh_tri_batch_candidates(void* h);
 void ccmh_tri_batch_destroy(void* h);
 int ccmh_search_for_initialization(int device, const float* x1, const float* y1, const int32_t* oct1, const float* a1, const uint8_t* d1, int N1, const float* x2, const float* y2, const int32_t* oct2, const float* a2, const uint8_t* d2, int N2, float minX, float minY, float maxX, float maxY, float* prev_xy, int window, float nnratio, int check_ori, int32_t* matches12);
 int ccmh_projected_window_search(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float minX, float minY, float maxX, float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, float th, int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist);
+void* ccmh_fuse_batch_create_cand(int device, int S, const int32_t* kf_off, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, const float* const* inv_sigma2, const int32_t* pt_off, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, const int32_t* cand_off, const int32_t* cand_base, const int32_t* cand_idx, int chi2_gate, int dist_threshold);
+int ccmh_fuse_batch_resolve(void* h, int s, const uint8_t* skip_now, int n_pts, int32_t* best_idx, int32_t* best_dist);
+void ccmh_fuse_batch_destroy(void* h);
 int ccmh_projected_window_search_cand(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, const int32_t* cand_off, const int32_t* cand_idx, int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist);
 int ccmh_projected_window_search_dev(int device, const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float maxX, float maxY, const float* scale_factors, const float* inv_sigma2, int n_pts, const uint8_t* valid, const float* u, const float* v, const int32_t* level, const uint8_t* pdesc, float th, int chi2_gate, int dist_threshold, int32_t* matched, int claim, const uint8_t* no_claim, int32_t* best_idx, int32_t* best_dist);
 int ccmh_bow_transform(int device, int n_nodes, int L, const int32_t* child_off, const int32_t* child_id, const uint8_t* node_desc, const int32_t* word_id, const double* weight, const uint8_t* desc, int N, int levelsup, int32_t* bow_ids, double* bow_vals, int32_t* fv_nodes, int32_t* fv_off, int32_t* fv_idx, int32_t* sizes );

@@ -383,6 +383,76 @@ int ref_fuse(const float* kx, const float* ky, const int32_t* oct, const uint8_t
   return n;
 }
 
+// The fan-out of LocalMapping::SearchInNeighbors (Mapping.cpp:469-503), replayed as the reference writes it: the current keyframe's best covisibility neighbours become
+// fuse targets and are marked (mFuseTargetForKF), each contributes up to five second neighbours (a LATER first-level neighbour listed there is not marked yet and is
+// pushed twice), then matcher.Fuse(pKFi, vpMapPointMatches) runs for every target in order on the SAME vector of the current keyframe's points.  All S keyframes share
+// one feature set (frame geometry) and differ in pose and in which features hold points.  nb1 [n1]: the current keyframe's covisibility list (indices into the S
+// keyframes); nb2 [S][5]: every keyframe's own best covisibility list (-1 = none, -2 = the current keyframe).  Per call c: call_target[c], n_out[c] and best_idx[c][i] =
+// the feature point i was fused with IN THAT CALL (recovered from what the call did to the map), -1 otherwise.
+int ref_fuse_fan_out(const float* kx, const float* ky, const int32_t* oct, const uint8_t* kdesc, int N, float minX, float minY, float maxX, float maxY, const float* sf,
+                     const float* inv_sigma2, const float* K4, int S, const float* T16s, const uint8_t* kf_has_mp, int n1, const int32_t* nb1, const int32_t* nb2,
+                     int n_pts, const float* Xw, const float* normal, const float* dmin, const float* dmax, const uint8_t* pdesc, float th, int max_calls,
+                     int32_t* call_target, int32_t* n_out, int32_t* best_idx) {
+  std::unique_ptr<KeyFrame[]> kfs(new KeyFrame[S + 1]);
+  std::vector<kfptr> k(S + 1);
+  for (int j = 0; j <= S; j++) k[j] = kfptr(&kfs[j], [](KeyFrame*) {});
+  std::vector<std::unique_ptr<Pool>> inkf;
+  for (int s = 0; s < S; s++) {
+    setup_keyframe(k[s], kx, ky, oct, kdesc, N, minX, minY, maxX, maxY, sf, inv_sigma2, K4, T16s + 16 * (size_t)s);
+    k[s]->mId = std::make_pair((size_t)(10 + s), (size_t)0); k[s]->mUniqueId = 10 + s;
+    inkf.emplace_back(new Pool(N));
+    for (int j = 0; j < N; j++) if (kf_has_mp[(size_t)s * N + j]) { inkf[s]->store[j].nObs = 3 + (j % 5); inkf[s]->store[j].mObservations[k[s]] = (size_t)j; k[s]->mvpMapPoints[j] = inkf[s]->at(j); }
+  }
+  kfptr cur = k[S];
+  cur->mId = std::make_pair((size_t)500, (size_t)0); cur->mUniqueId = 500; cur->N = n_pts;
+  Pool pts(n_pts);
+  setup_points(pts, n_pts, Xw, normal, dmin, dmax, pdesc, 4);
+  cur->mvpMapPoints.assign(n_pts, mpptr());
+  for (int i = 0; i < n_pts; i++) { cur->mvpMapPoints[i] = pts.at(i); pts.store[i].mObservations[cur] = (size_t)i; }
+  for (int a = 0; a < n1; a++) { cur->mvpOrderedConnectedKeyFrames.push_back(k[nb1[a]]); cur->mvOrderedWeights.push_back(1000 - a); cur->mConnectedKeyFrameWeights[k[nb1[a]]] = 1000 - a; }
+  for (int s = 0; s < S; s++)
+    for (int b = 0; b < 5; b++) {
+      const int o = nb2[5 * s + b];
+      if (o == -1) continue;
+      kfptr other = o == -2 ? cur : k[o];
+      k[s]->mvpOrderedConnectedKeyFrames.push_back(other); k[s]->mvOrderedWeights.push_back(900 - b); k[s]->mConnectedKeyFrameWeights[other] = 900 - b;
+    }
+  // ---- Mapping.cpp:472-492 ----
+  const std::vector<kfptr> vpNeighKFs = cur->GetBestCovisibilityKeyFrames(20);
+  std::vector<kfptr> vpTargetKFs;
+  for (std::vector<kfptr>::const_iterator vit = vpNeighKFs.begin(); vit != vpNeighKFs.end(); vit++) {
+    kfptr pKFi = *vit;
+    if (pKFi->isBad() || pKFi->mFuseTargetForKF == cur->mId) continue;
+    vpTargetKFs.push_back(pKFi);
+    pKFi->mFuseTargetForKF = cur->mId;
+    const std::vector<kfptr> vpSecondNeighKFs = pKFi->GetBestCovisibilityKeyFrames(5);
+    for (std::vector<kfptr>::const_iterator vit2 = vpSecondNeighKFs.begin(); vit2 != vpSecondNeighKFs.end(); vit2++) {
+      kfptr pKFi2 = *vit2;
+      if (pKFi2->isBad() || pKFi2->mFuseTargetForKF == cur->mId || pKFi2->mId == cur->mId) continue;
+      vpTargetKFs.push_back(pKFi2);
+    }
+  }
+  // ---- Mapping.cpp:495-503 ----
+  cslam::ORBmatcher matcher(0.6f, true);
+  std::vector<mpptr> vpMapPointMatches = cur->GetMapPointMatches();
+  int c = 0;
+  for (std::vector<kfptr>::iterator vit = vpTargetKFs.begin(); vit != vpTargetKFs.end() && c < max_calls; vit++, c++) {
+    kfptr pKFi = *vit;
+    std::vector<char> in_before(n_pts), rep_before(n_pts);
+    for (int i = 0; i < n_pts; i++) { in_before[i] = pts.store[i].IsInKeyFrame(pKFi); rep_before[i] = pts.store[i].mpReplaced != nullptr; }
+    n_out[c] = matcher.Fuse(pKFi, vpMapPointMatches, th);
+    call_target[c] = (int32_t)(pKFi.get() - kfs.get());
+    int32_t* b = best_idx + (size_t)c * n_pts;
+    for (int i = 0; i < n_pts; i++) {
+      b[i] = -1;
+      MapPoint& p = pts.store[i];
+      if (!rep_before[i] && p.mpReplaced) b[i] = p.mpReplaced->GetIndexInKeyFrame(pKFi);
+      else if (!in_before[i] && !p.isBad() && p.IsInKeyFrame(pKFi)) b[i] = p.GetIndexInKeyFrame(pKFi);
+    }
+  }
+  return c;
+}
+
 namespace {
 void decompose_scw(const float* S16, cv::Mat& Rcw, cv::Mat& tcw, cv::Mat& Ow) {   // ORBmatcher.cpp:316-321 / 1004-1008
   cv::Mat Scw(4, 4, CV_32F); std::memcpy(Scw.data, S16, 64);

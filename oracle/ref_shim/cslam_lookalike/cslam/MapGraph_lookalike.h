@@ -93,6 +93,7 @@ class KeyFrame : public boost::enable_shared_from_this<KeyFrame> {
   std::vector<kfptr> mvpOrderedConnectedKeyFrames;
   std::vector<int> mvOrderedWeights;
   std::map<kfptr, int> mConnectedKeyFrameWeights;
+  idpair mFuseTargetForKF = defpair;         // KeyFrame.h:294 (LocalMapping::SearchInNeighbors marks its first-level fuse targets, Mapping.cpp:481-482)
   std::vector<kfptr> GetVectorCovisibleKeyFrames() { return mvpOrderedConnectedKeyFrames; }
   std::vector<kfptr> GetBestCovisibilityKeyFrames(const int& N) {   // KeyFrame.cpp:443-451: the N strongest neighbours (all of them when there are fewer)
     if ((int)mvpOrderedConnectedKeyFrames.size() < N) return mvpOrderedConnectedKeyFrames;

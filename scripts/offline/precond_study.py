@@ -155,7 +155,7 @@ elif what == "f32":
         xe = np.linalg.solve(H, b)
         x64, it64 = pcg(H, b, M, np.zeros_like(b), tgt)
         row = [f"lambda {lam:.3g}: f64 {it64} it (err {np.linalg.norm(x64 - xe) / np.linalg.norm(xe):.1e})"]
-        for R in (0, 4, 8, 16):
+        for R in (0, 4, 8, 10, 12, 14, 16):
             x, it = pcg_f32(H, H32, b, M, tgt, R)
             true_res = b - H @ x
             row.append(f"R={R}: {it} it, err {np.linalg.norm(x - xe) / np.linalg.norm(xe):.1e}, true |r|_M/|b|_M {np.sqrt(true_res @ M(true_res)) / np.sqrt(b @ M(b)):.1e}")

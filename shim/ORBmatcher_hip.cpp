@@ -16,6 +16,7 @@
 
 #include <climits>
 #include <memory>
+#include <set>
 #include <cstdlib>
 #include <cstring>
 
@@ -421,13 +422,11 @@ int ORBmatcher::SearchBySim3(kfptr pKF1, kfptr pKF2, std::vector<mpptr>& vpMatch
   return nFound;
 }
 
-// M7 — ORBmatcher.cpp:854-993
-int ORBmatcher::Fuse(kfptr pKF, const vector<mpptr>& vpMapPoints, const float th) {
+namespace {
+// the tests that precede Fuse's candidate loop (ORBmatcher.cpp:868-913) for every point of the list, against one keyframe
+void fuse_project(const kfptr& pKF, const vector<mpptr>& vpMapPoints, float th, Projection& P) {
   const cv::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
-  const size_t n = vpMapPoints.size();
-  FlatKeys K(pKF->mvKeysUn, pKF->mDescriptors);
-  Projection P(n);
-  for (size_t i = 0; i < n; i++) {
+  for (size_t i = 0; i < vpMapPoints.size(); i++) {
     const mpptr& pMP = vpMapPoints[i];
     if (pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF)) {
       const cv::Mat p3Dw = pMP->GetWorldPos();
@@ -440,8 +439,115 @@ int ORBmatcher::Fuse(kfptr pKF, const vector<mpptr>& vpMapPoints, const float th
     }
     close_row(P, i);
   }
+}
+
+// (round 6) LocalMapping::SearchInNeighbors (Mapping.cpp:469-503) calls Fuse(pKFi, vpMapPointMatches) for every fuse target of the new keyframe — its (up to 20) best
+// covisibility neighbours and up to five second neighbours of each — one after the other on the SAME vector.  Mapping.cpp is not ours to change, but its first call tells
+// what the next ones will be: the first target carries the current keyframe's id in mFuseTargetForKF (Mapping.cpp:481), the current keyframe is among its covisible
+// keyframes, and the target list follows from the covisibility lists by the reference's own rules.  On a call with a vector this thread has not seen, the shim replays
+// that walk, projects the points into ALL predicted targets and sends their Hamming work to the MI355X as one launch (ccmh_fuse_batch_create_cand ->
+// ccm_hamming_csr_multi); every call — the first included — is then answered from the tables with the points' flags AS THEY ARE AT THAT CALL: what the calls change for
+// each other is only that a point has turned bad (Replace) or has joined the keyframe meanwhile, and such a point is skipped exactly as the reference's loop would
+// (ORBmatcher.cpp:884-888).  Poses, positions, descriptors and distance ranges do not change inside the loop.  A call the prediction did not foresee drops the tables and
+// takes the single-call path.  CCM_SHIM_FUSE_BATCH=0 switches the prediction off.
+struct FuseFanOut {
+  const void* pts = nullptr; size_t n = 0; float th = 0.f; const void* first = nullptr; const void* last = nullptr;
+  std::vector<const KeyFrame*> tg; std::vector<idpair> tg_id; size_t cursor = 0;
+  void* h = nullptr;
+  void drop() { if (h) ccmh_fuse_batch_destroy(h); h = nullptr; pts = nullptr; tg.clear(); tg_id.clear(); cursor = 0; }
+  ~FuseFanOut() { drop(); }
+};
+thread_local FuseFanOut g_fuse;
+bool fuse_batch_enabled() { static const bool on = !(std::getenv("CCM_SHIM_FUSE_BATCH") && std::atoi(std::getenv("CCM_SHIM_FUSE_BATCH")) == 0); return on; }
+
+void fuse_predict(FuseFanOut& c, const kfptr& pKF, const vector<mpptr>& vpMapPoints, float th) {
+  const idpair curId = pKF->mFuseTargetForKF;
+  kfptr cur;
+  {
+    const std::vector<kfptr> cov = pKF->GetVectorCovisibleKeyFrames();
+    for (size_t j = 0; j < cov.size(); j++) if (cov[j] && cov[j]->mId == curId) { cur = cov[j]; break; }
+  }
+  if (!cur || (size_t)cur->N != vpMapPoints.size()) return;                 // not the fan-out of SearchInNeighbors (vpMapPointMatches has one entry per feature)
+  // Mapping.cpp:472-492 replayed; the marks the reference has already set are reproduced with a local set (a second neighbour is tested against the marks of the
+  // first-level neighbours BEFORE it in the walk only)
+  std::vector<kfptr> targets;
+  std::set<const KeyFrame*> marked;
+  const std::vector<kfptr> vpNeighKFs = cur->GetBestCovisibilityKeyFrames(20);
+  for (size_t a = 0; a < vpNeighKFs.size(); a++) {
+    const kfptr& pKFi = vpNeighKFs[a];
+    if (pKFi->isBad() || marked.count(pKFi.get())) continue;
+    if (!(pKFi->mFuseTargetForKF == curId)) return;                         // the reference marked every first-level target before its first call: not this walk
+    targets.push_back(pKFi); marked.insert(pKFi.get());
+    const std::vector<kfptr> vpSecond = pKFi->GetBestCovisibilityKeyFrames(5);
+    for (size_t b = 0; b < vpSecond.size(); b++) {
+      const kfptr& pKFi2 = vpSecond[b];
+      if (pKFi2->isBad() || marked.count(pKFi2.get()) || pKFi2->mId == curId) continue;
+      targets.push_back(pKFi2);
+    }
+  }
+  if (targets.size() < 2 || targets[0] != pKF) return;
+  const int S = (int)targets.size();
+  const size_t n = vpMapPoints.size();
+  std::vector<int32_t> kf_off(S + 1, 0), pt_off(S + 1, 0), oct, level, cand_off, cand_base(S, 0), cand_idx;
+  std::vector<float> kx, ky, u, v;
+  std::vector<uint8_t> kdesc, valid, pdesc;
+  std::vector<const float*> isig(S);
+  for (int s = 0; s < S; s++) {
+    const kfptr& t = targets[s];
+    FlatKeys K(t->mvKeysUn, t->mDescriptors);
+    kx.insert(kx.end(), K.x.begin(), K.x.end()); ky.insert(ky.end(), K.y.begin(), K.y.end()); oct.insert(oct.end(), K.oct.begin(), K.oct.end());
+    kdesc.insert(kdesc.end(), K.desc, K.desc + (size_t)K.N * 32);
+    kf_off[s + 1] = kf_off[s] + K.N;
+    Projection P(n);
+    fuse_project(t, vpMapPoints, th, P);
+    valid.insert(valid.end(), P.valid.begin(), P.valid.end()); u.insert(u.end(), P.u.begin(), P.u.end()); v.insert(v.end(), P.v.begin(), P.v.end());
+    level.insert(level.end(), P.level.begin(), P.level.end()); pdesc.insert(pdesc.end(), P.desc.begin(), P.desc.end());
+    pt_off[s + 1] = pt_off[s] + (int32_t)n;
+    cand_off.insert(cand_off.end(), P.cand_off.begin(), P.cand_off.end());
+    cand_base[s] = (int32_t)cand_idx.size();
+    cand_idx.insert(cand_idx.end(), P.cand_idx.begin(), P.cand_idx.end());
+    isig[s] = t->mvInvLevelSigma2.data();
+  }
+  if (cand_idx.empty()) cand_idx.push_back(0);
+  c.h = ccmh_fuse_batch_create_cand(device(), S, kf_off.data(), kx.data(), ky.data(), oct.data(), kdesc.data(), isig.data(), pt_off.data(), valid.data(), u.data(), v.data(),
+                                    level.data(), pdesc.data(), cand_off.data(), cand_base.data(), cand_idx.data(), 1, ORBmatcher::TH_LOW);
+  if (!c.h) checked(-1000, "Fuse (fan-out)");
+  c.pts = vpMapPoints.data(); c.n = n; c.th = th; c.first = vpMapPoints.front().get(); c.last = vpMapPoints.back().get(); c.cursor = 0;
+  for (int s = 0; s < S; s++) { c.tg.push_back(targets[s].get()); c.tg_id.push_back(targets[s]->mId); }
+}
+}  // namespace
+
+// M7 — ORBmatcher.cpp:854-993
+int ORBmatcher::Fuse(kfptr pKF, const vector<mpptr>& vpMapPoints, const float th) {
+  const size_t n = vpMapPoints.size();
   std::vector<int32_t> best;
-  window_search(pKF, K, P, true, TH_LOW, nullptr, false, nullptr, best, "Fuse");
+  bool answered = false;
+  if (fuse_batch_enabled() && n > 0 && pKF->N > 0) {
+    FuseFanOut& c = g_fuse;
+    auto entry = [&]() -> int {
+      if (!c.h || c.pts != vpMapPoints.data() || c.n != n || c.th != th || c.first != vpMapPoints.front().get() || c.last != vpMapPoints.back().get()) return -1;
+      for (size_t e = c.cursor; e < c.tg.size(); e++) if (c.tg[e] == pKF.get() && c.tg_id[e] == pKF->mId) return (int)e;
+      return -1;
+    };
+    int e = entry();
+    if (e < 0) { c.drop(); fuse_predict(c, pKF, vpMapPoints, th); e = entry(); }
+    if (e >= 0) {
+      std::vector<uint8_t> skip(n, 0);
+      for (size_t i = 0; i < n; i++) { const mpptr& pMP = vpMapPoints[i]; skip[i] = !(pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF)); }
+      best.assign(n, -1);
+      std::vector<int32_t> bestDist(n, INT_MAX);
+      checked(ccmh_fuse_batch_resolve(c.h, e, skip.data(), (int)n, best.data(), bestDist.data()), "Fuse (fan-out)");
+      c.cursor = (size_t)e + 1;
+      if (c.cursor == c.tg.size()) c.drop();
+      answered = true;
+    }
+  }
+  if (!answered) {
+    FlatKeys K(pKF->mvKeysUn, pKF->mDescriptors);
+    Projection P(n);
+    fuse_project(pKF, vpMapPoints, th, P);
+    window_search(pKF, K, P, true, TH_LOW, nullptr, false, nullptr, best, "Fuse");
+  }
   // the map is mutated point by point: a point replaced (now bad) or adopted by the keyframe (Replace moved the observation) earlier in this loop is
   // skipped when its turn comes, exactly as the reference's per-point tests would
   int nFused = 0;

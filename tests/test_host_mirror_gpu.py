@@ -366,3 +366,62 @@ def test_search_by_projection_through_the_device_grid(hostlib, oracle_lib):
     assert np.array_equal(xy_un, xy_o)
     assert n == exp_n and n > 500
     assert np.array_equal(got, exp)
+
+
+def test_fuse_fan_out_of_twenty_target_keyframes_in_one_launch(hostlib, oracle_lib):
+    """LocalMapping::SearchInNeighbors (Mapping.cpp:497-503) calls matcher.Fuse(pKFi, vpMapPointMatches) for every target keyframe (20 neighbours + second neighbours).
+    FuseBatch sends the Hamming work of ALL targets out as one ccm_hamming_csr_multi launch; resolve(s) must return exactly what the single projected window search of
+    target s returns (host mirror, one launch per call) and what the oracle's sequential restatement returns — also when points have turned bad / have joined the
+    keyframe since the batch was built (the reference's loop skips them, ORBmatcher.cpp:884-888)."""
+    ext = oracle_lib.OrbOracle(1000)
+    S = 20
+    frames = [ext.extract(synth.gen_image(1000 + s // 5, s % 5)) for s in range(S)]
+    rng = np.random.default_rng(77)
+    sf, _, _, is2 = synth.scale_tables()
+    c = np.ascontiguousarray
+    n_pts = 900                                                 # the current keyframe's map points, projected into every target
+    kf_off, pt_off = [0], [0]
+    kx, ky, oc, kd, bounds, valid, u, v, level, pdesc = [], [], [], [], [], [], [], [], [], []
+    for kps, desc in frames:
+        N = len(kps)
+        src = rng.integers(0, N, n_pts)
+        kx.append(c(kps["x"])); ky.append(c(kps["y"])); oc.append(c(kps["octave"])); kd.append(desc)
+        bounds.append([0.0, 0.0, 752.0, 480.0])
+        u.append((kps["x"][src] + rng.normal(0, 1.5, n_pts)).astype(np.float32)); v.append((kps["y"][src] + rng.normal(0, 1.5, n_pts)).astype(np.float32))
+        level.append(np.clip(kps["octave"][src] + rng.integers(0, 2, n_pts), 0, 7).astype(np.int32))
+        valid.append((rng.random(n_pts) < 0.8).astype(np.uint8))
+        bits = np.unpackbits(desc[src], axis=1)
+        pdesc.append(np.packbits(bits ^ (rng.random(bits.shape) < 0.06), axis=1))
+        kf_off.append(kf_off[-1] + N); pt_off.append(pt_off[-1] + n_pts)
+    cat = lambda xs, dt: c(np.concatenate(xs).astype(dt))
+    KX, KY, OC, KD = cat(kx, np.float32), cat(ky, np.float32), cat(oc, np.int32), c(np.concatenate(kd))
+    B = c(np.array(bounds, np.float32)); VA, U, V, LV, PD = cat(valid, np.uint8), cat(u, np.float32), cat(v, np.float32), cat(level, np.int32), c(np.concatenate(pdesc))
+    KO, PO = np.array(kf_off, np.int32), np.array(pt_off, np.int32)
+    hostlib.ccmh_fuse_batch_create.restype = C.c_void_p
+    hostlib.ccmh_fuse_batch_create.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 14 + [C.c_float]
+    hostlib.ccmh_fuse_batch_candidates.restype = C.c_longlong
+    hostlib.ccmh_fuse_batch_candidates.argtypes = [C.c_void_p]
+    hostlib.ccmh_fuse_batch_resolve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    hostlib.ccmh_fuse_batch_destroy.argtypes = [C.c_void_p]; hostlib.ccmh_fuse_batch_destroy.restype = None
+    h = hostlib.ccmh_fuse_batch_create(0, S, _p(KO), _p(KX), _p(KY), _p(OC), _p(KD), _p(B), _p(sf), _p(is2), _p(PO), _p(VA), _p(U), _p(V), _p(LV), _p(PD), 3.0)
+    assert h, "ccmh_fuse_batch_create failed"
+    assert hostlib.ccmh_fuse_batch_candidates(h) > 5 * S * n_pts // 10
+    total = 0
+    for s in range(S):
+        kps, desc = frames[s]
+        N = len(kps)
+        # points that earlier calls of the loop turned bad (Replace) or added to this keyframe: skipped now
+        skip = (rng.random(n_pts) < (0.0 if s == 0 else 0.15)).astype(np.uint8)
+        bi = np.zeros(n_pts, np.int32); bd = np.zeros(n_pts, np.int32)
+        n = hostlib.ccmh_fuse_batch_resolve(h, s, _p(skip), n_pts, _p(bi), _p(bd))
+        valid_now = (valid[s] & (1 - skip)).astype(np.uint8)
+        exp_n, ebi, ebd, _ = oracle_lib.projected_window_search(kps["x"], kps["y"], kps["octave"], desc, (0.0, 0.0, 752.0, 480.0), sf, is2, valid_now, u[s], v[s], level[s],
+                                                                pdesc[s], 3.0, 1, 50, None, 0, np.zeros(n_pts, np.uint8))
+        assert n == exp_n and np.array_equal(bi, ebi) and np.array_equal(bd, ebd), s
+        gbi = np.zeros(n_pts, np.int32); gbd = np.zeros(n_pts, np.int32)
+        n1 = hostlib.ccmh_projected_window_search(0, _p(kx[s]), _p(ky[s]), _p(oc[s]), _p(desc), N, *[C.c_float(b) for b in (0.0, 0.0, 752.0, 480.0)], _p(sf), _p(is2), n_pts,
+                                                  _p(valid_now), _p(u[s]), _p(v[s]), _p(level[s]), _p(pdesc[s]), C.c_float(3.0), 1, 50, None, 0, None, _p(gbi), _p(gbd))
+        assert n1 == n and np.array_equal(gbi, bi) and np.array_equal(gbd, bd), s
+        total += n
+    assert total > 100 * S
+    hostlib.ccmh_fuse_batch_destroy(h)

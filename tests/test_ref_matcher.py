@@ -299,6 +299,57 @@ def test_fuse_M7_chi2_gate(rlib, frames):
         assert en2 > en
 
 
+def _fuse_fan_out_case(frames, seed=17, S=8):
+    """SearchInNeighbors' fan-out: S target keyframes around one pose (same features, poses a few centimetres / tenths of a degree apart, own sets of occupied features),
+    a current keyframe whose points project into all of them; first-level neighbours 0..4 (in that order), second neighbours chosen so that the walk meets an already
+    marked keyframe, the current keyframe itself, an unmarked LATER first-level neighbour (pushed twice) and keyframes that are second neighbours only."""
+    s = _projected_case(frames, seed)
+    rng = s["rng"]
+    Ts = np.zeros((S, 4, 4), np.float32)
+    for k in range(S):
+        a = 0.3 + 0.004 * rng.normal()
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = np.array([0.4, -0.2, 0.7]) + 0.01 * rng.normal(size=3)
+        Ts[k] = T.astype(np.float32)
+    has = (rng.random((S, s["N"])) < 0.5).astype(np.uint8)
+    nb1 = np.array([0, 1, 2, 3, 4], np.int32)
+    nb2 = -np.ones((S, 5), np.int32)
+    nb2[0, :4] = [-2, 1, 5, 6]      # the current keyframe (skipped), a later first-level neighbour (not marked yet: pushed here AND as first-level), two second-only
+    nb2[1, :3] = [0, -2, 5]         # an already marked one (skipped), current, 5 again (second neighbours are never marked: pushed again)
+    nb2[2, :2] = [7, 3]
+    nb2[4, :1] = [6]
+    return s, c(Ts), c(has), nb1, c(nb2)
+
+
+def _run_fuse_fan_out(lib, s, Ts, has, nb1, nb2, max_calls=32):
+    kps = s["kps"]; S = Ts.shape[0]; n = s["n_pts"]
+    call_target = -np.ones(max_calls, np.int32); n_out = np.zeros(max_calls, np.int32); best = -np.ones((max_calls, n), np.int32)
+    lib.ref_fuse_fan_out.restype = C.c_int
+    nc = lib.ref_fuse_fan_out(_p(c(kps["x"])), _p(c(kps["y"])), _p(c(kps["octave"])), _p(s["desc"]), s["N"], *fb, _p(s["sf"]), _p(s["isig"]), _p(s["K4"]), S, _p(Ts), _p(has),
+                              len(nb1), _p(nb1), _p(nb2), n, _p(s["Xw"]), _p(s["normal"]), _p(s["dmin"]), _p(s["dmax"]), _p(s["pdesc"]), C.c_float(3.0), max_calls,
+                              _p(call_target), _p(n_out), _p(best))
+    return nc, call_target[:nc], n_out[:nc], best[:nc]
+
+
+def test_fuse_fan_out_of_search_in_neighbors_M7_xS(rlib, frames):
+    """LocalMapping::SearchInNeighbors' first loop (Mapping.cpp:469-503) on the reference's own ORBmatcher.cpp: the target walk and a sequence of Fuse calls that change
+    the map for each other.  Pins the ORDER of the targets (incl. the keyframe pushed twice) and that every call fuses a substantial, different set of points; the
+    drop-in's prediction of this very sequence is compared with it call by call in tests/test_shim_matcher_gpu.py."""
+    s, Ts, has, nb1, nb2 = _fuse_fan_out_case(frames)
+    nc, tgt, n_out, best = _run_fuse_fan_out(rlib, s, Ts, has, nb1, nb2)
+    assert tgt.tolist() == [0, 1, 5, 6, 1, 5, 2, 7, 3, 3, 4, 6]
+    first_visits = [0, 1, 2, 3, 6, 7, 8, 10]
+    assert n_out[0] > 800 and (n_out[first_visits] > 100).all()
+    fused = best >= 0
+    # (what a call did to the map identifies the fused feature of all but a handful of its points: a point added to a feature and displaced again inside the same call)
+    assert (fused.sum(1) <= n_out).all() and (fused.sum(1) >= 0.98 * n_out).all()
+    # a point fused into a keyframe is in it (or bad) afterwards: the second visit of keyframes 1, 5, 3 and 6 finds nothing left to fuse
+    for first, second in ((1, 4), (2, 5), (8, 9), (3, 11)):
+        assert not (fused[first] & fused[second]).any() and n_out[second] < n_out[first]
+    # the calls change the map for each other: points replaced in an earlier call are bad in the later ones, so a later call on an untouched copy would fuse more
+    assert fused[1:].sum() > 1000
+
+
 def test_fuse_sim3_M8(rlib, frames):
     """ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cpp:995-1122): Sim3 decomposition, no chi2 gate, replacements returned."""
     s = _projected_case(frames, 8, sim3_scale=1.7)

@@ -101,3 +101,35 @@ def test_shim_and_reference_libraries_agree_call_by_call(slib, frames):
     assert outs[0][0] == outs[1][0] > 500
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert np.array_equal(a, b)
+
+
+def test_M7_fan_out_of_search_in_neighbors_through_the_class_api(slib, frames):
+    """LocalMapping::SearchInNeighbors' sequence of Fuse calls (Mapping.cpp:469-503, replayed by oracle/ref_matcher_driver.cpp::ref_fuse_fan_out) on shim/ORBmatcher_hip.cpp:
+    its first call predicts the twelve targets of the walk (one keyframe twice as first-level and second neighbour, second-only keyframes, repeats), projects the points
+    into all of them and sends the Hamming work out as ONE launch (ccm_hamming_csr_multi); every call is answered from those tables with the points' flags as they are
+    at that call.  Same targets, same return values, same fused feature for every point in every call as the reference's own ORBmatcher.cpp on the same scenario."""
+    rlib = C.CDLL(trm.LIB)
+    s, Ts, has, nb1, nb2 = trm._fuse_fan_out_case(frames)
+    nc_r, tgt_r, n_r, best_r = trm._run_fuse_fan_out(rlib, s, Ts, has, nb1, nb2)
+    nc_s, tgt_s, n_s, best_s = trm._run_fuse_fan_out(slib, s, Ts, has, nb1, nb2)
+    assert nc_r == nc_s == 12 and np.array_equal(tgt_r, tgt_s)
+    assert np.array_equal(n_r, n_s), (n_r, n_s)
+    assert np.array_equal(best_r, best_s)
+    # a walk that stops early (LocalMapping is interrupted): the tables of the unfinished fan-out must not leak into the next one
+    nc2, tgt2, n2, best2 = trm._run_fuse_fan_out(slib, s, Ts, has, nb1, nb2, max_calls=5)
+    assert nc2 == 5 and np.array_equal(n2, n_r[:5]) and np.array_equal(best2, best_r[:5])
+    nc3, tgt3, n3, best3 = trm._run_fuse_fan_out(slib, s, Ts, has, nb1, nb2)
+    assert np.array_equal(n3, n_r) and np.array_equal(best3, best_r)
+
+
+def test_M7_fan_out_without_the_prediction_is_the_same(frames):
+    import subprocess, sys
+    code = ("import ctypes as C, numpy as np, tests.test_ref_matcher as trm, tests.test_shim_matcher_gpu as t, oracle\n"
+            "from ccm_slam_amd import synth\n"
+            "o = oracle.OrbOracle(1000); fr = [o.extract(synth.gen_image(1000, k)) for k in (0, 1)]; o.close()\n"
+            "case = trm._fuse_fan_out_case(fr)\n"
+            "r = trm._run_fuse_fan_out(C.CDLL(trm.LIB), *case); q = trm._run_fuse_fan_out(C.CDLL(t.SHIM), *case)\n"
+            "assert r[0] == q[0] and all(np.array_equal(a, b) for a, b in zip(r[1:], q[1:]))\nprint('ok')\n")
+    env = dict(os.environ, CCM_SHIM_FUSE_BATCH="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
