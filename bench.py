@@ -677,7 +677,9 @@ def pmc_source(workload):
     try:
         name = "pmc_latest.json" if workload == "gba_c4" else f"pmc_{workload}.json"
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-        tag = pmc.get("tag") or pmc.get("source", "")[-8:]
+        import re as _re
+        m = _re.search(r"\((r\d+\w*)\)\s*$", pmc.get("source", ""))
+        tag = pmc.get("tag") or (m.group(1) if m else "")
         return f"profiles/{name} ({tag}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 2 x FETCH + WRITE per launch); not collected inside this process"
     except Exception:
         return None

@@ -2025,6 +2025,9 @@ __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambd
       if (s + 1 < nact) {
         double xa[4], xb[4], ya[4], yb[4];
         load_ops(s, xa, xb); load_ops(s + 1, ya, yb);
+#ifdef CR_EXPERIMENT_NO_MFMA   /* timing experiment only (results are wrong): what phase (3) costs without its matrix instructions */
+        acc[s][0] += xa[0] * xb[0] + xa[1] * xb[1] + xa[2] * xb[2] + xa[3] * xb[3]; acc[s + 1][0] += ya[0] * yb[0] + ya[1] * yb[1] + ya[2] * yb[2] + ya[3] * yb[3];
+#else
         asm volatile("v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %1, %10, %14, %1\n\t"
                      "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %1, %11, %15, %1\n\t"
                      "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\tv_mfma_f64_16x16x4_f64 %1, %12, %16, %1\n\t"
@@ -2033,6 +2036,7 @@ __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambd
                      : "+v"(acc[s]), "+v"(acc[s + 1])
                      : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]),
                        "v"(ya[0]), "v"(ya[1]), "v"(ya[2]), "v"(ya[3]), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]));
+#endif
         park(s); park(s + 1);
       } else if (s < nact) {
         double xa[4], xb[4];
