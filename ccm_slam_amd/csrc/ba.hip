@@ -1873,6 +1873,47 @@ __global__ __launch_bounds__(kCRTPB) void ba_cholreg_table(BaDev d, int* table /
   }
 }
 
+// Phase (3) of ba_solve_cholreg for the slots S, S + 1, ... of one wave: (-A_IJ) += L_IT L_JT^T in place, with the operands of slot S + 1 requested BEFORE slot S
+// multiplies.  The slots a step still updates are a prefix [0, nact) of the wave's slots, so the blocks are NESTED (slot S + 1 lives inside slot S's block): what a
+// block loads for the next one is simply in scope there — as sibling blocks behind their own `if`, every operand register became a phi of "loaded" and "not loaded",
+// and the register allocator answered with copies and scratch spills.
+struct CrStep { const double* P; double* Pn; int T, NT, R_n, wave, i16, kq, tvec; };
+typedef double cr_v4d __attribute__((ext_vector_type(4)));
+typedef double cr_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cr_load_ops(const CrStep& c, int s, double (&xa)[4], double (&xb)[4]) {
+  const int ij = __builtin_amdgcn_readlane(c.tvec, s);
+  const int I = min(max((ij >> 8) - c.T, 0), c.NT - 1 - c.T), J = min(max((ij & 255) - c.T, 0), c.NT - 1 - c.T);   // (clamped: the last block of a chain loads for a slot that is not updated)
+  // k-step kk of the four MFMAs takes k = 4 kq + kk from lane group kq — on both operands, so the sixteen products of an entry are the same ones, summed in another
+  // order — which makes a lane's four operand values CONTIGUOUS: two 16-byte LDS reads per operand, conflict-free at the row stride of 18 doubles
+  const cr_v2d* pa = reinterpret_cast<const cr_v2d*>(c.P + (16 * I + c.i16) * kCRStride + 4 * c.kq);
+  const cr_v2d* pb = reinterpret_cast<const cr_v2d*>(c.P + (16 * J + c.i16) * kCRStride + 4 * c.kq);
+  const cr_v2d a01 = pa[0], a23 = pa[1], b01 = pb[0], b23 = pb[1];
+  xa[0] = a01[0]; xa[1] = a01[1]; xa[2] = a23[0]; xa[3] = a23[1]; xb[0] = b01[0]; xb[1] = b01[1]; xb[2] = b23[0]; xb[3] = b23[1];
+}
+template <int S>
+__device__ __forceinline__ void cr_update_chain(cr_v4d (&acc)[kCRSlots], const CrStep& c, int nact, const double (&xa)[4], const double (&xb)[4]) {
+  if constexpr (S < kCRSlots) {
+    if (S < nact) {
+      double na[4], nb[4];
+      if constexpr (S + 1 < kCRSlots) cr_load_ops(c, S + 1, na, nb);
+#ifndef CR_EXPERIMENT_NO_MFMA   /* timing experiment only (results are wrong): what the phase costs without its matrix instructions */
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0"
+                   : "+v"(acc[S]) : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]));
+#else
+      acc[S][0] += xa[0] * xb[0] + xa[1] * xb[1] + xa[2] * xb[2] + xa[3] * xb[3];
+#endif
+      const int rho = kCRWaves * S + c.wave;
+      if (rho >= c.R_n) {                                    // column T + 1: up to date now -> the other panel buffer (the accumulators hold minus the matrix)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[S]));   // the compiler does not see the MFMAs inside the asm above: 18 wait states before a vector instruction reads the result of a 16x16 f64 MFMA
+        const int rb = 16 * (rho - c.R_n);
+#pragma unroll
+        for (int r = 0; r < 4; r++) c.Pn[(rb + c.kq + 4 * r) * kCRStride + c.i16] = -acc[S][r];
+      }
+      if constexpr (S + 1 < kCRSlots) cr_update_chain<S + 1>(acc, c, nact, na, nb);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambda, double* gL /* [n_pad][n_pad] scratch: the factor's rows below the diagonal tiles, written once and read once */, const int* table,
                                                              long long* dbg /* nullable: [8] phase clocks (10 ns ticks) + launches */, int cur, int add_lambda_term) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -2003,49 +2044,11 @@ __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambd
       if (t < 16) Pn[(16 + rows_below - 16) * kCRStride + t] = sv;       // the next step's right-hand side row (its rows_below is 16 less)
     }
     const int nact = min(max((R_T - wave + kCRWaves - 1) / kCRWaves, 0), kCRSlots);     // this wave's slots [0, nact) hold tiles of the columns > T
-    auto load_ops = [&](int s, double (&xa)[4], double (&xb)[4]) {
-      const int ij = CR_TIJ(s), I = ij >> 8, J = ij & 255;
-      const double* pa = P + (16 * (I - T) + i16) * kCRStride + kq;
-      const double* pb = P + (16 * (J - T) + i16) * kCRStride + kq;
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) { xa[kk] = pa[4 * kk]; xb[kk] = pb[4 * kk]; }
-    };
-    auto park = [&](int s) {                                 // column T + 1: up to date now -> the other panel buffer (the accumulators hold minus the matrix)
-      const int rho = kCRWaves * s + wave;
-      if (rho >= R_n) {
-        const int rb = 16 * (rho - R_n);
-#pragma unroll
-        for (int r = 0; r < 4; r++) Pn[(rb + kq + 4 * r) * kCRStride + i16] = -acc[s][r];
-      }
-    };
-    // (-A_IJ) += L_IT L_JT^T, in place (the asm ties every accumulator to ONE register block for the whole kernel), two tiles at a time: the two chains of four
-    // dependent MFMAs alternate, so that an instruction never waits for the result of the one before it
-#pragma unroll
-    for (int s = 0; s < kCRSlots; s += 2) {
-      if (s + 1 < nact) {
-        double xa[4], xb[4], ya[4], yb[4];
-        load_ops(s, xa, xb); load_ops(s + 1, ya, yb);
-#ifdef CR_EXPERIMENT_NO_MFMA   /* timing experiment only (results are wrong): what phase (3) costs without its matrix instructions */
-        acc[s][0] += xa[0] * xb[0] + xa[1] * xb[1] + xa[2] * xb[2] + xa[3] * xb[3]; acc[s + 1][0] += ya[0] * yb[0] + ya[1] * yb[1] + ya[2] * yb[2] + ya[3] * yb[3];
-#else
-        asm volatile("v_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %1, %10, %14, %1\n\t"
-                     "v_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %1, %11, %15, %1\n\t"
-                     "v_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\tv_mfma_f64_16x16x4_f64 %1, %12, %16, %1\n\t"
-                     "v_mfma_f64_16x16x4_f64 %0, %5, %9, %0\n\tv_mfma_f64_16x16x4_f64 %1, %13, %17, %1\n\t"
-                     "s_nop 15\n\ts_nop 3"      // the results may be read by the LDS stores right below: 18 wait states after a 16x16 f64 MFMA
-                     : "+v"(acc[s]), "+v"(acc[s + 1])
-                     : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]),
-                       "v"(ya[0]), "v"(ya[1]), "v"(ya[2]), "v"(ya[3]), "v"(yb[0]), "v"(yb[1]), "v"(yb[2]), "v"(yb[3]));
-#endif
-        park(s); park(s + 1);
-      } else if (s < nact) {
-        double xa[4], xb[4];
-        load_ops(s, xa, xb);
-        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %5, %0\n\tv_mfma_f64_16x16x4_f64 %0, %2, %6, %0\n\tv_mfma_f64_16x16x4_f64 %0, %3, %7, %0\n\tv_mfma_f64_16x16x4_f64 %0, %4, %8, %0\n\t"
-                     "s_nop 15\n\ts_nop 3"
-                     : "+v"(acc[s]) : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]));
-        park(s);
-      }
+    {
+      CrStep cs; cs.P = P; cs.Pn = Pn; cs.T = T; cs.NT = NT; cs.R_n = R_n; cs.wave = wave; cs.i16 = i16; cs.kq = kq; cs.tvec = tvec;
+      double fa[4], fb[4];
+      cr_load_ops(cs, 0, fa, fb);
+      cr_update_chain<0>(acc, cs, nact, fa, fb);
     }
     CR_TICK(6)
   }
