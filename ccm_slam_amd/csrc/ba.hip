@@ -531,6 +531,7 @@ __device__ __forceinline__ void ba_compact_factors(ba_v2d ea, ba_v2d eb, const b
 // 96 bytes (camRK, shared by the unit's 16 lanes) instead of 144 divergent bytes of the stored block.  ba_schur_row2 was bound by the address
 // processing of those nine divergent 16-byte loads per lane (one line look-up per lane and load: 3.8 us per 1024-lane pass on a CU); here it is two.  The
 // camera's own observations are read in camera-major order (contiguous) and re-derive exactly the stored block for Y and the diagonal block.
+template <int VAR>
 __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
   typedef double v2d __attribute__((ext_vector_type(2)));
@@ -562,8 +563,34 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
   if (wv * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + wv * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
   // ---- Y_e = W_e D^-1 of the camera's observations, one thread per observation; the same thread adds the observation's part of the diagonal block
   //      (Y_e W_e^T, symmetric: entries r <= c) and of b_schur (Y_e b_l) ----
-  {
-    const int t = threadIdx.x;
+  // (round 6, VAR) first-iteration operands of the wave's first pass: index vectors, the partners' records, the column camera — requested BEFORE the barrier by the waves that
+  // stage nothing (the two uses exclude each other: what is requested here is not alive across the staging code, which has no register to spare)
+  int f_ce1, f_ar0, f_ar1;
+  v2d f_ea, f_eb, f_r2[6];
+  auto preload_none = [&]() {   // (assigned at the END of the paths that request nothing: constants set ahead of the staging code would sit in registers all through it)
+    f_ce1 = 0; f_ar0 = zrow; f_ar1 = zrow;
+    f_ea[0] = f_ea[1] = f_eb[0] = f_eb[1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { f_r2[k][0] = 0.0; f_r2[k][1] = 0.0; }
+  };
+  auto preload = [&](int s0, int s1, int jc) {
+    const int ce0 = (s0 + q < s1) ? d.inst_cp[s0 + q] : 0;
+    f_ar0 = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow;
+    f_ce1 = (s0 + G + q < s1) ? d.inst_cp[s0 + G + q] : 0;
+    f_ar1 = (s0 + G + q < s1) ? d.inst_al[s0 + G + q] : zrow;
+    const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jc);
+#pragma unroll
+    for (int k = 0; k < 6; k++) f_r2[k] = rk[k];
+    const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce0);
+    f_ea = Ep[0]; f_eb = Ep[1];
+  };
+  const bool stager = VAR ? (NW - 1 - wv) * (kWave / G) < n_dgrp : true;   // (wave-uniform)
+  const bool early = VAR && !stager && wv * UPW < n_units;
+  if (!stager) { if (early) preload(n_s0, n_s1, n_j); else preload_none(); }
+  else {
+    // (round 6, VAR) the observations are staged by the LAST waves (observation = 1023 - thread): the first waves hold the row's longest units (the table lists them longest
+    // first) and have their first records on the way while the others stage; the butterfly below pairs the same observations (15 - q ^ 8 = 15 - (q ^ 8)): same sums
+    const int t = VAR ? kRow2TPB - 1 - (int)threadIdx.x : (int)threadIdx.x;
     double dacc[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) dacc[k] = 0.0;
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
         dacc[21 + r] = __builtin_fma(y2, bl2, __builtin_fma(y1, bl1, y0 * bl0));
       }
     }
-    if (wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
+    if (VAR ? true : wv * (kWave / G) < n_dgrp) {   // waves that hold observations: 27 sums per 16-lane group, <= 2 elements per lane afterwards
       double t1[14], t2[7], t3[4], t4[2];
       row2_halve<27>(dacc, t1, (q & 8) != 0, 8);
       row2_halve<14>(t1, t2, (q & 4) != 0, 4);
@@ -620,12 +647,13 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
       row2_halve<4>(t3, t4, (q & 1) != 0, 1);
       int e0, cnt;
       row2_range(27, q, &e0, &cnt);
-      const int g = threadIdx.x / G;
+      const int g = t / G;
       if (g < n_dgrp) {
 #pragma unroll
         for (int k = 0; k < 2; k++) if (k < cnt) dpart[27 * (size_t)g + e0 + k] = t4[k];
       }
     }
+    preload_none();
   }
   if (threadIdx.x < 18) Ys[18 * (size_t)zrow + threadIdx.x] = 0.0;
   __syncthreads();
@@ -641,32 +669,16 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
       n_s0 = n_s1 = n_slot = n_j = 0;
       if (p * UPW + grp < n_units) { const int4 te = d.unit_tab[u_first + p * UPW + grp]; n_s0 = te.y; n_s1 = te.z; n_slot = te.w; n_j = d.blk_j[te.x]; }
     }
+    if (VAR) { if (p != wv || !early) preload(n_s0, n_s1, n_j); }
     const int s0 = n_s0, s1 = n_s1, slot = n_slot, jc = n_j;
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0.0;
     // the table lists the units longest first, so group 0 of the pass sets the trip count of the wave
     const int nit = __builtin_amdgcn_readfirstlane((s1 - s0 + G - 1) / G);
-    int ce_n = (s0 + q < s1) ? d.inst_cp[s0 + q] : 0;         // index vectors one iteration ahead of the records they address
-    int ar_n = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow;
-    int jq = jc;
-    for (int it = 0; it < nit; it++) {
-      const int ce = ce_n, ar = ar_n;
-      // the block's column camera: the same 96 bytes for the 16 lanes of the unit.  Requested every iteration, first (the index is laundered: left alone,
-      // the compiler hoists these loop-invariant loads out of the loop, has no registers for their 24 values and reloads them from scratch memory — extra
-      // dependent L2 round trips in every iteration)
-      asm volatile("" : "+v"(jq));
-      const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jq);
-      v2d r2[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) r2[k] = rk[k];
-      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce);
-      const v2d ea = Ep[0], eb = Ep[1];
-      const int sn = s0 + (it + 1) * G + q;
-      ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
-      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
+    // Y_a W_c^T with W_c = Jj^T (wom Ji) never formed: V = Y_a (wom Ji)^T is 6 x 2, then V Jj (two structural zeros): 36 + 60 multiply-adds
+    auto multiply = [&](v2d ea, v2d eb, const v2d (&r2)[6], int ar) {
       const double* Yp = Ys + 18 * (size_t)ar;
-      // Y_a W_c^T with W_c = Jj^T (wom Ji) never formed: V = Y_a (wom Ji)^T is 6 x 2, then V Jj (two structural zeros): 36 + 60 multiply-adds
       double wj0[3], wj1[3], pj[5], qj[5];
       ba_compact_factors(ea, eb, r2, wj0, wj1, pj, qj);
 #pragma unroll
@@ -681,6 +693,31 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
         acc[6 * r + 4] = __builtin_fma(v1, qj[3], acc[6 * r + 4]);
         acc[6 * r + 5] = __builtin_fma(v1, qj[4], __builtin_fma(v0, pj[4], acc[6 * r + 5]));
       }
+    };
+    int ce_n, ar_n;                                            // index vectors one iteration ahead of the records they address
+    int it0 = 0;
+    if (VAR) {   // the first iteration stands in front of the loop: its operands are there (requested before the barrier, or at the head of the pass) and are dead before the loop begins
+      multiply(f_ea, f_eb, f_r2, f_ar0);
+      ce_n = f_ce1; ar_n = f_ar1; it0 = 1;
+      preload_none();   // (what flows around the pass loop is constants: the operands themselves must not stay alive through the loop below)
+    } else { ce_n = (s0 + q < s1) ? d.inst_cp[s0 + q] : 0; ar_n = (s0 + q < s1) ? d.inst_al[s0 + q] : zrow; }
+    int jq = jc;
+    for (int it = it0; it < nit; it++) {
+      const int ce = ce_n, ar = ar_n;
+      // the block's column camera: the same 96 bytes for the 16 lanes of the unit.  Requested every iteration, first (the index is laundered: left alone,
+      // the compiler hoists these loop-invariant loads out of the loop, has no registers for their 24 values and reloads them from scratch memory — extra
+      // dependent L2 round trips in every iteration)
+      asm volatile("" : "+v"(jq));
+      const v2d* rk = reinterpret_cast<const v2d*>(d.camRK + 12 * (size_t)jq);
+      v2d r2[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) r2[k] = rk[k];
+      const v2d* Ep = reinterpret_cast<const v2d*>(d.E4 + 4 * (size_t)ce);
+      const v2d ea = Ep[0], eb = Ep[1];
+      const int sn = s0 + (it + 1) * G + q;
+      ce_n = (sn < s1) ? d.inst_cp[sn] : 0;
+      ar_n = (sn < s1) ? d.inst_al[sn] : zrow;
+      multiply(ea, eb, r2, ar);
     }
     double t1[18], t2[9], t3[5], t4[3];
     row2_halve<36>(acc, t1, (q & 8) != 0, 8);
@@ -694,6 +731,31 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
 #pragma unroll
       for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
     }
+  }
+  // (round 6, VAR) the diagonal block and b_schur are summed HERE, by the last wave — the one with the row's shortest units, done long before the first waves —, not behind
+  // the barrier, where the serial sum over the 16-observation groups (~30 dependent LDS reads) was the tail every other wave waited for.  The partial sums are complete since
+  // the barrier above.  Eight reads are requested at a time, the additions keep their order.
+  if (VAR && wv == NW - 1 && lane < 27) {
+    const int e = lane;
+    int r = 0, c = 0;
+    double hv;
+    if (e < 21) {
+      r = e < 6 ? 0 : e < 11 ? 1 : e < 15 ? 2 : e < 18 ? 3 : e < 20 ? 4 : 5;
+      c = e - (r == 0 ? 0 : r == 1 ? 5 : r == 2 ? 9 : r == 3 ? 12 : r == 4 ? 14 : 15);
+      hv = d.Hpp[36 * (size_t)i + 6 * r + c];
+    } else hv = d.bp[6 * (size_t)i + e - 21];
+    double sum = 0;
+    for (int g0 = 0; g0 < n_dgrp; g0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = (g0 + k < n_dgrp) ? dpart[27 * (size_t)(g0 + k) + e] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (g0 + k < n_dgrp) sum += v[k];
+    }
+    if (e < 21) {
+      const double v = hv - sum;
+      d.S[36 * (size_t)i + 6 * r + c] = v; d.S[36 * (size_t)i + 6 * c + r] = v;   // the upper triangle is mirrored: S_ii is exactly symmetric
+    } else d.bs[6 * (size_t)i + e - 21] = hv - sum;
   }
   ROW3_TICK(1)   // (wave 0's share of the block passes)
   // the unit range of the thread's first block of the final sums is requested BEFORE the barrier: its round trip runs while the slower waves finish
@@ -715,7 +777,7 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
         for (int u = ub; u < ue; u++) sum += part[36 * (size_t)(u - u_first) + el];
         d.S[36 * (size_t)(d.Cp + b) + el] = -sum;
       }
-    if (threadIdx.x >= kRow2TPB - 64 && threadIdx.x - (kRow2TPB - 64) < 27) {   // the last wave (it has no block of the loop above when the row is short)
+    if (!VAR && threadIdx.x >= kRow2TPB - 64 && threadIdx.x - (kRow2TPB - 64) < 27) {   // the last wave (it has no block of the loop above when the row is short)
       // (measured and dropped: lane = 16-observation group and the 27 sums by the halving butterfly instead of this serial loop: 146 us against 143)
       const int e = threadIdx.x - (kRow2TPB - 64);
       double sum = 0;
@@ -2850,8 +2912,14 @@ static int launch_schur(ccm_ba* ba) {
     if (d.nOff <= row_min_blocks()) hipLaunchKernelGGL(ba_schur_off<4>, dim3(d.nOff), dim3(kTPB), 0, ctx->stream, d);
     else if (d.row_units_max) {
       const size_t lds_row = ((size_t)(d.max_cam_edges + 1) * 18 + 27 * (size_t)ccm_div_up(d.max_cam_edges, kRow2Group) + (size_t)d.row_units_max * 36) * sizeof(double);
-      CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3, 158 * 1024);
-      hipLaunchKernelGGL(ba_schur_row3, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+      static const bool row_old = getenv("CCM_BA_ROW_OLD") && atoi(getenv("CCM_BA_ROW_OLD"));   // experiments: the round-5 form of the kernel
+      if (row_old) {
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW4, ba_schur_row3<0>, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row3<0>, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+      } else {
+        CCM_LDS_ATTR(ctx, CCM_LDS_BA_ROW3, ba_schur_row3<1>, 158 * 1024);
+        hipLaunchKernelGGL(ba_schur_row3<1>, dim3(8 * ccm_div_up(d.Cp, 8)), dim3(kRow2TPB), lds_row, ctx->stream, d);
+      }
     } else hipLaunchKernelGGL(ba_schur_off<1>, dim3(ccm_div_up(d.nOff, kTPB / kWave)), dim3(kTPB), 0, ctx->stream, d);
   }
   CCM_HIP_CHECK(ctx, hipGetLastError());
