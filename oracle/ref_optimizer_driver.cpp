@@ -286,8 +286,56 @@ void mapg_get_state(void* h, float* kf_Tcw, float* kf_gba, uint8_t* kf_gba_flag,
 int mapg_pose_optimization(float* Tcw, int n, const float* kp_xy, const int32_t* kp_oct, const float* mp_pos, const float* K4, int n_levels,
                            float scale_factor, uint8_t* outlier) {
 #ifdef CCM_REAL_CLASSES
-  (void)Tcw; (void)n; (void)kp_xy; (void)kp_oct; (void)mp_pos; (void)K4; (void)n_levels; (void)scale_factor; (void)outlier;
-  return -100;   // the real Frame is only constructible from an image (ORB extraction + cv::undistortPoints): stays on the look-alike Frame
+  // The real Frame has two constructors: a copy and the tracking one (Frame.cpp:56-101), which extracts ORB features from an image.  So the harness gives it an image:
+  // a block texture that FAST finds corners in, run through the drop-in ORBextractor of this library (shim/ORBextractor_hip.cpp, on the MI355X), K with zero distortion
+  // (UndistortKeyPoints returns at its first line, Frame.cpp:262-266).  What the constructor builds — scale tables, image bounds, the calibration statics, the grid — is
+  // the reference's own code; the harness then replaces the OBSERVATION SET (keypoints, map points, outlier flags) by the test's, so that the same call can be made on
+  // the look-alike Frame, and the pose goes in through the real Frame::SetPose.
+  const int W = 752, H = 480;
+  cv::Mat im(H, W, CV_8UC1);
+  unsigned lcg = 12345u;
+  for (int by = 0; by < H; by += 12)
+    for (int bx = 0; bx < W; bx += 12) {
+      lcg = lcg * 1664525u + 1013904223u;
+      const unsigned char v = (unsigned char)(40 + (lcg >> 24) % 176);
+      for (int y = by; y < by + 12 && y < H; y++) for (int x = bx; x < bx + 12 && x < W; x++) im.data[(size_t)y * W + x] = v;
+    }
+  cv::Mat Kc = cv::Mat::eye(3, 3, CV_32F);
+  Kc.at<float>(0, 0) = K4[0]; Kc.at<float>(1, 1) = K4[1]; Kc.at<float>(0, 2) = K4[2]; Kc.at<float>(1, 2) = K4[3];
+  cv::Mat dist = cv::Mat::zeros(4, 1, CV_32F);
+  boost::shared_ptr<cslam::ORBextractor> ex(new cslam::ORBextractor(1000, scale_factor, n_levels, 20, 7));
+  Frame::mbInitialComputations = true;
+  Frame F(im, 0.0, ex, cslam::vocptr(), Kc, dist, (size_t)0);
+  if (F.N <= 0 || (int)F.mvInvLevelSigma2.size() != n_levels) return -101;   // the extractor found nothing in the texture / the tables are not the extractor's
+  const int n_extracted = F.N;
+  (void)n_extracted;
+  F.N = n;
+  F.mvKeys.resize(n); F.mvKeysUn.resize(n); F.mvpMapPoints.assign(n, mpptr()); F.mvbOutlier.assign(n, false);
+  boost::shared_ptr<cslam::Communicator> comm(static_cast<cslam::Communicator*>(::operator new(64)), [](cslam::Communicator* c) { ::operator delete(c); });
+  boost::shared_ptr<Map> map(new Map(ros::NodeHandle(), ros::NodeHandle(), (size_t)0, cslam::eSystemState::CLIENT));
+  map->mspComm.insert(comm);
+  Store<MapPoint> store;
+  store.alloc((size_t)n);
+  for (int i = 0; i < n; i++) {
+    F.mvKeys[i] = F.mvKeysUn[i] = cv::KeyPoint(kp_xy[2 * i], kp_xy[2 * i + 1], 31.f, -1, 0, kp_oct[i]);
+    new (&store[i]) MapPoint(map, comm, cslam::eSystemState::CLIENT, (size_t)i);
+    store.made++;
+    MapPoint& mp = store[i];
+    cv::Mat pos(3, 1, CV_32F);
+    for (int c = 0; c < 3; c++) pos.at<float>(c) = mp_pos[3 * (size_t)i + c];
+    F.mvpMapPoints[i] = mpptr(&mp, [](MapPoint*) {});
+    mp.mbOmitSending = true;
+    mp.SetWorldPos(pos, false, false);
+    mp.mbOmitSending = false;
+  }
+  F.SetPose(mat44(Tcw));
+  const int nin = cslam::Optimizer::PoseOptimizationClient(F);
+  std::memcpy(Tcw, F.mTcw.data, 64);
+  for (int i = 0; i < n; i++) outlier[i] = F.mvbOutlier[i] ? 1 : 0;
+  F.mvpMapPoints.clear();
+  for (size_t i = 0; i < store.made; i++) { store[i].mspComm.clear(); store[i].mpMap.reset(); }
+  map->mspComm.clear();
+  return nin;
 #else
   Frame F;
   F.N = n;

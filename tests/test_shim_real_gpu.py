@@ -147,3 +147,24 @@ def test_optimize_sim3_and_the_essential_graph_on_the_real_classes():
         assert np.abs(s["kf_Tcw"] - x["kf_Tcw"]).max() < 2e-5 and np.abs(s["mp_pos"] - x["mp_pos"]).max() < 1e-4, (np.abs(s["kf_Tcw"] - x["kf_Tcw"]).max(), np.abs(s["mp_pos"] - x["mp_pos"]).max())
         assert np.array_equal(s["mp_bad"], x["mp_bad"]) and np.array_equal(s["kf_Tcw"][0], x["kf_Tcw"][0])
         assert np.abs(r["kf_Tcw"] - x["kf_Tcw"]).max() < 2e-4 and np.abs(r["mp_pos"] - x["mp_pos"]).max() < 1e-3
+
+
+def test_pose_optimization_client_on_the_real_frame():
+    """cslam::Optimizer::PoseOptimizationClient(Frame&) (Optimizer.cpp:215-347) on the reference's REAL cslam::Frame.  The class has no default constructor: the harness
+    builds it with the tracking constructor (Frame.cpp:56-101) from a synthetic image — the ORB extraction inside it is this library's drop-in ORBextractor on the MI355X —,
+    then gives it the test's observation set (keypoints, real cslam::MapPoint objects, pose through the real Frame::SetPose); oracle/ref_optimizer_driver.cpp.  The same
+    call on the look-alike Frame (SHIM) must give the same pose bit for bit, the reference's own Optimizer.cpp + g2o (REF) within the bar of tests/test_shim_gpu.py."""
+    for n, seed, of in ((300, 0, 0.1), (1000, 7, 0.2), (40, 3, 0.3)):
+        pp = synth.make_pose_problem(n, seed, of)
+        R = synth.R_from_quat(pp["cam_qt"][None, :4])[0]
+        T = np.eye(4, dtype=np.float32); T[:3, :3] = R.astype(np.float32); T[:3, 3] = pp["cam_qt"][4:].astype(np.float32)
+        octv = np.rint(-np.log(pp["info"]) / (2 * np.log(1.2))).astype(np.int32)
+        args = (T, pp["obs"].astype(np.float32), octv, pp["Xw"].astype(np.float32), np.asarray(pp["K"], np.float32))
+        Tr, outr, nr = mg.pose_optimization(mg.REF_LIB, *args)
+        Ts, outs, ns = mg.pose_optimization(mg.SHIM_LIB, *args)
+        Tq, outq, nq = mg.pose_optimization(REAL_LIB, *args)
+        assert nq >= 0, f"the real Frame could not be built (code {nq})"
+        assert nq == ns == nr
+        assert np.array_equal(outq, outs) and np.array_equal(outq, outr)
+        assert np.array_equal(Tq, Ts)
+        assert ulps32(Tr, Tq).max() <= 2
