@@ -547,6 +547,8 @@ __device__ __forceinline__ void ba_compact_factors(ba_v2d ea, ba_v2d eb, const b
 //     path (that is wave 0's serial iterations), and every value carried around the row loop competes with the 36 accumulators: its first versions spilled 36-90 registers
 //     and ran 182-208 us;
 //   * a unit that is its whole block storing straight into S (85 % of the blocks), the second block range of the final sums requested before the barrier: +-1 us.
+//   * no second barrier and no final-sum phase at all — the unit that delivers a block's LAST partial sums (an LDS counter per block) adds them up in the units' order and
+//     stores the block, the waves end one by one: 128.6 us against 127-130, i.e. the final sums were not on the row's critical path either.
 __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
   extern __shared__ __attribute__((aligned(16))) double Ys[];
   typedef double v2d __attribute__((ext_vector_type(2)));
