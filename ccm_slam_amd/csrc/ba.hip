@@ -482,16 +482,37 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // costs one L1 line look-up per LANE (~64 cycles per instruction), so the gathers alone were ~140 us; the same holds for the nine W_c gathers per
 // instance here (~60 us of this kernel).  What would lift it: nine consecutive lanes fetching one 144-byte row (2.25 line look-ups) and handing it to the
 // computing lane through LDS — for which the 70-100 KB of Y leave no room.
-template <int N>
-__device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[(N + 1) / 2], bool hi, int mask) {
+// (round 6) One step of the halving butterfly without LDS and without selects.  Until now a step cost, per exchanged value, four v_cndmask (which half a lane keeps, which it
+// sends), two ds_bpermute and the addition — 476 instructions per pass for its 68 exchanges, as many as three iterations of the multiplication loop, with a chain of LDS
+// latencies in it.  Now the upper lanes SWAP their two halves first (v_swap_b32 under their own exec mask: two per value), after which every lane keeps [0, H) and sends
+// [H, N); the partner's value arrives through DPP (row_ror:8 / row_half_mirror + quad_perm / quad_perm: vector-ALU moves, nothing goes through LDS).  The sums are the same
+// sums (keep + received, pair by pair): same bits.
+template <int CTRL>
+__device__ __forceinline__ double row2_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int MASK>
+__device__ __forceinline__ double row2_from_partner(double v) {   // the value of lane ^ MASK (MASK = 8, 4, 2, 1: inside a row of 16 lanes)
+  if (MASK == 8) return row2_dpp<0x128>(v);                       // row_ror:8
+  if (MASK == 4) return row2_dpp<0x1B>(row2_dpp<0x141>(v));      // row_half_mirror (i -> 7 - i), then every quad reversed (j -> j ^ 3): i -> i ^ 4
+  if (MASK == 2) return row2_dpp<0x4E>(v);                       // quad_perm:[2,3,0,1]
+  return row2_dpp<0xB1>(v);                                       // quad_perm:[1,0,3,2]
+}
+template <int N, int MASK>
+__device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[(N + 1) / 2], bool hi) {
   constexpr int H = (N + 1) / 2;   // the lower lanes keep elements [0, H), the upper ones [H, N) (N - H <= H of them, padded with zeros)
+  double v[2 * H];
 #pragma unroll
-  for (int k = 0; k < H; k++) {
-    const double up = (H + k < N) ? in[H + k] : 0.0;
-    const double keep = hi ? up : in[k];
-    const double send = hi ? in[k] : up;
-    out[k] = keep + __shfl_xor(send, mask, kWave);
+  for (int k = 0; k < 2 * H; k++) v[k] = k < N ? in[k] : 0.0;
+  if (hi) {   // (a real branch: the empty asm keeps the compiler from turning the swaps back into selects)
+#pragma unroll
+    for (int k = 0; k < H; k++) { asm volatile("" : "+v"(v[k]), "+v"(v[H + k])); const double t = v[k]; v[k] = v[H + k]; v[H + k] = t; }
   }
+#pragma unroll
+  for (int k = 0; k < H; k++) out[k] = v[k] + row2_from_partner<MASK>(v[H + k]);
 }
 // element range [*e0, *e0 + *cnt) that a lane holds after the four steps (lane bits q3..q0 of its position inside the group)
 __device__ __forceinline__ void row2_range(int N, int q, int* e0, int* cnt) {
@@ -658,10 +679,10 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
     }
     {   // 27 sums per 16-lane group, <= 2 elements per lane afterwards
       double t1[14], t2[7], t3[4], t4[2];
-      row2_halve<27>(dacc, t1, (q & 8) != 0, 8);
-      row2_halve<14>(t1, t2, (q & 4) != 0, 4);
-      row2_halve<7>(t2, t3, (q & 2) != 0, 2);
-      row2_halve<4>(t3, t4, (q & 1) != 0, 1);
+      row2_halve<27, 8>(dacc, t1, (q & 8) != 0);
+      row2_halve<14, 4>(t1, t2, (q & 4) != 0);
+      row2_halve<7, 2>(t2, t3, (q & 2) != 0);
+      row2_halve<4, 1>(t3, t4, (q & 1) != 0);
       int e0, cnt;
       row2_range(27, q, &e0, &cnt);
       const int g = t / G;
@@ -734,10 +755,10 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
       multiply(ea, eb, r2, ar);
     }
     double t1[18], t2[9], t3[5], t4[3];
-    row2_halve<36>(acc, t1, (q & 8) != 0, 8);
-    row2_halve<18>(t1, t2, (q & 4) != 0, 4);
-    row2_halve<9>(t2, t3, (q & 2) != 0, 2);
-    row2_halve<5>(t3, t4, (q & 1) != 0, 1);
+    row2_halve<36, 8>(acc, t1, (q & 8) != 0);
+    row2_halve<18, 4>(t1, t2, (q & 4) != 0);
+    row2_halve<9, 2>(t2, t3, (q & 2) != 0);
+    row2_halve<5, 1>(t3, t4, (q & 1) != 0);
     int e0, cnt;
     row2_range(36, q, &e0, &cnt);
     if (uu < n_units) {
