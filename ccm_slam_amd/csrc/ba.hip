@@ -28,6 +28,7 @@
 #include "common.h"
 #include "test_internal.h"
 #include "ba_types.h"
+#include "lane_xor.h"
 #include "ba_math.h"
 #include <algorithm>
 #include <chrono>
@@ -49,11 +50,7 @@ inline double now_ms() {
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return lanex::wave_sum(v); }   // (xor butterfly 32 ... 1; round 6: by DPP / ds_swizzle where they reach, lane_xor.h)
 
 // deterministic block sum (fixed tree), result valid in thread 0; blockDim.x == kTPB
 __device__ __forceinline__ double block_sum(double v, double* lds /* >= kTPB/kWave */) {
@@ -240,10 +237,10 @@ __device__ __forceinline__ double wave_sum27(double* acc /* [32], entries 27..31
     for (int k = 0; k < c; k++) {
       const long long lo = __double_as_longlong(acc[k]), hi = __double_as_longlong(acc[k + c]);
       const double send = __longlong_as_double((lo & m) | (hi & ~m)), keep = __longlong_as_double((hi & m) | (lo & ~m));
-      acc[k] = keep + __shfl_xor(send, off, kWave);
+      acc[k] = keep + lanex::from_partner_c(send, off);
     }
   }
-  return acc[0] + __shfl_xor(acc[0], 1, kWave);
+  return acc[0] + lanex::from_partner<1>(acc[0]);
 }
 // value index k (0..20) of the packed upper triangle -> (a, b), a <= b
 __device__ __forceinline__ void tri_ab(int k, int& a, int& b) {
@@ -485,22 +482,8 @@ __global__ __launch_bounds__(kTPB) void ba_schur_off(BaDev d) {
 // (round 6) One step of the halving butterfly without LDS and without selects.  Until now a step cost, per exchanged value, four v_cndmask (which half a lane keeps, which it
 // sends), two ds_bpermute and the addition — 476 instructions per pass for its 68 exchanges, as many as three iterations of the multiplication loop, with a chain of LDS
 // latencies in it.  Now the upper lanes SWAP their two halves first (v_swap_b32 under their own exec mask: two per value), after which every lane keeps [0, H) and sends
-// [H, N); the partner's value arrives through DPP (row_ror:8 / row_half_mirror + quad_perm / quad_perm: vector-ALU moves, nothing goes through LDS).  The sums are the same
+// [H, N); the partner's value arrives through DPP (lane_xor.h: row_ror:8 / row_half_mirror + quad_perm / quad_perm: vector-ALU moves, nothing goes through LDS).  The sums are the same
 // sums (keep + received, pair by pair): same bits.
-template <int CTRL>
-__device__ __forceinline__ double row2_dpp(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int MASK>
-__device__ __forceinline__ double row2_from_partner(double v) {   // the value of lane ^ MASK (MASK = 8, 4, 2, 1: inside a row of 16 lanes)
-  if (MASK == 8) return row2_dpp<0x128>(v);                       // row_ror:8
-  if (MASK == 4) return row2_dpp<0x1B>(row2_dpp<0x141>(v));      // row_half_mirror (i -> 7 - i), then every quad reversed (j -> j ^ 3): i -> i ^ 4
-  if (MASK == 2) return row2_dpp<0x4E>(v);                       // quad_perm:[2,3,0,1]
-  return row2_dpp<0xB1>(v);                                       // quad_perm:[1,0,3,2]
-}
 template <int N, int MASK>
 __device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[(N + 1) / 2], bool hi) {
   constexpr int H = (N + 1) / 2;   // the lower lanes keep elements [0, H), the upper ones [H, N) (N - H <= H of them, padded with zeros)
@@ -512,7 +495,7 @@ __device__ __forceinline__ void row2_halve(const double (&in)[N], double (&out)[
     for (int k = 0; k < H; k++) { asm volatile("" : "+v"(v[k]), "+v"(v[H + k])); const double t = v[k]; v[k] = v[H + k]; v[H + k] = t; }
   }
 #pragma unroll
-  for (int k = 0; k < H; k++) out[k] = v[k] + row2_from_partner<MASK>(v[H + k]);
+  for (int k = 0; k < H; k++) out[k] = v[k] + lanex::from_partner<MASK>(v[H + k]);
 }
 // element range [*e0, *e0 + *cnt) that a lane holds after the four steps (lane bits q3..q0 of its position inside the group)
 __device__ __forceinline__ void row2_range(int N, int q, int* e0, int* cnt) {
@@ -977,9 +960,9 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
   }
   // sum over the 8 groups (lanes with equal r): fixed xor tree
-  acc += __shfl_xor(acc, 8, kWave);
-  acc += __shfl_xor(acc, 16, kWave);
-  acc += __shfl_xor(acc, 32, kWave);
+  acc += lanex::from_partner<8>(acc);
+  acc += lanex::from_partner<16>(acc);
+  acc += lanex::from_partner<32>(acc);
   if (lane < 8) half_sum[rl][h][lane] = acc;
   __syncthreads();
   double pq = 0, qv = 0;
@@ -2174,8 +2157,8 @@ __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambd
         double pv = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) pv = fma(acc[s][r], xv[16 * I + kq + 4 * r], pv);
-        pv += __shfl_xor(pv, 16);
-        pv += __shfl_xor(pv, 32);
+        pv += lanex::from_partner<16>(pv);
+        pv += lanex::from_partner<32>(pv);
         if (kq == 0) yv[16 * J + i16] -= pv;
       }
     }
@@ -2313,9 +2296,9 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       }
       const double w1 = coarse_hat_t(8 * u + kk, d.agg);
       double s0v = (1.0 - w1) * sv, s1v = w1 * sv;
-      s0v += __shfl_xor(s0v, 1, kWave); s1v += __shfl_xor(s1v, 1, kWave);
-      s0v += __shfl_xor(s0v, 2, kWave); s1v += __shfl_xor(s1v, 2, kWave);
-      s0v += __shfl_xor(s0v, 4, kWave); s1v += __shfl_xor(s1v, 4, kWave);
+      s0v += lanex::from_partner<1>(s0v); s1v += lanex::from_partner<1>(s1v);
+      s0v += lanex::from_partner<2>(s0v); s1v += lanex::from_partner<2>(s1v);
+      s0v += lanex::from_partner<4>(s0v); s1v += lanex::from_partner<4>(s1v);
       if (cc < 6 && kk == 0) { coh_store(a.cparts + (size_t)cc * nwg + u, s0v); coh_store(a.cparts + (size_t)(6 + cc) * nwg + u, s1v); }
     }
   };
@@ -2669,7 +2652,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
           }
         }
       }
-      acc += __shfl_xor(acc, 8, kWave); acc += __shfl_xor(acc, 16, kWave); acc += __shfl_xor(acc, 32, kWave);
+      acc += lanex::from_partner<8>(acc); acc += lanex::from_partner<16>(acc); acc += lanex::from_partner<32>(acc);
       if (lane < 6) qs[6 * i + lane] = acc + lambda * ps[6 * i + lane];
     }
     __syncthreads();

@@ -3,6 +3,7 @@
 // keeps the LM control flow workgroup-uniform without broadcasting decisions.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "lane_xor.h"
 
 namespace blockred {
 
@@ -36,7 +37,7 @@ struct BlockRedT {
   // one value: wave butterfly, then the NW partials through LDS
   __device__ __forceinline__ double sum1(double v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    for (int off = 32; off >= 1; off >>= 1) v += lanex::from_partner_c(v, off);   // (round 6: DPP / ds_swizzle where they reach, lane_xor.h; same pairs, same order)
     double* b = buf + phase * (NW * 64);
     phase ^= 1;
     if (lane == 0) b[wave * 64] = v;
@@ -59,10 +60,10 @@ struct BlockRedT {
         const double lo_v = acc[k], hi_v = acc[k + c];
         const double send = sel_bits(hi, lo_v, hi_v);
         const double keep = sel_bits(hi, hi_v, lo_v);
-        acc[k] = keep + __shfl_xor(send, off, kWave);
+        acc[k] = keep + lanex::from_partner_c(send, off);
       }
     }
-    acc[0] += __shfl_xor(acc[0], 1, kWave);
+    acc[0] += lanex::from_partner<1>(acc[0]);
     double* b = buf + phase * (NW * 64);
     phase ^= 1;
     if ((lane & 1) == 0) b[wave * 64 + (lane >> 1)] = acc[0];
@@ -95,7 +96,7 @@ struct BlockRedT {
       for (int i = 0; i < kTrCols / 8; i += 4) { s0 += row[8 * i]; s1 += row[8 * (i + 1)]; s2 += row[8 * (i + 2)]; s3 += row[8 * (i + 3)]; }
       s = (s0 + s1) + (s2 + s3);
     }
-    s += __shfl_xor(s, 1, kWave); s += __shfl_xor(s, 2, kWave); s += __shfl_xor(s, 4, kWave);
+    s += lanex::from_partner<1>(s); s += lanex::from_partner<2>(s); s += lanex::from_partner<4>(s);
     double* out = tr + 28 * kTrStride;
     if (t < 224 && (t & 7) == 0) out[t >> 3] = s;
     __syncthreads();
@@ -116,7 +117,7 @@ struct BlockRedT {
         const double lo_v = acc[k], hi_v = acc[k + c];
         const double send = sel_bits(hi, lo_v, hi_v);
         const double keep = sel_bits(hi, hi_v, lo_v);
-        acc[k] = keep + __shfl_xor(send, off, kWave);
+        acc[k] = keep + lanex::from_partner_c(send, off);
       }
     }
     double* b = buf + phase * (NW * 64);

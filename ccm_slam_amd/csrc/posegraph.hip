@@ -16,6 +16,7 @@
 // (Optimizer.cpp:1268-1330) stay with the caller.
 #include "common.h"
 #include "sim3_math.h"
+#include "lane_xor.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -59,11 +60,7 @@ struct PgDev {
   int n_wg_row, n_wg_upd, n_wg_edge;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return lanex::wave_sum(v); }   // (xor butterfly 32 ... 1, lane_xor.h)
 __device__ __forceinline__ double sum_partials(const double* __restrict__ p, int n) {
   const int lane = threadIdx.x & (kWave - 1);
   double s = 0;
@@ -283,9 +280,9 @@ __global__ __launch_bounds__(kTPB) void pg_pcg_spmv(PgDev d, int k) {
       }
     }
   }
-  acc += __shfl_xor(acc, 8, kWave);
-  acc += __shfl_xor(acc, 16, kWave);
-  acc += __shfl_xor(acc, 32, kWave);
+  acc += lanex::from_partner<8>(acc);
+  acc += lanex::from_partner<16>(acc);
+  acc += lanex::from_partner<32>(acc);
   double pq = 0;
   if (i < d.F && lane < 7) {
     const double pi = d.z[7 * (size_t)i + lane] + beta * pold[7 * (size_t)i + lane];
