@@ -232,13 +232,12 @@ __global__ __launch_bounds__(kTPB) void ba_linearize_pts_e(BaDev d, int cur, dou
 __device__ __forceinline__ double wave_sum27(double* acc /* [32], entries 27..31 zero */, int lane) {
 #pragma unroll
   for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
-    const long long m = -(long long)((lane & off) != 0);
+    if ((lane & off) != 0) {   // (round 6: the upper lanes swap their halves, see row2_halve)
 #pragma unroll
-    for (int k = 0; k < c; k++) {
-      const long long lo = __double_as_longlong(acc[k]), hi = __double_as_longlong(acc[k + c]);
-      const double send = __longlong_as_double((lo & m) | (hi & ~m)), keep = __longlong_as_double((hi & m) | (lo & ~m));
-      acc[k] = keep + lanex::from_partner_c(send, off);
+      for (int k = 0; k < c; k++) { asm volatile("" : "+v"(acc[k]), "+v"(acc[k + c])); const double tmp = acc[k]; acc[k] = acc[k + c]; acc[k + c] = tmp; }
     }
+#pragma unroll
+    for (int k = 0; k < c; k++) acc[k] = acc[k] + lanex::from_partner_c(acc[k + c], off);
   }
   return acc[0] + lanex::from_partner<1>(acc[0]);
 }

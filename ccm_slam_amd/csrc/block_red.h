@@ -54,14 +54,14 @@ struct BlockRedT {
   __device__ __forceinline__ void sum27(double* acc /* [32], entries 28..31 zero */) {
 #pragma unroll
     for (int c = 16, off = 32; c >= 1; c >>= 1, off >>= 1) {
-      const bool hi = (lane & off) != 0;
+      // (round 6) the upper lanes swap their halves — a real branch: the empty asm keeps the swaps from becoming selects again —, then every lane keeps [0, c) and sends
+      // [c, 2c): 3 moves instead of 8 bit operations per exchanged value, and the partner's value comes by DPP / ds_swizzle where they reach (lane_xor.h); same sums
+      if ((lane & off) != 0) {
 #pragma unroll
-      for (int k = 0; k < c; k++) {
-        const double lo_v = acc[k], hi_v = acc[k + c];
-        const double send = sel_bits(hi, lo_v, hi_v);
-        const double keep = sel_bits(hi, hi_v, lo_v);
-        acc[k] = keep + lanex::from_partner_c(send, off);
+        for (int k = 0; k < c; k++) { asm volatile("" : "+v"(acc[k]), "+v"(acc[k + c])); const double tmp = acc[k]; acc[k] = acc[k + c]; acc[k + c] = tmp; }
       }
+#pragma unroll
+      for (int k = 0; k < c; k++) acc[k] = acc[k] + lanex::from_partner_c(acc[k + c], off);
     }
     acc[0] += lanex::from_partner<1>(acc[0]);
     double* b = buf + phase * (NW * 64);
@@ -111,14 +111,14 @@ struct BlockRedT {
   __device__ __forceinline__ void sum64(double* acc /* [64], entries NV..63 zero */) {
 #pragma unroll
     for (int c = 32, off = 32; c >= 1; c >>= 1, off >>= 1) {
-      const bool hi = (lane & off) != 0;
+      // (round 6) the upper lanes swap their halves — a real branch: the empty asm keeps the swaps from becoming selects again —, then every lane keeps [0, c) and sends
+      // [c, 2c): 3 moves instead of 8 bit operations per exchanged value, and the partner's value comes by DPP / ds_swizzle where they reach (lane_xor.h); same sums
+      if ((lane & off) != 0) {
 #pragma unroll
-      for (int k = 0; k < c; k++) {
-        const double lo_v = acc[k], hi_v = acc[k + c];
-        const double send = sel_bits(hi, lo_v, hi_v);
-        const double keep = sel_bits(hi, hi_v, lo_v);
-        acc[k] = keep + lanex::from_partner_c(send, off);
+        for (int k = 0; k < c; k++) { asm volatile("" : "+v"(acc[k]), "+v"(acc[k + c])); const double tmp = acc[k]; acc[k] = acc[k + c]; acc[k + c] = tmp; }
       }
+#pragma unroll
+      for (int k = 0; k < c; k++) acc[k] = acc[k] + lanex::from_partner_c(acc[k + c], off);
     }
     double* b = buf + phase * (NW * 64);
     phase ^= 1;

@@ -354,7 +354,9 @@ extern "C" int ccm_pose_optimize(ccm_ctx* ctx, double cam_qt[7], int n, const do
   const size_t staged = 8 * (size_t)n * sizeof(double) + 3 * (size_t)n + 16;
   // the 27 sums through LDS whenever the transpose block fits beside the staged problem (up to ~1290 edges); CCM_POSEOPT_SHAPE=0: the cross-lane reduction always
   const bool shape0_env = false;
-  const bool tr_red = !shape0_env && PoseCfg<true>::kRed * sizeof(double) + staged <= 150 * 1024;
+  // (round 6: with the butterfly's cross-lane moves by DPP (block_red.h, lane_xor.h) the transpose wins up to a few hundred edges only — 0.162 against 0.173 ms per call at 150
+  // edges, 0.115 / 0.140 at 300, but 0.234 / 0.202 at 1000: its two barriers and 28 LDS columns grow with the edge passes around them; crossover taken at 600)
+  const bool tr_red = !shape0_env && n < 600 && PoseCfg<true>::kRed * sizeof(double) + staged <= 150 * 1024;
   const size_t red_bytes = (tr_red ? PoseCfg<true>::kRed : PoseCfg<false>::kRed) * sizeof(double);
   const size_t lds_full = red_bytes + staged;
   const int use_lds = lds_full <= 150 * 1024;
