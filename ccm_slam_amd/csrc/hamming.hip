@@ -16,7 +16,6 @@
 //    (2 x global_load_dwordx4).  Per-slot distances are written for the host-side ordered
 //    resolution pass; best/second come from two wave min-reductions over (dist,slot) keys.
 #include "common.h"
-#include "lane_xor.h"
 
 namespace {
 
@@ -91,7 +90,7 @@ __global__ __launch_bounds__(256) void hamming_dense_merge(
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, (uint32_t)lanex::from_partner_i32_c((int)v, off));   // (round 6: DPP / ds_swizzle where they reach, lane_xor.h)
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, kWave));
   return v;
 }
 
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256) void hamming_csr_group_kernel(
   // every group of the wave runs as many rounds as the longest list among them (the shuffles below need all lanes)
   int rounds = (c1 - c0 + G - 1) / G;
 #pragma unroll
-  for (int off = G; off < kWave; off <<= 1) rounds = max(rounds, lanex::from_partner_i32_c(rounds, off));
+  for (int off = G; off < kWave; off <<= 1) rounds = max(rounds, __shfl_xor(rounds, off, kWave));
   for (int r = 0; r < rounds; r++) {
     const int s = c0 + r * G + sub;
     uint32_t key = 0xFFFFFFFFu;
@@ -192,10 +191,10 @@ __global__ __launch_bounds__(256) void hamming_csr_group_kernel(
     if (best_idx) {
       uint32_t m1 = key;
 #pragma unroll
-      for (int off = G / 2; off >= 1; off >>= 1) m1 = min(m1, (uint32_t)lanex::from_partner_i32_c((int)m1, off));
+      for (int off = G / 2; off >= 1; off >>= 1) m1 = min(m1, (uint32_t)__shfl_xor((int)m1, off, kWave));
       uint32_t m2 = (key == m1) ? 0xFFFFFFFFu : key;   // keys are unique (slot bits)
 #pragma unroll
-      for (int off = G / 2; off >= 1; off >>= 1) m2 = min(m2, (uint32_t)lanex::from_partner_i32_c((int)m2, off));
+      for (int off = G / 2; off >= 1; off >>= 1) m2 = min(m2, (uint32_t)__shfl_xor((int)m2, off, kWave));
       if (m1 < kbest) { ksecond = min(kbest, m2); kbest = m1; }
       else            { ksecond = min(ksecond, m1); }
     }

@@ -29,28 +29,6 @@ __device__ __forceinline__ double from_partner(double v) {
   } else return __shfl_xor(v, 32, 64);
 }
 
-// 32-bit values (the Hamming kernels' packed (distance, slot) keys): the same moves, one per value
-template <int MASK>
-__device__ __forceinline__ int from_partner_i32(int v) {
-  static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "lane ^ MASK inside a wave of 64");
-  if constexpr (MASK == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
-  else if constexpr (MASK == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
-  else if constexpr (MASK == 4) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
-  else if constexpr (MASK == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false);
-  else if constexpr (MASK == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);
-  else return __shfl_xor(v, 32, 64);
-}
-__device__ __forceinline__ int from_partner_i32_c(int v, int off) {
-  switch (off) {
-    case 1: return from_partner_i32<1>(v);
-    case 2: return from_partner_i32<2>(v);
-    case 4: return from_partner_i32<4>(v);
-    case 8: return from_partner_i32<8>(v);
-    case 16: return from_partner_i32<16>(v);
-    default: return from_partner_i32<32>(v);
-  }
-}
-
 // the same for a step that is a constant after unrolling (off = 32, 16, ... 1)
 __device__ __forceinline__ double from_partner_c(double v, int off) {
   switch (off) {
