@@ -959,9 +959,9 @@ __global__ __launch_bounds__(kSpmvTPB) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
   }
   // sum over the 8 groups (lanes with equal r): fixed xor tree
-  acc += lanex::from_partner<8>(acc);
-  acc += lanex::from_partner<16>(acc);
-  acc += lanex::from_partner<32>(acc);
+  acc = lanex::add_partner<8>(acc);
+  acc = lanex::add_partner<16>(acc);
+  acc = lanex::add_partner<32>(acc);
   if (lane < 8) half_sum[rl][h][lane] = acc;
   __syncthreads();
   double pq = 0, qv = 0;
@@ -2156,8 +2156,8 @@ __global__ __launch_bounds__(kCRTPB) void ba_solve_cholreg(BaDev d, double lambd
         double pv = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) pv = fma(acc[s][r], xv[16 * I + kq + 4 * r], pv);
-        pv += lanex::from_partner<16>(pv);
-        pv += lanex::from_partner<32>(pv);
+        pv = lanex::add_partner<16>(pv);
+        pv = lanex::add_partner<32>(pv);
         if (kq == 0) yv[16 * J + i16] -= pv;
       }
     }
@@ -2295,9 +2295,9 @@ __global__ __launch_bounds__(kPersTPB) void ba_pcg_persist(BaDev d, PersArgs a) 
       }
       const double w1 = coarse_hat_t(8 * u + kk, d.agg);
       double s0v = (1.0 - w1) * sv, s1v = w1 * sv;
-      s0v += lanex::from_partner<1>(s0v); s1v += lanex::from_partner<1>(s1v);
-      s0v += lanex::from_partner<2>(s0v); s1v += lanex::from_partner<2>(s1v);
-      s0v += lanex::from_partner<4>(s0v); s1v += lanex::from_partner<4>(s1v);
+      s0v = lanex::add_partner<1>(s0v); s1v = lanex::add_partner<1>(s1v);
+      s0v = lanex::add_partner<2>(s0v); s1v = lanex::add_partner<2>(s1v);
+      s0v = lanex::add_partner<4>(s0v); s1v = lanex::add_partner<4>(s1v);
       if (cc < 6 && kk == 0) { coh_store(a.cparts + (size_t)cc * nwg + u, s0v); coh_store(a.cparts + (size_t)(6 + cc) * nwg + u, s1v); }
     }
   };
@@ -2651,7 +2651,7 @@ __global__ __launch_bounds__(kSmallTPB) void ba_pcg_small(BaDev d, double lambda
           }
         }
       }
-      acc += lanex::from_partner<8>(acc); acc += lanex::from_partner<16>(acc); acc += lanex::from_partner<32>(acc);
+      acc = lanex::add_partner<8>(acc); acc = lanex::add_partner<16>(acc); acc = lanex::add_partner<32>(acc);
       if (lane < 6) qs[6 * i + lane] = acc + lambda * ps[6 * i + lane];
     }
     __syncthreads();

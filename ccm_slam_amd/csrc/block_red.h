@@ -36,8 +36,7 @@ struct BlockRedT {
 
   // one value: wave butterfly, then the NW partials through LDS
   __device__ __forceinline__ double sum1(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += lanex::from_partner_c(v, off);   // (round 6: DPP / ds_swizzle where they reach, lane_xor.h; same pairs, same order)
+    v = lanex::wave_sum(v);   // (xor butterfly 32 ... 1; round 6: by v_permlane*_swap / DPP, lane_xor.h; same pairs, same order)
     double* b = buf + phase * (NW * 64);
     phase ^= 1;
     if (lane == 0) b[wave * 64] = v;
@@ -96,7 +95,7 @@ struct BlockRedT {
       for (int i = 0; i < kTrCols / 8; i += 4) { s0 += row[8 * i]; s1 += row[8 * (i + 1)]; s2 += row[8 * (i + 2)]; s3 += row[8 * (i + 3)]; }
       s = (s0 + s1) + (s2 + s3);
     }
-    s += lanex::from_partner<1>(s); s += lanex::from_partner<2>(s); s += lanex::from_partner<4>(s);
+    s = lanex::add_partner<1>(s); s = lanex::add_partner<2>(s); s = lanex::add_partner<4>(s);
     double* out = tr + 28 * kTrStride;
     if (t < 224 && (t & 7) == 0) out[t >> 3] = s;
     __syncthreads();

@@ -280,9 +280,9 @@ __global__ __launch_bounds__(kTPB) void pg_pcg_spmv(PgDev d, int k) {
       }
     }
   }
-  acc += lanex::from_partner<8>(acc);
-  acc += lanex::from_partner<16>(acc);
-  acc += lanex::from_partner<32>(acc);
+  acc = lanex::add_partner<8>(acc);
+  acc = lanex::add_partner<16>(acc);
+  acc = lanex::add_partner<32>(acc);
   double pq = 0;
   if (i < d.F && lane < 7) {
     const double pi = d.z[7 * (size_t)i + lane] + beta * pold[7 * (size_t)i + lane];
