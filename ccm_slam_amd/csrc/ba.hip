@@ -748,6 +748,7 @@ __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
 #pragma unroll
       for (int k = 0; k < 3; k++) if (k < cnt) pu[e0 + k] = t4[k];
     }
+    n_s0 = n_s1 = n_slot = n_j = 0;   // (constants flow around the pass loop: a later pass loads its own table entry, and the first pass's must not stay alive through the loop)
   }
   // (round 6) the diagonal block and b_schur are summed HERE, by the last wave — the one with the row's shortest units, done long before the first waves —, not behind
   // the barrier, where the serial sum over the 16-observation groups (~30 dependent LDS reads) was the tail every other wave waited for.  The partial sums are complete since
