@@ -3,6 +3,7 @@
 #include "common.h"
 #include "ba_types.h"
 #include "test_internal.h"
+#include "lane_xor.h"
 #include "../../include/ccm_testhooks.h"
 #include <cstring>
 #include <string>
@@ -89,4 +90,39 @@ extern "C" int ccm_orb_debug_level(ccm_orb* o, int level, uint8_t* score_out, ui
 extern "C" int ccm_orb_debug_candidates(ccm_orb* o, int level, ccm_keypoint* out, int cap, int* n_out) { return ccm_internal::orb_debug_candidates(o, level, out, cap, n_out); }
 extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const int32_t* y, const int32_t* response, int n, int W, int H, int N, int32_t* sel_out, int cap, int* n_out, int* overflow) {
   return ccm_internal::orb_debug_octree_dev(ctx, x, y, response, n, W, H, N, sel_out, cap, n_out, overflow);
+}
+
+// lane_xor.h against __shfl_xor: out[6][3][64] doubles — for MASK = 1, 2, 4, 8, 16, 32: from_partner<MASK>(v), add_partner<MASK>(v) and __shfl_xor(v, MASK) of the 64 lanes'
+// values in[64]; sum_out[0] = lanex::wave_sum, sum_out[1] = the __shfl_xor butterfly 32 ... 1.  tests/test_lane_xor_gpu.py.
+namespace {
+template <int MASK>
+__device__ void lane_xor_case(const double v, double* out, int slot) {
+  const int lane = threadIdx.x;
+  out[(3 * slot + 0) * 64 + lane] = lanex::from_partner<MASK>(v);
+  out[(3 * slot + 1) * 64 + lane] = lanex::add_partner<MASK>(v);
+  out[(3 * slot + 2) * 64 + lane] = __shfl_xor(v, MASK, 64);
+}
+__global__ __launch_bounds__(64) void lane_xor_probe(const double* in, double* out, double* sum_out) {
+  const double v = in[threadIdx.x];
+  lane_xor_case<1>(v, out, 0); lane_xor_case<2>(v, out, 1); lane_xor_case<4>(v, out, 2);
+  lane_xor_case<8>(v, out, 3); lane_xor_case<16>(v, out, 4); lane_xor_case<32>(v, out, 5);
+  double a = lanex::wave_sum(v), b = v;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) b += __shfl_xor(b, off, 64);
+  sum_out[threadIdx.x] = a; sum_out[64 + threadIdx.x] = b;
+}
+}  // namespace
+extern "C" int ccm_debug_lane_xor(ccm_ctx* ctx, const double* in64, double* out_6x3x64, double* sums_2x64) {
+  if (!ctx || !in64 || !out_6x3x64 || !sums_2x64) return CCM_E_ARG;
+  CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double* d = nullptr;
+  CCM_HIP_CHECK(ctx, hipMalloc(&d, (64 + 6 * 3 * 64 + 128) * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMemcpy(d, in64, 64 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(lane_xor_probe, dim3(1), dim3(64), 0, ctx->stream, d, d + 64, d + 64 + 6 * 3 * 64);
+  CCM_HIP_CHECK(ctx, hipGetLastError());
+  CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  CCM_HIP_CHECK(ctx, hipMemcpy(out_6x3x64, d + 64, 6 * 3 * 64 * sizeof(double), hipMemcpyDeviceToHost));
+  CCM_HIP_CHECK(ctx, hipMemcpy(sums_2x64, d + 64 + 6 * 3 * 64, 128 * sizeof(double), hipMemcpyDeviceToHost));
+  CCM_HIP_CHECK(ctx, hipFree(d));
+  return CCM_OK;
 }
