@@ -320,9 +320,12 @@ int ORBmatcher::SearchForTriangulation(kfptr pKF1, kfptr pKF2, cv::Mat F12, std:
                                     A.K.x.data(), A.K.y.data(), A.K.angle.data(), A.K.N, (int)n, n2.data(), o2.data(), i2.data(), nn2.data(), has2.data(), d2.data(),
                                     x2.data(), y2.data(), oct2.data(), a2.data(), N2.data());
         if (!c.h) checked(-1000, "SearchForTriangulation (fan-out)");
-        c.kf1 = pKF1.get(); c.id1 = pKF1->mId; c.N1 = pKF1->N; c.has1_build = A.has;
+        c.has1_build = A.has;
         for (size_t j = 0; j < n; j++) { c.nb.push_back(use[j].get()); c.nb_id.push_back(use[j]->mId); }
       }
+      // the keyframe is remembered whether or not a batch was built (fewer than two usable neighbours: c.h stays null and every call takes the single-call path
+      // below) — otherwise each of its calls would ask for the covisibility list again
+      c.kf1 = pKF1.get(); c.id1 = pKF1->mId; c.N1 = pKF1->N;
     }
     if (c.h) {
       for (size_t j = 0; j < c.nb.size(); j++) {
