@@ -47,6 +47,24 @@ def test_small_gba_two_agents(ctx, oracle_lib):
     _check(prob, 8, ctx, oracle_lib)
 
 
+@pytest.mark.parametrize("kfs, n_points, mean_track, max_track", [(48, 5800, 6.0, 30), (40, 4800, 8.0, 40)])
+def test_row_kernel_with_long_camera_lists(ctx, oracle_lib, kfs, n_points, mean_track, max_track):
+    """Cameras with 590 ... 777 observations (first case): the row Schur kernel with 10 ... 13 of its 16 waves staging observations and only the remaining ones requesting
+    their first operands ahead of the barrier (round 6: the roles of the waves depend on the row's length) — the 4-agent map of the fixtures stops at 547 observations per
+    camera.  Second case: up to 953 observations per camera, whose Y rows and partial sums no longer fit the kernel's LDS plan: the per-block fallback kernel."""
+    from tests.test_ba_structure_gpu import dev_array
+    prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=kfs, n_points=n_points, seed=31, mean_track=mean_track, max_track=max_track)
+    h = optimizer.BAHandle(ctx, prob)
+    Cp, Lp, Lloc, Eloc, nOff, max_ce, units_max = (int(v) for v in dev_array(h, "sizes", np.int32)[:7])
+    h.close()
+    assert nOff > 256
+    if mean_track == 6.0:
+        assert max_ce > 704 and units_max > 0        # the row kernel, rows longer than eleven waves
+    else:
+        assert max_ce > 900 and units_max == 0       # beyond the LDS plan
+    _check(prob, 6, ctx, oracle_lib)
+
+
 def test_no_robust_kernel_and_levels(ctx, oracle_lib):
     prob = synth.make_ba_problem(n_agents=1, kfs_per_agent=40, n_points=2500, seed=5, n_fixed=10, fixed_mode="tail")
     rng = np.random.default_rng(0)
