@@ -65,6 +65,19 @@ __device__ __forceinline__ double from_partner_c(double v, int off) {
   }
 }
 
+// inclusive prefix sum of a 32-bit integer over the 64 lanes of the wave (exact: integer additions): four shifts inside the rows of 16 lanes (row_shr, lanes without a
+// source get 0), then the rows' totals handed on by row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3) — six vector-ALU instructions instead of six ds_bpermute
+// round trips with a select each.  Every lane of the wave must be active.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // v summed over the wave by the xor butterfly 32, 16, 8, 4, 2, 1 (the order every wave sum of this library has always used)
 __device__ __forceinline__ double wave_sum(double v) {
   v = add_partner<32>(v); v = add_partner<16>(v); v = add_partner<8>(v);

@@ -21,6 +21,7 @@
 // count down.  The batch entry point pipelines frames over several streams so the host octree of frame
 // i overlaps the device phases of frame i+1.
 #include "common.h"
+#include "lane_xor.h"
 #include "test_internal.h"
 #include "orb_math.h"
 #include "orb_pattern.h"
@@ -261,11 +262,7 @@ __global__ __launch_bounds__(256) void orb_fast_score_kernel(OrbDev d, const uin
 }
 
 // ---- per-cell threshold + NMS + fallback + ordered compaction ------------------------------------
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) { const int t = __shfl_up(v, off, kWave); if (lane >= off) v += t; }
-  return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) { (void)lane; return lanex::wave_incl_scan_i32(v); }   // (round 6: by DPP, lane_xor.h; every lane of the wave is active at both call sites)
 
 // Round 4: the FAST scores of the cell's interior are computed HERE, from a (w + 6) x (h + 6) pixel tile staged in LDS (the score kernel over all levels and its
 // 1.1 MB score map are gone from the extraction: one launch and one round trip through memory less per frame; 13 % of the pixels are scored twice, by the
@@ -488,9 +485,7 @@ template <int TPB>
 __device__ __forceinline__ int oct_scan2(int v0, int v1, int& e0, int& e1, int* wsum) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int a = v0 + v1;
-  int inc = a;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+  const int inc = lanex::wave_incl_scan_i32(a);   // (round 6: by DPP, lane_xor.h; the whole workgroup calls this — barriers below)
   __syncthreads();                       // wsum may still be read by the previous call
   if (lane == 63) wsum[wv] = inc;
   __syncthreads();

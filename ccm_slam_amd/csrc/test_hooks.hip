@@ -93,7 +93,7 @@ extern "C" int ccm_orb_debug_octree_dev(ccm_ctx* ctx, const int32_t* x, const in
 }
 
 // lane_xor.h against __shfl_xor: out[6][3][64] doubles — for MASK = 1, 2, 4, 8, 16, 32: from_partner<MASK>(v), add_partner<MASK>(v) and __shfl_xor(v, MASK) of the 64 lanes'
-// values in[64]; sum_out[0] = lanex::wave_sum, sum_out[1] = the __shfl_xor butterfly 32 ... 1.  tests/test_lane_xor_gpu.py.
+// values in[64]; sum_out[0] = lanex::wave_sum, sum_out[1] = the __shfl_xor butterfly 32 ... 1, sum_out[2] = lanex::wave_incl_scan_i32 of the pattern (37 lane mod 101) - 20.  tests/test_lane_xor_gpu.py.
 namespace {
 template <int MASK>
 __device__ void lane_xor_case(const double v, double* out, int slot) {
@@ -110,19 +110,20 @@ __global__ __launch_bounds__(64) void lane_xor_probe(const double* in, double* o
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) b += __shfl_xor(b, off, 64);
   sum_out[threadIdx.x] = a; sum_out[64 + threadIdx.x] = b;
+  sum_out[128 + threadIdx.x] = (double)lanex::wave_incl_scan_i32((int)(threadIdx.x * 37 % 101) - 20);   // (integer scan of a fixed pattern)
 }
 }  // namespace
-extern "C" int ccm_debug_lane_xor(ccm_ctx* ctx, const double* in64, double* out_6x3x64, double* sums_2x64) {
+extern "C" int ccm_debug_lane_xor(ccm_ctx* ctx, const double* in64, double* out_6x3x64, double* sums_2x64 /* [3][64]: wave sums by lane_xor.h, by __shfl_xor, inclusive integer scan */) {
   if (!ctx || !in64 || !out_6x3x64 || !sums_2x64) return CCM_E_ARG;
   CCM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double* d = nullptr;
-  CCM_HIP_CHECK(ctx, hipMalloc(&d, (64 + 6 * 3 * 64 + 128) * sizeof(double)));
+  CCM_HIP_CHECK(ctx, hipMalloc(&d, (64 + 6 * 3 * 64 + 192) * sizeof(double)));
   CCM_HIP_CHECK(ctx, hipMemcpy(d, in64, 64 * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(lane_xor_probe, dim3(1), dim3(64), 0, ctx->stream, d, d + 64, d + 64 + 6 * 3 * 64);
   CCM_HIP_CHECK(ctx, hipGetLastError());
   CCM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   CCM_HIP_CHECK(ctx, hipMemcpy(out_6x3x64, d + 64, 6 * 3 * 64 * sizeof(double), hipMemcpyDeviceToHost));
-  CCM_HIP_CHECK(ctx, hipMemcpy(sums_2x64, d + 64 + 6 * 3 * 64, 128 * sizeof(double), hipMemcpyDeviceToHost));
+  CCM_HIP_CHECK(ctx, hipMemcpy(sums_2x64, d + 64 + 6 * 3 * 64, 192 * sizeof(double), hipMemcpyDeviceToHost));
   CCM_HIP_CHECK(ctx, hipFree(d));
   return CCM_OK;
 }

@@ -52,8 +52,9 @@ int  ccm_debug_tile_solve(ccm_ctx* ctx, const double* A, const double* b, int n,
 int  ccm_debug_dense_inverse(ccm_ctx* ctx, const double* A, int n, double* Ainv, int* info);
 
 /* test hook for ccm_slam_amd/csrc/lane_xor.h (round 6: the cross-lane moves of every xor butterfly — DPP, v_permlane16_swap / v_permlane32_swap): for MASK = 1, 2, 4, 8, 16, 32
- * the 64 lanes' from_partner<MASK>(v), add_partner<MASK>(v) and __shfl_xor(v, MASK) of in64, then lanex::wave_sum and the __shfl_xor butterfly of the same values. */
-int  ccm_debug_lane_xor(ccm_ctx* ctx, const double* in64, double* out_6x3x64, double* sums_2x64);
+ * the 64 lanes' from_partner<MASK>(v), add_partner<MASK>(v) and __shfl_xor(v, MASK) of in64, then [3][64]: lanex::wave_sum, the __shfl_xor butterfly of the same values, and
+ * lanex::wave_incl_scan_i32 of the integer pattern (37 lane mod 101) - 20. */
+int  ccm_debug_lane_xor(ccm_ctx* ctx, const double* in64, double* out_6x3x64, double* sums_3x64);
 
 #ifdef __cplusplus
 }

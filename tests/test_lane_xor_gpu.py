@@ -27,7 +27,7 @@ def test_lane_moves_equal_shfl_xor(seed):
     rng = np.random.default_rng(seed)
     v = rng.standard_normal(64) * 10.0 ** rng.integers(-15, 15, 64)
     v[3] = 0.0; v[35] = -0.0; v[17] = 5e-324; v[60] = -v[28]
-    out = np.zeros((6, 3, 64)); sums = np.zeros((2, 64))
+    out = np.zeros((6, 3, 64)); sums = np.zeros((3, 64))
     rc = _hooks().ccm_debug_lane_xor(ctx.handle, v.ctypes.data, out.ctypes.data, sums.ctypes.data)
     assert rc == 0
     lanes = np.arange(64)
@@ -38,3 +38,4 @@ def test_lane_moves_equal_shfl_xor(seed):
         assert np.array_equal(out[k, 1].view(np.uint64), (v + partner).view(np.uint64)), f"add_partner<{mask}>"
     assert np.array_equal(sums[0].view(np.uint64), sums[1].view(np.uint64))
     assert len(set(sums[0].view(np.uint64).tolist())) == 1   # every lane ends with the same bits
+    assert np.array_equal(sums[2], np.cumsum((np.arange(64) * 37 % 101) - 20).astype(np.float64))   # the DPP prefix sum (ORB's compactions)
