@@ -550,6 +550,9 @@ __device__ __forceinline__ void ba_compact_factors(ba_v2d ea, ba_v2d eb, const b
 //     path (that is wave 0's serial iterations), and every value carried around the row loop competes with the 36 accumulators: its first versions spilled 36-90 registers
 //     and ran 182-208 us;
 //   * a unit that is its whole block storing straight into S (85 % of the blocks), the second block range of the final sums requested before the barrier: +-1 us.
+//   * (after the butterfly went to DPP, below) the upper lanes of a unit accumulating the block's rows rotated by three, so that the butterfly's first step needs no exchange
+//     of halves (54 moves fewer per pass, two more address selects per iteration): 106-108 us against 106-107; the halves swapped by v_swap_b32 instead of three moves:
+//     110-112 us;
 //   * no second barrier and no final-sum phase at all — the unit that delivers a block's LAST partial sums (an LDS counter per block) adds them up in the units' order and
 //     stores the block, the waves end one by one: 128.6 us against 127-130, i.e. the final sums were not on the row's critical path either.
 __global__ __launch_bounds__(kRow2TPB) void ba_schur_row3(BaDev d) {
